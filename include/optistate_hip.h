@@ -1,0 +1,135 @@
+/*
+ * optistate_hip.h -- C ABI of liboptistate_hip.so, the MI355X (gfx950) implementation of the
+ * OptiState Kalman+GRU hot path.
+ *
+ * The reference (AlexS28/OptiState) exposes a Python call surface only; there is no FFI in it.
+ * Each entry point below names the reference interface it replaces (file:line into the
+ * reference tree).  The Python host side (optistate_amd/) binds these with ctypes and mirrors
+ * the reference's `Kalman_Filter` and `RNN` classes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor storage) unless it
+ *     is marked "host".  The caller owns all buffers; the library allocates only context scratch.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     stream-ordered and asynchronous; no call synchronises the device.
+ *   - Return value: 0 ok, <0 error (os_last_error() gives text).  Per-trajectory numerical
+ *     status is reported in `status[B]`: bit0 = innovation covariance S not positive definite /
+ *     non-finite, bit1 = non-finite state (the reference raises LinAlgError /
+ *     propagates NaN: kalman_filter/kalman_filter.py:168).
+ *   - Stream layout (structure of arrays, trajectory index fastest, float32):
+ *       p, f, dp, body_ref : [T][12][B]      imu, accel : [T][6][B]
+ *       contact            : [T][B] of 4 packed bytes (byte k = leg k, 0 swing / 1 stance)
+ *       x                  : [12][B]         P : [144][B] (row-major 12x12 per trajectory)
+ *       x_out, p_rot_out   : [T][12][B]      ptrace_out, kgain_out : [T][B]
+ *   - State order: thx thy thz  x y z  wx wy wz  vx vy vz  (kalman_filter/kalman_filter.py:9);
+ *     measurement = state rows {0,1,2,5,6,7,8,9,10,11} (kalman_filter/kalman_filter.py:15-24).
+ */
+#ifndef OPTISTATE_HIP_H
+#define OPTISTATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct os_ctx os_ctx;
+
+/* Model constants: settings.py:5-23, kalman_filter/kalman_filter.py:33-59, misc/force_controller.py:244-262. */
+typedef struct os_kf_config {
+    int32_t device;        /* HIP device ordinal */
+    float dt;              /* settings.py:5   DT_mpc = 0.01 */
+    float mass;            /* settings.py:11  8.8 kg */
+    float inertia[3];      /* settings.py:20-23  body-frame diag(Ixx,Iyy,Izz) */
+    float gz;              /* kalman_filter/kalman_filter.py:56  -9.81 (added to vz) */
+} os_kf_config;
+
+/* Flags for os_kf_run / os_fused_run. */
+enum {
+    OS_KF_SEQUENTIAL_UPDATE = 1,  /* process the 10 measurements one at a time (requires diagonal R; same
+                                     posterior as the batch form in exact arithmetic).  Without it the
+                                     batch form K = P H^T S^-1 (Cholesky of S) is used, as written in
+                                     kalman_filter/kalman_filter.py:166-172. */
+    OS_KF_DENSE_FD          = 2,  /* predict_mpc covariance: F_d = element-wise exp(dt F), R from body_ref
+                                     (kalman_filter/kalman_filter.py:153-158); needs body_ref. */
+    OS_KF_SYMMETRIC_P       = 4   /* reserved */
+};
+
+/* Replaces Kalman_Filter.__init__ (kalman_filter/kalman_filter.py:8-62): creates a context on cfg->device. */
+int os_create(const os_kf_config *cfg, os_ctx **out);
+void os_destroy(os_ctx *ctx);
+const char *os_last_error(const os_ctx *ctx);
+/* Library/ABI version and build target string ("gfx950"). */
+int os_version(void);
+const char *os_build_arch(void);
+
+/* Replaces the attribute writes KF.Q = Q; KF.R = R (data_collection/data_conversion_Kalman_to_Training.py:139-143).
+ * Q host float[144], R host float[100], row-major. */
+int os_kf_set_noise(os_ctx *ctx, const float *Q_host, const float *R_host);
+
+/* Replaces the per-trajectory loop body
+ *   odom = get_odom(p, dp, contact, imu); set_measurements(imu, odom); predict(p, f); update()
+ * (kalman_filter/kalman_filter.py:79-138,164-174; caller loop
+ * data_collection/data_conversion_Kalman_to_Training.py:193-199) for B trajectories x T steps.
+ * x, P are in/out.  p_rot_out (world-rotated p, the in-place side effect of next_state,
+ * misc/force_controller.py:274-277), ptrace_out (P_trace), kgain_out (K_gain; batch form only),
+ * body_ref may be NULL. */
+int os_kf_run(os_ctx *ctx, int32_t B, int32_t T,
+              const float *p, const float *f, const float *dp, const float *imu, const uint32_t *contact,
+              const float *body_ref,
+              float *x, float *P,
+              float *x_out, float *p_rot_out, float *ptrace_out, float *kgain_out,
+              int32_t *status, uint32_t flags, void *stream);
+
+/* Single-instance pieces for the drop-in Kalman_Filter class (B = 1 views over the same kernels).
+ * os_kf_odom   : get_odom + set_measurements (kalman_filter/kalman_filter.py:79-117) -> z [10][B]
+ * os_kf_predict: predict(p, f) (kalman_filter/kalman_filter.py:119-138); p [12][B] is rotated in place.
+ * os_kf_update : update() (kalman_filter/kalman_filter.py:164-174); K_out [120][B] (12x10 row-major) optional. */
+int os_kf_odom(os_ctx *ctx, int32_t B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
+               float *z, void *stream);
+int os_kf_predict(os_ctx *ctx, int32_t B, float *p, const float *f, const float *body_ref, float *x, float *P,
+                  float *ptrace_out, uint32_t flags, void *stream);
+int os_kf_update(os_ctx *ctx, int32_t B, const float *z, float *x, float *P, float *K_out, float *ptrace_out,
+                 float *kgain_out, int32_t *status, uint32_t flags, void *stream);
+
+/* GRU head dims: RNN(input_size, hidden_size, num_layers, num_classes) (gru/gru_model.py:8-24). */
+typedef struct os_gru_dims {
+    int32_t input_size, hidden_size, num_layers, num_classes, use_sigmoid;
+} os_gru_dims;
+
+/* Number of floats in the flat weight vector: per layer W_ih [3H][I_l], W_hh [3H][H], b_ih [3H], b_hh [3H]
+ * (gate order r|z|n, torch.nn.GRU), then fc.weight [C][H], fc.bias [C]. */
+size_t os_gru_param_count(const os_gru_dims *d);
+
+/* Replaces model.load_state_dict(...) (gru/gru_test.py:160): w_flat is a DEVICE float vector in the flat
+ * layout above; the library re-packs it into MFMA fragment order in context scratch. */
+int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream);
+
+/* Replaces RNN.forward (gru/gru_model.py:25-49): x [B][T][I] (batch_first, as the reference passes it)
+ * -> out [B][C]; h0 = 0; fc + sigmoid on the last step.  h_last (optional) [L][B][H]. */
+int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *h_last, void *stream);
+
+/* Same with the input already in the library's stream layout xs [T][I][B]; h_last_soa (optional) [L][H][B]. */
+int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_soa, void *stream);
+
+/* Fused path: KF loop + 60-feature row [x_post | accel | f | p_world | dp | imu]
+ * (data_collection/data_conversion_Kalman_to_Training.py:245-254) + min-max normalisation
+ * (gru/gru_test.py:99-101; minmax = device float[2][60]: mins then maxs) + optional latent [T][NL][B] appended
+ * (gru/gru_test.py:135-136) + GRU over the T-step sequence + head, without writing feature rows to HBM.
+ * Requires os_gru_load with input_size == 60 + n_latent.  out [B][C]. */
+int os_fused_run(os_ctx *ctx, int32_t B, int32_t T,
+                 const float *p, const float *f, const float *dp, const float *imu, const uint32_t *contact,
+                 const float *accel, const float *body_ref, const float *latent, int32_t n_latent,
+                 const float *minmax,
+                 float *x, float *P, float *x_out, float *out, int32_t *status, uint32_t flags, void *stream);
+
+/* Layout helper: [B][T][F] (the reference's per-trajectory row lists) -> [T][F][B]. */
+int os_pack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src_btf, float *dst_tfb, void *stream);
+int os_unpack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src_tfb, float *dst_btf, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTISTATE_HIP_H */

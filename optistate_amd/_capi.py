@@ -1,0 +1,68 @@
+"""ctypes binding of liboptistate_hip.so (include/optistate_hip.h).  No CPU fallback: if the HIP library is
+missing or no MI355X is visible, loading/creating a context raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liboptistate_hip.so")
+
+OS_KF_SEQUENTIAL_UPDATE = 1
+OS_KF_DENSE_FD = 2
+
+# every symbol include/optistate_hip.h declares
+EXPORTS = [
+    "os_create", "os_destroy", "os_last_error", "os_version", "os_build_arch", "os_kf_set_noise", "os_kf_run",
+    "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_param_count", "os_gru_load", "os_gru_forward",
+    "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream",
+]
+
+
+class OsKfConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dt", C.c_float), ("mass", C.c_float), ("inertia", C.c_float * 3),
+                ("gz", C.c_float)]
+
+
+class OsGruDims(C.Structure):
+    _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
+                ("num_classes", C.c_int32), ("use_sigmoid", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (built by optistate_amd.build) and declares prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m optistate_amd.build` "
+                           "(there is no CPU fallback for the OptiState hot path)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, f32p = C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p
+    lib.os_create.argtypes = [C.POINTER(OsKfConfig), C.POINTER(vp)]
+    lib.os_create.restype = C.c_int
+    lib.os_destroy.argtypes = [vp]
+    lib.os_destroy.restype = None
+    lib.os_last_error.argtypes = [vp]
+    lib.os_last_error.restype = C.c_char_p
+    lib.os_version.restype = C.c_int
+    lib.os_build_arch.restype = C.c_char_p
+    lib.os_kf_set_noise.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.os_kf_run.argtypes = [vp, i32, i32] + [f32p] * 6 + [f32p] * 2 + [f32p] * 4 + [vp, u32, vp]
+    lib.os_kf_odom.argtypes = [vp, i32, f32p, f32p, vp, f32p, f32p, vp]
+    lib.os_kf_predict.argtypes = [vp, i32, f32p, f32p, f32p, f32p, f32p, f32p, u32, vp]
+    lib.os_kf_update.argtypes = [vp, i32, f32p, f32p, f32p, f32p, f32p, f32p, vp, u32, vp]
+    lib.os_gru_param_count.argtypes = [C.POINTER(OsGruDims)]
+    lib.os_gru_param_count.restype = C.c_size_t
+    lib.os_gru_load.argtypes = [vp, C.POINTER(OsGruDims), f32p, vp]
+    lib.os_gru_forward.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp]
+    lib.os_gru_forward_soa.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp]
+    lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]
+    lib.os_pack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
+    lib.os_unpack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
+    for n in ("os_kf_set_noise", "os_kf_run", "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_load",
+              "os_gru_forward", "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream"):
+        getattr(lib, n).restype = C.c_int
+    _lib = lib
+    return lib

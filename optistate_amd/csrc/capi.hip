@@ -1,0 +1,70 @@
+// capi.hip -- context lifetime and configuration entry points of liboptistate_hip.so.
+#include "launch.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+
+extern "C" {
+
+int os_version(void) { return 1; }
+const char *os_build_arch(void) { return "gfx950"; }
+
+int os_create(const os_kf_config *cfg, os_ctx **out)
+{
+    if (!cfg || !out) return -2;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -11;   // no HIP device: fail loudly
+    if (cfg->device < 0 || cfg->device >= ndev) return -12;
+    os_ctx *c = (os_ctx *)calloc(1, sizeof(os_ctx));
+    if (!c) return -13;
+    c->magic = OS_MAGIC;
+    c->device = cfg->device;
+    c->k.dt = cfg->dt;
+    c->k.inv_mass = 1.0f / cfg->mass;
+    c->k.gz = cfg->gz;
+    for (int i = 0; i < 3; i++) c->k.inv_inertia[i] = 1.0f / cfg->inertia[i];
+    // defaults: settings.py:28-31
+    static const float qd[12] = {0.01f, 0.01f, 0.01f, 0.01f, 0.0001f, 0.01f, 0.01f, 0.01f, 0.01f, 0.01f, 0.01f, 0.0001f};
+    for (int i = 0; i < 12; i++) c->k.Q[i * 12 + i] = qd[i];
+    for (int i = 0; i < 10; i++) c->k.R[i * 10 + i] = 0.01f;
+    c->r_is_diagonal = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { free(c); return -10; }
+    c->cu_count = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // built for gfx950 only; refuse to pretend on anything else
+        free(c);
+        return -14;
+    }
+    *out = c;
+    return 0;
+}
+
+void os_destroy(os_ctx *ctx)
+{
+    if (!ctx || ctx->magic != OS_MAGIC) return;
+    (void)hipSetDevice(ctx->device);
+    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat};
+    for (float *b : bufs)
+        if (b) (void)hipFree(b);
+    ctx->magic = 0;
+    free(ctx);
+}
+
+const char *os_last_error(const os_ctx *ctx) { return (ctx && ctx->magic == OS_MAGIC) ? ctx->err : "invalid context"; }
+
+int os_kf_set_noise(os_ctx *ctx, const float *Q_host, const float *R_host)
+{
+    OS_CHECK_CTX(ctx);
+    if (!Q_host || !R_host) return os_fail(ctx, -2, "os_kf_set_noise: null pointer");
+    memcpy(ctx->k.Q, Q_host, sizeof(float) * 144);
+    memcpy(ctx->k.R, R_host, sizeof(float) * 100);
+    bool diag = true;
+    for (int a = 0; a < 10; a++)
+        for (int b = 0; b < 10; b++)
+            if (a != b && R_host[a * 10 + b] != 0.0f) diag = false;
+    ctx->r_is_diagonal = diag;
+    return 0;
+}
+
+}  // extern "C"

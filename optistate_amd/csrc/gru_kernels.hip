@@ -1,0 +1,334 @@
+// gru_kernels.hip -- GRU head of OptiState (reference gru/gru_model.py:7-49) on gfx950 matrix cores.
+//
+// One launch per layer runs the whole T-step recurrence for a tile of BM trajectories ("rows"):
+//   gates[BM x 3H] = [x_t | h_{t-1}] . [W_ih | W_hh]^T      -> v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD)
+//   r,z = sigmoid, n = tanh(gi_n + r*gh_n), h = (1-z)*n + z*h  -> VALU epilogue on the accumulator registers
+// Layout decisions (MI355X-first, not a cuDNN translation):
+//   * activations are structure-of-arrays [T][K][B] (trajectory index fastest), the same layout the Kalman kernels
+//     stream, so an MFMA A-fragment (32 rows x 1 k) is one coalesced 128-byte segment per k straight from global/L2;
+//   * weights are re-packed once (os_gru_load) into B-fragment order: for each 32-column chunk and each k-pair the 64
+//     floats lane l needs (W[g*H + chunk*32 + (l&31)][2kp + (l>>5)]) are contiguous, so a wave streams its chunk's
+//     weights with perfectly coalesced dword loads that stay L2-resident (<= 1.7 MB for the reference config);
+//   * a wave owns one 32-column chunk of all three gates for RBW row blocks: the three gate pre-activations of a hidden
+//     unit land in the same lane, so the cell update needs no cross-lane traffic;
+//   * h lives in LDS ([BM][H+1] floats, odd stride -> conflict-free ds_read_b32 A-fragments), never in HBM; the layer's
+//     output sequence is written back in SoA through a cooperative LDS->global pass (coalesced).
+#include "launch.hpp"
+
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace osg {
+
+struct LayerArgs {
+    int B, T, K, H;            // K = input width of this layer
+    int KPx, KPh;              // k-pairs of the x part (ceil(K/2)) and of the h part (H/2)
+    const float *xs;           // [T][K][B]
+    const float *w;            // packed weights of this layer (see pack kernel)
+    float *seq_out;            // [T][H][B] or null
+    float *h_last;             // [H][B] or null
+};
+
+__host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// RBW = row blocks (of 32 trajectories) per wave.  NCH = H/32 column chunks; with NCH < 4 several waves share a chunk
+// and split the rows.  BM = 32 * RBW * max(1, 4/NCH).
+template <int RBW>
+__global__ __launch_bounds__(256, (RBW <= 2 ? 2 : 1)) void gru_layer_kernel(const LayerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float hl[];   // [BM][HS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = a.H, HS = H + 1, NCH = H >> 5;
+    const int WPC = NCH >= 4 ? 1 : 4 / NCH;          // waves per chunk
+    const int BM = 32 * RBW * WPC;
+    const int chunk = NCH >= 4 ? wave : wave % NCH;
+    const int rgrp = NCH >= 4 ? 0 : wave / NCH;
+    const int row_blk0 = rgrp * RBW;                  // first row block (within the tile) of this wave
+    const int tile_row0 = blockIdx.x * BM;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t B = (size_t)a.B;
+
+    for (int i = threadIdx.x; i < BM * HS; i += 256) hl[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
+
+    const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
+    const float *wh = wx + (size_t)a.KPx * 3 * 64;
+    const float *bias = wh + (size_t)a.KPh * 3 * 64;
+    const float b_r = bias[li], b_z = bias[32 + li], b_in = bias[64 + li], b_hn = bias[96 + li];
+
+    int grow[RBW];          // global trajectory index of this lane's A-fragment row, per row block
+    bool gok[RBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; rb++) {
+        grow[rb] = tile_row0 + (row_blk0 + rb) * 32 + li;
+        gok[rb] = grow[rb] < a.B;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < a.T; t++) {
+        f32x16 acc[RBW][4];
+#pragma unroll
+        for (int rb = 0; rb < RBW; rb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
+
+        // ---- input part: A fragments straight from the SoA stream (coalesced over trajectories) ----
+        const float *xt = a.xs + (size_t)t * a.K * B;
+#pragma unroll 2
+        for (int kp = 0; kp < a.KPx; kp++) {
+            const int k = 2 * kp + lh;
+            const float w_r = wx[(kp * 3 + 0) * 64 + lane];
+            const float w_z = wx[(kp * 3 + 1) * 64 + lane];
+            const float w_n = wx[(kp * 3 + 2) * 64 + lane];
+            const bool kok = k < a.K;
+#pragma unroll
+            for (int rb = 0; rb < RBW; rb++) {
+                const float av = (kok && gok[rb]) ? xt[(size_t)k * B + grow[rb]] : 0.f;
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[rb][1], 0, 0, 0);
+                acc[rb][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[rb][2], 0, 0, 0);
+            }
+        }
+        // ---- recurrent part: A fragments from the LDS-resident h ----
+#pragma unroll 2
+        for (int kp = 0; kp < a.KPh; kp++) {
+            const int k = 2 * kp + lh;
+            const float w_r = wh[(kp * 3 + 0) * 64 + lane];
+            const float w_z = wh[(kp * 3 + 1) * 64 + lane];
+            const float w_n = wh[(kp * 3 + 2) * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < RBW; rb++) {
+                const float av = hl[((row_blk0 + rb) * 32 + li) * HS + k];
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[rb][1], 0, 0, 0);
+                acc[rb][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[rb][3], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // every wave has finished reading h_{t-1}
+
+        // ---- cell update on the accumulator layout: col = lane&31 (hidden unit), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int rb = 0; rb < RBW; rb++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = (row_blk0 + rb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float *hp = &hl[row * HS + chunk * 32 + li];
+                const float r = sigmoidf_(acc[rb][0][e] + b_r);
+                const float z = sigmoidf_(acc[rb][1][e] + b_z);
+                const float n = tanhf(acc[rb][2][e] + b_in + r * (acc[rb][3][e] + b_hn));
+                *hp = (1.0f - z) * n + z * (*hp);
+            }
+        }
+        __syncthreads();   // h_t complete
+
+        // ---- cooperative, coalesced write-back of h_t in SoA ----
+        float *dst = a.seq_out ? a.seq_out + (size_t)t * H * B : ((t == a.T - 1) ? a.h_last : nullptr);
+        if (dst) {
+            for (int i = threadIdx.x; i < BM * H; i += 256) {
+                const int row = i % BM, k = i / BM;
+                const int g = tile_row0 + row;
+                if (g < a.B) dst[(size_t)k * B + g] = hl[row * HS + k];
+            }
+            if (a.seq_out && a.h_last && t == a.T - 1) {
+                for (int i = threadIdx.x; i < BM * H; i += 256) {
+                    const int row = i % BM, k = i / BM;
+                    const int g = tile_row0 + row;
+                    if (g < a.B) a.h_last[(size_t)k * B + g] = hl[row * HS + k];
+                }
+            }
+        }
+        // no barrier needed here: the next step only reads hl until its first __syncthreads()
+    }
+}
+
+// Re-pack one layer's torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order.
+__global__ void gru_pack_kernel(int K, int H, int KPx, int KPh, const float *Wih, const float *Whh, const float *bih,
+                                const float *bhh, float *dst)
+{
+    const int chunk = blockIdx.x;
+    float *d = dst + (size_t)chunk * chunk_floats(KPx, KPh);
+    const int nx = KPx * 3 * 64, nh = KPh * 3 * 64;
+    for (int i = threadIdx.x; i < nx + nh + 128; i += blockDim.x) {
+        float v;
+        if (i < nx + nh) {
+            const bool isx = i < nx;
+            const int j = isx ? i : i - nx;
+            const int lane = j & 63, g = (j >> 6) % 3, kp = (j >> 6) / 3;
+            const int k = 2 * kp + (lane >> 5), col = g * H + chunk * 32 + (lane & 31);
+            if (isx) v = (k < K) ? Wih[(size_t)col * K + k] : 0.f;
+            else v = Whh[(size_t)col * H + k];
+        } else {
+            const int j = i - nx - nh, which = j >> 5, c = chunk * 32 + (j & 31);
+            if (which == 0) v = bih[c] + bhh[c];
+            else if (which == 1) v = bih[H + c] + bhh[H + c];
+            else if (which == 2) v = bih[2 * H + c];
+            else v = bhh[2 * H + c];
+        }
+        d[i] = v;
+    }
+}
+
+// fc + sigmoid on the last hidden state (gru/gru_model.py:43-48).  h_last [H][B] -> out [B][C].
+__global__ void gru_head_kernel(int B, int H, int C, const float *h_last, const float *fcw, const float *fcb,
+                                int use_sigmoid, float *out)
+{
+    extern __shared__ float sw[];   // fc weights [C][H] + bias [C]
+    for (int i = threadIdx.x; i < C * H + C; i += blockDim.x) sw[i] = i < C * H ? fcw[i] : fcb[i - C * H];
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = (c0 + j < C) ? sw[C * H + c0 + j] : 0.f;
+        for (int k = 0; k < H; k++) {
+            const float hv = h_last[(size_t)k * B + b];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (c0 + j < C) s[j] += sw[(c0 + j) * H + k] * hv;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (c0 + j < C) out[(size_t)b * C + c0 + j] = use_sigmoid ? sigmoidf_(s[j]) : s[j];
+    }
+}
+
+}  // namespace osg
+
+using namespace osg;
+
+static size_t layer_packed_floats(int K, int H)
+{
+    return (size_t)(H / 32) * chunk_floats((K + 1) / 2, H / 2);
+}
+
+static int ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats)
+{
+    if (*cap >= need_floats) return 0;
+    if (*buf) OS_HIP(ctx, hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    OS_HIP(ctx, hipMalloc((void **)buf, need_floats * sizeof(float)));
+    *cap = need_floats;
+    return 0;
+}
+
+extern "C" {
+
+size_t os_gru_param_count(const os_gru_dims *d)
+{
+    size_t n = 0;
+    for (int l = 0; l < d->num_layers; l++) {
+        const size_t il = l == 0 ? d->input_size : d->hidden_size, H = d->hidden_size;
+        n += 3 * H * il + 3 * H * H + 6 * H;
+    }
+    return n + (size_t)d->num_classes * d->hidden_size + d->num_classes;
+}
+
+int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!d || !w_flat) return os_fail(ctx, -2, "os_gru_load: null pointer");
+    const int H = d->hidden_size;
+    if (H != 32 && H != 64 && H != 128) return os_fail(ctx, -4, "os_gru_load: hidden_size must be 32, 64 or 128");
+    if (d->input_size <= 0 || d->num_layers <= 0 || d->num_layers > 16 || d->num_classes <= 0 || d->num_classes > 256)
+        return os_fail(ctx, -4, "os_gru_load: unsupported dimensions");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    size_t total = 0;
+    for (int l = 0; l < d->num_layers; l++) total += layer_packed_floats(l == 0 ? d->input_size : H, H);
+    if (ensure_scratch(ctx, &ctx->gru_packed, &ctx->gru_packed_floats, total)) return -10;
+    size_t src = 0, dst = 0;
+    for (int l = 0; l < d->num_layers; l++) {
+        const int K = l == 0 ? d->input_size : H;
+        const float *Wih = w_flat + src, *Whh = Wih + (size_t)3 * H * K, *bih = Whh + (size_t)3 * H * H, *bhh = bih + 3 * H;
+        hipLaunchKernelGGL(gru_pack_kernel, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, K, H, (K + 1) / 2, H / 2,
+                           Wih, Whh, bih, bhh, ctx->gru_packed + dst);
+        OS_HIP(ctx, hipGetLastError());
+        src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;
+        dst += layer_packed_floats(K, H);
+    }
+    ctx->gru = *d;
+    ctx->gru_flat = w_flat;
+    ctx->gru_loaded = true;
+    return 0;
+}
+
+// Runs the layer stack on an SoA input sequence xs [T][I][B] (device).  Internal entry shared with the fused path.
+int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_all, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
+    if (B <= 0 || T <= 0 || !xs || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    const os_gru_dims &d = ctx->gru;
+    const int H = d.hidden_size, L = d.num_layers, NCH = H / 32;
+    hipStream_t s = (hipStream_t)stream;
+    // scratch: two ping-pong sequence buffers [T][H][B] (only for L > 1) and one h_last [H][B]
+    const size_t seqf = (size_t)T * H * B, hf = (size_t)H * B;
+    const size_t need = (L > 1 ? 2 * seqf : 0) + hf;
+    if (ensure_scratch(ctx, &ctx->gru_seq, &ctx->gru_seq_floats, need)) return -10;
+    float *seqbuf[2] = {ctx->gru_seq, ctx->gru_seq + seqf};
+    float *hlast = ctx->gru_seq + (L > 1 ? 2 * seqf : 0);
+    size_t woff = 0;
+    const float *in = xs;
+    for (int l = 0; l < L; l++) {
+        const int K = l == 0 ? d.input_size : H;
+        LayerArgs a;
+        a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
+        a.xs = in; a.w = ctx->gru_packed + woff;
+        a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
+        a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
+        const int WPC = NCH >= 4 ? 1 : 4 / NCH;
+        // rows per workgroup: 128 (H = 64: RBW 2 x 2 waves/chunk; H = 128: RBW 4; H = 32: RBW 1 x 4 waves/chunk)
+        const int RBW = H == 128 ? 4 : (H == 64 ? 2 : 1);
+        const int BM = 32 * RBW * WPC;
+        const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
+        dim3 grid((B + BM - 1) / BM), block(256);
+        if (RBW == 4) hipLaunchKernelGGL(gru_layer_kernel<4>, grid, block, lds, s, a);
+        else if (RBW == 2) hipLaunchKernelGGL(gru_layer_kernel<2>, grid, block, lds, s, a);
+        else hipLaunchKernelGGL(gru_layer_kernel<1>, grid, block, lds, s, a);
+        OS_HIP(ctx, hipGetLastError());
+        in = a.seq_out;
+        woff += layer_packed_floats(K, H);
+    }
+    const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
+    const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
+    const size_t hlds = ((size_t)d.num_classes * H + d.num_classes) * sizeof(float);
+    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 255) / 256), dim3(256), hlds, s, B, H, d.num_classes, top, fcw,
+                       fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *h_last, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
+    if (B <= 0 || T <= 0 || !x || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    // (B, T, I) batch_first as the reference passes it -> SoA [T][I][B] in context scratch
+    const int I = ctx->gru.input_size;
+    if (ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;
+    int rc = os_pack_stream(ctx, B, T, I, x, ctx->gru_xs, stream);
+    if (rc) return rc;
+    // h_last is requested in torch layout [L][B][H]; produce SoA [L][H][B] then transpose
+    float *hl_soa = nullptr;
+    const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
+    if (h_last) {
+        if (ensure_scratch(ctx, &ctx->gru_hl, &ctx->gru_hl_floats, (size_t)L * H * B)) return -10;
+        hl_soa = ctx->gru_hl;
+    }
+    rc = os_gru_forward_soa(ctx, B, T, ctx->gru_xs, out, hl_soa, stream);
+    if (rc) return rc;
+    if (h_last)
+        for (int l = 0; l < L; l++) {
+            rc = os_unpack_stream(ctx, B, 1, H, hl_soa + (size_t)l * H * B, h_last + (size_t)l * B * H, stream);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+// kf_device.hpp -- per-lane Kalman filter arithmetic for gfx950 (one trajectory per lane).
+//
+// All state (x: 12, P: 144 floats) lives in VGPRs of the lane that owns the trajectory; every loop is
+// fully unrolled with compile-time indices so nothing is spilled to scratch.  The math is derived from
+// the reference's equations (not its code):
+//   rotation          kalman_filter/kalman_filter.py:184-193
+//   odometry + z      kalman_filter/kalman_filter.py:79-117
+//   dynamics          misc/force_controller.py:269-291 (with the int64 truncation of A[0:3,6:9], :248-251,:271)
+//   covariance        kalman_filter/kalman_filter.py:124-135 (F_d = I + dt F has two non-trivial 3x3 blocks)
+//   update            kalman_filter/kalman_filter.py:164-174 (H is a row selection)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace osk {
+
+constexpr int NS = 12;
+constexpr int NM = 10;
+// H selects these state rows (kalman_filter/kalman_filter.py:15-24)
+__device__ constexpr int SEL[NM] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11};
+
+struct KfConst {
+    float dt, inv_mass, gz;
+    float inv_inertia[3];
+    float Q[NS * NS];
+    float R[NM * NM];
+};
+
+struct Rot { float m[9]; };
+
+// ---- buffer addressing: wave-uniform descriptor + SGPR row offset + one constant per-lane VGPR offset ----
+// Every stream is [rows][B] with the trajectory index fastest, so element (row, b) is
+//   base + row*B*4 (uniform -> SGPR soffset)  +  b*4 (per lane -> the same voffset VGPR for every access).
+// With flat 64-bit addresses hipcc materialises one address pair per access (hundreds of VGPRs in a fully
+// unrolled 144-element state load); buffer_load/store needs none (cdna_hip_programming.md T8).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ uint32_t buf_load_u32(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, uint32_t voff, uint32_t soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+}
+
+// R = Rz(thz) * Ry(thy) * Rx(thx), closed form of the product at kalman_filter/kalman_filter.py:187-191
+__device__ __forceinline__ Rot rotation(float thx, float thy, float thz)
+{
+    float sx, cx, sy, cy, sz, cz;
+    sincosf(thx, &sx, &cx);
+    sincosf(thy, &sy, &cy);
+    sincosf(thz, &sz, &cz);
+    Rot r;
+    r.m[0] = cz * cy; r.m[1] = cz * sy * sx - sz * cx; r.m[2] = cz * sy * cx + sz * sx;
+    r.m[3] = sz * cy; r.m[4] = sz * sy * sx + cz * cx; r.m[5] = sz * sy * cx - cz * sx;
+    r.m[6] = -sy;     r.m[7] = cy * sx;                r.m[8] = cy * cx;
+    return r;
+}
+
+// The reference's module-global `A` is int64, so A[0:3,6:9] = R^T truncates toward zero
+// (misc/force_controller.py:248-251,271): an entry survives only when |R_ji| >= 1 in float64.
+// The decision is made in float64 from the float32 angles promoted to double: cosf() rounds to
+// 1.0f for |th| up to ~3e-4 where the float64 cosine is still < 1, and that would integrate omega into theta
+// where the reference adds 0.  The float64 path only runs for lanes whose float32 entry is within a few ulp of 1.
+__device__ __forceinline__ void trunc_block_f64(float thx, float thy, float thz, float *A /* 9, A[i][j] = trunc(R[j][i]) */)
+{
+    double sx = sin((double)thx), cx = cos((double)thx);
+    double sy = sin((double)thy), cy = cos((double)thy);
+    double sz = sin((double)thz), cz = cos((double)thz);
+    // M = Ry*Rx, R = Rz*M with the zero terms dropped (adding exact zeros changes nothing)
+    double m00 = cy, m01 = sy * sx, m02 = sy * cx;
+    double m10 = 0.0, m11 = cx, m12 = -sx;
+    double m20 = -sy, m21 = cy * sx, m22 = cy * cx;
+    double r[9];
+    r[0] = cz * m00 + (-sz) * m10; r[1] = cz * m01 + (-sz) * m11; r[2] = cz * m02 + (-sz) * m12;
+    r[3] = sz * m00 + cz * m10;    r[4] = sz * m01 + cz * m11;    r[5] = sz * m02 + cz * m12;
+    r[6] = m20;                    r[7] = m21;                    r[8] = m22;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A[3 * i + j] = (float)trunc(r[3 * j + i]);
+}
+
+struct StepIn {
+    float p[12], f[12], dp[12], imu[6];
+    uint32_t contact;   // 4 packed bytes
+};
+
+// get_odom + set_measurements (kalman_filter/kalman_filter.py:79-117).  p is the body-frame foot position.
+__device__ __forceinline__ void measurement(const StepIn &in, float *z /*10*/)
+{
+    float c[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) c[l] = (float)((in.contact >> (8 * l)) & 0xffu);
+    float sum_c = (c[0] + c[1]) + (c[2] + c[3]);
+    float vx = 0.f, vy = 0.f, vz = 0.f, pz = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        bool st = ((in.contact >> (8 * l)) & 0xffu) == 1u;
+        bool sw = ((in.contact >> (8 * l)) & 0xffu) == 0u;
+        vx += st ? in.dp[3 * l] : 0.f;
+        vy += st ? in.dp[3 * l + 1] : 0.f;
+        pz += st ? in.p[3 * l + 2] : 0.f;
+        vz += sw ? in.dp[3 * l + 2] : 0.f;
+    }
+    float inv = (sum_c != 0.f) ? (1.0f / sum_c) : 0.f;   // no stance leg -> odom = 0 (:97-98)
+    float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
+    float bpz = -pz * inv;
+    Rot r = rotation(in.imu[0], in.imu[1], in.imu[2]);
+    z[0] = in.imu[0]; z[1] = in.imu[1]; z[2] = in.imu[2];
+    z[3] = bpz;
+    z[4] = in.imu[3]; z[5] = in.imu[4]; z[6] = in.imu[5];
+    z[7] = r.m[0] * bx + r.m[1] * by + r.m[2] * bz;
+    z[8] = r.m[3] * bx + r.m[4] * by + r.m[5] * bz;
+    z[9] = r.m[6] * bx + r.m[7] * by + r.m[8] * bz;
+}
+
+// next_state (misc/force_controller.py:269-291): x <- (I + A dt) x + B dt f + dt g, foot positions rotated
+// to the world frame (returned in pw: the reference mutates the caller's p, :274-277).
+// I_hat^-1 = R diag(1/I) R^T (R orthogonal), tau = sum_j pw_j x f_j.
+__device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p, const float *f, float *pw,
+                                         const KfConst &k)
+{
+    float tau[3] = {0.f, 0.f, 0.f}, fs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        float a = p[3 * l], b = p[3 * l + 1], c = p[3 * l + 2];
+        float wx = r.m[0] * a + r.m[1] * b + r.m[2] * c;
+        float wy = r.m[3] * a + r.m[4] * b + r.m[5] * c;
+        float wz = r.m[6] * a + r.m[7] * b + r.m[8] * c;
+        pw[3 * l] = wx; pw[3 * l + 1] = wy; pw[3 * l + 2] = wz;
+        float fx = f[3 * l], fy = f[3 * l + 1], fz = f[3 * l + 2];
+        tau[0] += wy * fz - wz * fy;
+        tau[1] += wz * fx - wx * fz;
+        tau[2] += wx * fy - wy * fx;
+        fs[0] += fx; fs[1] += fy; fs[2] += fz;
+    }
+    // body-frame torque, scaled by 1/I, back to world
+    float tb0 = (r.m[0] * tau[0] + r.m[3] * tau[1] + r.m[6] * tau[2]) * k.inv_inertia[0];
+    float tb1 = (r.m[1] * tau[0] + r.m[4] * tau[1] + r.m[7] * tau[2]) * k.inv_inertia[1];
+    float tb2 = (r.m[2] * tau[0] + r.m[5] * tau[1] + r.m[8] * tau[2]) * k.inv_inertia[2];
+    float aw0 = r.m[0] * tb0 + r.m[1] * tb1 + r.m[2] * tb2;
+    float aw1 = r.m[3] * tb0 + r.m[4] * tb1 + r.m[5] * tb2;
+    float aw2 = r.m[6] * tb0 + r.m[7] * tb1 + r.m[8] * tb2;
+
+    // theta: A[0:3,6:9] = trunc(R^T) -- zero unless an entry of R reaches +-1 in float64
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) amax = fmaxf(amax, fabsf(r.m[i]));
+    float w0 = x[6], w1 = x[7], w2 = x[8];
+    if (amax >= 0.9999995f) {
+        float A[9];
+        trunc_block_f64(x[0], x[1], x[2], A);
+        x[0] += k.dt * (A[0] * w0 + A[1] * w1 + A[2] * w2);
+        x[1] += k.dt * (A[3] * w0 + A[4] * w1 + A[5] * w2);
+        x[2] += k.dt * (A[6] * w0 + A[7] * w1 + A[8] * w2);
+    }
+    // position integrates the PRIOR velocity
+    x[3] += k.dt * x[9]; x[4] += k.dt * x[10]; x[5] += k.dt * x[11];
+    x[6] = w0 + k.dt * aw0; x[7] = w1 + k.dt * aw1; x[8] = w2 + k.dt * aw2;
+    x[9] += k.dt * (fs[0] * k.inv_mass);
+    x[10] += k.dt * (fs[1] * k.inv_mass);
+    x[11] += k.dt * (fs[2] * k.inv_mass) + k.dt * k.gz;
+}
+
+// P <- F_d P F_d^T + Q with F_d = I + dt F, F[0:3,6:9] = R^T, F[3:6,9:12] = I
+// (kalman_filter/kalman_filter.py:124-128,135).  ~300 FMA instead of two dense 12^3 products.
+__device__ __forceinline__ void cov_predict(float *P, const Rot &r, const KfConst &k)
+{
+    float g[9];   // g[i][kk] = dt * R^T[i][kk] = dt * R[kk][i]
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * r.m[3 * kk + i];
+    // rows: M = F_d P
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        float a6 = P[6 * NS + j], a7 = P[7 * NS + j], a8 = P[8 * NS + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            P[i * NS + j] += g[3 * i] * a6 + g[3 * i + 1] * a7 + g[3 * i + 2] * a8;
+            P[(3 + i) * NS + j] += k.dt * P[(9 + i) * NS + j];
+        }
+    }
+    // columns: M F_d^T
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        float a6 = P[i * NS + 6], a7 = P[i * NS + 7], a8 = P[i * NS + 8];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            P[i * NS + j] += g[3 * j] * a6 + g[3 * j + 1] * a7 + g[3 * j + 2] * a8;
+            P[i * NS + 3 + j] += k.dt * P[i * NS + 9 + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) P[i] += k.Q[i];
+}
+
+// predict_mpc covariance (kalman_filter/kalman_filter.py:153-158): F_d = element-wise exp(dt F), i.e.
+// ones everywhere except exp(dt R^T_ij) in [0:3,6:9] and e^dt on the diagonal of [3:6,9:12].
+// F_d = 1 1^T + E  ->  F_d P F_d^T evaluated through column/row sums plus the sparse E.
+__device__ __forceinline__ void cov_predict_dense(float *P, const Rot &rb, const KfConst &k)
+{
+    float e[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) e[3 * i + kk] = expm1f(k.dt * rb.m[3 * kk + i]);
+    float ed = expm1f(k.dt);
+    float M[NS * NS];
+    // M = F_d P = 1 (1^T P) + E P
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        float cs = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; i++) cs += P[i * NS + j];
+#pragma unroll
+        for (int i = 0; i < NS; i++) M[i * NS + j] = cs;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            M[i * NS + j] += e[3 * i] * P[6 * NS + j] + e[3 * i + 1] * P[7 * NS + j] + e[3 * i + 2] * P[8 * NS + j];
+            M[(3 + i) * NS + j] += ed * P[(9 + i) * NS + j];
+        }
+    }
+    // P = M F_d^T = (M 1) 1^T + M E^T
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NS; j++) rs += M[i * NS + j];
+#pragma unroll
+        for (int j = 0; j < NS; j++) P[i * NS + j] = rs + k.Q[i * NS + j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            P[i * NS + j] += e[3 * j] * M[i * NS + 6] + e[3 * j + 1] * M[i * NS + 7] + e[3 * j + 2] * M[i * NS + 8];
+            P[i * NS + 3 + j] += ed * M[i * NS + 9 + j];
+        }
+    }
+}
+
+// Batch update as the reference writes it (kalman_filter/kalman_filter.py:166-172):
+//   y = z - x[sel]; S = P[sel,sel] + R; K = P[:,sel] S^-1; x += K y; P <- P - K P[sel,:]
+// S^-1 is applied through the Cholesky factor S = L L^T (S is symmetric positive definite; unpivoted and
+// branch-free, which suits 64 lanes in lock-step).  Returns status bits.
+template <bool WANT_K>
+__device__ __forceinline__ int update_batch(float *x, float *P, const float *z, const KfConst &k, float *Kout,
+                                            float *kgain)
+{
+    int status = 0;
+    float L[NM * (NM + 1) / 2];   // packed lower triangle, L[a(a+1)/2 + b]
+    float dinv[NM];
+#pragma unroll
+    for (int a = 0; a < NM; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++)
+            // symmetrised entry: the reference's S is symmetric up to rounding of P
+            L[a * (a + 1) / 2 + b] = 0.5f * (P[SEL[a] * NS + SEL[b]] + P[SEL[b] * NS + SEL[a]]) +
+                                     0.5f * (k.R[a * NM + b] + k.R[b * NM + a]);
+#pragma unroll
+    for (int j = 0; j < NM; j++) {
+        float d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int q = 0; q < j; q++) d -= L[j * (j + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+        if (!(d > 0.f) || !(d < 3.0e38f)) { status |= 1; d = 1.0f; }
+        float di = rsqrtf(d);
+        // one Newton step: rsqrtf is ~1 ulp on gfx950 but keep the factor tight for cond(S) ~ 1e6
+        di = di * (1.5f - 0.5f * d * di * di);
+        dinv[j] = di;
+        L[j * (j + 1) / 2 + j] = d * di;
+#pragma unroll
+        for (int i = j + 1; i < NM; i++) {
+            float s = L[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int q = 0; q < j; q++) s -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+            L[i * (i + 1) / 2 + j] = s * di;
+        }
+    }
+    // K[i,:] = solve(S, P[i,sel]) for each of the 12 rows (S symmetric: K = P[:,sel] S^-1)
+    float K[NS * NM];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        float y[NM];
+#pragma unroll
+        for (int a = 0; a < NM; a++) {
+            float s = P[i * NS + SEL[a]];
+#pragma unroll
+            for (int q = 0; q < a; q++) s -= L[a * (a + 1) / 2 + q] * y[q];
+            y[a] = s * dinv[a];
+        }
+#pragma unroll
+        for (int a = NM - 1; a >= 0; a--) {
+            float s = y[a];
+#pragma unroll
+            for (int q = a + 1; q < NM; q++) s -= L[q * (q + 1) / 2 + a] * K[i * NM + q];
+            K[i * NM + a] = s * dinv[a];
+        }
+    }
+    float innov[NM];
+#pragma unroll
+    for (int a = 0; a < NM; a++) innov[a] = z[a] - x[SEL[a]];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < NM; a++) s += K[i * NM + a] * innov[a];
+        x[i] += s;
+    }
+    // P <- P - K P[sel,:], one column at a time (the selected rows of the OLD column are needed)
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        float c[NM];
+#pragma unroll
+        for (int a = 0; a < NM; a++) c[a] = P[SEL[a] * NS + j];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < NM; a++) s += K[i * NM + a] * c[a];
+            P[i * NS + j] -= s;
+        }
+    }
+    if (WANT_K) {
+        if (Kout) {
+#pragma unroll
+            for (int i = 0; i < NS * NM; i++) Kout[i] = K[i];
+        }
+        float t = 0.f;   // np.trace of the 12x10 K sums its 10 main-diagonal entries (kalman_filter.py:174)
+#pragma unroll
+        for (int a = 0; a < NM; a++) t += K[a * NM + a];
+        *kgain = t;
+    }
+    return status;
+}
+
+// Sequential (one measurement at a time) form of the same update; exact-arithmetic identical to the batch
+// form when R is diagonal, which every Q/R set of the reference is (settings.py:30,
+// data_collection/data_conversion_Kalman_to_Training.py:103-105 np.diag).  No factorisation, 24 temporaries.
+__device__ __forceinline__ int update_sequential(float *x, float *P, const float *z, const KfConst &k)
+{
+    int status = 0;
+#pragma unroll
+    for (int a = 0; a < NM; a++) {
+        const int sa = SEL[a];
+        float s = P[sa * NS + sa] + k.R[a * NM + a];
+        if (!(s > 0.f) || !(s < 3.0e38f)) { status |= 1; s = 1.0f; }
+        float inv = 1.0f / s;
+        float innov = z[a] - x[sa];
+        float kc[NS], row[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) { kc[i] = P[i * NS + sa] * inv; row[i] = P[sa * NS + i]; }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            x[i] += kc[i] * innov;
+#pragma unroll
+            for (int j = 0; j < NS; j++) P[i * NS + j] -= kc[i] * row[j];
+        }
+    }
+    return status;
+}
+
+__device__ __forceinline__ float trace12(const float *P)
+{
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++) t += P[i * NS + i];
+    return t;
+}
+
+__device__ __forceinline__ int finite_status(const float *x)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++) s += x[i] * 0.f;   // NaN/Inf propagate
+    return (s == 0.f) ? 0 : 2;
+}
+
+// One full filter step, split in two so the caller can reuse the input registers between the halves:
+//   kf_step_front: everything that consumes the step's inputs (measurement, covariance predict, dynamics)
+//   kf_step_back : the measurement update (the long part; needs only z)
+template <bool DENSE>
+__device__ __forceinline__ void kf_step_front(float *x, float *P, const StepIn &in, const float *body_ref /*3 angles*/,
+                                              const KfConst &k, float *z, float *pw)
+{
+    measurement(in, z);
+    Rot r = rotation(x[0], x[1], x[2]);     // prior attitude drives both F_d and next_state
+    if (DENSE) {
+        Rot rb = rotation(body_ref[0], body_ref[1], body_ref[2]);
+        cov_predict_dense(P, rb, k);
+    } else {
+        cov_predict(P, r, k);
+    }
+    dynamics(x, r, in.p, in.f, pw, k);
+}
+
+template <bool SEQ, bool AUX>
+__device__ __forceinline__ int kf_step_back(float *x, float *P, const float *z, const KfConst &k, float *ptrace,
+                                            float *kgain)
+{
+    int st;
+    if (SEQ) st = update_sequential(x, P, z, k);
+    else st = update_batch<AUX>(x, P, z, k, nullptr, kgain);
+    if (AUX) *ptrace = trace12(P);
+    return st | finite_status(x);
+}
+
+}  // namespace osk

@@ -1,0 +1,393 @@
+// kf_kernels.hip -- batched Kalman filter kernels for gfx950: one trajectory per lane, the whole T-step
+// recurrence inside one launch, x/P resident in VGPRs, inputs streamed coalesced from [T][field][B].
+#include "kf_device.hpp"
+#include "launch.hpp"
+
+namespace osk {
+
+struct KfRunArgs {
+    int B, T;
+    const float *p, *f, *dp, *imu;
+    const uint32_t *contact;
+    const float *body_ref;
+    float *x, *P;
+    float *x_out, *p_rot_out, *ptrace_out, *kgain_out;
+    int32_t *status;
+    // optional feature-row emission (fused path v0): normalised rows [T][feat_I][B]
+    const float *accel;      // [T][6][B]
+    const float *minmax;     // [2][60]: mins, maxs
+    float *feat_out;
+    int feat_I;
+    KfConst k;
+};
+
+// Loads one step's 43 input dwords for this lane.  rowB = B*4 (bytes per row), voff = b*4.
+__device__ __forceinline__ void load_step(const KfRunArgs &a, int t, uint32_t voff, uint32_t rowB, StepIn &in)
+{
+    const size_t B = (size_t)a.B;
+    rsrc_t rp = make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t rf = make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t rd = make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t ri = make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB);
+    rsrc_t rc = make_rsrc(a.contact + (size_t)t * B, rowB);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        in.p[i] = buf_load(rp, voff, i * rowB);
+        in.f[i] = buf_load(rf, voff, i * rowB);
+        in.dp[i] = buf_load(rd, voff, i * rowB);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.imu[i] = buf_load(ri, voff, i * rowB);
+    in.contact = buf_load_u32(rc, voff, 0);
+}
+
+// 64-lane workgroups: lanes are independent, so small groups give the dispatcher the most freedom to
+// spread waves over the 1024 SIMDs.  State: 156 VGPRs (x, P) + 43 input dwords + update temporaries.
+// Feature row layout (data_collection/data_conversion_Kalman_to_Training.py:245-254):
+//   [0:12) x_post | [12:18) accel | [18:30) f | [30:42) p_world | [42:54) dp | [54:60) imu ; then (v - min)/(max - min).
+__device__ __forceinline__ void store_feat(rsrc_t rf, const float *mm, uint32_t voff, uint32_t rowB, int j, float v)
+{
+    const float mn = mm[j], mx = mm[60 + j];
+    buf_store(rf, voff, j * rowB, (v - mn) / (mx - mn));
+}
+
+template <bool SEQ, bool DENSE, bool AUX, bool FEAT>
+__global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const size_t B = (size_t)a.B;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    float x[NS], P[NS * NS];
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+#pragma unroll
+        for (int i = 0; i < NS * NS; i++) P[i] = buf_load(rP, voff, i * rowB);
+    }
+    int status = 0;
+    StepIn in;
+    float bref[3] = {0.f, 0.f, 0.f};
+    load_step(a, 0, voff, rowB, in);
+    if (DENSE) {
+        rsrc_t rb = make_rsrc(a.body_ref, 12 * rowB);
+#pragma unroll
+        for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
+    }
+    for (int t = 0; t < a.T; t++) {
+        float z[NM], pw[12], ptrace = 0.f, kgain = 0.f;
+        kf_step_front<DENSE>(x, P, in, bref, a.k, z, pw);
+        rsrc_t rfeat;
+        if (FEAT) {
+            rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
+            rsrc_t ra = make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB);
+#pragma unroll
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load(ra, voff, i * rowB));
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                store_feat(rfeat, a.minmax, voff, rowB, 18 + i, in.f[i]);
+                store_feat(rfeat, a.minmax, voff, rowB, 30 + i, pw[i]);
+                store_feat(rfeat, a.minmax, voff, rowB, 42 + i, in.dp[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 54 + i, in.imu[i]);
+        }
+        if (a.p_rot_out) {
+            rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < 12; i++) buf_store(ro, voff, i * rowB, pw[i]);
+        }
+        // the inputs are dead now: reuse their registers to prefetch step t+1 underneath the update,
+        // which is the long part of the step (43 coalesced loads in flight, one wave per SIMD)
+        const int tn = (t + 1 < a.T) ? t + 1 : t;
+        load_step(a, tn, voff, rowB, in);
+        if (DENSE) {
+            rsrc_t rb = make_rsrc(a.body_ref + (size_t)tn * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
+        }
+        status |= kf_step_back<SEQ, AUX>(x, P, z, a.k, &ptrace, &kgain);
+        {
+            rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
+        }
+        if (FEAT) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, x[i]);
+        }
+        if (AUX) {
+            if (a.ptrace_out) a.ptrace_out[(size_t)t * B + b] = ptrace;
+            if (a.kgain_out) a.kgain_out[(size_t)t * B + b] = kgain;
+        }
+    }
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+#pragma unroll
+        for (int i = 0; i < NS * NS; i++) buf_store(rP, voff, i * rowB, P[i]);
+    }
+    a.status[b] = status;
+}
+
+// ---- single pieces for the drop-in Kalman_Filter class (B is tiny there; latency-bound by design) ----
+
+__global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
+                               float *z)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    StepIn in;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { in.p[i] = p[(size_t)i * B + b]; in.dp[i] = dp[(size_t)i * B + b]; in.f[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.imu[i] = imu[(size_t)i * B + b];
+    in.contact = contact[b];
+    float zz[NM];
+    measurement(in, zz);
+#pragma unroll
+    for (int i = 0; i < NM; i++) z[(size_t)i * B + b] = zz[i];
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(64, 1) void kf_predict_kernel(int B, float *p, const float *f, const float *body_ref,
+                                                           float *x, float *P, float *ptrace_out, const KfConst k)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float xx[NS], PP[NS * NS], pp[12], ff[12], pw[12];
+#pragma unroll
+    for (int i = 0; i < NS; i++) xx[i] = x[(size_t)i * B + b];
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) PP[i] = P[(size_t)i * B + b];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { pp[i] = p[(size_t)i * B + b]; ff[i] = f[(size_t)i * B + b]; }
+    Rot r = rotation(xx[0], xx[1], xx[2]);
+    if (DENSE) {
+        Rot rb = rotation(body_ref[b], body_ref[(size_t)B + b], body_ref[(size_t)2 * B + b]);
+        cov_predict_dense(PP, rb, k);
+    } else {
+        cov_predict(PP, r, k);
+    }
+    dynamics(xx, r, pp, ff, pw, k);
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[(size_t)i * B + b] = xx[i];
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) P[(size_t)i * B + b] = PP[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) p[(size_t)i * B + b] = pw[i];
+    if (ptrace_out) ptrace_out[b] = trace12(PP);
+}
+
+template <bool SEQ>
+__global__ __launch_bounds__(64, 1) void kf_update_kernel(int B, const float *z, float *x, float *P, float *K_out,
+                                                          float *ptrace_out, float *kgain_out, int32_t *status,
+                                                          const KfConst k)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float xx[NS], PP[NS * NS], zz[NM];
+#pragma unroll
+    for (int i = 0; i < NS; i++) xx[i] = x[(size_t)i * B + b];
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) PP[i] = P[(size_t)i * B + b];
+#pragma unroll
+    for (int i = 0; i < NM; i++) zz[i] = z[(size_t)i * B + b];
+    int st;
+    float kg = 0.f;
+    if (SEQ) {
+        st = update_sequential(xx, PP, zz, k);
+    } else {
+        float K[NS * NM];
+        st = update_batch<true>(xx, PP, zz, k, K, &kg);
+        if (K_out) {
+#pragma unroll
+            for (int i = 0; i < NS * NM; i++) K_out[(size_t)i * B + b] = K[i];
+        }
+    }
+    st |= finite_status(xx);
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[(size_t)i * B + b] = xx[i];
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) P[(size_t)i * B + b] = PP[i];
+    if (ptrace_out) ptrace_out[b] = trace12(PP);
+    if (kgain_out) kgain_out[b] = kg;
+    if (status) status[b] = st;
+}
+
+// ---- layout helpers: [B][T][F] <-> [T][F][B] through a 32x32 LDS tile (coalesced on both sides) ----
+__global__ void pack_btf_to_tfb(int B, int TF, const float *__restrict__ src, float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    // src viewed as [B][TF], dst as [TF][B]
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx over TF, by over B
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        int bb = by + r, c = bx + threadIdx.x;
+        if (bb < B && c < TF) tile[r][threadIdx.x] = src[(size_t)bb * TF + c];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        int c = bx + r, bb = by + threadIdx.x;
+        if (bb < B && c < TF) dst[(size_t)c * B + bb] = tile[threadIdx.x][r];
+    }
+}
+
+}  // namespace osk
+
+using namespace osk;
+
+template <bool SEQ, bool DENSE, bool AUX, bool FEAT>
+static hipError_t launch_kf_run(const KfRunArgs &a, hipStream_t s)
+{
+    dim3 grid((a.B + 63) / 64), block(64);
+    hipLaunchKernelGGL((kf_run_kernel<SEQ, DENSE, AUX, FEAT>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// Shared by os_kf_run and os_fused_run (v0: Kalman kernel emits normalised feature rows for the GRU kernels).
+int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
+{
+    const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE, dense = flags & OS_KF_DENSE_FD;
+    if (dense && !a.body_ref) return os_fail(ctx, -2, "os_kf_run: OS_KF_DENSE_FD needs body_ref");
+    if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_run: sequential update needs a diagonal R");
+    if (seq && a.kgain_out) return os_fail(ctx, -3, "os_kf_run: K_gain is only defined by the batch update");
+    if ((size_t)a.B * 144 * 4 >= 0xffffffffull) return os_fail(ctx, -2, "os_kf_run: B too large for 32-bit buffer offsets");
+    a.k = ctx->k;
+    const bool aux = a.ptrace_out || a.kgain_out, feat = a.feat_out != nullptr;
+    if (feat && aux) return os_fail(ctx, -3, "os_kf_run: feature emission and P_trace/K_gain outputs are exclusive");
+    hipError_t e;
+#define OS_DISPATCH(SEQ, DENSE)                                                        \
+    (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
+          : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
+    if (seq) e = dense ? OS_DISPATCH(true, true) : OS_DISPATCH(true, false);
+    else e = dense ? OS_DISPATCH(false, true) : OS_DISPATCH(false, false);
+#undef OS_DISPATCH
+    OS_HIP(ctx, e);
+    return 0;
+}
+
+extern "C" {
+
+int os_kf_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f, const float *dp, const float *imu,
+              const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *p_rot_out,
+              float *ptrace_out, float *kgain_out, int32_t *status, uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0) return os_fail(ctx, -2, "os_kf_run: B and T must be positive");
+    if (!p || !f || !dp || !imu || !contact || !x || !P || !x_out || !status)
+        return os_fail(ctx, -2, "os_kf_run: null required pointer");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    KfRunArgs a;
+    a.B = B; a.T = T; a.p = p; a.f = f; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = body_ref;
+    a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = p_rot_out; a.ptrace_out = ptrace_out; a.kgain_out = kgain_out;
+    a.status = status; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
+    return os_kf_run_impl(ctx, a, flags, (hipStream_t)stream);
+}
+
+int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f, const float *dp, const float *imu,
+                 const uint32_t *contact, const float *accel, const float *body_ref, const float *latent,
+                 int32_t n_latent, const float *minmax, float *x, float *P, float *x_out, float *out, int32_t *status,
+                 uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0) return os_fail(ctx, -2, "os_fused_run: B and T must be positive");
+    if (!p || !f || !dp || !imu || !contact || !accel || !minmax || !x || !P || !x_out || !out || !status)
+        return os_fail(ctx, -2, "os_fused_run: null required pointer");
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_fused_run: call os_gru_load first");
+    if (n_latent < 0 || (n_latent > 0 && !latent)) return os_fail(ctx, -2, "os_fused_run: bad latent");
+    const int I = 60 + n_latent;
+    if (ctx->gru.input_size != I) return os_fail(ctx, -4, "os_fused_run: GRU input_size must be 60 + n_latent");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)T * I * B;
+    if (ctx->feat_floats < need) {
+        if (ctx->feat) OS_HIP(ctx, hipFree(ctx->feat));
+        ctx->feat = nullptr; ctx->feat_floats = 0;
+        OS_HIP(ctx, hipMalloc((void **)&ctx->feat, need * sizeof(float)));
+        ctx->feat_floats = need;
+    }
+    KfRunArgs a;
+    a.B = B; a.T = T; a.p = p; a.f = f; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = body_ref;
+    a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = nullptr; a.ptrace_out = nullptr; a.kgain_out = nullptr;
+    a.status = status; a.accel = accel; a.minmax = minmax; a.feat_out = ctx->feat; a.feat_I = I;
+    int rc = os_kf_run_impl(ctx, a, flags, s);
+    if (rc) return rc;
+    if (n_latent > 0) {
+        // rows [60, 60+NL) of every step: latent [T][NL][B] -> feat [T][I][B] (gru/gru_test.py:135-136)
+        OS_HIP(ctx, hipMemcpy2DAsync(ctx->feat + (size_t)60 * B, (size_t)I * B * sizeof(float), latent,
+                                     (size_t)n_latent * B * sizeof(float), (size_t)n_latent * B * sizeof(float), T,
+                                     hipMemcpyDeviceToDevice, s));
+    }
+    return os_gru_forward_soa(ctx, B, T, ctx->feat, out, nullptr, stream);
+}
+
+int os_kf_odom(os_ctx *ctx, int32_t B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
+               float *z, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || !p || !dp || !contact || !imu || !z) return os_fail(ctx, -2, "os_kf_odom: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(kf_odom_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, p, dp, contact, imu, z);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_kf_predict(os_ctx *ctx, int32_t B, float *p, const float *f, const float *body_ref, float *x, float *P,
+                  float *ptrace_out, uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || !p || !f || !x || !P) return os_fail(ctx, -2, "os_kf_predict: bad argument");
+    const bool dense = flags & OS_KF_DENSE_FD;
+    if (dense && !body_ref) return os_fail(ctx, -2, "os_kf_predict: OS_KF_DENSE_FD needs body_ref");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid((B + 63) / 64), block(64);
+    if (dense) hipLaunchKernelGGL(kf_predict_kernel<true>, grid, block, 0, (hipStream_t)stream, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
+    else hipLaunchKernelGGL(kf_predict_kernel<false>, grid, block, 0, (hipStream_t)stream, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_kf_update(os_ctx *ctx, int32_t B, const float *z, float *x, float *P, float *K_out, float *ptrace_out,
+                 float *kgain_out, int32_t *status, uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || !z || !x || !P) return os_fail(ctx, -2, "os_kf_update: bad argument");
+    const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE;
+    if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_update: sequential update needs a diagonal R");
+    if (seq && (K_out || kgain_out)) return os_fail(ctx, -3, "os_kf_update: K is only formed by the batch update");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid((B + 63) / 64), block(64);
+    if (seq) hipLaunchKernelGGL(kf_update_kernel<true>, grid, block, 0, (hipStream_t)stream, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
+    else hipLaunchKernelGGL(kf_update_kernel<false>, grid, block, 0, (hipStream_t)stream, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_pack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src, float *dst, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0 || F <= 0 || !src || !dst) return os_fail(ctx, -2, "os_pack_stream: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    const int TF = T * F;
+    dim3 grid((TF + 31) / 32, (B + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(pack_btf_to_tfb, grid, block, 0, (hipStream_t)stream, B, TF, src, dst);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_unpack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src, float *dst, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0 || F <= 0 || !src || !dst) return os_fail(ctx, -2, "os_unpack_stream: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    // [TF][B] -> [B][TF] is the same transpose with the roles of the two extents swapped
+    const int TF = T * F;
+    dim3 grid((B + 31) / 32, (TF + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(pack_btf_to_tfb, grid, block, 0, (hipStream_t)stream, TF, B, src, dst);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// launch.hpp -- context object and error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/optistate_hip.h"
+#include "kf_device.hpp"
+
+struct GruPacked;   // gru_kernels.hip
+
+struct os_ctx {
+    uint32_t magic;
+    int device;
+    osk::KfConst k;
+    bool r_is_diagonal;
+    char err[512];
+    // GRU state (owned scratch)
+    os_gru_dims gru;
+    bool gru_loaded;
+    float *gru_packed;        // device: weights re-packed into MFMA fragment order
+    size_t gru_packed_floats;
+    const float *gru_flat;    // caller-owned flat weights (kept for the head / biases)
+    float *gru_seq;  size_t gru_seq_floats;   // inter-layer sequences [T][H][B] x2 + h_last
+    float *gru_xs;   size_t gru_xs_floats;    // SoA copy of a (B,T,I) input
+    float *gru_hl;   size_t gru_hl_floats;    // SoA h_last of all layers
+    float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
+    int cu_count;
+};
+
+#define OS_MAGIC 0x4f53414du
+
+static inline int os_fail(os_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+    return code;
+}
+
+#define OS_CHECK_CTX(ctx)                                         \
+    do {                                                          \
+        if (!(ctx) || (ctx)->magic != OS_MAGIC) return -1;        \
+    } while (0)
+
+#define OS_HIP(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d: %s", __FILE__, __LINE__,              \
+                     hipGetErrorString(_e));                                                       \
+            return -10;                                                                            \
+        }                                                                                          \
+    } while (0)

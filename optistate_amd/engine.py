@@ -1,0 +1,188 @@
+"""Batched Kalman+GRU engine: the host side of the C-ABI (include/optistate_hip.h).
+
+torch is used for device memory and streams only; all arithmetic on the hot path happens in the HIP
+kernels of liboptistate_hip.so.  There is no CPU fallback: constructing an engine without a visible
+MI355X raises.
+
+Stream layout (see the header): structure of arrays, trajectory index fastest, e.g. p [T][12][B].
+`pack()` converts the reference's per-trajectory row lists ([B][T][F]) on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE  # noqa: F401
+
+# settings.py:5-23 and kalman_filter/kalman_filter.py:56
+DT, MASS, GZ = 0.01, 8.8, -9.81
+INERTIA = (55303643.08 / 1e9, 60119440.34 / 1e9, 105304340.05 / 1e9)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, device=0, dt=DT, mass=MASS, inertia=INERTIA, gz=GZ):
+        self.lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("optistate_amd: no HIP device visible (the hot path has no CPU fallback)")
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index or 0)
+        cfg = _capi.OsKfConfig(self.device.index, dt, mass, (C.c_float * 3)(*inertia), gz)
+        h = C.c_void_p()
+        rc = self.lib.os_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"os_create failed with code {rc} (is this an MI355X / gfx950?)")
+        self._h = h
+        self._gru_dims = None
+        self._gru_flat = None      # keeps the flat weight tensor alive (the library references it for the head)
+        self._diag_R = True
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.os_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.os_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, a, shape=None):
+        t = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32) if not torch.is_tensor(a) else a)
+        t = t.to(self.device, dtype=torch.float32).contiguous()
+        return t if shape is None else t.reshape(shape)
+
+    # ---- Kalman filter ----
+    def set_noise(self, Q, R):
+        """KF.Q = Q; KF.R = R (data_collection/data_conversion_Kalman_to_Training.py:139-143)."""
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(144)
+        R = np.ascontiguousarray(R, dtype=np.float32).reshape(100)
+        self._diag_R = bool(np.count_nonzero(R.reshape(10, 10) - np.diag(np.diag(R.reshape(10, 10)))) == 0)
+        self._check(self.lib.os_kf_set_noise(self._h, Q.ctypes.data_as(C.POINTER(C.c_float)),
+                                             R.ctypes.data_as(C.POINTER(C.c_float))), "os_kf_set_noise")
+
+    def pack(self, a_btf):
+        """[B][T][F] -> [T][F][B] on the device."""
+        a = self._f32(a_btf)
+        B, T, F = a.shape
+        out = torch.empty((T, F, B), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_pack_stream(self._h, B, T, F, _ptr(a), _ptr(out), self._stream()), "os_pack_stream")
+        return out
+
+    def unpack(self, a_tfb):
+        T, F, B = a_tfb.shape
+        out = torch.empty((B, T, F), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_unpack_stream(self._h, B, T, F, _ptr(a_tfb), _ptr(out), self._stream()),
+                    "os_unpack_stream")
+        return out
+
+    def pack_contact(self, c_bt4):
+        """uint8 [B][T][4] -> packed uint32-as-4-bytes [T][B]."""
+        c = torch.as_tensor(c_bt4).to(self.device, dtype=torch.uint8).contiguous()
+        return c.permute(1, 0, 2).contiguous().view(torch.int32).reshape(c.shape[1], c.shape[0])
+
+    @staticmethod
+    def contact_soa_to_packed(c_t4b):
+        """uint8 [T][4][B] -> packed [T][B] int32."""
+        return c_t4b.permute(0, 2, 1).contiguous().view(torch.int32).reshape(c_t4b.shape[0], c_t4b.shape[2])
+
+    def kf_run(self, p, f, dp, imu, contact, x, P, body_ref=None, sequential=None, dense_fd=False,
+               want_p_rot=False, want_trace=False, want_gain=False):
+        """Runs T filter steps for B trajectories.  All stream arguments are SoA device tensors; x [12][B] and
+        P [144][B] are updated in place.  Returns dict(x_out [T][12][B], status [B], p_rot?, P_trace?, K_gain?)."""
+        T, _, B = p.shape
+        if sequential is None:
+            sequential = self._diag_R and not want_gain
+        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0)
+        dev = self.device
+        x_out = torch.empty((T, 12, B), dtype=torch.float32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        p_rot = torch.empty((T, 12, B), dtype=torch.float32, device=dev) if want_p_rot else None
+        ptr = torch.empty((T, B), dtype=torch.float32, device=dev) if want_trace else None
+        kg = torch.empty((T, B), dtype=torch.float32, device=dev) if want_gain else None
+        self._check(self.lib.os_kf_run(self._h, B, T, _ptr(p), _ptr(f), _ptr(dp), _ptr(imu), _ptr(contact),
+                                       _ptr(body_ref), _ptr(x), _ptr(P), _ptr(x_out), _ptr(p_rot), _ptr(ptr), _ptr(kg),
+                                       _ptr(status), flags, self._stream()), "os_kf_run")
+        return dict(x_out=x_out, status=status, p_rot=p_rot, P_trace=ptr, K_gain=kg)
+
+    # ---- GRU ----
+    def load_gru(self, flat, input_size, hidden_size, num_layers, num_classes, use_sigmoid=True):
+        """flat: 1-D float32 device tensor in the flat layout of the header (see flatten_state_dict)."""
+        d = _capi.OsGruDims(input_size, hidden_size, num_layers, num_classes, 1 if use_sigmoid else 0)
+        n = self.lib.os_gru_param_count(C.byref(d))
+        flat = flat.to(self.device, dtype=torch.float32).contiguous()
+        if flat.numel() != n:
+            raise ValueError(f"flat weight vector has {flat.numel()} floats, expected {n}")
+        self._check(self.lib.os_gru_load(self._h, C.byref(d), _ptr(flat), self._stream()), "os_gru_load")
+        self._gru_flat, self._gru_dims = flat, d
+
+    def gru_forward(self, x_bti, want_h_last=False):
+        """RNN.forward on x (B, T, I) -> (B, C)  (gru/gru_model.py:25-49)."""
+        x = x_bti.to(self.device, dtype=torch.float32).contiguous()
+        B, T, I = x.shape
+        d = self._gru_dims
+        if d is None or I != d.input_size:
+            raise ValueError("load_gru first / input width mismatch")
+        out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
+        hl = torch.empty((d.num_layers, B, d.hidden_size), dtype=torch.float32, device=self.device) if want_h_last else None
+        self._check(self.lib.os_gru_forward(self._h, B, T, _ptr(x), _ptr(out), _ptr(hl), self._stream()), "os_gru_forward")
+        return (out, hl) if want_h_last else out
+
+    def gru_forward_soa(self, xs_tib):
+        T, I, B = xs_tib.shape
+        d = self._gru_dims
+        out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_gru_forward_soa(self._h, B, T, _ptr(xs_tib), _ptr(out), None, self._stream()),
+                    "os_gru_forward_soa")
+        return out
+
+    # ---- fused ----
+    def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
+                  dense_fd=False):
+        """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B])."""
+        T, _, B = p.shape
+        if sequential is None:
+            sequential = self._diag_R
+        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0)
+        d = self._gru_dims
+        nl = 0 if latent is None else latent.shape[1]
+        out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
+        x_out = torch.empty((T, 12, B), dtype=torch.float32, device=self.device)
+        status = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.os_fused_run(self._h, B, T, _ptr(p), _ptr(f), _ptr(dp), _ptr(imu), _ptr(contact),
+                                          _ptr(accel), _ptr(body_ref), _ptr(latent), nl, _ptr(minmax), _ptr(x), _ptr(P),
+                                          _ptr(x_out), _ptr(out), _ptr(status), flags, self._stream()), "os_fused_run")
+        return dict(out=out, x_out=x_out, status=status)
+
+
+def flatten_state_dict(sd, num_layers, device=None):
+    """state_dict with the reference's keys (gru.weight_ih_l{k}, gru.weight_hh_l{k}, gru.bias_ih_l{k},
+    gru.bias_hh_l{k}, fc.weight, fc.bias) -> flat float32 tensor."""
+    parts = []
+    for l in range(num_layers):
+        for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            parts.append(sd[f"gru.{k}_l{l}"].detach().reshape(-1).float())
+    parts += [sd["fc.weight"].detach().reshape(-1).float(), sd["fc.bias"].detach().reshape(-1).float()]
+    flat = torch.cat(parts)
+    return flat.to(device) if device is not None else flat
+
+
+_default_engines = {}
+
+
+def default_engine(device=0):
+    idx = device if isinstance(device, int) else (torch.device(device).index or 0)
+    if idx not in _default_engines:
+        _default_engines[idx] = Engine(idx)
+    return _default_engines[idx]

@@ -1,0 +1,47 @@
+"""Drop-in `RNN` with the reference's surface (gru/gru_model.py:7-49): same constructor signature, same
+state_dict keys (gru.weight_ih_l{k}, gru.weight_hh_l{k}, gru.bias_ih_l{k}, gru.bias_hh_l{k}, fc.weight, fc.bias),
+`.to()/.eval()/.parameters()` work because nn.GRU / nn.Linear are kept as the *weight containers*.
+`forward` never calls them: it runs the HIP GRU kernels through the C-ABI.  No CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from .engine import default_engine, flatten_state_dict
+
+
+class RNN(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, num_classes, device, evaluate=False, use_sigmoid=True):
+        super().__init__()
+        self.num_layers = num_layers
+        self.hidden_size = hidden_size
+        self.input_size = input_size
+        self.num_classes = num_classes
+        self.device = device
+        self.gru = nn.GRU(input_size, hidden_size, num_layers, batch_first=True)   # container only
+        self.fc = nn.Linear(hidden_size, num_classes)                               # container only
+        self.evaluate = evaluate
+        self.use_sigmoid = use_sigmoid
+        self.sigmoid = nn.Sigmoid()
+        self._loaded_versions = None
+        self._engine = None
+
+    def _sync_weights(self, dev):
+        if self._engine is None or self._engine.device != dev:
+            self._engine = default_engine(dev.index or 0)
+            self._loaded_versions = None
+        versions = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if versions != self._loaded_versions:
+            flat = flatten_state_dict(self.state_dict(), self.num_layers, device=dev)
+            self._engine.load_gru(flat, self.input_size, self.hidden_size, self.num_layers, self.num_classes,
+                                  self.use_sigmoid)
+            self._loaded_versions = versions
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("optistate_amd.RNN.forward needs a tensor on the MI355X (no CPU fallback); "
+                               "move the input with .to('cuda')")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .train import gru_forward_autograd        # training path: HIP forward + HIP backward
+            return gru_forward_autograd(self, x)
+        self._sync_weights(x.device)
+        return self._engine.gru_forward(x)

@@ -1,0 +1,138 @@
+"""Drop-in `Kalman_Filter` with the reference's Python surface (kalman_filter/kalman_filter.py:7-193).
+
+Same constructor, attributes (x, z, H, P, Q, R, P_trace, K_gain, K, x_model, f, dt) and methods
+(get_odom, set_measurements, predict, update, estimate_state_mpc, rotation_matrix_body_world); arrays are
+float64 column vectors as in the reference.  Every method runs the HIP kernels through the C-ABI with B = 1
+(latency-bound by design: this class exists so that the reference's scripts keep working; throughput
+comes from `Engine.kf_run`, which steps many trajectories per launch).  Values carry float32 precision.
+
+Differences from the reference, all deliberate (SURVEY.md section 5 "race detection" and appendix):
+  * no global state: x/P/Q/R are per-instance copies (the reference aliases class attributes of
+    settings.INITIAL_PARAMS, kalman_filter/kalman_filter.py:10,27-29);
+  * get_odom is defined for 0 and 4 stance legs (the reference raises ValueError there);
+  * estimate_state_mpc needs the ground-reaction forces as an argument: the convex-MPC QP that produces them in
+    the reference (misc/force_controller.py:15-225, casadi/qpOASES) is out of scope.
+"""
+import numpy as np
+import torch
+
+from .engine import default_engine, _ptr, OS_KF_DENSE_FD
+from . import synth
+
+
+class Kalman_Filter:
+    def __init__(self, device=0):
+        self._eng = default_engine(device)
+        self._dev = self._eng.device
+        self.x = synth.X0.reshape(12, 1).copy()                       # kalman_filter.py:10 / settings.py:25
+        self.z = np.zeros((10, 1))
+        self.H = np.zeros((10, 12), dtype=np.int64)
+        for a, s in enumerate([0, 1, 2, 5, 6, 7, 8, 9, 10, 11]):     # kalman_filter.py:15-24
+            self.H[a, s] = 1
+        self.P = synth.Q_DEFAULT.copy()                               # settings.py:31  P = Q
+        self.Q = synth.Q_DEFAULT.copy()
+        self.R = synth.R_DEFAULT.copy()
+        self.P_trace = float(np.trace(self.P))
+        self.K_gain = 0.0
+        self.K = np.zeros((12, 10))
+        self.m = 8.8
+        self.dt = 0.01
+        self.x_model = self.x.copy()
+        self.f = np.zeros((12, 5))
+
+    # -- helpers --
+    def _up(self, a, n):
+        return torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(n, 1)).to(self._dev)
+
+    def _sync_noise(self):
+        self._eng.set_noise(self.Q, self.R)
+
+    def rotation_matrix_body_world(self, thx, thy, thz):
+        # closed form of Rz Ry Rx (kalman_filter.py:184-193); host helper, not on the hot path
+        cx, sx, cy, sy, cz, sz = np.cos(thx), np.sin(thx), np.cos(thy), np.sin(thy), np.cos(thz), np.sin(thz)
+        return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                         [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                         [-sy, cy * sx, cy * cx]], dtype=np.float64).reshape(3, 3)
+
+    def get_odom(self, p_cur, dp_cur, contact_cur, imu):
+        e = self._eng
+        c = np.asarray(contact_cur).reshape(4)
+        packed = int(sum((int(c[k]) & 0xff) << (8 * k) for k in range(4)))
+        ct = torch.tensor([packed], dtype=torch.int32, device=self._dev)
+        z = torch.empty((10, 1), dtype=torch.float32, device=self._dev)
+        e._check(e.lib.os_kf_odom(e._h, 1, _ptr(self._up(p_cur, 12)), _ptr(self._up(dp_cur, 12)), _ptr(ct),
+                                  _ptr(self._up(np.asarray(imu).reshape(-1)[:6], 6)), _ptr(z), e._stream()), "os_kf_odom")
+        zz = z.cpu().numpy().astype(np.float64).reshape(10)
+        return np.array([zz[3], zz[7], zz[8], zz[9]]).reshape(4, 1)
+
+    def set_measurements(self, imu, odom):
+        # pure data movement (kalman_filter.py:108-117)
+        imu = np.asarray(imu, dtype=np.float64).reshape(-1, 1)
+        odom = np.asarray(odom, dtype=np.float64).reshape(4, 1)
+        self.z[0:3] = imu[0:3]
+        self.z[4:7] = imu[3:6]
+        self.z[3] = odom[0]
+        self.z[7:10] = odom[1:]
+
+    def _predict(self, p, f, body_ref=None):
+        e = self._eng
+        self._sync_noise()
+        pt, ft = self._up(p, 12), self._up(f, 12)
+        xt = self._up(self.x, 12)
+        Pt = self._up(np.asarray(self.P, dtype=np.float64).reshape(144), 144)
+        tr = torch.empty((1,), dtype=torch.float32, device=self._dev)
+        bt = None if body_ref is None else self._up(np.asarray(body_ref).reshape(-1)[:12], 12)
+        e._check(e.lib.os_kf_predict(e._h, 1, _ptr(pt), _ptr(ft), _ptr(bt), _ptr(xt), _ptr(Pt), _ptr(tr),
+                                     OS_KF_DENSE_FD if body_ref is not None else 0, e._stream()), "os_kf_predict")
+        self.x = xt.cpu().numpy().astype(np.float64).reshape(12, 1)
+        self.P = Pt.cpu().numpy().astype(np.float64).reshape(12, 12)
+        # the reference rotates the caller's p in place (misc/force_controller.py:274-277)
+        p_arr = np.asarray(p)
+        if isinstance(p, np.ndarray) and p.flags.writeable:
+            p[...] = pt.cpu().numpy().astype(p_arr.dtype).reshape(p_arr.shape)
+        self.x_model = self.x.copy()
+        self.P_trace = float(tr.item())
+
+    def predict(self, p, f):
+        """kalman_filter.py:119-138: p, f (12,1); p is rotated to the world frame in place."""
+        self._predict(p, f)
+
+    def update(self):
+        """kalman_filter.py:164-174."""
+        e = self._eng
+        self._sync_noise()
+        xt = self._up(self.x, 12)
+        Pt = self._up(np.asarray(self.P, dtype=np.float64).reshape(144), 144)
+        zt = self._up(self.z, 10)
+        Kt = torch.empty((120, 1), dtype=torch.float32, device=self._dev)
+        tr = torch.empty((1,), dtype=torch.float32, device=self._dev)
+        kg = torch.empty((1,), dtype=torch.float32, device=self._dev)
+        st = torch.zeros((1,), dtype=torch.int32, device=self._dev)
+        e._check(e.lib.os_kf_update(e._h, 1, _ptr(zt), _ptr(xt), _ptr(Pt), _ptr(Kt), _ptr(tr), _ptr(kg), _ptr(st), 0,
+                                    e._stream()), "os_kf_update")
+        status = int(st.item())
+        if status & 1:
+            # the reference's np.linalg.inv raises here (kalman_filter.py:168)
+            raise np.linalg.LinAlgError("Singular matrix")
+        self.x = xt.cpu().numpy().astype(np.float64).reshape(12, 1)
+        self.P = Pt.cpu().numpy().astype(np.float64).reshape(12, 12)
+        self.K = Kt.cpu().numpy().astype(np.float64).reshape(12, 10)
+        self.P_trace = float(tr.item())
+        self.K_gain = float(kg.item())
+
+    def predict_mpc(self, p, body_ref, cur_contact, f=None):
+        """kalman_filter.py:140-162 with the QP's forces supplied by the caller (f: (12,) or (12,N), column 0 used)."""
+        if f is None:
+            raise NotImplementedError("predict_mpc needs the ground-reaction forces f: the casadi/qpOASES convex MPC "
+                                      "(misc/force_controller.py:15-225) is outside this library's scope")
+        f = np.asarray(f, dtype=np.float64)
+        self.f = f.reshape(12, -1)
+        self._predict(p, self.f[:, 0], body_ref=body_ref)
+
+    def estimate_state_mpc(self, imu, p, dp, body_ref, contact, f=None):
+        """kalman_filter.py:176-182."""
+        odom = self.get_odom(p, dp, contact, imu)
+        self.set_measurements(imu, odom)
+        self.predict_mpc(p, body_ref, contact, f=f)
+        self.update()
+        return self.x

@@ -1,0 +1,93 @@
+"""GPU parity: HIP GRU kernels vs the reference RNN's outputs (golden) and vs the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+GRU_TOL = 1e-5   # exact-fp32 MFMA path; sigmoid outputs in (0,1)
+
+
+def load_module(name):
+    from optistate_amd import RNN
+    g = load_golden(f"gru_g5_{name}.npz")
+    I, H, L, C = [int(v) for v in g["dims"]]
+    m = RNN(I, H, L, C, torch.device("cuda"))
+    sd = {k[2:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("w:")}
+    m.load_state_dict(sd)           # the reference's keys must load unchanged
+    return m.to("cuda").eval(), g
+
+
+@pytest.mark.parametrize("name", ["small", "ref"])
+def test_g5_forward_matches_reference(name):
+    m, g = load_module(name)
+    with torch.no_grad():
+        out = m(torch.as_tensor(g["x"]).cuda())
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - g["out"]).max()
+    assert out.shape == g["out"].shape
+    assert err < GRU_TOL, err
+
+
+@pytest.mark.parametrize("name", ["small", "ref"])
+def test_h_last_matches_reference(name):
+    m, g = load_module(name)
+    x = torch.as_tensor(g["x"]).cuda()
+    with torch.no_grad():
+        m(x)
+    out, hl = m._engine.gru_forward(x, want_h_last=True)
+    assert np.abs(hl.cpu().numpy() - g["h_last"]).max() < GRU_TOL
+
+
+@pytest.mark.parametrize("dims", [(60, 64, 1, 24), (60, 64, 4, 24), (61, 32, 2, 5), (60, 128, 4, 24)])
+def test_ragged_batch_vs_oracle(dims):
+    """B not a multiple of the 128-row tile, odd input width, several layer counts; float64 oracle as truth."""
+    from optistate_amd import RNN
+    from oracle import c_oracle as orc
+    I, H, L, C = dims
+    torch.manual_seed(3)
+    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda").eval()
+    B, T = 333, 7
+    x = torch.rand(B, T, I)
+    with torch.no_grad():
+        out = m(x.cuda()).cpu().numpy()
+    w = orc.flatten_state_dict(m.state_dict(), L)
+    ref, _, _ = orc.gru_forward(x.numpy(), w, I, H, L, C)
+    err = np.abs(out - ref).max()
+    assert err < GRU_TOL, err
+
+
+def test_fused_matches_oracle_chain():
+    """os_fused_run (KF -> 60-feature row -> min-max -> GRU) vs oracle KF -> oracle feature rows -> oracle GRU."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    from oracle import c_oracle as orc
+    B, T = 200, 20
+    d = synth_numpy(B, T, seed=21)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)),
+                           Q_FITTED, R_FITTED)
+    rows = np.concatenate([ref["x"], d["accel"].astype(np.float64), d["f"].astype(np.float64), ref["p_rot"],
+                           d["dp"].astype(np.float64), d["imu"].astype(np.float64)], axis=2)      # [B][T][60]
+    mn, mx = rows.reshape(-1, 60).min(0), rows.reshape(-1, 60).max(0)
+    norm = (rows - mn) / (mx - mn)
+    torch.manual_seed(5)
+    m = RNN(60, 64, 1, 24, torch.device("cpu"))
+    w = orc.flatten_state_dict(m.state_dict(), 1)
+    ref_out, _, _ = orc.gru_forward(norm, w, 60, 64, 1, 24)
+
+    eng = Engine(0)
+    eng.set_noise(Q_FITTED, R_FITTED)
+    eng.load_gru(flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    mm = torch.as_tensor(np.stack([mn, mx]).astype(np.float32)).cuda()
+    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P)
+    torch.cuda.synchronize()
+    xo = eng.unpack(r["x_out"]).cpu().numpy()
+    assert np.abs(xo - ref["x"]).max() < 1e-4
+    err = np.abs(r["out"].cpu().numpy() - ref_out).max()
+    assert err < 1e-4, err       # feature rows carry fp32 KF noise (~1e-6) through T GRU steps
