@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- KF+GRU timesteps/s (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (Kalman predict/update + feature pack + GRU + head) over one batch of
+synthetic input: B = 65,536 trajectories x T = 100 timesteps per GPU (BASELINE.json configs[2]).  Inputs are
+resident in HBM before the timed region.  Trajectories are independent, so N GPUs run N disjoint batches with
+no data-path collective (weak scaling); the only cross-rank traffic is the barrier and the max-over-ranks of
+the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+BYTES_PER_STEP_FUSED = 244   # 196 B read + 48 B KF-state write per (trajectory, timestep)
+BYTES_PER_STEP_KF = 220
+
+
+def gru_flops_per_step(I, H, L):
+    return sum(2 * 3 * H * ((I if l == 0 else H) + H) for l in range(L))
+
+
+def cpu_baseline(H, L, target_seconds):
+    """The float64 C oracle (oracle/kf_oracle.c + gru_oracle.c: a port of the reference's algorithm) timed on one
+    host core over a bounded sample of the same workload (same distributions, T = 100)."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
+    from optistate_amd import RNN
+    T = 100
+    torch.manual_seed(0)
+    w = orc.flatten_state_dict(RNN(60, H, L, 24, torch.device("cpu")).state_dict(), L)
+
+    def run(Bs):
+        d = synth_numpy(Bs, T, seed=77)
+        t0 = time.perf_counter()
+        r = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_DEFAULT, (Bs, 1, 1)),
+                             Q_DEFAULT, R_DEFAULT)
+        rows = np.concatenate([r["x"], d["accel"].astype(np.float64), d["f"].astype(np.float64), r["p_rot"],
+                               d["dp"].astype(np.float64), d["imu"].astype(np.float64)], axis=2)
+        rows = (rows + 30.0) / 60.0
+        orc.gru_forward(rows, w, 60, H, L, 24)
+        return time.perf_counter() - t0
+
+    probe_B = 16
+    t_probe = run(probe_B)
+    Bs = max(probe_B, int(probe_B * target_seconds / max(t_probe, 1e-6)))
+    Bs = min(Bs, 4096)
+    el = run(Bs)
+    return {"value": Bs * T / el, "unit": "timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"{Bs} trajectories x {T} steps (KF float64 C oracle + GRU float64 C oracle, 1 thread, {el:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--seq", type=int, default=100)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--mode", default="fused", choices=["fused", "kf"], help="kf = BASELINE configs[1] style KF-only run")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+
+    B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60
+    eng = Engine(local_rank)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    dev = eng.device
+    d = synth_torch(B, T, dev, seed=1000 + rank)
+    contact = eng.contact_soa_to_packed(d["contact"])
+    torch.manual_seed(0)
+    model = RNN(I, H, L, 24, dev)                       # random-init weights of the named architecture
+    eng.load_gru(flatten_state_dict(model.state_dict(), L, dev), I, H, L, 24)
+    # min-max constants for the synthetic distributions (every feature lands in (0,1) like the reference's scaling)
+    minmax = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).to(dev)
+    x0, P0 = d["x0"], d["P0"]
+    x, P = x0.clone(), P0.clone()
+
+    def one_step():
+        x.copy_(x0); P.copy_(P0)                        # device-to-device reset of the 40 MB filter state
+        if a.mode == "fused":
+            return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P)
+        return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    eng.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = one_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    prof = eng.profile_read()
+    eng.profile(False)
+    bad = int((r["status"] != 0).sum().item())
+
+    if rank == 0:
+        steps_per_pass = B * T
+        total = steps_per_pass * world * a.steps
+        # dominant kernel: the one with the largest summed device time in the timed region
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_ms, dom_n) = dom
+        avg_ms = dom_ms / max(dom_n, 1)
+        if dom_name in ("gru_layer",):
+            launches_per_pass = L
+            fl = gru_flops_per_step(I, H, L) * steps_per_pass / launches_per_pass
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            roof = {"kernel": "gru_layer_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
+                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                    "avg_launch_ms": avg_ms}
+        else:
+            bps = BYTES_PER_STEP_FUSED if dom_name == "fused" else BYTES_PER_STEP_KF
+            ach = bps * steps_per_pass / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": "kf_run_kernel" if dom_name == "kf" else dom_name, "bound": "hbm", "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": avg_ms}
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                roof["traffic"] = json.load(open(tj)).get(roof["kernel"].split(" ")[0])
+            except Exception:
+                pass
+        kernels = {k: {"ms_per_launch": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items() if v[1]}
+        if "kf" in kernels:
+            kf_ms = kernels["kf"]["ms_per_launch"]
+            kernels["kf"]["algorithmic_GBps"] = BYTES_PER_STEP_KF * steps_per_pass / (kf_ms * 1e-3) / 1e9
+            kernels["kf"]["hbm_frac"] = kernels["kf"]["algorithmic_GBps"] / HBM_PEAK_GBS
+        out = {
+            "metric": "KF+GRU timesteps/sec" if a.mode == "fused" else "KF timesteps/sec",
+            "value": total / el, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"fused Kalman(12-state/10-meas)+GRU(in={I},hidden={H},layers={L},out=24) inference"
+                                   if a.mode == "fused" else "Kalman(12-state/10-meas) predict/update only",
+                       "batch_per_gpu": B, "seq_len": T, "global_batch": B * world,
+                       "parallelism": f"trajectory-sharded x{world}, no collective",
+                       "baseline_config": "BASELINE.json configs[2]" if a.mode == "fused" else "configs[1]-like"},
+            "roofline": roof,
+            "kernels": kernels,
+            "status_nonzero_trajectories": bad,
+        }
+        if a.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,14 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T,
                  const float *minmax,
                  float *x, float *P, float *x_out, float *out, int32_t *status, uint32_t flags, void *stream);
 
+/* Per-kernel device timing (HIP events recorded on the launch stream around each internal kernel), used by
+ * bench.py for the roofline of the dominant kernel.  Phases: 0 Kalman kernel, 1 GRU layer kernels, 2 GRU head,
+ * 3 fused Kalman+GRU kernel.  os_profile_read synchronises on the recorded events, adds up the elapsed
+ * milliseconds and launch counts per phase since os_profile_enable(ctx, 1), and resets them. */
+#define OS_PROF_PHASES 4
+int os_profile_enable(os_ctx *ctx, int enable);
+int os_profile_read(os_ctx *ctx, double *ms_sum /* host [OS_PROF_PHASES] */, int32_t *launches /* host [OS_PROF_PHASES] */);
+
 /* Layout helper: [B][T][F] (the reference's per-trajectory row lists) -> [T][F][B]. */
 int os_pack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src_btf, float *dst_tfb, void *stream);
 int os_unpack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src_tfb, float *dst_btf, void *stream);

@@ -13,7 +13,7 @@ OS_KF_DENSE_FD = 2
 EXPORTS = [
     "os_create", "os_destroy", "os_last_error", "os_version", "os_build_arch", "os_kf_set_noise", "os_kf_run",
     "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_param_count", "os_gru_load", "os_gru_forward",
-    "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream",
+    "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream", "os_profile_enable", "os_profile_read",
 ]
 
 
@@ -61,6 +61,10 @@ def load():
     lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]
     lib.os_pack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
     lib.os_unpack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
+    lib.os_profile_enable.argtypes = [vp, C.c_int]
+    lib.os_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.os_profile_enable.restype = C.c_int
+    lib.os_profile_read.restype = C.c_int
     for n in ("os_kf_set_noise", "os_kf_run", "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_load",
               "os_gru_forward", "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream"):
         getattr(lib, n).restype = C.c_int

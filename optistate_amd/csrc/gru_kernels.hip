@@ -283,13 +283,15 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
         a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
         const int WPC = NCH >= 4 ? 1 : 4 / NCH;
         // rows per workgroup: 128 (H = 64: RBW 2 x 2 waves/chunk; H = 128: RBW 4; H = 32: RBW 1 x 4 waves/chunk)
-        const int RBW = H == 128 ? 4 : (H == 64 ? 2 : 1);
+        const int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
         const int BM = 32 * RBW * WPC;
         const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
         dim3 grid((B + BM - 1) / BM), block(256);
+        const int slot = os_prof_begin(ctx, 1, s);
         if (RBW == 4) hipLaunchKernelGGL(gru_layer_kernel<4>, grid, block, lds, s, a);
         else if (RBW == 2) hipLaunchKernelGGL(gru_layer_kernel<2>, grid, block, lds, s, a);
         else hipLaunchKernelGGL(gru_layer_kernel<1>, grid, block, lds, s, a);
+        os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
         in = a.seq_out;
         woff += layer_packed_floats(K, H);
@@ -297,8 +299,10 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
     const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
     const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
     const size_t hlds = ((size_t)d.num_classes * H + d.num_classes) * sizeof(float);
+    const int hslot = os_prof_begin(ctx, 2, s);
     hipLaunchKernelGGL(gru_head_kernel, dim3((B + 255) / 256), dim3(256), hlds, s, B, H, d.num_classes, top, fcw,
                        fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
+    os_prof_end(ctx, hslot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }

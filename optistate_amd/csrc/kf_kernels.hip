@@ -258,12 +258,14 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool aux = a.ptrace_out || a.kgain_out, feat = a.feat_out != nullptr;
     if (feat && aux) return os_fail(ctx, -3, "os_kf_run: feature emission and P_trace/K_gain outputs are exclusive");
     hipError_t e;
+    const int slot = os_prof_begin(ctx, 0, s);
 #define OS_DISPATCH(SEQ, DENSE)                                                        \
     (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
           : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
     if (seq) e = dense ? OS_DISPATCH(true, true) : OS_DISPATCH(true, false);
     else e = dense ? OS_DISPATCH(false, true) : OS_DISPATCH(false, false);
 #undef OS_DISPATCH
+    os_prof_end(ctx, slot, s);
     OS_HIP(ctx, e);
     return 0;
 }

@@ -27,7 +27,34 @@ struct os_ctx {
     float *gru_hl;   size_t gru_hl_floats;    // SoA h_last of all layers
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;
+    // per-kernel timing (os_profile_*): ring of event pairs
+    bool prof;
+    int prof_n;                          // recorded pairs
+    hipEvent_t prof_ev[2 * 512];
+    int prof_phase[512];
+    double prof_ms[OS_PROF_PHASES];
+    int prof_cnt[OS_PROF_PHASES];
 };
+
+// RAII-less helpers: bracket a kernel launch with events when profiling is on
+static inline int os_prof_begin(os_ctx *ctx, int phase, hipStream_t s)
+{
+    if (!ctx->prof || ctx->prof_n >= 512) return -1;
+    const int i = ctx->prof_n;
+    if (!ctx->prof_ev[2 * i]) {
+        if (hipEventCreate(&ctx->prof_ev[2 * i]) != hipSuccess || hipEventCreate(&ctx->prof_ev[2 * i + 1]) != hipSuccess)
+            return -1;
+    }
+    ctx->prof_phase[i] = phase;
+    (void)hipEventRecord(ctx->prof_ev[2 * i], s);
+    return i;
+}
+static inline void os_prof_end(os_ctx *ctx, int slot, hipStream_t s)
+{
+    if (slot < 0) return;
+    (void)hipEventRecord(ctx->prof_ev[2 * slot + 1], s);
+    ctx->prof_n = slot + 1;
+}
 
 #define OS_MAGIC 0x4f53414du
 

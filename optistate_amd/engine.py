@@ -63,6 +63,17 @@ class Engine:
         t = t.to(self.device, dtype=torch.float32).contiguous()
         return t if shape is None else t.reshape(shape)
 
+    # ---- per-kernel device timing ----
+    def profile(self, enable=True):
+        self._check(self.lib.os_profile_enable(self._h, 1 if enable else 0), "os_profile_enable")
+
+    def profile_read(self):
+        """Returns {phase: (ms_sum, launches)} for phases kf, gru_layer, gru_head, fused since the last read."""
+        ms = (C.c_double * 4)()
+        n = (C.c_int32 * 4)()
+        self._check(self.lib.os_profile_read(self._h, ms, n), "os_profile_read")
+        return {k: (ms[i], n[i]) for i, k in enumerate(("kf", "gru_layer", "gru_head", "fused"))}
+
     # ---- Kalman filter ----
     def set_noise(self, Q, R):
         """KF.Q = Q; KF.R = R (data_collection/data_conversion_Kalman_to_Training.py:139-143)."""

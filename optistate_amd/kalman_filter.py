@@ -60,8 +60,9 @@ class Kalman_Filter:
         packed = int(sum((int(c[k]) & 0xff) << (8 * k) for k in range(4)))
         ct = torch.tensor([packed], dtype=torch.int32, device=self._dev)
         z = torch.empty((10, 1), dtype=torch.float32, device=self._dev)
-        e._check(e.lib.os_kf_odom(e._h, 1, _ptr(self._up(p_cur, 12)), _ptr(self._up(dp_cur, 12)), _ptr(ct),
-                                  _ptr(self._up(np.asarray(imu).reshape(-1)[:6], 6)), _ptr(z), e._stream()), "os_kf_odom")
+        # keep the device copies referenced until the launch is queued (a dead temporary's block would be reused)
+        pt, dpt, it = self._up(p_cur, 12), self._up(dp_cur, 12), self._up(np.asarray(imu).reshape(-1)[:6], 6)
+        e._check(e.lib.os_kf_odom(e._h, 1, _ptr(pt), _ptr(dpt), _ptr(ct), _ptr(it), _ptr(z), e._stream()), "os_kf_odom")
         zz = z.cpu().numpy().astype(np.float64).reshape(10)
         return np.array([zz[3], zz[7], zz[8], zz[9]]).reshape(4, 1)
 
