@@ -54,7 +54,9 @@ enum {
                                      kalman_filter/kalman_filter.py:166-172. */
     OS_KF_DENSE_FD          = 2,  /* predict_mpc covariance: F_d = element-wise exp(dt F), R from body_ref
                                      (kalman_filter/kalman_filter.py:153-158); needs body_ref. */
-    OS_KF_SYMMETRIC_P       = 4   /* reserved */
+    OS_KF_SYMMETRIC_P       = 4   /* with OS_KF_SEQUENTIAL_UPDATE (and not DENSE_FD): keep only the upper triangle of
+                                     P in registers (P is symmetric in exact arithmetic); P0's upper triangle is used
+                                     and the final P is written back mirrored.  ~2x faster; same 1e-4 parity bar. */
 };
 
 /* Replaces Kalman_Filter.__init__ (kalman_filter/kalman_filter.py:8-62): creates a context on cfg->device. */

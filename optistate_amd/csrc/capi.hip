@@ -28,6 +28,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
     for (int i = 0; i < 12; i++) c->k.Q[i * 12 + i] = qd[i];
     for (int i = 0; i < 10; i++) c->k.R[i * 10 + i] = 0.01f;
     c->r_is_diagonal = true;
+    c->q_is_diagonal = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { free(c); return -10; }
     c->cu_count = prop.multiProcessorCount;
@@ -66,6 +67,11 @@ int os_kf_set_noise(os_ctx *ctx, const float *Q_host, const float *R_host)
         for (int b = 0; b < 10; b++)
             if (a != b && R_host[a * 10 + b] != 0.0f) diag = false;
     ctx->r_is_diagonal = diag;
+    bool qd = true;
+    for (int a = 0; a < 12; a++)
+        for (int b = 0; b < 12; b++)
+            if (a != b && Q_host[a * 12 + b] != 0.0f) qd = false;
+    ctx->q_is_diagonal = qd;
     return 0;
 }
 

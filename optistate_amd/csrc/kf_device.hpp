@@ -52,18 +52,58 @@ __device__ __forceinline__ void buf_store(rsrc_t r, uint32_t voff, uint32_t soff
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
 }
 
+// Branch-free sincos for the attitude angles (Cody-Waite reduction by pi/2 + Cephes-style minimax polynomials on
+// [-pi/4, pi/4]; |error| <~ 1.5e-7 for |x| < 1e3).  ocml's sincosf carries a Payne-Hanek slow path per call that costs
+// code size and registers in a kernel that is otherwise straight-line.
+__device__ __forceinline__ void sincos_f32(float x, float *s, float *c)
+{
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, 1.57079637050628662109375f, x);
+    r = fmaf(-k, -4.37113900018624283e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // R = Rz(thz) * Ry(thy) * Rx(thx), closed form of the product at kalman_filter/kalman_filter.py:187-191
 __device__ __forceinline__ Rot rotation(float thx, float thy, float thz)
 {
     float sx, cx, sy, cy, sz, cz;
-    sincosf(thx, &sx, &cx);
-    sincosf(thy, &sy, &cy);
-    sincosf(thz, &sz, &cz);
+    sincos_f32(thx, &sx, &cx);
+    sincos_f32(thy, &sy, &cy);
+    sincos_f32(thz, &sz, &cz);
     Rot r;
     r.m[0] = cz * cy; r.m[1] = cz * sy * sx - sz * cx; r.m[2] = cz * sy * cx + sz * sx;
     r.m[3] = sz * cy; r.m[4] = sz * sy * sx + cz * cx; r.m[5] = sz * sy * cx - cz * sx;
     r.m[6] = -sy;     r.m[7] = cy * sx;                r.m[8] = cy * cx;
     return r;
+}
+
+// float64 sincos for the truncation predicate: fdlibm-style two-term reduction by pi/2 (33 + 53 bits of pi/2) and
+// the classic degree-13/14 kernels (published constants).  < 1 ulp for |x| < ~1e5, and in particular cos(e) == 1.0
+// exactly for |e| < 1.05e-8 and sin/cos(k*pi/2 as a double) land where a correctly rounded libm puts them.
+__device__ __forceinline__ void sincos_f64(double x, double *s, double *c)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double sp = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+    const double w = z * z;
+    const double rr = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                      (w * w) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+    const double hz = 0.5 * z, w1 = 1.0 - hz;
+    const double cp = w1 + (((1.0 - w1) - hz) + z * rr);
+    const long long q = (long long)k;
+    const double ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
 }
 
 // The reference's module-global `A` is int64, so A[0:3,6:9] = R^T truncates toward zero
@@ -73,9 +113,10 @@ __device__ __forceinline__ Rot rotation(float thx, float thy, float thz)
 // where the reference adds 0.  The float64 path only runs for lanes whose float32 entry is within a few ulp of 1.
 __device__ __forceinline__ void trunc_block_f64(float thx, float thy, float thz, float *A /* 9, A[i][j] = trunc(R[j][i]) */)
 {
-    double sx = sin((double)thx), cx = cos((double)thx);
-    double sy = sin((double)thy), cy = cos((double)thy);
-    double sz = sin((double)thz), cz = cos((double)thz);
+    double sx, cx, sy, cy, sz, cz;
+    sincos_f64((double)thx, &sx, &cx);
+    sincos_f64((double)thy, &sy, &cy);
+    sincos_f64((double)thz, &sz, &cz);
     // M = Ry*Rx, R = Rz*M with the zero terms dropped (adding exact zeros changes nothing)
     double m00 = cy, m01 = sy * sx, m02 = sy * cx;
     double m10 = 0.0, m11 = cx, m12 = -sx;
@@ -174,6 +215,7 @@ __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p,
 
 // P <- F_d P F_d^T + Q with F_d = I + dt F, F[0:3,6:9] = R^T, F[3:6,9:12] = I
 // (kalman_filter/kalman_filter.py:124-128,135).  ~300 FMA instead of two dense 12^3 products.
+template <bool QDIAG>
 __device__ __forceinline__ void cov_predict(float *P, const Rot &r, const KfConst &k)
 {
     float g[9];   // g[i][kk] = dt * R^T[i][kk] = dt * R[kk][i]
@@ -201,8 +243,15 @@ __device__ __forceinline__ void cov_predict(float *P, const Rot &r, const KfCons
             P[i * NS + 3 + j] += k.dt * P[i * NS + 9 + j];
         }
     }
+    if (QDIAG) {
+        // every Q the reference uses is diagonal (settings.py:28, np.diag at Kalman_to_Training.py:87): 12 scalars
+        // instead of 144 keeps the noise terms in SGPRs without spilling
 #pragma unroll
-    for (int i = 0; i < NS * NS; i++) P[i] += k.Q[i];
+        for (int i = 0; i < NS; i++) P[i * NS + i] += k.Q[i * NS + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NS * NS; i++) P[i] += k.Q[i];
+    }
 }
 
 // predict_mpc covariance (kalman_filter/kalman_filter.py:153-158): F_d = element-wise exp(dt F), i.e.
@@ -363,8 +412,97 @@ __device__ __forceinline__ int update_sequential(float *x, float *P, const float
 #pragma unroll
             for (int j = 0; j < NS; j++) P[i * NS + j] -= kc[i] * row[j];
         }
+        // keep hipcc's scheduler from interleaving successive measurement updates: they are a dependent chain,
+        // and letting them overlap only stretches live ranges past the 256 architectural VGPRs
+        __builtin_amdgcn_sched_barrier(0);
     }
     return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric-storage fast path.  P is symmetric in exact arithmetic (P0 = Q diagonal; F P F^T + Q and the scalar
+// updates P - c c^T / s preserve symmetry), so only the upper triangle is kept: 78 registers instead of 144 and
+// ~40 % fewer FMAs.  The reference never symmetrises its float64 P (kalman_filter.py:172), whose asymmetry stays
+// at rounding level (~1e-17 relative); the difference is far below the fp32 rounding of either form.
+constexpr int NU = NS * (NS + 1) / 2;   // 78
+__host__ __device__ constexpr int uidx(int i, int j) { return i * NS - i * (i - 1) / 2 + (j - i); }   // i <= j
+#define OSK_SYM(U, i, j) ((i) <= (j) ? (U)[uidx((i), (j))] : (U)[uidx((j), (i))])
+
+// P <- F_d P F_d^T + Q, F_d = I + G with G[0:3,6:9] = dt R^T, G[3:6,9:12] = dt I (kalman_filter.py:124-135):
+//   P' = P + M + M^T + M G^T,  M = G P (rows 0..5 only).
+template <bool QDIAG>
+__device__ __forceinline__ void cov_predict_sym(float *U, const Rot &r, const KfConst &k)
+{
+    float g[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * r.m[3 * kk + i];
+    float M[6 * NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const float a6 = OSK_SYM(U, 6, j), a7 = OSK_SYM(U, 7, j), a8 = OSK_SYM(U, 8, j);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            M[i * NS + j] = g[3 * i] * a6 + g[3 * i + 1] * a7 + g[3 * i + 2] * a8;
+            M[(3 + i) * NS + j] = k.dt * OSK_SYM(U, 9 + i, j);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = i; j < NS; j++) {
+            float v = U[uidx(i, j)] + M[i * NS + j];
+            if (j < 6) {
+                v += M[j * NS + i];
+                // (M G^T)[i][j] = sum_k M[i][k] G[j][k]
+                if (j < 3) v += M[i * NS + 6] * g[3 * j] + M[i * NS + 7] * g[3 * j + 1] + M[i * NS + 8] * g[3 * j + 2];
+                else v += k.dt * M[i * NS + 9 + (j - 3)];
+            }
+            U[uidx(i, j)] = v;
+        }
+    }
+    if (QDIAG) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) U[uidx(i, i)] += k.Q[i * NS + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) U[uidx(i, j)] += 0.5f * (k.Q[i * NS + j] + k.Q[j * NS + i]);
+    }
+}
+
+// Sequential scalar updates on the packed upper triangle (diagonal R).
+__device__ __forceinline__ int update_sequential_sym(float *x, float *U, const float *z, const KfConst &k)
+{
+    int status = 0;
+#pragma unroll
+    for (int a = 0; a < NM; a++) {
+        const int sa = SEL[a];
+        float s = U[uidx(sa, sa)] + k.R[a * NM + a];
+        if (!(s > 0.f) || !(s < 3.0e38f)) { status |= 1; s = 1.0f; }
+        const float inv = 1.0f / s;
+        const float innov = z[a] - x[sa];
+        float c[NS], kc[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) { c[i] = OSK_SYM(U, i, sa); kc[i] = c[i] * inv; }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            x[i] += kc[i] * innov;
+#pragma unroll
+            for (int j = i; j < NS; j++) U[uidx(i, j)] -= kc[i] * c[j];
+        }
+    }
+    return status;
+}
+
+__device__ __forceinline__ float trace_sym(const float *U)
+{
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++) t += U[uidx(i, i)];
+    return t;
 }
 
 __device__ __forceinline__ float trace12(const float *P)
@@ -386,7 +524,7 @@ __device__ __forceinline__ int finite_status(const float *x)
 // One full filter step, split in two so the caller can reuse the input registers between the halves:
 //   kf_step_front: everything that consumes the step's inputs (measurement, covariance predict, dynamics)
 //   kf_step_back : the measurement update (the long part; needs only z)
-template <bool DENSE>
+template <bool DENSE, bool QDIAG>
 __device__ __forceinline__ void kf_step_front(float *x, float *P, const StepIn &in, const float *body_ref /*3 angles*/,
                                               const KfConst &k, float *z, float *pw)
 {
@@ -396,9 +534,25 @@ __device__ __forceinline__ void kf_step_front(float *x, float *P, const StepIn &
         Rot rb = rotation(body_ref[0], body_ref[1], body_ref[2]);
         cov_predict_dense(P, rb, k);
     } else {
-        cov_predict(P, r, k);
+        cov_predict<QDIAG>(P, r, k);
     }
     dynamics(x, r, in.p, in.f, pw, k);
+}
+
+// Symmetric-storage halves (fast path: sequential update, predict(p,f) covariance).
+template <bool QDIAG>
+__device__ __forceinline__ void kf_step_front_sym(float *x, float *U, const StepIn &in, const KfConst &k, float *z,
+                                                  float *pw)
+{
+    measurement(in, z);
+    Rot r = rotation(x[0], x[1], x[2]);
+    cov_predict_sym<QDIAG>(U, r, k);
+    dynamics(x, r, in.p, in.f, pw, k);
+}
+
+__device__ __forceinline__ int kf_step_back_sym(float *x, float *U, const float *z, const KfConst &k)
+{
+    return update_sequential_sym(x, U, z, k) | finite_status(x);
 }
 
 template <bool SEQ, bool AUX>

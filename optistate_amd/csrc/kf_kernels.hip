@@ -51,7 +51,7 @@ __device__ __forceinline__ void store_feat(rsrc_t rf, const float *mm, uint32_t 
     buf_store(rf, voff, j * rowB, (v - mn) / (mx - mn));
 }
 
-template <bool SEQ, bool DENSE, bool AUX, bool FEAT>
+template <bool SEQ, bool DENSE, bool AUX, bool FEAT, bool QDIAG>
 __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
     }
     for (int t = 0; t < a.T; t++) {
         float z[NM], pw[12], ptrace = 0.f, kgain = 0.f;
-        kf_step_front<DENSE>(x, P, in, bref, a.k, z, pw);
+        kf_step_front<DENSE, QDIAG>(x, P, in, bref, a.k, z, pw);
         rsrc_t rfeat;
         if (FEAT) {
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
@@ -132,6 +132,76 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
     a.status[b] = status;
 }
 
+// Fast path: symmetric P storage (78 VGPRs), sequential update, predict(p,f) covariance.  OUT: 0 plain, 1 P_trace, 2 features.
+template <int OUT, bool QDIAG>
+__global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const size_t B = (size_t)a.B;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    float x[NS], U[NU];
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) U[uidx(i, j)] = buf_load(rP, voff, (i * NS + j) * rowB);
+    }
+    int status = 0;
+    StepIn in;
+    load_step(a, 0, voff, rowB, in);
+    for (int t = 0; t < a.T; t++) {
+        float z[NM], pw[12];
+        kf_step_front_sym<QDIAG>(x, U, in, a.k, z, pw);
+        rsrc_t rfeat;
+        if (OUT == 2) {
+            rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
+            rsrc_t ra = make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB);
+#pragma unroll
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load(ra, voff, i * rowB));
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                store_feat(rfeat, a.minmax, voff, rowB, 18 + i, in.f[i]);
+                store_feat(rfeat, a.minmax, voff, rowB, 30 + i, pw[i]);
+                store_feat(rfeat, a.minmax, voff, rowB, 42 + i, in.dp[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 54 + i, in.imu[i]);
+        }
+        if (a.p_rot_out) {
+            rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < 12; i++) buf_store(ro, voff, i * rowB, pw[i]);
+        }
+        const int tn = (t + 1 < a.T) ? t + 1 : t;
+        load_step(a, tn, voff, rowB, in);           // prefetch underneath the update
+        status |= kf_step_back_sym(x, U, z, a.k);
+        {
+            rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
+        }
+        if (OUT == 2) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, x[i]);
+        }
+        if (OUT == 1 && a.ptrace_out) a.ptrace_out[(size_t)t * B + b] = trace_sym(U);
+    }
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+    }
+    a.status[b] = status;
+}
+
 // ---- single pieces for the drop-in Kalman_Filter class (B is tiny there; latency-bound by design) ----
 
 __global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
@@ -169,7 +239,7 @@ __global__ __launch_bounds__(64, 1) void kf_predict_kernel(int B, float *p, cons
         Rot rb = rotation(body_ref[b], body_ref[(size_t)B + b], body_ref[(size_t)2 * B + b]);
         cov_predict_dense(PP, rb, k);
     } else {
-        cov_predict(PP, r, k);
+        cov_predict<false>(PP, r, k);
     }
     dynamics(xx, r, pp, ff, pw, k);
 #pragma unroll
@@ -238,11 +308,11 @@ __global__ void pack_btf_to_tfb(int B, int TF, const float *__restrict__ src, fl
 
 using namespace osk;
 
-template <bool SEQ, bool DENSE, bool AUX, bool FEAT>
+template <bool SEQ, bool DENSE, bool AUX, bool FEAT, bool QDIAG = false>
 static hipError_t launch_kf_run(const KfRunArgs &a, hipStream_t s)
 {
     dim3 grid((a.B + 63) / 64), block(64);
-    hipLaunchKernelGGL((kf_run_kernel<SEQ, DENSE, AUX, FEAT>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((kf_run_kernel<SEQ, DENSE, AUX, FEAT, QDIAG>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -262,7 +332,22 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
 #define OS_DISPATCH(SEQ, DENSE)                                                        \
     (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
           : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
-    if (seq) e = dense ? OS_DISPATCH(true, true) : OS_DISPATCH(true, false);
+    if (seq && !dense && (flags & OS_KF_SYMMETRIC_P) && !a.kgain_out) {
+        dim3 grid((a.B + 63) / 64), block(64);
+        const bool qd = ctx->q_is_diagonal;
+#define OS_SYM(OUT)                                                                                        \
+    do {                                                                                                   \
+        if (qd) hipLaunchKernelGGL((kf_run_sym_kernel<OUT, true>), grid, block, 0, s, a);                  \
+        else hipLaunchKernelGGL((kf_run_sym_kernel<OUT, false>), grid, block, 0, s, a);                    \
+    } while (0)
+        if (feat) OS_SYM(2); else if (aux) OS_SYM(1); else OS_SYM(0);
+#undef OS_SYM
+        e = hipGetLastError();
+    } else if (seq && !dense && ctx->q_is_diagonal)   // sequential update, diagonal Q and R, full P
+        e = feat ? launch_kf_run<true, false, false, true, true>(a, s)
+                 : (aux ? launch_kf_run<true, false, true, false, true>(a, s)
+                        : launch_kf_run<true, false, false, false, true>(a, s));
+    else if (seq) e = dense ? OS_DISPATCH(true, true) : OS_DISPATCH(true, false);
     else e = dense ? OS_DISPATCH(false, true) : OS_DISPATCH(false, false);
 #undef OS_DISPATCH
     os_prof_end(ctx, slot, s);

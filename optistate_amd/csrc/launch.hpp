@@ -14,7 +14,7 @@ struct os_ctx {
     uint32_t magic;
     int device;
     osk::KfConst k;
-    bool r_is_diagonal;
+    bool r_is_diagonal, q_is_diagonal;
     char err[512];
     // GRU state (owned scratch)
     os_gru_dims gru;

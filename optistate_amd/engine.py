@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE  # noqa: F401
+from ._capi import OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P  # noqa: F401
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -109,13 +109,16 @@ class Engine:
         return c_t4b.permute(0, 2, 1).contiguous().view(torch.int32).reshape(c_t4b.shape[0], c_t4b.shape[2])
 
     def kf_run(self, p, f, dp, imu, contact, x, P, body_ref=None, sequential=None, dense_fd=False,
-               want_p_rot=False, want_trace=False, want_gain=False):
+               want_p_rot=False, want_trace=False, want_gain=False, symmetric=None):
         """Runs T filter steps for B trajectories.  All stream arguments are SoA device tensors; x [12][B] and
         P [144][B] are updated in place.  Returns dict(x_out [T][12][B], status [B], p_rot?, P_trace?, K_gain?)."""
         T, _, B = p.shape
         if sequential is None:
             sequential = self._diag_R and not want_gain
-        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0)
+        if symmetric is None:
+            symmetric = sequential and not dense_fd
+        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
+                (OS_KF_SYMMETRIC_P if symmetric else 0)
         dev = self.device
         x_out = torch.empty((T, 12, B), dtype=torch.float32, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -160,12 +163,15 @@ class Engine:
 
     # ---- fused ----
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
-                  dense_fd=False):
+                  dense_fd=False, symmetric=None):
         """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B])."""
         T, _, B = p.shape
         if sequential is None:
             sequential = self._diag_R
-        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0)
+        if symmetric is None:
+            symmetric = sequential and not dense_fd
+        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
+                (OS_KF_SYMMETRIC_P if symmetric else 0)
         d = self._gru_dims
         nl = 0 if latent is None else latent.shape[1]
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)

@@ -34,11 +34,11 @@ def run(eng, g, Q, R, B, **kw):
 
 
 @pytest.mark.parametrize("s", [0, 1])
-@pytest.mark.parametrize("sequential", [False, True])
-def test_g3_trajectory_matches_reference(eng, s, sequential):
+@pytest.mark.parametrize("sequential,symmetric", [(False, False), (True, False), (True, True)])
+def test_g3_trajectory_matches_reference(eng, s, sequential, symmetric):
     g = load_golden("kf_g3_traj.npz")
-    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], 2, sequential=sequential, want_p_rot=True, want_trace=True,
-            want_gain=not sequential)
+    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], 2, sequential=sequential, symmetric=symmetric, want_p_rot=True,
+            want_trace=True, want_gain=not sequential)
     xo = eng.unpack(r["x_out"]).cpu().numpy()
     pr = eng.unpack(r["p_rot"]).cpu().numpy()
     for b in range(2):
@@ -56,11 +56,11 @@ def test_g3_trajectory_matches_reference(eng, s, sequential):
 
 
 @pytest.mark.parametrize("s", [0, 1])
-@pytest.mark.parametrize("sequential", [False, True])
-def test_g4_batch_matches_reference(eng, s, sequential):
+@pytest.mark.parametrize("sequential,symmetric", [(False, False), (True, False), (True, True)])
+def test_g4_batch_matches_reference(eng, s, sequential, symmetric):
     g = load_golden("kf_g4_batch.npz")
     B = g["p"].shape[0]
-    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], B, sequential=sequential)
+    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], B, sequential=sequential, symmetric=symmetric)
     xo = eng.unpack(r["x_out"]).cpu().numpy()
     err = np.abs(xo - g[f"s{s}_x"]).max()
     assert err < STATE_TOL, err
@@ -100,11 +100,13 @@ def test_large_batch_vs_oracle(eng):
     ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)),
                            Q_FITTED, R_FITTED, aux=False)
     g = dict(d)
-    for seq in (True, False):
-        r = run(eng, g, Q_FITTED, R_FITTED, B, sequential=seq)
+    for seq, sym in ((True, True), (True, False), (False, False)):
+        r = run(eng, g, Q_FITTED, R_FITTED, B, sequential=seq, symmetric=sym)
         xo = eng.unpack(r["x_out"]).cpu().numpy()
         err = np.abs(xo - ref["x"]).max()
-        assert err < STATE_TOL, (seq, err)
+        assert err < STATE_TOL, (seq, sym, err)
+        Pf = r["P_final"].cpu().numpy().T.reshape(B, 12, 12)
+        assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
         assert int(r["status"].abs().sum()) == 0
 
 
