@@ -54,9 +54,12 @@ enum {
                                      kalman_filter/kalman_filter.py:166-172. */
     OS_KF_DENSE_FD          = 2,  /* predict_mpc covariance: F_d = element-wise exp(dt F), R from body_ref
                                      (kalman_filter/kalman_filter.py:153-158); needs body_ref. */
-    OS_KF_SYMMETRIC_P       = 4   /* with OS_KF_SEQUENTIAL_UPDATE (and not DENSE_FD): keep only the upper triangle of
+    OS_KF_SYMMETRIC_P       = 4,  /* with OS_KF_SEQUENTIAL_UPDATE (and not DENSE_FD): keep only the upper triangle of
                                      P in registers (P is symmetric in exact arithmetic); P0's upper triangle is used
                                      and the final P is written back mirrored.  ~2x faster; same 1e-4 parity bar. */
+    OS_FUSED_TWO_KERNEL     = 8   /* os_fused_run only: force the general two-kernel path (Kalman kernel writes the
+                                     normalised feature rows to context scratch, GRU kernels read them) even where
+                                     the single-kernel path applies (60 features, hidden 64, sequential+symmetric). */
 };
 
 /* Replaces Kalman_Filter.__init__ (kalman_filter/kalman_filter.py:8-62): creates a context on cfg->device. */
@@ -116,7 +119,7 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
 /* Same with the input already in the library's stream layout xs [T][I][B]; h_last_soa (optional) [L][H][B]. */
 int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_soa, void *stream);
 
-/* Fused path: KF loop + 60-feature row [x_post | accel | f | p_world | dp | imu]
+/* Fused path (single kernel where it applies, see OS_FUSED_TWO_KERNEL): KF loop + 60-feature row [x_post | accel | f | p_world | dp | imu]
  * (data_collection/data_conversion_Kalman_to_Training.py:245-254) + min-max normalisation
  * (gru/gru_test.py:99-101; minmax = device float[2][60]: mins then maxs) + optional latent [T][NL][B] appended
  * (gru/gru_test.py:135-136) + GRU over the T-step sequence + head, without writing feature rows to HBM.

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liboptistate_hip.so")
 OS_KF_SEQUENTIAL_UPDATE = 1
 OS_KF_DENSE_FD = 2
 OS_KF_SYMMETRIC_P = 4
+OS_FUSED_TWO_KERNEL = 8
 
 # every symbol include/optistate_hip.h declares
 EXPORTS = [

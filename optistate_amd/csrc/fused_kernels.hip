@@ -1,0 +1,317 @@
+// fused_kernels.hip -- Kalman filter + feature pack + min-max normalise + GRU layer 0 (+ head) in ONE kernel for
+// the headline configuration (60 features -> GRU hidden 64).  Nothing but the input streams, the 48-byte state
+// history and the final 24 outputs touches HBM: feature rows never leave registers.
+//
+// Wave-autonomous design (one CU = one 256-thread workgroup = 4 waves, no inter-wave synchronisation in the T loop):
+//   * each wave owns 64 trajectories; lane = trajectory for the Kalman part (x: 12, upper triangle of P: 78 VGPRs);
+//   * the 60 normalised features of step t sit in the owning lane's registers; one v_permlane32_swap per feature
+//     pair turns them into the two 32-row MFMA A-fragments (lanes 0-31: feature k, lanes 32-63: feature k+1) -- no LDS;
+//   * the wave then runs its own rows through the GRU cell: gates[64 x 192] = [x_t | h] [W_ih | W_hh]^T on
+//     v_mfma_f32_32x32x2_f32, B-fragments from the LDS-resident fragment-ordered weights (95 KB, loaded once per
+//     workgroup), recurrent A-fragments from the wave-private h tile in LDS ([64][65] floats);
+//   * the two 32-column chunks are processed one after the other (128 accumulator registers at a time); chunk 0's
+//     new h is parked in 32 VGPRs until chunk 1's MFMAs no longer need the old h.
+// LDS: 2 x 12,032 floats weights+bias (96,256 B) + 4 x 64 x 65 floats h (66,560 B) = 162,816 B of the 163,840 B per CU.
+#include "launch.hpp"
+
+#include "gru_common.hpp"
+#include "kf_args.hpp"
+
+namespace osf {
+
+using namespace osk;
+
+constexpr int H = 64, KX = 60, KPX = KX / 2, KPH = H / 2, HS = H + 1;
+constexpr int CHF = (KPX + KPH) * 3 * 64 + 128;   // floats per 32-column chunk in the packed layout (incl. biases)
+constexpr int WAVES = 4;
+constexpr size_t LDS_BYTES = (size_t)(2 * CHF + WAVES * 64 * HS) * sizeof(float);
+
+struct FusedArgs {
+    KfRunArgs kf;              // streams, x/P in-out, x_out, status, accel, minmax
+    const float *wpacked;      // layer-0 weights in fragment order (2 chunks x CHF floats)
+    const float *fcw, *fcb;    // head (used when seq_out == nullptr)
+    int C, use_sigmoid;
+    float *out;                // [B][C]
+    float *seq_out;            // [T][64][B] layer-0 output sequence for deeper stacks, or nullptr
+};
+
+__device__ __forceinline__ float norm_feat(const float *mm, int j, float v)
+{
+    const float mn = mm[j], mx = mm[60 + j];
+    return (v - mn) / (mx - mn);
+}
+
+template <bool QDIAG>
+__global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    float *W = lds;
+    float *hl = lds + 2 * CHF + wave * 64 * HS;
+    const KfRunArgs &k = a.kf;
+    const size_t B = (size_t)k.B;
+
+    // ---- one-time staging: weights -> LDS (coalesced float4), h0 = 0 ----
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.wpacked);
+        float4 *dst = reinterpret_cast<float4 *>(W);
+        for (int i = threadIdx.x; i < 2 * CHF / 4; i += 256) dst[i] = src[i];
+        for (int i = lane; i < 64 * HS; i += 64) hl[i] = 0.f;
+    }
+    __syncthreads();
+
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool live = b < k.B;
+    const int bb = live ? b : k.B - 1;                 // dead lanes shadow the last trajectory, stores masked
+    const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
+
+    float x[NS], U[NU];
+    {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) U[uidx(i, j)] = buf_load(rP, voff, (i * NS + j) * rowB);
+    }
+    // biases of both chunks for this lane's column
+    float bias[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) bias[c][g] = W[c * CHF + (KPX + KPH) * 192 + g * 32 + li];
+
+    int status = 0;
+    StepIn in;
+    float acl[6];
+    load_step(k, 0, voff, rowB, in);
+    {
+        rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acl[i] = buf_load(ra, voff, i * rowB);
+    }
+
+    for (int t = 0; t < k.T; t++) {
+        // ================= Kalman step (lane = trajectory) =================
+        float z[NM], pw[12], F[KX];
+        kf_step_front_sym<QDIAG>(x, U, in, k.k, z, pw);
+#pragma unroll
+        for (int i = 0; i < 6; i++) F[12 + i] = norm_feat(k.minmax, 12 + i, acl[i]);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            F[18 + i] = norm_feat(k.minmax, 18 + i, in.f[i]);
+            F[30 + i] = norm_feat(k.minmax, 30 + i, pw[i]);
+            F[42 + i] = norm_feat(k.minmax, 42 + i, in.dp[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) F[54 + i] = norm_feat(k.minmax, 54 + i, in.imu[i]);
+        status |= kf_step_back_sym(x, U, z, k.k);
+        if (live) {
+            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) F[i] = norm_feat(k.minmax, i, x[i]);
+
+        // ================= GRU cell on this wave's 64 rows =================
+        // feature registers -> A fragments: after the swap, F[2kp] holds rows 0-31 (k = 2kp | 2kp+1 by lane half),
+        // F[2kp+1] holds rows 32-63
+#pragma unroll
+        for (int kp = 0; kp < KPX; kp++) {
+            // v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second.  Written as inline
+            // asm because hipcc (ROCm 7.2) drops the second result of __builtin_amdgcn_permlane32_swap in this kernel
+            // (the rows 32-63 MFMAs were folded onto rows 0-31); s_nop 1 covers the VALU->permlane->VALU wait states.
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(F[2 * kp]), "+v"(F[2 * kp + 1]));
+        }
+        float hnew0[2][16];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float *Wc = W + c * CHF;
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
+            // Explicit two-deep software pipeline over the 62 k-pairs (30 input + 32 recurrent): the B fragments (and the
+            // recurrent A fragments) of k-pair q+1 are requested from LDS before the six MFMAs of k-pair q issue, and a
+            // sched_barrier per k-pair keeps hipcc from hoisting all 372 LDS reads to the top (which spills).
+            float wb[2][3], ab[2][2];
+#pragma unroll
+            for (int g = 0; g < 3; g++) wb[0][g] = Wc[g * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < KPX + KPH; q++) {
+                const int cur = q & 1, nxt = cur ^ 1;
+                if (q + 1 < KPX + KPH) {
+#pragma unroll
+                    for (int g = 0; g < 3; g++) wb[nxt][g] = Wc[((q + 1) * 3 + g) * 64 + lane];
+                    if (q + 1 >= KPX) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++) ab[nxt][rb] = hl[(rb * 32 + li) * HS + 2 * (q + 1 - KPX) + lh];
+                    }
+                }
+                if (c == 1 && q == KPX) {
+                    // the feature registers are dead from here on: issue step t+1's 49 input loads into the space they
+                    // free, underneath the remaining ~200 MFMAs and the cell update (one wave per SIMD: nobody else
+                    // hides the HBM latency)
+                    const int tn = (t + 1 < k.T) ? t + 1 : t;
+                    load_step(k, tn, voff, rowB, in);
+                    rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) acl[i] = buf_load(ra, voff, i * rowB);
+                }
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    const float av = q < KPX ? F[2 * (q < KPX ? q : 0) + rb] : ab[cur][rb];
+                    const int gn = q < KPX ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[cur][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[cur][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][gn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[cur][2], acc[rb][gn], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // cell update on the accumulator layout: col = li (hidden unit c*32+li), row = (e&3) + 8*(e>>2) + 4*lh
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float hold = hl[row * HS + c * 32 + li];
+                    const float r = osg::sigmoidf_(acc[rb][0][e] + bias[c][0]);
+                    const float zg = osg::sigmoidf_(acc[rb][1][e] + bias[c][1]);
+                    const float n = osg::tanhf_(acc[rb][2][e] + bias[c][2] + r * (acc[rb][3][e] + bias[c][3]));
+                    const float hn = (1.0f - zg) * n + zg * hold;
+                    if (c == 0) hnew0[rb][e] = hn;            // old h[:, 0:32] is still needed by chunk 1
+                    else hl[row * HS + 32 + li] = hn;
+                }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                hl[row * HS + li] = hnew0[rb][e];
+            }
+        // LDS operations of one wave complete in order: the next step's reads see these writes without a barrier.
+        if (a.seq_out && live) {
+            rsrc_t rs = make_rsrc(a.seq_out + (size_t)t * H * B, (uint32_t)H * rowB);
+#pragma unroll 8
+            for (int kk = 0; kk < H; kk++) buf_store(rs, voff, kk * rowB, hl[lane * HS + kk]);
+        }
+    }
+
+    // ---- final state, status, head ----
+    if (live) {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+        k.status[b] = status;
+        if (!a.seq_out) {
+            // fc + sigmoid on h_T (gru/gru_model.py:43-48), lane = trajectory
+            float hrow[H];
+#pragma unroll
+            for (int kk = 0; kk < H; kk++) hrow[kk] = hl[lane * HS + kk];
+            for (int c = 0; c < a.C; c++) {
+                float s = a.fcb[c];
+#pragma unroll
+                for (int kk = 0; kk < H; kk++) s += a.fcw[c * H + kk] * hrow[kk];
+                a.out[(size_t)b * a.C + c] = a.use_sigmoid ? osg::sigmoidf_(s) : s;
+            }
+        }
+    }
+}
+
+}  // namespace osf
+
+int os_kf_run_impl(os_ctx *ctx, osk::KfRunArgs &a, uint32_t flags, hipStream_t s);   // kf_kernels.hip
+int os_gru_scratch(os_ctx *ctx, int B, int T, float **seq0, float **seq1, float **hlast);   // gru_kernels.hip
+int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_layer, float *out, float *h_last_all,
+                       hipStream_t s);
+
+extern "C" {
+
+int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f, const float *dp, const float *imu,
+                 const uint32_t *contact, const float *accel, const float *body_ref, const float *latent,
+                 int32_t n_latent, const float *minmax, float *x, float *P, float *x_out, float *out, int32_t *status,
+                 uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0) return os_fail(ctx, -2, "os_fused_run: B and T must be positive");
+    if (!p || !f || !dp || !imu || !contact || !accel || !minmax || !x || !P || !x_out || !out || !status)
+        return os_fail(ctx, -2, "os_fused_run: null required pointer");
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_fused_run: call os_gru_load first");
+    if (n_latent < 0 || (n_latent > 0 && !latent)) return os_fail(ctx, -2, "os_fused_run: bad latent");
+    const int I = 60 + n_latent;
+    if (ctx->gru.input_size != I) return os_fail(ctx, -4, "os_fused_run: GRU input_size must be 60 + n_latent");
+    if ((size_t)B * 144 * 4 >= 0xffffffffull) return os_fail(ctx, -2, "os_fused_run: B too large for 32-bit buffer offsets");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const os_gru_dims &d = ctx->gru;
+    osk::KfRunArgs a;
+    a.B = B; a.T = T; a.p = p; a.f = f; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = body_ref;
+    a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = nullptr; a.ptrace_out = nullptr; a.kgain_out = nullptr;
+    a.status = status; a.accel = accel; a.minmax = minmax; a.feat_out = nullptr; a.feat_I = I;
+
+    const bool single_kernel = (flags & OS_KF_SEQUENTIAL_UPDATE) && (flags & OS_KF_SYMMETRIC_P) &&
+                               !(flags & OS_KF_DENSE_FD) && !(flags & OS_FUSED_TWO_KERNEL) && ctx->r_is_diagonal &&
+                               n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
+    if (single_kernel) {
+        // the single-kernel path: features stay in registers
+        osf::FusedArgs fa;
+        fa.kf = a; fa.kf.k = ctx->k;
+        fa.wpacked = ctx->gru_packed;
+        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
+        fa.fcw = fcw; fa.fcb = fcw + (size_t)d.num_classes * 64;
+        fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out; fa.seq_out = nullptr;
+        float *seq0 = nullptr, *seq1 = nullptr, *hlast = nullptr;
+        if (d.num_layers > 1) {
+            if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
+            fa.seq_out = seq0;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel<true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
+            attr_set = true;
+        }
+        dim3 grid((B + 255) / 256), block(256);
+        const int slot = os_prof_begin(ctx, 3, s);
+        if (ctx->q_is_diagonal) hipLaunchKernelGGL(osf::fused_kf_gru_kernel<true>, grid, block, osf::LDS_BYTES, s, fa);
+        else hipLaunchKernelGGL(osf::fused_kf_gru_kernel<false>, grid, block, osf::LDS_BYTES, s, fa);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+        if (d.num_layers > 1) return os_gru_layers_impl(ctx, B, T, seq0, 1, out, nullptr, s);
+        return 0;
+    }
+
+    // general path: Kalman kernel emits normalised feature rows [T][I][B] into context scratch, GRU kernels consume them
+    const size_t need = (size_t)T * I * B;
+    if (ctx->feat_floats < need) {
+        if (ctx->feat) OS_HIP(ctx, hipFree(ctx->feat));
+        ctx->feat = nullptr; ctx->feat_floats = 0;
+        OS_HIP(ctx, hipMalloc((void **)&ctx->feat, need * sizeof(float)));
+        ctx->feat_floats = need;
+    }
+    a.feat_out = ctx->feat;
+    int rc = os_kf_run_impl(ctx, a, flags & ~OS_FUSED_TWO_KERNEL, s);
+    if (rc) return rc;
+    if (n_latent > 0) {
+        // rows [60, 60+NL) of every step: latent [T][NL][B] -> feat [T][I][B] (gru/gru_test.py:135-136)
+        OS_HIP(ctx, hipMemcpy2DAsync(ctx->feat + (size_t)60 * B, (size_t)I * B * sizeof(float), latent,
+                                     (size_t)n_latent * B * sizeof(float), (size_t)n_latent * B * sizeof(float), T,
+                                     hipMemcpyDeviceToDevice, s));
+    }
+    return os_gru_layers_impl(ctx, B, T, ctx->feat, 0, out, nullptr, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// gru_common.hpp -- types and helpers shared by the GRU layer kernels and the fused Kalman+GRU kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace osg {
+
+struct LayerArgs {
+    int B, T, K, H;            // K = input width of this layer
+    int KPx, KPh;              // k-pairs of the x part (ceil(K/2)) and of the h part (H/2)
+    const float *xs;           // [T][K][B]
+    const float *w;            // packed weights of this layer (see pack kernel)
+    float *seq_out;            // [T][H][B] or null
+    float *h_last;             // [H][B] or null
+};
+
+__host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }
+
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// absolute error < 2e-7 on outputs in (0,1) / (-1,1), far inside the 1e-5 parity bar of the GRU head.
+__device__ __forceinline__ float sigmoidf_(float v)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
+}
+__device__ __forceinline__ float tanhf_(float v)
+{
+    // tanh(v) = 1 - 2 / (1 + e^{2v}); e^{2v} -> inf gives 1, -> 0 gives -1
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
+}
+
+}  // namespace osg

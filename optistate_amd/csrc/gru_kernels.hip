@@ -17,32 +17,9 @@
 
 #include <math.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "gru_common.hpp"
 
 namespace osg {
-
-struct LayerArgs {
-    int B, T, K, H;            // K = input width of this layer
-    int KPx, KPh;              // k-pairs of the x part (ceil(K/2)) and of the h part (H/2)
-    const float *xs;           // [T][K][B]
-    const float *w;            // packed weights of this layer (see pack kernel)
-    float *seq_out;            // [T][H][B] or null
-    float *h_last;             // [H][B] or null
-};
-
-__host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }
-
-// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
-// absolute error < 2e-7 on outputs in (0,1) / (-1,1), far inside the 1e-5 parity bar of the GRU head.
-__device__ __forceinline__ float sigmoidf_(float v)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
-}
-__device__ __forceinline__ float tanhf_(float v)
-{
-    // tanh(v) = 1 - 2 / (1 + e^{2v}); e^{2v} -> inf gives 1, -> 0 gives -1
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
-}
 
 // RBW = row blocks (of 32 trajectories) per wave.  NCH = H/32 column chunks; with NCH < 4 several waves share a chunk
 // and split the rows.  BM = 32 * RBW * max(1, 4/NCH).
@@ -266,25 +243,33 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
     return 0;
 }
 
-// Runs the layer stack on an SoA input sequence xs [T][I][B] (device).  Internal entry shared with the fused path.
-int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_all, void *stream)
+}  // extern "C"
+
+// Scratch for the layer stack: two ping-pong sequence buffers [T][H][B] (only for L > 1) and one h_last [H][B].
+int os_gru_scratch(os_ctx *ctx, int B, int T, float **seq0, float **seq1, float **hlast)
 {
-    OS_CHECK_CTX(ctx);
-    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
-    if (B <= 0 || T <= 0 || !xs || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
-    OS_HIP(ctx, hipSetDevice(ctx->device));
+    const os_gru_dims &d = ctx->gru;
+    const size_t seqf = (size_t)T * d.hidden_size * B, hf = (size_t)d.hidden_size * B;
+    const size_t need = (d.num_layers > 1 ? 2 * seqf : 0) + hf;
+    if (ensure_scratch(ctx, &ctx->gru_seq, &ctx->gru_seq_floats, need)) return -10;
+    *seq0 = ctx->gru_seq; *seq1 = ctx->gru_seq + seqf;
+    *hlast = ctx->gru_seq + (d.num_layers > 1 ? 2 * seqf : 0);
+    return 0;
+}
+
+// Runs layers first_layer..L-1 and the head.  `in` is the SoA input of layer first_layer ([T][K][B]); for
+// first_layer > 0 it must be the ping-pong buffer seq[(first_layer-1)&1] returned by os_gru_scratch.
+int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_layer, float *out, float *h_last_all,
+                       hipStream_t s)
+{
     const os_gru_dims &d = ctx->gru;
     const int H = d.hidden_size, L = d.num_layers, NCH = H / 32;
-    hipStream_t s = (hipStream_t)stream;
-    // scratch: two ping-pong sequence buffers [T][H][B] (only for L > 1) and one h_last [H][B]
-    const size_t seqf = (size_t)T * H * B, hf = (size_t)H * B;
-    const size_t need = (L > 1 ? 2 * seqf : 0) + hf;
-    if (ensure_scratch(ctx, &ctx->gru_seq, &ctx->gru_seq_floats, need)) return -10;
-    float *seqbuf[2] = {ctx->gru_seq, ctx->gru_seq + seqf};
-    float *hlast = ctx->gru_seq + (L > 1 ? 2 * seqf : 0);
+    float *seqbuf[2], *hlast;
+    if (os_gru_scratch(ctx, B, T, &seqbuf[0], &seqbuf[1], &hlast)) return -10;
+    const size_t hf = (size_t)H * B;
     size_t woff = 0;
-    const float *in = xs;
-    for (int l = 0; l < L; l++) {
+    for (int l = 0; l < first_layer; l++) woff += layer_packed_floats(l == 0 ? d.input_size : H, H);
+    for (int l = first_layer; l < L; l++) {
         const int K = l == 0 ? d.input_size : H;
         LayerArgs a;
         a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
@@ -292,7 +277,7 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
         a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
         a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
         const int WPC = NCH >= 4 ? 1 : 4 / NCH;
-        // rows per workgroup: 128 (H = 64: RBW 2 x 2 waves/chunk; H = 128: RBW 4; H = 32: RBW 1 x 4 waves/chunk)
+        // rows per workgroup: H = 64: RBW 2 x 2 waves/chunk = 128; H = 128: RBW 2 = 64; H = 32: RBW 1 x 4 waves/chunk = 128
         const int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
         const int BM = 32 * RBW * WPC;
         const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
@@ -315,6 +300,18 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
     os_prof_end(ctx, hslot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
+}
+
+extern "C" {
+
+// Runs the layer stack on an SoA input sequence xs [T][I][B] (device).
+int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_all, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
+    if (B <= 0 || T <= 0 || !xs || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    return os_gru_layers_impl(ctx, B, T, xs, 0, out, h_last_all, (hipStream_t)stream);
 }
 
 int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *h_last, void *stream)

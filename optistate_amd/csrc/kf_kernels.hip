@@ -1,45 +1,10 @@
 // kf_kernels.hip -- batched Kalman filter kernels for gfx950: one trajectory per lane, the whole T-step
 // recurrence inside one launch, x/P resident in VGPRs, inputs streamed coalesced from [T][field][B].
 #include "kf_device.hpp"
+#include "kf_args.hpp"
 #include "launch.hpp"
 
 namespace osk {
-
-struct KfRunArgs {
-    int B, T;
-    const float *p, *f, *dp, *imu;
-    const uint32_t *contact;
-    const float *body_ref;
-    float *x, *P;
-    float *x_out, *p_rot_out, *ptrace_out, *kgain_out;
-    int32_t *status;
-    // optional feature-row emission (fused path v0): normalised rows [T][feat_I][B]
-    const float *accel;      // [T][6][B]
-    const float *minmax;     // [2][60]: mins, maxs
-    float *feat_out;
-    int feat_I;
-    KfConst k;
-};
-
-// Loads one step's 43 input dwords for this lane.  rowB = B*4 (bytes per row), voff = b*4.
-__device__ __forceinline__ void load_step(const KfRunArgs &a, int t, uint32_t voff, uint32_t rowB, StepIn &in)
-{
-    const size_t B = (size_t)a.B;
-    rsrc_t rp = make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB);
-    rsrc_t rf = make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB);
-    rsrc_t rd = make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB);
-    rsrc_t ri = make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB);
-    rsrc_t rc = make_rsrc(a.contact + (size_t)t * B, rowB);
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        in.p[i] = buf_load(rp, voff, i * rowB);
-        in.f[i] = buf_load(rf, voff, i * rowB);
-        in.dp[i] = buf_load(rd, voff, i * rowB);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) in.imu[i] = buf_load(ri, voff, i * rowB);
-    in.contact = buf_load_u32(rc, voff, 0);
-}
 
 // 64-lane workgroups: lanes are independent, so small groups give the dispatcher the most freedom to
 // spread waves over the 1024 SIMDs.  State: 156 VGPRs (x, P) + 43 input dwords + update temporaries.
@@ -371,43 +336,6 @@ int os_kf_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f,
     a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = p_rot_out; a.ptrace_out = ptrace_out; a.kgain_out = kgain_out;
     a.status = status; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
     return os_kf_run_impl(ctx, a, flags, (hipStream_t)stream);
-}
-
-int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f, const float *dp, const float *imu,
-                 const uint32_t *contact, const float *accel, const float *body_ref, const float *latent,
-                 int32_t n_latent, const float *minmax, float *x, float *P, float *x_out, float *out, int32_t *status,
-                 uint32_t flags, void *stream)
-{
-    OS_CHECK_CTX(ctx);
-    if (B <= 0 || T <= 0) return os_fail(ctx, -2, "os_fused_run: B and T must be positive");
-    if (!p || !f || !dp || !imu || !contact || !accel || !minmax || !x || !P || !x_out || !out || !status)
-        return os_fail(ctx, -2, "os_fused_run: null required pointer");
-    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_fused_run: call os_gru_load first");
-    if (n_latent < 0 || (n_latent > 0 && !latent)) return os_fail(ctx, -2, "os_fused_run: bad latent");
-    const int I = 60 + n_latent;
-    if (ctx->gru.input_size != I) return os_fail(ctx, -4, "os_fused_run: GRU input_size must be 60 + n_latent");
-    OS_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t need = (size_t)T * I * B;
-    if (ctx->feat_floats < need) {
-        if (ctx->feat) OS_HIP(ctx, hipFree(ctx->feat));
-        ctx->feat = nullptr; ctx->feat_floats = 0;
-        OS_HIP(ctx, hipMalloc((void **)&ctx->feat, need * sizeof(float)));
-        ctx->feat_floats = need;
-    }
-    KfRunArgs a;
-    a.B = B; a.T = T; a.p = p; a.f = f; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = body_ref;
-    a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = nullptr; a.ptrace_out = nullptr; a.kgain_out = nullptr;
-    a.status = status; a.accel = accel; a.minmax = minmax; a.feat_out = ctx->feat; a.feat_I = I;
-    int rc = os_kf_run_impl(ctx, a, flags, s);
-    if (rc) return rc;
-    if (n_latent > 0) {
-        // rows [60, 60+NL) of every step: latent [T][NL][B] -> feat [T][I][B] (gru/gru_test.py:135-136)
-        OS_HIP(ctx, hipMemcpy2DAsync(ctx->feat + (size_t)60 * B, (size_t)I * B * sizeof(float), latent,
-                                     (size_t)n_latent * B * sizeof(float), (size_t)n_latent * B * sizeof(float), T,
-                                     hipMemcpyDeviceToDevice, s));
-    }
-    return os_gru_forward_soa(ctx, B, T, ctx->feat, out, nullptr, stream);
 }
 
 int os_kf_odom(os_ctx *ctx, int32_t B, const float *p, const float *dp, const uint32_t *contact, const float *imu,

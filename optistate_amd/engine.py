@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P  # noqa: F401
+from ._capi import OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL  # noqa: F401
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -163,7 +163,7 @@ class Engine:
 
     # ---- fused ----
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
-                  dense_fd=False, symmetric=None):
+                  dense_fd=False, symmetric=None, two_kernel=False):
         """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B])."""
         T, _, B = p.shape
         if sequential is None:
@@ -171,7 +171,7 @@ class Engine:
         if symmetric is None:
             symmetric = sequential and not dense_fd
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
-                (OS_KF_SYMMETRIC_P if symmetric else 0)
+                (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_FUSED_TWO_KERNEL if two_kernel else 0)
         d = self._gru_dims
         nl = 0 if latent is None else latent.shape[1]
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)

@@ -59,12 +59,14 @@ def test_ragged_batch_vs_oracle(dims):
     assert err < GRU_TOL, err
 
 
-def test_fused_matches_oracle_chain():
-    """os_fused_run (KF -> 60-feature row -> min-max -> GRU) vs oracle KF -> oracle feature rows -> oracle GRU."""
+@pytest.mark.parametrize("two_kernel,L,B,T", [(False, 1, 200, 20), (True, 1, 200, 20), (False, 4, 333, 12),
+                                                (False, 1, 1000, 100)])
+def test_fused_matches_oracle_chain(two_kernel, L, B, T):
+    """os_fused_run (KF -> 60-feature row -> min-max -> GRU) vs oracle KF -> oracle feature rows -> oracle GRU;
+    single-kernel path (features stay in registers), forced two-kernel path, a 4-layer stack, full T = 100."""
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
     from oracle import c_oracle as orc
-    B, T = 200, 20
     d = synth_numpy(B, T, seed=21)
     ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)),
                            Q_FITTED, R_FITTED)
@@ -73,21 +75,25 @@ def test_fused_matches_oracle_chain():
     mn, mx = rows.reshape(-1, 60).min(0), rows.reshape(-1, 60).max(0)
     norm = (rows - mn) / (mx - mn)
     torch.manual_seed(5)
-    m = RNN(60, 64, 1, 24, torch.device("cpu"))
-    w = orc.flatten_state_dict(m.state_dict(), 1)
-    ref_out, _, _ = orc.gru_forward(norm, w, 60, 64, 1, 24)
+    m = RNN(60, 64, L, 24, torch.device("cpu"))
+    w = orc.flatten_state_dict(m.state_dict(), L)
+    ref_out, _, _ = orc.gru_forward(norm, w, 60, 64, L, 24)
 
     eng = Engine(0)
     eng.set_noise(Q_FITTED, R_FITTED)
-    eng.load_gru(flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    eng.load_gru(flatten_state_dict(m.state_dict(), L), 60, 64, L, 24)
     s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
     c = eng.pack_contact(torch.as_tensor(d["contact"]))
     x = torch.as_tensor(d["x0"].T.copy()).cuda()
     P = torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144, 1), (1, B))).cuda()
     mm = torch.as_tensor(np.stack([mn, mx]).astype(np.float32)).cuda()
-    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P)
+    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P, two_kernel=two_kernel)
     torch.cuda.synchronize()
     xo = eng.unpack(r["x_out"]).cpu().numpy()
+    assert int(r["status"].abs().sum()) == 0
     assert np.abs(xo - ref["x"]).max() < 1e-4
+    Pf = P.cpu().numpy().T.reshape(B, 12, 12)
+    assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
+    assert np.abs(x.cpu().numpy().T - ref["x_final"]).max() < 1e-4
     err = np.abs(r["out"].cpu().numpy() - ref_out).max()
     assert err < 1e-4, err       # feature rows carry fp32 KF noise (~1e-6) through T GRU steps

@@ -1,16 +1,20 @@
-import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys; sys.path.insert(0,'.')
 import numpy as np, torch
-from optistate_amd import Kalman_Filter
-g=np.load('tests/golden/kf_g3_traj.npz')
-kf=Kalman_Filter()
-kf.x[:]=g["x0"][0].reshape(12,1); kf.Q=g["Q1"].copy(); kf.R=g["R1"].copy(); kf.P=g["Q1"].copy()
-for t in range(2):
-    p=g["p"][0,t].astype(np.float64).reshape(12,1)
-    od=kf.get_odom(p,g["dp"][0,t].reshape(12,1),g["contact"][0,t].reshape(4,1),g["imu"][0,t].reshape(6,1))
-    kf.set_measurements(g["imu"][0,t].reshape(6,1),od)
-    print('z err',np.abs(kf.z.ravel()-g["s1_b0_z"][t]).max())
-    kf.predict(p,g["f"][0,t].reshape(12,1))
-    print('prior err',np.abs(kf.x_model.ravel()-g["s1_b0_x_prior"][t]).max(), 'P', kf.P_trace)
-    kf.update()
-    print('post err',np.abs(kf.x.ravel()-g["s1_b0_x"][t]), 'ptrace', kf.P_trace, g["s1_b0_P_trace"][t], 'kg', kf.K_gain, g["s1_b0_K_gain"][t])
-    if t in (0,1): print('K err', np.abs(kf.K-g[f"s1_b0_K{t}"]).max()); print(np.round(kf.K-g[f"s1_b0_K{t}"],4))
+from optistate_amd import Engine, RNN, flatten_state_dict
+from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+eng=Engine(0); eng.set_noise(Q_FITTED,R_FITTED)
+torch.manual_seed(5); m=RNN(60,64,1,24,torch.device("cpu"))
+eng.load_gru(flatten_state_dict(m.state_dict(),1),60,64,1,24)
+B,T=64,1
+d=synth_numpy(B,T,seed=21)
+s={k:eng.pack(torch.as_tensor(d[k])) for k in ("p","f","dp","imu","accel")}
+c=eng.pack_contact(torch.as_tensor(d["contact"]))
+mm=torch.stack([torch.full((60,),-3.0),torch.full((60,),3.0)]).cuda()
+outs=[]
+for tk in (False,True):
+    x=torch.as_tensor(d["x0"].T.copy()).cuda(); P=torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144,1),(1,B))).cuda()
+    r=eng.fused_run(s["p"],s["f"],s["dp"],s["imu"],c,s["accel"],mm,x,P,two_kernel=tk); torch.cuda.synchronize()
+    outs.append(r["out"].cpu().numpy())
+o=outs[0]; ref=outs[1]
+for rrow in range(28,64,3):
+    dist=np.abs(ref-o[rrow]).max(1); print(rrow,'best match ref row',dist.argmin(), dist.min(), 'own', dist[rrow])

@@ -49,8 +49,9 @@ print(f"gru_forward_soa H={a.H} L={a.L}: {ms:.3f} ms  {steps / ms * 1e3:.3e} ste
 mm = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).cuda()
 
 
-def fused():
-    x = d["x0"].clone(); P = d["P0"].clone()
-    eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], c, d["accel"], mm, x, P)
-ms = timeit(fused)
-print(f"fused_run: {ms:.3f} ms  {steps / ms * 1e3:.3e} steps/s")
+for tk in (False, True):
+    def fused():
+        x = d["x0"].clone(); P = d["P0"].clone()
+        eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], c, d["accel"], mm, x, P, two_kernel=tk)
+    ms = timeit(fused)
+    print(f"fused_run two_kernel={tk}: {ms:.3f} ms  {steps / ms * 1e3:.3e} steps/s")
