@@ -45,7 +45,7 @@ void os_destroy(os_ctx *ctx)
 {
     if (!ctx || ctx->magic != OS_MAGIC) return;
     (void)hipSetDevice(ctx->device);
-    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat};
+    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)

@@ -29,16 +29,24 @@ constexpr size_t LDS_BYTES = (size_t)(2 * CHF + WAVES * 64 * HS) * sizeof(float)
 struct FusedArgs {
     KfRunArgs kf;              // streams, x/P in-out, x_out, status, accel, minmax
     const float *wpacked;      // layer-0 weights in fragment order (2 chunks x CHF floats)
+    const float *nrm;          // [120]: mins, then 1/(max-min) (norm_prep_kernel)
     const float *fcw, *fcb;    // head (used when seq_out == nullptr)
     int C, use_sigmoid;
     float *out;                // [B][C]
     float *seq_out;            // [T][64][B] layer-0 output sequence for deeper stacks, or nullptr
 };
 
-__device__ __forceinline__ float norm_feat(const float *mm, int j, float v)
+// (v - min) * (1 / (max - min)); norm_prep_kernel forms [min | 1/(max-min)] once per call (IEEE division), the fused
+// kernel reads them with scalar loads (uniform address), so each feature costs one v_sub and one v_mul
+__device__ __forceinline__ float norm_feat(const float *__restrict__ nrm, int j, float v) { return (v - nrm[j]) * nrm[60 + j]; }
+
+__global__ void norm_prep_kernel(const float *minmax, float *nrm)
 {
-    const float mn = mm[j], mx = mm[60 + j];
-    return (v - mn) / (mx - mn);
+    const int j = threadIdx.x;
+    if (j < 60) {
+        nrm[j] = minmax[j];
+        nrm[60 + j] = 1.0f / (minmax[60 + j] - minmax[j]);
+    }
 }
 
 template <bool QDIAG>
@@ -60,6 +68,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
         for (int i = lane; i < 64 * HS; i += 64) hl[i] = 0.f;
     }
     __syncthreads();
+    const float *__restrict__ nrm = a.nrm;
 
     const int b = blockIdx.x * 256 + threadIdx.x;
     const bool live = b < k.B;
@@ -98,15 +107,15 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
         float z[NM], pw[12], F[KX];
         kf_step_front_sym<QDIAG>(x, U, in, k.k, z, pw);
 #pragma unroll
-        for (int i = 0; i < 6; i++) F[12 + i] = norm_feat(k.minmax, 12 + i, acl[i]);
+        for (int i = 0; i < 6; i++) F[12 + i] = norm_feat(nrm, 12 + i, acl[i]);
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            F[18 + i] = norm_feat(k.minmax, 18 + i, in.f[i]);
-            F[30 + i] = norm_feat(k.minmax, 30 + i, pw[i]);
-            F[42 + i] = norm_feat(k.minmax, 42 + i, in.dp[i]);
+            F[18 + i] = norm_feat(nrm, 18 + i, in.f[i]);
+            F[30 + i] = norm_feat(nrm, 30 + i, pw[i]);
+            F[42 + i] = norm_feat(nrm, 42 + i, in.dp[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) F[54 + i] = norm_feat(k.minmax, 54 + i, in.imu[i]);
+        for (int i = 0; i < 6; i++) F[54 + i] = norm_feat(nrm, 54 + i, in.imu[i]);
         status |= kf_step_back_sym(x, U, z, k.k);
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
             for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
         }
 #pragma unroll
-        for (int i = 0; i < NS; i++) F[i] = norm_feat(k.minmax, i, x[i]);
+        for (int i = 0; i < NS; i++) F[i] = norm_feat(nrm, i, x[i]);
 
         // ================= GRU cell on this wave's 64 rows =================
         // feature registers -> A fragments: after the swap, F[2kp] holds rows 0-31 (k = 2kp | 2kp+1 by lane half),
@@ -284,6 +293,9 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
             attr_set = true;
         }
+        if (!ctx->nrm) OS_HIP(ctx, hipMalloc((void **)&ctx->nrm, 120 * sizeof(float)));
+        hipLaunchKernelGGL(osf::norm_prep_kernel, dim3(1), dim3(64), 0, s, minmax, ctx->nrm);
+        fa.nrm = ctx->nrm;
         dim3 grid((B + 255) / 256), block(256);
         const int slot = os_prof_begin(ctx, 3, s);
         if (ctx->q_is_diagonal) hipLaunchKernelGGL(osf::fused_kf_gru_kernel<true>, grid, block, osf::LDS_BYTES, s, fa);

@@ -482,7 +482,8 @@ __device__ __forceinline__ int update_sequential_sym(float *x, float *U, const f
         const int sa = SEL[a];
         float s = U[uidx(sa, sa)] + k.R[a * NM + a];
         if (!(s > 0.f) || !(s < 3.0e38f)) { status |= 1; s = 1.0f; }
-        const float inv = 1.0f / s;
+        float inv = __builtin_amdgcn_rcpf(s);
+        inv = inv * (2.0f - s * inv);          // one Newton step: <= 1 ulp, 3 instructions instead of the ~10 of a division
         const float innov = z[a] - x[sa];
         float c[NS], kc[NS];
 #pragma unroll

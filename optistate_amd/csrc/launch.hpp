@@ -25,6 +25,7 @@ struct os_ctx {
     float *gru_seq;  size_t gru_seq_floats;   // inter-layer sequences [T][H][B] x2 + h_last
     float *gru_xs;   size_t gru_xs_floats;    // SoA copy of a (B,T,I) input
     float *gru_hl;   size_t gru_hl_floats;    // SoA h_last of all layers
+    float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;
     // per-kernel timing (os_profile_*): ring of event pairs
