@@ -130,6 +130,23 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T,
                  const float *minmax,
                  float *x, float *P, float *x_out, float *out, int32_t *status, uint32_t flags, void *stream);
 
+/* ---- Training step of the GRU head (gru/gru_train.py:232-249) ----
+ * os_gru_forward_train: RNN.forward (gru/gru_train.py:236) keeping the per-step activations in context scratch.
+ * os_gru_loss          : the target construction + nn.MSELoss of gru/gru_train.py:237-245:
+ *                        target = [y | |out[:, :C/2] - y|] with `out` detached; loss (device scalar) = mean squared error
+ *                        over B*C entries; dout [B][C] = d(loss)/d(out); target [B][C] optional.  y [B][C/2].
+ * os_gru_backward      : loss.backward() (gru/gru_train.py:248): all parameter gradients into grad_flat (flat layout of
+ *                        os_gru_param_count; this is the single bucket a data-parallel step all-reduces), optional
+ *                        d(loss)/d(x) in dx [B][T][I].  Weight-gradient GEMMs (T*B-long reductions) use rocBLAS.
+ * os_adam_step         : torch.optim.Adam's update (gru/gru_train.py:219,249) fused over flat vectors; step counts from 1. */
+int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, void *stream);
+int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float *target, float *dout, float *loss,
+                void *stream);
+int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const float *out, const float *dout,
+                    float *grad_flat, float *dx, void *stream);
+int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                 float eps, int32_t step, void *stream);
+
 /* Per-kernel device timing (HIP events recorded on the launch stream around each internal kernel), used by
  * bench.py for the roofline of the dominant kernel.  Phases: 0 Kalman kernel, 1 GRU layer kernels, 2 GRU head,
  * 3 fused Kalman+GRU kernel.  os_profile_read synchronises on the recorded events, adds up the elapsed

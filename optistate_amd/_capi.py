@@ -16,6 +16,7 @@ EXPORTS = [
     "os_create", "os_destroy", "os_last_error", "os_version", "os_build_arch", "os_kf_set_noise", "os_kf_run",
     "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_param_count", "os_gru_load", "os_gru_forward",
     "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream", "os_profile_enable", "os_profile_read",
+    "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
 ]
 
 
@@ -63,6 +64,12 @@ def load():
     lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]
     lib.os_pack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
     lib.os_unpack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
+    lib.os_gru_forward_train.argtypes = [vp, i32, i32, f32p, f32p, vp]
+    lib.os_gru_loss.argtypes = [vp, i32, f32p, f32p, f32p, f32p, f32p, vp]
+    lib.os_gru_backward.argtypes = [vp, i32, i32, f32p, f32p, f32p, f32p, f32p, vp]
+    lib.os_adam_step.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]
+    for n in ("os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step"):
+        getattr(lib, n).restype = C.c_int
     lib.os_profile_enable.argtypes = [vp, C.c_int]
     lib.os_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.os_profile_enable.restype = C.c_int

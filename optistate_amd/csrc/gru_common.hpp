@@ -14,6 +14,8 @@ struct LayerArgs {
     const float *w;            // packed weights of this layer (see pack kernel)
     float *seq_out;            // [T][H][B] or null
     float *h_last;             // [H][B] or null
+    // training only (null for inference): per-step activations saved row-major [T][B][H] for the backward sweep
+    float *sv_r, *sv_z, *sv_n, *sv_g, *sv_h;   // r, z, n, gh_n (= W_hn h + b_hn), h_t
 };
 
 __host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }

@@ -106,8 +106,17 @@ __global__ __launch_bounds__(256, (RBW <= 2 ? 2 : 1)) void gru_layer_kernel(cons
                 float *hp = &hl[row * HS + chunk * 32 + li];
                 const float r = sigmoidf_(acc[rb][0][e] + b_r);
                 const float z = sigmoidf_(acc[rb][1][e] + b_z);
-                const float n = tanhf_(acc[rb][2][e] + b_in + r * (acc[rb][3][e] + b_hn));
-                *hp = (1.0f - z) * n + z * (*hp);
+                const float ghn = acc[rb][3][e] + b_hn;
+                const float n = tanhf_(acc[rb][2][e] + b_in + r * ghn);
+                const float hn = (1.0f - z) * n + z * (*hp);
+                *hp = hn;
+                if (a.sv_r) {
+                    const int g = tile_row0 + row;
+                    if (g < a.B) {
+                        const size_t o = ((size_t)t * B + g) * H + chunk * 32 + li;   // lanes 0-31: 128 contiguous bytes
+                        a.sv_r[o] = r; a.sv_z[o] = z; a.sv_n[o] = n; a.sv_g[o] = ghn; a.sv_h[o] = hn;
+                    }
+                }
             }
         }
         __syncthreads();   // h_t complete
@@ -188,12 +197,12 @@ __global__ void gru_head_kernel(int B, int H, int C, const float *h_last, const 
 
 using namespace osg;
 
-static size_t layer_packed_floats(int K, int H)
+size_t os_layer_packed_floats(int K, int H)
 {
     return (size_t)(H / 32) * chunk_floats((K + 1) / 2, H / 2);
 }
 
-static int ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats)
+int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats)
 {
     if (*cap >= need_floats) return 0;
     if (*buf) OS_HIP(ctx, hipFree(*buf));
@@ -225,8 +234,8 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
         return os_fail(ctx, -4, "os_gru_load: unsupported dimensions");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     size_t total = 0;
-    for (int l = 0; l < d->num_layers; l++) total += layer_packed_floats(l == 0 ? d->input_size : H, H);
-    if (ensure_scratch(ctx, &ctx->gru_packed, &ctx->gru_packed_floats, total)) return -10;
+    for (int l = 0; l < d->num_layers; l++) total += os_layer_packed_floats(l == 0 ? d->input_size : H, H);
+    if (os_ensure_scratch(ctx, &ctx->gru_packed, &ctx->gru_packed_floats, total)) return -10;
     size_t src = 0, dst = 0;
     for (int l = 0; l < d->num_layers; l++) {
         const int K = l == 0 ? d->input_size : H;
@@ -235,7 +244,7 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
                            Wih, Whh, bih, bhh, ctx->gru_packed + dst);
         OS_HIP(ctx, hipGetLastError());
         src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;
-        dst += layer_packed_floats(K, H);
+        dst += os_layer_packed_floats(K, H);
     }
     ctx->gru = *d;
     ctx->gru_flat = w_flat;
@@ -245,13 +254,45 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
 
 }  // extern "C"
 
+// fc + sigmoid head on an SoA hidden state top [H][B]; fcw points at fc.weight followed by fc.bias.
+int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s)
+{
+    const os_gru_dims &d = ctx->gru;
+    const int H = d.hidden_size;
+    const size_t hlds = ((size_t)d.num_classes * H + d.num_classes) * sizeof(float);
+    const int hslot = os_prof_begin(ctx, 2, s);
+    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 255) / 256), dim3(256), hlds, s, B, H, d.num_classes, top, fcw,
+                       fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
+    os_prof_end(ctx, hslot, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// Launches gru_layer_kernel for one layer (shared by inference and the training forward).
+int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
+{
+    const int H = a.H, NCH = H / 32;
+    const int WPC = NCH >= 4 ? 1 : 4 / NCH;
+    // rows per workgroup: H = 64: RBW 2 x 2 waves/chunk = 128; H = 128: RBW 2 = 64; H = 32: RBW 1 x 4 waves/chunk = 128
+    const int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
+    const int BM = 32 * RBW * WPC;
+    const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
+    dim3 grid((a.B + BM - 1) / BM), block(256);
+    const int slot = os_prof_begin(ctx, 1, s);
+    if (RBW == 2) hipLaunchKernelGGL(gru_layer_kernel<2>, grid, block, lds, s, a);
+    else hipLaunchKernelGGL(gru_layer_kernel<1>, grid, block, lds, s, a);
+    os_prof_end(ctx, slot, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // Scratch for the layer stack: two ping-pong sequence buffers [T][H][B] (only for L > 1) and one h_last [H][B].
 int os_gru_scratch(os_ctx *ctx, int B, int T, float **seq0, float **seq1, float **hlast)
 {
     const os_gru_dims &d = ctx->gru;
     const size_t seqf = (size_t)T * d.hidden_size * B, hf = (size_t)d.hidden_size * B;
     const size_t need = (d.num_layers > 1 ? 2 * seqf : 0) + hf;
-    if (ensure_scratch(ctx, &ctx->gru_seq, &ctx->gru_seq_floats, need)) return -10;
+    if (os_ensure_scratch(ctx, &ctx->gru_seq, &ctx->gru_seq_floats, need)) return -10;
     *seq0 = ctx->gru_seq; *seq1 = ctx->gru_seq + seqf;
     *hlast = ctx->gru_seq + (d.num_layers > 1 ? 2 * seqf : 0);
     return 0;
@@ -268,7 +309,7 @@ int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_lay
     if (os_gru_scratch(ctx, B, T, &seqbuf[0], &seqbuf[1], &hlast)) return -10;
     const size_t hf = (size_t)H * B;
     size_t woff = 0;
-    for (int l = 0; l < first_layer; l++) woff += layer_packed_floats(l == 0 ? d.input_size : H, H);
+    for (int l = 0; l < first_layer; l++) woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
     for (int l = first_layer; l < L; l++) {
         const int K = l == 0 ? d.input_size : H;
         LayerArgs a;
@@ -276,30 +317,14 @@ int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_lay
         a.xs = in; a.w = ctx->gru_packed + woff;
         a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
         a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
-        const int WPC = NCH >= 4 ? 1 : 4 / NCH;
-        // rows per workgroup: H = 64: RBW 2 x 2 waves/chunk = 128; H = 128: RBW 2 = 64; H = 32: RBW 1 x 4 waves/chunk = 128
-        const int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
-        const int BM = 32 * RBW * WPC;
-        const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
-        dim3 grid((B + BM - 1) / BM), block(256);
-        const int slot = os_prof_begin(ctx, 1, s);
-        if (RBW == 4) hipLaunchKernelGGL(gru_layer_kernel<4>, grid, block, lds, s, a);
-        else if (RBW == 2) hipLaunchKernelGGL(gru_layer_kernel<2>, grid, block, lds, s, a);
-        else hipLaunchKernelGGL(gru_layer_kernel<1>, grid, block, lds, s, a);
-        os_prof_end(ctx, slot, s);
-        OS_HIP(ctx, hipGetLastError());
+        a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
+        if (os_gru_launch_layer(ctx, a, s)) return -10;
         in = a.seq_out;
-        woff += layer_packed_floats(K, H);
+        woff += os_layer_packed_floats(K, H);
     }
     const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
     const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
-    const size_t hlds = ((size_t)d.num_classes * H + d.num_classes) * sizeof(float);
-    const int hslot = os_prof_begin(ctx, 2, s);
-    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 255) / 256), dim3(256), hlds, s, B, H, d.num_classes, top, fcw,
-                       fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
-    os_prof_end(ctx, hslot, s);
-    OS_HIP(ctx, hipGetLastError());
-    return 0;
+    return os_gru_head_launch(ctx, B, top, fcw, out, s);
 }
 
 extern "C" {
@@ -322,14 +347,14 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
     OS_HIP(ctx, hipSetDevice(ctx->device));
     // (B, T, I) batch_first as the reference passes it -> SoA [T][I][B] in context scratch
     const int I = ctx->gru.input_size;
-    if (ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;
+    if (os_ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;
     int rc = os_pack_stream(ctx, B, T, I, x, ctx->gru_xs, stream);
     if (rc) return rc;
     // h_last is requested in torch layout [L][B][H]; produce SoA [L][H][B] then transpose
     float *hl_soa = nullptr;
     const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
     if (h_last) {
-        if (ensure_scratch(ctx, &ctx->gru_hl, &ctx->gru_hl_floats, (size_t)L * H * B)) return -10;
+        if (os_ensure_scratch(ctx, &ctx->gru_hl, &ctx->gru_hl_floats, (size_t)L * H * B)) return -10;
         hl_soa = ctx->gru_hl;
     }
     rc = os_gru_forward_soa(ctx, B, T, ctx->gru_xs, out, hl_soa, stream);

@@ -1,0 +1,453 @@
+// gru_train_kernels.hip -- training step of the GRU head (reference gru/gru_train.py:232-249) on gfx950.
+//
+//   forward  : the inference layer kernels with the per-step activations (r, z, n, gh_n, h_t) saved row-major
+//   loss     : target = [y | |out[:, :C/2].detach() - y|], MSE over all B*C entries (gru_train.py:237-245), d(loss)/d(out)
+//   head bwd : d(pre) = dout * out(1-out); d(fc.weight), d(fc.bias), d(h_T)
+//   sweep    : per layer, reverse in time: gate derivatives on the VALU, then
+//                dx_t      = [da_r | da_z | da_n    ] . W_ih      (fp32 MFMA, reduction over the 3H gate units)
+//                dh_{t-1} += [da_r | da_z | da_n * r] . W_hh
+//              with dh carried in LDS, gate derivatives staged in LDS as MFMA A-fragments and written out once
+//              ([T][B][3H]) for the weight gradients
+//   weights  : dW_ih = sum_t dGI_t^T X_t, dW_hh = sum_t dGH_t^T H_{t-1}: plain dense GEMMs with a T*B-long reduction ->
+//              rocBLAS sgemm (the one place a vendor GEMM is used); biases by a column-sum kernel.
+// All gradients land in one flat fp32 vector in the flat parameter layout (include/optistate_hip.h), which is the
+// single bucket the data-parallel step all-reduces over RCCL.
+#include "launch.hpp"
+
+#include <rocblas/rocblas.h>
+
+#include "gru_common.hpp"
+
+namespace ost {
+
+using osg::sigmoidf_;
+
+// ---- loss + d(out) -------------------------------------------------------------------------------------------
+// out [B][C], y [B][C/2]; target [B][C] (optional), dout [B][C]; loss_acc: one float, pre-zeroed.
+__global__ void loss_kernel(int B, int C, const float *out, const float *y, float *target, float *dout, float *loss_acc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = C / 2;
+    float sq = 0.f;
+    if (i < B * C) {
+        const int b = i / C, c = i % C;
+        const float o = out[i];
+        const float tgt = c < half ? y[b * half + c] : fabsf(out[b * C + (c - half)] - y[b * half + (c - half)]);
+        const float d = o - tgt;
+        sq = d * d;
+        if (target) target[i] = tgt;
+        dout[i] = 2.0f * d / (float)(B * C);       // the target is detached (gru_train.py:239): no gradient through |.|
+    }
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, sq / (float)(B * C));
+}
+
+// ---- head backward -------------------------------------------------------------------------------------------
+// dpre = dout * out * (1 - out) (sigmoid) or dout; dh_T [B][H] = dpre . fcw; dfcw [C][H] += dpre^T h_T; dfcb += sum dpre.
+// One workgroup per 64 rows; partial dfcw/dfcb accumulated with float atomics (C*H is tiny).
+__global__ void head_backward_kernel(int B, int H, int C, int use_sigmoid, const float *out, const float *dout,
+                                     const float *hT /*[B][H]*/, const float *fcw, float *dhT /*[B][H]*/, float *dfcw,
+                                     float *dfcb)
+{
+    extern __shared__ float sm[];          // dpre [64][C] , h [64][H+1]
+    float *dp = sm, *hs = sm + 64 * C;
+    const int row0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) {
+        const int r = i / C, c = i % C, g = row0 + r;
+        float v = 0.f;
+        if (g < B) {
+            const float o = out[(size_t)g * C + c];
+            v = dout[(size_t)g * C + c] * (use_sigmoid ? o * (1.0f - o) : 1.0f);
+        }
+        dp[i] = v;
+    }
+    for (int i = threadIdx.x; i < 64 * H; i += blockDim.x) {
+        const int r = i / H, k = i % H, g = row0 + r;
+        hs[r * (H + 1) + k] = g < B ? hT[(size_t)g * H + k] : 0.f;
+    }
+    __syncthreads();
+    // dh_T
+    for (int i = threadIdx.x; i < 64 * H; i += blockDim.x) {
+        const int r = i / H, k = i % H, g = row0 + r;
+        if (g >= B) continue;
+        float s = 0.f;
+        for (int c = 0; c < C; c++) s += dp[r * C + c] * fcw[c * H + k];
+        dhT[(size_t)g * H + k] = s;
+    }
+    // dfcw, dfcb partials
+    for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
+        const int c = i / H, k = i % H;
+        float s = 0.f;
+        for (int r = 0; r < 64; r++) s += dp[r * C + c] * hs[r * (H + 1) + k];
+        atomicAdd(&dfcw[i], s);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < 64; r++) s += dp[r * C + c];
+        atomicAdd(&dfcb[c], s);
+    }
+}
+
+// ---- transposed weight packing for the backward MFMAs --------------------------------------------------------
+// W [3H][K] row-major -> for each 32-wide output chunk c (columns of W) and each gate-unit pair q: 64 floats,
+// lane l -> W[2q + (l>>5)][c*32 + (l&31)] (0 beyond K).
+__global__ void pack_T_kernel(int K, int H3, const float *W, float *dst)
+{
+    const int chunk = blockIdx.x;
+    const int n = (H3 / 2) * 64;
+    float *d = dst + (size_t)chunk * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int lane = i & 63, q = i >> 6;
+        const int j = 2 * q + (lane >> 5), col = chunk * 32 + (lane & 31);
+        d[i] = col < K ? W[(size_t)j * K + col] : 0.f;
+    }
+}
+
+struct SweepArgs {
+    int B, T, K, H;
+    int need_dx;                 // write dx (layer > 0 or caller wants d(input))
+    const float *sv_r, *sv_z, *sv_n, *sv_g, *sv_h;   // [T][B][H]
+    const float *dy;             // [T][B][H] gradient w.r.t. this layer's outputs, or null
+    const float *dy_last;        // [B][H] gradient w.r.t. h_T only (top layer), or null
+    const float *wihT, *whhT;    // transposed-packed weights
+    float *dgi, *dgh;            // [T][B][3H]
+    float *dx;                   // [T][B][K]
+};
+
+// RB = 32-row blocks per workgroup (BM = 32*RB).  LDS: dh [BM][H+1] | dG [BM][4H+1] (sections da_r, da_z, da_n, da_n*r).
+template <int RB>
+__global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = a.H, K = a.K, HS = H + 1, GS = 4 * H + 1, BM = 32 * RB;
+    float *dh = sm, *dG = sm + BM * HS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int row0 = blockIdx.x * BM;
+    const size_t B = (size_t)a.B;
+    for (int i = threadIdx.x; i < BM * HS; i += 256) dh[i] = 0.f;
+    __syncthreads();
+    const int nchx = a.need_dx ? (K + 31) / 32 : 0, nchh = H / 32;
+    const int Q = 3 * H / 2;                   // gate-unit pairs in the reduction
+
+    for (int t = a.T - 1; t >= 0; t--) {
+        // ---- gate derivatives (VALU), coalesced over the hidden index ----
+        for (int i = threadIdx.x; i < BM * H; i += 256) {
+            const int r = i / H, c = i % H, g = row0 + r;
+            float dar = 0.f, daz = 0.f, dan = 0.f, danr = 0.f, dhc = 0.f;
+            if (g < a.B) {
+                const size_t o = ((size_t)t * B + g) * H + c;
+                const float rr = a.sv_r[o], zz = a.sv_z[o], nn = a.sv_n[o], gg = a.sv_g[o];
+                const float hp = t > 0 ? a.sv_h[o - B * H] : 0.f;
+                float dht = dh[r * HS + c];
+                if (a.dy) dht += a.dy[o];
+                if (a.dy_last && t == a.T - 1) dht += a.dy_last[(size_t)g * H + c];
+                const float dn = dht * (1.0f - zz);
+                const float dz = dht * (hp - nn);
+                dhc = dht * zz;
+                dan = dn * (1.0f - nn * nn);
+                danr = dan * rr;
+                dar = dan * gg * rr * (1.0f - rr);
+                daz = dz * zz * (1.0f - zz);
+                const size_t og = ((size_t)t * B + g) * (3 * H) + c;
+                a.dgi[og] = dar; a.dgi[og + H] = daz; a.dgi[og + 2 * H] = dan;
+                a.dgh[og] = dar; a.dgh[og + H] = daz; a.dgh[og + 2 * H] = danr;
+            }
+            dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
+            dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
+        }
+        __syncthreads();
+        // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
+        for (int ch = wave; ch < nchx + nchh; ch += 4) {
+            const bool is_h = ch >= nchx;
+            const int oc = is_h ? ch - nchx : ch;
+            const float *wp = (is_h ? a.whhT : a.wihT) + (size_t)oc * Q * 64;
+            f32x16 acc[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[rb][e] = 0.f;
+#pragma unroll 4
+            for (int q = 0; q < Q; q++) {
+                const int j = 2 * q + lh;                                   // gate unit in [0, 3H)
+                const int col = (is_h && j >= 2 * H) ? j + H : j;           // n-part of the recurrent path is scaled by r
+                const float w = wp[q * 64 + lane];
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) {
+                    const float av = dG[(rb * 32 + li) * GS + col];
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w, acc[rb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, c = oc * 32 + li, g = row0 + r;
+                    if (is_h) dh[r * HS + c] += acc[rb][e];
+                    else if (g < a.B && c < K) a.dx[((size_t)t * B + g) * K + c] = acc[rb][e];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// column sums of a [R][N] row-major matrix into dst[N] (bias gradients)
+__global__ void colsum_kernel(size_t R, int N, const float *src, float *dst)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const size_t r0 = (size_t)blockIdx.y * 4096, r1 = r0 + 4096 < R ? r0 + 4096 : R;
+    float s = 0.f;
+    for (size_t r = r0; r < r1; r++) s += src[r * N + n];
+    atomicAdd(&dst[n], s);
+}
+
+// [T][B][F] -> [B][T][F]
+__global__ void permute_tb_kernel(int B, int T, int F, const float *src, float *dst)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)B * T * F;
+    if (i >= n) return;
+    const int f = i % F;
+    const size_t bt = i / F;
+    const int t = bt % T, b = bt / T;
+    dst[i] = src[((size_t)t * B + b) * F + f];
+}
+
+// fused Adam (torch.optim.Adam defaults, gru_train.py:219): one pass over the flat parameter / gradient vectors
+__global__ void adam_kernel(size_t n, float *w, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    w[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace ost
+
+using namespace ost;
+
+struct os_train_state {
+    rocblas_handle blas;
+    float *act;   size_t act_floats;     // saved activations: L x 5 x [T][B][H]
+    float *seq;   size_t seq_floats;     // SoA layer outputs [L][T][H][B] (forward inputs of the next layer)
+    float *xs;    size_t xs_floats;      // SoA copy of the input [T][I][B]
+    float *dg;    size_t dg_floats;      // dGI, dGH [T][B][3H] x 2
+    float *dxy;   size_t dxy_floats;     // dx ping-pong [T][B][max(K,H)] x 2 + dh_T [B][H]
+    float *wT;    size_t wT_floats;      // transposed-packed weights
+    int B, T;
+};
+
+static os_train_state *train_state(os_ctx *ctx)
+{
+    if (!ctx->train) {
+        os_train_state *t = (os_train_state *)calloc(1, sizeof(os_train_state));
+        if (!t) return nullptr;
+        if (rocblas_create_handle(&t->blas) != rocblas_status_success) { free(t); return nullptr; }
+        ctx->train = t;
+    }
+    return (os_train_state *)ctx->train;
+}
+
+void os_train_destroy(os_ctx *ctx)
+{
+    os_train_state *t = (os_train_state *)ctx->train;
+    if (!t) return;
+    float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->wT};
+    for (float *b : bufs)
+        if (b) (void)hipFree(b);
+    rocblas_destroy_handle(t->blas);
+    free(t);
+    ctx->train = nullptr;
+}
+
+extern "C" {
+
+int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward_train: call os_gru_load first");
+    if (B <= 0 || T <= 0 || !x || !out) return os_fail(ctx, -2, "os_gru_forward_train: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    os_train_state *ts = train_state(ctx);
+    if (!ts) return os_fail(ctx, -13, "os_gru_forward_train: cannot create training state");
+    hipStream_t s = (hipStream_t)stream;
+    const os_gru_dims &d = ctx->gru;
+    const int H = d.hidden_size, L = d.num_layers, I = d.input_size;
+    const size_t tbh = (size_t)T * B * H;
+    if (os_ensure_scratch(ctx, &ts->act, &ts->act_floats, (size_t)L * 5 * tbh)) return -10;
+    if (os_ensure_scratch(ctx, &ts->seq, &ts->seq_floats, (size_t)L * tbh)) return -10;
+    if (os_ensure_scratch(ctx, &ts->xs, &ts->xs_floats, (size_t)T * I * B)) return -10;
+    ts->B = B; ts->T = T;
+    int rc = os_pack_stream(ctx, B, T, I, x, ts->xs, stream);
+    if (rc) return rc;
+    size_t woff = 0;
+    const float *in = ts->xs;
+    for (int l = 0; l < L; l++) {
+        const int K = l == 0 ? I : H;
+        osg::LayerArgs a;
+        a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
+        a.xs = in; a.w = ctx->gru_packed + woff;
+        a.seq_out = ts->seq + (size_t)l * tbh;
+        a.h_last = nullptr;
+        float *base = ts->act + (size_t)l * 5 * tbh;
+        a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
+        if (os_gru_launch_layer(ctx, a, s)) return -10;
+        in = a.seq_out;
+        woff += os_layer_packed_floats(K, H);
+    }
+    // head on h_T of the top layer: the SoA sequence's last step is [H][B]
+    const float *top = ts->seq + (size_t)(L - 1) * tbh + (size_t)(T - 1) * H * B;
+    const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
+    return os_gru_head_launch(ctx, B, top, fcw, out, s);
+}
+
+int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float *target, float *dout, float *loss,
+                void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded || B <= 0 || !out || !y || !dout || !loss) return os_fail(ctx, -2, "os_gru_loss: bad argument");
+    const int C = ctx->gru.num_classes;
+    if (C % 2) return os_fail(ctx, -4, "os_gru_loss: num_classes must be even (state | error bands)");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    OS_HIP(ctx, hipMemsetAsync(loss, 0, sizeof(float), s));
+    hipLaunchKernelGGL(loss_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, B, C, out, y, target, dout, loss);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const float *out, const float *dout,
+                    float *grad_flat, float *dx_out, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_backward: call os_gru_load first");
+    os_train_state *ts = (os_train_state *)ctx->train;
+    if (!ts || ts->B != B || ts->T != T) return os_fail(ctx, -5, "os_gru_backward: call os_gru_forward_train first (same B, T)");
+    if (!x || !out || !dout || !grad_flat) return os_fail(ctx, -2, "os_gru_backward: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const os_gru_dims &d = ctx->gru;
+    const int H = d.hidden_size, L = d.num_layers, I = d.input_size, C = d.num_classes, H3 = 3 * H;
+    const size_t tbh = (size_t)T * B * H, nparam = os_gru_param_count(&d);
+    const int Kmax = I > H ? I : H;
+    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, 2 * (size_t)T * B * H3)) return -10;
+    if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, 2 * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
+    // transposed-packed weights (re-done every call: parameters change every optimiser step)
+    size_t wT_total = 0;
+    for (int l = 0; l < L; l++) {
+        const int K = l == 0 ? I : H;
+        wT_total += (size_t)((K + 31) / 32 + H / 32) * (H3 / 2) * 64;
+    }
+    if (os_ensure_scratch(ctx, &ts->wT, &ts->wT_floats, wT_total)) return -10;
+    const size_t rows = (size_t)T * B;
+    OS_HIP(ctx, hipMemsetAsync(grad_flat, 0, nparam * sizeof(float), s));
+    rocblas_set_stream(ts->blas, s);
+
+    // ---- head ----
+    const size_t fc_off = nparam - ((size_t)C * H + C);
+    const float *fcw = ctx->gru_flat + fc_off;
+    float *dhT = ts->dxy + 2 * (size_t)T * B * Kmax;
+    const float *hT = ts->act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
+    {
+        const size_t lds = (size_t)(64 * C + 64 * (H + 1)) * sizeof(float);
+        hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(256), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
+                           fcw, dhT, grad_flat + fc_off, grad_flat + fc_off + (size_t)C * H);
+        OS_HIP(ctx, hipGetLastError());
+    }
+    // ---- layers, top to bottom ----
+    size_t poff[17], wToff[17];
+    {
+        size_t po = 0, wo = 0;
+        for (int l = 0; l < L; l++) {
+            const int K = l == 0 ? I : H;
+            poff[l] = po; wToff[l] = wo;
+            po += (size_t)H3 * K + (size_t)H3 * H + 2 * (size_t)H3;
+            wo += (size_t)((K + 31) / 32 + H / 32) * (H3 / 2) * 64;
+        }
+    }
+    float *dgi = ts->dg, *dgh = ts->dg + (size_t)T * B * H3;
+    float *dxbuf[2] = {ts->dxy, ts->dxy + (size_t)T * B * Kmax};
+    const float *dy = nullptr;
+    const float alpha = 1.0f, beta = 1.0f;
+    for (int l = L - 1; l >= 0; l--) {
+        const int K = l == 0 ? I : H;
+        const float *Wih = ctx->gru_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
+        float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
+        hipLaunchKernelGGL(pack_T_kernel, dim3((K + 31) / 32), dim3(256), 0, s, K, H3, Wih, wihT);
+        hipLaunchKernelGGL(pack_T_kernel, dim3(H / 32), dim3(256), 0, s, H, H3, Whh, whhT);
+        const float *base = ts->act + (size_t)l * 5 * tbh;
+        SweepArgs a;
+        a.B = B; a.T = T; a.K = K; a.H = H;
+        a.need_dx = (l > 0 || dx_out) ? 1 : 0;
+        a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
+        a.dy = dy; a.dy_last = (l == L - 1) ? dhT : nullptr;
+        a.wihT = wihT; a.whhT = whhT; a.dgi = dgi; a.dgh = dgh;
+        a.dx = dxbuf[l & 1];
+        const int RB = H <= 64 ? 2 : 1;
+        const int BM = 32 * RB;
+        const size_t lds = (size_t)(BM * (H + 1) + BM * (4 * H + 1)) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        dim3 grid((B + BM - 1) / BM), block(256);
+        if (RB == 2) hipLaunchKernelGGL(bwd_sweep_kernel<2>, grid, block, lds, s, a);
+        else hipLaunchKernelGGL(bwd_sweep_kernel<1>, grid, block, lds, s, a);
+        OS_HIP(ctx, hipGetLastError());
+        // ---- weight gradients (row-major C[3H][K] = col-major [K x 3H] = X_cm [K x R] . dG_cm^T [R x 3H]) ----
+        float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
+        if (l == 0) {
+            // input is (B, T, I) batch_first: one GEMM per step, rows strided by T*I
+            for (int t = 0; t < T; t++) {
+                if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, K, H3, B, &alpha,
+                                  x + (size_t)t * I, T * I, dgi + (size_t)t * B * H3, H3, &beta, gWih, K) != rocblas_status_success)
+                    return os_fail(ctx, -20, "rocblas_sgemm (dW_ih, layer 0) failed");
+            }
+        } else {
+            const float *hin = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh;      // h of the layer below, [T][B][H]
+            if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, K, H3, (int)rows, &alpha, hin, K,
+                              dgi, H3, &beta, gWih, K) != rocblas_status_success)
+                return os_fail(ctx, -20, "rocblas_sgemm (dW_ih) failed");
+        }
+        if (T > 1) {
+            const float *hprev = base + 4 * tbh;                                 // h_{t-1} for t = 1..T-1
+            if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, H, H3, (int)((size_t)(T - 1) * B),
+                              &alpha, hprev, H, dgh + (size_t)B * H3, H3, &beta, gWhh, H) != rocblas_status_success)
+                return os_fail(ctx, -20, "rocblas_sgemm (dW_hh) failed");
+        }
+        dim3 cg((H3 + 255) / 256, (unsigned)((rows + 4095) / 4096));
+        hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgi, gbih);
+        hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
+        OS_HIP(ctx, hipGetLastError());
+        dy = a.dx;
+    }
+    if (dx_out) {
+        // dx of layer 0 is [T][B][I]; the caller's layout is (B, T, I)
+        const size_t n = (size_t)B * T * I;
+        hipLaunchKernelGGL(permute_tb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, T, I, dxbuf[0], dx_out);
+        OS_HIP(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                 float eps, int32_t step, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!n || !w || !g || !m || !v || step < 1) return os_fail(ctx, -2, "os_adam_step: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, w, g, m, v, lr,
+                       beta1, beta2, eps, bc1, bc2);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -161,6 +161,44 @@ class Engine:
                     "os_gru_forward_soa")
         return out
 
+    # ---- training step (gru/gru_train.py:232-249) ----
+    def gru_forward_train(self, x_bti):
+        x = x_bti.to(self.device, dtype=torch.float32).contiguous()
+        B, T, I = x.shape
+        d = self._gru_dims
+        if d is None or I != d.input_size:
+            raise ValueError("load_gru first / input width mismatch")
+        out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_gru_forward_train(self._h, B, T, _ptr(x), _ptr(out), self._stream()), "os_gru_forward_train")
+        return out
+
+    def gru_loss(self, out, y, want_target=False):
+        """target = [y | |out[:, :C/2] - y|] (detached), MSE; returns (loss (1,) device tensor, dout, target|None)."""
+        B, Cc = out.shape
+        y = y.to(self.device, dtype=torch.float32).contiguous()
+        dout = torch.empty_like(out)
+        loss = torch.empty((1,), dtype=torch.float32, device=self.device)
+        tgt = torch.empty_like(out) if want_target else None
+        self._check(self.lib.os_gru_loss(self._h, B, _ptr(out), _ptr(y), _ptr(tgt), _ptr(dout), _ptr(loss), self._stream()),
+                    "os_gru_loss")
+        return loss, dout, tgt
+
+    def gru_backward(self, x_bti, out, dout, grad_flat=None, want_dx=False):
+        x = x_bti.to(self.device, dtype=torch.float32).contiguous()
+        B, T, I = x.shape
+        n = self.lib.os_gru_param_count(C.byref(self._gru_dims))
+        if grad_flat is None:
+            grad_flat = torch.empty((n,), dtype=torch.float32, device=self.device)
+        dx = torch.empty_like(x) if want_dx else None
+        dout = dout.to(self.device, dtype=torch.float32).contiguous()
+        self._check(self.lib.os_gru_backward(self._h, B, T, _ptr(x), _ptr(out), _ptr(dout), _ptr(grad_flat), _ptr(dx),
+                                             self._stream()), "os_gru_backward")
+        return (grad_flat, dx) if want_dx else grad_flat
+
+    def adam_step(self, w, g, m, v, lr, beta1, beta2, eps, step):
+        self._check(self.lib.os_adam_step(self._h, w.numel(), _ptr(w), _ptr(g), _ptr(m), _ptr(v), lr, beta1, beta2, eps, step,
+                                          self._stream()), "os_adam_step")
+
     # ---- fused ----
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
                   dense_fd=False, symmetric=None, two_kernel=False):

@@ -1,0 +1,117 @@
+"""Training side of the GRU head (reference gru/gru_train.py:217-251) on the HIP kernels.
+
+* `gru_forward_autograd`: what `RNN.forward` calls when gradients are enabled, so the reference's own loop
+  (`outputs = model(inputs); loss = criterion(...); loss.backward(); optimizer.step()`) runs unchanged with
+  torch.optim.Adam: forward and backward are the HIP kernels, torch only does the autograd bookkeeping.
+* `FlatBucket` / `DataParallelTrainer`: the data-parallel step of BASELINE config 4 -- one process per GPU, identical
+  replicas, ONE flat fp32 gradient bucket (422,424 floats at the reference config) all-reduced over RCCL
+  (`torch.distributed`, backend "nccl"), then identical fused-Adam updates.  The bucket is latency-bound at 1.69 MB, so
+  there is no bucketing/overlap machinery.  The target of gru_train.py:237-244 is built on the
+  device (no host round trip, no per-sample Python loop).
+"""
+import torch
+import torch.distributed as dist
+
+
+def _flat_order_params(module):
+    """Parameters in the flat layout's order: per layer weight_ih, weight_hh, bias_ih, bias_hh; then fc.weight, fc.bias."""
+    ps = []
+    for l in range(module.num_layers):
+        for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            ps.append(getattr(module.gru, f"{k}_l{l}"))
+    ps += [module.fc.weight, module.fc.bias]
+    return ps
+
+
+class _GruFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        module._sync_weights(x.device)
+        eng = module._engine
+        xd = x.detach().contiguous()
+        out = eng.gru_forward_train(xd)
+        ctx.module, ctx.x_req = module, x.requires_grad
+        ctx.save_for_backward(xd, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xd, out = ctx.saved_tensors
+        module = ctx.module
+        eng = module._engine
+        res = eng.gru_backward(xd, out, dout.contiguous(), want_dx=ctx.x_req)
+        flat, dx = res if ctx.x_req else (res, None)
+        grads, off = [], 0
+        for p in _flat_order_params(module):
+            n = p.numel()
+            grads.append(flat[off:off + n].view_as(p))
+            off += n
+        return (dx, None, *grads)
+
+
+def gru_forward_autograd(module, x):
+    return _GruFn.apply(x, module, *_flat_order_params(module))
+
+
+def shard_range(n, rank, world):
+    """Contiguous split of n independent units (trajectories / samples): rank r gets [lo, hi)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatBucket:
+    """All parameters (and their gradients) of a module as views of ONE flat fp32 tensor each."""
+
+    def __init__(self, params, device=None):
+        params = list(params)
+        device = device or params[0].device
+        n = sum(p.numel() for p in params)
+        self.w = torch.empty(n, dtype=torch.float32, device=device)
+        self.g = torch.zeros(n, dtype=torch.float32, device=device)
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.w[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.w[off:off + k].view_as(p)           # state_dict()/checkpoints keep working
+            p.grad = self.g[off:off + k].view_as(p)
+            off += k
+        self.params = params
+
+    def allreduce_mean_(self, group=None):
+        """SUM all-reduce of the single gradient bucket, then divide by the world size."""
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+            if world > 1:
+                dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group)
+                self.g.div_(world)
+        return self.g
+
+
+class DataParallelTrainer:
+    """One optimisation step = forward, device-side target + MSE, backward, bucket all-reduce, fused Adam."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None):
+        from .engine import default_engine
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("DataParallelTrainer needs the model on the MI355X (no CPU fallback)")
+        self.model, self.group = model, group
+        self.eng = default_engine(dev.index or 0)
+        self.bucket = FlatBucket(_flat_order_params(model), dev)
+        self.m = torch.zeros_like(self.bucket.w)
+        self.v = torch.zeros_like(self.bucket.w)
+        self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.bucket.w, src=0, group=group)   # identical replicas
+
+    def step(self, x, y):
+        m, e = self.model, self.eng
+        e.load_gru(self.bucket.w, m.input_size, m.hidden_size, m.num_layers, m.num_classes, m.use_sigmoid)
+        out = e.gru_forward_train(x)
+        loss, dout, _ = e.gru_loss(out, y)
+        e.gru_backward(x, out, dout, grad_flat=self.bucket.g)
+        self.bucket.allreduce_mean_(self.group)
+        self.t += 1
+        e.adam_step(self.bucket.w, self.bucket.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        return loss

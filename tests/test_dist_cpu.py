@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the host-side sharding and flat-bucket logic of the multi-GPU paths.
+
+Inference shards the trajectory axis with no collective; training all-reduces ONE flat gradient bucket.
+The HIP kernels cannot run here, so the per-rank gradients come from torch's own GRU (test-only stand-in); what
+is under test is optistate_amd.train.FlatBucket / shard_range and their equivalence to a single-process run."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from optistate_amd.train import FlatBucket, shard_range
+        torch.manual_seed(0)                               # identical replicas
+        gru = torch.nn.GRU(12, 16, 2, batch_first=True); fc = torch.nn.Linear(16, 8)
+        params = list(gru.parameters()) + list(fc.parameters())
+        B = 37                                             # ragged on purpose
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(B, 5, 12, generator=g); y = torch.rand(B, 4, generator=g)
+
+        def loss_of(xs, ys, scale):
+            o, _ = gru(xs)
+            out = torch.sigmoid(fc(o[:, -1, :]))
+            tgt = torch.cat([ys, (out[:, :4].detach() - ys).abs()], dim=1)
+            return ((out - tgt) ** 2).sum() / scale
+
+        bucket = FlatBucket(params)
+        lo, hi = shard_range(B, rank, world)
+        # each rank's loss is normalised by the GLOBAL element count times 1/world so that the bucket MEAN equals
+        # the full-batch gradient even with unequal shards
+        bucket.g.zero_()
+        loss = loss_of(x[lo:hi], y[lo:hi], B * 8 / world)
+        grads = torch.autograd.grad(loss, params)
+        off = 0
+        for p, gr in zip(params, grads):
+            bucket.g[off:off + p.numel()].copy_(gr.reshape(-1)); off += p.numel()
+        bucket.allreduce_mean_()
+        # single-process reference on the full batch
+        full = torch.autograd.grad(loss_of(x, y, B * 8), params)
+        ref = torch.cat([t.reshape(-1) for t in full])
+        err = (bucket.g - ref).abs().max().item()
+        # parameters are views of the flat tensor: an in-place update of the bucket is visible through state_dict
+        bucket.w.add_(1.0)
+        view_ok = all(torch.equal(p.data.reshape(-1), bucket.w[o:o + p.numel()]) for p, o in
+                      zip(params, [sum(q.numel() for q in params[:i]) for i in range(len(params))]))
+        ret[rank] = (err, lo, hi, view_ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_equals_full_batch_gradient():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 1000
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    spans = sorted((ret[r][1], ret[r][2]) for r in range(world))
+    assert spans[0][0] == 0 and spans[-1][1] == 37 and spans[0][1] == spans[1][0]      # disjoint cover
+    for r in range(world):
+        assert ret[r][0] < 1e-6, ret[r]
+        assert ret[r][3]
+
+
+def test_shard_range_covers_every_unit_once():
+    from optistate_amd.train import shard_range
+    for n in (0, 1, 7, 64, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
