@@ -62,6 +62,56 @@ def cpu_baseline(H, L, target_seconds):
             "sample": f"{Bs} trajectories x {T} steps (KF float64 C oracle + GRU float64 C oracle, 1 thread, {el:.1f} s)"}
 
 
+def bench_train(a, rank, local_rank, world, dist):
+    """BASELINE configs[3]: data-parallel gru_train.py step, RNN(188,128,4,24), 8192 windows of 10 steps per GPU, Adam 1e-4,
+    one flat 1.69 MB fp32 gradient bucket all-reduced per step.  A 'step' here is one optimisation step."""
+    import torch
+    from optistate_amd import RNN
+    from optistate_amd.train import DataParallelTrainer
+    dev = torch.device("cuda", local_rank)
+    B, T, I, H, L, C = 8192, 10, 188, 128, 4, 24
+    torch.manual_seed(0)
+    model = RNN(I, H, L, C, dev).to(dev)
+    tr = DataParallelTrainer(model, lr=1e-4)
+    g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+    x = torch.rand(B, T, I, device=dev, generator=g); y = torch.rand(B, C // 2, device=dev, generator=g)
+    for _ in range(a.warmup):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(x, y)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ar_us = None
+    if dist:
+        dist.barrier()
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(tr.bucket.g)
+        e1.record(); torch.cuda.synchronize()
+        ar_us = e0.elapsed_time(e1) / 20 * 1e3
+    if rank == 0:
+        fl_fwd = gru_flops_per_step(I, H, L) * B * T
+        out = {"metric": "GRU training windows/sec (gru_train.py step, data parallel)", "value": B * world * a.steps / el,
+               "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "gru_train.py step RNN(188,128,4,24), Adam lr 1e-4, windows of 10", "batch_per_gpu": B,
+                          "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}, one flat fp32 bucket all-reduce",
+                          "baseline_config": "BASELINE.json configs[3]"},
+               "approx_TFLOPs_fwd_bwd": 3 * fl_fwd / (el / a.steps) / 1e12, "allreduce_us": ar_us,
+               "grad_bucket_bytes": int(tr.bucket.g.numel() * 4), "final_loss": float(loss.item())}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +122,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
-    ap.add_argument("--mode", default="fused", choices=["fused", "kf"], help="kf = BASELINE configs[1] style KF-only run")
+    ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train"],
+                    help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")
     a = ap.parse_args()
 
     import torch
@@ -92,6 +143,8 @@ def main():
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
 
+    if a.mode == "train":
+        return bench_train(a, rank, local_rank, world, dist)
     B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60
     eng = Engine(local_rank)
     eng.set_noise(Q_DEFAULT, R_DEFAULT)

@@ -18,16 +18,70 @@
 #include <math.h>
 
 #include "gru_common.hpp"
+#include "kf_device.hpp"   // buffer addressing helpers (make_rsrc / buf_load)
 
 namespace osg {
+
+using osk::buf_load;
+using osk::make_rsrc;
+using osk::rsrc_t;
+
+// One half of the gate GEMM (input part: XPART, accumulates gi_n into acc[.][2]; recurrent part: gh_n into acc[.][3]).
+// Software pipeline, DEPTH k-pairs deep: the B fragments (coalesced dword loads of the fragment-ordered weights,
+// L2-resident) and the A fragments (x part: one 128-B segment per k straight from the SoA stream; h part: LDS) of
+// k-pair q+DEPTH are requested right after the MFMAs of k-pair q issue, so DEPTH * 3 * RBW MFMAs (>= 1500 cycles) cover
+// each L2 round trip; a sched_barrier per k-pair keeps hipcc from hoisting every load to the top of the loop.
+template <int RBW, bool XPART, typename AF>
+__device__ __forceinline__ void mfma_part(f32x16 (*acc)[4], const float *wbase, int KP, int lane, AF afrag)
+{
+    constexpr int DEPTH = 4;
+    float wb[DEPTH][3], ab[DEPTH][RBW];
+    // weights: wave-uniform descriptor + SGPR offset (k-pair, gate) + constant per-lane offset -> no address VALU
+    const rsrc_t w = make_rsrc(wbase, (uint32_t)KP * 3 * 256);
+    const uint32_t wl = (uint32_t)lane * 4u;
+#pragma unroll
+    for (int j = 0; j < DEPTH; j++) {
+        if (j < KP) {
+#pragma unroll
+            for (int g = 0; g < 3; g++) wb[j][g] = buf_load(w, wl, (uint32_t)(j * 3 + g) * 256u);
+#pragma unroll
+            for (int rb = 0; rb < RBW; rb++) ab[j][rb] = afrag(j, rb);
+        }
+    }
+    for (int q0 = 0; q0 < KP; q0 += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const int q = q0 + j;
+            if (q < KP) {
+#pragma unroll
+                for (int rb = 0; rb < RBW; rb++) {
+                    const float av = ab[j][rb];
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[j][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[j][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][XPART ? 2 : 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[j][2], acc[rb][XPART ? 2 : 3], 0, 0, 0);
+                }
+                if (q + DEPTH < KP) {
+#pragma unroll
+                    for (int g = 0; g < 3; g++)
+                        wb[j][g] = buf_load(w, wl, __builtin_amdgcn_readfirstlane((uint32_t)((q + DEPTH) * 3 + g) * 256u));
+#pragma unroll
+                    for (int rb = 0; rb < RBW; rb++) ab[j][rb] = afrag(q + DEPTH, rb);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 
 // RBW = row blocks (of 32 trajectories) per wave.  NCH = H/32 column chunks; with NCH < 4 several waves share a chunk
 // and split the rows.  BM = 32 * RBW * max(1, 4/NCH).
 template <int RBW>
-__global__ __launch_bounds__(256, (RBW <= 2 ? 2 : 1)) void gru_layer_kernel(const LayerArgs a)
+__global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float hl[];   // [BM][HS]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index is wave-uniform but derived from threadIdx: readfirstlane makes that provable, so descriptors built
+    // from it stay in SGPRs (otherwise hipcc wraps every buffer_load in a waterfall loop)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, HS = H + 1, NCH = H >> 5;
     const int WPC = NCH >= 4 ? 1 : 4 / NCH;          // waves per chunk
     const int BM = 32 * RBW * WPC;
@@ -45,12 +99,16 @@ __global__ __launch_bounds__(256, (RBW <= 2 ? 2 : 1)) void gru_layer_kernel(cons
     const float *bias = wh + (size_t)a.KPh * 3 * 64;
     const float b_r = bias[li], b_z = bias[32 + li], b_in = bias[64 + li], b_hn = bias[96 + li];
 
-    int grow[RBW];          // global trajectory index of this lane's A-fragment row, per row block
-    bool gok[RBW];
+    // A-fragment rows of this lane, clamped to the last trajectory (rows past B only feed their own, never-stored
+    // outputs); xoff = byte offset of (row, k = lh) inside one step's [K][B] block: the k-pair is added as an SGPR offset
+    const uint32_t rowB = (uint32_t)a.B * 4u;
+    int growc[RBW];
+    uint32_t xoff[RBW];
 #pragma unroll
     for (int rb = 0; rb < RBW; rb++) {
-        grow[rb] = tile_row0 + (row_blk0 + rb) * 32 + li;
-        gok[rb] = grow[rb] < a.B;
+        const int g = tile_row0 + (row_blk0 + rb) * 32 + li;
+        growc[rb] = g < a.B ? g : a.B - 1;
+        xoff[rb] = (uint32_t)growc[rb] * 4u + (uint32_t)lh * rowB;
     }
     __syncthreads();
 
@@ -63,38 +121,27 @@ __global__ __launch_bounds__(256, (RBW <= 2 ? 2 : 1)) void gru_layer_kernel(cons
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
 
-        // ---- input part: A fragments straight from the SoA stream (coalesced over trajectories) ----
+        // ---- gates = [x_t | h_{t-1}] . [W_ih | W_hh]^T, software-pipelined DEPTH k-pairs deep (see mfma_part) ----
         const float *xt = a.xs + (size_t)t * a.K * B;
-#pragma unroll 2
-        for (int kp = 0; kp < a.KPx; kp++) {
-            const int k = 2 * kp + lh;
-            const float w_r = wx[(kp * 3 + 0) * 64 + lane];
-            const float w_z = wx[(kp * 3 + 1) * 64 + lane];
-            const float w_n = wx[(kp * 3 + 2) * 64 + lane];
-            const bool kok = k < a.K;
+        const rsrc_t rx = make_rsrc(xt, (uint32_t)a.K * rowB);
+        const int KPfull = a.K / 2;       // k-pairs with both k in range; an odd K leaves one masked tail pair
+        mfma_part<RBW, true>(acc, wx, KPfull, lane, [&](int q, int rb) {
+            return buf_load(rx, xoff[rb], __builtin_amdgcn_readfirstlane((uint32_t)(2 * q) * rowB));   // k = 2q + lh: see xoff
+        });
+        if (a.KPx > KPfull) {
+            const int q = KPfull;
+            const float w_r = wx[(q * 3 + 0) * 64 + lane], w_z = wx[(q * 3 + 1) * 64 + lane], w_n = wx[(q * 3 + 2) * 64 + lane];
 #pragma unroll
             for (int rb = 0; rb < RBW; rb++) {
-                const float av = (kok && gok[rb]) ? xt[(size_t)k * B + grow[rb]] : 0.f;
+                const float av = (lh == 0) ? xt[(size_t)(2 * q) * B + growc[rb]] : 0.f;
                 acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[rb][0], 0, 0, 0);
                 acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[rb][1], 0, 0, 0);
                 acc[rb][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[rb][2], 0, 0, 0);
             }
         }
-        // ---- recurrent part: A fragments from the LDS-resident h ----
-#pragma unroll 2
-        for (int kp = 0; kp < a.KPh; kp++) {
-            const int k = 2 * kp + lh;
-            const float w_r = wh[(kp * 3 + 0) * 64 + lane];
-            const float w_z = wh[(kp * 3 + 1) * 64 + lane];
-            const float w_n = wh[(kp * 3 + 2) * 64 + lane];
-#pragma unroll
-            for (int rb = 0; rb < RBW; rb++) {
-                const float av = hl[((row_blk0 + rb) * 32 + li) * HS + k];
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[rb][1], 0, 0, 0);
-                acc[rb][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[rb][3], 0, 0, 0);
-            }
-        }
+        mfma_part<RBW, false>(acc, wh, a.KPh, lane, [&](int q, int rb) {
+            return hl[((row_blk0 + rb) * 32 + li) * HS + 2 * q + lh];
+        });
         __syncthreads();   // every wave has finished reading h_{t-1}
 
         // ---- cell update on the accumulator layout: col = lane&31 (hidden unit), row = (e&3) + 8*(e>>2) + 4*(lane>>5)

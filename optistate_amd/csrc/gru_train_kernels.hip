@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = a.H, K = a.K, HS = H + 1, GS = 4 * H + 1, BM = 32 * RB;
     float *dh = sm, *dG = sm + BM * HS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * BM;
     const size_t B = (size_t)a.B;
     for (int i = threadIdx.x; i < BM * HS; i += 256) dh[i] = 0.f;
@@ -191,15 +191,20 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
     }
 }
 
-// column sums of a [R][N] row-major matrix into dst[N] (bias gradients)
+// column sums of a [R][N] row-major matrix into dst[N] (bias gradients): 64 columns x 4 row-lanes per workgroup,
+// 1024 rows per workgroup, one atomic per column per workgroup
 __global__ void colsum_kernel(size_t R, int N, const float *src, float *dst)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const size_t r0 = (size_t)blockIdx.y * 4096, r1 = r0 + 4096 < R ? r0 + 4096 : R;
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cx;
+    const size_t r0 = (size_t)blockIdx.y * 1024, r1 = r0 + 1024 < R ? r0 + 1024 : R;
     float s = 0.f;
-    for (size_t r = r0; r < r1; r++) s += src[r * N + n];
-    atomicAdd(&dst[n], s);
+    if (n < N)
+        for (size_t r = r0 + ry; r < r1; r += 4) s += src[r * N + n];
+    part[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) atomicAdd(&dst[n], part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
 }
 
 // [T][B][F] -> [B][T][F]
@@ -411,18 +416,23 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
                     return os_fail(ctx, -20, "rocblas_sgemm (dW_ih, layer 0) failed");
             }
         } else {
+            // one GEMM per step (8192-row reductions map onto many workgroups; a single T*B-long GEMM lands on 4 tiles)
             const float *hin = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh;      // h of the layer below, [T][B][H]
-            if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, K, H3, (int)rows, &alpha, hin, K,
-                              dgi, H3, &beta, gWih, K) != rocblas_status_success)
-                return os_fail(ctx, -20, "rocblas_sgemm (dW_ih) failed");
+            for (int t = 0; t < T; t++) {
+                if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, K, H3, B, &alpha,
+                                  hin + (size_t)t * B * K, K, dgi + (size_t)t * B * H3, H3, &beta, gWih, K) != rocblas_status_success)
+                    return os_fail(ctx, -20, "rocblas_sgemm (dW_ih) failed");
+            }
         }
-        if (T > 1) {
+        {
             const float *hprev = base + 4 * tbh;                                 // h_{t-1} for t = 1..T-1
-            if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, H, H3, (int)((size_t)(T - 1) * B),
-                              &alpha, hprev, H, dgh + (size_t)B * H3, H3, &beta, gWhh, H) != rocblas_status_success)
-                return os_fail(ctx, -20, "rocblas_sgemm (dW_hh) failed");
+            for (int t = 1; t < T; t++) {
+                if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, H, H3, B, &alpha,
+                                  hprev + (size_t)(t - 1) * B * H, H, dgh + (size_t)t * B * H3, H3, &beta, gWhh, H) != rocblas_status_success)
+                    return os_fail(ctx, -20, "rocblas_sgemm (dW_hh) failed");
+            }
         }
-        dim3 cg((H3 + 255) / 256, (unsigned)((rows + 4095) / 4096));
+        dim3 cg((H3 + 63) / 64, (unsigned)((rows + 1023) / 1024));
         hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgi, gbih);
         hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
         OS_HIP(ctx, hipGetLastError());
