@@ -38,10 +38,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m optistate_amd.build` "
+    path = os.environ.get("OPTISTATE_HIP_LIB", LIB_PATH)      # A/B builds of the same C-ABI (development aid)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -m optistate_amd.build` "
                            "(there is no CPU fallback for the OptiState hot path)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, u32, f32p = C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p
     lib.os_create.argtypes = [C.POINTER(OsKfConfig), C.POINTER(vp)]
     lib.os_create.restype = C.c_int

@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
                     const int g = tile_row0 + row;
                     if (g < a.B) {
                         const size_t o = ((size_t)t * B + g) * H + chunk * 32 + li;   // lanes 0-31: 128 contiguous bytes
-                        a.sv_r[o] = r; a.sv_z[o] = z; a.sv_n[o] = n; a.sv_g[o] = ghn; a.sv_h[o] = hn;
+                        // write-once streams: non-temporal, so they do not evict the L2-resident weights
+                        __builtin_nontemporal_store(r, a.sv_r + o); __builtin_nontemporal_store(z, a.sv_z + o);
+                        __builtin_nontemporal_store(n, a.sv_n + o); __builtin_nontemporal_store(ghn, a.sv_g + o);
+                        __builtin_nontemporal_store(hn, a.sv_h + o);
                     }
                 }
             }

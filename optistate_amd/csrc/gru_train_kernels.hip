@@ -17,6 +17,7 @@
 #include <rocblas/rocblas.h>
 
 #include "gru_common.hpp"
+#include "kf_device.hpp"   // buffer addressing helpers
 
 namespace ost {
 
@@ -131,30 +132,45 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
     const int Q = 3 * H / 2;                   // gate-unit pairs in the reduction
 
     for (int t = a.T - 1; t >= 0; t--) {
-        // ---- gate derivatives (VALU), coalesced over the hidden index ----
-        for (int i = threadIdx.x; i < BM * H; i += 256) {
-            const int r = i / H, c = i % H, g = row0 + r;
-            float dar = 0.f, daz = 0.f, dan = 0.f, danr = 0.f, dhc = 0.f;
-            if (g < a.B) {
-                const size_t o = ((size_t)t * B + g) * H + c;
-                const float rr = a.sv_r[o], zz = a.sv_z[o], nn = a.sv_n[o], gg = a.sv_g[o];
-                const float hp = t > 0 ? a.sv_h[o - B * H] : 0.f;
+        // ---- gate derivatives (VALU), coalesced over the hidden index.  Unrolled 8x with restrict-qualified streams so
+        // that the loads of a batch are in flight together; read-once / write-once streams are non-temporal so they do
+        // not evict the L2-resident weights ----
+        {
+            const float *__restrict__ pr = a.sv_r, *__restrict__ pz = a.sv_z, *__restrict__ pn = a.sv_n,
+                        *__restrict__ pg = a.sv_g, *__restrict__ ph = a.sv_h, *__restrict__ pdy = a.dy,
+                        *__restrict__ pdl = a.dy_last;
+            float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
+            const bool last = (t == a.T - 1);
+#pragma unroll 8
+            for (int i = threadIdx.x; i < BM * H; i += 256) {
+                const int r = i / H, c = i % H, g = row0 + r;
+                const bool ok = g < a.B;
+                const int gc = ok ? g : a.B - 1;
+                const size_t o = ((size_t)t * B + gc) * H + c;
+                const float rr = __builtin_nontemporal_load(pr + o), zz = __builtin_nontemporal_load(pz + o),
+                            nn = __builtin_nontemporal_load(pn + o), gg = __builtin_nontemporal_load(pg + o);
+                const float hp = t > 0 ? __builtin_nontemporal_load(ph + o - B * H) : 0.f;
                 float dht = dh[r * HS + c];
-                if (a.dy) dht += a.dy[o];
-                if (a.dy_last && t == a.T - 1) dht += a.dy_last[(size_t)g * H + c];
+                if (pdy) dht += __builtin_nontemporal_load(pdy + o);
+                if (pdl && last) dht += pdl[(size_t)gc * H + c];
+                if (!ok) dht = 0.f;
                 const float dn = dht * (1.0f - zz);
                 const float dz = dht * (hp - nn);
-                dhc = dht * zz;
-                dan = dn * (1.0f - nn * nn);
-                danr = dan * rr;
-                dar = dan * gg * rr * (1.0f - rr);
-                daz = dz * zz * (1.0f - zz);
-                const size_t og = ((size_t)t * B + g) * (3 * H) + c;
-                a.dgi[og] = dar; a.dgi[og + H] = daz; a.dgi[og + 2 * H] = dan;
-                a.dgh[og] = dar; a.dgh[og + H] = daz; a.dgh[og + 2 * H] = danr;
+                const float dhc = dht * zz;
+                const float dan = dn * (1.0f - nn * nn);
+                const float danr = dan * rr;
+                const float dar = dan * gg * rr * (1.0f - rr);
+                const float daz = dz * zz * (1.0f - zz);
+                if (ok) {
+                    const size_t og = ((size_t)t * B + g) * (3 * H) + c;
+                    __builtin_nontemporal_store(dar, ogi + og); __builtin_nontemporal_store(daz, ogi + og + H);
+                    __builtin_nontemporal_store(dan, ogi + og + 2 * H);
+                    __builtin_nontemporal_store(dar, ogh + og); __builtin_nontemporal_store(daz, ogh + og + H);
+                    __builtin_nontemporal_store(danr, ogh + og + 2 * H);
+                }
+                dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
+                dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
             }
-            dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
-            dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
         }
         __syncthreads();
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
@@ -167,15 +183,41 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
             for (int rb = 0; rb < RB; rb++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[rb][e] = 0.f;
-#pragma unroll 4
-            for (int q = 0; q < Q; q++) {
-                const int j = 2 * q + lh;                                   // gate unit in [0, 3H)
-                const int col = (is_h && j >= 2 * H) ? j + H : j;           // n-part of the recurrent path is scaled by r
-                const float w = wp[q * 64 + lane];
+            // DEPTH-deep software pipeline: B fragments by buffer loads (wave-uniform descriptor + SGPR offset), A fragments
+            // from the LDS tile; the n-part of the recurrent path reads the r-scaled section of the tile
+            constexpr int DEPTH = 16 / RB;     // one MFMA per k-pair and row block: 16 x 64 cycles cover an L2 round trip
+            const osk::rsrc_t rw = osk::make_rsrc(wp, (uint32_t)Q * 256u);
+            const uint32_t wl = (uint32_t)lane * 4u;
+            float wbf[DEPTH], abf[DEPTH][RB];
+            auto acol = [&](int q) {
+                const int j = 2 * q + lh;
+                return (is_h && j >= 2 * H) ? j + H : j;
+            };
 #pragma unroll
-                for (int rb = 0; rb < RB; rb++) {
-                    const float av = dG[(rb * 32 + li) * GS + col];
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w, acc[rb], 0, 0, 0);
+            for (int d = 0; d < DEPTH; d++) {
+                if (d < Q) {
+                    wbf[d] = osk::buf_load(rw, wl, (uint32_t)d * 256u);
+                    const int col = acol(d);
+#pragma unroll
+                    for (int rb = 0; rb < RB; rb++) abf[d][rb] = dG[(rb * 32 + li) * GS + col];
+                }
+            }
+            for (int q0 = 0; q0 < Q; q0 += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) {
+                    const int q = q0 + d;
+                    if (q < Q) {
+#pragma unroll
+                        for (int rb = 0; rb < RB; rb++)
+                            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
+                        if (q + DEPTH < Q) {
+                            wbf[d] = osk::buf_load(rw, wl, __builtin_amdgcn_readfirstlane((uint32_t)(q + DEPTH) * 256u));
+                            const int col = acol(q + DEPTH);
+#pragma unroll
+                            for (int rb = 0; rb < RB; rb++) abf[d][rb] = dG[(rb * 32 + li) * GS + col];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
