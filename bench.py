@@ -214,10 +214,14 @@ def main():
             roof = {"kernel": "kf_run_sym_kernel" if dom_name == "kf" else dom_name, "bound": "hbm", "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": avg_ms}
+        # HBM bytes per launch from the PMC passes (tools/traffic_pass.sh -> profiles/traffic.json; FETCH_SIZE corrected
+        # x2 per the gfx950 calibration); valid for the default bench shape only
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and B == 65536 and T == 100:
             try:
                 roof["traffic"] = json.load(open(tj)).get(roof["kernel"].split(" ")[0])
+                roof["traffic_unit"] = "bytes/launch"
+                roof["algorithmic_bytes"] = (BYTES_PER_STEP_FUSED if dom_name == "fused" else BYTES_PER_STEP_KF) * steps_per_pass
             except Exception:
                 pass
         kernels = {k: {"ms_per_launch": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items() if v[1]}

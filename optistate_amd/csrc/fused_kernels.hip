@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
     {
         rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
 #pragma unroll
-        for (int i = 0; i < 6; i++) acl[i] = buf_load(ra, voff, i * rowB);
+        for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
     }
 
     for (int t = 0; t < k.T; t++) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
         }
 #pragma unroll
         for (int i = 0; i < NS; i++) F[i] = norm_feat(nrm, i, x[i]);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
                     load_step(k, tn, voff, rowB, in);
                     rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
 #pragma unroll
-                    for (int i = 0; i < 6; i++) acl[i] = buf_load(ra, voff, i * rowB);
+                    for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
                 }
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++) {
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
         }
     }
 }
+
 
 }  // namespace osf
 

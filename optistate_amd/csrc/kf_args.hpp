@@ -31,13 +31,13 @@ __device__ __forceinline__ void load_step(const KfRunArgs &a, int t, uint32_t vo
     rsrc_t rc = make_rsrc(a.contact + (size_t)t * B, rowB);
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        in.p[i] = buf_load(rp, voff, i * rowB);
-        in.f[i] = buf_load(rf, voff, i * rowB);
-        in.dp[i] = buf_load(rd, voff, i * rowB);
+        in.p[i] = buf_load_nt(rp, voff, i * rowB);
+        in.f[i] = buf_load_nt(rf, voff, i * rowB);
+        in.dp[i] = buf_load_nt(rd, voff, i * rowB);
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) in.imu[i] = buf_load(ri, voff, i * rowB);
-    in.contact = buf_load_u32(rc, voff, 0);
+    for (int i = 0; i < 6; i++) in.imu[i] = buf_load_nt(ri, voff, i * rowB);
+    in.contact = buf_load_u32_nt(rc, voff, 0);
 }
 
 

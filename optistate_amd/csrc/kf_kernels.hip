@@ -13,7 +13,7 @@ namespace osk {
 __device__ __forceinline__ void store_feat(rsrc_t rf, const float *mm, uint32_t voff, uint32_t rowB, int j, float v)
 {
     const float mn = mm[j], mx = mm[60 + j];
-    buf_store(rf, voff, j * rowB, (v - mn) / (mx - mn));
+    buf_store_nt(rf, voff, j * rowB, (v - mn) / (mx - mn));
 }
 
 template <bool SEQ, bool DENSE, bool AUX, bool FEAT, bool QDIAG>
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
             rsrc_t ra = make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB);
 #pragma unroll
-            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load(ra, voff, i * rowB));
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load_nt(ra, voff, i * rowB));
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 store_feat(rfeat, a.minmax, voff, rowB, 18 + i, in.f[i]);
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
         if (a.p_rot_out) {
             rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < 12; i++) buf_store(ro, voff, i * rowB, pw[i]);
+            for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw[i]);
         }
         // the inputs are dead now: reuse their registers to prefetch step t+1 underneath the update,
         // which is the long part of the step (43 coalesced loads in flight, one wave per SIMD)
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
         }
         if (FEAT) {
 #pragma unroll
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
             rsrc_t ra = make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB);
 #pragma unroll
-            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load(ra, voff, i * rowB));
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load_nt(ra, voff, i * rowB));
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 store_feat(rfeat, a.minmax, voff, rowB, 18 + i, in.f[i]);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
         if (a.p_rot_out) {
             rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < 12; i++) buf_store(ro, voff, i * rowB, pw[i]);
+            for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw[i]);
         }
         const int tn = (t + 1 < a.T) ? t + 1 : t;
         load_step(a, tn, voff, rowB, in);           // prefetch underneath the update
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store(ro, voff, i * rowB, x[i]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
         }
         if (OUT == 2) {
 #pragma unroll

@@ -1,0 +1,26 @@
+#!/bin/bash
+# HBM traffic of the bench kernels from PMC counters, one counter per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do
+# not fit one pass), plus the calibration kernels with known byte counts.
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/traffic
+mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -- $R/tools/micro/traffic_cal > $OUT/cal_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/run_$c -- python3 $R/tools/run_fused_once.py 2 > $OUT/run_$c.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections, json
+res = collections.defaultdict(dict)
+for tag in ("cal", "run"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob("$OUT/%s_%s/**/*counter_collection.csv" % (tag, c), recursive=True)
+        if not f: continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            acc[r["Kernel_Name"].split("(")[0][-40:]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            res[k][c] = sum(v) / len(v)
+for k, d in res.items():
+    if any(s in k for s in ("rd_dword", "wr_dword", "fused_kf_gru", "kf_run_sym")):
+        print(k, {c: "%.4g" % v for c, v in d.items()})
+json.dump(res, open("$OUT/traffic_raw.json", "w"), indent=1)
+PY
