@@ -156,6 +156,8 @@ class Engine:
     def gru_forward_soa(self, xs_tib):
         T, I, B = xs_tib.shape
         d = self._gru_dims
+        if d is None:
+            raise RuntimeError("gru_forward_soa: load_gru first")
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
         self._check(self.lib.os_gru_forward_soa(self._h, B, T, _ptr(xs_tib), _ptr(out), None, self._stream()),
                     "os_gru_forward_soa")
