@@ -147,6 +147,20 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
 int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, float *v, float lr, float beta1, float beta2,
                  float eps, int32_t step, void *stream);
 
+/* ---- Optional ViT-encoder latent (transformer/transformer_model.py:113-135; BASELINE config 5).  PARITY UNPINNED: timm 0.3.2
+ * (PatchEmbed, Block) and the trained weights are absent from the build image; this follows that release's published
+ * definition and is checked against this repo's own float64 restatement only.
+ * Flat weight layout (device floats): patch_embed.proj.weight [D][P*P], .bias [D], cls_token [D], pos_embed [L][D]; per block:
+ * norm1.weight, norm1.bias, attn.qkv.weight [3D][D], attn.qkv.bias [3D], attn.proj.weight [D][D], attn.proj.bias, norm2.weight,
+ * norm2.bias, mlp.fc1.weight [M][D], mlp.fc1.bias [M], mlp.fc2.weight [D][M], mlp.fc2.bias [D]; then norm.weight, norm.bias.
+ * os_vit_encode: images [N][img][img] float in [0,1] (gru/gru_test.py:49-53) -> latent [N][D] = sigmoid(LN(cls token)). */
+typedef struct os_vit_dims {
+    int32_t img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden;
+} os_vit_dims;
+size_t os_vit_param_count(const os_vit_dims *d);
+int os_vit_load(os_ctx *ctx, const os_vit_dims *d, const float *w_flat);
+int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, void *stream);
+
 /* Per-kernel device timing (HIP events recorded on the launch stream around each internal kernel), used by
  * bench.py for the roofline of the dominant kernel.  Phases: 0 Kalman kernel, 1 GRU layer kernels, 2 GRU head,
  * 3 fused Kalman+GRU kernel.  os_profile_read synchronises on the recorded events, adds up the elapsed

@@ -17,12 +17,18 @@ EXPORTS = [
     "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_param_count", "os_gru_load", "os_gru_forward",
     "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream", "os_profile_enable", "os_profile_read",
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
+    "os_vit_param_count", "os_vit_load", "os_vit_encode",
 ]
 
 
 class OsKfConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("dt", C.c_float), ("mass", C.c_float), ("inertia", C.c_float * 3),
                 ("gz", C.c_float)]
+
+
+class OsVitDims(C.Structure):
+    _fields_ = [("img_size", C.c_int32), ("patch_size", C.c_int32), ("in_chans", C.c_int32), ("embed_dim", C.c_int32),
+                ("depth", C.c_int32), ("num_heads", C.c_int32), ("mlp_hidden", C.c_int32)]
 
 
 class OsGruDims(C.Structure):
@@ -71,6 +77,12 @@ def load():
     lib.os_adam_step.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]
     for n in ("os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step"):
         getattr(lib, n).restype = C.c_int
+    lib.os_vit_param_count.argtypes = [C.POINTER(OsVitDims)]
+    lib.os_vit_param_count.restype = C.c_size_t
+    lib.os_vit_load.argtypes = [vp, C.POINTER(OsVitDims), f32p]
+    lib.os_vit_encode.argtypes = [vp, i32, f32p, f32p, vp]
+    lib.os_vit_load.restype = C.c_int
+    lib.os_vit_encode.restype = C.c_int
     lib.os_profile_enable.argtypes = [vp, C.c_int]
     lib.os_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.os_profile_enable.restype = C.c_int

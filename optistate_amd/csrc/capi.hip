@@ -46,6 +46,7 @@ void os_destroy(os_ctx *ctx)
     if (!ctx || ctx->magic != OS_MAGIC) return;
     (void)hipSetDevice(ctx->device);
     os_train_destroy(ctx);
+    os_vit_destroy(ctx);
     float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm};
     for (float *b : bufs)
         if (b) (void)hipFree(b);

@@ -28,6 +28,7 @@ struct os_ctx {
     float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;
+    void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
     // per-kernel timing (os_profile_*): ring of event pairs
     bool prof;
@@ -88,3 +89,4 @@ int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats)
 int os_gru_launch_layer(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s);
 int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s);
 void os_train_destroy(os_ctx *ctx);
+void os_vit_destroy(os_ctx *ctx);

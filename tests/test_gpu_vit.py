@@ -1,0 +1,71 @@
+"""GPU: ViT-encoder latent (optional row A10 / config 5).  PARITY UNPINNED with respect to the reference (timm 0.3.2 and
+the trained weights are absent): the HIP path is compared with this repo's own float64 restatement (oracle/vit_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_encoder_latent_matches_float64_restatement():
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    m = Transformer_Autoencoder().to("cuda")
+    with torch.no_grad():            # make biases / LayerNorm affine non-trivial so every term is exercised
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    x = torch.rand(5, 1, 224, 224)
+    lat = m.forward_encoder(x.cuda())
+    assert lat.shape == (5, 1, 128)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ref = vit_oracle.encode(x[:, 0].numpy(), sd)
+    err = np.abs(lat.cpu().numpy()[:, 0] - ref).max()
+    assert err < 2e-5, err
+    assert 0.0 < lat.min().item() and lat.max().item() < 1.0
+
+
+def test_pos_embed_table_and_state_dict_keys():
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    from oracle import vit_oracle
+    m = Transformer_Autoencoder()
+    assert np.abs(m.pos_embed[0].numpy() - vit_oracle.sincos_pos_embed(128, 14)).max() < 1e-6
+    keys = set(m.state_dict().keys())
+    for k in ("patch_embed.proj.weight", "cls_token", "pos_embed", "blocks.0.attn.qkv.weight", "blocks.2.mlp.fc2.bias",
+              "norm.weight"):
+        assert k in keys
+    assert sum(p.numel() for n, p in m.named_parameters() if n != "pos_embed") + 197 * 128 == \
+        128 * 256 + 128 + 128 + 197 * 128 + 3 * (2 * 128 + 384 * 128 + 384 + 128 * 128 + 128 + 2 * 128 + 512 * 128 + 512 + 128 * 512 + 128) + 256
+
+
+def test_config5_pipeline_latent_feeds_gru():
+    """depth frames -> latent -> appended to the 60 Kalman features -> GRU(188,128,4,24) (gru/gru_test.py:119-136)."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    from oracle import c_oracle as orc, vit_oracle
+    B, T = 6, 5
+    torch.manual_seed(1)
+    vit = Transformer_Autoencoder().to("cuda")
+    frames = torch.rand(B * T, 1, 224, 224)
+    lat = vit.forward_encoder(frames.cuda()).reshape(B, T, 128)
+    ref_lat = vit_oracle.encode(frames[:, 0].numpy(), {k: v.cpu().numpy() for k, v in vit.state_dict().items()}).reshape(B, T, 128)
+    d = synth_numpy(B, T, seed=31)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)), Q_FITTED, R_FITTED)
+    rows = np.concatenate([ref["x"], d["accel"], d["f"], ref["p_rot"], d["dp"], d["imu"]], axis=2)
+    mn, mx = rows.reshape(-1, 60).min(0), rows.reshape(-1, 60).max(0)
+    full = np.concatenate([(rows - mn) / (mx - mn), ref_lat], axis=2)                       # [B][T][188]
+    m = RNN(188, 128, 4, 24, torch.device("cpu"))
+    ref_out, _, _ = orc.gru_forward(full, orc.flatten_state_dict(m.state_dict(), 4), 188, 128, 4, 24)
+    eng = Engine(0)
+    eng.set_noise(Q_FITTED, R_FITTED)
+    eng.load_gru(flatten_state_dict(m.state_dict(), 4), 188, 128, 4, 24)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    mm = torch.as_tensor(np.stack([mn, mx]).astype(np.float32)).cuda()
+    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P, latent=eng.pack(lat))
+    torch.cuda.synchronize()
+    assert np.abs(r["out"].cpu().numpy() - ref_out).max() < 2e-4
