@@ -137,7 +137,7 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T,
  *                        over B*C entries; dout [B][C] = d(loss)/d(out); target [B][C] optional.  y [B][C/2].
  * os_gru_backward      : loss.backward() (gru/gru_train.py:248): all parameter gradients into grad_flat (flat layout of
  *                        os_gru_param_count; this is the single bucket a data-parallel step all-reduces), optional
- *                        d(loss)/d(x) in dx [B][T][I].  Weight-gradient GEMMs (T*B-long reductions) use rocBLAS.
+ *                        d(loss)/d(x) in dx [B][T][I].
  * os_adam_step         : torch.optim.Adam's update (gru/gru_train.py:219,249) fused over flat vectors; step counts from 1. */
 int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, void *stream);
 int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float *target, float *dout, float *loss,

@@ -324,7 +324,10 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     const int H = a.H, NCH = H / 32;
     const int WPC = NCH >= 4 ? 1 : 4 / NCH;
     // rows per workgroup: H = 64: RBW 2 x 2 waves/chunk = 128; H = 128: RBW 2 = 64; H = 32: RBW 1 x 4 waves/chunk = 128
-    const int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
+    int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
+    // small batches: halve the row tile when the grid would leave compute units idle (256 CUs; the recurrence cannot be
+    // split across workgroups, so rows are the only parallel axis)
+    if (RBW == 2 && (a.B + 32 * RBW * WPC - 1) / (32 * RBW * WPC) < ctx->cu_count) RBW = 1;
     const int BM = 32 * RBW * WPC;
     const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
     dim3 grid((a.B + BM - 1) / BM), block(256);

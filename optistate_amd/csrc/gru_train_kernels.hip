@@ -8,13 +8,14 @@
 //                dh_{t-1} += [da_r | da_z | da_n * r] . W_hh
 //              with dh carried in LDS, gate derivatives staged in LDS as MFMA A-fragments and written out once
 //              ([T][B][3H]) for the weight gradients
-//   weights  : dW_ih = sum_t dGI_t^T X_t, dW_hh = sum_t dGH_t^T H_{t-1}: plain dense GEMMs with a T*B-long reduction ->
-//              rocBLAS sgemm (the one place a vendor GEMM is used); biases by a column-sum kernel.
+//   weights  : dW_ih = sum_t dGI_t^T X_t, dW_hh = sum_t dGH_t^T H_{t-1} (T*B-long reductions): split-K fp32 MFMA kernel with
+//              both operands coalesced straight from memory and fp32 atomics for the partial tiles (dw_kernel); the bias
+//              gradients ride along / a column-sum kernel.
 // All gradients land in one flat fp32 vector in the flat parameter layout (include/optistate_hip.h), which is the
 // single bucket the data-parallel step all-reduces over RCCL.
 #include "launch.hpp"
 
-#include <rocblas/rocblas.h>
+#include <stdlib.h>
 
 #include "gru_common.hpp"
 #include "kf_device.hpp"   // buffer addressing helpers
@@ -233,6 +234,95 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
     }
 }
 
+// ---- weight gradients: dW[3H][K] += dG^T X over a slice of the T*B rows, db[3H] += column sums of dG ----
+// Both MFMA operands are coalesced straight from HBM/L2: for a 2-row step, lane (i = l&31, kk = l>>5) supplies
+// A = dG[r+kk][j0+i] (32 consecutive gate units) and B = X[r+kk][k0+i] (32 consecutive inputs); a wave keeps one 32-wide
+// gate chunk and up to 6 input chunks (96 accumulator registers), so dG is read once per wave and X once per gate chunk
+// (it stays in the 256 MiB Infinity Cache).  The T*B-long reduction is split over blockIdx.y; partial tiles are added
+// with fp32 atomics (two 128-B row segments per wave instruction).  The bias gradient rides along on the VALU.
+struct DwArgs {
+    int H3, K;                // gate units, input width
+    size_t r_begin, r_end;    // rows of dG to reduce (row r of dG pairs with row r - x_row_shift of X)
+    size_t x_row_shift;
+    int rows_per_slice;
+    const float *dG;          // [rows][H3]
+    const float *X;           // [rows][K], or (B, T, K) batch_first when x_btf (row r = t*B + b lives at (b*T + t)*K)
+    int x_btf, B, T;
+    float *dW;                // [H3][K]
+    float *db;                // [H3] or null
+};
+
+__global__ __launch_bounds__(64, 2) void dw_kernel(const DwArgs a)
+{
+    const int lane = threadIdx.x, li = lane & 31, kk = lane >> 5;
+    const int j0 = blockIdx.x * 32;
+    const size_t r0 = a.r_begin + (size_t)blockIdx.y * a.rows_per_slice;
+    size_t r1 = r0 + a.rows_per_slice;
+    if (r1 > a.r_end) r1 = a.r_end;
+    if (r0 >= r1) return;
+    const int nkc = (a.K + 31) / 32;
+    const int nsteps = (int)((r1 - r0 + 1) / 2);
+    float bsum = 0.f;
+    constexpr int DEPTH = 4;                      // 2-row steps in flight: 4 x 7 loads cover an HBM round trip
+    for (int kc0 = 0; kc0 < nkc; kc0 += 6) {
+        f32x16 acc[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
+        float av[DEPTH], bv[DEPTH][6];
+        auto fetch = [&](int step, int slot) {
+            const size_t rr = r0 + 2 * (size_t)step + kk;
+            const bool ok = step < nsteps && rr < r1;
+            const size_t rc = ok ? rr : r0;                       // clamp: masked lanes read a valid row, value zeroed
+            const float v = a.dG[rc * a.H3 + j0 + li];
+            av[slot] = ok ? v : 0.f;
+            size_t xo;
+            if (a.x_btf) {
+                const size_t xr = rc - a.x_row_shift;
+                xo = ((xr % a.B) * a.T + xr / a.B) * a.K;
+            } else {
+                xo = (rc - a.x_row_shift) * a.K;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int k = (kc0 + c) * 32 + li;
+                const float b = a.X[xo + (k < a.K ? k : 0)];
+                bv[slot][c] = (ok && k < a.K) ? b : 0.f;
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) fetch(d, d);
+        for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                if (s0 + d < nsteps) {
+                    if (kc0 == 0) bsum += av[d];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], bv[d][c], acc[c], 0, 0, 0);
+                    fetch(s0 + d + DEPTH, d);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const int k = (kc0 + c) * 32 + li;
+            if (k < a.K) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                    atomicAdd(&a.dW[(size_t)j * a.K + k], acc[c][e]);
+                }
+            }
+        }
+    }
+    if (a.db) {
+        bsum += __shfl_xor(bsum, 32, 64);            // the two row parities of the same gate unit
+        if (kk == 0) atomicAdd(&a.db[j0 + li], bsum);
+    }
+}
+
 // column sums of a [R][N] row-major matrix into dst[N] (bias gradients): 64 columns x 4 row-lanes per workgroup,
 // 1024 rows per workgroup, one atomic per column per workgroup
 __global__ void colsum_kernel(size_t R, int N, const float *src, float *dst)
@@ -278,8 +368,13 @@ __global__ void adam_kernel(size_t n, float *w, const float *g, float *m, float 
 
 using namespace ost;
 
+static int os_dw_rps()
+{
+    const char *e = getenv("OS_DW_RPS");     // tuning knob (development)
+    return e ? atoi(e) : 512;
+}
+
 struct os_train_state {
-    rocblas_handle blas;
     float *act;   size_t act_floats;     // saved activations: L x 5 x [T][B][H]
     float *seq;   size_t seq_floats;     // SoA layer outputs [L][T][H][B] (forward inputs of the next layer)
     float *xs;    size_t xs_floats;      // SoA copy of the input [T][I][B]
@@ -294,7 +389,6 @@ static os_train_state *train_state(os_ctx *ctx)
     if (!ctx->train) {
         os_train_state *t = (os_train_state *)calloc(1, sizeof(os_train_state));
         if (!t) return nullptr;
-        if (rocblas_create_handle(&t->blas) != rocblas_status_success) { free(t); return nullptr; }
         ctx->train = t;
     }
     return (os_train_state *)ctx->train;
@@ -307,7 +401,6 @@ void os_train_destroy(os_ctx *ctx)
     float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->wT};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
-    rocblas_destroy_handle(t->blas);
     free(t);
     ctx->train = nullptr;
 }
@@ -393,7 +486,6 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
     if (os_ensure_scratch(ctx, &ts->wT, &ts->wT_floats, wT_total)) return -10;
     const size_t rows = (size_t)T * B;
     OS_HIP(ctx, hipMemsetAsync(grad_flat, 0, nparam * sizeof(float), s));
-    rocblas_set_stream(ts->blas, s);
 
     // ---- head ----
     const size_t fc_off = nparam - ((size_t)C * H + C);
@@ -420,7 +512,6 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
     float *dgi = ts->dg, *dgh = ts->dg + (size_t)T * B * H3;
     float *dxbuf[2] = {ts->dxy, ts->dxy + (size_t)T * B * Kmax};
     const float *dy = nullptr;
-    const float alpha = 1.0f, beta = 1.0f;
     for (int l = L - 1; l >= 0; l--) {
         const int K = l == 0 ? I : H;
         const float *Wih = ctx->gru_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
@@ -448,36 +539,26 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         if (RB == 2) hipLaunchKernelGGL(bwd_sweep_kernel<2>, grid, block, lds, s, a);
         else hipLaunchKernelGGL(bwd_sweep_kernel<1>, grid, block, lds, s, a);
         OS_HIP(ctx, hipGetLastError());
-        // ---- weight gradients (row-major C[3H][K] = col-major [K x 3H] = X_cm [K x R] . dG_cm^T [R x 3H]) ----
+        // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
-        if (l == 0) {
-            // input is (B, T, I) batch_first: one GEMM per step, rows strided by T*I
-            for (int t = 0; t < T; t++) {
-                if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, K, H3, B, &alpha,
-                                  x + (size_t)t * I, T * I, dgi + (size_t)t * B * H3, H3, &beta, gWih, K) != rocblas_status_success)
-                    return os_fail(ctx, -20, "rocblas_sgemm (dW_ih, layer 0) failed");
-            }
-        } else {
-            // one GEMM per step (8192-row reductions map onto many workgroups; a single T*B-long GEMM lands on 4 tiles)
-            const float *hin = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh;      // h of the layer below, [T][B][H]
-            for (int t = 0; t < T; t++) {
-                if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, K, H3, B, &alpha,
-                                  hin + (size_t)t * B * K, K, dgi + (size_t)t * B * H3, H3, &beta, gWih, K) != rocblas_status_success)
-                    return os_fail(ctx, -20, "rocblas_sgemm (dW_ih) failed");
-            }
-        }
         {
-            const float *hprev = base + 4 * tbh;                                 // h_{t-1} for t = 1..T-1
-            for (int t = 1; t < T; t++) {
-                if (rocblas_sgemm(ts->blas, rocblas_operation_none, rocblas_operation_transpose, H, H3, B, &alpha,
-                                  hprev + (size_t)(t - 1) * B * H, H, dgh + (size_t)t * B * H3, H3, &beta, gWhh, H) != rocblas_status_success)
-                    return os_fail(ctx, -20, "rocblas_sgemm (dW_hh) failed");
-            }
+            const int rps = os_dw_rps();               // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
+            DwArgs d1;
+            d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.rows_per_slice = rps;
+            d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
+            if (l == 0) { d1.X = x; d1.x_btf = 1; }
+            else { d1.X = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
+            hipLaunchKernelGGL(dw_kernel, dim3(H3 / 32, (unsigned)((rows + rps - 1) / rps)), dim3(64), 0, s, d1);
+            // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
+            DwArgs d2 = d1;
+            d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
+            d2.dW = gWhh; d2.db = nullptr;
+            if (T > 1)
+                hipLaunchKernelGGL(dw_kernel, dim3(H3 / 32, (unsigned)((rows - B + rps - 1) / rps)), dim3(64), 0, s, d2);
+            dim3 cg((H3 + 63) / 64, (unsigned)((rows + 1023) / 1024));
+            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
+            OS_HIP(ctx, hipGetLastError());
         }
-        dim3 cg((H3 + 63) / 64, (unsigned)((rows + 1023) / 1024));
-        hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgi, gbih);
-        hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
-        OS_HIP(ctx, hipGetLastError());
         dy = a.dx;
     }
     if (dx_out) {
