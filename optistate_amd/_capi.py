@@ -44,6 +44,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime, and the library must bind to that same copy (loading the system
+    # libamdhip64 before torch's leaves the process with two runtimes and os_create then sees no device)
+    import torch  # noqa: F401
     path = os.environ.get("OPTISTATE_HIP_LIB", LIB_PATH)      # A/B builds of the same C-ABI (development aid)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -m optistate_amd.build` "
