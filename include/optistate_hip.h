@@ -57,9 +57,11 @@ enum {
     OS_KF_SYMMETRIC_P       = 4,  /* with OS_KF_SEQUENTIAL_UPDATE (and not DENSE_FD): keep only the upper triangle of
                                      P in registers (P is symmetric in exact arithmetic); P0's upper triangle is used
                                      and the final P is written back mirrored.  ~2x faster; same 1e-4 parity bar. */
-    OS_FUSED_TWO_KERNEL     = 8   /* os_fused_run only: force the general two-kernel path (Kalman kernel writes the
+    OS_FUSED_TWO_KERNEL     = 8,  /* os_fused_run only: force the general two-kernel path (Kalman kernel writes the
                                      normalised feature rows to context scratch, GRU kernels read them) even where
                                      the single-kernel path applies (60 features, hidden 64, sequential+symmetric). */
+    OS_KF_LANE_PER_TRAJECTORY = 32 /* os_kf_run: never use the small-batch kernel (16 lanes per trajectory, row-parallel P),
+                                     which is otherwise chosen for sequential updates when B < 10,240 (the measured crossover). */
 };
 
 /* Replaces Kalman_Filter.__init__ (kalman_filter/kalman_filter.py:8-62): creates a context on cfg->device. */

@@ -10,6 +10,7 @@ OS_KF_SEQUENTIAL_UPDATE = 1
 OS_KF_DENSE_FD = 2
 OS_KF_SYMMETRIC_P = 4
 OS_FUSED_TWO_KERNEL = 8
+OS_KF_LANE_PER_TRAJECTORY = 32
 
 # every symbol include/optistate_hip.h declares
 EXPORTS = [

@@ -29,11 +29,23 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
     for (int i = 0; i < 10; i++) c->k.R[i * 10 + i] = 0.01f;
     c->r_is_diagonal = true;
     c->q_is_diagonal = true;
+    c->rows_kernel_below = 10240;   // measured crossover with the lane-per-trajectory kernels: ~10 k trajectories
+    {
+        const char *e = getenv("OS_KF_ROWS_BELOW");      // tuning knob (development)
+        if (e) c->rows_kernel_below = atoi(e);
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc((void **)&c->kf_qr, 244 * sizeof(float)) != hipSuccess ||
+        hipMemcpy(c->kf_qr, c->k.Q, 144 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->kf_qr + 144, c->k.R, 100 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        free(c);
+        return -10;
+    }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { free(c); return -10; }
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { (void)hipFree(c->kf_qr); free(c); return -10; }
     c->cu_count = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         // built for gfx950 only; refuse to pretend on anything else
+        (void)hipFree(c->kf_qr);
         free(c);
         return -14;
     }
@@ -47,7 +59,7 @@ void os_destroy(os_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     os_train_destroy(ctx);
     os_vit_destroy(ctx);
-    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm};
+    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)
@@ -74,6 +86,9 @@ int os_kf_set_noise(os_ctx *ctx, const float *Q_host, const float *R_host)
         for (int b = 0; b < 12; b++)
             if (a != b && Q_host[a * 12 + b] != 0.0f) qd = false;
     ctx->q_is_diagonal = qd;
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    OS_HIP(ctx, hipMemcpy(ctx->kf_qr, ctx->k.Q, 144 * sizeof(float), hipMemcpyHostToDevice));
+    OS_HIP(ctx, hipMemcpy(ctx->kf_qr + 144, ctx->k.R, 100 * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -167,6 +167,134 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
     a.status[b] = status;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small-batch variant: 16 lanes per trajectory (4 trajectories per wave), lane r of a group holds ROW r of P (12 VGPRs)
+// and x[r].  At B = 4096 the lane-per-trajectory kernels fill 64 of the 1024 SIMDs; this one fills all of them.  Row
+// broadcasts inside a 16-lane DPP row are single `row_share` moves, the rank-1 covariance updates are 12 FMAs per lane.
+// Scalars of a trajectory (inputs, rotation, dynamics, z) are computed redundantly by its 16 lanes.  Same arithmetic as
+// the sequential full-P form (update_sequential), so the same parity bars apply.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SRC>
+__device__ __forceinline__ float row_bcast(float v)
+{
+    // value of lane SRC of this lane's 16-lane row (DPP row_share)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + SRC, 0xf, 0xf, true));
+}
+
+template <bool AUX>
+__global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, const float *__restrict__ qmat)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+    const int b_raw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + grp;
+    const bool live = b_raw < a.B;
+    const int b = live ? b_raw : a.B - 1;
+    const int rr = r < 12 ? r : 11;                    // idle lanes 12-15 shadow row 11 (never broadcast from, never stored)
+    const size_t B = (size_t)a.B;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    const KfConst &k = a.k;
+
+    float Prow[NS], qrow[NS], xr;
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+        xr = buf_load(rx, voff, (uint32_t)rr * rowB);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            Prow[j] = buf_load(rP, voff, (uint32_t)(rr * NS + j) * rowB);
+            qrow[j] = qmat[rr * NS + j];
+        }
+    }
+    // per-lane row selectors for the structured F_d = I + dt F
+    const bool top = r < 3, mid = r >= 3 && r < 6;
+    int status = 0;
+    StepIn in;
+    load_step(a, 0, voff, rowB, in);
+    for (int t = 0; t < a.T; t++) {
+        // ---- gather the full prior state (replicated per lane) ----
+        float x[NS];
+        x[0] = row_bcast<0>(xr); x[1] = row_bcast<1>(xr); x[2] = row_bcast<2>(xr); x[3] = row_bcast<3>(xr);
+        x[4] = row_bcast<4>(xr); x[5] = row_bcast<5>(xr); x[6] = row_bcast<6>(xr); x[7] = row_bcast<7>(xr);
+        x[8] = row_bcast<8>(xr); x[9] = row_bcast<9>(xr); x[10] = row_bcast<10>(xr); x[11] = row_bcast<11>(xr);
+        float z[NM], pw[12];
+        measurement(in, z);
+        Rot rot = rotation(x[0], x[1], x[2]);
+        // ---- covariance predict, row-parallel: M = F_d P (rows), then P' = M F_d^T (columns, local) + Q ----
+        float g[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * rot.m[3 * kk + i];
+        const float cg0 = top ? (r == 0 ? g[0] : (r == 1 ? g[3] : g[6])) : 0.f;
+        const float cg1 = top ? (r == 0 ? g[1] : (r == 1 ? g[4] : g[7])) : 0.f;
+        const float cg2 = top ? (r == 0 ? g[2] : (r == 1 ? g[5] : g[8])) : 0.f;
+        const float cd = mid ? k.dt : 0.f;
+        const int src6 = (lane & ~15) | ((r + 6) & 15);
+        float M[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const float b6 = row_bcast<6>(Prow[j]), b7 = row_bcast<7>(Prow[j]), b8 = row_bcast<8>(Prow[j]);
+            const float up = __shfl(Prow[j], src6, 64);                 // row r+6 (rows 9..11 for lanes 3..5)
+            M[j] = Prow[j] + cg0 * b6 + cg1 * b7 + cg2 * b8 + cd * up;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8] + qrow[j];
+            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j] + qrow[3 + j];
+        }
+#pragma unroll
+        for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
+        // ---- dynamics (replicated), keep this lane's component ----
+        dynamics(x, rot, in.p, in.f, pw, k);
+        float xn = x[0];
+#pragma unroll
+        for (int i = 1; i < NS; i++) xn = (rr == i) ? x[i] : xn;
+        xr = xn;
+        if (a.p_rot_out && live && r < 12) {
+            float pv = pw[0];
+#pragma unroll
+            for (int i = 1; i < 12; i++) pv = (r == i) ? pw[i] : pv;
+            a.p_rot_out[((size_t)t * 12 + r) * B + b] = pv;
+        }
+        // prefetch the next step's inputs underneath the update
+        const int tn = (t + 1 < a.T) ? t + 1 : t;
+        load_step(a, tn, voff, rowB, in);
+        // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
+#define OS_ROW_UPDATE(A, S)                                                                  \
+        {                                                                                    \
+            float rowv[NS];                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) rowv[j] = row_bcast<S>(Prow[j]);   \
+            float sv = rowv[S] + k.R[A * NM + A];                                            \
+            if (!(sv > 0.f) || !(sv < 3.0e38f)) { status |= 1; sv = 1.0f; }                  \
+            const float inv = 1.0f / sv;                                                     \
+            const float innov = z[A] - row_bcast<S>(xr);                                     \
+            const float kc = Prow[S] * inv;                                                  \
+            xr += kc * innov;                                                                \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) Prow[j] -= kc * rowv[j];           \
+        }
+        OS_ROW_UPDATE(0, 0) OS_ROW_UPDATE(1, 1) OS_ROW_UPDATE(2, 2) OS_ROW_UPDATE(3, 5) OS_ROW_UPDATE(4, 6)
+        OS_ROW_UPDATE(5, 7) OS_ROW_UPDATE(6, 8) OS_ROW_UPDATE(7, 9) OS_ROW_UPDATE(8, 10) OS_ROW_UPDATE(9, 11)
+#undef OS_ROW_UPDATE
+        if (!(xr * 0.f == 0.f)) status |= 2;
+        if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
+        if (AUX && a.ptrace_out) {
+            float dg = Prow[0];
+#pragma unroll
+            for (int i = 1; i < NS; i++) dg = (r == i) ? Prow[i] : dg;
+            dg = r < 12 ? dg : 0.f;
+            dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
+            if (live && r == 0) a.ptrace_out[(size_t)t * B + b] = dg;
+        }
+    }
+    // ---- final state: lane r writes x[r] and row r of P; the status word is OR-reduced over the 16 lanes ----
+    status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
+    status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
+    if (live && r < 12) {
+        a.x[(size_t)r * B + b] = xr;
+#pragma unroll
+        for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = Prow[j];
+        if (r == 0) a.status[b] = status;
+    }
+}
+
 // ---- single pieces for the drop-in Kalman_Filter class (B is tiny there; latency-bound by design) ----
 
 __global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
@@ -297,7 +425,13 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
 #define OS_DISPATCH(SEQ, DENSE)                                                        \
     (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
           : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
-    if (seq && !dense && (flags & OS_KF_SYMMETRIC_P) && !a.kgain_out) {
+    if (seq && !dense && !feat && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) && a.B < ctx->rows_kernel_below && ctx->kf_qr) {
+        // small batch: 16 lanes per trajectory so that every SIMD gets a wave
+        dim3 grid((a.B + 15) / 16), block(256);                       // 4 waves x 4 trajectories per workgroup
+        if (aux) hipLaunchKernelGGL(kf_run_rows_kernel<true>, grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else hipLaunchKernelGGL(kf_run_rows_kernel<false>, grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        e = hipGetLastError();
+    } else if (seq && !dense && (flags & OS_KF_SYMMETRIC_P) && !a.kgain_out) {
         dim3 grid((a.B + 63) / 64), block(64);
         const bool qd = ctx->q_is_diagonal;
 #define OS_SYM(OUT)                                                                                        \

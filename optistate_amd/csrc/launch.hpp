@@ -15,6 +15,8 @@ struct os_ctx {
     int device;
     osk::KfConst k;
     bool r_is_diagonal, q_is_diagonal;
+    float *kf_qr;                        // device copy of Q (144) and R (100) for per-lane indexing (small-batch kernel)
+    int rows_kernel_below;               // use the 16-lanes-per-trajectory kernel when B is below this
     char err[512];
     // GRU state (owned scratch)
     os_gru_dims gru;

@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL  # noqa: F401
+from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
+                    OS_KF_LANE_PER_TRAJECTORY)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -109,7 +110,7 @@ class Engine:
         return c_t4b.permute(0, 2, 1).contiguous().view(torch.int32).reshape(c_t4b.shape[0], c_t4b.shape[2])
 
     def kf_run(self, p, f, dp, imu, contact, x, P, body_ref=None, sequential=None, dense_fd=False,
-               want_p_rot=False, want_trace=False, want_gain=False, symmetric=None):
+               want_p_rot=False, want_trace=False, want_gain=False, symmetric=None, lane_per_trajectory=False):
         """Runs T filter steps for B trajectories.  All stream arguments are SoA device tensors; x [12][B] and
         P [144][B] are updated in place.  Returns dict(x_out [T][12][B], status [B], p_rot?, P_trace?, K_gain?)."""
         T, _, B = p.shape
@@ -118,7 +119,7 @@ class Engine:
         if symmetric is None:
             symmetric = sequential and not dense_fd
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
-                (OS_KF_SYMMETRIC_P if symmetric else 0)
+                (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_KF_LANE_PER_TRAJECTORY if lane_per_trajectory else 0)
         dev = self.device
         x_out = torch.empty((T, 12, B), dtype=torch.float32, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)

@@ -33,12 +33,18 @@ def run(eng, g, Q, R, B, **kw):
     return r
 
 
+# kernel families: batch (Cholesky), sequential full-P lanes, sequential symmetric lanes, 16-lanes-per-trajectory rows
+VARIANTS = [dict(sequential=False, symmetric=False), dict(sequential=True, symmetric=False, lane_per_trajectory=True),
+            dict(sequential=True, symmetric=True, lane_per_trajectory=True), dict(sequential=True, symmetric=True)]
+VIDS = ["batch", "seq-lanes", "sym-lanes", "rows"]
+
+
 @pytest.mark.parametrize("s", [0, 1])
-@pytest.mark.parametrize("sequential,symmetric", [(False, False), (True, False), (True, True)])
-def test_g3_trajectory_matches_reference(eng, s, sequential, symmetric):
+@pytest.mark.parametrize("v", VARIANTS, ids=VIDS)
+def test_g3_trajectory_matches_reference(eng, s, v):
     g = load_golden("kf_g3_traj.npz")
-    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], 2, sequential=sequential, symmetric=symmetric, want_p_rot=True,
-            want_trace=True, want_gain=not sequential)
+    sequential = v["sequential"]
+    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], 2, want_p_rot=True, want_trace=True, want_gain=not sequential, **v)
     xo = eng.unpack(r["x_out"]).cpu().numpy()
     pr = eng.unpack(r["p_rot"]).cpu().numpy()
     for b in range(2):
@@ -56,11 +62,11 @@ def test_g3_trajectory_matches_reference(eng, s, sequential, symmetric):
 
 
 @pytest.mark.parametrize("s", [0, 1])
-@pytest.mark.parametrize("sequential,symmetric", [(False, False), (True, False), (True, True)])
-def test_g4_batch_matches_reference(eng, s, sequential, symmetric):
+@pytest.mark.parametrize("v", VARIANTS, ids=VIDS)
+def test_g4_batch_matches_reference(eng, s, v):
     g = load_golden("kf_g4_batch.npz")
     B = g["p"].shape[0]
-    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], B, sequential=sequential, symmetric=symmetric)
+    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], B, **v)
     xo = eng.unpack(r["x_out"]).cpu().numpy()
     err = np.abs(xo - g[f"s{s}_x"]).max()
     assert err < STATE_TOL, err
@@ -100,11 +106,11 @@ def test_large_batch_vs_oracle(eng):
     ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)),
                            Q_FITTED, R_FITTED, aux=False)
     g = dict(d)
-    for seq, sym in ((True, True), (True, False), (False, False)):
-        r = run(eng, g, Q_FITTED, R_FITTED, B, sequential=seq, symmetric=sym)
+    for v in VARIANTS:
+        r = run(eng, g, Q_FITTED, R_FITTED, B, **v)
         xo = eng.unpack(r["x_out"]).cpu().numpy()
         err = np.abs(xo - ref["x"]).max()
-        assert err < STATE_TOL, (seq, sym, err)
+        assert err < STATE_TOL, (v, err)
         Pf = r["P_final"].cpu().numpy().T.reshape(B, 12, 12)
         assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
         assert int(r["status"].abs().sum()) == 0
@@ -129,9 +135,10 @@ def test_status_flags_nonfinite_input(eng):
     from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
     d = synth_numpy(64, 4, seed=9)
     d["imu"][3, 1, 0] = np.nan
-    r = run(eng, d, Q_DEFAULT, R_DEFAULT, 64, sequential=True)
-    st = r["status"].cpu().numpy()
-    assert st[3] != 0 and (np.delete(st, 3) == 0).all()
+    for v in VARIANTS:
+        r = run(eng, d, Q_DEFAULT, R_DEFAULT, 64, **v)
+        st = r["status"].cpu().numpy()
+        assert st[3] != 0 and (np.delete(st, 3) == 0).all(), v
 
 
 def test_pack_unpack_roundtrip(eng):

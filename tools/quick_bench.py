@@ -32,12 +32,12 @@ def timeit(fn, n=a.iters):
 
 
 steps = a.B * a.T
-for seq, sym in ((True, True), (True, False), (False, False)):
+for seq, sym, lanes in ((True, True, False), (True, True, True), (True, False, True), (False, False, True)):
     def kf():
         x = d["x0"].clone(); P = d["P0"].clone()
-        eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], c, x, P, sequential=seq, symmetric=sym)
+        eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], c, x, P, sequential=seq, symmetric=sym, lane_per_trajectory=lanes)
     ms = timeit(kf)
-    print(f"kf_run seq={seq} sym={sym}: {ms:.3f} ms  {steps / ms * 1e3:.3e} steps/s  {steps * 220 / ms * 1e3 / 1e9:.1f} GB/s algorithmic")
+    print(f"kf_run seq={seq} sym={sym} force_lanes={lanes}: {ms:.3f} ms  {steps / ms * 1e3:.3e} steps/s  {steps * 220 / ms * 1e3 / 1e9:.1f} GB/s algorithmic")
 
 torch.manual_seed(0)
 m = RNN(60, a.H, a.L, 24, torch.device("cuda"))
