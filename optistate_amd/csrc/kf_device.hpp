@@ -183,11 +183,8 @@ __device__ __forceinline__ void measurement(const StepIn &in, float *z /*10*/)
 // next_state (misc/force_controller.py:269-291): x <- (I + A dt) x + B dt f + dt g, foot positions rotated
 // to the world frame (returned in pw: the reference mutates the caller's p, :274-277).
 // I_hat^-1 = R diag(1/I) R^T (R orthogonal), tau = sum_j pw_j x f_j.
-// DEFER = true: branch-free variant for code that must stay in one basic block; the (rare) float64 truncation term of
-// theta is NOT applied here: *need64 says whether theta_trunc_apply() has to run (before the update), wprior keeps omega.
-template <bool DEFER = false>
 __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p, const float *f, float *pw,
-                                         const KfConst &k, bool *need64 = nullptr, float *wprior = nullptr)
+                                         const KfConst &k)
 {
     float tau[3] = {0.f, 0.f, 0.f}, fs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -216,10 +213,7 @@ __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p,
 #pragma unroll
     for (int i = 0; i < 9; i++) amax = fmaxf(amax, fabsf(r.m[i]));
     float w0 = x[6], w1 = x[7], w2 = x[8];
-    if (DEFER) {
-        *need64 = amax >= 0.9999995f;
-        wprior[0] = w0; wprior[1] = w1; wprior[2] = w2;
-    } else if (amax >= 0.9999995f) {
+    if (amax >= 0.9999995f) {
         float A[9];
         trunc_block_f64(x[0], x[1], x[2], A);
         x[0] += k.dt * (A[0] * w0 + A[1] * w1 + A[2] * w2);
@@ -232,17 +226,6 @@ __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p,
     x[9] += k.dt * (fs[0] * k.inv_mass);
     x[10] += k.dt * (fs[1] * k.inv_mass);
     x[11] += k.dt * (fs[2] * k.inv_mass) + k.dt * k.gz;
-}
-
-// The deferred truncation term: theta (x[0:3]) still holds the prior angles, wprior the prior angular rate.
-__device__ __forceinline__ void theta_trunc_apply(float *x, const float *wprior, const KfConst &k)
-{
-    float A[9];
-    trunc_block_f64(x[0], x[1], x[2], A);
-    const float t0 = k.dt * (A[0] * wprior[0] + A[1] * wprior[1] + A[2] * wprior[2]);
-    const float t1 = k.dt * (A[3] * wprior[0] + A[4] * wprior[1] + A[5] * wprior[2]);
-    const float t2 = k.dt * (A[6] * wprior[0] + A[7] * wprior[1] + A[8] * wprior[2]);
-    x[0] += t0; x[1] += t1; x[2] += t2;
 }
 
 // P <- F_d P F_d^T + Q with F_d = I + dt F, F[0:3,6:9] = R^T, F[3:6,9:12] = I
@@ -581,17 +564,6 @@ __device__ __forceinline__ void kf_step_front_sym(float *x, float *U, const Step
     Rot r = rotation(x[0], x[1], x[2]);
     cov_predict_sym<QDIAG>(U, r, k);
     dynamics(x, r, in.p, in.f, pw, k);
-}
-
-// Branch-free front half (one basic block): the float64 truncation term is deferred, see dynamics<true>.
-template <bool QDIAG>
-__device__ __forceinline__ void kf_step_front_sym_deferred(float *x, float *U, const StepIn &in, const KfConst &k, float *z,
-                                                           float *pw, bool *need64, float *wprior)
-{
-    measurement(in, z);
-    Rot r = rotation(x[0], x[1], x[2]);
-    cov_predict_sym<QDIAG>(U, r, k);
-    dynamics<true>(x, r, in.p, in.f, pw, k, need64, wprior);
 }
 
 __device__ __forceinline__ int kf_step_back_sym(float *x, float *U, const float *z, const KfConst &k)
