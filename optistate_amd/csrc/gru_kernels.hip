@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
     const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
     const float *wh = wx + (size_t)a.KPx * 3 * 64;
     const float *bias = wh + (size_t)a.KPh * 3 * 64;
-    const float b_r = bias[li], b_z = bias[32 + li], b_in = bias[64 + li], b_hn = bias[96 + li];
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float nb_r = -LOG2E * bias[li], nb_z = -LOG2E * bias[32 + li], nb_n = 2.0f * LOG2E * bias[64 + li], b_hn = bias[96 + li];
 
     // A-fragment rows of this lane, clamped to the last trajectory (rows past B only feed their own, never-stored
     // outputs); xoff = byte offset of (row, k = lh) inside one step's [K][B] block: the k-pair is added as an SGPR offset
@@ -151,11 +152,13 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
             for (int e = 0; e < 16; e++) {
                 const int row = (row_blk0 + rb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 float *hp = &hl[row * HS + chunk * 32 + li];
-                const float r = sigmoidf_(acc[rb][0][e] + b_r);
-                const float z = sigmoidf_(acc[rb][1][e] + b_z);
+                // biases folded into the exp2 arguments: one FMA per gate instead of add + mul
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
+                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
                 const float ghn = acc[rb][3][e] + b_hn;
-                const float n = tanhf_(acc[rb][2][e] + b_in + r * ghn);
-                const float hn = (1.0f - z) * n + z * (*hp);
+                const float u = fmaf(r, ghn, acc[rb][2][e]);
+                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
+                const float hn = fmaf(z, *hp - n, n);          // (1 - z) n + z h
                 *hp = hn;
                 if (a.sv_r) {
                     const int g = tile_row0 + row;
