@@ -252,72 +252,101 @@ struct DwArgs {
     float *db;                // [H3] or null
 };
 
-__global__ __launch_bounds__(64, 2) void dw_kernel(const DwArgs a)
+// Workgroup = 4 waves = 4 gate chunks (wave w owns chunk 4*blockIdx.x + w) over one slice of rows.  The X rows of a
+// 32-row tile are staged ONCE per workgroup through LDS (register-staged double buffering: the global loads of tile i+1
+// are in flight while tile i feeds 16 x 6 MFMAs per wave), so X is read from L2/HBM once per 4 gate chunks instead of once
+// per chunk; each wave streams its own dG column chunk straight from memory, one step ahead.
+constexpr int DW_TR = 32;            // rows per tile
+constexpr int DW_KMAX = 192;         // input columns held per pass (6 chunks of 32)
+
+__global__ __launch_bounds__(256, 1) void dw_kernel(const DwArgs a)
 {
-    const int lane = threadIdx.x, li = lane & 31, kk = lane >> 5;
-    const int j0 = blockIdx.x * 32;
+    __shared__ float Xs[2][DW_TR][DW_KMAX];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const bool jok = j0 < a.H3;
     const size_t r0 = a.r_begin + (size_t)blockIdx.y * a.rows_per_slice;
     size_t r1 = r0 + a.rows_per_slice;
     if (r1 > a.r_end) r1 = a.r_end;
     if (r0 >= r1) return;
     const int nkc = (a.K + 31) / 32;
-    const int nsteps = (int)((r1 - r0 + 1) / 2);
+    const int ntiles = (int)((r1 - r0 + DW_TR - 1) / DW_TR);
     float bsum = 0.f;
-    constexpr int DEPTH = 4;                      // 2-row steps in flight: 4 x 7 loads cover an HBM round trip
+    auto xrow_off = [&](size_t rr) -> size_t {
+        const size_t xr = rr - a.x_row_shift;
+        return a.x_btf ? ((xr % a.B) * a.T + xr / a.B) * (size_t)a.K : xr * (size_t)a.K;
+    };
     for (int kc0 = 0; kc0 < nkc; kc0 += 6) {
+        const int kbase = kc0 * 32, kw = (a.K - kbase) < DW_KMAX ? (a.K - kbase) : DW_KMAX;   // columns of this pass
         f32x16 acc[6];
 #pragma unroll
         for (int c = 0; c < 6; c++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
-        float av[DEPTH], bv[DEPTH][6];
-        auto fetch = [&](int step, int slot) {
-            const size_t rr = r0 + 2 * (size_t)step + kk;
-            const bool ok = step < nsteps && rr < r1;
-            const size_t rc = ok ? rr : r0;                       // clamp: masked lanes read a valid row, value zeroed
-            const float v = a.dG[rc * a.H3 + j0 + li];
-            av[slot] = ok ? v : 0.f;
-            size_t xo;
-            if (a.x_btf) {
-                const size_t xr = rc - a.x_row_shift;
-                xo = ((xr % a.B) * a.T + xr / a.B) * a.K;
-            } else {
-                xo = (rc - a.x_row_shift) * a.K;
-            }
+        // staging registers: 32 rows x 192 columns / 256 threads = 24 floats per thread (thread -> column, 3 x 8 rows)
+        float stg[24];
+        const int scol = threadIdx.x % DW_KMAX, srow0 = threadIdx.x / DW_KMAX;      // 256 threads: rows srow0, srow0+?...
+        auto stage_load = [&](int tile) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const int k = (kc0 + c) * 32 + li;
-                const float b = a.X[xo + (k < a.K ? k : 0)];
-                bv[slot][c] = (ok && k < a.K) ? b : 0.f;
+            for (int i = 0; i < 24; i++) {
+                const int flat = threadIdx.x + 256 * i;                             // 0 .. 6143
+                const int row = flat / DW_KMAX, col = flat % DW_KMAX;
+                const size_t rr = r0 + (size_t)tile * DW_TR + row;
+                const bool ok = tile < ntiles && rr < r1 && col < kw;
+                stg[i] = ok ? a.X[xrow_off(rr) + kbase + col] : 0.f;
             }
         };
+        auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) fetch(d, d);
-        for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
-#pragma unroll
-            for (int d = 0; d < DEPTH; d++) {
-                if (s0 + d < nsteps) {
-                    if (kc0 == 0) bsum += av[d];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], bv[d][c], acc[c], 0, 0, 0);
-                    fetch(s0 + d + DEPTH, d);
+            for (int i = 0; i < 24; i++) {
+                const int flat = threadIdx.x + 256 * i;
+                Xs[buf][flat / DW_KMAX][flat % DW_KMAX] = stg[i];
+            }
+        };
+        (void)scol; (void)srow0;
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        for (int tile = 0; tile < ntiles; tile++) {
+            const int buf = tile & 1;
+            stage_load(tile + 1);                                   // in flight during this tile's MFMAs
+            const size_t rt = r0 + (size_t)tile * DW_TR;
+            float av_next = 0.f;
+            {
+                const size_t rr = rt + kk;
+                av_next = (jok && rr < r1) ? a.dG[rr * a.H3 + j0 + li] : 0.f;
+            }
+#pragma unroll 4
+            for (int st = 0; st < DW_TR / 2; st++) {
+                const float av = av_next;
+                {
+                    const size_t rr = rt + 2 * (st + 1) + kk;
+                    av_next = (jok && st + 1 < DW_TR / 2 && rr < r1) ? a.dG[rr * a.H3 + j0 + li] : 0.f;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (kc0 == 0) bsum += av;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Xs[buf][2 * st + kk][c * 32 + li], acc[c], 0, 0, 0);
+            }
+            stage_store(buf ^ 1);
+            __syncthreads();
+        }
+        if (jok) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int k = kbase + c * 32 + li;
+                if (k < a.K) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                        atomicAdd(&a.dW[(size_t)j * a.K + k], acc[c][e]);
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            const int k = (kc0 + c) * 32 + li;
-            if (k < a.K) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                    atomicAdd(&a.dW[(size_t)j * a.K + k], acc[c][e]);
-                }
-            }
-        }
+        __syncthreads();
     }
-    if (a.db) {
+    if (a.db && jok) {
         bsum += __shfl_xor(bsum, 32, 64);            // the two row parities of the same gate unit
         if (kk == 0) atomicAdd(&a.db[j0 + li], bsum);
     }
@@ -371,7 +400,7 @@ using namespace ost;
 static int os_dw_rps()
 {
     const char *e = getenv("OS_DW_RPS");     // tuning knob (development)
-    return e ? atoi(e) : 512;
+    return e ? atoi(e) : 1024;
 }
 
 struct os_train_state {
@@ -548,13 +577,13 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
             d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
             else { d1.X = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
-            hipLaunchKernelGGL(dw_kernel, dim3(H3 / 32, (unsigned)((rows + rps - 1) / rps)), dim3(64), 0, s, d1);
+            hipLaunchKernelGGL(dw_kernel, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
             // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
             DwArgs d2 = d1;
             d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
             d2.dW = gWhh; d2.db = nullptr;
             if (T > 1)
-                hipLaunchKernelGGL(dw_kernel, dim3(H3 / 32, (unsigned)((rows - B + rps - 1) / rps)), dim3(64), 0, s, d2);
+                hipLaunchKernelGGL(dw_kernel, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
             dim3 cg((H3 + 63) / 64, (unsigned)((rows + 1023) / 1024));
             hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
             OS_HIP(ctx, hipGetLastError());
