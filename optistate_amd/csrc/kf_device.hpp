@@ -272,19 +272,23 @@ __device__ __forceinline__ void cov_predict(float *P, const Rot &r, const KfCons
 // predict_mpc covariance (kalman_filter/kalman_filter.py:153-158): F_d = element-wise exp(dt F), i.e.
 // ones everywhere except exp(dt R^T_ij) in [0:3,6:9] and e^dt on the diagonal of [3:6,9:12].
 // F_d = 1 1^T + E  ->  F_d P F_d^T evaluated through column/row sums plus the sparse E.
-__device__ __forceinline__ void cov_predict_dense(float *P, const Rot &rb, const KfConst &k)
+// PT = double in the batched kernel: the all-ones F_d adds a common-mode term ~sum(P) (1e2..1e4) to every entry, the
+// following update has to cancel it again against R ~ 1e-4, and float32 keeps only ~1e-2 of the state through that
+// (measured); float64 covariance arithmetic restores the 1e-4 bar for this variant.
+template <typename PT>
+__device__ __forceinline__ void cov_predict_dense(PT *P, const Rot &rb, const KfConst &k)
 {
-    float e[9];
+    PT e[9];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++) e[3 * i + kk] = expm1f(k.dt * rb.m[3 * kk + i]);
-    float ed = expm1f(k.dt);
-    float M[NS * NS];
+        for (int kk = 0; kk < 3; kk++) e[3 * i + kk] = (PT)expm1((double)k.dt * (double)rb.m[3 * kk + i]);
+    PT ed = (PT)expm1((double)k.dt);
+    PT M[NS * NS];
     // M = F_d P = 1 (1^T P) + E P
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        float cs = 0.f;
+        PT cs = 0;
 #pragma unroll
         for (int i = 0; i < NS; i++) cs += P[i * NS + j];
 #pragma unroll
@@ -298,7 +302,7 @@ __device__ __forceinline__ void cov_predict_dense(float *P, const Rot &rb, const
     // P = M F_d^T = (M 1) 1^T + M E^T
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        float rs = 0.f;
+        PT rs = 0;
 #pragma unroll
         for (int j = 0; j < NS; j++) rs += M[i * NS + j];
 #pragma unroll
@@ -315,78 +319,83 @@ __device__ __forceinline__ void cov_predict_dense(float *P, const Rot &rb, const
 //   y = z - x[sel]; S = P[sel,sel] + R; K = P[:,sel] S^-1; x += K y; P <- P - K P[sel,:]
 // S^-1 is applied through the Cholesky factor S = L L^T (S is symmetric positive definite; unpivoted and
 // branch-free, which suits 64 lanes in lock-step).  Returns status bits.
-template <bool WANT_K>
-__device__ __forceinline__ int update_batch(float *x, float *P, const float *z, const KfConst &k, float *Kout,
+template <bool WANT_K, typename PT = float>
+__device__ __forceinline__ int update_batch(float *x, PT *P, const float *z, const KfConst &k, float *Kout,
                                             float *kgain)
 {
     int status = 0;
-    float L[NM * (NM + 1) / 2];   // packed lower triangle, L[a(a+1)/2 + b]
-    float dinv[NM];
+    PT L[NM * (NM + 1) / 2];   // packed lower triangle, L[a(a+1)/2 + b]
+    PT dinv[NM];
 #pragma unroll
     for (int a = 0; a < NM; a++)
 #pragma unroll
         for (int b = 0; b <= a; b++)
             // symmetrised entry: the reference's S is symmetric up to rounding of P
-            L[a * (a + 1) / 2 + b] = 0.5f * (P[SEL[a] * NS + SEL[b]] + P[SEL[b] * NS + SEL[a]]) +
-                                     0.5f * (k.R[a * NM + b] + k.R[b * NM + a]);
+            L[a * (a + 1) / 2 + b] = (PT)0.5 * (P[SEL[a] * NS + SEL[b]] + P[SEL[b] * NS + SEL[a]]) +
+                                     (PT)(0.5f * (k.R[a * NM + b] + k.R[b * NM + a]));
 #pragma unroll
     for (int j = 0; j < NM; j++) {
-        float d = L[j * (j + 1) / 2 + j];
+        PT d = L[j * (j + 1) / 2 + j];
 #pragma unroll
         for (int q = 0; q < j; q++) d -= L[j * (j + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
-        if (!(d > 0.f) || !(d < 3.0e38f)) { status |= 1; d = 1.0f; }
-        float di = rsqrtf(d);
-        // one Newton step: rsqrtf is ~1 ulp on gfx950 but keep the factor tight for cond(S) ~ 1e6
-        di = di * (1.5f - 0.5f * d * di * di);
+        if (!(d > 0) || !(d < (PT)3.0e38)) { status |= 1; d = 1; }
+        PT di;
+        if (sizeof(PT) == 8) {
+            di = (PT)(1.0 / sqrt((double)d));
+        } else {
+            di = (PT)rsqrtf((float)d);
+            // one Newton step: rsqrtf is ~1 ulp on gfx950 but keep the factor tight for cond(S) ~ 1e6
+            di = di * ((PT)1.5 - (PT)0.5 * d * di * di);
+        }
         dinv[j] = di;
         L[j * (j + 1) / 2 + j] = d * di;
 #pragma unroll
         for (int i = j + 1; i < NM; i++) {
-            float s = L[i * (i + 1) / 2 + j];
+            PT s = L[i * (i + 1) / 2 + j];
 #pragma unroll
             for (int q = 0; q < j; q++) s -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
             L[i * (i + 1) / 2 + j] = s * di;
         }
     }
     // K[i,:] = solve(S, P[i,sel]) for each of the 12 rows (S symmetric: K = P[:,sel] S^-1)
-    float K[NS * NM];
+    PT K[NS * NM];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        float y[NM];
+        PT y[NM];
 #pragma unroll
         for (int a = 0; a < NM; a++) {
-            float s = P[i * NS + SEL[a]];
+            PT s = P[i * NS + SEL[a]];
 #pragma unroll
             for (int q = 0; q < a; q++) s -= L[a * (a + 1) / 2 + q] * y[q];
             y[a] = s * dinv[a];
         }
 #pragma unroll
         for (int a = NM - 1; a >= 0; a--) {
-            float s = y[a];
+            PT s = y[a];
 #pragma unroll
             for (int q = a + 1; q < NM; q++) s -= L[q * (q + 1) / 2 + a] * K[i * NM + q];
             K[i * NM + a] = s * dinv[a];
         }
     }
-    float innov[NM];
+    PT innov[NM];
 #pragma unroll
-    for (int a = 0; a < NM; a++) innov[a] = z[a] - x[SEL[a]];
+    for (int a = 0; a < NM; a++) innov[a] = (PT)z[a] - (PT)x[SEL[a]];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        float s = 0.f;
+        PT s = 0;
 #pragma unroll
         for (int a = 0; a < NM; a++) s += K[i * NM + a] * innov[a];
-        x[i] += s;
+        x[i] = (float)((PT)x[i] + s);
     }
     // P <- P - K P[sel,:], one column at a time (the selected rows of the OLD column are needed)
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        float c[NM];
+        PT c[NM];
 #pragma unroll
         for (int a = 0; a < NM; a++) c[a] = P[SEL[a] * NS + j];
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            float s = 0.f;
+            PT s = 0;
 #pragma unroll
             for (int a = 0; a < NM; a++) s += K[i * NM + a] * c[a];
             P[i * NS + j] -= s;
@@ -395,12 +404,12 @@ __device__ __forceinline__ int update_batch(float *x, float *P, const float *z, 
     if (WANT_K) {
         if (Kout) {
 #pragma unroll
-            for (int i = 0; i < NS * NM; i++) Kout[i] = K[i];
+            for (int i = 0; i < NS * NM; i++) Kout[i] = (float)K[i];
         }
-        float t = 0.f;   // np.trace of the 12x10 K sums its 10 main-diagonal entries (kalman_filter.py:174)
+        PT t = 0;   // np.trace of the 12x10 K sums its 10 main-diagonal entries (kalman_filter.py:174)
 #pragma unroll
         for (int a = 0; a < NM; a++) t += K[a * NM + a];
-        *kgain = t;
+        *kgain = (float)t;
     }
     return status;
 }
@@ -408,22 +417,23 @@ __device__ __forceinline__ int update_batch(float *x, float *P, const float *z, 
 // Sequential (one measurement at a time) form of the same update; exact-arithmetic identical to the batch
 // form when R is diagonal, which every Q/R set of the reference is (settings.py:30,
 // data_collection/data_conversion_Kalman_to_Training.py:103-105 np.diag).  No factorisation, 24 temporaries.
-__device__ __forceinline__ int update_sequential(float *x, float *P, const float *z, const KfConst &k)
+template <typename PT = float>
+__device__ __forceinline__ int update_sequential(float *x, PT *P, const float *z, const KfConst &k)
 {
     int status = 0;
 #pragma unroll
     for (int a = 0; a < NM; a++) {
         const int sa = SEL[a];
-        float s = P[sa * NS + sa] + k.R[a * NM + a];
-        if (!(s > 0.f) || !(s < 3.0e38f)) { status |= 1; s = 1.0f; }
-        float inv = 1.0f / s;
-        float innov = z[a] - x[sa];
-        float kc[NS], row[NS];
+        PT s = P[sa * NS + sa] + (PT)k.R[a * NM + a];
+        if (!(s > 0) || !(s < (PT)3.0e38)) { status |= 1; s = 1; }
+        PT inv = (PT)1 / s;
+        PT innov = (PT)z[a] - (PT)x[sa];
+        PT kc[NS], row[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) { kc[i] = P[i * NS + sa] * inv; row[i] = P[sa * NS + i]; }
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            x[i] += kc[i] * innov;
+            x[i] = (float)((PT)x[i] + kc[i] * innov);
 #pragma unroll
             for (int j = 0; j < NS; j++) P[i * NS + j] -= kc[i] * row[j];
         }
@@ -521,12 +531,13 @@ __device__ __forceinline__ float trace_sym(const float *U)
     return t;
 }
 
-__device__ __forceinline__ float trace12(const float *P)
+template <typename PT>
+__device__ __forceinline__ float trace12(const PT *P)
 {
-    float t = 0.f;
+    PT t = 0;
 #pragma unroll
     for (int i = 0; i < NS; i++) t += P[i * NS + i];
-    return t;
+    return (float)t;
 }
 
 __device__ __forceinline__ int finite_status(const float *x)
@@ -540,8 +551,8 @@ __device__ __forceinline__ int finite_status(const float *x)
 // One full filter step, split in two so the caller can reuse the input registers between the halves:
 //   kf_step_front: everything that consumes the step's inputs (measurement, covariance predict, dynamics)
 //   kf_step_back : the measurement update (the long part; needs only z)
-template <bool DENSE, bool QDIAG>
-__device__ __forceinline__ void kf_step_front(float *x, float *P, const StepIn &in, const float *body_ref /*3 angles*/,
+template <bool DENSE, bool QDIAG, typename PT>
+__device__ __forceinline__ void kf_step_front(float *x, PT *P, const StepIn &in, const float *body_ref /*3 angles*/,
                                               const KfConst &k, float *z, float *pw)
 {
     measurement(in, z);
@@ -550,7 +561,7 @@ __device__ __forceinline__ void kf_step_front(float *x, float *P, const StepIn &
         Rot rb = rotation(body_ref[0], body_ref[1], body_ref[2]);
         cov_predict_dense(P, rb, k);
     } else {
-        cov_predict<QDIAG>(P, r, k);
+        if constexpr (sizeof(PT) == 4) cov_predict<QDIAG>(P, r, k);
     }
     dynamics(x, r, in.p, in.f, pw, k);
 }
@@ -571,13 +582,13 @@ __device__ __forceinline__ int kf_step_back_sym(float *x, float *U, const float 
     return update_sequential_sym(x, U, z, k) | finite_status(x);
 }
 
-template <bool SEQ, bool AUX>
-__device__ __forceinline__ int kf_step_back(float *x, float *P, const float *z, const KfConst &k, float *ptrace,
+template <bool SEQ, bool AUX, typename PT>
+__device__ __forceinline__ int kf_step_back(float *x, PT *P, const float *z, const KfConst &k, float *ptrace,
                                             float *kgain)
 {
     int st;
     if (SEQ) st = update_sequential(x, P, z, k);
-    else st = update_batch<AUX>(x, P, z, k, nullptr, kgain);
+    else st = update_batch<AUX, PT>(x, P, z, k, nullptr, kgain);
     if (AUX) *ptrace = trace12(P);
     return st | finite_status(x);
 }

@@ -1,5 +1,7 @@
 // kf_kernels.hip -- batched Kalman filter kernels for gfx950: one trajectory per lane, the whole T-step
 // recurrence inside one launch, x/P resident in VGPRs, inputs streamed coalesced from [T][field][B].
+#include <type_traits>
+
 #include "kf_device.hpp"
 #include "kf_args.hpp"
 #include "launch.hpp"
@@ -23,13 +25,16 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
     if (b >= a.B) return;
     const size_t B = (size_t)a.B;
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
-    float x[NS], P[NS * NS];
+    // the predict_mpc covariance (DENSE) is carried in float64: see cov_predict_dense
+    using PT = typename std::conditional<DENSE, double, float>::type;
+    float x[NS];
+    PT P[NS * NS];
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
 #pragma unroll
         for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
 #pragma unroll
-        for (int i = 0; i < NS * NS; i++) P[i] = buf_load(rP, voff, i * rowB);
+        for (int i = 0; i < NS * NS; i++) P[i] = (PT)buf_load(rP, voff, i * rowB);
     }
     int status = 0;
     StepIn in;
@@ -42,7 +47,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
     }
     for (int t = 0; t < a.T; t++) {
         float z[NM], pw[12], ptrace = 0.f, kgain = 0.f;
-        kf_step_front<DENSE, QDIAG>(x, P, in, bref, a.k, z, pw);
+        kf_step_front<DENSE, QDIAG, PT>(x, P, in, bref, a.k, z, pw);
         rsrc_t rfeat;
         if (FEAT) {
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 #pragma unroll
             for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
         }
-        status |= kf_step_back<SEQ, AUX>(x, P, z, a.k, &ptrace, &kgain);
+        status |= kf_step_back<SEQ, AUX, PT>(x, P, z, a.k, &ptrace, &kgain);
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 #pragma unroll
         for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
 #pragma unroll
-        for (int i = 0; i < NS * NS; i++) buf_store(rP, voff, i * rowB, P[i]);
+        for (int i = 0; i < NS * NS; i++) buf_store(rP, voff, i * rowB, (float)P[i]);
     }
     a.status[b] = status;
 }

@@ -131,9 +131,32 @@ class Kalman_Filter:
         self._predict(p, self.f[:, 0], body_ref=body_ref)
 
     def estimate_state_mpc(self, imu, p, dp, body_ref, contact, f=None):
-        """kalman_filter.py:176-182."""
+        """kalman_filter.py:176-182.  Runs odometry + predict_mpc + update as ONE T = 1 launch of the batched kernel, which
+        carries the predict_mpc covariance in float64 between the predict and the update (its element-wise exp(dt F) makes P
+        ill-conditioned for float32 there); attributes x, P, z, x_model is not split out, P_trace, K_gain and f are set; `K`
+        itself is only produced by update()."""
+        if f is None:
+            raise NotImplementedError("estimate_state_mpc needs the ground-reaction forces f: the casadi/qpOASES convex MPC "
+                                      "(misc/force_controller.py:15-225) is outside this library's scope")
+        e = self._eng
+        self._sync_noise()
+        self.f = np.asarray(f, dtype=np.float64).reshape(12, -1)
         odom = self.get_odom(p, dp, contact, imu)
         self.set_measurements(imu, odom)
-        self.predict_mpc(p, body_ref, contact, f=f)
-        self.update()
+        col = lambda a, n: torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(-1)[:n].reshape(1, n, 1)).to(self._dev)
+        c = np.asarray(contact).reshape(4)
+        packed = int(sum((int(c[k]) & 0xff) << (8 * k) for k in range(4)))
+        ct = torch.tensor([[packed]], dtype=torch.int32, device=self._dev)
+        xt = self._up(self.x, 12)
+        Pt = self._up(np.asarray(self.P, dtype=np.float64).reshape(144), 144)
+        r = e.kf_run(col(p, 12), col(self.f[:, 0], 12), col(dp, 12), col(imu, 6), ct, xt, Pt, body_ref=col(body_ref, 12),
+                     sequential=False, dense_fd=True, want_p_rot=True, want_trace=True, want_gain=True)
+        if int(r["status"].item()) & 1:
+            raise np.linalg.LinAlgError("Singular matrix")
+        self.x = xt.cpu().numpy().astype(np.float64).reshape(12, 1)
+        self.P = Pt.cpu().numpy().astype(np.float64).reshape(12, 12)
+        self.P_trace = float(r["P_trace"].item())
+        self.K_gain = float(r["K_gain"].item())
+        if isinstance(p, np.ndarray) and p.flags.writeable:            # next_state rotates the caller's p in place
+            p[...] = r["p_rot"].cpu().numpy().astype(p.dtype).reshape(p.shape)
         return self.x

@@ -97,3 +97,46 @@ def test_fused_matches_oracle_chain(two_kernel, L, B, T):
     assert np.abs(x.cpu().numpy().T - ref["x_final"]).max() < 1e-4
     err = np.abs(r["out"].cpu().numpy() - ref_out).max()
     assert err < 1e-4, err       # feature rows carry fp32 KF noise (~1e-6) through T GRU steps
+
+
+@pytest.mark.parametrize("mode", ["batch_update", "dense_fd", "full_Q"])
+def test_fused_general_paths(mode):
+    """Fused chain through the non-default Kalman variants: batch (Cholesky) update, predict_mpc covariance with body_ref
+    (two-kernel path), and a non-diagonal Q in the single kernel (QDIAG = false instantiation)."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    from oracle import c_oracle as orc
+    B, T = 150, 12
+    d = synth_numpy(B, T, seed=33)
+    rng = np.random.default_rng(5)
+    Q = Q_FITTED
+    if mode == "full_Q":
+        A = rng.normal(size=(12, 12)); Q = (A @ A.T / 12 + np.eye(12)) * 1e-3
+    body_ref = None
+    if mode == "dense_fd":
+        body_ref = np.zeros((B, T, 12), dtype=np.float32)
+        body_ref[..., 0:3] = d["imu"][..., 0:3] + rng.normal(0, 0.01, (B, T, 3)).astype(np.float32)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q, (B, 1, 1)), Q, R_FITTED,
+                           body_ref=body_ref, mode=1 if mode == "dense_fd" else 0)
+    rows = np.concatenate([ref["x"], d["accel"], d["f"], ref["p_rot"], d["dp"], d["imu"]], axis=2)
+    mn, mx = rows.reshape(-1, 60).min(0), rows.reshape(-1, 60).max(0)
+    torch.manual_seed(8)
+    m = RNN(60, 64, 1, 24, torch.device("cpu"))
+    ref_out, _, _ = orc.gru_forward((rows - mn) / (mx - mn), orc.flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    eng = Engine(0)
+    eng.set_noise(Q, R_FITTED)
+    eng.load_gru(flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(np.asarray(Q, dtype=np.float32).reshape(144, 1), (1, B))).cuda()
+    mm = torch.as_tensor(np.stack([mn, mx]).astype(np.float32)).cuda()
+    kw = {}
+    if mode == "batch_update":
+        kw = dict(sequential=False, symmetric=False)
+    if mode == "dense_fd":
+        kw = dict(body_ref=eng.pack(torch.as_tensor(body_ref)), dense_fd=True, sequential=False, symmetric=False)
+    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P, **kw)
+    torch.cuda.synchronize()
+    assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < 1e-4
+    assert np.abs(r["out"].cpu().numpy() - ref_out).max() < 1e-4

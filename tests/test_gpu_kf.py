@@ -127,8 +127,9 @@ def test_dense_fd_variant_matches_reference_g8(eng):
     xo = eng.unpack(r["x_out"]).cpu().numpy()
     for b in range(2):
         err = np.abs(xo[b] - g[f"b{b}_x"]).max()
-        # dense ~all-ones F_d inflates P by ~1e2 per step and the update cancels it again: fp32 keeps ~1e-3 here
-        assert err < 5e-3, err
+        # the dense ~all-ones F_d makes P ill-conditioned between predict and update: that variant's covariance
+        # arithmetic runs in float64 inside the kernel, so the usual bar holds
+        assert err < STATE_TOL, err
 
 
 def test_status_flags_nonfinite_input(eng):
@@ -170,3 +171,59 @@ def test_dropin_kalman_filter_class(eng):
         assert abs(kf.P_trace / g["s1_b0_P_trace"][t] - 1) < 1e-3
         if t in (0, 1):
             assert np.abs(kf.K - g[f"s1_b0_K{t}"]).max() < 1e-4      # the 12x10 gain itself
+
+
+def _spd(rng, n, scale):
+    A = rng.normal(size=(n, n))
+    return (A @ A.T / n + np.eye(n)) * scale
+
+
+@pytest.mark.parametrize("v", VARIANTS, ids=VIDS)
+def test_full_process_noise_matrix(eng, v):
+    """Non-diagonal Q (the reference's are diagonal, the interface is not): every kernel family's general-Q instantiation."""
+    from optistate_amd.synth import synth_numpy, R_FITTED
+    from oracle import c_oracle as orc
+    rng = np.random.default_rng(12)
+    Q = _spd(rng, 12, 1e-3)
+    B, T = 96, 40
+    d = synth_numpy(B, T, seed=6)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q, (B, 1, 1)), Q, R_FITTED, aux=False)
+    r = run(eng, d, Q, R_FITTED, B, **v)
+    assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < STATE_TOL
+    Pf = r["P_final"].cpu().numpy().T.reshape(B, 12, 12)
+    assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
+
+
+def test_full_measurement_noise_matrix_uses_batch_update(eng):
+    """Non-diagonal R: only the batch (Cholesky) form applies; the sequential forms must refuse it."""
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT
+    from oracle import c_oracle as orc
+    rng = np.random.default_rng(13)
+    R = _spd(rng, 10, 1e-2)
+    B, T = 64, 30
+    d = synth_numpy(B, T, seed=7)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_DEFAULT, (B, 1, 1)), Q_DEFAULT, R)
+    r = run(eng, d, Q_DEFAULT, R, B, want_gain=True)                  # sequential=None -> batch, because R is not diagonal
+    assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < STATE_TOL
+    assert np.abs(r["K_gain"].cpu().numpy().T - ref["K_gain"]).max() < 1e-3
+    with pytest.raises(RuntimeError):
+        run(eng, d, Q_DEFAULT, R, B, sequential=True)
+
+
+def test_dropin_estimate_state_mpc_with_supplied_forces(eng):
+    """estimate_state_mpc on the drop-in class with the QP's forces passed in (G8: the reference run with primed forces)."""
+    from optistate_amd import Kalman_Filter
+    g = load_golden("kf_g8_mpc.npz")
+    kf = Kalman_Filter()
+    kf.x[:] = g["x0"][0].reshape(12, 1)
+    kf.Q = g["Q"].copy(); kf.R = g["R"].copy(); kf.P = g["Q"].copy()
+    for t in range(8):
+        p = g["p"][0, t].astype(np.float64).reshape(12, 1)
+        x = kf.estimate_state_mpc(g["imu"][0, t].reshape(6, 1), p, g["dp"][0, t].reshape(12, 1), g["body_ref"][0, t].reshape(12, 1),
+                                  g["contact"][0, t].reshape(4, 1), f=g["f"][0, t])
+        assert x is kf.x
+        assert np.abs(x.ravel() - g["b0_x"][t]).max() < STATE_TOL
+        assert np.abs(p.ravel() - g["b0_p_rot"][t]).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        kf.estimate_state_mpc(g["imu"][0, 0].reshape(6, 1), g["p"][0, 0].reshape(12, 1).astype(np.float64),
+                              g["dp"][0, 0].reshape(12, 1), g["body_ref"][0, 0].reshape(12, 1), g["contact"][0, 0].reshape(4, 1))
