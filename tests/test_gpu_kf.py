@@ -227,3 +227,19 @@ def test_dropin_estimate_state_mpc_with_supplied_forces(eng):
     with pytest.raises(NotImplementedError):
         kf.estimate_state_mpc(g["imu"][0, 0].reshape(6, 1), g["p"][0, 0].reshape(12, 1).astype(np.float64),
                               g["dp"][0, 0].reshape(12, 1), g["body_ref"][0, 0].reshape(12, 1), g["contact"][0, 0].reshape(4, 1))
+
+
+@pytest.mark.parametrize("v", VARIANTS, ids=VIDS)
+def test_long_horizon_config1_length(eng, v):
+    """T = 4063 steps (one full trajectory of the reference pipeline: settings.py:15-16 cut-offs 430..4494): the float32 filter
+    must not drift away from the float64 reference over the whole horizon."""
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    from oracle import c_oracle as orc
+    B, T = 24, 4063
+    d = synth_numpy(B, T, seed=77)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)), Q_FITTED,
+                           R_FITTED, aux=False)
+    r = run(eng, d, Q_FITTED, R_FITTED, B, **v)
+    err = np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"])
+    assert err.max() < STATE_TOL, err.max()
+    assert err[:, -500:].max() < 2 * err[:, :500].max() + 1e-5          # no growth with time
