@@ -41,8 +41,23 @@ class Kalman_Filter:
         self.f = np.zeros((12, 5))
 
     # -- helpers --
+    # Every call stages ALL its inputs in one host array -> one host-to-device copy, and reads ALL its outputs back with
+    # one device-to-host copy (B = 1 is pure latency: ~20 separate transfers per step cost more than the kernels).
     def _up(self, a, n):
         return torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(n, 1)).to(self._dev)
+
+    def _stage(self, *parts):
+        host = np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in parts])
+        buf = torch.from_numpy(host).to(self._dev)
+        offs, o = [], 0
+        for a in parts:
+            n = int(np.asarray(a).size)
+            offs.append((o, n)); o += n
+        return buf, offs
+
+    @staticmethod
+    def _seg(buf, off):
+        return buf[off[0]:off[0] + off[1]]
 
     def _sync_noise(self):
         self._eng.set_noise(self.Q, self.R)
@@ -54,16 +69,19 @@ class Kalman_Filter:
                          [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
                          [-sy, cy * sx, cy * cx]], dtype=np.float64).reshape(3, 3)
 
+    @staticmethod
+    def _pack_contact(contact_cur):
+        c = np.asarray(contact_cur).reshape(4)
+        packed = np.array([sum((int(c[k]) & 0xff) << (8 * k) for k in range(4))], dtype=np.int32)
+        return packed.view(np.float32)                       # carried bit-for-bit inside the float staging buffer
+
     def get_odom(self, p_cur, dp_cur, contact_cur, imu):
         e = self._eng
-        c = np.asarray(contact_cur).reshape(4)
-        packed = int(sum((int(c[k]) & 0xff) << (8 * k) for k in range(4)))
-        ct = torch.tensor([packed], dtype=torch.int32, device=self._dev)
-        z = torch.empty((10, 1), dtype=torch.float32, device=self._dev)
-        # keep the device copies referenced until the launch is queued (a dead temporary's block would be reused)
-        pt, dpt, it = self._up(p_cur, 12), self._up(dp_cur, 12), self._up(np.asarray(imu).reshape(-1)[:6], 6)
-        e._check(e.lib.os_kf_odom(e._h, 1, _ptr(pt), _ptr(dpt), _ptr(ct), _ptr(it), _ptr(z), e._stream()), "os_kf_odom")
-        zz = z.cpu().numpy().astype(np.float64).reshape(10)
+        buf, o = self._stage(np.asarray(p_cur).reshape(-1)[:12], np.asarray(dp_cur).reshape(-1)[:12],
+                             np.asarray(imu).reshape(-1)[:6], self._pack_contact(contact_cur), np.zeros(10))
+        sg = lambda i: _ptr(self._seg(buf, o[i]))
+        e._check(e.lib.os_kf_odom(e._h, 1, sg(0), sg(1), sg(3), sg(2), sg(4), e._stream()), "os_kf_odom")
+        zz = self._seg(buf, o[4]).cpu().numpy().astype(np.float64)
         return np.array([zz[3], zz[7], zz[8], zz[9]]).reshape(4, 1)
 
     def set_measurements(self, imu, odom):
@@ -78,21 +96,20 @@ class Kalman_Filter:
     def _predict(self, p, f, body_ref=None):
         e = self._eng
         self._sync_noise()
-        pt, ft = self._up(p, 12), self._up(f, 12)
-        xt = self._up(self.x, 12)
-        Pt = self._up(np.asarray(self.P, dtype=np.float64).reshape(144), 144)
-        tr = torch.empty((1,), dtype=torch.float32, device=self._dev)
-        bt = None if body_ref is None else self._up(np.asarray(body_ref).reshape(-1)[:12], 12)
-        e._check(e.lib.os_kf_predict(e._h, 1, _ptr(pt), _ptr(ft), _ptr(bt), _ptr(xt), _ptr(Pt), _ptr(tr),
+        br = np.zeros(12) if body_ref is None else np.asarray(body_ref).reshape(-1)[:12]
+        buf, o = self._stage(np.asarray(p).reshape(-1)[:12], np.asarray(f).reshape(-1)[:12], self.x,
+                             np.asarray(self.P, dtype=np.float64).reshape(144), np.zeros(1), br)
+        sg = lambda i: _ptr(self._seg(buf, o[i]))
+        e._check(e.lib.os_kf_predict(e._h, 1, sg(0), sg(1), sg(5) if body_ref is not None else None, sg(2), sg(3), sg(4),
                                      OS_KF_DENSE_FD if body_ref is not None else 0, e._stream()), "os_kf_predict")
-        self.x = xt.cpu().numpy().astype(np.float64).reshape(12, 1)
-        self.P = Pt.cpu().numpy().astype(np.float64).reshape(12, 12)
+        h = buf.cpu().numpy().astype(np.float64)
+        self.x = h[o[2][0]:o[2][0] + 12].reshape(12, 1)
+        self.P = h[o[3][0]:o[3][0] + 144].reshape(12, 12)
         # the reference rotates the caller's p in place (misc/force_controller.py:274-277)
-        p_arr = np.asarray(p)
         if isinstance(p, np.ndarray) and p.flags.writeable:
-            p[...] = pt.cpu().numpy().astype(p_arr.dtype).reshape(p_arr.shape)
+            p[...] = h[0:12].astype(p.dtype).reshape(p.shape)
         self.x_model = self.x.copy()
-        self.P_trace = float(tr.item())
+        self.P_trace = float(h[o[4][0]])
 
     def predict(self, p, f):
         """kalman_filter.py:119-138: p, f (12,1); p is rotated to the world frame in place."""
@@ -102,24 +119,22 @@ class Kalman_Filter:
         """kalman_filter.py:164-174."""
         e = self._eng
         self._sync_noise()
-        xt = self._up(self.x, 12)
-        Pt = self._up(np.asarray(self.P, dtype=np.float64).reshape(144), 144)
-        zt = self._up(self.z, 10)
-        Kt = torch.empty((120, 1), dtype=torch.float32, device=self._dev)
-        tr = torch.empty((1,), dtype=torch.float32, device=self._dev)
-        kg = torch.empty((1,), dtype=torch.float32, device=self._dev)
-        st = torch.zeros((1,), dtype=torch.int32, device=self._dev)
-        e._check(e.lib.os_kf_update(e._h, 1, _ptr(zt), _ptr(xt), _ptr(Pt), _ptr(Kt), _ptr(tr), _ptr(kg), _ptr(st), 0,
-                                    e._stream()), "os_kf_update")
-        status = int(st.item())
+        buf, o = self._stage(self.z, self.x, np.asarray(self.P, dtype=np.float64).reshape(144), np.zeros(120), np.zeros(1),
+                             np.zeros(1), np.zeros(1))
+        sg = lambda i: _ptr(self._seg(buf, o[i]))
+        st = self._seg(buf, o[6]).view(torch.int32)
+        e._check(e.lib.os_kf_update(e._h, 1, sg(0), sg(1), sg(2), sg(3), sg(4), sg(5), _ptr(st), 0, e._stream()), "os_kf_update")
+        hb = buf.cpu().numpy()
+        status = int(hb[o[6][0]:o[6][0] + 1].view(np.int32)[0])
         if status & 1:
             # the reference's np.linalg.inv raises here (kalman_filter.py:168)
             raise np.linalg.LinAlgError("Singular matrix")
-        self.x = xt.cpu().numpy().astype(np.float64).reshape(12, 1)
-        self.P = Pt.cpu().numpy().astype(np.float64).reshape(12, 12)
-        self.K = Kt.cpu().numpy().astype(np.float64).reshape(12, 10)
-        self.P_trace = float(tr.item())
-        self.K_gain = float(kg.item())
+        h = hb.astype(np.float64)
+        self.x = h[o[1][0]:o[1][0] + 12].reshape(12, 1)
+        self.P = h[o[2][0]:o[2][0] + 144].reshape(12, 12)
+        self.K = h[o[3][0]:o[3][0] + 120].reshape(12, 10)
+        self.P_trace = float(h[o[4][0]])
+        self.K_gain = float(h[o[5][0]])
 
     def predict_mpc(self, p, body_ref, cur_contact, f=None):
         """kalman_filter.py:140-162 with the QP's forces supplied by the caller (f: (12,) or (12,N), column 0 used)."""
@@ -143,20 +158,22 @@ class Kalman_Filter:
         self.f = np.asarray(f, dtype=np.float64).reshape(12, -1)
         odom = self.get_odom(p, dp, contact, imu)
         self.set_measurements(imu, odom)
-        col = lambda a, n: torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(-1)[:n].reshape(1, n, 1)).to(self._dev)
-        c = np.asarray(contact).reshape(4)
-        packed = int(sum((int(c[k]) & 0xff) << (8 * k) for k in range(4)))
-        ct = torch.tensor([[packed]], dtype=torch.int32, device=self._dev)
-        xt = self._up(self.x, 12)
-        Pt = self._up(np.asarray(self.P, dtype=np.float64).reshape(144), 144)
-        r = e.kf_run(col(p, 12), col(self.f[:, 0], 12), col(dp, 12), col(imu, 6), ct, xt, Pt, body_ref=col(body_ref, 12),
-                     sequential=False, dense_fd=True, want_p_rot=True, want_trace=True, want_gain=True)
-        if int(r["status"].item()) & 1:
+        buf, o = self._stage(np.asarray(p).reshape(-1)[:12], self.f[:, 0], np.asarray(dp).reshape(-1)[:12],
+                             np.asarray(imu).reshape(-1)[:6], self._pack_contact(contact), np.asarray(body_ref).reshape(-1)[:12],
+                             self.x, np.asarray(self.P, dtype=np.float64).reshape(144), np.zeros(12), np.zeros(12), np.zeros(1),
+                             np.zeros(1), np.zeros(1))
+        sg = lambda i: _ptr(self._seg(buf, o[i]))
+        st = self._seg(buf, o[12]).view(torch.int32)
+        e._check(e.lib.os_kf_run(e._h, 1, 1, sg(0), sg(1), sg(2), sg(3), sg(4), sg(5), sg(6), sg(7), sg(8), sg(9), sg(10), sg(11),
+                                 _ptr(st), OS_KF_DENSE_FD, e._stream()), "os_kf_run")
+        hb = buf.cpu().numpy()
+        if int(hb[o[12][0]:o[12][0] + 1].view(np.int32)[0]) & 1:
             raise np.linalg.LinAlgError("Singular matrix")
-        self.x = xt.cpu().numpy().astype(np.float64).reshape(12, 1)
-        self.P = Pt.cpu().numpy().astype(np.float64).reshape(12, 12)
-        self.P_trace = float(r["P_trace"].item())
-        self.K_gain = float(r["K_gain"].item())
+        h = hb.astype(np.float64)
+        self.x = h[o[6][0]:o[6][0] + 12].reshape(12, 1)
+        self.P = h[o[7][0]:o[7][0] + 144].reshape(12, 12)
+        self.P_trace = float(h[o[10][0]])
+        self.K_gain = float(h[o[11][0]])
         if isinstance(p, np.ndarray) and p.flags.writeable:            # next_state rotates the caller's p in place
-            p[...] = r["p_rot"].cpu().numpy().astype(p.dtype).reshape(p.shape)
+            p[...] = h[o[9][0]:o[9][0] + 12].astype(p.dtype).reshape(p.shape)
         return self.x

@@ -1,18 +1,20 @@
-import sys; sys.path.insert(0,'.')
+import sys, time; sys.path.insert(0,'.')
 import numpy as np, torch
-from optistate_amd import Engine
-from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
-from oracle import c_oracle as orc
-B,T=150,12
-d=synth_numpy(B,T,seed=33); rng=np.random.default_rng(5)
-body_ref=np.zeros((B,T,12),dtype=np.float32); body_ref[...,0:3]=d["imu"][...,0:3]+rng.normal(0,0.01,(B,T,3)).astype(np.float32)
-ref=orc.kf_run_batch(d["p"],d["f"],d["dp"],d["imu"],d["contact"],d["x0"],np.tile(Q_FITTED,(B,1,1)),Q_FITTED,R_FITTED,body_ref=body_ref,mode=1)
-eng=Engine(0); eng.set_noise(Q_FITTED,R_FITTED)
-s={k:eng.pack(torch.as_tensor(d[k])) for k in ("p","f","dp","imu")}; c=eng.pack_contact(torch.as_tensor(d["contact"]))
-x=torch.as_tensor(d["x0"].T.copy()).cuda(); P=torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144,1),(1,B))).cuda()
-r=eng.kf_run(s["p"],s["f"],s["dp"],s["imu"],c,x,P,body_ref=eng.pack(torch.as_tensor(body_ref)),dense_fd=True,sequential=False)
-xo=eng.unpack(r["x_out"]).cpu().numpy()
-err=np.abs(xo-ref["x"])
-print('per-state max err',err.max(axis=(0,1)).round(5))
-print('per-step max err',err.max(axis=(0,2)).round(5))
-print('P trace ref', ref["P_trace"][0,:5], 'x scale', np.abs(ref["x"]).max(axis=(0,1)).round(3))
+from optistate_amd import Kalman_Filter
+from optistate_amd.synth import synth_numpy
+d=synth_numpy(1,300,seed=1)
+kf=Kalman_Filter()
+def step(t):
+    p=d["p"][0,t].astype(np.float64).reshape(12,1)
+    od=kf.get_odom(p,d["dp"][0,t].reshape(12,1),d["contact"][0,t].reshape(4,1),d["imu"][0,t].reshape(6,1))
+    kf.set_measurements(d["imu"][0,t].reshape(6,1),od)
+    kf.predict(p,d["f"][0,t].reshape(12,1)); kf.update()
+for t in range(20): step(t)
+t0=time.perf_counter()
+for t in range(20,220): step(t)
+print("drop-in class, 4 calls per step: %.0f us/step"%((time.perf_counter()-t0)/200*1e6))
+t0=time.perf_counter()
+for t in range(20,220):
+    p=d["p"][0,t].astype(np.float64).reshape(12,1)
+    kf.estimate_state_mpc(d["imu"][0,t].reshape(6,1),p,d["dp"][0,t].reshape(12,1),np.zeros((12,1)),d["contact"][0,t].reshape(4,1),f=d["f"][0,t])
+print("drop-in class, estimate_state_mpc (one launch + odom): %.0f us/step"%((time.perf_counter()-t0)/200*1e6))
