@@ -2,7 +2,9 @@
 # HBM traffic of the bench kernels from PMC counters, one counter per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do
 # not fit one pass), plus the calibration kernels with known byte counts.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/traffic
-mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+mkdir -p $OUT
+[ -x $R/tools/micro/traffic_cal ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/micro/traffic_cal.hip -o $R/tools/micro/traffic_cal
+cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -- $R/tools/micro/traffic_cal > $OUT/cal_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $OUT/run_$c -- python3 $R/tools/run_fused_once.py 2 > $OUT/run_$c.log 2>&1
