@@ -296,13 +296,12 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
             if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
             fa.seq_out = seq0;
         }
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!ctx->fused_attr_set) {            // per context (= per device), not process-global
             OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel<true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel<false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
-            attr_set = true;
+            ctx->fused_attr_set = true;
         }
         if (!ctx->nrm) OS_HIP(ctx, hipMalloc((void **)&ctx->nrm, 120 * sizeof(float)));
         hipLaunchKernelGGL(osf::norm_prep_kernel, dim3(1), dim3(64), 0, s, minmax, ctx->nrm);

@@ -558,11 +558,10 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         const int RB = H <= 64 ? 2 : 1;
         const int BM = 32 * RB;
         const size_t lds = (size_t)(BM * (H + 1) + BM * (4 * H + 1)) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!ctx->sweep_attr_set) {            // per context (= per device), not process-global
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            ctx->sweep_attr_set = true;
         }
         dim3 grid((B + BM - 1) / BM), block(256);
         if (RB == 2) hipLaunchKernelGGL(bwd_sweep_kernel<2>, grid, block, lds, s, a);
