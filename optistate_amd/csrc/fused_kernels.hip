@@ -114,6 +114,16 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
         // ================= Kalman step (lane = trajectory) =================
         float z[NM], pw[12], F[KX];
         kf_step_front_sym<QDIAG>(x, U, in, k.k, z, pw);
+        status |= kf_step_back_sym(x, U, z, k.k);
+        if (live) {
+            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
+        }
+        // feature row [x_post | accel | f | p_world | dp | imu], normalised; built only now so that the update above does
+        // not have to keep 48 extra registers alive (the inputs stay in `in` until the prefetch inside the GRU cell)
+#pragma unroll
+        for (int i = 0; i < NS; i++) F[i] = norm_feat(nrm, i, x[i]);
 #pragma unroll
         for (int i = 0; i < 6; i++) F[12 + i] = norm_feat(nrm, 12 + i, acl[i]);
 #pragma unroll
@@ -124,14 +134,6 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) F[54 + i] = norm_feat(nrm, 54 + i, in.imu[i]);
-        status |= kf_step_back_sym(x, U, z, k.k);
-        if (live) {
-            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
-#pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < NS; i++) F[i] = norm_feat(nrm, i, x[i]);
 
         // ================= GRU cell on this wave's 64 rows =================
         // feature registers -> A fragments: after the swap, F[2kp] holds rows 0-31 (k = 2kp | 2kp+1 by lane half),
