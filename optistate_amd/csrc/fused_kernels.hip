@@ -85,20 +85,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
 #pragma unroll
             for (int j = i; j < NS; j++) U[uidx(i, j)] = buf_load(rP, voff, (i * NS + j) * rowB);
     }
-    // biases of both chunks for this lane's column
-    float bias[2][4];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) bias[c][g] = W[c * CHF + (KPX + KPH) * 192 + g * 32 + li];
     constexpr float LOG2E = 1.44269504088896341f;
-    float nbias[2][3];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        nbias[c][0] = -LOG2E * bias[c][0];
-        nbias[c][1] = -LOG2E * bias[c][1];
-        nbias[c][2] = 2.0f * LOG2E * bias[c][2];
-    }
 
     int status = 0;
     StepIn in;
@@ -193,18 +180,21 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // cell update on the accumulator layout: col = li (hidden unit c*32+li), row = (e&3) + 8*(e>>2) + 4*lh
+            // cell update on the accumulator layout: col = li (hidden unit c*32+li), row = (e&3) + 8*(e>>2) + 4*lh.
+            // The four biases of this lane's column come from the LDS weight image each time (cheaper than 14 live VGPRs);
+            // three of them are folded into the exp2 arguments (-log2e * b, 2 log2e * b_in): one FMA per gate.
+            const float *bc = Wc + (KPX + KPH) * 192 + li;
+            const float nb_r = -LOG2E * bc[0], nb_z = -LOG2E * bc[32], nb_n = 2.0f * LOG2E * bc[64], b_hn = bc[96];
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     const float hold = hl[row * HS + c * 32 + li];
-                    // biases are folded into the exp2 arguments (nb* = -log2e * b, nbn = 2 log2e * b_in): one FMA each
-                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nbias[c][0])));
-                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nbias[c][1])));
-                    const float u = fmaf(r, acc[rb][3][e] + bias[c][3], acc[rb][2][e]);
-                    const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nbias[c][2]))), 1.0f);
+                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
+                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
+                    const float u = fmaf(r, acc[rb][3][e] + b_hn, acc[rb][2][e]);
+                    const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
                     const float hn = fmaf(zg, hold - n, n);          // (1 - z) n + z h
                     if (c == 0) hnew0[rb][e] = hn;            // old h[:, 0:32] is still needed by chunk 1
                     else hl[row * HS + 32 + li] = hn;
