@@ -84,3 +84,19 @@ def test_argument_errors_are_reported_not_crashes():
     with pytest.raises(RuntimeError):
         eng.kf_run(z, z, z, torch.zeros(2, 6, 8, device="cuda"), torch.zeros(2, 8, dtype=torch.int32, device="cuda"),
                    torch.zeros(12, 8, device="cuda"), torch.zeros(144, 8, device="cuda"), sequential=True)
+
+
+def test_empty_and_oversize_batches_are_refused_cleanly():
+    """B = 0 / T = 0 (the reference would simply loop zero times) and a batch beyond the 32-bit buffer-offset range must
+    come back as argument errors from the C-ABI, without launching anything."""
+    import ctypes as C
+    from optistate_amd import Engine
+    eng = Engine(0)
+    buf = torch.zeros(4096, device="cuda")
+    p = C.c_void_p(buf.data_ptr())
+    for B, T in ((0, 5), (5, 0)):
+        rc = eng.lib.os_kf_run(eng._h, B, T, p, p, p, p, p, None, p, p, p, None, None, None, p, 1, None)
+        assert rc == -2 and b"positive" in eng.lib.os_last_error(eng._h)
+    rc = eng.lib.os_kf_run(eng._h, 8_000_000, 1, p, p, p, p, p, None, p, p, p, None, None, None, p, 1 | 4, None)
+    assert rc == -2 and b"too large" in eng.lib.os_last_error(eng._h)
+    torch.cuda.synchronize()
