@@ -243,3 +243,29 @@ def test_long_horizon_config1_length(eng, v):
     err = np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"])
     assert err.max() < STATE_TOL, err.max()
     assert err[:, -500:].max() < 2 * err[:, :500].max() + 1e-5          # no growth with time
+
+
+def test_rotation_accuracy_for_large_angles(eng):
+    """The kernels' branch-free sincos (Cody-Waite by pi/2 + minimax) against the float64 oracle for yaw/roll/pitch up to
+    +-60 rad (unwrapped yaw), through the odometry kernel (z[7:10] = R(imu theta) . v_body)."""
+    from oracle import c_oracle as orc
+    from optistate_amd.engine import _ptr
+    rng = np.random.default_rng(4)
+    n = 4096
+    th = rng.uniform(-60.0, 60.0, (n, 3)); th[:64] = rng.uniform(-1e-3, 1e-3, (64, 3)); th[64:128, 2] = np.pi * rng.integers(-8, 9, 64) / 2
+    imu = np.concatenate([th, rng.normal(0, 0.5, (n, 3))], axis=1).astype(np.float32)
+    p = rng.normal(0, 0.3, (n, 12)).astype(np.float32); dp = rng.normal(0, 0.5, (n, 12)).astype(np.float32)
+    contact = np.zeros((n, 4), dtype=np.uint8)
+    for i in range(n):
+        contact[i, rng.permutation(4)[:1 + i % 3]] = 1
+    packed = torch.as_tensor(contact.view(np.int32).reshape(n).copy()).cuda()
+    z = torch.empty((10, n), dtype=torch.float32, device="cuda")
+    up = lambda a: torch.as_tensor(a.T.copy()).cuda()
+    pt, dpt, it = up(p), up(dp), up(imu)
+    eng._check(eng.lib.os_kf_odom(eng._h, n, _ptr(pt), _ptr(dpt), _ptr(packed), _ptr(it), _ptr(z), eng._stream()), "os_kf_odom")
+    zz = z.cpu().numpy().T
+    worst = 0.0
+    for i in range(n):
+        od = orc.get_odom(p[i].astype(np.float64), dp[i].astype(np.float64), contact[i], imu[i].astype(np.float64))
+        worst = max(worst, abs(zz[i, 3] - od[0]), np.abs(zz[i, 7:10] - od[1:]).max())
+    assert worst < 2e-6, worst
