@@ -35,7 +35,9 @@ class Kalman_Filter:
         self.P_trace = float(np.trace(self.P))
         self.K_gain = 0.0
         self.K = np.zeros((12, 10))
-        self.m = 8.8
+        self.m = 8.8                                                   # settings.py:11
+        self.inertia_rot = np.diag([55303643.08 / 1e9, 60119440.34 / 1e9, 105304340.05 / 1e9])   # settings.py:20-23
+        self.g = np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -9.81]).reshape(12, 1)               # kalman_filter.py:56
         self.dt = 0.01
         self.x_model = self.x.copy()
         self.f = np.zeros((12, 5))
@@ -135,6 +137,10 @@ class Kalman_Filter:
         self.K = h[o[3][0]:o[3][0] + 120].reshape(12, 10)
         self.P_trace = float(h[o[4][0]])
         self.K_gain = float(h[o[5][0]])
+
+    def skew(self, x):
+        # kalman_filter.py:195-198
+        return np.array([[0, -x[2][0], x[1][0]], [x[2][0], 0, -x[0][0]], [-x[1][0], x[0][0], 0]])
 
     def predict_mpc(self, p, body_ref, cur_contact, f=None):
         """kalman_filter.py:140-162 with the QP's forces supplied by the caller (f: (12,) or (12,N), column 0 used)."""
