@@ -1,0 +1,75 @@
+// Issue cost (cycles per wave64 instruction, one wave per SIMD) of the VALU instruction kinds the Kalman part uses.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int KIND>
+__global__ __launch_bounds__(512, 1) void k(float *out, int iters, unsigned long long *cyc)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    float a = threadIdx.x * 0.001f + 1.f;
+    f2 d[8];
+    for (int i = 0; i < 8; i++) d[i] = (f2){a + i, a - i};
+    const f2 m = (f2){1.0001f, 0.9999f}, c = (f2){0.5f, 0.25f};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d[v].x) : "v"(m.x), "v"(c.x));
+                if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[v]) : "v"(m), "v"(c));
+                if (KIND == 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[v]) : "v"(m));
+                if (KIND == 3) asm volatile("v_exp_f32 %0, %0" : "+v"(d[v].x));
+                if (KIND == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(d[v].x));
+                if (KIND == 5) asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[v].x) : "v"(d[(v + 1) & 7].y));
+                if (KIND == 6) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d[v].x), "+v"(d[v].y));
+                if (KIND == 7) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[v]) : "v"(m), "v"(c));
+                if (KIND == 8) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[v]) : "v"(m));
+                if (KIND == 9) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(d[v].x) : "v"(m.x));
+                if (KIND == 10) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d[v].x) : "s"(1.0001f), "v"(c.x));
+                if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(d[v]) : "v"(m), "v"(c));
+                if (KIND == 12) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(d[v].x) : "v"(m.x));
+                if (KIND == 13) asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %0, a0" : "+v"(d[v].x));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+    float s = 0.f;
+    for (int i = 0; i < 8; i++) s += d[i].x + d[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int KIND> void run1(float *d, const char *name, int per, int threads)
+{
+    unsigned long long *cyc; hipHostMalloc(&cyc, 8); *cyc = 0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;
+    hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(threads), 0, 0, d, 2000, cyc);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(threads), 0, 0, d, iters, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double n = (double)iters * 32 * per;
+    printf("%-28s %d waves/SIMD: %.3f ms, s_memtime %.2f ticks/instr/wave (clock ratio %.3f GHz-equivalent)\n", name, threads / 256, ms,
+           (double)*cyc / n, (double)*cyc / (ms * 1e6));
+}
+template <int KIND> void run(float *d, const char *name, int per) { run1<KIND>(d, name, per, 256); run1<KIND>(d, name, per, 512); }
+int main()
+{
+    float *d; hipMalloc(&d, 256 * 512 * 4);
+    run<0>(d, "v_fma_f32", 1);
+    run<10>(d, "v_fma_f32 (sgpr src)", 1);
+    run<9>(d, "v_mul_f32", 1);
+    run<1>(d, "v_pk_fma_f32", 1);
+    run<11>(d, "v_pk_fma_f32 op_sel bcast", 1);
+    run<2>(d, "v_pk_mul_f32", 1);
+    run<8>(d, "v_pk_add_f32", 1);
+    run<3>(d, "v_exp_f32", 1);
+    run<4>(d, "v_rcp_f32", 1);
+    run<5>(d, "v_mov_b32_dpp row_share", 1);
+    run<6>(d, "v_permlane32_swap_b32", 1);
+    run<7>(d, "v_fma_f64", 1);
+    run<12>(d, "v_cndmask_b32", 1);
+    run<13>(d, "accvgpr write+read", 2);
+    return 0;
+}
