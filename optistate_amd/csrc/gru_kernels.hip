@@ -75,10 +75,15 @@ __device__ __forceinline__ void mfma_part(f32x16 (*acc)[4], const float *wbase, 
 
 // RBW = row blocks (of 32 trajectories) per wave.  NCH = H/32 column chunks; with NCH < 4 several waves share a chunk
 // and split the rows.  BM = 32 * RBW * max(1, 4/NCH).
-template <int RBW>
-__global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
+// OCC = workgroups per CU the register budget is sized for.  Two resident workgroups matter more than a bigger row
+// tile: while one sits in its cell update / barrier the other keeps the matrix pipe busy (measured, B = 65,536,
+// T = 100: (60,128,4) 86 -> 114 TFLOP/s, (60,64,1) 82 -> 102).
+// h is double-buffered in LDS ([2][BM][H+1]): step t reads h_{t-1} from one buffer and writes h_t into the other, so a
+// step needs ONE barrier, and the SoA write-back of h_{t-1} is issued at the top of step t, under its MFMAs.
+template <int RBW, int OCC>
+__global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float hl[];   // [BM][HS]
+    extern __shared__ __attribute__((aligned(16))) float hl2[];   // [2][BM][HS]
     // the wave index is wave-uniform but derived from threadIdx: readfirstlane makes that provable, so descriptors built
     // from it stay in SGPRs (otherwise hipcc wraps every buffer_load in a waterfall loop)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
     const int li = lane & 31, lh = lane >> 5;
     const size_t B = (size_t)a.B;
 
-    for (int i = threadIdx.x; i < BM * HS; i += 256) hl[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
+    for (int i = threadIdx.x; i < BM * HS; i += 256) hl2[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
 
     const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
     const float *wh = wx + (size_t)a.KPx * 3 * 64;
@@ -113,7 +118,20 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
     }
     __syncthreads();
 
+    // cooperative, coalesced write-back of one h tile in SoA ([H][B] block at dst)
+    auto write_back = [&](const float *hsrc, float *dst) {
+        for (int i = threadIdx.x; i < BM * H; i += 256) {
+            const int row = i % BM, k = i / BM;
+            const int g = tile_row0 + row;
+            if (g < a.B) dst[(size_t)k * B + g] = hsrc[row * HS + k];
+        }
+    };
+
     for (int t = 0; t < a.T; t++) {
+        const float *hl = hl2 + (t & 1) * BM * HS;          // h_{t-1}
+        float *hn_buf = hl2 + ((t + 1) & 1) * BM * HS;       // h_t
+        if (t > 0 && a.seq_out) write_back(hl, a.seq_out + (size_t)(t - 1) * H * B);
+
         f32x16 acc[RBW][4];
 #pragma unroll
         for (int rb = 0; rb < RBW; rb++)
@@ -143,7 +161,6 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
         mfma_part<RBW, false>(acc, wh, a.KPh, lane, [&](int q, int rb) {
             return hl[((row_blk0 + rb) * 32 + li) * HS + 2 * q + lh];
         });
-        __syncthreads();   // every wave has finished reading h_{t-1}
 
         // ---- cell update on the accumulator layout: col = lane&31 (hidden unit), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
@@ -151,15 +168,15 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = (row_blk0 + rb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float *hp = &hl[row * HS + chunk * 32 + li];
+                const int hidx = row * HS + chunk * 32 + li;
                 // biases folded into the exp2 arguments: one FMA per gate instead of add + mul
                 const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
                 const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
                 const float ghn = acc[rb][3][e] + b_hn;
                 const float u = fmaf(r, ghn, acc[rb][2][e]);
                 const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
-                const float hn = fmaf(z, *hp - n, n);          // (1 - z) n + z h
-                *hp = hn;
+                const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
+                hn_buf[hidx] = hn;
                 if (a.sv_r) {
                     const int g = tile_row0 + row;
                     if (g < a.B) {
@@ -172,26 +189,11 @@ __global__ __launch_bounds__(256, 1) void gru_layer_kernel(const LayerArgs a)
                 }
             }
         }
-        __syncthreads();   // h_t complete
-
-        // ---- cooperative, coalesced write-back of h_t in SoA ----
-        float *dst = a.seq_out ? a.seq_out + (size_t)t * H * B : ((t == a.T - 1) ? a.h_last : nullptr);
-        if (dst) {
-            for (int i = threadIdx.x; i < BM * H; i += 256) {
-                const int row = i % BM, k = i / BM;
-                const int g = tile_row0 + row;
-                if (g < a.B) dst[(size_t)k * B + g] = hl[row * HS + k];
-            }
-            if (a.seq_out && a.h_last && t == a.T - 1) {
-                for (int i = threadIdx.x; i < BM * H; i += 256) {
-                    const int row = i % BM, k = i / BM;
-                    const int g = tile_row0 + row;
-                    if (g < a.B) a.h_last[(size_t)k * B + g] = hl[row * HS + k];
-                }
-            }
-        }
-        // no barrier needed here: the next step only reads hl until its first __syncthreads()
+        __syncthreads();   // h_t complete; every wave is also done with h_{t-1}, which the NEXT epilogue overwrites
     }
+    const float *hT = hl2 + (a.T & 1) * BM * HS;
+    if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
+    if (a.h_last) write_back(hT, a.h_last);
 }
 
 // Re-pack one layer's torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order.
@@ -327,16 +329,21 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     const int H = a.H, NCH = H / 32;
     const int WPC = NCH >= 4 ? 1 : 4 / NCH;
     // rows per workgroup: H = 64: RBW 2 x 2 waves/chunk = 128; H = 128: RBW 2 = 64; H = 32: RBW 1 x 4 waves/chunk = 128
-    int RBW = H == 128 ? 2 : (H == 64 ? 2 : 1);
-    // small batches: halve the row tile when the grid would leave compute units idle (256 CUs; the recurrence cannot be
-    // split across workgroups, so rows are the only parallel axis)
-    if (RBW == 2 && (a.B + 32 * RBW * WPC - 1) / (32 * RBW * WPC) < ctx->cu_count) RBW = 1;
+    int RBW = H == 32 ? 1 : 2;
+    // small batches: halve the row tile when the grid would not put two workgroups on every compute unit (256 CUs; the
+    // recurrence cannot be split across workgroups, so rows are the only parallel axis)
+    if (RBW == 2 && (a.B + 32 * RBW * WPC - 1) / (32 * RBW * WPC) < 2 * ctx->cu_count) RBW = 1;
     const int BM = 32 * RBW * WPC;
-    const size_t lds = (size_t)BM * (H + 1) * sizeof(float);
+    const size_t lds = (size_t)2 * BM * (H + 1) * sizeof(float);      // double-buffered h tile (<= 66.6 KB)
+    if (!ctx->layer_attr_set) {            // per context (= per device)
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        ctx->layer_attr_set = true;
+    }
     dim3 grid((a.B + BM - 1) / BM), block(256);
     const int slot = os_prof_begin(ctx, 1, s);
-    if (RBW == 2) hipLaunchKernelGGL(gru_layer_kernel<2>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(gru_layer_kernel<1>, grid, block, lds, s, a);
+    if (RBW == 2) hipLaunchKernelGGL((gru_layer_kernel<2, 2>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gru_layer_kernel<1, 3>), grid, block, lds, s, a);
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;

@@ -30,7 +30,7 @@ struct os_ctx {
     float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;
-    bool fused_attr_set, sweep_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
+    bool fused_attr_set, sweep_attr_set, layer_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
     // per-kernel timing (os_profile_*): ring of event pairs

@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: tools/pmc_gru.sh <tag> H L "<counters...>"  -- one rocprofv3 --pmc pass over tools/run_gru_once.py
+TAG=$1; H=$2; L=$3; shift 3
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_$TAG
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc $@ --output-format csv -d $OUT -- python3 $R/tools/run_gru_once.py 2 $H $L > $OUT.log 2>&1
+tail -2 $OUT.log
+python3 - <<PY
+import csv, glob, collections
+f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)
+if not f: print("no counter csv"); raise SystemExit
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f[0])):
+    k = r["Kernel_Name"]
+    if "gru_layer" in k:
+        acc[k[:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:32s} n={len(v)} " + " ".join(f"{x:.4g}" for x in v[:4]))
+PY
