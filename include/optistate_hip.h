@@ -163,11 +163,28 @@ size_t os_vit_param_count(const os_vit_dims *d);
 int os_vit_load(os_ctx *ctx, const os_vit_dims *d, const float *w_flat);
 int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, void *stream);
 
+/* ---- Convex-MPC ground-reaction forces ("next" row f.2): the QP the reference solves with casadi + qpOASES inside
+ * predict_mpc (misc/force_controller.py:70-162 builds it, kalman_filter/kalman_filter.py:141-152 fills the parameters
+ * and takes column 0 of the solution).  N = 5 horizon steps x 12 forces; per trajectory:
+ *     min  sum_i (x_{i+1} - body_ref)^T Q (x_{i+1} - body_ref) + u_i^T R u_i,
+ *          x_{i+1} = (I + A_i dt) x_i + B_i dt u_i + dt g   (A_0, B_0 from the current x, A_i, B_i (i >= 1) from body_ref)
+ *     s.t. contact byte 0: u_leg = 0;  contact byte 1: 0 <= fz <= fz_max, |fx| <= mu fz, |fy| <= mu fz.
+ * Solved exactly (float64 primal active-set iteration, one wavefront per trajectory); PARITY UNPINNED against qpOASES
+ * (absent), checked against the KKT-certified oracle/mpc_oracle.py.
+ * os_mpc_set_weights: diag(Q) (12), R scalar, mu, fz_max; defaults are the reference's (kalman_filter.py:64-70,
+ *   force_controller.py:147-149).
+ * os_mpc_solve: x, body_ref, p [12][B] float32 device arrays, contact [B] packed bytes -> f_out [12][B] (the forces of
+ *   horizon step 0 = self.f[:, 0], kalman_filter.py:161), optional u_out [60][B] (all steps) and iters [B];
+ *   status [B] is OR-ed with 4 where the iteration cap max_iter (<= 0: 200) was reached. */
+int os_mpc_set_weights(os_ctx *ctx, const double *q_weights, double r_weight, double mu, double fz_max);
+int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, const float *p, const uint32_t *contact,
+                 float *f_out, float *u_out, int32_t *iters, int32_t *status, int32_t max_iter, void *stream);
+
 /* Per-kernel device timing (HIP events recorded on the launch stream around each internal kernel), used by
  * bench.py for the roofline of the dominant kernel.  Phases: 0 Kalman kernel, 1 GRU layer kernels, 2 GRU head,
- * 3 fused Kalman+GRU kernel.  os_profile_read synchronises on the recorded events, adds up the elapsed
+ * 3 fused Kalman+GRU kernel, 4 MPC force QP kernel.  os_profile_read synchronises on the recorded events, adds up the elapsed
  * milliseconds and launch counts per phase since os_profile_enable(ctx, 1), and resets them. */
-#define OS_PROF_PHASES 4
+#define OS_PROF_PHASES 5
 int os_profile_enable(os_ctx *ctx, int enable);
 int os_profile_read(os_ctx *ctx, double *ms_sum /* host [OS_PROF_PHASES] */, int32_t *launches /* host [OS_PROF_PHASES] */);
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_param_count", "os_gru_load", "os_gru_forward",
     "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream", "os_profile_enable", "os_profile_read",
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
-    "os_vit_param_count", "os_vit_load", "os_vit_encode",
+    "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve",
 ]
 
 
@@ -87,6 +87,10 @@ def load():
     lib.os_vit_encode.argtypes = [vp, i32, f32p, f32p, vp]
     lib.os_vit_load.restype = C.c_int
     lib.os_vit_encode.restype = C.c_int
+    lib.os_mpc_set_weights.argtypes = [vp, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double]
+    lib.os_mpc_solve.argtypes = [vp, i32, f32p, f32p, f32p, vp, f32p, f32p, vp, vp, i32, vp]
+    lib.os_mpc_set_weights.restype = C.c_int
+    lib.os_mpc_solve.restype = C.c_int
     lib.os_profile_enable.argtypes = [vp, C.c_int]
     lib.os_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.os_profile_enable.restype = C.c_int

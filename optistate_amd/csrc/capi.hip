@@ -23,6 +23,13 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
     c->k.inv_mass = 1.0f / cfg->mass;
     c->k.gz = cfg->gz;
     for (int i = 0; i < 3; i++) c->k.inv_inertia[i] = 1.0f / cfg->inertia[i];
+    c->mass64 = (double)cfg->mass; c->gz64 = (double)cfg->gz;
+    for (int i = 0; i < 3; i++) c->inertia64[i] = (double)cfg->inertia[i];
+    {   // StanceController weights: Q = diag(10,10,10,100,100,100,1,1,5,1,1,1), R = 1e-6 I (kalman_filter.py:64-70)
+        static const double wq[12] = {10, 10, 10, 100, 100, 100, 1, 1, 5, 1, 1, 1};
+        for (int i = 0; i < 12; i++) c->mpc_w[i] = wq[i];
+        c->mpc_rw = 1e-6; c->mpc_mu = 0.6; c->mpc_fzmax = 150.0;      // force_controller.py:147-149
+    }
     // defaults: settings.py:28-31
     static const float qd[12] = {0.01f, 0.01f, 0.01f, 0.01f, 0.0001f, 0.01f, 0.01f, 0.01f, 0.01f, 0.01f, 0.01f, 0.0001f};
     for (int i = 0; i < 12; i++) c->k.Q[i * 12 + i] = qd[i];

@@ -30,6 +30,9 @@ struct os_ctx {
     float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;
+    // convex-MPC force QP (mpc_kernels.hip): weights of kalman_filter.py:64-72, constraints of force_controller.py:143-155
+    double mpc_w[12], mpc_rw, mpc_mu, mpc_fzmax;
+    double mass64, inertia64[3], gz64;
     bool fused_attr_set, sweep_attr_set, layer_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use

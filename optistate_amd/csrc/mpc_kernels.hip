@@ -1,0 +1,573 @@
+// mpc_kernels.hip -- the convex-MPC force QP of the reference (misc/force_controller.py:70-162, solved there by
+// casadi + qpOASES at kalman_filter/kalman_filter.py:150) as a batched exact active-set solver on gfx950.
+//
+// One wavefront per QP (60 variables = 3 forces x 4 legs x 5 horizon steps), lane v = variable v, float64 throughout
+// (the Hessian's spectrum spans 1e-6 ... 0.17: the 1e-6 R-term alone fixes the force distribution in the directions the
+// body wrench does not see, which float32 cannot resolve).
+//
+// Structure that keeps it cheap:
+//   * H and q are never stored.  With a_v = I_hat^-1 (R p_leg x e_c) and b_v = e_c / m the generators of variable v,
+//       H[v][w] = a_v^T (al W_w + be R1 W_th R1^T) a_w + b_v^T (al W_v + be W_r) b_w + r delta_vw,
+//       al = dt^2 (5 - max(i,l)),  be = dt^4 sum_{k>max(i,l)} (k-1-i)(k-1-l)       (i, l = horizon steps of v, w)
+//     because x_k depends on the inputs only through the per-step wrench (derivation in DESIGN.md); a row is rebuilt
+//     from the 60 six-vectors in LDS whenever it is needed.
+//   * the feasible set is a product of truncated friction pyramids, so an active set is a FACE per (leg, step):
+//     (sx, sy) in {-1, 0, +1} (fx = +-mu fz active) and sz in {free, fz = 0 (apex, f = 0), fz = fz_max}.  Restricting
+//     the QP to a face only replaces each generator by a linear combination of its leg's three generators, so the
+//     reduced Hessian has the same closed form: no KKT system, no projections of a stored matrix.
+//   * the face-restricted system (dead slots = identity rows) is solved by Gaussian elimination with one row per lane:
+//     the pivot row is broadcast through LDS, dead pivots are skipped wave-uniformly.
+// Algorithm: cold start (stance legs free, swing legs zero) -> subspace minimiser -> clamp into the pyramids -> primal
+// active-set iteration (ratio test adds the blocking constraint, multiplier signs release one constraint; at the apex the
+// dual-cone test g_z >= mu(|g_x|+|g_y|) decides and the steepest edge ray is released) until the KKT conditions hold.
+// In normal walking the clamp never triggers and one solve is the answer.
+#include "launch.hpp"
+
+#include <math.h>
+
+namespace osm {
+
+constexpr int NVMAX = 60, NLSMAX = 20;
+enum : int { SZ_FREE = 0, SZ_ZERO = 1, SZ_MAX = 2 };
+
+struct MpcParams {
+    double w[12];            // state weights (kalman_filter/kalman_filter.py:64), terminal = stage (:72)
+    double rw, mu, fzmax;    // control weight (:66), friction coefficient and force cap (force_controller.py:147-149)
+    double dt, inv_mass, inv_inertia[3], gz;
+};
+
+struct MpcArgs {
+    int B;
+    const float *x, *ref, *p;      // [12][B]
+    const uint32_t *contact;       // [B] 4 packed bytes
+    float *f_out;                  // [12][B] forces of horizon step 0
+    float *u_out;                  // [60][B] or null
+    int32_t *iters;                // [B] or null
+    int32_t *status;               // [B] bit 2 set when the iteration cap was hit (or-ed in)
+    int max_iter;
+    MpcParams prm;
+};
+
+template <int NV_>
+struct WaveMemT {
+    double gen0[NV_][6];     // generators (a, b) of the variables
+    double gent[NV_][6];     // generators of the face coordinates
+    double rows[NV_][64];    // staging of the reduced system's rows: rows[w][lane] (built by a rolled loop, then read into registers)
+    double rowbuf[64];
+    double vec[64];          // broadcast vector (solution / u / u0)
+    double al[NLSMAX];
+    int code[NLSMAX];
+};
+
+// 1/a to full double precision: v_rcp_f64 + two Newton steps (an IEEE division costs ~4x as many instructions)
+__device__ __forceinline__ double rcp64(double a)
+{
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void rotation64(double tx, double ty, double tz, double *R)
+{
+    double sx, cx, sy, cy, sz, cz;
+    sincos(tx, &sx, &cx); sincos(ty, &sy, &cy); sincos(tz, &sz, &cz);
+    R[0] = cz * cy; R[1] = cz * sy * sx - sz * cx; R[2] = cz * sy * cx + sz * sx;
+    R[3] = sz * cy; R[4] = sz * sy * sx + cz * cx; R[5] = sz * sy * cx - cz * sx;
+    R[6] = -sy;     R[7] = cy * sx;                R[8] = cy * cx;
+}
+
+// al, be of the header comment for horizon steps i, l
+__device__ __forceinline__ void alpha_beta(int i, int l, double dt, double &al, double &be)
+{
+    const int m = i > l ? i : l;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k <= 5; k++) s += (k > m) ? (k - 1 - i) * (k - 1 - l) : 0;
+    const double dt2 = dt * dt;
+    al = dt2 * (double)(5 - m);
+    be = dt2 * dt2 * (double)s;
+}
+
+struct LaneCtx {
+    int lane, v, i, leg, c, ls;
+    bool pad;
+    double Cth[9];                         // R1 diag(w_theta) R1^T (wave-uniform: kept in SGPRs via readfirstlane)
+};
+
+// Row of the reduced system for face generator g (6) at horizon step L.i against the face generators G[w] (LDS), written
+// to M.rows[w][lane].  Deliberately a ROLLED loop: unrolled, hipcc hoists all 6 * NV generator loads to the top and
+// spills them to scratch.
+template <int NPS, typename WaveMem>
+__device__ __forceinline__ void form_row(const LaneCtx &L, const MpcParams &P, const double *g, bool live, double diag_add, WaveMem &M)
+{
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < 5; l++) {
+        double al, be;
+        alpha_beta(L.i, l, P.dt, al, be);
+        double zA[3], zB[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
+            zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+        }
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < NPS; j++) {
+            const int w = NPS * l + j;
+            const double *gw = M.gent[w];
+            double val = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
+            if (w == L.v) val = live ? val + diag_add : 1.0;       // dead slots: identity row
+            else if (!live) val = 0.0;
+            M.rows[w][L.lane] = val;
+        }
+    }
+}
+
+// sum_w form(g, G[w]) * vec[w]
+template <int NPS>
+__device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P, const double *g, const double (*G)[6], const double *vec)
+{
+    double acc = 0.0;
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < 5; l++) {
+        double al, be;
+        alpha_beta(L.i, l, P.dt, al, be);
+        double zA[3], zB[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
+            zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+        }
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < NPS; j++) {
+            const int w = NPS * l + j;
+            const double *gw = G[w];
+            acc += (zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5]) * vec[w];
+        }
+    }
+    return acc;
+}
+
+// Minimiser of the QP restricted to the face (sx, sy, sz of this lane's leg-step); returns this lane's component.
+template <int NST, typename WaveMem>
+__device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &P, WaveMem &M, int sx, int sy, int sz,
+                                             const double *cw, const double *cv /* this lane's step */)
+{
+    constexpr int NV = 15 * NST, NPS = 3 * NST;
+    const int b0 = 3 * L.ls;
+    // ---- face generators ----
+    bool live;
+    double g[6], tt = 1.0;
+    if (L.c == 2) {
+        live = sz == SZ_FREE;
+        const double fx = sx * P.mu, fy = sy * P.mu;
+#pragma unroll
+        for (int r = 0; r < 6; r++) g[r] = M.gen0[b0 + 2][r] + fx * M.gen0[b0][r] + fy * M.gen0[b0 + 1][r];
+        tt = 1.0 + P.mu * P.mu * (double)(sx * sx + sy * sy);
+    } else {
+        live = sz != SZ_ZERO && (L.c == 0 ? sx : sy) == 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) g[r] = M.gen0[L.v][r];
+    }
+    live = live && !L.pad;
+    if (!live) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) g[r] = 0.0;
+    }
+    // the fixed part of the face (fz = fz_max faces)
+    const double u0 = (sz == SZ_MAX && !L.pad) ? (L.c == 2 ? P.fzmax : (double)(L.c == 0 ? sx : sy) * P.mu * P.fzmax) : 0.0;
+    const bool any_u0 = __ballot(u0 != 0.0) != 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (!L.pad) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) M.gent[L.v][r] = g[r];
+        M.vec[L.v] = u0;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- row of the reduced system ----
+    form_row<NPS>(L, P, g, live, P.rw * tt, M);
+    double rhs = -(g[0] * cw[0] + g[1] * cw[1] + g[2] * cw[2] + g[3] * cv[0] + g[4] * cv[1] + g[5] * cv[2]);
+    if (any_u0) rhs -= form_dot<NPS>(L, P, g, M.gen0, M.vec);
+    double A[NV + 1];
+#pragma unroll
+    for (int w = 0; w < NV; w++) A[w] = M.rows[w][L.lane];
+    A[NV] = live ? rhs : 0.0;
+    const unsigned long long live_mask = __ballot(live);
+
+    // ---- forward elimination, one row per lane, pivot row broadcast through LDS ----
+    double dinv = 1.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        if (!((live_mask >> k) & 1ull)) continue;          // wave-uniform
+        __builtin_amdgcn_wave_barrier();
+        if (L.lane == k) {
+#pragma unroll
+            for (int j = k; j <= NV; j++) M.rowbuf[j] = A[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double inv = rcp64(M.rowbuf[k]);
+        if (L.lane == k) dinv = inv;
+        const double f = (L.lane > k && L.lane < NV) ? A[k] * inv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j <= NV; j++) {
+            A[j] = fma(-f, M.rowbuf[j], A[j]);
+            if (((j - k) & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- back substitution ----
+    double r = A[NV], sol = 0.0;
+#pragma unroll
+    for (int k = NV - 1; k >= 0; k--) {
+        if (!((live_mask >> k) & 1ull)) continue;
+        const double wk = readlane_f64(r * dinv, k);
+        if (L.lane == k) sol = wk;
+        if (L.lane < k) r = fma(-A[k], wk, r);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- face coordinates -> forces ----
+    __builtin_amdgcn_wave_barrier();
+    if (!L.pad) M.vec[L.v] = sol;
+    __builtin_amdgcn_wave_barrier();
+    const double fz = sz == SZ_MAX ? P.fzmax : (sz == SZ_ZERO ? 0.0 : M.vec[b0 + 2]);
+    double u;
+    if (L.c == 2) u = fz;
+    else {
+        const int s = L.c == 0 ? sx : sy;
+        u = s != 0 ? (double)s * P.mu * fz : (sz == SZ_ZERO ? 0.0 : sol);
+    }
+    return L.pad ? 0.0 : u;
+}
+
+// NST = number of legs that carry force variables (contact byte != 0).  Swing legs are eliminated up front: a trot
+// problem has 30 variables, not 60 (elimination work ~ n^3), and each instance gets the register budget its row needs.
+// Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
+template <int NST>
+__global__ __launch_bounds__(64, 2) void mpc_solve_kernel(const MpcArgs a)
+{
+    constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST;
+    typedef WaveMemT<15 * NST> WaveMem;
+    __shared__ WaveMem M;
+    const MpcParams &P = a.prm;
+    const int b = blockIdx.x;
+    const size_t B = (size_t)a.B;
+    const uint32_t cbits = a.contact[b];
+    int legs[4] = {0, 0, 0, 0}, nst = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        if (((cbits >> (8 * l)) & 0xffu) != 0u) {
+            if (nst == 0) legs[0] = l; else if (nst == 1) legs[1] = l; else if (nst == 2) legs[2] = l; else legs[3] = l;
+            nst++;
+        }
+    }
+    if (nst == 0 && NST == 1) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
+        const int t = threadIdx.x;
+        if (t < 12) a.f_out[(size_t)t * B + b] = 0.f;
+        if (a.u_out && t < 60) a.u_out[(size_t)t * B + b] = 0.f;
+        if (t == 0 && a.iters) a.iters[b] = 0;
+        return;
+    }
+    if (nst != NST) return;
+
+    LaneCtx L;
+    L.lane = threadIdx.x;
+    L.pad = L.lane >= NV;
+    L.v = L.pad ? NV - 1 : L.lane;
+    L.i = L.v / NPS; L.c = L.v % 3; L.ls = L.v / 3;
+    {
+        const int rank = (L.v % NPS) / 3;
+        L.leg = rank == 0 ? legs[0] : (rank == 1 ? legs[1] : (rank == 2 ? legs[2] : legs[3]));
+    }
+
+    // ---- problem data (wave-uniform) ----
+    double x[12], ref[12], p[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        x[j] = (double)a.x[(size_t)j * B + b];
+        ref[j] = (double)a.ref[(size_t)j * B + b];
+        p[j] = (double)a.p[(size_t)j * B + b];
+    }
+    const uint32_t cleg = (cbits >> (8 * L.leg)) & 0xffu;
+    const bool stance = cleg == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
+
+    double R0[9], R1[9];
+    rotation64(x[0], x[1], x[2], R0);
+    rotation64(ref[0], ref[1], ref[2], R1);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+            L.Cth[3 * r + s] = readlane_f64(R1[3 * r] * P.w[0] * R1[3 * s] + R1[3 * r + 1] * P.w[1] * R1[3 * s + 1] + R1[3 * r + 2] * P.w[2] * R1[3 * s + 2], 0);
+
+    // generators of this lane's variable: a = I_hat^-1 (R p_leg x e_c), b = e_c / m, with R of the lane's horizon step
+    {
+        const double *R = L.i == 0 ? R0 : R1;
+        double Rm[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) Rm[r] = L.i == 0 ? R0[r] : R1[r];
+        (void)R;
+        double px = p[0], py = p[1], pz = p[2];
+#pragma unroll
+        for (int l = 1; l < 4; l++)
+            if (L.leg == l) { px = p[3 * l]; py = p[3 * l + 1]; pz = p[3 * l + 2]; }
+        const double wx = Rm[0] * px + Rm[1] * py + Rm[2] * pz, wy = Rm[3] * px + Rm[4] * py + Rm[5] * pz,
+                     wz = Rm[6] * px + Rm[7] * py + Rm[8] * pz;
+        double cr[3];                                  // pw x e_c
+        if (L.c == 0) { cr[0] = 0.0; cr[1] = wz; cr[2] = -wy; }
+        else if (L.c == 1) { cr[0] = -wz; cr[1] = 0.0; cr[2] = wx; }
+        else { cr[0] = wy; cr[1] = -wx; cr[2] = 0.0; }
+        // I_hat^-1 = R diag(1/I) R^T
+        double tb[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) tb[k] = (Rm[k] * cr[0] + Rm[3 + k] * cr[1] + Rm[6 + k] * cr[2]) * P.inv_inertia[k];
+        double g0[6];
+#pragma unroll
+        for (int r = 0; r < 3; r++) g0[r] = Rm[3 * r] * tb[0] + Rm[3 * r + 1] * tb[1] + Rm[3 * r + 2] * tb[2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) g0[3 + r] = (r == L.c) ? P.inv_mass : 0.0;
+        if (!L.pad) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) M.gen0[L.v][r] = g0[r];
+        }
+    }
+
+    // linear term: q_v = a_v . cw_i + b_v . cv_i from the zero-input trajectory (see header / DESIGN.md)
+    double cw[3] = {0, 0, 0}, cv[3] = {0, 0, 0};
+    {
+        const double dt = P.dt;
+        double r0w[3], r1w[3];             // R0^T w0, R1^T w0
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            r0w[r] = R0[r] * x[6] + R0[3 + r] * x[7] + R0[6 + r] * x[8];
+            r1w[r] = R1[r] * x[6] + R1[3 + r] * x[7] + R1[6 + r] * x[8];
+        }
+#pragma unroll
+        for (int k = 1; k <= 5; k++) {
+            if (k <= L.i) continue;
+            const double kk = (double)k, lev = (double)(k - 1 - L.i);
+            double eth[3], er[3], ew[3], ev[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                eth[r] = x[r] + dt * (r0w[r] + (kk - 1.0) * r1w[r]) - ref[r];
+                er[r] = x[3 + r] + dt * kk * x[9 + r] - ref[3 + r];
+                ew[r] = x[6 + r] - ref[6 + r];
+                ev[r] = x[9 + r] - ref[9 + r];
+            }
+            er[2] += dt * dt * P.gz * kk * (kk - 1.0) * 0.5;
+            ev[2] += kk * dt * P.gz;
+            double wt[3] = {P.w[0] * eth[0], P.w[1] * eth[1], P.w[2] * eth[2]};
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                cw[r] += dt * P.w[6 + r] * ew[r] + dt * dt * lev * (R1[3 * r] * wt[0] + R1[3 * r + 1] * wt[1] + R1[3 * r + 2] * wt[2]);
+                cv[r] += dt * P.w[9 + r] * ev[r] + dt * dt * lev * P.w[3 + r] * er[r];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- cold start: stance (and unconstrained) legs free, swing legs zero; then the primal active-set iteration ----
+    int sx = 0, sy = 0, sz = SZ_FREE;
+    double u = 0.0;
+    int iters = 0;
+    bool first = true, done = false, converged = false;
+    constexpr double EPS = 1e-11, TOL = 1e-12;
+    while (!done && iters < a.max_iter) {
+        iters++;
+        const double us = solve_face<NST>(L, P, M, sx, sy, sz, cw, cv);
+        if (first) {
+            // clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
+            first = false;
+            u = us;
+            __builtin_amdgcn_wave_barrier();
+            if (!L.pad) M.vec[L.v] = u;
+            __builtin_amdgcn_wave_barrier();
+            bool clamped = false;
+            if (stance && !L.pad) {
+                double fx = M.vec[3 * L.ls], fy = M.vec[3 * L.ls + 1], fz = M.vec[3 * L.ls + 2];
+                if (fz <= 0.0) { sx = 0; sy = 0; sz = SZ_ZERO; fx = fy = fz = 0.0; clamped = true; }
+                else {
+                    if (fz >= P.fzmax) { sz = SZ_MAX; fz = P.fzmax; clamped = true; }
+                    const double lim = P.mu * fz;
+                    if (fx >= lim) { sx = 1; fx = lim; clamped = true; } else if (fx <= -lim) { sx = -1; fx = -lim; clamped = true; }
+                    if (fy >= lim) { sy = 1; fy = lim; clamped = true; } else if (fy <= -lim) { sy = -1; fy = -lim; clamped = true; }
+                }
+                u = L.c == 0 ? fx : (L.c == 1 ? fy : fz);
+            }
+            if (__ballot(clamped) == 0ull) { done = true; converged = true; }
+            continue;
+        }
+        const double d = us - u;
+        __builtin_amdgcn_wave_barrier();
+        if (!L.pad) { M.vec[L.v] = u; M.rowbuf[L.v] = d; }
+        __builtin_amdgcn_wave_barrier();
+        // ratio test of this lane's leg-step (computed by its fz lane)
+        if (L.c == 2 && !L.pad) {
+            double best = 2.0; int code = 0;
+            if (stance && sz != SZ_ZERO) {
+                const double fx = M.vec[3 * L.ls], fy = M.vec[3 * L.ls + 1], fz = M.vec[3 * L.ls + 2];
+                const double dx = M.rowbuf[3 * L.ls], dy = M.rowbuf[3 * L.ls + 1], dz = M.rowbuf[3 * L.ls + 2];
+                auto cand = [&](double num, double den, int cd) {
+                    if (den > EPS) {
+                        const double al = fmax(0.0, num * rcp64(den));
+                        if (al < best) { best = al; code = cd; }
+                    }
+                };
+                if (sz == SZ_FREE) { cand(fz, -dz, 1); cand(P.fzmax - fz, dz, 2); }
+                if (sx == 0) { cand(P.mu * fz - fx, dx - P.mu * dz, 3); cand(P.mu * fz + fx, -dx - P.mu * dz, 4); }
+                if (sy == 0) { cand(P.mu * fz - fy, dy - P.mu * dz, 5); cand(P.mu * fz + fy, -dy - P.mu * dz, 6); }
+            }
+            M.al[L.ls] = best; M.code[L.ls] = code;
+        }
+        __builtin_amdgcn_wave_barrier();
+        double amin = 1.0; int lsmin = -1, cmin = 0;
+        for (int q = 0; q < NLS; q++) {
+            const double aq = M.al[q];
+            if (aq < amin) { amin = aq; lsmin = q; cmin = M.code[q]; }
+        }
+        u += amin * d;
+        if (lsmin >= 0) {
+            if (L.ls == lsmin && !L.pad) {
+                if (cmin == 1) { sx = 0; sy = 0; sz = SZ_ZERO; }
+                else if (cmin == 2) sz = SZ_MAX;
+                else if (cmin == 3) sx = 1;
+                else if (cmin == 4) sx = -1;
+                else if (cmin == 5) sy = 1;
+                else if (cmin == 6) sy = -1;
+            }
+        }
+        // snap onto the face equalities
+        __builtin_amdgcn_wave_barrier();
+        if (!L.pad) M.vec[L.v] = u;
+        __builtin_amdgcn_wave_barrier();
+        if (!L.pad && stance) {
+            double fz = M.vec[3 * L.ls + 2];
+            if (sz == SZ_ZERO) fz = 0.0;
+            if (sz == SZ_MAX) fz = P.fzmax;
+            if (L.c == 2) u = fz;
+            else {
+                const int s = L.c == 0 ? sx : sy;
+                if (sz == SZ_ZERO) u = 0.0;
+                else if (s != 0) u = (double)s * P.mu * fz;
+            }
+        }
+        if (lsmin >= 0) continue;
+
+        // subspace minimiser reached: multiplier signs
+        __builtin_amdgcn_wave_barrier();
+        if (!L.pad) M.vec[L.v] = u;
+        __builtin_amdgcn_wave_barrier();
+        double g0[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) g0[r] = M.gen0[L.v][r];
+        const double q0 = g0[0] * cw[0] + g0[1] * cw[1] + g0[2] * cw[2] + g0[3] * cv[0] + g0[4] * cv[1] + g0[5] * cv[2];
+        const double grad = 2.0 * (form_dot<NPS>(L, P, g0, M.gen0, M.vec) + P.rw * u + q0);
+        __builtin_amdgcn_wave_barrier();
+        if (!L.pad) M.rowbuf[L.v] = grad;
+        __builtin_amdgcn_wave_barrier();
+        if (L.c == 2 && !L.pad) {
+            double best = TOL; int code = 0;
+            if (stance) {
+                const double gx = M.rowbuf[3 * L.ls], gy = M.rowbuf[3 * L.ls + 1], gz = M.rowbuf[3 * L.ls + 2];
+                if (sz == SZ_ZERO) {
+                    // apex: optimal iff the gradient lies in the dual cone; otherwise release along the steepest edge ray
+                    const double vx = P.mu * fabs(gx), vy = P.mu * fabs(gy);
+                    const double val = gz - vx - vy;
+                    if (-val > best) { best = -val; code = 16 + (gx > 0.0 ? 0 : 1) + (gy > 0.0 ? 0 : 2); }
+                } else {
+                    if (sx == 1 && gx > best) { best = gx; code = 1; }
+                    if (sx == -1 && -gx > best) { best = -gx; code = 1; }
+                    if (sy == 1 && gy > best) { best = gy; code = 2; }
+                    if (sy == -1 && -gy > best) { best = -gy; code = 2; }
+                    if (sz == SZ_MAX) {
+                        const double lamU = -gz - sx * P.mu * gx - sy * P.mu * gy;
+                        if (-lamU > best) { best = -lamU; code = 3; }
+                    }
+                }
+            }
+            M.al[L.ls] = best; M.code[L.ls] = code;
+        }
+        __builtin_amdgcn_wave_barrier();
+        double rmax = TOL; int lsr = -1, cr = 0;
+        for (int q = 0; q < NLS; q++) {
+            const double aq = M.al[q];
+            if (M.code[q] != 0 && aq > rmax) { rmax = aq; lsr = q; cr = M.code[q]; }
+        }
+        if (lsr < 0) { done = true; converged = true; break; }
+        if (L.ls == lsr && !L.pad) {
+            if (cr == 1) sx = 0;
+            else if (cr == 2) sy = 0;
+            else if (cr == 3) sz = SZ_FREE;
+            else { sx = (cr & 1) ? 1 : -1; sy = (cr & 2) ? 1 : -1; sz = SZ_FREE; }
+        }
+    }
+
+    // ---- outputs in the reference's variable order (12 per horizon step, leg-major); swing legs are zero ----
+    __builtin_amdgcn_wave_barrier();
+    if (!L.pad) M.vec[L.v] = u;
+    __builtin_amdgcn_wave_barrier();
+    if (L.lane < 60) {
+        const int oi = L.lane / 12, oleg = (L.lane % 12) / 3, oc = L.lane % 3;
+        int rank = -1;
+#pragma unroll
+        for (int r = 0; r < NST; r++)
+            if ((r == 0 ? legs[0] : (r == 1 ? legs[1] : (r == 2 ? legs[2] : legs[3]))) == oleg) rank = r;
+        const float val = rank < 0 ? 0.f : (float)M.vec[oi * NPS + 3 * rank + oc];
+        if (L.lane < 12) a.f_out[(size_t)L.lane * B + b] = val;
+        if (a.u_out) a.u_out[(size_t)L.lane * B + b] = val;
+    }
+    if (L.lane == 0) {
+        if (a.iters) a.iters[b] = iters;
+        if (!converged) a.status[b] |= 4;
+    }
+}
+
+}  // namespace osm
+
+extern "C" {
+
+int os_mpc_set_weights(os_ctx *ctx, const double *q_weights, double r_weight, double mu, double fz_max)
+{
+    OS_CHECK_CTX(ctx);
+    if (!q_weights) return os_fail(ctx, -2, "os_mpc_set_weights: null weights");
+    for (int i = 0; i < 12; i++) {
+        if (!(q_weights[i] >= 0.0)) return os_fail(ctx, -2, "os_mpc_set_weights: weights must be non-negative");
+        ctx->mpc_w[i] = q_weights[i];
+    }
+    if (!(r_weight > 0.0) || !(mu >= 0.0) || !(fz_max > 0.0)) return os_fail(ctx, -2, "os_mpc_set_weights: need r_weight > 0, mu >= 0, fz_max > 0");
+    ctx->mpc_rw = r_weight; ctx->mpc_mu = mu; ctx->mpc_fzmax = fz_max;
+    return 0;
+}
+
+int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, const float *p, const uint32_t *contact,
+                 float *f_out, float *u_out, int32_t *iters, int32_t *status, int32_t max_iter, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0) return os_fail(ctx, -2, "os_mpc_solve: B must be positive");
+    if (!x || !body_ref || !p || !contact || !f_out || !status) return os_fail(ctx, -2, "os_mpc_solve: null required pointer");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    osm::MpcArgs a;
+    a.B = B; a.x = x; a.ref = body_ref; a.p = p; a.contact = contact; a.f_out = f_out; a.u_out = u_out; a.iters = iters;
+    a.status = status; a.max_iter = max_iter > 0 ? max_iter : 200;
+    for (int i = 0; i < 12; i++) a.prm.w[i] = ctx->mpc_w[i];
+    a.prm.rw = ctx->mpc_rw; a.prm.mu = ctx->mpc_mu; a.prm.fzmax = ctx->mpc_fzmax;
+    a.prm.dt = (double)ctx->k.dt; a.prm.inv_mass = 1.0 / ctx->mass64; a.prm.gz = ctx->gz64;
+    for (int i = 0; i < 3; i++) a.prm.inv_inertia[i] = 1.0 / ctx->inertia64[i];
+    hipStream_t s = (hipStream_t)stream;
+    const int slot = os_prof_begin(ctx, 4, s);
+    hipLaunchKernelGGL(osm::mpc_solve_kernel<1>, dim3(B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(osm::mpc_solve_kernel<2>, dim3(B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(osm::mpc_solve_kernel<3>, dim3(B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(osm::mpc_solve_kernel<4>, dim3(B), dim3(64), 0, s, a);
+    os_prof_end(ctx, slot, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -224,6 +224,25 @@ class Engine:
         return dict(out=out, x_out=x_out, status=status)
 
 
+    # ---- convex-MPC ground-reaction forces (misc/force_controller.py:70-162, kalman_filter.py:141-152) ----
+    def mpc_set_weights(self, q_weights, r_weight=1e-6, mu=0.6, fz_max=150.0):
+        """diag(Q) of the stance controller (kalman_filter.py:64), R scalar (:66), friction and force cap (force_controller.py:147-149)."""
+        w = (C.c_double * 12)(*[float(v) for v in q_weights])
+        self._check(self.lib.os_mpc_set_weights(self._h, w, float(r_weight), float(mu), float(fz_max)), "os_mpc_set_weights")
+
+    def mpc_solve(self, x, body_ref, p, contact, want_all=False, max_iter=0):
+        """x, body_ref, p: [12][B] float32 device tensors; contact: [B] packed uint32 (int32 storage).
+        Returns dict(f [12][B] = column 0 of the optimal controls, status [B], iters [B], u [60][B] if want_all)."""
+        B = x.shape[1]
+        f = torch.empty((12, B), dtype=torch.float32, device=self.device)
+        u = torch.empty((60, B), dtype=torch.float32, device=self.device) if want_all else None
+        iters = torch.empty((B,), dtype=torch.int32, device=self.device)
+        status = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.os_mpc_solve(self._h, B, _ptr(x), _ptr(body_ref), _ptr(p), _ptr(contact), _ptr(f), _ptr(u),
+                                          _ptr(iters), _ptr(status), int(max_iter), self._stream()), "os_mpc_solve")
+        return dict(f=f, u=u, iters=iters, status=status)
+
+
 def flatten_state_dict(sd, num_layers, device=None):
     """state_dict with the reference's keys (gru.weight_ih_l{k}, gru.weight_hh_l{k}, gru.bias_ih_l{k},
     gru.bias_hh_l{k}, fc.weight, fc.bias) -> flat float32 tensor."""

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Device timing + iteration statistics of os_mpc_solve (development aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from optistate_amd import Engine
+from optistate_amd.synth import synth_torch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+eng = Engine(0)
+d = synth_torch(B, 2, "cuda", seed=1)
+c = eng.contact_soa_to_packed(d["contact"])[0].contiguous()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+x = d["x0"].clone()
+x += scale * torch.randn(x.shape, device="cuda", generator=g) * torch.tensor([0.05] * 3 + [0.02] * 3 + [0.2] * 3 + [0.1] * 3, device="cuda")[:, None]
+ref = torch.zeros_like(x); ref[5] = 0.28; ref[9] = 0.1
+ref += scale * torch.randn(x.shape, device="cuda", generator=g) * 0.02
+p = d["p"][0].contiguous()
+r = eng.mpc_solve(x, ref, p, c)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+n = 3
+for _ in range(n):
+    r = eng.mpc_solve(x, ref, p, c)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+it = r["iters"].cpu().numpy()
+print(f"B={B} scale={scale}: {ms:.3f} ms per batch -> {B / ms * 1e3:.3e} QP/s; iters mean {it.mean():.2f} max {it.max()} hist {np.bincount(it)[:12]}; status nonzero {int((r['status'] != 0).sum())}")
