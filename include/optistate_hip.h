@@ -60,6 +60,7 @@ enum {
     OS_FUSED_TWO_KERNEL     = 8,  /* os_fused_run only: force the general two-kernel path (Kalman kernel writes the
                                      normalised feature rows to context scratch, GRU kernels read them) even where
                                      the single-kernel path applies (60 features, hidden 64, sequential+symmetric). */
+    OS_MPC_COLD_START       = 64, /* os_kf_mpc_run: do not reuse the previous step's active set (development / tests) */
     OS_KF_LANE_PER_TRAJECTORY = 32 /* os_kf_run: never use the small-batch kernel (16 lanes per trajectory, row-parallel P),
                                      which is otherwise chosen for sequential updates when B < 10,240 (the measured crossover). */
 };
@@ -179,6 +180,18 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
 int os_mpc_set_weights(os_ctx *ctx, const double *q_weights, double r_weight, double mu, double fz_max);
 int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, const float *p, const uint32_t *contact,
                  float *f_out, float *u_out, int32_t *iters, int32_t *status, int32_t max_iter, void *stream);
+
+/* B trajectories x T steps of Kalman_Filter.estimate_state_mpc (kalman_filter/kalman_filter.py:176-182) exactly as
+ * data_collection/data_conversion_Kalman_to_Training.py:194-199 drives it: per step the forces come from the QP above
+ * (solved from the state before the predict), then get_odom + set_measurements + predict_mpc (dense F_d covariance,
+ * next_state with f[:, 0]) + update.  Streams as os_kf_run; f_out [T][12][B] receives the forces (KF2.f[:, 0], the
+ * feature columns 18..29 of :248-250), mpc_iters [T][B] (optional) the active-set iteration counts; status [B] is
+ * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  Launches two to five kernels per step and reads the
+ * contact stream's leg-count histogram back once per call (one stream synchronisation at entry). */
+int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
+                  const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *f_out,
+                  float *p_rot_out, float *ptrace_out, float *kgain_out, int32_t *mpc_iters, int32_t *status,
+                  uint32_t flags, void *stream);
 
 /* Per-kernel device timing (HIP events recorded on the launch stream around each internal kernel), used by
  * bench.py for the roofline of the dominant kernel.  Phases: 0 Kalman kernel, 1 GRU layer kernels, 2 GRU head,

@@ -11,6 +11,7 @@ OS_KF_DENSE_FD = 2
 OS_KF_SYMMETRIC_P = 4
 OS_FUSED_TWO_KERNEL = 8
 OS_KF_LANE_PER_TRAJECTORY = 32
+OS_MPC_COLD_START = 64
 
 # every symbol include/optistate_hip.h declares
 EXPORTS = [
@@ -18,7 +19,7 @@ EXPORTS = [
     "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_param_count", "os_gru_load", "os_gru_forward",
     "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream", "os_profile_enable", "os_profile_read",
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
-    "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve",
+    "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
 ]
 
 
@@ -89,6 +90,8 @@ def load():
     lib.os_vit_encode.restype = C.c_int
     lib.os_mpc_set_weights.argtypes = [vp, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double]
     lib.os_mpc_solve.argtypes = [vp, i32, f32p, f32p, f32p, vp, f32p, f32p, vp, vp, i32, vp]
+    lib.os_kf_mpc_run.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp, vp, u32, vp]
+    lib.os_kf_mpc_run.restype = C.c_int
     lib.os_mpc_set_weights.restype = C.c_int
     lib.os_mpc_solve.restype = C.c_int
     lib.os_profile_enable.argtypes = [vp, C.c_int]

@@ -24,6 +24,9 @@
 #include "launch.hpp"
 
 #include <math.h>
+#include <stdlib.h>
+
+#include "kf_args.hpp"
 
 namespace osm {
 
@@ -45,6 +48,11 @@ struct MpcArgs {
     int32_t *iters;                // [B] or null
     int32_t *status;               // [B] bit 2 set when the iteration cap was hit (or-ed in)
     int max_iter;
+    // warm start across the steps of os_kf_mpc_run (null: always cold): the previous step's solution and faces are reused
+    // when the trajectory's contact word is unchanged (the pyramids do not move, so the old u stays feasible)
+    double *warm_u;                // [B][64]
+    uint8_t *warm_state;           // [B][64]  (sx+1) | (sy+1) << 2 | sz << 4 of the lane's leg-step
+    uint32_t *warm_contact;        // [B]
     MpcParams prm;
 };
 
@@ -272,6 +280,7 @@ __global__ __launch_bounds__(64, 2) void mpc_solve_kernel(const MpcArgs a)
         if (t < 12) a.f_out[(size_t)t * B + b] = 0.f;
         if (a.u_out && t < 60) a.u_out[(size_t)t * B + b] = 0.f;
         if (t == 0 && a.iters) a.iters[b] = 0;
+        if (t == 0 && a.warm_contact) a.warm_contact[b] = cbits;
         return;
     }
     if (nst != NST) return;
@@ -377,6 +386,12 @@ __global__ __launch_bounds__(64, 2) void mpc_solve_kernel(const MpcArgs a)
     double u = 0.0;
     int iters = 0;
     bool first = true, done = false, converged = false;
+    if (a.warm_u && a.warm_contact[b] == cbits) {
+        u = a.warm_u[(size_t)b * 64 + L.lane];
+        const int st = a.warm_state[(size_t)b * 64 + L.lane];
+        sx = (st & 3) - 1; sy = ((st >> 2) & 3) - 1; sz = (st >> 4) & 3;
+        first = false;
+    }
     constexpr double EPS = 1e-11, TOL = 1e-12;
     while (!done && iters < a.max_iter) {
         iters++;
@@ -522,13 +537,58 @@ __global__ __launch_bounds__(64, 2) void mpc_solve_kernel(const MpcArgs a)
         if (L.lane < 12) a.f_out[(size_t)L.lane * B + b] = val;
         if (a.u_out) a.u_out[(size_t)L.lane * B + b] = val;
     }
+    if (a.warm_u) {
+        a.warm_u[(size_t)b * 64 + L.lane] = L.pad ? 0.0 : u;
+        a.warm_state[(size_t)b * 64 + L.lane] = (uint8_t)((sx + 1) | ((sy + 1) << 2) | (sz << 4));
+        if (L.lane == 0) a.warm_contact[b] = cbits;
+    }
     if (L.lane == 0) {
         if (a.iters) a.iters[b] = iters;
         if (!converged) a.status[b] |= 4;
     }
 }
 
+// which leg counts occur at each step of a [T][B] contact stream: flags[t] bit n set <=> some trajectory has n legs on the ground
+__global__ void nst_presence_kernel(int B, int T, const uint32_t *contact, uint32_t *flags)
+{
+    const int t = blockIdx.y;
+    uint32_t m = 0;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const uint32_t c = contact[(size_t)t * B + b];
+        const int n = ((c & 0xffu) != 0) + (((c >> 8) & 0xffu) != 0) + (((c >> 16) & 0xffu) != 0) + (((c >> 24) & 0xffu) != 0);
+        m |= 1u << n;
+    }
+    if (m) atomicOr(&flags[t], m);
+}
+
+__global__ void or_status_kernel(int B, int32_t *dst, const int32_t *src)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) dst[b] |= src[b];
+}
+
+static void fill_args(os_ctx *ctx, MpcArgs &a)
+{
+    for (int i = 0; i < 12; i++) a.prm.w[i] = ctx->mpc_w[i];
+    a.prm.rw = ctx->mpc_rw; a.prm.mu = ctx->mpc_mu; a.prm.fzmax = ctx->mpc_fzmax;
+    a.prm.dt = (double)ctx->k.dt; a.prm.inv_mass = 1.0 / ctx->mass64; a.prm.gz = ctx->gz64;
+    for (int i = 0; i < 3; i++) a.prm.inv_inertia[i] = 1.0 / ctx->inertia64[i];
+}
+
+// nst_mask: bit n set = launch the instance for n legs on the ground (bit 0 rides on the 1-leg instance)
+static void launch_instances(const MpcArgs &a, uint32_t nst_mask, hipStream_t s)
+{
+    const dim3 grid(a.B), block(64);
+    if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a);
+    if (nst_mask & 4u) hipLaunchKernelGGL(mpc_solve_kernel<2>, grid, block, 0, s, a);
+    if (nst_mask & 8u) hipLaunchKernelGGL(mpc_solve_kernel<3>, grid, block, 0, s, a);
+    if (nst_mask & 16u) hipLaunchKernelGGL(mpc_solve_kernel<4>, grid, block, 0, s, a);
+}
+
 }  // namespace osm
+
+int os_kf_run_impl(os_ctx *ctx, osk::KfRunArgs &a, uint32_t flags, hipStream_t s);   // kf_kernels.hip
+int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats);   // gru_kernels.hip
 
 extern "C" {
 
@@ -555,17 +615,78 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
     osm::MpcArgs a;
     a.B = B; a.x = x; a.ref = body_ref; a.p = p; a.contact = contact; a.f_out = f_out; a.u_out = u_out; a.iters = iters;
     a.status = status; a.max_iter = max_iter > 0 ? max_iter : 200;
-    for (int i = 0; i < 12; i++) a.prm.w[i] = ctx->mpc_w[i];
-    a.prm.rw = ctx->mpc_rw; a.prm.mu = ctx->mpc_mu; a.prm.fzmax = ctx->mpc_fzmax;
-    a.prm.dt = (double)ctx->k.dt; a.prm.inv_mass = 1.0 / ctx->mass64; a.prm.gz = ctx->gz64;
-    for (int i = 0; i < 3; i++) a.prm.inv_inertia[i] = 1.0 / ctx->inertia64[i];
+    a.warm_u = nullptr; a.warm_state = nullptr; a.warm_contact = nullptr;
+    osm::fill_args(ctx, a);
     hipStream_t s = (hipStream_t)stream;
     const int slot = os_prof_begin(ctx, 4, s);
-    hipLaunchKernelGGL(osm::mpc_solve_kernel<1>, dim3(B), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(osm::mpc_solve_kernel<2>, dim3(B), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(osm::mpc_solve_kernel<3>, dim3(B), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(osm::mpc_solve_kernel<4>, dim3(B), dim3(64), 0, s, a);
+    osm::launch_instances(a, 31u, s);       // all leg counts: a wavefront whose problem has another count exits at once
     os_prof_end(ctx, slot, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
+                  const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *f_out,
+                  float *p_rot_out, float *ptrace_out, float *kgain_out, int32_t *mpc_iters, int32_t *status,
+                  uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0) return os_fail(ctx, -2, "os_kf_mpc_run: B and T must be positive");
+    if (!p || !dp || !imu || !contact || !body_ref || !x || !P || !x_out || !f_out || !status)
+        return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    // scratch: warm-start store (u [B][64] doubles, faces [B][64] bytes, contact [B]) + per-step Kalman status [B] +
+    // leg-count presence flags [T]
+    const size_t need = (size_t)B * 128 + (size_t)B * 16 + (size_t)B + (size_t)B + (size_t)T;
+    if (os_ensure_scratch(ctx, &ctx->mpc_scratch, &ctx->mpc_scratch_floats, need)) return -10;
+    double *warm_u = (double *)ctx->mpc_scratch;                       // hipMalloc alignment covers the doubles
+    uint8_t *warm_state = (uint8_t *)(ctx->mpc_scratch + (size_t)B * 128);
+    uint32_t *warm_contact = (uint32_t *)(ctx->mpc_scratch + (size_t)B * 144);
+    int32_t *st_step = (int32_t *)(ctx->mpc_scratch + (size_t)B * 145);
+    uint32_t *flags_d = (uint32_t *)(ctx->mpc_scratch + (size_t)B * 146);
+    // no previous solution: u = 0 with all faces free is feasible for every contact word, so even a match is harmless
+    OS_HIP(ctx, hipMemsetAsync(warm_u, 0, (size_t)B * 64 * sizeof(double), s));
+    OS_HIP(ctx, hipMemsetAsync(warm_state, 0x05, (size_t)B * 64, s));
+    OS_HIP(ctx, hipMemsetAsync(warm_contact, 0xff, (size_t)B * sizeof(uint32_t), s));
+    OS_HIP(ctx, hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
+    OS_HIP(ctx, hipMemsetAsync(flags_d, 0, (size_t)T * sizeof(uint32_t), s));
+    {
+        const int gx = (B + 255) / 256 < 64 ? (B + 255) / 256 : 64;
+        hipLaunchKernelGGL(osm::nst_presence_kernel, dim3(gx, T), dim3(256), 0, s, B, T, contact, flags_d);
+    }
+    // one host read-back per call: only the solver instances a step needs are launched
+    uint32_t *flags_h = (uint32_t *)malloc((size_t)T * sizeof(uint32_t));
+    if (!flags_h) return os_fail(ctx, -13, "os_kf_mpc_run: out of host memory");
+    hipError_t e = hipMemcpyAsync(flags_h, flags_d, (size_t)T * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { free(flags_h); return os_fail(ctx, -10, hipGetErrorString(e)); }
+
+    osm::MpcArgs m;
+    m.B = B; m.x = x; m.u_out = nullptr; m.status = status; m.max_iter = 200;
+    m.warm_u = (flags & OS_MPC_COLD_START) ? nullptr : warm_u; m.warm_state = warm_state; m.warm_contact = warm_contact;
+    osm::fill_args(ctx, m);
+    int rc = 0;
+    for (int t = 0; t < T && rc == 0; t++) {
+        const size_t o12 = (size_t)t * 12 * B, o6 = (size_t)t * 6 * B, o1 = (size_t)t * B;
+        // forces from the state BEFORE this step's predict (kalman_filter.py:141-152) ...
+        m.ref = body_ref + o12; m.p = p + o12; m.contact = contact + o1; m.f_out = f_out + o12;
+        m.iters = mpc_iters ? mpc_iters + o1 : nullptr;
+        const int slot = os_prof_begin(ctx, 4, s);
+        osm::launch_instances(m, flags_h[t], s);
+        os_prof_end(ctx, slot, s);
+        // ... then get_odom + set_measurements + predict_mpc covariance + next_state + update (kalman_filter.py:176-182)
+        osk::KfRunArgs a;
+        a.B = B; a.T = 1; a.p = p + o12; a.f = f_out + o12; a.dp = dp + o12; a.imu = imu + o6; a.contact = contact + o1;
+        a.body_ref = body_ref + o12; a.x = x; a.P = P; a.x_out = x_out + o12;
+        a.p_rot_out = p_rot_out ? p_rot_out + o12 : nullptr;
+        a.ptrace_out = ptrace_out ? ptrace_out + o1 : nullptr; a.kgain_out = kgain_out ? kgain_out + o1 : nullptr;
+        a.status = st_step; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
+        rc = os_kf_run_impl(ctx, a, (flags | OS_KF_DENSE_FD) & ~(uint32_t)OS_KF_SYMMETRIC_P, s);
+        hipLaunchKernelGGL(osm::or_status_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, status, st_step);
+    }
+    free(flags_h);
+    if (rc) return rc;
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }

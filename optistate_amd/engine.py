@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
-                    OS_KF_LANE_PER_TRAJECTORY)
+                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -102,12 +102,14 @@ class Engine:
     def pack_contact(self, c_bt4):
         """uint8 [B][T][4] -> packed uint32-as-4-bytes [T][B]."""
         c = torch.as_tensor(c_bt4).to(self.device, dtype=torch.uint8).contiguous()
-        return c.permute(1, 0, 2).contiguous().view(torch.int32).reshape(c.shape[1], c.shape[0])
+        B, T = c.shape[0], c.shape[1]
+        return c.permute(1, 0, 2).reshape(T * B, 4).contiguous().view(torch.int32).reshape(T, B)
 
     @staticmethod
     def contact_soa_to_packed(c_t4b):
         """uint8 [T][4][B] -> packed [T][B] int32."""
-        return c_t4b.permute(0, 2, 1).contiguous().view(torch.int32).reshape(c_t4b.shape[0], c_t4b.shape[2])
+        T, _, B = c_t4b.shape
+        return c_t4b.permute(0, 2, 1).reshape(T * B, 4).contiguous().view(torch.int32).reshape(T, B)
 
     def kf_run(self, p, f, dp, imu, contact, x, P, body_ref=None, sequential=None, dense_fd=False,
                want_p_rot=False, want_trace=False, want_gain=False, symmetric=None, lane_per_trajectory=False):
@@ -241,6 +243,25 @@ class Engine:
         self._check(self.lib.os_mpc_solve(self._h, B, _ptr(x), _ptr(body_ref), _ptr(p), _ptr(contact), _ptr(f), _ptr(u),
                                           _ptr(iters), _ptr(status), int(max_iter), self._stream()), "os_mpc_solve")
         return dict(f=f, u=u, iters=iters, status=status)
+
+
+    def kf_mpc_run(self, p, dp, imu, contact, body_ref, x, P, sequential=False, want_p_rot=False, want_trace=False,
+                   want_gain=False, want_iters=False, cold_start=False):
+        """estimate_state_mpc for B trajectories x T steps (kalman_filter.py:176-182): QP forces + dense-F_d filter step.
+        Streams [T][.][B] as kf_run; x [12][B], P [144][B] in/out.  Returns dict(x_out, f [T][12][B], status, ...)."""
+        T, _, B = p.shape
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
+        x_out, f_out = mk(T, 12, B), mk(T, 12, B)
+        p_rot = mk(T, 12, B) if want_p_rot else None
+        ptrace = mk(T, B) if want_trace else None
+        kgain = mk(T, B) if want_gain else None
+        iters = torch.empty((T, B), dtype=torch.int32, device=self.device) if want_iters else None
+        status = torch.empty((B,), dtype=torch.int32, device=self.device)
+        flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_MPC_COLD_START if cold_start else 0)
+        self._check(self.lib.os_kf_mpc_run(self._h, B, T, _ptr(p), _ptr(dp), _ptr(imu), _ptr(contact), _ptr(body_ref),
+                                           _ptr(x), _ptr(P), _ptr(x_out), _ptr(f_out), _ptr(p_rot), _ptr(ptrace),
+                                           _ptr(kgain), _ptr(iters), _ptr(status), flags, self._stream()), "os_kf_mpc_run")
+        return dict(x_out=x_out, f=f_out, p_rot=p_rot, ptrace=ptrace, kgain=kgain, iters=iters, status=status)
 
 
 def flatten_state_dict(sd, num_layers, device=None):

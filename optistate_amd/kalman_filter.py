@@ -142,13 +142,20 @@ class Kalman_Filter:
         # kalman_filter.py:195-198
         return np.array([[0, -x[2][0], x[1][0]], [x[2][0], 0, -x[0][0]], [-x[1][0], x[0][0], 0]])
 
+    def solve_mpc(self, p, body_ref, cur_contact):
+        """The stance controller's QP (misc/force_controller.py:70-162, parameters as kalman_filter.py:141-149 sets them)
+        solved on the GPU (os_mpc_solve); returns the (12, N) control matrix the reference keeps in self.f."""
+        e = self._eng
+        col = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64).reshape(-1)[:12].astype(np.float32)).reshape(12, 1).to(e.device)
+        c = torch.as_tensor(self._pack_contact(cur_contact).view(np.int32)).to(e.device)
+        r = e.mpc_solve(col(self.x), col(body_ref), col(p), c, want_all=True)
+        if int(r["status"].cpu()[0]) & 4:
+            raise RuntimeError("convex MPC: active-set iteration cap reached")       # qpOASES would report a failed solve
+        return r["u"].cpu().numpy().astype(np.float64).reshape(5, 12).T.copy()
+
     def predict_mpc(self, p, body_ref, cur_contact, f=None):
-        """kalman_filter.py:140-162 with the QP's forces supplied by the caller (f: (12,) or (12,N), column 0 used)."""
-        if f is None:
-            raise NotImplementedError("predict_mpc needs the ground-reaction forces f: the casadi/qpOASES convex MPC "
-                                      "(misc/force_controller.py:15-225) is outside this library's scope")
-        f = np.asarray(f, dtype=np.float64)
-        self.f = f.reshape(12, -1)
+        """kalman_filter.py:140-162.  f (12,) or (12,N), column 0 used: forces from a log; None: solve the QP here."""
+        self.f = self.solve_mpc(p, body_ref, cur_contact) if f is None else np.asarray(f, dtype=np.float64).reshape(12, -1)
         self._predict(p, self.f[:, 0], body_ref=body_ref)
 
     def estimate_state_mpc(self, imu, p, dp, body_ref, contact, f=None):
@@ -156,12 +163,10 @@ class Kalman_Filter:
         carries the predict_mpc covariance in float64 between the predict and the update (its element-wise exp(dt F) makes P
         ill-conditioned for float32 there); attributes x, P, z, x_model is not split out, P_trace, K_gain and f are set; `K`
         itself is only produced by update()."""
-        if f is None:
-            raise NotImplementedError("estimate_state_mpc needs the ground-reaction forces f: the casadi/qpOASES convex MPC "
-                                      "(misc/force_controller.py:15-225) is outside this library's scope")
         e = self._eng
         self._sync_noise()
-        self.f = np.asarray(f, dtype=np.float64).reshape(12, -1)
+        # f = None: the convex MPC of kalman_filter.py:141-152 is solved on the GPU (os_mpc_solve); otherwise forces from a log
+        self.f = self.solve_mpc(p, body_ref, contact) if f is None else np.asarray(f, dtype=np.float64).reshape(12, -1)
         odom = self.get_odom(p, dp, contact, imu)
         self.set_measurements(imu, odom)
         buf, o = self._stage(np.asarray(p).reshape(-1)[:12], self.f[:, 0], np.asarray(dp).reshape(-1)[:12],

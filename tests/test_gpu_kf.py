@@ -224,9 +224,6 @@ def test_dropin_estimate_state_mpc_with_supplied_forces(eng):
         assert x is kf.x
         assert np.abs(x.ravel() - g["b0_x"][t]).max() < STATE_TOL
         assert np.abs(p.ravel() - g["b0_p_rot"][t]).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        kf.estimate_state_mpc(g["imu"][0, 0].reshape(6, 1), g["p"][0, 0].reshape(12, 1).astype(np.float64),
-                              g["dp"][0, 0].reshape(12, 1), g["body_ref"][0, 0].reshape(12, 1), g["contact"][0, 0].reshape(4, 1))
 
 
 @pytest.mark.parametrize("v", VARIANTS, ids=VIDS)

@@ -72,3 +72,82 @@ def test_mpc_constraints_hold_and_swing_zero(eng):
         assert np.all(np.abs(u[st][:, :, leg, 1]) <= 0.6 * fz + 1e-4)
     it = r["iters"].cpu().numpy()
     assert it.min() >= 0 and it.max() < 200      # 0 iterations: no leg on the ground
+
+
+def _oracle_mpc_filter(d, Q, R, T, B):
+    """estimate_state_mpc per trajectory and step with the two oracles: QP forces (mpc_oracle) from the state before the
+    predict, then one predict_mpc + update step of the C oracle (mode 1)."""
+    from oracle import c_oracle as co
+    xs = np.zeros((B, T, 12)); fs = np.zeros((B, T, 12))
+    for b in range(B):
+        x = d["x0"][b].astype(np.float64).copy(); P = Q.copy()
+        for t in range(T):
+            # the device path holds the state in float32 between steps
+            x32 = x.astype(np.float32).astype(np.float64)
+            f, _, info = mo.mpc_forces(x32, d["body_ref"][b, t].astype(np.float64), d["p"][b, t].astype(np.float64), d["contact"][b, t],
+                                       **_oracle_kw())
+            f32 = f.astype(np.float32).astype(np.float64)
+            r = co.kf_run_batch(d["p"][b:b + 1, t:t + 1], f32.reshape(1, 1, 12), d["dp"][b:b + 1, t:t + 1], d["imu"][b:b + 1, t:t + 1],
+                                d["contact"][b:b + 1, t:t + 1], x.reshape(1, 12), P.reshape(1, 144), Q, R,
+                                body_ref=d["body_ref"][b:b + 1, t:t + 1], mode=1)
+            x = r["x_final"][0].copy(); P = r["P_final"][0].copy()
+            xs[b, t] = x; fs[b, t] = f
+    return xs, fs
+
+
+def _mpc_traj_inputs(B, T, seed):
+    from optistate_amd.synth import synth_numpy
+    d = synth_numpy(B, T, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    tt = np.arange(T) * 0.01
+    ref = np.zeros((B, T, 12), np.float32)
+    ref[:, :, 0] = 0.02 * np.sin(3 * tt); ref[:, :, 1] = 0.02 * np.cos(2 * tt); ref[:, :, 5] = 0.28; ref[:, :, 9] = 0.1
+    ref += rng.normal(0, 0.005, ref.shape).astype(np.float32)
+    d["body_ref"] = ref
+    return d
+
+
+def test_kf_mpc_run_matches_oracles(eng, monkeypatch):
+    """os_kf_mpc_run = estimate_state_mpc over B x T (kalman_filter.py:176-182): forces and states against the oracles."""
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    monkeypatch.setattr(mo, "MASS", float(np.float32(8.8)))
+    monkeypatch.setattr(mo, "INERTIA", np.asarray(np.float32([0.05530364, 0.06011944, 0.10530434]), np.float64))
+    B, T = 3, 12
+    d = _mpc_traj_inputs(B, T, seed=21)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "dp", "imu", "body_ref")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    r = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x, P, want_iters=True)
+    assert int(r["status"].abs().max()) == 0
+    xs, fs = _oracle_mpc_filter(d, Q_DEFAULT, R_DEFAULT, T, B)
+    x_gpu = eng.unpack(r["x_out"]).cpu().numpy(); f_gpu = eng.unpack(r["f"]).cpu().numpy()
+    assert np.abs(f_gpu - fs).max() < 5e-3            # N; forces ~20-40 N (float32 state feedback between steps)
+    assert np.abs(x_gpu - xs).max() < 1e-4            # the state bar of the filter path
+    assert int(r["iters"].min()) >= 1
+    # the warm start (previous step's active set) must not change the answer
+    x2 = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P2 = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    r2 = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x2, P2, cold_start=True)
+    assert float((r2["f"] - r["f"]).abs().max()) < 1e-3 and float((r2["x_out"] - r["x_out"]).abs().max()) < 1e-5
+
+
+def test_dropin_estimate_state_mpc_solves_the_qp(eng, monkeypatch):
+    """The reference's call, no forces supplied (kalman_filter.py:176-182): the class solves the MPC on the GPU."""
+    from optistate_amd import Kalman_Filter
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    monkeypatch.setattr(mo, "MASS", float(np.float32(8.8)))
+    monkeypatch.setattr(mo, "INERTIA", np.asarray(np.float32([0.05530364, 0.06011944, 0.10530434]), np.float64))
+    T = 6
+    d = _mpc_traj_inputs(1, T, seed=4)
+    xs, fs = _oracle_mpc_filter(d, Q_DEFAULT, R_DEFAULT, T, 1)
+    kf = Kalman_Filter()
+    kf.x[:] = d["x0"][0].reshape(12, 1)
+    for t in range(T):
+        p = d["p"][0, t].astype(np.float64).reshape(12, 1)
+        x = kf.estimate_state_mpc(d["imu"][0, t].reshape(6, 1), p, d["dp"][0, t].reshape(12, 1), d["body_ref"][0, t].reshape(12, 1),
+                                  d["contact"][0, t].reshape(4, 1))
+        assert kf.f.shape == (12, 5)
+        assert np.abs(kf.f[:, 0] - fs[0, t]).max() < 5e-3
+        assert np.abs(x.ravel() - xs[0, t]).max() < 1e-4
