@@ -99,24 +99,11 @@ int os_kf_set_noise(os_ctx *ctx, const float *Q_host, const float *R_host)
     return 0;
 }
 
-static void prof_drain(os_ctx *ctx)
-{
-    for (int i = 0; i < ctx->prof_n; i++) {
-        float ms = 0.f;
-        if (hipEventSynchronize(ctx->prof_ev[2 * i + 1]) == hipSuccess &&
-            hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) == hipSuccess) {
-            ctx->prof_ms[ctx->prof_phase[i]] += ms;
-            ctx->prof_cnt[ctx->prof_phase[i]] += 1;
-        }
-    }
-    ctx->prof_n = 0;
-}
-
 int os_profile_enable(os_ctx *ctx, int enable)
 {
     OS_CHECK_CTX(ctx);
     OS_HIP(ctx, hipSetDevice(ctx->device));
-    prof_drain(ctx);
+    os_prof_drain(ctx);
     for (int i = 0; i < OS_PROF_PHASES; i++) { ctx->prof_ms[i] = 0.0; ctx->prof_cnt[i] = 0; }
     ctx->prof = enable != 0;
     return 0;
@@ -127,7 +114,7 @@ int os_profile_read(os_ctx *ctx, double *ms_sum, int32_t *launches)
     OS_CHECK_CTX(ctx);
     if (!ms_sum || !launches) return os_fail(ctx, -2, "os_profile_read: null pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
-    prof_drain(ctx);
+    os_prof_drain(ctx);
     for (int i = 0; i < OS_PROF_PHASES; i++) {
         ms_sum[i] = ctx->prof_ms[i]; launches[i] = ctx->prof_cnt[i];
         ctx->prof_ms[i] = 0.0; ctx->prof_cnt[i] = 0;

@@ -46,10 +46,25 @@ struct os_ctx {
     int prof_cnt[OS_PROF_PHASES];
 };
 
+// adds the elapsed times of the recorded event pairs to the per-phase sums (synchronises on them) and empties the ring
+static inline void os_prof_drain(os_ctx *ctx)
+{
+    for (int i = 0; i < ctx->prof_n; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ctx->prof_ev[2 * i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) == hipSuccess) {
+            ctx->prof_ms[ctx->prof_phase[i]] += ms;
+            ctx->prof_cnt[ctx->prof_phase[i]] += 1;
+        }
+    }
+    ctx->prof_n = 0;
+}
+
 // RAII-less helpers: bracket a kernel launch with events when profiling is on
 static inline int os_prof_begin(os_ctx *ctx, int phase, hipStream_t s)
 {
-    if (!ctx->prof || ctx->prof_n >= 512) return -1;
+    if (!ctx->prof) return -1;
+    if (ctx->prof_n >= 512) os_prof_drain(ctx);      // ring full (per-step launch loops): fold it into the sums
     const int i = ctx->prof_n;
     if (!ctx->prof_ev[2 * i]) {
         if (hipEventCreate(&ctx->prof_ev[2 * i]) != hipSuccess || hipEventCreate(&ctx->prof_ev[2 * i + 1]) != hipSuccess)

@@ -69,11 +69,11 @@ class Engine:
         self._check(self.lib.os_profile_enable(self._h, 1 if enable else 0), "os_profile_enable")
 
     def profile_read(self):
-        """Returns {phase: (ms_sum, launches)} for phases kf, gru_layer, gru_head, fused since the last read."""
-        ms = (C.c_double * 4)()
-        n = (C.c_int32 * 4)()
+        """Returns {phase: (ms_sum, launches)} for phases kf, gru_layer, gru_head, fused, mpc since the last read."""
+        ms = (C.c_double * _capi.OS_PROF_PHASES)()
+        n = (C.c_int32 * _capi.OS_PROF_PHASES)()
         self._check(self.lib.os_profile_read(self._h, ms, n), "os_profile_read")
-        return {k: (ms[i], n[i]) for i, k in enumerate(("kf", "gru_layer", "gru_head", "fused"))}
+        return {k: (ms[i], n[i]) for i, k in enumerate(("kf", "gru_layer", "gru_head", "fused", "mpc"))}
 
     # ---- Kalman filter ----
     def set_noise(self, Q, R):

@@ -10,8 +10,8 @@ Differences from the reference, all deliberate (SURVEY.md section 5 "race detect
   * no global state: x/P/Q/R are per-instance copies (the reference aliases class attributes of
     settings.INITIAL_PARAMS, kalman_filter/kalman_filter.py:10,27-29);
   * get_odom is defined for 0 and 4 stance legs (the reference raises ValueError there);
-  * estimate_state_mpc needs the ground-reaction forces as an argument: the convex-MPC QP that produces them in
-    the reference (misc/force_controller.py:15-225, casadi/qpOASES) is out of scope.
+  * the convex-MPC QP inside predict_mpc (misc/force_controller.py:70-162, casadi/qpOASES in the reference) is solved
+    by the library's own exact active-set kernel (os_mpc_solve); pass f= to replay logged forces instead.
 """
 import numpy as np
 import torch

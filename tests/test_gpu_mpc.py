@@ -151,3 +151,17 @@ def test_dropin_estimate_state_mpc_solves_the_qp(eng, monkeypatch):
         assert kf.f.shape == (12, 5)
         assert np.abs(kf.f[:, 0] - fs[0, t]).max() < 5e-3
         assert np.abs(x.ravel() - xs[0, t]).max() < 1e-4
+
+
+def test_mpc_matches_committed_fixture(eng):
+    """tests/golden/mpc_g9_oracle.npz (tools/gen_golden.py g9: oracle-certified solutions; includes an 'unconstrained' leg,
+    contact byte 2, and force-cap cases).  The fixture was solved with the exact constants; the library holds mass and
+    inertia as float32, hence the slightly wider bar than in test_mpc_matches_certified_oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpc_g9_oracle.npz"))
+    X, R, P = (np.asarray(g[k], np.float32) for k in ("x", "body_ref", "p"))
+    Cn = np.asarray(g["contact"], np.uint8)
+    r = _solve_gpu(eng, X, R, P, Cn)
+    assert int(r["status"].abs().max()) == 0
+    u = r["u"].cpu().numpy().T.astype(np.float64)
+    assert np.abs(u - g["u"]).max() < 2e-3

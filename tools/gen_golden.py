@@ -250,7 +250,31 @@ def g5_g6():
              **{"w1:" + k: v for k, v in w1.items()}, **{"g:" + k: v for k, v in grads.items()})
 
 
+def g9():
+    """Convex-MPC force QP (misc/force_controller.py:70-162).  NOT reference-generated: casadi/qpOASES are absent, so this
+    fixture holds float32-representable inputs and the KKT-certified solutions of oracle/mpc_oracle.py (parity unpinned)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import mpc_oracle as mo
+    rng = np.random.default_rng(2024)
+    pats = [(1, 0, 0, 1), (0, 1, 1, 0), (1, 1, 1, 1), (1, 1, 0, 1), (0, 0, 1, 0), (0, 0, 0, 0), (1, 0, 1, 1), (2, 1, 1, 0)]
+    X, R, P, Cn, U = [], [], [], [], []
+    for t in range(40):
+        s = [0.3, 1.0, 3.0, 6.0][t % 4]
+        x = np.array([0, 0, 0, 0, 0, 0.28, 0, 0, 0, 0, 0, 0.]) + s * rng.normal(0, [0.05] * 3 + [0.02] * 3 + [0.2] * 3 + [0.1] * 3)
+        ref = np.array([0, 0, 0, 0, 0, 0.28, 0, 0, 0, 0.1, 0, 0.]) + s * rng.normal(0, [0.02] * 3 + [0.01] * 3 + [0.05] * 3 + [0.05] * 3)
+        p = np.array([0.2, 0.1, -0.28, 0.2, -0.1, -0.28, -0.2, 0.1, -0.28, -0.2, -0.1, -0.28]) + rng.normal(0, 0.01, 12)
+        c = np.array(pats[t % len(pats)], dtype=np.uint8)
+        x, ref, p = (a.astype(np.float32).astype(np.float64) for a in (x, ref, p))
+        f, u, info = mo.mpc_forces(x, ref, p, c)
+        X.append(x); R.append(ref); P.append(p); Cn.append(c); U.append(u)
+    np.savez_compressed(os.path.join(OUT, "mpc_g9_oracle.npz"), x=np.array(X), body_ref=np.array(R), p=np.array(P),
+                        contact=np.array(Cn), u=np.array(U))
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3_g7(); g4(); g8(); g5_g6()
+    if "--g9-only" in sys.argv:
+        g9()
+    else:
+        g1(); g2(); g3_g7(); g4(); g8(); g5_g6(); g9()
     for fn in sorted(os.listdir(OUT)):
         print(f"{fn:28s} {os.path.getsize(os.path.join(OUT, fn)) / 1024:9.1f} KiB")
