@@ -226,6 +226,22 @@ class Engine:
         return dict(out=out, x_out=x_out, status=status)
 
 
+    # ---- batched single-step pieces (the B = 1 drop-in class uses the same entry points) ----
+    def kf_odom(self, p, dp, contact, imu):
+        """get_odom + set_measurements for B trajectories (kalman_filter.py:79-117): p, dp [12][B], imu [6][B],
+        contact [B] packed -> z [10][B]."""
+        B = p.shape[1]
+        z = torch.empty((10, B), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_kf_odom(self._h, B, _ptr(p), _ptr(dp), _ptr(contact), _ptr(imu), _ptr(z), self._stream()), "os_kf_odom")
+        return z
+
+    def kf_predict(self, p, f, x, P, body_ref=None):
+        """predict (kalman_filter.py:119-138) or, with body_ref, predict_mpc's covariance (:153-161) for B trajectories.
+        p [12][B] is rotated to the world frame in place, x [12][B] and P [144][B] are updated in place."""
+        B = p.shape[1]
+        self._check(self.lib.os_kf_predict(self._h, B, _ptr(p), _ptr(f), _ptr(body_ref), _ptr(x), _ptr(P), None,
+                                           OS_KF_DENSE_FD if body_ref is not None else 0, self._stream()), "os_kf_predict")
+
     # ---- convex-MPC ground-reaction forces (misc/force_controller.py:70-162, kalman_filter.py:141-152) ----
     def mpc_set_weights(self, q_weights, r_weight=1e-6, mu=0.6, fz_max=150.0):
         """diag(Q) of the stance controller (kalman_filter.py:64), R scalar (:66), friction and force cap (force_controller.py:147-149)."""

@@ -165,3 +165,59 @@ def test_mpc_matches_committed_fixture(eng):
     assert int(r["status"].abs().max()) == 0
     u = r["u"].cpu().numpy().T.astype(np.float64)
     assert np.abs(u - g["u"]).max() < 2e-3
+
+
+def test_fit_noise_covariances_matches_oracle_loop(eng, monkeypatch):
+    """Q/R fitting branch of data_conversion_Kalman_to_Training.py:31-104 (one batch on the device) against the same loop
+    written with the oracles, with and without the script's `measurement_data.append(KF.z)` aliasing."""
+    from oracle import c_oracle as co
+    from optistate_amd import pipeline
+    monkeypatch.setattr(mo, "MASS", float(np.float32(8.8)))
+    monkeypatch.setattr(mo, "INERTIA", np.asarray(np.float32([0.05530364, 0.06011944, 0.10530434]), np.float64))
+    T = 24
+    d = _mpc_traj_inputs(1, T, seed=9)
+    rng = np.random.default_rng(5)
+    mocap = (np.tile(np.array([0, 0, 0, 0, 0, 0.28, 0, 0, 0, 0.1, 0, 0.]), (T, 1)) + rng.normal(0, 0.02, (T, 12))).astype(np.float32)
+    p, dp, imu, contact = d["p"][0], d["dp"][0], d["imu"][0], d["contact"][0]
+    xm, zs = [], []
+    for i in range(T - 1):
+        x = mocap[i].astype(np.float64)
+        f, _, _ = mo.mpc_forces(x, x, p[i].astype(np.float64), contact[i], **_oracle_kw())
+        xn, _ = co.next_state(x, p[i].astype(np.float64), f.astype(np.float32).astype(np.float64), dt=float(np.float32(0.01)))
+        xm.append(xn)
+        od = co.get_odom(p[i + 1], dp[i + 1], contact[i + 1], imu[i + 1])
+        zs.append(np.concatenate([imu[i + 1][0:3], [od[0]], imu[i + 1][3:6], od[1:4]]))
+    xm, zs = np.array(xm), np.array(zs)
+    sel = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11]
+    gt1 = mocap[1:].astype(np.float64)
+    for alias in (True, False):
+        Q, R = pipeline.fit_noise_covariances(eng, p, dp, imu, contact, mocap, alias_measurements=alias)
+        q_ref = np.var(gt1 - xm, axis=0)
+        r_ref = np.var(gt1[:, sel] - (zs[-1][None, :] if alias else zs), axis=0)
+        assert np.allclose(np.diag(Q), q_ref, rtol=2e-3, atol=1e-9), (np.diag(Q), q_ref)
+        assert np.allclose(np.diag(R), r_ref, rtol=2e-3, atol=1e-9)
+        assert np.count_nonzero(Q - np.diag(np.diag(Q))) == 0
+
+
+def test_feature_rows_with_mpc_forces(eng):
+    """60-column rows of data_conversion_Kalman_to_Training.py:245-254 built from the estimate_state_mpc loop: the force
+    columns are KF2.f[:, 0], the p columns are the world-rotated feet (next_state mutates p in place)."""
+    from oracle import c_oracle as co
+    from optistate_amd import pipeline
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    B, T = 2, 6
+    d = _mpc_traj_inputs(B, T, seed=33)
+    d["ref"] = d["body_ref"]
+    rows, x_hist, forces, status = pipeline.kalman_feature_rows_mpc(eng, d, Q_DEFAULT, R_DEFAULT, d["x0"])
+    assert rows.shape == (B, T, 60) and int(status.abs().max()) == 0
+    rows = rows.cpu().numpy(); xh = x_hist.cpu().numpy()
+    assert np.array_equal(rows[:, :, 0:12], xh) and np.array_equal(rows[:, :, 18:30], forces.cpu().numpy())
+    assert np.array_equal(rows[:, :, 12:18], d["accel"]) and np.array_equal(rows[:, :, 42:54], d["dp"])
+    # p columns: R(x_prior) p; the prior of step t is the posterior of step t-1 (x0 for t = 0)
+    for b in range(B):
+        prior = d["x0"][b].astype(np.float64)
+        for t in range(T):
+            Rm = co.rotation(*prior[0:3])
+            pw = (Rm @ d["p"][b, t].astype(np.float64).reshape(4, 3).T).T.reshape(12)
+            assert np.abs(rows[b, t, 30:42] - pw).max() < 1e-5
+            prior = xh[b, t].astype(np.float64)
