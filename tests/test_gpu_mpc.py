@@ -221,3 +221,37 @@ def test_feature_rows_with_mpc_forces(eng):
             pw = (Rm @ d["p"][b, t].astype(np.float64).reshape(4, 3).T).T.reshape(12)
             assert np.abs(rows[b, t, 30:42] - pw).max() < 1e-5
             prior = xh[b, t].astype(np.float64)
+
+
+def test_mpc_custom_weights_and_limits(eng, monkeypatch):
+    """os_mpc_set_weights: other Q/R weights, friction coefficient and force cap (the reference hard-codes its own at
+    kalman_filter.py:64-70 / force_controller.py:147-149) against the oracle with the same numbers."""
+    from optistate_amd import Engine
+    e2 = Engine(0)
+    wq = np.array([5.0, 20.0, 1.0, 50.0, 80.0, 200.0, 0.5, 2.0, 1.0, 3.0, 0.2, 1.0])
+    e2.mpc_set_weights(wq, r_weight=1e-4, mu=0.35, fz_max=60.0)
+    monkeypatch.setattr(mo, "MASS", float(np.float32(8.8)))
+    monkeypatch.setattr(mo, "INERTIA", np.asarray(np.float32([0.05530364, 0.06011944, 0.10530434]), np.float64))
+    monkeypatch.setattr(mo, "MU", 0.35)
+    monkeypatch.setattr(mo, "FZ_MAX", 60.0)
+    X, R, P, Cn = _problems(24, seed=77)
+    r = _solve_gpu(e2, X, R, P, Cn)
+    assert int(r["status"].abs().max()) == 0
+    u = r["u"].cpu().numpy().T.astype(np.float64)
+    for k in range(X.shape[0]):
+        _, u_o, info = mo.mpc_forces(X[k].astype(np.float64), R[k].astype(np.float64), P[k].astype(np.float64), Cn[k],
+                                     q_weights=wq, r_weight=1e-4, **_oracle_kw())
+        assert np.abs(u[k] - u_o).max() < 2e-4
+    with pytest.raises(RuntimeError):
+        e2.mpc_set_weights(wq, r_weight=0.0)          # R must stay positive definite
+
+
+def test_mpc_nonfinite_input_terminates_and_flags(eng):
+    X, R, P, Cn = _problems(8, seed=2)
+    X[3, 7] = np.nan
+    r = _solve_gpu(eng, X, R, P, Cn)
+    st = r["status"].cpu().numpy(); u = r["u"].cpu().numpy().T
+    ok = [k for k in range(8) if k != 3]
+    assert np.all(st[ok] == 0) and np.all(np.isfinite(u[ok]))
+    # the poisoned problem must not hang the wavefront: it ends at the iteration cap (bit 2) or with non-finite forces
+    assert (st[3] & 4) or not np.all(np.isfinite(u[3]))
