@@ -31,8 +31,9 @@ def gru_flops_per_step(I, H, L):
 
 
 def cpu_baseline(H, L, target_seconds):
-    """The float64 C oracle (oracle/kf_oracle.c + gru_oracle.c: a port of the reference's algorithm) timed on one
-    host core over a bounded sample of the same workload (same distributions, T = 100)."""
+    """The float64 C oracle (oracle/kf_oracle.c + gru_oracle.c: a port of the reference's algorithm) timed on the host
+    cores over a bounded sample of the same workload (same distributions, T = 100): trajectories split over all cores
+    (OpenMP), plus the single-thread figure of the scalar port."""
     import numpy as np
     import torch
     from oracle import c_oracle as orc
@@ -54,12 +55,18 @@ def cpu_baseline(H, L, target_seconds):
         return time.perf_counter() - t0
 
     probe_B = 16
+    orc.set_threads(1)
     t_probe = run(probe_B)
-    Bs = max(probe_B, int(probe_B * target_seconds / max(t_probe, 1e-6)))
-    Bs = min(Bs, 20000)
+    B1 = min(max(probe_B, int(probe_B * 0.3 * target_seconds / max(t_probe, 1e-6))), 20000)
+    el1 = run(B1)
+    cores = orc.set_threads(os.cpu_count() or 1)
+    Bs = min(max(cores * probe_B, int(B1 * cores * 0.7 / 0.3)), 200000)
     el = run(Bs)
-    return {"value": Bs * T / el, "unit": "timesteps/s", "cores": 1, "kind": "port",
-            "sample": f"{Bs} trajectories x {T} steps (KF float64 C oracle + GRU float64 C oracle, 1 thread, {el:.1f} s)"}
+    orc.set_threads(1)
+    return {"value": Bs * T / el, "unit": "timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{Bs} trajectories x {T} steps (KF + GRU float64 C oracle, {cores} threads, {el:.1f} s)",
+            "single_thread_value": B1 * T / el1,
+            "single_thread_sample": f"{B1} trajectories x {T} steps, 1 thread, {el1:.1f} s"}
 
 
 def bench_train(a, rank, local_rank, world, dist):

@@ -30,7 +30,20 @@ def lib():
         _LIB.ok_gru_train_loss.restype = C.c_double
         _LIB.ok_kf_run.restype = C.c_int
         _LIB.ok_update.restype = C.c_int
+        _LIB.ok_max_threads.restype = C.c_int
+        _LIB.ok_set_threads(1)            # default: the scalar port; the batch entry points can be split over threads
     return _LIB
+
+
+def set_threads(n):
+    """Threads for kf_run_batch / gru_forward (independent trajectories).  Returns the count actually set."""
+    n = max(1, min(int(n), max_threads()))
+    lib().ok_set_threads(n)
+    return n
+
+
+def max_threads():
+    return int(lib().ok_max_threads())
 
 
 def _d(a):

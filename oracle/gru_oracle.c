@@ -40,9 +40,13 @@ size_t ok_gru_param_count(int I, int H, int L, int C)
 void ok_gru_forward(int B, int T, int I, int H, int L, int C, const double *x, const double *w,
                     int use_sigmoid, double *out, double *hlast, double *seq_out)
 {
+    /* trajectories are independent (one RNN.forward row each): optional OpenMP split over b, scratch per thread */
+#pragma omp parallel
+    {
     double *h = (double *)calloc((size_t)L * H, sizeof(double));
     double *hn = (double *)malloc(sizeof(double) * H);
     double *inp = (double *)malloc(sizeof(double) * (I > H ? I : H));
+#pragma omp for schedule(static)
     for (int b = 0; b < B; b++) {
         memset(h, 0, sizeof(double) * L * H);
         for (int t = 0; t < T; t++) {
@@ -85,6 +89,7 @@ void ok_gru_forward(int B, int T, int I, int H, int L, int C, const double *x, c
             for (int l = 0; l < L; l++) memcpy(hlast + ((size_t)l * B + b) * H, h + (size_t)l * H, sizeof(double) * H);
     }
     free(h); free(hn); free(inp);
+    }
 }
 
 /* gru/gru_train.py:237-245: target = [y(12), |out[0:12] - y|(12)] with out detached; loss = mean
