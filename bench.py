@@ -30,6 +30,24 @@ def gru_flops_per_step(I, H, L):
     return sum(2 * 3 * H * ((I if l == 0 else H) + H) for l in range(L))
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container usually gets fewer
+    than os.cpu_count(); oversubscribing the quota only adds scheduler noise)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(H, L, target_seconds):
     """The float64 C oracle (oracle/kf_oracle.c + gru_oracle.c: a port of the reference's algorithm) timed on the host
     cores over a bounded sample of the same workload (same distributions, T = 100): trajectories split over all cores
@@ -63,7 +81,7 @@ def cpu_baseline(H, L, target_seconds):
     t_probe = run(probe_B)
     B1 = min(max(probe_B, int(probe_B * 0.3 * target_seconds / max(t_probe, 1e-6))), 20000)
     el1 = run(B1)
-    cores = orc.set_threads(os.cpu_count() or 1)
+    cores = orc.set_threads(usable_cores())
     Bs = min(max(cores * probe_B, int(B1 * cores * 0.7 / 0.3)), 65536)      # at most the GPU workload's own batch
     el = run(Bs)
     orc.set_threads(1)
