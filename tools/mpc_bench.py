@@ -12,6 +12,8 @@ scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 eng = Engine(0)
 d = synth_torch(B, 2, "cuda", seed=1)
 c = eng.contact_soa_to_packed(d["contact"])[0].contiguous()
+if len(sys.argv) > 3:      # contact word override, e.g. 0x01010101 = all four legs in stance
+    c = torch.full_like(c, int(sys.argv[3], 16))
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 x = d["x0"].clone()
 x += scale * torch.randn(x.shape, device="cuda", generator=g) * torch.tensor([0.05] * 3 + [0.02] * 3 + [0.2] * 3 + [0.1] * 3, device="cuda")[:, None]
