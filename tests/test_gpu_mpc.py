@@ -131,6 +131,13 @@ def test_kf_mpc_run_matches_oracles(eng, monkeypatch):
     P2 = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, B))).cuda()
     r2 = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x2, P2, cold_start=True)
     assert float((r2["f"] - r["f"]).abs().max()) < 1e-3 and float((r2["x_out"] - r["x_out"]).abs().max()) < 1e-5
+    # sequential scalar updates (diagonal R) instead of the batch form: same posterior
+    x3 = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P3 = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    r3 = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x3, P3, sequential=True, want_p_rot=True, want_trace=True)
+    x3o = eng.unpack(r3["x_out"]).cpu().numpy()
+    assert np.abs(x3o - xs).max() < 1e-4 and int(r3["status"].abs().max()) == 0
+    assert r3["ptrace"].shape == (T, B) and bool(torch.isfinite(r3["ptrace"]).all())
 
 
 def test_dropin_estimate_state_mpc_solves_the_qp(eng, monkeypatch):
