@@ -58,9 +58,10 @@ struct MpcArgs {
 
 template <int NV_>
 struct WaveMemT {
+    static constexpr int LW = NV_ <= 32 ? 32 : 64;   // lanes that own a row
     double gen0[NV_][6];     // generators (a, b) of the variables
     double gent[NV_][6];     // generators of the face coordinates
-    double rows[NV_][64];    // staging of the reduced system's rows: rows[w][lane] (built by a rolled loop, then read into registers)
+    double rows[NV_][LW];    // staging of the reduced system's rows: rows[w][lane] (built by a rolled loop, then read into registers)
     double rowbuf[64];
     double vec[64];          // broadcast vector (solution / u / u0)
     double al[NLSMAX];
@@ -132,7 +133,7 @@ __device__ __forceinline__ void form_row(const LaneCtx &L, const MpcParams &P, c
             double val = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
             if (w == L.v) val = live ? val + diag_add : 1.0;       // dead slots: identity row
             else if (!live) val = 0.0;
-            M.rows[w][L.lane] = val;
+            if (L.lane < WaveMem::LW) M.rows[w][L.lane] = val;
         }
     }
 }
@@ -205,7 +206,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     if (any_u0) rhs -= form_dot<NPS>(L, P, g, M.gen0, M.vec);
     double A[NV + 1];
 #pragma unroll
-    for (int w = 0; w < NV; w++) A[w] = M.rows[w][L.lane];
+    for (int w = 0; w < NV; w++) A[w] = M.rows[w][L.lane & (WaveMem::LW - 1)];
     A[NV] = live ? rhs : 0.0;
     const unsigned long long live_mask = __ballot(live);
 
@@ -258,7 +259,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
 // problem has 30 variables, not 60 (elimination work ~ n^3), and each instance gets the register budget its row needs.
 // Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
 template <int NST>
-__global__ __launch_bounds__(64, 2) void mpc_solve_kernel(const MpcArgs a)
+__global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const MpcArgs a)
 {
     constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST;
     typedef WaveMemT<15 * NST> WaveMem;
