@@ -85,7 +85,19 @@ def cpu_baseline(H, L, target_seconds):
     Bs = min(max(cores * probe_B, int(B1 * cores * 0.7 / 0.3)), 65536)      # at most the GPU workload's own batch
     el = run(Bs)
     orc.set_threads(1)
+    # the GRU half as the reference itself computes it (gru/gru_model.py:16-24 = torch.nn.GRU + Linear + sigmoid) on the
+    # host cores, fp32, for context: torch is a library, not reference code
+    torch.set_num_threads(cores)
+    ref_gru = torch.nn.GRU(60, H, L, batch_first=True); ref_fc = torch.nn.Linear(H, 24)
+    xb = torch.rand(min(Bs, 8192), T, 60)
+    with torch.no_grad():
+        torch.sigmoid(ref_fc(ref_gru(xb[:64])[0][:, -1]))
+        tg = time.perf_counter()
+        torch.sigmoid(ref_fc(ref_gru(xb)[0][:, -1]))
+        tg = time.perf_counter() - tg
     return {"value": Bs * T / el, "unit": "timesteps/s", "cores": cores, "kind": "port",
+            "gru_half_torch_cpu": {"value": xb.shape[0] * T / tg, "unit": "timesteps/s", "threads": cores,
+                                   "what": "torch.nn.GRU(60,%d,%d)+Linear+sigmoid fp32 on the host, GRU half only" % (H, L)},
             "sample": f"{Bs} trajectories x {T} steps (KF + GRU float64 C oracle, {cores} threads, {el:.1f} s)",
             "single_thread_value": B1 * T / el1,
             "single_thread_sample": f"{B1} trajectories x {T} steps, 1 thread, {el1:.1f} s"}
