@@ -61,7 +61,7 @@ struct WaveMemT {
     static constexpr int LW = NV_ <= 32 ? 32 : 64;   // lanes that own a row
     double gen0[NV_][6];     // generators (a, b) of the variables
     double gent[NV_][6];     // generators of the face coordinates
-    double rows[NV_][LW];    // staging of the reduced system's rows: rows[w][lane] (built by a rolled loop, then read into registers)
+    double rows[NV_ / 5][LW]; // staging of one horizon-step block of the reduced system's rows: rows[w][lane] (built by a rolled loop, then read into registers)
     double rowbuf[64];
     double vec[64];          // broadcast vector (solution / u / u0)
     double al[NLSMAX];
@@ -110,31 +110,33 @@ struct LaneCtx {
     double Cth[9];                         // R1 diag(w_theta) R1^T (wave-uniform: kept in SGPRs via readfirstlane)
 };
 
-// Row of the reduced system for face generator g (6) at horizon step L.i against the face generators G[w] (LDS), written
-// to M.rows[w][lane].  Deliberately a ROLLED loop: unrolled, hipcc hoists all 6 * NV generator loads to the top and
-// spills them to scratch.
+// One horizon-step block (NPS columns, step l) of the reduced system's row for face generator g (6) at horizon step L.i
+// against the face generators M.gent[w], staged in M.rows[j][lane] (the caller then reads it into registers).
+// Deliberately a ROLLED loop over the columns: unrolled, hipcc hoists all generator loads to the top and spills them.
 template <int NPS, typename WaveMem>
-__device__ __forceinline__ void form_row(const LaneCtx &L, const MpcParams &P, const double *g, bool live, double diag_add, WaveMem &M)
+__device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams &P, const double *g, bool live, double diag_add,
+                                               int l, WaveMem &M)
 {
-#pragma clang loop unroll(disable)
-    for (int l = 0; l < 5; l++) {
-        double al, be;
-        alpha_beta(L.i, l, P.dt, al, be);
-        double zA[3], zB[3];
+    // opaque copy of the step index: otherwise the (al, be) x weight products of all five blocks are hoisted out of the
+    // active-set loop and spilled
+    int li = L.i;
+    asm volatile("" : "+v"(li));
+    double al, be;
+    alpha_beta(li, l, P.dt, al, be);
+    double zA[3], zB[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
-            zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
-        }
+    for (int r = 0; r < 3; r++) {
+        zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
+        zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+    }
 #pragma clang loop unroll(disable)
-        for (int j = 0; j < NPS; j++) {
-            const int w = NPS * l + j;
-            const double *gw = M.gent[w];
-            double val = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
-            if (w == L.v) val = live ? val + diag_add : 1.0;       // dead slots: identity row
-            else if (!live) val = 0.0;
-            if (L.lane < WaveMem::LW) M.rows[w][L.lane] = val;
-        }
+    for (int j = 0; j < NPS; j++) {
+        const int w = NPS * l + j;
+        const double *gw = M.gent[w];
+        double val = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
+        if (w == L.v) val = live ? val + diag_add : 1.0;       // dead slots: identity row
+        else if (!live) val = 0.0;
+        if (L.lane < WaveMem::LW) M.rows[j][L.lane] = val;
     }
 }
 
@@ -201,12 +203,16 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     __builtin_amdgcn_wave_barrier();
 
     // ---- row of the reduced system ----
-    form_row<NPS>(L, P, g, live, P.rw * tt, M);
     double rhs = -(g[0] * cw[0] + g[1] * cw[1] + g[2] * cw[2] + g[3] * cv[0] + g[4] * cv[1] + g[5] * cv[2]);
     if (any_u0) rhs -= form_dot<NPS>(L, P, g, M.gen0, M.vec);
     double A[NV + 1];
 #pragma unroll
-    for (int w = 0; w < NV; w++) A[w] = M.rows[w][L.lane & (WaveMem::LW - 1)];
+    for (int l = 0; l < 5; l++) {
+        form_row_block<NPS>(L, P, g, live, P.rw * tt, l, M);
+#pragma unroll
+        for (int j = 0; j < NPS; j++) A[NPS * l + j] = M.rows[j][L.lane & (WaveMem::LW - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     A[NV] = live ? rhs : 0.0;
     const unsigned long long live_mask = __ballot(live);
 
