@@ -6,7 +6,7 @@ recorded `.mat` data is not redistributable):
   2. gru_train.py                          : min-max scaling, windows of 10, Adam on the self-referential target
   3. gru_test.py                           : sliding-window inference, de-normalised predictions with error bands
 
-Run on an MI355X:  python examples/pipeline_demo.py [--traj 64 --steps 400 --epochs 3]
+Run on an MI355X:  python examples/pipeline_demo.py [--traj 64 --steps 400 --epochs 3] [--mpc]
 """
 import argparse
 import os
@@ -28,13 +28,23 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--mpc", action="store_true",
+                    help="ground-reaction forces from the convex MPC (KF2.estimate_state_mpc, as the reference's script runs it) "
+                         "instead of a force log")
     a = ap.parse_args(argv)
     dev = torch.device("cuda")
     eng = Engine(0)
 
     # 1. Kalman filter over all trajectories at once; "mocap" ground truth = the clean synthetic state + noise-free copy
     d = synth_numpy(a.traj, a.steps, seed=0)
-    rows, x_hist, status = pl.kalman_feature_rows(eng, d, Q_FITTED, R_FITTED, d["x0"])
+    if a.mpc:
+        # data_conversion_Kalman_to_Training.py:194-199: x = KF2.estimate_state_mpc(imu, p, dp, x_ref, contact_ref)
+        ref = np.zeros((a.traj, a.steps, 12), np.float32); ref[..., 5] = 0.28; ref[..., 9] = 0.1
+        d["ref"] = ref
+        rows, x_hist, forces, status = pl.kalman_feature_rows_mpc(eng, d, Q_FITTED, R_FITTED, d["x0"])
+        print(f"MPC forces: |f| max {float(forces.abs().max()):.1f} N")
+    else:
+        rows, x_hist, status = pl.kalman_feature_rows(eng, d, Q_FITTED, R_FITTED, d["x0"])
     assert int(status.abs().sum()) == 0
     mocap = x_hist + 0.01 * torch.randn_like(x_hist)          # stand-in labels with the same 12-state layout
 

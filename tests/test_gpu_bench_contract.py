@@ -31,7 +31,8 @@ def test_default_mode_contract():
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and "traffic" in ro
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["single_thread_value"] > 0 and cb["gru_half_torch_cpu"]["value"] > 0
     assert abs(d["value"] - 4096 * 20 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
 
 
@@ -39,3 +40,5 @@ def test_other_modes_print_one_line():
     assert _run(["--mode", "kf", "--batch", "4096", "--seq", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])["value"] > 0
     d = _run(["--mode", "train", "--steps", "2", "--warmup", "1"])
     assert d["config"]["batch_per_gpu"] == 8192 and d["grad_bucket_bytes"] == 422424 * 4
+    m = _run(["--mode", "mpc", "--batch", "512", "--seq", "10", "--steps", "1", "--warmup", "1"])
+    assert m["value"] > 0 and m["status_nonzero_trajectories"] == 0 and m["kernels"]["mpc"][1] == 10
