@@ -3,7 +3,7 @@
 // history and the final 24 outputs touches HBM: feature rows never leave registers.
 //
 // Wave-autonomous design (one CU = one 256-thread workgroup = 4 waves, no inter-wave synchronisation in the T loop):
-//   * each wave owns 64 trajectories; lane = trajectory for the Kalman part (x: 12, upper triangle of P: 78 VGPRs);
+//   * each wave owns 64 trajectories; lane = trajectory for the Kalman part (x: 12, upper triangle of P: 78 VGPRs, scalar storage: kf_device.hpp);
 //   * the 60 normalised features of step t sit in the owning lane's registers; one v_permlane32_swap per feature
 //     pair turns them into the two 32-row MFMA A-fragments (lanes 0-31: feature k, lanes 32-63: feature k+1) -- no LDS;
 //   * the wave then runs its own rows through the GRU cell: gates[64 x 192] = [x_t | h] [W_ih | W_hh]^T on
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
     const int bb = live ? b : k.B - 1;                 // dead lanes shadow the last trajectory, stores masked
     const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
 
-    float x[NS], U[NU];
+    float x[NS], U[NT];
     {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
     for (int t = 0; t < k.T; t++) {
         // ================= Kalman step (lane = trajectory) =================
         float z[NM], pw[12], F[KX];
-        kf_step_front_sym<QDIAG>(x, U, in, k.k, z, pw);
-        status |= kf_step_back_sym(x, U, z, k.k);
+        kf_step_front_tri<QDIAG>(x, U, in, k.k, z, pw);
+        status |= kf_step_back_tri(x, U, z, k.k);
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_TRI(U, i, j));
         k.status[b] = status;
         if (!a.seq_out) {
             // fc + sigmoid on h_T (gru/gru_model.py:43-48), lane = trajectory

@@ -445,18 +445,17 @@ __device__ __forceinline__ int update_sequential(float *x, PT *P, const float *z
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Symmetric-storage fast path.  P is symmetric in exact arithmetic (P0 = Q diagonal; F P F^T + Q and the scalar
-// updates P - c c^T / s preserve symmetry), so only the upper triangle is kept: 78 registers instead of 144 and
-// ~40 % fewer FMAs.  The reference never symmetrises its float64 P (kalman_filter.py:172), whose asymmetry stays
-// at rounding level (~1e-17 relative); the difference is far below the fp32 rounding of either form.
-constexpr int NU = NS * (NS + 1) / 2;   // 78
+// Scalar upper triangle (78 floats, row-major) -- the storage the fused kernel keeps: there the paired layout below costs
+// more in register-pair alignment than it saves (36 -> 139 spilled VGPRs, 3.09 -> 4.08 ms), so fused_kf_gru_kernel stays
+// on this form and lets hipcc's SLP vectoriser pack what it can.
+constexpr int NT = NS * (NS + 1) / 2;   // 78
 __host__ __device__ constexpr int uidx(int i, int j) { return i * NS - i * (i - 1) / 2 + (j - i); }   // i <= j
-#define OSK_SYM(U, i, j) ((i) <= (j) ? (U)[uidx((i), (j))] : (U)[uidx((j), (i))])
+#define OSK_TRI(U, i, j) ((i) <= (j) ? (U)[uidx((i), (j))] : (U)[uidx((j), (i))])
 
 // P <- F_d P F_d^T + Q, F_d = I + G with G[0:3,6:9] = dt R^T, G[3:6,9:12] = dt I (kalman_filter.py:124-135):
 //   P' = P + M + M^T + M G^T,  M = G P (rows 0..5 only).
 template <bool QDIAG>
-__device__ __forceinline__ void cov_predict_sym(float *U, const Rot &r, const KfConst &k)
+__device__ __forceinline__ void cov_predict_tri(float *U, const Rot &r, const KfConst &k)
 {
     float g[9];
 #pragma unroll
@@ -466,11 +465,11 @@ __device__ __forceinline__ void cov_predict_sym(float *U, const Rot &r, const Kf
     float M[6 * NS];
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        const float a6 = OSK_SYM(U, 6, j), a7 = OSK_SYM(U, 7, j), a8 = OSK_SYM(U, 8, j);
+        const float a6 = OSK_TRI(U, 6, j), a7 = OSK_TRI(U, 7, j), a8 = OSK_TRI(U, 8, j);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             M[i * NS + j] = g[3 * i] * a6 + g[3 * i + 1] * a7 + g[3 * i + 2] * a8;
-            M[(3 + i) * NS + j] = k.dt * OSK_SYM(U, 9 + i, j);
+            M[(3 + i) * NS + j] = k.dt * OSK_TRI(U, 9 + i, j);
         }
     }
 #pragma unroll
@@ -499,7 +498,7 @@ __device__ __forceinline__ void cov_predict_sym(float *U, const Rot &r, const Kf
 }
 
 // Sequential scalar updates on the packed upper triangle (diagonal R).
-__device__ __forceinline__ int update_sequential_sym(float *x, float *U, const float *z, const KfConst &k)
+__device__ __forceinline__ int update_sequential_tri(float *x, float *U, const float *z, const KfConst &k)
 {
     int status = 0;
 #pragma unroll
@@ -512,7 +511,7 @@ __device__ __forceinline__ int update_sequential_sym(float *x, float *U, const f
         const float innov = z[a] - x[sa];
         float c[NS], kc[NS];
 #pragma unroll
-        for (int i = 0; i < NS; i++) { c[i] = OSK_SYM(U, i, sa); kc[i] = c[i] * inv; }
+        for (int i = 0; i < NS; i++) { c[i] = OSK_TRI(U, i, sa); kc[i] = c[i] * inv; }
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             x[i] += kc[i] * innov;
@@ -523,12 +522,133 @@ __device__ __forceinline__ int update_sequential_sym(float *x, float *U, const f
     return status;
 }
 
-__device__ __forceinline__ float trace_sym(const float *U)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric-storage fast path.  P is symmetric in exact arithmetic (P0 = Q diagonal; F P F^T + Q and the scalar
+// updates P - c c^T / s preserve symmetry), so only the upper triangle is kept.  The reference never symmetrises its
+// float64 P (kalman_filter.py:172), whose asymmetry stays at rounding level (~1e-17 relative); the difference is far
+// below the fp32 rounding of either form.
+//
+// Storage: float2 PAIRS of adjacent columns, U[pidx(i, jp)] = (P[i][2jp], P[i][2jp+1]) for jp >= i/2 -- 42 pairs.  An
+// even row starts at its diagonal; an odd row's first pair also carries P[i][i-1], a duplicate of P[i-1][i] that is
+// updated with the same formulas (and never read as the source of truth).  With one wave per SIMD a VALU instruction
+// costs an issue slot whether it is packed or not (profiles/r01j_valu_rates.md), and on this layout the rank-1 updates
+// and the covariance products are v_pk_fma_f32 on aligned pairs with the scalar factor broadcast by op_sel: 42
+// instructions per measurement update instead of 78 + the shuffles hipcc's own SLP packing needed.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int NU = 42;   // pairs
+__host__ __device__ constexpr int prow0(int i)
+{
+    int o = 0;
+    for (int r = 0; r < i; r++) o += 6 - r / 2;
+    return o;
+}
+__host__ __device__ constexpr int pidx(int i, int jp) { return prow0(i) + (jp - i / 2); }   // jp >= i/2
+#define OSK_SYM(U, i, j) ((i) <= (j) ? (U)[pidx((i), (j) / 2)][(j) & 1] : (U)[pidx((j), (i) / 2)][(i) & 1])
+__device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// (P[k][2jp], P[k][2jp+1]) for any row k: the stored pair where it exists, otherwise gathered through symmetry
+#define OSK_ROWPAIR(U, k, jp) ((jp) >= (k) / 2 ? (U)[pidx((k), (jp))] : (f2){OSK_SYM(U, k, 2 * (jp)), OSK_SYM(U, k, 2 * (jp) + 1)})
+
+// P <- F_d P F_d^T + Q, F_d = I + G with G[0:3,6:9] = dt R^T, G[3:6,9:12] = dt I (kalman_filter.py:124-135):
+//   P' = P + M + M^T + M G^T,  M = G P (rows 0..5 only).
+template <bool QDIAG>
+__device__ __forceinline__ void cov_predict_sym(f2 *U, const Rot &r, const KfConst &k)
+{
+    float g[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * r.m[3 * kk + i];
+    // M rows as pairs over all 12 columns
+    f2 M[6][6];
+#pragma unroll
+    for (int jp = 0; jp < 6; jp++) {
+        const f2 a6 = OSK_ROWPAIR(U, 6, jp), a7 = OSK_ROWPAIR(U, 7, jp), a8 = OSK_ROWPAIR(U, 8, jp);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            M[i][jp] = fma2(splat2(g[3 * i + 2]), a8, fma2(splat2(g[3 * i + 1]), a7, splat2(g[3 * i]) * a6));
+            const f2 a9 = OSK_ROWPAIR(U, 9 + i, jp);
+            M[3 + i][jp] = splat2(k.dt) * a9;
+        }
+    }
+    // (M G^T)[i][j], j < 6, per row i as three pairs: columns (0,1), (2,3), (4,5)
+    const f2 ga = {g[0], g[3]}, gb = {g[1], g[4]}, gc = {g[2], g[5]};          // G[j][6..8] for j = 0, 1
+    const f2 gd = {g[6], 0.f}, ge = {g[7], 0.f}, gf = {g[8], 0.f}, gt = {0.f, k.dt};   // j = 2 | j = 3 takes dt M[i][9]
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float m6 = M[i][3][0], m7 = M[i][3][1], m8 = M[i][4][0], m9 = M[i][4][1];
+        f2 mg[3];
+        mg[0] = fma2(splat2(m8), gc, fma2(splat2(m7), gb, splat2(m6) * ga));
+        mg[1] = fma2(splat2(m9), gt, fma2(splat2(m8), gf, fma2(splat2(m7), ge, splat2(m6) * gd)));
+        mg[2] = splat2(k.dt) * M[i][5];
+#pragma unroll
+        for (int jp = i / 2; jp < 6; jp++) {
+            f2 v = U[pidx(i, jp)] + M[i][jp];
+            if (jp < 3) {
+                const f2 mt = {M[2 * jp][i / 2][i & 1], M[2 * jp + 1][i / 2][i & 1]};     // M[j][i] for the pair's two j
+                v = v + mt + mg[jp];
+            }
+            U[pidx(i, jp)] = v;
+        }
+    }
+    if (QDIAG) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) U[pidx(i, i / 2)][i & 1] += k.Q[i * NS + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int jp = i / 2; jp < 6; jp++) {
+                const int j0 = 2 * jp, j1 = 2 * jp + 1;
+                U[pidx(i, jp)] += (f2){0.5f * (k.Q[i * NS + j0] + k.Q[j0 * NS + i]), 0.5f * (k.Q[i * NS + j1] + k.Q[j1 * NS + i])};
+            }
+    }
+}
+
+// Sequential scalar updates on the paired upper triangle (diagonal R).
+__device__ __forceinline__ int update_sequential_sym(float *x, f2 *U, const float *z, const KfConst &k)
+{
+    int status = 0;
+#pragma unroll
+    for (int a = 0; a < NM; a++) {
+        const int sa = SEL[a];
+        float s = OSK_SYM(U, sa, sa) + k.R[a * NM + a];
+        if (!(s > 0.f) || !(s < 3.0e38f)) { status |= 1; s = 1.0f; }
+        float inv = __builtin_amdgcn_rcpf(s);
+        inv = inv * (2.0f - s * inv);          // one Newton step: <= 1 ulp, 3 instructions instead of the ~10 of a division
+        const float innov = z[a] - x[sa];
+        f2 c[6], kc[6];
+#pragma unroll
+        for (int jp = 0; jp < 6; jp++) { c[jp] = OSK_ROWPAIR(U, sa, jp); kc[jp] = c[jp] * splat2(inv); }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const float ki = kc[i / 2][i & 1];
+            x[i] = fmaf(ki, innov, x[i]);
+#pragma unroll
+            for (int jp = i / 2; jp < 6; jp++) U[pidx(i, jp)] = fma2(splat2(-ki), c[jp], U[pidx(i, jp)]);
+        }
+    }
+    return status;
+}
+
+__device__ __forceinline__ float trace_sym(const f2 *U)
 {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < NS; i++) t += U[uidx(i, i)];
+    for (int i = 0; i < NS; i++) t += OSK_SYM(U, i, i);
     return t;
+}
+
+// state load / store of the paired triangle from / to the row-major P [144][B] stream
+template <typename LoadF>
+__device__ __forceinline__ void sym_load(f2 *U, LoadF ld)
+{
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int jp = i / 2; jp < 6; jp++) U[pidx(i, jp)] = (f2){ld(i * NS + 2 * jp), ld(i * NS + 2 * jp + 1)};
 }
 
 template <typename PT>
@@ -568,7 +688,7 @@ __device__ __forceinline__ void kf_step_front(float *x, PT *P, const StepIn &in,
 
 // Symmetric-storage halves (fast path: sequential update, predict(p,f) covariance).
 template <bool QDIAG>
-__device__ __forceinline__ void kf_step_front_sym(float *x, float *U, const StepIn &in, const KfConst &k, float *z,
+__device__ __forceinline__ void kf_step_front_sym(float *x, f2 *U, const StepIn &in, const KfConst &k, float *z,
                                                   float *pw)
 {
     measurement(in, z);
@@ -577,9 +697,24 @@ __device__ __forceinline__ void kf_step_front_sym(float *x, float *U, const Step
     dynamics(x, r, in.p, in.f, pw, k);
 }
 
-__device__ __forceinline__ int kf_step_back_sym(float *x, float *U, const float *z, const KfConst &k)
+__device__ __forceinline__ int kf_step_back_sym(float *x, f2 *U, const float *z, const KfConst &k)
 {
     return update_sequential_sym(x, U, z, k) | finite_status(x);
+}
+
+// the same halves on the scalar triangle (fused kernel)
+template <bool QDIAG>
+__device__ __forceinline__ void kf_step_front_tri(float *x, float *U, const StepIn &in, const KfConst &k, float *z, float *pw)
+{
+    measurement(in, z);
+    Rot r = rotation(x[0], x[1], x[2]);
+    cov_predict_tri<QDIAG>(U, r, k);
+    dynamics(x, r, in.p, in.f, pw, k);
+}
+
+__device__ __forceinline__ int kf_step_back_tri(float *x, float *U, const float *z, const KfConst &k)
+{
+    return update_sequential_tri(x, U, z, k) | finite_status(x);
 }
 
 template <bool SEQ, bool AUX, typename PT>

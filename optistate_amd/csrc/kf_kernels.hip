@@ -110,15 +110,13 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
     if (b >= a.B) return;
     const size_t B = (size_t)a.B;
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
-    float x[NS], U[NU];
+    float x[NS];
+    f2 U[NU];
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
 #pragma unroll
         for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i; j < NS; j++) U[uidx(i, j)] = buf_load(rP, voff, (i * NS + j) * rowB);
+        sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
     int status = 0;
     StepIn in;
