@@ -1,7 +1,8 @@
 // mpc_kernels.hip -- the convex-MPC force QP of the reference (misc/force_controller.py:70-162, solved there by
 // casadi + qpOASES at kalman_filter/kalman_filter.py:150) as a batched exact active-set solver on gfx950.
 //
-// One wavefront per QP (60 variables = 3 forces x 4 legs x 5 horizon steps), lane v = variable v, float64 throughout
+// One wavefront per QP (3 forces x 5 horizon steps per leg that carries force: swing legs are eliminated, so 15 / 30 /
+// 45 / 60 variables), lane v = variable v, float64 throughout
 // (the Hessian's spectrum spans 1e-6 ... 0.17: the 1e-6 R-term alone fixes the force distribution in the directions the
 // body wrench does not see, which float32 cannot resolve).
 //
@@ -10,7 +11,8 @@
 //       H[v][w] = a_v^T (al W_w + be R1 W_th R1^T) a_w + b_v^T (al W_v + be W_r) b_w + r delta_vw,
 //       al = dt^2 (5 - max(i,l)),  be = dt^4 sum_{k>max(i,l)} (k-1-i)(k-1-l)       (i, l = horizon steps of v, w)
 //     because x_k depends on the inputs only through the per-step wrench (derivation in DESIGN.md); a row is rebuilt
-//     from the 60 six-vectors in LDS whenever it is needed.
+//     from the six-vectors in LDS whenever it is needed (one horizon-step block at a time: 3.5 - 13 KB of LDS per
+//     wavefront, two to three wavefronts per SIMD).
 //   * the feasible set is a product of truncated friction pyramids, so an active set is a FACE per (leg, step):
 //     (sx, sy) in {-1, 0, +1} (fx = +-mu fz active) and sz in {free, fz = 0 (apex, f = 0), fz = fz_max}.  Restricting
 //     the QP to a face only replaces each generator by a linear combination of its leg's three generators, so the
