@@ -118,16 +118,20 @@ struct SweepArgs {
 };
 
 // RB = 32-row blocks per workgroup (BM = 32*RB).  LDS: dh [BM][H+1] | dG [BM][4H+1] (sections da_r, da_z, da_n, da_n*r).
-template <int RB>
-__global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
+// NW = wavefronts per workgroup.  The sweep is serial in T and a workgroup owns its rows, so at the training batch (8192
+// rows = one 32-row workgroup per CU) nothing else can hide a wave's stalls: eight waves (two per SIMD) split the gate
+// derivatives and the output chunks finer and cover each other's load / LDS latency.
+template <int RB, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a)
 {
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = a.H, K = a.K, HS = H + 1, GS = 4 * H + 1, BM = 32 * RB;
     float *dh = sm, *dG = sm + BM * HS;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * BM;
     const size_t B = (size_t)a.B;
-    for (int i = threadIdx.x; i < BM * HS; i += 256) dh[i] = 0.f;
+    for (int i = threadIdx.x; i < BM * HS; i += NT) dh[i] = 0.f;
     __syncthreads();
     const int nchx = a.need_dx ? (K + 31) / 32 : 0, nchh = H / 32;
     const int Q = 3 * H / 2;                   // gate-unit pairs in the reduction
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
             float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
             const bool last = (t == a.T - 1);
 #pragma unroll 8
-            for (int i = threadIdx.x; i < BM * H; i += 256) {
+            for (int i = threadIdx.x; i < BM * H; i += NT) {
                 const int r = i / H, c = i % H, g = row0 + r;
                 const bool ok = g < a.B;
                 const int gc = ok ? g : a.B - 1;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void bwd_sweep_kernel(const SweepArgs a)
         }
         __syncthreads();
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
-        for (int ch = wave; ch < nchx + nchh; ch += 4) {
+        for (int ch = wave; ch < nchx + nchh; ch += NW) {
             const bool is_h = ch >= nchx;
             const int oc = is_h ? ch - nchx : ch;
             const float *wp = (is_h ? a.whhT : a.wihT) + (size_t)oc * Q * 64;
@@ -259,9 +263,13 @@ struct DwArgs {
 constexpr int DW_TR = 32;            // rows per tile
 constexpr int DW_KMAX = 192;         // input columns held per pass (6 chunks of 32)
 
-__global__ __launch_bounds__(256, 1) void dw_kernel(const DwArgs a)
+#ifndef OS_DW_OCC
+#define OS_DW_OCC 1
+#endif
+template <bool VEC4>
+__global__ __launch_bounds__(256, OS_DW_OCC) void dw_kernel(const DwArgs a)
 {
-    __shared__ float Xs[2][DW_TR][DW_KMAX];
+    __shared__ __attribute__((aligned(16))) float Xs[2][DW_TR][DW_KMAX];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
     const int j0 = (blockIdx.x * 4 + wave) * 32;
     const bool jok = j0 < a.H3;
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwArgs a)
     const int ntiles = (int)((r1 - r0 + DW_TR - 1) / DW_TR);
     float bsum = 0.f;
     auto xrow_off = [&](size_t rr) -> size_t {
-        const size_t xr = rr - a.x_row_shift;
-        return a.x_btf ? ((xr % a.B) * a.T + xr / a.B) * (size_t)a.K : xr * (size_t)a.K;
+        const uint32_t xr = (uint32_t)(rr - a.x_row_shift);            // row counts are far below 2^32: 32-bit div/mod
+        return a.x_btf ? ((size_t)(xr % (uint32_t)a.B) * a.T + xr / (uint32_t)a.B) * (size_t)a.K : (size_t)xr * (size_t)a.K;
     };
     for (int kc0 = 0; kc0 < nkc; kc0 += 6) {
         const int kbase = kc0 * 32, kw = (a.K - kbase) < DW_KMAX ? (a.K - kbase) : DW_KMAX;   // columns of this pass
@@ -283,53 +291,84 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwArgs a)
         for (int c = 0; c < 6; c++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
-        // staging registers: 32 rows x 192 columns / 256 threads = 24 floats per thread (thread -> column, 3 x 8 rows)
+        // staging registers: 32 rows x 192 columns / 256 threads = 24 floats per thread.  With K % 4 == 0 (every shape the
+        // reference uses: 60, 64, 128, 188) a thread moves six float4 -- six row addresses per tile instead of 24 (the address
+        // arithmetic was half of this kernel's VALU time, and VALU time is MFMA time lost: they share the pipe)
         float stg[24];
-        const int scol = threadIdx.x % DW_KMAX, srow0 = threadIdx.x / DW_KMAX;      // 256 threads: rows srow0, srow0+?...
         auto stage_load = [&](int tile) {
+            if (VEC4) {
 #pragma unroll
-            for (int i = 0; i < 24; i++) {
-                const int flat = threadIdx.x + 256 * i;                             // 0 .. 6143
-                const int row = flat / DW_KMAX, col = flat % DW_KMAX;
-                const size_t rr = r0 + (size_t)tile * DW_TR + row;
-                const bool ok = tile < ntiles && rr < r1 && col < kw;
-                stg[i] = ok ? a.X[xrow_off(rr) + kbase + col] : 0.f;
+                for (int i = 0; i < 6; i++) {
+                    const int f4 = threadIdx.x + 256 * i;                           // 0 .. 1535
+                    const int row = f4 / (DW_KMAX / 4), col = 4 * (f4 % (DW_KMAX / 4));
+                    const size_t rr = r0 + (size_t)tile * DW_TR + row;
+                    const bool ok = tile < ntiles && rr < r1 && col < kw;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) v = *reinterpret_cast<const float4 *>(a.X + xrow_off(rr) + kbase + col);
+                    stg[4 * i] = v.x; stg[4 * i + 1] = v.y; stg[4 * i + 2] = v.z; stg[4 * i + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 24; i++) {
+                    const int flat = threadIdx.x + 256 * i;                         // 0 .. 6143
+                    const int row = flat / DW_KMAX, col = flat % DW_KMAX;
+                    const size_t rr = r0 + (size_t)tile * DW_TR + row;
+                    const bool ok = tile < ntiles && rr < r1 && col < kw;
+                    stg[i] = ok ? a.X[xrow_off(rr) + kbase + col] : 0.f;
+                }
             }
         };
         auto stage_store = [&](int buf) {
+            if (VEC4) {
 #pragma unroll
-            for (int i = 0; i < 24; i++) {
-                const int flat = threadIdx.x + 256 * i;
-                Xs[buf][flat / DW_KMAX][flat % DW_KMAX] = stg[i];
+                for (int i = 0; i < 6; i++) {
+                    const int f4 = threadIdx.x + 256 * i;
+                    *reinterpret_cast<float4 *>(&Xs[buf][f4 / (DW_KMAX / 4)][4 * (f4 % (DW_KMAX / 4))]) =
+                        make_float4(stg[4 * i], stg[4 * i + 1], stg[4 * i + 2], stg[4 * i + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 24; i++) {
+                    const int flat = threadIdx.x + 256 * i;
+                    Xs[buf][flat / DW_KMAX][flat % DW_KMAX] = stg[i];
+                }
             }
         };
-        (void)scol; (void)srow0;
         stage_load(0);
         stage_store(0);
         __syncthreads();
-        for (int tile = 0; tile < ntiles; tile++) {
-            const int buf = tile & 1;
-            stage_load(tile + 1);                                   // in flight during this tile's MFMAs
+        // this wave's dG operand: the 16 two-row steps of a tile are fetched one whole tile ahead (register double buffer), so a
+        // full tile of MFMAs (16 x 6 x 64 cycles) covers the HBM round trip instead of one step's worth
+        float avb[2][DW_TR / 2];
+        auto dg_load = [&](int tile, float *dst) {
             const size_t rt = r0 + (size_t)tile * DW_TR;
-            float av_next = 0.f;
-            {
-                const size_t rr = rt + kk;
-                av_next = (jok && rr < r1) ? a.dG[rr * a.H3 + j0 + li] : 0.f;
-            }
-#pragma unroll 4
-            for (int st = 0; st < DW_TR / 2; st++) {
-                const float av = av_next;
-                {
-                    const size_t rr = rt + 2 * (st + 1) + kk;
-                    av_next = (jok && st + 1 < DW_TR / 2 && rr < r1) ? a.dG[rr * a.H3 + j0 + li] : 0.f;
-                }
-                if (kc0 == 0) bsum += av;
 #pragma unroll
-                for (int c = 0; c < 6; c++)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Xs[buf][2 * st + kk][c * 32 + li], acc[c], 0, 0, 0);
+            for (int st = 0; st < DW_TR / 2; st++) {
+                const size_t rr = rt + 2 * st + kk;
+                dst[st] = (jok && tile < ntiles && rr < r1) ? __builtin_nontemporal_load(a.dG + rr * a.H3 + j0 + li) : 0.f;
             }
-            stage_store(buf ^ 1);
-            __syncthreads();
+        };
+        dg_load(0, avb[0]);
+        for (int tile = 0; tile < ntiles; tile += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int tl = tile + half, buf = half;            // ntiles may be odd: the last half-iteration is skipped
+                if (tl < ntiles) {
+                    stage_load(tl + 1);                             // X tile: in flight during this tile's MFMAs
+                    dg_load(tl + 1, avb[half ^ 1]);
+#pragma unroll
+                    for (int st = 0; st < DW_TR / 2; st++) {
+                        const float av = avb[half][st];
+                        if (kc0 == 0) bsum += av;
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Xs[buf][2 * st + kk][c * 32 + li], acc[c], 0, 0, 0);
+                        if (st & 1) __builtin_amdgcn_sched_barrier(0);      // keep the 96 LDS reads of a tile from being hoisted (spills)
+                    }
+                    stage_store(buf ^ 1);
+                }
+                __syncthreads();
+            }
         }
         if (jok) {
 #pragma unroll
@@ -559,13 +598,17 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         const int BM = 32 * RB;
         const size_t lds = (size_t)(BM * (H + 1) + BM * (4 * H + 1)) * sizeof(float);
         if (!ctx->sweep_attr_set) {            // per context (= per device), not process-global
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             ctx->sweep_attr_set = true;
         }
-        dim3 grid((B + BM - 1) / BM), block(256);
-        if (RB == 2) hipLaunchKernelGGL(bwd_sweep_kernel<2>, grid, block, lds, s, a);
-        else hipLaunchKernelGGL(bwd_sweep_kernel<1>, grid, block, lds, s, a);
+        dim3 grid((B + BM - 1) / BM);
+        int nw = (RB == 1 && (a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8) ? 8 : 4;      // enough output chunks for eight waves
+        if (const char *e = getenv("OS_SWEEP_NW")) nw = atoi(e) == 8 && RB == 1 ? 8 : 4;       // tuning knob (development)
+        if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
+        else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((bwd_sweep_kernel<1, 4>), grid, dim3(256), lds, s, a);
         OS_HIP(ctx, hipGetLastError());
         // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
@@ -576,13 +619,16 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
             d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
             else { d1.X = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
-            hipLaunchKernelGGL(dw_kernel, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
+            if ((K & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
+            else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
             // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
             DwArgs d2 = d1;
             d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
             d2.dW = gWhh; d2.db = nullptr;
-            if (T > 1)
-                hipLaunchKernelGGL(dw_kernel, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
+            if (T > 1) {
+                if ((H & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
+                else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
+            }
             dim3 cg((H3 + 63) / 64, (unsigned)((rows + 1023) / 1024));
             hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
             OS_HIP(ctx, hipGetLastError());

@@ -9,7 +9,7 @@ f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"]
-    if "bwd_sweep" in k or "gru_layer" in k:
+    if "bwd_sweep" in k or "gru_layer" in k or "dw_kernel" in k:
         acc[k[:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
