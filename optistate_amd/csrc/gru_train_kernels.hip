@@ -391,17 +391,19 @@ __global__ __launch_bounds__(256, OS_DW_OCC) void dw_kernel(const DwArgs a)
     }
 }
 
-// column sums of a [R][N] row-major matrix into dst[N] (bias gradients): 64 columns x 4 row-lanes per workgroup,
-// 1024 rows per workgroup, one atomic per column per workgroup
-__global__ void colsum_kernel(size_t R, int N, const float *src, float *dst)
+// column sums of columns [n0, N) of a [R][N] row-major matrix into dst (bias gradients): 64 columns x 4 row-lanes per
+// workgroup, 256 rows per workgroup (64 loads per thread, eight in flight), one atomic per column per workgroup
+__global__ void colsum_kernel(size_t R, int N, int n0, const float *src, float *dst)
 {
     __shared__ float part[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + cx;
-    const size_t r0 = (size_t)blockIdx.y * 1024, r1 = r0 + 1024 < R ? r0 + 1024 : R;
+    const int n = n0 + blockIdx.x * 64 + cx;
+    const size_t r0 = (size_t)blockIdx.y * 256, r1 = r0 + 256 < R ? r0 + 256 : R;
     float s = 0.f;
-    if (n < N)
-        for (size_t r = r0 + ry; r < r1; r += 4) s += src[r * N + n];
+    if (n < N) {
+#pragma unroll 8
+        for (size_t r = r0 + ry; r < r1; r += 4) s += __builtin_nontemporal_load(src + r * N + n);
+    }
     part[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && n < N) atomicAdd(&dst[n], part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
@@ -629,8 +631,11 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
                 if ((H & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
                 else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
             }
-            dim3 cg((H3 + 63) / 64, (unsigned)((rows + 1023) / 1024));
-            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, dgh, gbhh);
+            // b_hh: dgh differs from dgi only in the n gate (da_n * r instead of da_n), so the r and z thirds of the two bias
+            // gradients are the same sums: copy them from b_ih (complete after the dW_ih launch) and reduce the n third only
+            OS_HIP(ctx, hipMemcpyAsync(gbhh, gbih, (size_t)2 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            dim3 cg((H + 63) / 64, (unsigned)((rows + 255) / 256));
+            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, 2 * H, dgh, gbhh);
             OS_HIP(ctx, hipGetLastError());
         }
         dy = a.dx;
