@@ -263,11 +263,9 @@ struct DwArgs {
 constexpr int DW_TR = 32;            // rows per tile
 constexpr int DW_KMAX = 192;         // input columns held per pass (6 chunks of 32)
 
-#ifndef OS_DW_OCC
-#define OS_DW_OCC 1
-#endif
+// two workgroups per CU for the float4 variant (the scalar-staging fallback needs the full register file)
 template <bool VEC4>
-__global__ __launch_bounds__(256, OS_DW_OCC) void dw_kernel(const DwArgs a)
+__global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
 {
     __shared__ __attribute__((aligned(16))) float Xs[2][DW_TR][DW_KMAX];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
@@ -441,7 +439,7 @@ using namespace ost;
 static int os_dw_rps()
 {
     const char *e = getenv("OS_DW_RPS");     // tuning knob (development)
-    return e ? atoi(e) : 1024;
+    return e ? atoi(e) : 512;        // 2 x 240 workgroups at the training batch: two per CU
 }
 
 struct os_train_state {

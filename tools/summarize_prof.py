@@ -3,7 +3,7 @@
 usage: tools/summarize_prof.py gpurun_out/prof_TAG profiles/TAG_kernel_stats.md "command line" """
 import csv, glob, os, sys
 src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
-f = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest run
 rows = list(csv.DictReader(open(f)))
 with open(dst, "w") as o:
     o.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\nsource: `{os.path.relpath(f)}` (MI355X, gfx950)\n\n")
