@@ -196,6 +196,113 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
     if (a.h_last) write_back(hT, a.h_last);
 }
 
+// Small-batch variant for H = 128 (four 32-column chunks): EIGHT waves per workgroup on one 32-row tile.  Waves 0-3 run the
+// input part of the gate GEMM and the cell update of their chunk, waves 4-7 the recurrent part; the recurrent partial sums
+// cross over through LDS.  With B <= 16 k a 32-row tile is all a CU gets (the recurrence cannot be split across
+// workgroups), so a second wave per SIMD is the only thing that can hide a wave's L2 / LDS stalls -- the same lever as the
+// eight-wave backward sweep.  Numerically identical to gru_layer_kernel up to the order of one addition per gate.
+__global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][32][HS] h double buffer | [4][48][64] exchange
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, HS = H + 1;
+    constexpr int BM = 32;
+    const int chunk = wave & 3, part = wave >> 2;                  // part 0: x part + cell update, part 1: h part
+    const int tile_row0 = blockIdx.x * BM;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t B = (size_t)a.B;
+    float *hl2 = smem;
+    float *xch = smem + 2 * BM * HS + chunk * 48 * 64;
+
+    for (int i = threadIdx.x; i < BM * HS; i += 512) hl2[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
+
+    const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
+    const float *wh = wx + (size_t)a.KPx * 3 * 64;
+    const float *bias = wh + (size_t)a.KPh * 3 * 64;
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float nb_r = -LOG2E * bias[li], nb_z = -LOG2E * bias[32 + li], nb_n = 2.0f * LOG2E * bias[64 + li], b_hn = bias[96 + li];
+    const uint32_t rowB = (uint32_t)a.B * 4u;
+    const int g0 = tile_row0 + li;
+    const int growc = g0 < a.B ? g0 : a.B - 1;
+    const uint32_t xoff = (uint32_t)growc * 4u + (uint32_t)lh * rowB;
+    __syncthreads();
+
+    auto write_back = [&](const float *hsrc, float *dst) {
+        for (int i = threadIdx.x; i < BM * H; i += 512) {
+            const int row = i % BM, k = i / BM;
+            const int g = tile_row0 + row;
+            if (g < a.B) dst[(size_t)k * B + g] = hsrc[row * HS + k];
+        }
+    };
+
+    for (int t = 0; t < a.T; t++) {
+        const float *hl = hl2 + (t & 1) * BM * HS;          // h_{t-1}
+        float *hn_buf = hl2 + ((t + 1) & 1) * BM * HS;       // h_t
+        if (t > 0 && a.seq_out) write_back(hl, a.seq_out + (size_t)(t - 1) * H * B);
+
+        f32x16 acc[1][4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[0][g][e] = 0.f;
+
+        if (part == 0) {
+            const float *xt = a.xs + (size_t)t * a.K * B;
+            const rsrc_t rx = make_rsrc(xt, (uint32_t)a.K * rowB);
+            const int KPfull = a.K / 2;
+            mfma_part<1, true>(acc, wx, KPfull, lane, [&](int q, int) {
+                return buf_load(rx, xoff, __builtin_amdgcn_readfirstlane((uint32_t)(2 * q) * rowB));
+            });
+            if (a.KPx > KPfull) {
+                const int q = KPfull;
+                const float w_r = wx[(q * 3 + 0) * 64 + lane], w_z = wx[(q * 3 + 1) * 64 + lane], w_n = wx[(q * 3 + 2) * 64 + lane];
+                const float av = (lh == 0) ? xt[(size_t)(2 * q) * B + growc] : 0.f;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[0][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[0][2], 0, 0, 0);
+            }
+        } else {
+            mfma_part<1, false>(acc, wh, a.KPh, lane, [&](int q, int) { return hl[li * HS + 2 * q + lh]; });
+            // recurrent partial sums of (r, z, gh_n) -> the chunk's cell-update wave
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                xch[(0 * 16 + e) * 64 + lane] = acc[0][0][e];
+                xch[(1 * 16 + e) * 64 + lane] = acc[0][1][e];
+                xch[(2 * 16 + e) * 64 + lane] = acc[0][3][e];
+            }
+        }
+        __syncthreads();   // exchange complete; every wave is done reading h_{t-1}'s A fragments
+        if (part == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int hidx = row * HS + chunk * 32 + li;
+                const float ar = acc[0][0][e] + xch[(0 * 16 + e) * 64 + lane], az = acc[0][1][e] + xch[(1 * 16 + e) * 64 + lane];
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(ar, -LOG2E, nb_r)));
+                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(az, -LOG2E, nb_z)));
+                const float ghn = xch[(2 * 16 + e) * 64 + lane] + b_hn;
+                const float u = fmaf(r, ghn, acc[0][2][e]);
+                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
+                const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
+                hn_buf[hidx] = hn;
+                if (a.sv_r) {
+                    const int g = tile_row0 + row;
+                    if (g < a.B) {
+                        const size_t o = ((size_t)t * B + g) * H + chunk * 32 + li;
+                        __builtin_nontemporal_store(r, a.sv_r + o); __builtin_nontemporal_store(z, a.sv_z + o);
+                        __builtin_nontemporal_store(n, a.sv_n + o); __builtin_nontemporal_store(ghn, a.sv_g + o);
+                        __builtin_nontemporal_store(hn, a.sv_h + o);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // h_t complete (and the exchange buffer free again)
+    }
+    const float *hT = hl2 + (a.T & 1) * BM * HS;
+    if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
+    if (a.h_last) write_back(hT, a.h_last);
+}
+
 // Re-pack one layer's torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order.
 __global__ void gru_pack_kernel(int K, int H, int KPx, int KPh, const float *Wih, const float *Whh, const float *bih,
                                 const float *bhh, float *dst)
@@ -341,8 +448,19 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
         ctx->layer_attr_set = true;
     }
     dim3 grid((a.B + BM - 1) / BM), block(256);
+    // H = 128 and at most one 32-row tile per CU: eight waves on one tile (input / recurrent halves of the gate GEMM);
+    // measured (60,128,4), T = 100: B = 4096 35 -> 48, B = 8192 70 -> 92 TFLOP/s; from two tiles per CU on the plain kernel wins
+    bool split = H == 128 && RBW == 1 && (a.B + 31) / 32 <= ctx->cu_count;
+    if (const char *e = getenv("OS_GRU_SPLIT")) split = split && atoi(e) != 0;       // tuning knob (development)
     const int slot = os_prof_begin(ctx, 1, s);
-    if (RBW == 2) hipLaunchKernelGGL((gru_layer_kernel<2, 2>), grid, block, lds, s, a);
+    if (split) {
+        const size_t lds_s = ((size_t)2 * 32 * (H + 1) + 4 * 48 * 64) * sizeof(float);
+        if (!ctx->split_attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            ctx->split_attr_set = true;
+        }
+        hipLaunchKernelGGL(gru_layer_split_kernel, dim3((a.B + 31) / 32), dim3(512), lds_s, s, a);
+    } else if (RBW == 2) hipLaunchKernelGGL((gru_layer_kernel<2, 2>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gru_layer_kernel<1, 3>), grid, block, lds, s, a);
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());

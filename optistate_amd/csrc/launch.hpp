@@ -34,7 +34,7 @@ struct os_ctx {
     double mpc_w[12], mpc_rw, mpc_mu, mpc_fzmax;
     double mass64, inertia64[3], gz64;
     float *mpc_scratch; size_t mpc_scratch_floats;
-    bool fused_attr_set, sweep_attr_set, layer_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
+    bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
     // per-kernel timing (os_profile_*): ring of event pairs
