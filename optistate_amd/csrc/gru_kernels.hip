@@ -334,20 +334,28 @@ __global__ void gru_pack_kernel(int K, int H, int KPx, int KPh, const float *Wih
 __global__ void gru_head_kernel(int B, int H, int C, const float *h_last, const float *fcw, const float *fcb,
                                 int use_sigmoid, float *out)
 {
-    extern __shared__ float sw[];   // fc weights [C][H] + bias [C]
-    for (int i = threadIdx.x; i < C * H + C; i += blockDim.x) sw[i] = i < C * H ? fcw[i] : fcb[i - C * H];
+    // fc weights transposed to [H][Cp] (Cp = C rounded up to 8): the eight weights a pass needs for one k are two
+    // ds_read_b128 at a wave-uniform address; bias [Cp] behind them
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    const int Cp = (C + 7) & ~7;
+    for (int i = threadIdx.x; i < H * Cp; i += blockDim.x) {
+        const int k = i / Cp, c = i % Cp;
+        sw[i] = c < C ? fcw[c * H + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < Cp; i += blockDim.x) sw[H * Cp + i] = i < C ? fcb[i] : 0.f;
     __syncthreads();
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     for (int c0 = 0; c0 < C; c0 += 8) {
         float s[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = (c0 + j < C) ? sw[C * H + c0 + j] : 0.f;
+        for (int j = 0; j < 8; j++) s[j] = sw[H * Cp + c0 + j];
+#pragma unroll 8
         for (int k = 0; k < H; k++) {
             const float hv = h_last[(size_t)k * B + b];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (c0 + j < C) s[j] += sw[(c0 + j) * H + k] * hv;
+            const float4 w0 = *reinterpret_cast<const float4 *>(&sw[k * Cp + c0]), w1 = *reinterpret_cast<const float4 *>(&sw[k * Cp + c0 + 4]);
+            s[0] = fmaf(w0.x, hv, s[0]); s[1] = fmaf(w0.y, hv, s[1]); s[2] = fmaf(w0.z, hv, s[2]); s[3] = fmaf(w0.w, hv, s[3]);
+            s[4] = fmaf(w1.x, hv, s[4]); s[5] = fmaf(w1.y, hv, s[5]); s[6] = fmaf(w1.z, hv, s[6]); s[7] = fmaf(w1.w, hv, s[7]);
         }
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -421,9 +429,10 @@ int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, f
 {
     const os_gru_dims &d = ctx->gru;
     const int H = d.hidden_size;
-    const size_t hlds = ((size_t)d.num_classes * H + d.num_classes) * sizeof(float);
+    const int Cp = (d.num_classes + 7) & ~7;
+    const size_t hlds = ((size_t)Cp * H + Cp) * sizeof(float);
     const int hslot = os_prof_begin(ctx, 2, s);
-    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 255) / 256), dim3(256), hlds, s, B, H, d.num_classes, top, fcw,
+    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 63) / 64), dim3(64), hlds, s, B, H, d.num_classes, top, fcw,
                        fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
     os_prof_end(ctx, hslot, s);
     OS_HIP(ctx, hipGetLastError());
