@@ -179,10 +179,15 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
         }
         __syncthreads();
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
-        for (int ch = wave; ch < nchx + nchh; ch += NW) {
+        // work items: output chunks; with need_dx == 0 (layer 0: only the four recurrent chunks) every chunk's reduction is
+        // split in two halves so that all eight waves have work, and the halves meet in dh through LDS atomics
+        const int qsplit = (!a.need_dx && NW > nchh) ? 2 : 1;
+        for (int item = wave; item < (nchx + nchh) * qsplit; item += NW) {
+            const int ch = item / qsplit, qh = item % qsplit;
             const bool is_h = ch >= nchx;
             const int oc = is_h ? ch - nchx : ch;
             const float *wp = (is_h ? a.whhT : a.wihT) + (size_t)oc * Q * 64;
+            const int qlo = qh * (Q / qsplit), qhi = qsplit == 1 ? Q : (qh + 1) * (Q / qsplit);   // Q = 3H/2 is even
             f32x16 acc[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; rb++)
@@ -200,22 +205,22 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             };
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) {
-                if (d < Q) {
-                    wbf[d] = osk::buf_load(rw, wl, (uint32_t)d * 256u);
-                    const int col = acol(d);
+                if (qlo + d < qhi) {
+                    wbf[d] = osk::buf_load(rw, wl, __builtin_amdgcn_readfirstlane((uint32_t)(qlo + d) * 256u));
+                    const int col = acol(qlo + d);
 #pragma unroll
                     for (int rb = 0; rb < RB; rb++) abf[d][rb] = dG[(rb * 32 + li) * GS + col];
                 }
             }
-            for (int q0 = 0; q0 < Q; q0 += DEPTH) {
+            for (int q0 = qlo; q0 < qhi; q0 += DEPTH) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) {
                     const int q = q0 + d;
-                    if (q < Q) {
+                    if (q < qhi) {
 #pragma unroll
                         for (int rb = 0; rb < RB; rb++)
                             acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
-                        if (q + DEPTH < Q) {
+                        if (q + DEPTH < qhi) {
                             wbf[d] = osk::buf_load(rw, wl, __builtin_amdgcn_readfirstlane((uint32_t)(q + DEPTH) * 256u));
                             const int col = acol(q + DEPTH);
 #pragma unroll
@@ -230,8 +235,10 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, c = oc * 32 + li, g = row0 + r;
-                    if (is_h) dh[r * HS + c] += acc[rb][e];
-                    else if (g < a.B && c < K) a.dx[((size_t)t * B + g) * K + c] = acc[rb][e];
+                    if (is_h) {
+                        if (qsplit == 1) dh[r * HS + c] += acc[rb][e];
+                        else atomicAdd(&dh[r * HS + c], acc[rb][e]);       // ds_add_f32: two waves share the chunk
+                    } else if (g < a.B && c < K) a.dx[((size_t)t * B + g) * K + c] = acc[rb][e];
                 }
         }
         __syncthreads();
@@ -604,7 +611,7 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
             ctx->sweep_attr_set = true;
         }
         dim3 grid((B + BM - 1) / BM);
-        int nw = (RB == 1 && (a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8) ? 8 : 4;      // enough output chunks for eight waves
+        int nw = (RB == 1 && ((a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8 || (!a.need_dx && H / 32 >= 4))) ? 8 : 4;   // enough work items for eight waves
         if (const char *e = getenv("OS_SWEEP_NW")) nw = atoi(e) == 8 && RB == 1 ? 8 : 4;       // tuning knob (development)
         if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
         else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
