@@ -310,7 +310,7 @@ __global__ void gru_pack_kernel(int K, int H, int KPx, int KPh, const float *Wih
     const int chunk = blockIdx.x;
     float *d = dst + (size_t)chunk * chunk_floats(KPx, KPh);
     const int nx = KPx * 3 * 64, nh = KPh * 3 * 64;
-    for (int i = threadIdx.x; i < nx + nh + 128; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nx + nh + 128; i += gridDim.y * blockDim.x) {      // grid.y slices the chunk
         float v;
         if (i < nx + nh) {
             const bool isx = i < nx;
@@ -410,7 +410,7 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
     for (int l = 0; l < d->num_layers; l++) {
         const int K = l == 0 ? d->input_size : H;
         const float *Wih = w_flat + src, *Whh = Wih + (size_t)3 * H * K, *bih = Whh + (size_t)3 * H * H, *bhh = bih + 3 * H;
-        hipLaunchKernelGGL(gru_pack_kernel, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, K, H, (K + 1) / 2, H / 2,
+        hipLaunchKernelGGL(gru_pack_kernel, dim3(H / 32, 16), dim3(256), 0, (hipStream_t)stream, K, H, (K + 1) / 2, H / 2,
                            Wih, Whh, bih, bhh, ctx->gru_packed + dst);
         OS_HIP(ctx, hipGetLastError());
         src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;

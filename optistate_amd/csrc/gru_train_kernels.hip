@@ -99,7 +99,8 @@ __global__ void pack_T_kernel(int K, int H3, const float *W, float *dst)
     const int chunk = blockIdx.x;
     const int n = (H3 / 2) * 64;
     float *d = dst + (size_t)chunk * n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    // grid.y slices of the chunk: a handful of workgroups looping over 12 k elements each were pure latency (22 us)
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         const int lane = i & 63, q = i >> 6;
         const int j = 2 * q + (lane >> 5), col = chunk * 32 + (lane & 31);
         d[i] = col < K ? W[(size_t)j * K + col] : 0.f;
@@ -591,8 +592,8 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         const int K = l == 0 ? I : H;
         const float *Wih = ctx->gru_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
         float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
-        hipLaunchKernelGGL(pack_T_kernel, dim3((K + 31) / 32), dim3(256), 0, s, K, H3, Wih, wihT);
-        hipLaunchKernelGGL(pack_T_kernel, dim3(H / 32), dim3(256), 0, s, H, H3, Whh, whhT);
+        hipLaunchKernelGGL(pack_T_kernel, dim3((K + 31) / 32, 16), dim3(256), 0, s, K, H3, Wih, wihT);
+        hipLaunchKernelGGL(pack_T_kernel, dim3(H / 32, 16), dim3(256), 0, s, H, H3, Whh, whhT);
         const float *base = ts->act + (size_t)l * 5 * tbh;
         SweepArgs a;
         a.B = B; a.T = T; a.K = K; a.H = H;
