@@ -12,6 +12,7 @@ OS_KF_SYMMETRIC_P = 4
 OS_FUSED_TWO_KERNEL = 8
 OS_KF_LANE_PER_TRAJECTORY = 32
 OS_MPC_COLD_START = 64
+OS_FUSED_ONE_KERNEL = 128
 OS_PROF_PHASES = 5          # include/optistate_hip.h
 
 # every symbol include/optistate_hip.h declares
