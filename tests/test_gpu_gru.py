@@ -140,3 +140,21 @@ def test_fused_general_paths(mode):
     torch.cuda.synchronize()
     assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < 1e-4
     assert np.abs(r["out"].cpu().numpy() - ref_out).max() < 1e-4
+
+
+def test_large_batch_kernels_agree_with_small_batch_kernels():
+    """The layer kernel has three launch shapes (64-row tiles with two workgroups per CU at large batches, 32-row tiles, and
+    the eight-wave split kernel at small batches for H = 128): a ragged large batch must reproduce what its slices give
+    through the small-batch kernels (those are the ones the oracle tests above cover)."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    eng = Engine(0)
+    for (I, H, L) in ((60, 128, 2), (60, 64, 2)):
+        torch.manual_seed(5)
+        m = RNN(I, H, L, 24, torch.device("cuda"))
+        eng.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, 24)
+        B, T = 40000 + 37, 6
+        xs = torch.rand(T, I, B, device="cuda")
+        full = eng.gru_forward_soa(xs)
+        for lo, n in ((0, 4096), (17000, 333), (B - 2048, 2048)):
+            part = eng.gru_forward_soa(xs[:, :, lo:lo + n].contiguous())
+            assert (part - full[lo:lo + n]).abs().max().item() < 2e-6, (I, H, L, lo, n)
