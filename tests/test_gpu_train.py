@@ -28,7 +28,9 @@ def torch_reference_grads(sd, dims, x, y):
 
 
 @pytest.mark.parametrize("dims,B,T", [((60, 64, 1, 24), 50, 10), ((60, 64, 2, 24), 130, 7), ((188, 128, 4, 24), 70, 10),
-                                      ((61, 32, 2, 6), 33, 5)])
+                                      ((61, 32, 2, 6), 33, 5),
+                                      # large ragged batches: 64-row layer kernel with activation saves, many dW slices
+                                      ((60, 128, 2, 24), 20013, 4), ((60, 64, 2, 24), 40001, 3)])
 def test_backward_matches_torch_autograd(dims, B, T):
     from optistate_amd import RNN
     I, H, L, C = dims
