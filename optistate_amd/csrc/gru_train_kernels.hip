@@ -147,9 +147,10 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                         *__restrict__ pdl = a.dy_last;
             float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
             const bool last = (t == a.T - 1);
+            const int lgH = 31 - __builtin_clz(H);             // H is 32, 64 or 128: shifts instead of integer division
 #pragma unroll 8
             for (int i = threadIdx.x; i < BM * H; i += NT) {
-                const int r = i / H, c = i % H, g = row0 + r;
+                const int r = i >> lgH, c = i & (H - 1), g = row0 + r;
                 const bool ok = g < a.B;
                 const int gc = ok ? g : a.B - 1;
                 const size_t o = ((size_t)t * B + gc) * H + c;
