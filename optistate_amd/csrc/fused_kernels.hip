@@ -274,7 +274,7 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
 
     // The single kernel puts 256 trajectories on a CU and takes ~30 us per time step whatever the batch; below half a chip
     // of workgroups (B <= 32 k on 256 CUs) the two-kernel path (Kalman kernel + layer kernel, ~24 us per step) is as fast
-    // or faster (measured, T = 100: B = 8192 2.45 vs 3.0 ms, B = 32768 3.0 vs 3.07 ms, B = 65536 4.4 vs 3.1 ms).
+    // or faster (measured, T = 100: B = 8192 1.49 vs 3.0 ms, B = 32768 3.0 vs 3.07 ms, B = 65536 4.4 vs 3.1 ms).
     const bool shapes_ok = (flags & OS_KF_SEQUENTIAL_UPDATE) && (flags & OS_KF_SYMMETRIC_P) && !(flags & OS_KF_DENSE_FD) &&
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
     const bool single_kernel = shapes_ok && !(flags & OS_FUSED_TWO_KERNEL) &&

@@ -196,23 +196,27 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
     if (a.h_last) write_back(hT, a.h_last);
 }
 
-// Small-batch variant for H = 128 (four 32-column chunks): EIGHT waves per workgroup on one 32-row tile.  Waves 0-3 run the
-// input part of the gate GEMM and the cell update of their chunk, waves 4-7 the recurrent part; the recurrent partial sums
-// cross over through LDS.  With B <= 16 k a 32-row tile is all a CU gets (the recurrence cannot be split across
-// workgroups), so a second wave per SIMD is the only thing that can hide a wave's L2 / LDS stalls -- the same lever as the
-// eight-wave backward sweep.  Numerically identical to gru_layer_kernel up to the order of one addition per gate.
+// Small-batch variant: EIGHT waves per workgroup on one 32-row tile.  The concatenated k-pair range [x part | h part] of
+// the gate GEMM is cut into PARTS = 8 / NCH slices per 32-column chunk (H = 128: input half / recurrent half; H = 64: four
+// slices); wave (chunk, part) accumulates its slice, parts 1.. hand their partial sums to part 0 through
+// LDS, part 0 adds them up and does the cell update of the chunk.  With B <= 8 k a 32-row tile is all a CU gets (the
+// recurrence cannot be split across workgroups), so a second wave per SIMD is the only thing that can hide a wave's L2 /
+// LDS stalls -- the same lever as the eight-wave backward sweep.  Numerically identical to gru_layer_kernel up to the order
+// of PARTS - 1 additions per gate.
+template <int NCH>
 __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][32][HS] h double buffer | [4][48][64] exchange
+    constexpr int PARTS = 8 / NCH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][32][HS] h double buffer | [NCH][PARTS-1][64][64] exchange
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, HS = H + 1;
     constexpr int BM = 32;
-    const int chunk = wave & 3, part = wave >> 2;                  // part 0: x part + cell update, part 1: h part
+    const int chunk = wave % NCH, part = wave / NCH;               // part 0 also does the chunk's cell update
     const int tile_row0 = blockIdx.x * BM;
     const int li = lane & 31, lh = lane >> 5;
     const size_t B = (size_t)a.B;
     float *hl2 = smem;
-    float *xch = smem + 2 * BM * HS + chunk * 48 * 64;
+    float *xch = smem + 2 * BM * HS + (size_t)chunk * (PARTS - 1) * 64 * 64;
 
     for (int i = threadIdx.x; i < BM * HS; i += 512) hl2[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
 
@@ -225,6 +229,11 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
     const int g0 = tile_row0 + li;
     const int growc = g0 < a.B ? g0 : a.B - 1;
     const uint32_t xoff = (uint32_t)growc * 4u + (uint32_t)lh * rowB;
+    // this part's slice of the k-pair range: x k-pairs [xb, xe), h k-pairs [hb, he)
+    const int KPfull = a.K / 2, total = KPfull + a.KPh;
+    const int qb = (int)((long)total * part / PARTS), qe = (int)((long)total * (part + 1) / PARTS);
+    const int xb = qb < KPfull ? qb : KPfull, xe = qe < KPfull ? qe : KPfull;
+    const int hb = (qb > KPfull ? qb : KPfull) - KPfull, he = (qe > KPfull ? qe : KPfull) - KPfull;
     __syncthreads();
 
     auto write_back = [&](const float *hsrc, float *dst) {
@@ -246,41 +255,47 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[0][g][e] = 0.f;
 
-        if (part == 0) {
-            const float *xt = a.xs + (size_t)t * a.K * B;
+        const float *xt = a.xs + (size_t)t * a.K * B;
+        if (xe > xb) {
             const rsrc_t rx = make_rsrc(xt, (uint32_t)a.K * rowB);
-            const int KPfull = a.K / 2;
-            mfma_part<1, true>(acc, wx, KPfull, lane, [&](int q, int) {
-                return buf_load(rx, xoff, __builtin_amdgcn_readfirstlane((uint32_t)(2 * q) * rowB));
+            mfma_part<1, true>(acc, wx + (size_t)xb * 3 * 64, xe - xb, lane, [&](int q, int) {
+                return buf_load(rx, xoff, __builtin_amdgcn_readfirstlane((uint32_t)(2 * (q + xb)) * rowB));
             });
-            if (a.KPx > KPfull) {
-                const int q = KPfull;
-                const float w_r = wx[(q * 3 + 0) * 64 + lane], w_z = wx[(q * 3 + 1) * 64 + lane], w_n = wx[(q * 3 + 2) * 64 + lane];
-                const float av = (lh == 0) ? xt[(size_t)(2 * q) * B + growc] : 0.f;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[0][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[0][2], 0, 0, 0);
-            }
-        } else {
-            mfma_part<1, false>(acc, wh, a.KPh, lane, [&](int q, int) { return hl[li * HS + 2 * q + lh]; });
-            // recurrent partial sums of (r, z, gh_n) -> the chunk's cell-update wave
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                xch[(0 * 16 + e) * 64 + lane] = acc[0][0][e];
-                xch[(1 * 16 + e) * 64 + lane] = acc[0][1][e];
-                xch[(2 * 16 + e) * 64 + lane] = acc[0][3][e];
-            }
         }
-        __syncthreads();   // exchange complete; every wave is done reading h_{t-1}'s A fragments
+        if (part == 0 && a.KPx > KPfull) {                  // odd input width: one masked tail pair
+            const int q = KPfull;
+            const float w_r = wx[(q * 3 + 0) * 64 + lane], w_z = wx[(q * 3 + 1) * 64 + lane], w_n = wx[(q * 3 + 2) * 64 + lane];
+            const float av = (lh == 0) ? xt[(size_t)(2 * q) * B + growc] : 0.f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[0][2], 0, 0, 0);
+        }
+        if (he > hb)
+            mfma_part<1, false>(acc, wh + (size_t)hb * 3 * 64, he - hb, lane, [&](int q, int) { return hl[li * HS + 2 * (q + hb) + lh]; });
+        if (part > 0) {
+            float *dst = xch + (size_t)(part - 1) * 64 * 64;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) dst[(g * 16 + e) * 64 + lane] = acc[0][g][e];
+        }
+        __syncthreads();   // partial sums in place; every wave is done reading h_{t-1}'s A fragments
         if (part == 0) {
+#pragma unroll
+            for (int p = 0; p < PARTS - 1; p++) {
+                const float *src = xch + (size_t)p * 64 * 64;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[0][g][e] += src[(g * 16 + e) * 64 + lane];
+            }
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int hidx = row * HS + chunk * 32 + li;
-                const float ar = acc[0][0][e] + xch[(0 * 16 + e) * 64 + lane], az = acc[0][1][e] + xch[(1 * 16 + e) * 64 + lane];
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(ar, -LOG2E, nb_r)));
-                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(az, -LOG2E, nb_z)));
-                const float ghn = xch[(2 * 16 + e) * 64 + lane] + b_hn;
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][0][e], -LOG2E, nb_r)));
+                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][1][e], -LOG2E, nb_z)));
+                const float ghn = acc[0][3][e] + b_hn;
                 const float u = fmaf(r, ghn, acc[0][2][e]);
                 const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
                 const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
                 }
             }
         }
-        __syncthreads();   // h_t complete (and the exchange buffer free again)
+        __syncthreads();   // h_t complete (and the exchange buffers free again)
     }
     const float *hT = hl2 + (a.T & 1) * BM * HS;
     if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
@@ -457,18 +472,24 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
         ctx->layer_attr_set = true;
     }
     dim3 grid((a.B + BM - 1) / BM), block(256);
-    // H = 128 and at most one 32-row tile per CU: eight waves on one tile (input / recurrent halves of the gate GEMM);
+    // at most one 32-row tile per CU: eight waves on one tile (slices of the gate GEMM's reduction);
     // measured (60,128,4), T = 100: B = 4096 35 -> 48, B = 8192 70 -> 92 TFLOP/s; from two tiles per CU on the plain kernel wins
-    bool split = H == 128 && RBW == 1 && (a.B + 31) / 32 <= ctx->cu_count;
+    bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
     if (const char *e = getenv("OS_GRU_SPLIT")) split = split && atoi(e) != 0;       // tuning knob (development)
     const int slot = os_prof_begin(ctx, 1, s);
     if (split) {
-        const size_t lds_s = ((size_t)2 * 32 * (H + 1) + 4 * 48 * 64) * sizeof(float);
+        const int parts = 8 / NCH;
+        const size_t lds_s = ((size_t)2 * 32 * (H + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
         if (!ctx->split_attr_set) {
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             ctx->split_attr_set = true;
         }
-        hipLaunchKernelGGL(gru_layer_split_kernel, dim3((a.B + 31) / 32), dim3(512), lds_s, s, a);
+        const dim3 g32((a.B + 31) / 32), b512(512);
+        if (NCH == 4) hipLaunchKernelGGL(gru_layer_split_kernel<4>, g32, b512, lds_s, s, a);
+        else if (NCH == 2) hipLaunchKernelGGL(gru_layer_split_kernel<2>, g32, b512, lds_s, s, a);
+        else hipLaunchKernelGGL(gru_layer_split_kernel<1>, g32, b512, lds_s, s, a);
     } else if (RBW == 2) hipLaunchKernelGGL((gru_layer_kernel<2, 2>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gru_layer_kernel<1, 3>), grid, block, lds, s, a);
     os_prof_end(ctx, slot, s);

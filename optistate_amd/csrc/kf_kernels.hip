@@ -184,7 +184,9 @@ __device__ __forceinline__ float row_bcast(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + SRC, 0xf, 0xf, true));
 }
 
-template <bool AUX>
+// FEAT: emit the normalised 60-feature row [x_post | accel | f | p_world | dp | imu] (two-kernel fused path at small batches);
+// lane r of a trajectory's group writes the r-th element of each block
+template <bool AUX, bool FEAT>
 __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, const float *__restrict__ qmat)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
@@ -257,6 +259,22 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
             for (int i = 1; i < 12; i++) pv = (r == i) ? pw[i] : pv;
             a.p_rot_out[((size_t)t * 12 + r) * B + b] = pv;
         }
+        if (FEAT && live && r < 12) {
+            float fv = in.f[0], pv = pw[0], dv = in.dp[0];
+#pragma unroll
+            for (int i = 1; i < 12; i++) { fv = (r == i) ? in.f[i] : fv; pv = (r == i) ? pw[i] : pv; dv = (r == i) ? in.dp[i] : dv; }
+            float *fo = a.feat_out + (size_t)t * a.feat_I * B + b;
+            const float *mm = a.minmax;
+            auto put = [&](int j, float v) { __builtin_nontemporal_store((v - mm[j]) / (mm[60 + j] - mm[j]), fo + (size_t)j * B); };
+            put(18 + r, fv); put(30 + r, pv); put(42 + r, dv);
+            if (r < 6) {
+                float iv = in.imu[0];
+#pragma unroll
+                for (int i = 1; i < 6; i++) iv = (r == i) ? in.imu[i] : iv;
+                put(54 + r, iv);
+                put(12 + r, a.accel[((size_t)t * 6 + r) * B + b]);
+            }
+        }
         // prefetch the next step's inputs underneath the update
         const int tn = (t + 1 < a.T) ? t + 1 : t;
         load_step(a, tn, voff, rowB, in);
@@ -278,6 +296,8 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
 #undef OS_ROW_UPDATE
         if (!(xr * 0.f == 0.f)) status |= 2;
         if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
+        if (FEAT && live && r < 12)
+            __builtin_nontemporal_store((xr - a.minmax[r]) / (a.minmax[60 + r] - a.minmax[r]), a.feat_out + ((size_t)t * a.feat_I + r) * B + b);
         if (AUX && a.ptrace_out) {
             float dg = Prow[0];
 #pragma unroll
@@ -428,11 +448,12 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
 #define OS_DISPATCH(SEQ, DENSE)                                                        \
     (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
           : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
-    if (seq && !dense && !feat && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) && a.B < ctx->rows_kernel_below && ctx->kf_qr) {
+    if (seq && !dense && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) && a.B < ctx->rows_kernel_below && ctx->kf_qr) {
         // small batch: 16 lanes per trajectory so that every SIMD gets a wave
         dim3 grid((a.B + 15) / 16), block(256);                       // 4 waves x 4 trajectories per workgroup
-        if (aux) hipLaunchKernelGGL(kf_run_rows_kernel<true>, grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else hipLaunchKernelGGL(kf_run_rows_kernel<false>, grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
         e = hipGetLastError();
     } else if (seq && !dense && (flags & OS_KF_SYMMETRIC_P) && !a.kgain_out) {
         dim3 grid((a.B + 63) / 64), block(64);
