@@ -107,6 +107,130 @@ __global__ void attention_kernel(int L, int D, int heads, const float *QKV, cons
     }
 }
 
+// The same attention on the matrix cores for head_dim = 32 (the reference's ViT: 4 heads x 32).  One workgroup per
+// (image, head), K and V (+bias) of the head in LDS; a wave owns 32-query tiles.  Per tile: S = Q K^T as seven 32x32
+// v_mfma_f32_32x32x2_f32 tiles (exact fp32), keys beyond L masked, row max / row sum by in-lane reduction over the tiles
+// plus five xor-shuffles inside each 32-lane half (a C-layout row lives in one half), P = exp(S - max) handed from the
+// C layout to the A layout through a wave-private LDS tile, O = P V accumulated over the key tiles, scaled by 1 / sum.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+constexpr int ATT_HD = 32, ATT_KS = ATT_HD + 1, ATT_MAXT = 8;      // up to 256 tokens
+
+template <int NT /* key / query tiles = ceil(L / 32) */>
+__global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
+{
+    extern __shared__ float sm[];            // K [L][33] | V [L][33] | P tiles [4][32][33]
+    float *Ks = sm, *Vs = sm + (size_t)L * ATT_KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    float *pt = sm + (size_t)2 * L * ATT_KS + (size_t)wave * 32 * ATT_KS;
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const float *base = QKV + (size_t)n * L * 3 * D;
+    // staging with float4 loads, four in flight per thread (a scalar loop here was one exposed HBM round trip per element:
+    // it dominated the kernel)
+    {
+        const int c4 = (threadIdx.x & 7) * 4;                       // 8 float4 per 32-wide head row
+        const float4 kb = *reinterpret_cast<const float4 *>(qkv_b + D + h * ATT_HD + c4);
+        const float4 vb = *reinterpret_cast<const float4 *>(qkv_b + 2 * D + h * ATT_HD + c4);
+#pragma unroll 4
+        for (int l = threadIdx.x >> 3; l < L; l += 32) {
+            const float4 kv = *reinterpret_cast<const float4 *>(base + (size_t)l * 3 * D + D + h * ATT_HD + c4);
+            const float4 vv = *reinterpret_cast<const float4 *>(base + (size_t)l * 3 * D + 2 * D + h * ATT_HD + c4);
+            float *kd = Ks + l * ATT_KS + c4, *vd = Vs + l * ATT_KS + c4;
+            kd[0] = kv.x + kb.x; kd[1] = kv.y + kb.y; kd[2] = kv.z + kb.z; kd[3] = kv.w + kb.w;
+            vd[0] = vv.x + vb.x; vd[1] = vv.y + vb.y; vd[2] = vv.z + vb.z; vd[3] = vv.w + vb.w;
+        }
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)ATT_HD);
+    for (int qt = wave; qt < NT; qt += 4) {
+        const int r0 = 32 * qt;
+        // Q tile as A fragments: lane -> (row r0 + li, dim 2q + lh)
+        const int qrow = r0 + li < L ? r0 + li : L - 1;
+        float qa[ATT_HD / 2];
+#pragma unroll
+        for (int q = 0; q < ATT_HD / 2; q++)
+            qa[q] = (base[(size_t)qrow * 3 * D + h * ATT_HD + 2 * q + lh] + qkv_b[h * ATT_HD + 2 * q + lh]) * scale;
+        // S tiles; the 16 K fragments of tile jt+1 are requested from LDS before the 16 MFMAs of tile jt issue
+        f32x16v S[NT];
+        float kb[2][ATT_HD / 2];
+        {
+            const int key = li < L ? li : L - 1;
+#pragma unroll
+            for (int q = 0; q < ATT_HD / 2; q++) kb[0][q] = Ks[key * ATT_KS + 2 * q + lh];
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) {
+            if (jt + 1 < NT) {
+                const int key = 32 * (jt + 1) + li < L ? 32 * (jt + 1) + li : L - 1;
+#pragma unroll
+                for (int q = 0; q < ATT_HD / 2; q++) kb[(jt + 1) & 1][q] = Ks[key * ATT_KS + 2 * q + lh];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) S[jt][e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < ATT_HD / 2; q++) S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q], kb[jt & 1][q], S[jt], 0, 0, 0);
+            if (32 * jt + li >= L) {                     // this lane's key column does not exist
+#pragma unroll
+                for (int e = 0; e < 16; e++) S[jt][e] = -3.0e38f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // row statistics: element e of a lane belongs to row (e&3) + 8(e>>2) + 4 lh, its 32 columns sit in the 32 lanes of the half
+        float mx[16], den[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float m = S[0][e];
+#pragma unroll
+            for (int jt = 1; jt < NT; jt++) m = fmaxf(m, S[jt][e]);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            mx[e] = m;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float d = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; jt++) { const float pv = __expf(S[jt][e] - mx[e]); S[jt][e] = pv; d += pv; }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            den[e] = d;
+        }
+        // O = P V
+        f32x16v acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        float vbf[2][16];
+        {
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const int key = 2 * q + lh < L ? 2 * q + lh : L - 1; vbf[0][q] = Vs[key * ATT_KS + li]; }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++) pt[((e & 3) + 8 * (e >> 2) + 4 * lh) * ATT_KS + li] = S[jt][e];
+            __builtin_amdgcn_wave_barrier();
+            float pa[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) pa[q] = pt[li * ATT_KS + 2 * q + lh];
+            if (jt + 1 < NT) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int key = 32 * (jt + 1) + 2 * q + lh < L ? 32 * (jt + 1) + 2 * q + lh : L - 1;      // P is 0 there
+                    vbf[(jt + 1) & 1][q] = Vs[key * ATT_KS + li];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[q], vbf[jt & 1][q], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (row < L) O[((size_t)n * L + row) * D + h * ATT_HD + li] = acc[e] / den[e];
+        }
+    }
+}
+
 // X += P + bias
 __global__ void bias_residual_kernel(size_t total, int D, const float *P, const float *bias, float *X)
 {
@@ -156,6 +280,7 @@ struct os_vit_state {
     const float *w;          // caller-owned flat weights
     rocblas_handle blas;
     float *buf; size_t buf_floats;
+    bool att_attr_set;
 };
 
 static size_t vit_param_count(const VitDims &d)
@@ -253,7 +378,15 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln1w, ln1b, Y, (size_t)D);
         if (gemm_nt(ctx, v, M, 3 * D, D, Y, qkvw, big)) return -20;
         const size_t alds = (size_t)2 * L * (hd + 1) * sizeof(float);
-        if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
+        const int ntl = (L + 31) / 32;
+        if (hd == 32 && ntl == 7) {              // the reference's shape: 197 tokens, head_dim 32 -> matrix cores
+            const size_t mlds = ((size_t)2 * L * 33 + 4 * 32 * 33) * sizeof(float);
+            if (!v->att_attr_set) {
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)attention_mfma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                v->att_attr_set = true;
+            }
+            hipLaunchKernelGGL(attention_mfma_kernel<7>, dim3(N * d.heads), dim3(256), mlds, s, L, D, d.heads, big, qkvb, Y);
+        } else if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         else hipLaunchKernelGGL(attention_kernel<64>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         if (gemm_nt(ctx, v, M, D, D, Y, projw, tmp)) return -20;
         hipLaunchKernelGGL(bias_residual_kernel, dim3(GB), dim3(TB), 0, s, M * D, D, tmp, projb, X);
