@@ -17,7 +17,7 @@ tt = torch.arange(T, device="cuda")[:, None] * 0.01
 ref[:, 0] = 0.02 * torch.sin(3 * tt); ref[:, 1] = 0.02 * torch.cos(2 * tt)
 def run():
     x = d["x0"].clone(); P = d["P0"].clone()
-    return eng.kf_mpc_run(d["p"], d["dp"], d["imu"], c, ref, x, P, want_iters=True)
+    return eng.kf_mpc_run(d["p"], d["dp"], d["imu"], c, ref, x, P, want_iters=True, sequential=(os.environ.get("SEQ", "0") == "1"))
 r = run(); torch.cuda.synchronize()
 t0 = time.time(); r = run(); torch.cuda.synchronize(); dt = time.time() - t0
 it = r["iters"].float()
