@@ -38,8 +38,11 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
     c->q_is_diagonal = true;
     c->rows_kernel_below = 10240;   // measured crossover with the lane-per-trajectory kernels: ~10 k trajectories
     {
-        const char *e = getenv("OS_KF_ROWS_BELOW");      // tuning knob (development)
+        const char *e = getenv("OS_KF_ROWS_BELOW");      // tuning knobs (development): read once, here
         if (e) c->rows_kernel_below = atoi(e);
+        e = getenv("OS_GRU_SPLIT"); c->tune_gru_split = e ? (atoi(e) != 0 ? -1 : 0) : -1;
+        e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 512;      // 2 x 240 workgroups at the training batch: two per CU
+        e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
     }
     if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc((void **)&c->kf_qr, 244 * sizeof(float)) != hipSuccess ||
         hipMemcpy(c->kf_qr, c->k.Q, 144 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||

@@ -475,7 +475,7 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     // at most one 32-row tile per CU: eight waves on one tile (slices of the gate GEMM's reduction);
     // measured (60,128,4), T = 100: B = 4096 35 -> 48, B = 8192 70 -> 92 TFLOP/s; from two tiles per CU on the plain kernel wins
     bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
-    if (const char *e = getenv("OS_GRU_SPLIT")) split = split && atoi(e) != 0;       // tuning knob (development)
+    if (ctx->tune_gru_split == 0) split = false;
     const int slot = os_prof_begin(ctx, 1, s);
     if (split) {
         const int parts = 8 / NCH;

@@ -445,11 +445,6 @@ __global__ void adam_kernel(size_t n, float *w, const float *g, float *m, float 
 
 using namespace ost;
 
-static int os_dw_rps()
-{
-    const char *e = getenv("OS_DW_RPS");     // tuning knob (development)
-    return e ? atoi(e) : 512;        // 2 x 240 workgroups at the training batch: two per CU
-}
 
 struct os_train_state {
     float *act;   size_t act_floats;     // saved activations: L x 5 x [T][B][H]
@@ -614,7 +609,7 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         }
         dim3 grid((B + BM - 1) / BM);
         int nw = (RB == 1 && ((a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8 || (!a.need_dx && H / 32 >= 4))) ? 8 : 4;   // enough work items for eight waves
-        if (const char *e = getenv("OS_SWEEP_NW")) nw = atoi(e) == 8 && RB == 1 ? 8 : 4;       // tuning knob (development)
+        if (ctx->tune_sweep_nw) nw = ctx->tune_sweep_nw == 8 && RB == 1 ? 8 : 4;
         if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
         else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((bwd_sweep_kernel<1, 4>), grid, dim3(256), lds, s, a);
@@ -622,7 +617,7 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
         {
-            const int rps = os_dw_rps();               // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
+            const int rps = ctx->tune_dw_rps;          // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
             DwArgs d1;
             d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.rows_per_slice = rps;
             d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;

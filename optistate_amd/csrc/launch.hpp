@@ -17,6 +17,10 @@ struct os_ctx {
     bool r_is_diagonal, q_is_diagonal;
     float *kf_qr;                        // device copy of Q (144) and R (100) for per-lane indexing (small-batch kernel)
     int rows_kernel_below;               // use the 16-lanes-per-trajectory kernel when B is below this
+    // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
+    int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
+    int tune_dw_rps;                     // rows per dW slice
+    int tune_sweep_nw;                   // 0 automatic, 4 / 8 waves per backward-sweep workgroup
     char err[512];
     // GRU state (owned scratch)
     os_gru_dims gru;
