@@ -86,6 +86,15 @@ __device__ __forceinline__ void sincos_f32(float x, float *s, float *c)
 }
 
 // R = Rz(thz) * Ry(thy) * Rx(thx), closed form of the product at kalman_filter/kalman_filter.py:187-191
+__device__ __forceinline__ Rot rotation_sc(float sx, float cx, float sy, float cy, float sz, float cz)
+{
+    Rot r;
+    r.m[0] = cz * cy; r.m[1] = cz * sy * sx - sz * cx; r.m[2] = cz * sy * cx + sz * sx;
+    r.m[3] = sz * cy; r.m[4] = sz * sy * sx + cz * cx; r.m[5] = sz * sy * cx - cz * sx;
+    r.m[6] = -sy;     r.m[7] = cy * sx;                r.m[8] = cy * cx;
+    return r;
+}
+
 __device__ __forceinline__ Rot rotation(float thx, float thy, float thz)
 {
     float sx, cx, sy, cy, sz, cz;
@@ -152,7 +161,8 @@ struct StepIn {
 };
 
 // get_odom + set_measurements (kalman_filter/kalman_filter.py:79-117).  p is the body-frame foot position.
-__device__ __forceinline__ void measurement(const StepIn &in, float *z /*10*/)
+// r = R(imu angles) (supplied by the caller: the 16-lanes-per-trajectory kernel shares its sincos across the lanes).
+__device__ __forceinline__ void measurement_r(const StepIn &in, const Rot &r, float *z /*10*/)
 {
     float c[4];
 #pragma unroll
@@ -171,13 +181,18 @@ __device__ __forceinline__ void measurement(const StepIn &in, float *z /*10*/)
     float inv = (sum_c != 0.f) ? (1.0f / sum_c) : 0.f;   // no stance leg -> odom = 0 (:97-98)
     float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
     float bpz = -pz * inv;
-    Rot r = rotation(in.imu[0], in.imu[1], in.imu[2]);
     z[0] = in.imu[0]; z[1] = in.imu[1]; z[2] = in.imu[2];
     z[3] = bpz;
     z[4] = in.imu[3]; z[5] = in.imu[4]; z[6] = in.imu[5];
     z[7] = r.m[0] * bx + r.m[1] * by + r.m[2] * bz;
     z[8] = r.m[3] * bx + r.m[4] * by + r.m[5] * bz;
     z[9] = r.m[6] * bx + r.m[7] * by + r.m[8] * bz;
+}
+
+__device__ __forceinline__ void measurement(const StepIn &in, float *z /*10*/)
+{
+    const Rot r = rotation(in.imu[0], in.imu[1], in.imu[2]);
+    measurement_r(in, r, z);
 }
 
 // next_state (misc/force_controller.py:269-291): x <- (I + A dt) x + B dt f + dt g, foot positions rotated

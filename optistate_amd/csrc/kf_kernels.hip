@@ -220,8 +220,16 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
         x[4] = row_bcast<4>(xr); x[5] = row_bcast<5>(xr); x[6] = row_bcast<6>(xr); x[7] = row_bcast<7>(xr);
         x[8] = row_bcast<8>(xr); x[9] = row_bcast<9>(xr); x[10] = row_bcast<10>(xr); x[11] = row_bcast<11>(xr);
         float z[NM], pw[12];
-        measurement(in, z);
-        Rot rot = rotation(x[0], x[1], x[2]);
+        // the six sincos of a step (prior attitude, IMU attitude) are shared: lane r < 6 evaluates one angle, twelve row
+        // broadcasts hand the values to the group (replicated, they were a sixth of this kernel's instructions)
+        float sv, cv;
+        {
+            const float ang = r < 3 ? xr : (r == 3 ? in.imu[0] : (r == 4 ? in.imu[1] : in.imu[2]));
+            sincos_f32(ang, &sv, &cv);
+        }
+        const Rot rot = rotation_sc(row_bcast<0>(sv), row_bcast<0>(cv), row_bcast<1>(sv), row_bcast<1>(cv), row_bcast<2>(sv), row_bcast<2>(cv));
+        const Rot rimu = rotation_sc(row_bcast<3>(sv), row_bcast<3>(cv), row_bcast<4>(sv), row_bcast<4>(cv), row_bcast<5>(sv), row_bcast<5>(cv));
+        measurement_r(in, rimu, z);
         // ---- covariance predict, row-parallel: M = F_d P (rows), then P' = M F_d^T (columns, local) + Q ----
         float g[9];
 #pragma unroll
