@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
             _Pragma("unroll") for (int j = 0; j < NS; j++) rowv[j] = row_bcast<S>(Prow[j]);   \
             float sv = rowv[S] + k.R[A * NM + A];                                            \
             if (!(sv > 0.f) || !(sv < 3.0e38f)) { status |= 1; sv = 1.0f; }                  \
-            const float inv = 1.0f / sv;                                                     \
+            float inv = __builtin_amdgcn_rcpf(sv);                                           \
+            inv = inv * (2.0f - sv * inv);      /* one Newton step, <= 1 ulp (as in the lane kernels) */ \
             const float innov = z[A] - row_bcast<S>(xr);                                     \
             const float kc = Prow[S] * inv;                                                  \
             xr += kc * innov;                                                                \
