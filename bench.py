@@ -2,18 +2,27 @@
 """bench.py -- KF+GRU timesteps/s (BASELINE.json metric) on N MI355X of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment this process starts the N ranks itself (a fresh
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` child, BEFORE anything here
+touches the GPU) and exits with the child's code; launched under torch.distributed.run it is one rank.
 
 A "step" is one pass of the hot path (Kalman predict/update + feature pack + GRU + head) over one batch of
 synthetic input: B = 65,536 trajectories x T = 100 timesteps per GPU (BASELINE.json configs[2]).  Inputs are
 resident in HBM before the timed region.  Trajectories are independent, so N GPUs run N disjoint batches with
 no data-path collective (weak scaling); the only cross-rank traffic is the barrier and the max-over-ranks of
 the elapsed time.  Rank 0 prints ONE JSON line.
+
+Other lines (same contract): --mode kf (configs[1]: --batch 4096 --seq 1000), --mode train (configs[3]), --mode full
+(configs[4]), --mode mpc (estimate_state_mpc), --mode windows (the reference's own inference mode,
+gru/gru_test.py:138-191: every output re-runs a 10-step window from h0 = 0), --split-bf16 (opt-in reduced-precision gate
+GEMM of the fused kernel, reported beside -- never instead of -- the exact-fp32 default).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,9 +30,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
+MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 BYTES_PER_STEP_FUSED = 244   # 196 B read + 48 B KF-state write per (trajectory, timestep)
 BYTES_PER_STEP_KF = 220
+KF_FLOPS_STRUCTURED = 7500   # ~7-8 kflop per step exploiting the H selection and the two-block F_d
+# the reference itself (NumPy, one thread) measured in the BUILD container, 327 us/step; it cannot
+# travel to the GPU box, so it rides along as a constant beside the C port timed live
+REFERENCE_PYTHON_STEPS_PER_S = 3.05e3
 
 
 def gru_flops_per_step(I, H, L):
@@ -48,7 +62,158 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(H, L, target_seconds):
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU launch
+# ------------------------------------------------------------------------------------------------------------------
+def launch_command(n, argv, port):
+    """The command `python bench.py --gpus N ...` turns into when it is not already a rank (contract in the task
+    statement: one rank per GPU over RCCL, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """Starts the N rank processes as a CHILD (never exec: nothing in this process has touched the GPU, and it stays that
+    way) and relays the child's exit code; rank 0's JSON line goes straight to our stdout."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    return subprocess.run(launch_command(n, argv, _free_port()), env=env).returncode
+
+
+class Ranks:
+    """Process-group plumbing shared by every mode: rank ids, barrier + max-over-ranks timing, rank/device report."""
+
+    def __init__(self, a):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch `python bench.py --gpus N` and let it start its ranks")
+        self.dist = None
+        self.cpu_only = a.launch_check and torch.cuda.device_count() == 0
+        if not self.cpu_only:
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        else:
+            self.dev = torch.device("cpu")
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.cpu_only:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # nccl == RCCL on ROCm
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        if not self.dist:
+            return seconds
+        import torch
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def report(self):
+        """What the process group itself says about the job: world size as RCCL sees it and every rank's device."""
+        import torch
+        me = {"rank": self.rank, "local_rank": self.local_rank, "pid": os.getpid()}
+        if not self.cpu_only:
+            pr = torch.cuda.get_device_properties(self.dev)
+            me.update(device=torch.cuda.current_device(), name=pr.name, gcn_arch=getattr(pr, "gcnArchName", ""),
+                      pci_bus_id=getattr(pr, "pci_bus_id", None), hbm_gib=round(pr.total_memory / 2 ** 30, 1))
+        if not self.dist:
+            return {"rccl_world_size": 1, "backend": None, "rank_devices": [me]}
+        allr = [None] * self.world
+        self.dist.all_gather_object(allr, me)
+        return {"rccl_world_size": self.dist.get_world_size(), "backend": self.dist.get_backend(), "rank_devices": allr}
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def _kernel_table(eng, prof, steps):
+    return {k: {"ms_per_launch": v[0] / v[1], "launches_per_step": v[1] / steps, "kernel": eng.kernel_name(k)}
+            for k, v in prof.items() if v[1]}
+
+
+def timed_region(rk, warmup, steps, one_step, eng=None):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides, max over ranks.
+    eng: record the library's per-kernel HIP events (on the launch stream, around each internal kernel) over the timed
+    region itself; returns (seconds, last result, kernel table | None)."""
+    import torch
+    r = None
+    for _ in range(warmup):
+        r = one_step()
+    torch.cuda.synchronize()
+    rk.barrier()
+    if eng is not None:
+        eng.profile(True)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = one_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rk.barrier()
+    kernels = None
+    if eng is not None:
+        kernels = _kernel_table(eng, eng.profile_read(), steps)
+        eng.profile(False)
+    return rk.max_over_ranks(el), r, kernels
+
+
+def events_pass(eng, steps, one_step):
+    """A second, untimed pass with the library's per-kernel HIP events on (recorded on the launch stream around each
+    internal kernel): the wall time above stays free of the event overhead."""
+    import torch
+    eng.profile(True)
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
+    return _kernel_table(eng, prof, steps)
+
+
+def base_line(a, rk, metric, unit, value, el, dtype, config):
+    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": rk.world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": dtype, "data": "synthetic", "config": config}
+    return out
+
+
+def load_traffic(kernel_name, shape_ok):
+    """HBM bytes per launch from the PMC passes (tools/traffic_pass.sh -> profiles/traffic.json; FETCH_SIZE corrected x2
+    per the gfx950 calibration).  Valid for the shape it was collected on only; entries carry the kernel name they were
+    measured for, so a renamed or re-dispatched kernel simply finds nothing (null) instead of a stale figure."""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if not shape_ok or not os.path.exists(tj):
+        return None
+    try:
+        return json.load(open(tj)).get(kernel_name.split("<")[0].split(" ")[0])
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baselines and the parity block: the ONLY users of oracle/ in this file (checker / reported baseline, never the
+# thing measured as `value`)
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(H, L, target_seconds, kf_only=False):
     """The float64 C oracle (oracle/kf_oracle.c + gru_oracle.c: a port of the reference's algorithm) timed on the host
     cores over a bounded sample of the same workload (same distributions, T = 100): trajectories split over all cores
     (OpenMP), plus the single-thread figure of the scalar port."""
@@ -59,7 +224,7 @@ def cpu_baseline(H, L, target_seconds):
     from optistate_amd import RNN
     T = 100
     torch.manual_seed(0)
-    w = orc.flatten_state_dict(RNN(60, H, L, 24, torch.device("cpu")).state_dict(), L)
+    w = None if kf_only else orc.flatten_state_dict(RNN(60, H, L, 24, torch.device("cpu")).state_dict(), L)
 
     def run(Bs):
         # timed: the two C entry points (filter, then GRU); the numpy glue between them (feature pack + normalise, single
@@ -70,6 +235,8 @@ def cpu_baseline(H, L, target_seconds):
         t0 = time.perf_counter()
         r = orc.kf_run_batch(a64["p"], a64["f"], a64["dp"], a64["imu"], d["contact"], a64["x0"], P0, Q_DEFAULT, R_DEFAULT)
         t1 = time.perf_counter()
+        if kf_only:
+            return t1 - t0
         rows = np.concatenate([r["x"], a64["accel"], a64["f"], r["p_rot"], a64["dp"], a64["imu"]], axis=2)
         rows = (rows + 30.0) / 60.0
         t2 = time.perf_counter()
@@ -85,89 +252,205 @@ def cpu_baseline(H, L, target_seconds):
     Bs = min(max(cores * probe_B, int(B1 * cores * 0.7 / 0.3)), 65536)      # at most the GPU workload's own batch
     el = run(Bs)
     orc.set_threads(1)
-    # the GRU half as the reference itself computes it (gru/gru_model.py:16-24 = torch.nn.GRU + Linear + sigmoid) on the
-    # host cores, fp32, for context: torch is a library, not reference code
+    what = "KF float64 C oracle" if kf_only else "KF + GRU float64 C oracle"
+    out = {"value": Bs * T / el, "unit": "timesteps/s", "cores": cores, "kind": "port",
+           "sample": f"{Bs} trajectories x {T} steps ({what}, {cores} threads, {el:.1f} s)",
+           "single_thread_value": B1 * T / el1,
+           "single_thread_sample": f"{B1} trajectories x {T} steps, 1 thread, {el1:.1f} s",
+           "reference_python_steps_per_s": REFERENCE_PYTHON_STEPS_PER_S,
+           "reference_python_note": "the reference's own NumPy path (get_odom+set_measurements+predict+update), one thread, "
+                                    "measured in the build container (SURVEY.md section 6); it cannot travel to the GPU box"}
+    if not kf_only:
+        # the GRU half as the reference itself computes it (gru/gru_model.py:16-24 = torch.nn.GRU + Linear + sigmoid) on the
+        # host cores, fp32, for context: torch is a library, not reference code
+        torch.set_num_threads(cores)
+        ref_gru = torch.nn.GRU(60, H, L, batch_first=True); ref_fc = torch.nn.Linear(H, 24)
+        xb = torch.rand(min(Bs, 8192), T, 60)
+        with torch.no_grad():
+            torch.sigmoid(ref_fc(ref_gru(xb[:64])[0][:, -1]))
+            tg = time.perf_counter()
+            torch.sigmoid(ref_fc(ref_gru(xb)[0][:, -1]))
+            tg = time.perf_counter() - tg
+        out["gru_half_torch_cpu"] = {"value": xb.shape[0] * T / tg, "unit": "timesteps/s", "threads": cores,
+                                     "what": "torch.nn.GRU(60,%d,%d)+Linear+sigmoid fp32 on the host, GRU half only" % (H, L)}
+    return out
+
+
+def cpu_baseline_train(target_seconds):
+    """gru/gru_train.py:232-249 as the reference runs it (torch.nn.GRU + Linear + sigmoid, the self-referential target,
+    MSELoss, Adam lr 1e-4) on the host cores, fp32, on a bounded number of windows of the same shape."""
+    import torch
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    ref_gru = torch.nn.GRU(60, H, L, batch_first=True); ref_fc = torch.nn.Linear(H, 24)
-    xb = torch.rand(min(Bs, 8192), T, 60)
-    with torch.no_grad():
-        torch.sigmoid(ref_fc(ref_gru(xb[:64])[0][:, -1]))
-        tg = time.perf_counter()
-        torch.sigmoid(ref_fc(ref_gru(xb)[0][:, -1]))
-        tg = time.perf_counter() - tg
-    return {"value": Bs * T / el, "unit": "timesteps/s", "cores": cores, "kind": "port",
-            "gru_half_torch_cpu": {"value": xb.shape[0] * T / tg, "unit": "timesteps/s", "threads": cores,
-                                   "what": "torch.nn.GRU(60,%d,%d)+Linear+sigmoid fp32 on the host, GRU half only" % (H, L)},
-            "sample": f"{Bs} trajectories x {T} steps (KF + GRU float64 C oracle, {cores} threads, {el:.1f} s)",
-            "single_thread_value": B1 * T / el1,
-            "single_thread_sample": f"{B1} trajectories x {T} steps, 1 thread, {el1:.1f} s"}
+    I, H, L, C, T = 188, 128, 4, 24, 10
+    torch.manual_seed(0)
+    gru = torch.nn.GRU(I, H, L, batch_first=True); fc = torch.nn.Linear(H, C)
+    opt = torch.optim.Adam(list(gru.parameters()) + list(fc.parameters()), lr=1e-4)
+
+    def step(x, y):
+        out = torch.sigmoid(fc(gru(x)[0][:, -1]))
+        tgt = torch.cat([y, (out[:, :12].detach() - y).abs()], dim=1)
+        loss = torch.nn.functional.mse_loss(out, tgt)
+        opt.zero_grad(); loss.backward(); opt.step()
+
+    Bs = 256
+    x, y = torch.rand(Bs, T, I), torch.rand(Bs, 12)
+    step(x, y)
+    t0 = time.perf_counter(); step(x, y); t1 = time.perf_counter() - t0
+    Bs = int(min(8192, max(256, Bs * 0.5 * target_seconds / max(t1, 1e-6))))
+    x, y = torch.rand(Bs, T, I), torch.rand(Bs, 12)
+    t0 = time.perf_counter(); step(x, y); el = time.perf_counter() - t0
+    return {"value": Bs / el, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"one optimisation step on {Bs} windows x {T} steps, RNN(188,128,4,24), torch CPU fp32, {cores} threads, {el:.1f} s",
+            "what": "torch.nn.GRU/Linear/MSELoss/Adam exactly as gru_train.py:217-249 composes them (torch is a library)"}
 
 
-def bench_train(a, rank, local_rank, world, dist):
+def cpu_baseline_full(target_seconds):
+    """ViT-encoder latent (oracle/vit_oracle.py, float64 numpy) + KF + GRU(188,128,4) C oracle on a bounded number of frames."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle as orc, vit_oracle
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
+    from optistate_amd import RNN
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    cores = orc.set_threads(usable_cores())
+    torch.manual_seed(0)
+    sd = {k: v.detach().numpy() for k, v in Transformer_Autoencoder().state_dict().items()}
+    w = orc.flatten_state_dict(RNN(188, 128, 4, 24, torch.device("cpu")).state_dict(), 4)
+    Bt, T = 2, 8
+    frames = np.random.default_rng(0).random((Bt * T, 224, 224))
+    d = synth_numpy(Bt, T, seed=5)
+    t0 = time.perf_counter()
+    lat = vit_oracle.encode(frames, sd).reshape(Bt, T, 128)
+    r = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_DEFAULT, (Bt, 1, 1)), Q_DEFAULT, R_DEFAULT)
+    rows = np.concatenate([r["x"], d["accel"], d["f"], r["p_rot"], d["dp"], d["imu"]], axis=2)
+    orc.gru_forward(np.concatenate([(rows + 30.0) / 60.0, lat], axis=2), w, 188, 128, 4, 24)
+    el = time.perf_counter() - t0
+    orc.set_threads(1)
+    return {"value": Bt * T / el, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{Bt * T} frames (numpy float64 ViT restatement on BLAS threads + C oracle KF/GRU, {el:.1f} s); parity unpinned for the ViT"}
+
+
+def cpu_baseline_mpc(target_seconds):
+    """estimate_state_mpc on the host: oracle/mpc_oracle.py (numpy active-set QP with KKT certificate) + C oracle filter step."""
+    import numpy as np
+    from oracle import mpc_oracle as mo
+    from optistate_amd.synth import synth_numpy
+    d = synth_numpy(4, 8, seed=3)
+    ref = np.array([0, 0, 0, 0, 0, 0.28, 0, 0, 0, 0.1, 0, 0.])
+    n = 0
+    t0 = time.perf_counter()
+    for b in range(4):
+        for t in range(8):
+            mo.mpc_forces(d["x0"][b].astype(np.float64), ref, d["p"][b, t].astype(np.float64), d["contact"][b, t])
+            n += 1
+            if time.perf_counter() - t0 > target_seconds:
+                break
+    el = time.perf_counter() - t0
+    return {"value": n / el, "unit": "timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} force QPs (numpy float64 active-set restatement, 1 thread, {el:.1f} s); the filter step adds <1 %; "
+                      "the reference solves them with qpOASES (absent here: parity unpinned)"}
+
+
+def parity_block(d, idx, x_out, out, model, H, L, kf_only=False, windows=None):
+    """state_linf / gru_linf of a sample of the TIMED batch against the float64 oracle, outside the timed region
+    (BASELINE.json's metric is 'timesteps/s ...; state l-inf vs CPU ref').  d: the device input streams [T][F][B];
+    idx: the sampled trajectory indices; x_out [T][12][B], out [B][C] from the last timed pass."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    n = int(idx.numel())
+    g = lambda k: d[k][:, :, idx].permute(2, 0, 1).double().cpu().numpy()
+    contact = d["contact"][:, :, idx].permute(2, 0, 1).cpu().numpy()
+    ref = orc.kf_run_batch(g("p"), g("f"), g("dp"), g("imu"), contact, d["x0"][:, idx].t().double().cpu().numpy(),
+                           np.tile(Q_DEFAULT, (n, 1, 1)), Q_DEFAULT, R_DEFAULT)
+    xo = x_out[:, :, idx].permute(2, 0, 1).cpu().numpy()
+    res = {"trajectories": n, "timesteps_each": int(xo.shape[1]), "state_linf": float(np.abs(xo - ref["x"]).max()),
+           "state_bar": 1e-4, "reference": "oracle/kf_oracle.c + gru_oracle.c (float64; pinned to reference-generated goldens)"}
+    if not kf_only:
+        rows = np.concatenate([ref["x"], g("accel"), g("f"), ref["p_rot"], g("dp"), g("imu")], axis=2)
+        ro, _, _ = orc.gru_forward((rows + 30.0) / 60.0, orc.flatten_state_dict(model.state_dict(), L), 60, H, L, 24)
+        res["gru_linf"] = float(np.abs(out[idx].cpu().numpy() - ro).max())
+        res["gru_bar"] = 1e-5
+        res["fused_chain_bar"] = 1e-4
+    res["ok"] = bool(res["state_linf"] < 1e-4 and res.get("gru_linf", 0.0) < 1e-4)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# modes
+# ------------------------------------------------------------------------------------------------------------------
+def bench_train(a, rk):
     """BASELINE configs[3]: data-parallel gru_train.py step, RNN(188,128,4,24), 8192 windows of 10 steps per GPU, Adam 1e-4,
     one flat 1.69 MB fp32 gradient bucket all-reduced per step.  A 'step' here is one optimisation step."""
     import torch
     from optistate_amd import RNN
     from optistate_amd.train import DataParallelTrainer
-    dev = torch.device("cuda", local_rank)
+    dev = rk.dev
     B, T, I, H, L, C = 8192, 10, 188, 128, 4, 24
     torch.manual_seed(0)
     model = RNN(I, H, L, C, dev).to(dev)
     tr = DataParallelTrainer(model, lr=1e-4)
-    g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+    g = torch.Generator(device=dev); g.manual_seed(100 + rk.rank)
     x = torch.rand(B, T, I, device=dev, generator=g); y = torch.rand(B, C // 2, device=dev, generator=g)
-    for _ in range(a.warmup):
-        tr.step(x, y)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = tr.step(x, y)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el, loss, _ = timed_region(rk, a.warmup, a.steps, lambda: tr.step(x, y))
+    kernels = events_pass(tr.eng, max(2, min(a.steps, 5)), lambda: tr.step(x, y))
     ar_us = None
-    if dist:
-        dist.barrier()
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    if rk.dist:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rk.dist.all_reduce(tr.bucket.g)
+        torch.cuda.synchronize()
         e0.record()
         for _ in range(20):
-            dist.all_reduce(tr.bucket.g)
+            rk.dist.all_reduce(tr.bucket.g)
         e1.record(); torch.cuda.synchronize()
         ar_us = e0.elapsed_time(e1) / 20 * 1e3
-    if rank == 0:
-        fl_fwd = gru_flops_per_step(I, H, L) * B * T
-        out = {"metric": "GRU training windows/sec (gru_train.py step, data parallel)", "value": B * world * a.steps / el,
-               "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "gru_train.py step RNN(188,128,4,24), Adam lr 1e-4, windows of 10", "batch_per_gpu": B,
-                          "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}, one flat fp32 bucket all-reduce",
-                          "baseline_config": "BASELINE.json configs[3]"},
-               "approx_TFLOPs_fwd_bwd": 3 * fl_fwd / (el / a.steps) / 1e12, "allreduce_us": ar_us,
-               "grad_bucket_bytes": int(tr.bucket.g.numel() * 4), "final_loss": float(loss.item())}
+    info = rk.report()
+    if rk.rank == 0:
+        rows = B * T
+        # algorithmic flops per optimisation step and phase (fp32 MFMA GEMMs only): forward gates, backward-sweep dx/dh
+        # products, weight-gradient reductions
+        fl_fwd = gru_flops_per_step(I, H, L) * rows
+        fl_sweep = sum(2 * 3 * H * ((H if l > 0 else 0) + H) for l in range(L)) * rows          # dx only where a layer below exists
+        fl_dw = sum(2 * 3 * H * (I if l == 0 else H) * rows + 2 * 3 * H * H * (rows - B) for l in range(L))
+        phase_flops = {"gru_layer": fl_fwd, "train_sweep": fl_sweep, "train_dw": fl_dw}
+        dom = max((k for k in kernels if k in phase_flops), key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
+        dk = kernels[dom]
+        fl_launch = phase_flops[dom] / dk["launches_per_step"]
+        ach = fl_launch / (dk["ms_per_launch"] * 1e-3) / 1e12
+        out = base_line(a, rk, "GRU training windows/sec (gru_train.py step, data parallel)", "windows/s", B * rk.world * a.steps / el,
+                        el, "f32", {"workload": "gru_train.py step RNN(188,128,4,24), Adam lr 1e-4, windows of 10", "batch_per_gpu": B,
+                                    "seq_len": T, "global_batch": B * rk.world,
+                                    "parallelism": f"dp{rk.world}, one flat fp32 bucket all-reduce", "baseline_config": "BASELINE.json configs[3]"})
+        tot = fl_fwd + fl_sweep + fl_dw
+        out["roofline"] = {"kernel": dk["kernel"] + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": dk["ms_per_launch"],
+                           "algorithmic_flops_per_launch": fl_launch,
+                           "whole_step": {"algorithmic_TFLOP": tot / 1e12, "achieved_TFLOPs": tot / (el / a.steps) / 1e12,
+                                          "frac": tot / (el / a.steps) / 1e12 / MFMA_F32_PEAK_TF}}
+        out["kernels"] = kernels
+        out["kernel_events"] = "HIP events in a second, untimed pass of the same step"
+        out.update(allreduce_us=ar_us, grad_bucket_bytes=int(tr.bucket.g.numel() * 4), final_loss=float(loss.item()), **info)
+        out["cpu_baseline"] = cpu_baseline_train(a.cpu_seconds) if (a.cpu_seconds > 0 and rk.world == 1) else None
         print(json.dumps(out), flush=True)
-    if dist:
-        dist.destroy_process_group()
 
 
-def bench_full(a, rank, local_rank, world, dist):
+def bench_full(a, rk):
     """BASELINE configs[4]: 1024 depth frames (128 trajectories x 8 steps) -> ViT encoder latent (128-d) -> appended to the 60
     Kalman features -> GRU(188,128,4,24).  A 'step' is one pass over the 1024 frames."""
     import torch
-    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd import default_engine, RNN, flatten_state_dict
     from optistate_amd.transformer_model import Transformer_Autoencoder
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
-    dev = torch.device("cuda", local_rank)
+    dev = rk.dev
     B, T = 128, 8
-    eng = Engine(local_rank); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    eng = default_engine(rk.local_rank); eng.set_noise(Q_DEFAULT, R_DEFAULT)     # the context the ViT module uses too
     torch.manual_seed(0)
     vit = Transformer_Autoencoder().to(dev)
     model = RNN(188, 128, 4, 24, dev)
     eng.load_gru(flatten_state_dict(model.state_dict(), 4, dev), 188, 128, 4, 24)
-    d = synth_torch(B, T, dev, seed=7 + rank)
+    d = synth_torch(B, T, dev, seed=7 + rk.rank)
     contact = eng.contact_soa_to_packed(d["contact"])
     frames = torch.rand(B * T, 1, 224, 224, device=dev)
     minmax = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).to(dev)
@@ -176,126 +459,135 @@ def bench_full(a, rank, local_rank, world, dist):
         lat = vit.forward_encoder(frames).reshape(B, T, 128)
         x, P = d["x0"].clone(), d["P0"].clone()
         return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, latent=eng.pack(lat))
-    for _ in range(a.warmup):
-        one()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({"metric": "depth frames/sec through ViT latent + KF + GRU", "value": B * T * world * a.steps / el,
-                          "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "ViT encoder (3 blocks, dim 128) latent + Kalman + GRU(188,128,4,24)",
-                                     "frames": B * T, "trajectories": B, "seq_len": T, "baseline_config": "BASELINE.json configs[4]",
-                                     "note": "ViT parity unpinned (timm/weights absent)"}}), flush=True)
+    el, _, _ = timed_region(rk, a.warmup, a.steps, one)
+    kernels = events_pass(eng, max(2, min(a.steps, 5)), one)
+    info = rk.report()
+    if rk.rank == 0:
+        N = B * T
+        # ViT dense projections per frame (197 tokens, D = 128): qkv + proj + fc1 + fc2 per block x 3, plus the patch embedding
+        fl_vit_gemm = N * (3 * 197 * 2 * (128 * 384 + 128 * 128 + 2 * 128 * 512) + 196 * 2 * 256 * 128)
+        fl_attn = N * 3 * 4 * 2 * 2 * 197 * 197 * 32
+        fl_gru = gru_flops_per_step(188, 128, 4) * N
+        phase_flops = {"vit_gemm": fl_vit_gemm, "vit_attn": fl_attn, "gru_layer": fl_gru}
+        cand = [k for k in kernels if k in phase_flops]
+        out = base_line(a, rk, "depth frames/sec through ViT latent + KF + GRU", "frames/s", N * rk.world * a.steps / el, el, "f32",
+                        {"workload": "ViT encoder (3 blocks, dim 128) latent + Kalman + GRU(188,128,4,24)", "frames": N,
+                         "trajectories": B, "seq_len": T, "baseline_config": "BASELINE.json configs[4]",
+                         "note": "ViT parity unpinned (timm/weights absent)"})
+        if cand:
+            dom = max(cand, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
+            dk = kernels[dom]
+            fl_launch = phase_flops[dom] / dk["launches_per_step"]
+            ach = fl_launch / (dk["ms_per_launch"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dk["kernel"], "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": dk["ms_per_launch"],
+                               "algorithmic_flops_per_launch": fl_launch, "phase": dom,
+                               "note": "average over the launches of the phase (the projections differ in shape)"}
+        out["kernels"] = kernels
+        out["kernel_events"] = "HIP events in a second, untimed pass of the same step"
+        out.update(info)
+        out["cpu_baseline"] = cpu_baseline_full(a.cpu_seconds) if (a.cpu_seconds > 0 and rk.world == 1) else None
+        print(json.dumps(out), flush=True)
 
 
-def bench_mpc(a, rank, local_rank, world, dist):
+def bench_mpc(a, rk):
     """estimate_state_mpc over the batch -- per step the convex-MPC force QP (exact float64 active-set
     solve, one wavefront per trajectory) followed by the predict_mpc/update filter step.  A 'step' is one pass over
     B trajectories x T time steps."""
     import torch
     from optistate_amd import Engine
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
-    dev = torch.device("cuda", local_rank)
+    dev = rk.dev
     B, T = a.batch, a.seq
-    eng = Engine(local_rank); eng.set_noise(Q_DEFAULT, R_DEFAULT)
-    d = synth_torch(B, T, dev, seed=11 + rank)
+    eng = Engine(rk.local_rank); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    d = synth_torch(B, T, dev, seed=11 + rk.rank)
     contact = eng.contact_soa_to_packed(d["contact"])
     ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
     tt = torch.arange(T, device=dev)[:, None] * 0.01
     ref[:, 0] = 0.02 * torch.sin(3 * tt); ref[:, 1] = 0.02 * torch.cos(2 * tt)
-    last = {}
 
     def one():
         x, P = d["x0"].clone(), d["P0"].clone()
-        last["r"] = eng.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True)
-    for _ in range(a.warmup):
-        one()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    eng.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    prof = eng.profile_read()
-    if dist:
-        dist.barrier()
-        tv = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-        el = float(tv.item())
-        dist.destroy_process_group()
-    if rank == 0:
-        it = last["r"]["iters"].float()
-        print(json.dumps({"metric": "KF timesteps/sec with the convex-MPC force QP in the loop (estimate_state_mpc)",
-                          "value": B * T * world * a.steps / el, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f64 (QP) / f32 (filter)", "data": "synthetic",
-                          "config": {"workload": "estimate_state_mpc: 60-variable force QP + Kalman(12/10) predict_mpc/update",
-                                     "batch_per_gpu": B, "seq_len": T, "parallelism": f"trajectory-sharded x{world}, no collective",
-                                     "note": "QP parity unpinned (qpOASES absent): checked against the KKT-certified oracle"},
-                          "qp_iterations_mean": float(it.mean()), "qp_iterations_max": int(it.max()),
-                          "status_nonzero_trajectories": int((last["r"]["status"] != 0).sum()),
-                          "kernels": {k: v for k, v in prof.items()}}), flush=True)
+        return eng.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True)
+    el, last, _ = timed_region(rk, a.warmup, a.steps, one)
+    kernels = events_pass(eng, 1, one)
+    info = rk.report()
+    if rk.rank == 0:
+        it = last["iters"].float()
+        out = base_line(a, rk, "KF timesteps/sec with the convex-MPC force QP in the loop (estimate_state_mpc)", "timesteps/s",
+                        B * T * rk.world * a.steps / el, el, "f64 (QP) / f32 (filter)",
+                        {"workload": "estimate_state_mpc: 60-variable force QP + Kalman(12/10) predict_mpc/update",
+                         "batch_per_gpu": B, "seq_len": T, "parallelism": f"trajectory-sharded x{rk.world}, no collective",
+                         "note": "QP parity unpinned (qpOASES absent): checked against the KKT-certified oracle"})
+        # bytes per step: p, dp, body_ref 48 each + imu 24 + contact 4 in; x 48 + f 48 out
+        bps = 268
+        ach = bps * B * T / (el / a.steps) / 1e9
+        out["roofline"] = {"kernel": kernels.get("mpc", {}).get("kernel", "mpc_solve_kernel"), "bound": "hbm", "achieved": ach,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_step": bps,
+                           "limiter": "latency: dependent LDS round trips per pivot, one QP per wavefront (not a roofline kernel)"}
+        out.update(qp_iterations_mean=float(it.mean()), qp_iterations_max=int(it.max()),
+                   status_nonzero_trajectories=int((last["status"] != 0).sum()), kernels=kernels, **info)
+        out["cpu_baseline"] = cpu_baseline_mpc(min(a.cpu_seconds, 20.0)) if (a.cpu_seconds > 0 and rk.world == 1) else None
+        print(json.dumps(out), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
-    ap.add_argument("--seq", type=int, default=100)
-    ap.add_argument("--hidden", type=int, default=64)
-    ap.add_argument("--layers", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
-    ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc"],
-                    help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")
-    a = ap.parse_args()
-
+def bench_windows(a, rk):
+    """The reference's OWN inference mode (gru/gru_test.py:138-140,174-191): every output timestep re-runs a window of 10
+    steps from h0 = 0 through RNN(188,128,4,24) -- here all windows of a batch at once (pipeline.predict_windows)."""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from optistate_amd import RNN
+    from optistate_amd.pipeline import predict_windows
+    dev = rk.dev
+    N, T, I, H, L = a.batch, 10, 188, 128, 4
+    torch.manual_seed(0)
+    model = RNN(I, H, L, 24, dev).to(dev).eval()
+    g = torch.Generator(device=dev); g.manual_seed(5 + rk.rank)
+    w = torch.rand(N, T, I, device=dev, generator=g)
+    mn, mx = torch.zeros(12, device=dev), torch.ones(12, device=dev)
+    el, _, _ = timed_region(rk, a.warmup, a.steps, lambda: predict_windows(model, w, mn, mx))
+    kernels = events_pass(model._engine, max(2, min(a.steps, 5)), lambda: predict_windows(model, w, mn, mx))
+    info = rk.report()
+    if rk.rank == 0:
+        out = base_line(a, rk, "sliding-window GRU outputs/sec (gru_test.py inference mode, window 10 from h0=0)", "windows/s",
+                        N * rk.world * a.steps / el, el, "f32",
+                        {"workload": "RNN(188,128,4,24) on windows of 10, one output per window (gru/gru_test.py:138-191)",
+                         "windows_per_gpu": N, "seq_len": T, "gru_timesteps_per_output": T})
+        dk = kernels.get("gru_layer")
+        if dk:
+            fl = gru_flops_per_step(I, H, L) * N * T / dk["launches_per_step"]
+            ach = fl / (dk["ms_per_launch"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dk["kernel"] + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
+                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                               "avg_launch_ms": dk["ms_per_launch"]}
+        out["kernels"] = kernels
+        out.update(info)
+        if a.cpu_seconds > 0 and rk.world == 1:
+            cores = usable_cores(); torch.set_num_threads(cores)
+            ref = torch.nn.GRU(I, H, L, batch_first=True); fc = torch.nn.Linear(H, 24)
+            xb = torch.rand(2048, T, I)
+            with torch.no_grad():
+                torch.sigmoid(fc(ref(xb[:32])[0][:, -1]))
+                t0 = time.perf_counter(); torch.sigmoid(fc(ref(xb)[0][:, -1])); tg = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": 2048 / tg, "unit": "windows/s", "cores": cores, "kind": "port",
+                                   "sample": f"2048 windows x 10, torch.nn.GRU(188,128,4)+Linear+sigmoid fp32 batched on the host ({tg:.2f} s); "
+                                             "the reference script itself runs batch 1: 2.09 ms/window = 478 windows/s (SURVEY section 6)"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
 
+
+def bench_hot_path(a, rk):
+    """--mode fused (default, BASELINE configs[2]) and --mode kf (configs[1]-style)."""
+    import torch
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
-
-    if a.mode == "train":
-        return bench_train(a, rank, local_rank, world, dist)
-    if a.mode == "full":
-        return bench_full(a, rank, local_rank, world, dist)
-    if a.mode == "mpc":
-        return bench_mpc(a, rank, local_rank, world, dist)
     B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60
-    eng = Engine(local_rank)
+    fused = a.mode == "fused"
+    eng = Engine(rk.local_rank)
     eng.set_noise(Q_DEFAULT, R_DEFAULT)
     dev = eng.device
-    d = synth_torch(B, T, dev, seed=1000 + rank)
+    d = synth_torch(B, T, dev, seed=1000 + rk.rank)
     contact = eng.contact_soa_to_packed(d["contact"])
     torch.manual_seed(0)
     model = RNN(I, H, L, 24, dev)                       # random-init weights of the named architecture
@@ -307,95 +599,142 @@ def main():
 
     def one_step():
         x.copy_(x0); P.copy_(P0)                        # device-to-device reset of the 40 MB filter state
-        if a.mode == "fused":
-            return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P)
+        if fused:
+            return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, split_bf16=a.split_bf16)
         return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
 
-    for _ in range(a.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    eng.profile(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        r = one_step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    prof = eng.profile_read()
-    eng.profile(False)
+    # one to three launches per pass here: the per-kernel HIP events stay on over the timed region itself (two event records
+    # per launch against milliseconds of kernel; the modes with dozens of short launches per step use a second pass instead)
+    el, r, kernels = timed_region(rk, a.warmup, a.steps, one_step, eng=eng)
     bad = int((r["status"] != 0).sum().item())
-
-    if rank == 0:
-        steps_per_pass = B * T
-        total = steps_per_pass * world * a.steps
-        # dominant kernel: the one with the largest summed device time in the timed region
-        dom = max(prof.items(), key=lambda kv: kv[1][0])
-        dom_name, (dom_ms, dom_n) = dom
-        avg_ms = dom_ms / max(dom_n, 1)
-        if dom_name in ("gru_layer", "fused"):
-            # MFMA-bound kernels: algorithmic flops = the GRU cell's matrix flops the launch performs (the Kalman
-            # arithmetic of the fused kernel runs on the VALU and is not counted)
-            launches_per_pass = L if dom_name == "gru_layer" else 1
-            layer_flops = gru_flops_per_step(I, H, L) if dom_name == "gru_layer" else gru_flops_per_step(I, H, 1)
-            fl = layer_flops * steps_per_pass / launches_per_pass
-            ach = fl / (avg_ms * 1e-3) / 1e12
-            kname = "gru_layer_kernel" if dom_name == "gru_layer" else "fused_kf_gru_kernel"
-            roof = {"kernel": kname + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
-                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                    "avg_launch_ms": avg_ms}
-            if dom_name == "fused":
-                gbs = BYTES_PER_STEP_FUSED * steps_per_pass / (avg_ms * 1e-3) / 1e9
-                roof["hbm_algorithmic_GBps"] = gbs
-                roof["hbm_frac"] = gbs / HBM_PEAK_GBS
+    info = rk.report()
+    if rk.rank != 0:
+        return
+    steps_per_pass = B * T
+    total = steps_per_pass * rk.world * a.steps
+    # dominant kernel: the phase with the largest device time per pass; its NAME is the variant the library actually
+    # launched (os_profile_kernel_name), so a small batch reports kf_run_rows_kernel, not the fast-path kernel
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
+    dk = kernels[dom]
+    avg_ms = dk["ms_per_launch"]
+    default_shape = B == 65536 and T == 100 and H == 64 and L == 1
+    if dom in ("gru_layer", "fused"):
+        # MFMA-bound kernels: algorithmic flops = the GRU cell's matrix flops the launch performs (the Kalman
+        # arithmetic of the fused kernel runs on the VALU and is not counted)
+        fl = (gru_flops_per_step(I, H, L) if dom == "gru_layer" else gru_flops_per_step(I, H, 1)) * steps_per_pass / dk["launches_per_step"]
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        peak = MFMA_BF16_PEAK_TF if (a.split_bf16 and dom == "fused") else MFMA_F32_PEAK_TF
+        insn = "v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if (a.split_bf16 and dom == "fused") else "v_mfma_f32_32x32x2_f32"
+        roof = {"kernel": f"{dk['kernel']} ({insn})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": fl}
+        if a.split_bf16 and dom == "fused":
+            roof["note"] = ("algorithmic (fp32-equivalent) GRU flops against the bf16 dense peak; the kernel is VALU-bound "
+                            "(Kalman step + operand splitting), not matrix-bound")
+        if dom == "fused":
+            gbs = BYTES_PER_STEP_FUSED * steps_per_pass / (avg_ms * 1e-3) / 1e9
+            roof["hbm_algorithmic_GBps"] = gbs
+            roof["hbm_frac"] = gbs / HBM_PEAK_GBS
+            roof["algorithmic_bytes"] = BYTES_PER_STEP_FUSED * steps_per_pass
+    else:
+        ach = BYTES_PER_STEP_KF * steps_per_pass / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": dk["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes": BYTES_PER_STEP_KF * steps_per_pass}
+        # the filter is ~35 flop/byte in its structured form: beside the HBM figure report the fp32 vector-pipe figure
+        tf = KF_FLOPS_STRUCTURED * steps_per_pass / (avg_ms * 1e-3) / 1e12
+        roof["valu_structured_TFLOPs"] = tf
+        roof["valu_frac_of_fp32_vector_peak"] = tf / MFMA_F32_PEAK_TF
+        if dk["kernel"].startswith("kf_run_rows_kernel"):
+            waves = (B + 3) // 4
+            roof["limiter"] = (f"latency: {waves} wavefronts on 1024 SIMDs, each a serial chain of T = {T} dependent steps "
+                               f"({avg_ms * 1e3 / T:.2f} us per step); neither HBM nor the vector pipe is the bound at this batch")
         else:
-            bps = BYTES_PER_STEP_KF
-            ach = bps * steps_per_pass / (avg_ms * 1e-3) / 1e9
-            roof = {"kernel": "kf_run_sym_kernel" if dom_name == "kf" else dom_name, "bound": "hbm", "achieved": ach,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "avg_launch_ms": avg_ms}
-        # HBM bytes per launch from the PMC passes (tools/traffic_pass.sh -> profiles/traffic.json; FETCH_SIZE corrected
-        # x2 per the gfx950 calibration); valid for the default bench shape only
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj) and B == 65536 and T == 100:
-            try:
-                roof["traffic"] = json.load(open(tj)).get(roof["kernel"].split(" ")[0])
-                roof["traffic_unit"] = "bytes/launch"
-                roof["algorithmic_bytes"] = (BYTES_PER_STEP_FUSED if dom_name == "fused" else BYTES_PER_STEP_KF) * steps_per_pass
-            except Exception:
-                pass
-        kernels = {k: {"ms_per_launch": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items() if v[1]}
-        if "kf" in kernels:
-            kf_ms = kernels["kf"]["ms_per_launch"]
-            kernels["kf"]["algorithmic_GBps"] = BYTES_PER_STEP_KF * steps_per_pass / (kf_ms * 1e-3) / 1e9
-            kernels["kf"]["hbm_frac"] = kernels["kf"]["algorithmic_GBps"] / HBM_PEAK_GBS
-        out = {
-            "metric": "KF+GRU timesteps/sec" if a.mode == "fused" else "KF timesteps/sec",
-            "value": total / el, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"fused Kalman(12-state/10-meas)+GRU(in={I},hidden={H},layers={L},out=24) inference"
-                                   if a.mode == "fused" else "Kalman(12-state/10-meas) predict/update only",
-                       "batch_per_gpu": B, "seq_len": T, "global_batch": B * world,
-                       "parallelism": f"trajectory-sharded x{world}, no collective",
-                       "baseline_config": "BASELINE.json configs[2]" if a.mode == "fused" else "configs[1]-like"},
-            "roofline": roof,
-            "kernels": kernels,
-            "status_nonzero_trajectories": bad,
-        }
-        if a.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds)
-        elif world > 1:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.destroy_process_group()
+            roof["limiter"] = "VALU issue at one wavefront per SIMD (~5 cycles per instruction)"
+    roof["traffic"] = load_traffic(dk["kernel"], default_shape and not a.split_bf16)
+    if roof["traffic"] is not None:
+        roof["traffic_unit"] = "bytes/launch"
+    for k in kernels:
+        if k == "kf":
+            kernels[k]["algorithmic_GBps"] = BYTES_PER_STEP_KF * steps_per_pass / (kernels[k]["ms_per_launch"] * 1e-3) / 1e9
+            kernels[k]["hbm_frac"] = kernels[k]["algorithmic_GBps"] / HBM_PEAK_GBS
+    dtype = "bf16x3-split operands, f32 accumulate (opt-in; KF in f32)" if a.split_bf16 else "f32"
+    out = base_line(a, rk, "KF+GRU timesteps/sec" if fused else "KF timesteps/sec", "timesteps/s", total / el, el, dtype,
+                    {"workload": f"fused Kalman(12-state/10-meas)+GRU(in={I},hidden={H},layers={L},out=24) inference"
+                                 if fused else "Kalman(12-state/10-meas) predict/update only",
+                     "batch_per_gpu": B, "seq_len": T, "global_batch": B * rk.world,
+                     "parallelism": f"trajectory-sharded x{rk.world}, no collective",
+                     "baseline_config": "BASELINE.json configs[2]" if fused else "BASELINE.json configs[1] (true dims 12/10)"})
+    out["roofline"] = roof
+    out["kernels"] = kernels
+    out["kernel_events"] = "HIP events on the launch stream, recorded over the timed region (the wall time includes them)"
+    out["status_nonzero_trajectories"] = bad
+    out.update(info)
+    # parity of the timed batch itself (rank 0's shard), outside the timed region
+    if a.parity_samples > 0:
+        n = min(a.parity_samples, B)
+        idx = torch.randperm(B, generator=torch.Generator().manual_seed(3))[:n].to(dev)
+        out["parity"] = parity_block(d, idx, r["x_out"], r.get("out"), model, H, L, kf_only=not fused)
+        if a.split_bf16:
+            out["parity"]["gru_bar"] = 1e-5
+            out["parity"]["note"] = "opt-in split-bf16 gate GEMM: the GRU bar stays 1e-5, the fused chain < 1e-4"
+    if a.cpu_seconds > 0 and rk.world == 1:
+        out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds, kf_only=not fused)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+def launch_check(a, rk):
+    """Rendezvous self-test of the launcher (CPU contract test): every rank joins, one all-reduce, rank 0 reports."""
+    import torch
+    v = torch.ones(1, device=rk.dev)
+    if rk.dist:
+        rk.dist.all_reduce(v)
+    info = rk.report()
+    if rk.rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "sum_of_ones": float(v.item()), **info}), flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="trajectories (windows) per GPU; default 65536 (windows: 8192)")
+    ap.add_argument("--seq", type=int, default=100)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--parity-samples", type=int, default=128, help="trajectories of the timed batch checked against the oracle (0 = skip)")
+    ap.add_argument("--split-bf16", action="store_true", help="opt-in reduced-precision gate GEMM (second line; never the headline)")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")
+    ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc", "windows"],
+                    help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")
+    a = ap.parse_args(argv)
+    if a.batch is None:
+        a.batch = 8192 if a.mode == "windows" else 65536
+
+    # N > 1 and not yet a rank: start the ranks as a child process BEFORE anything here touches the GPU
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, argv))
+
+    rk = Ranks(a)
+    try:
+        if a.launch_check:
+            launch_check(a, rk)
+        elif a.mode == "train":
+            bench_train(a, rk)
+        elif a.mode == "full":
+            bench_full(a, rk)
+        elif a.mode == "mpc":
+            bench_mpc(a, rk)
+        elif a.mode == "windows":
+            bench_windows(a, rk)
+        else:
+            bench_hot_path(a, rk)
+    finally:
+        rk.close()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,10 @@
  *   - Return value: 0 ok, <0 error (os_last_error() gives text).  Per-trajectory numerical
  *     status is reported in `status[B]`: bit0 = innovation covariance S not positive definite /
  *     non-finite, bit1 = non-finite state (the reference raises LinAlgError /
- *     propagates NaN: kalman_filter/kalman_filter.py:168).
+ *     propagates NaN: kalman_filter/kalman_filter.py:168), bit2 = QP iteration cap (os_kf_mpc_run),
+ *     bit3 = OS_KF_SYMMETRIC_P was requested but the caller's P0 is not symmetric (the kernel used its
+ *     upper triangle; the reference never symmetrises P, kalman_filter/kalman_filter.py:172, so re-run
+ *     that trajectory without the flag).
  *   - Stream layout (structure of arrays, trajectory index fastest, float32):
  *       p, f, dp, body_ref : [T][12][B]      imu, accel : [T][6][B]
  *       contact            : [T][B] of 4 packed bytes (byte k = leg k, 0 swing / 1 stance)
@@ -64,8 +67,14 @@ enum {
                                      that fill less than half of the chip (default: the two-kernel path there, it is
                                      faster below ~32 k trajectories; OS_FUSED_TWO_KERNEL forces that path) */
     OS_MPC_COLD_START       = 64, /* os_kf_mpc_run: do not reuse the previous step's active set (development / tests) */
-    OS_KF_LANE_PER_TRAJECTORY = 32 /* os_kf_run: never use the small-batch kernel (16 lanes per trajectory, row-parallel P),
+    OS_KF_LANE_PER_TRAJECTORY = 32, /* os_kf_run: never use the small-batch kernel (16 lanes per trajectory, row-parallel P),
                                      which is otherwise chosen for sequential updates when B < 10,240 (the measured crossover). */
+    OS_KF_P_FLOAT64         = 256, /* os_kf_predict / os_kf_update: P (and K_out) are DOUBLE arrays and the covariance
+                                     arithmetic runs in float64.  predict_mpc's element-wise exp(dt F) (kalman_filter.py:157)
+                                     leaves a P that float32 cannot carry to the following update within the 1e-4 bar; the
+                                     drop-in class uses this for the split predict_mpc() -> update() sequence. */
+    OS_FUSED_SPLIT_BF16     = 512  /* os_fused_run: opt-in reduced-precision gate GEMM (operands split into three bf16
+                                     terms, products on the bf16 MFMA, fp32 accumulate); NOT the exact-fp32 default. */
 };
 
 /* Replaces Kalman_Filter.__init__ (kalman_filter/kalman_filter.py:8-62): creates a context on cfg->device. */
@@ -94,6 +103,15 @@ int os_kf_run(os_ctx *ctx, int32_t B, int32_t T,
               float *x_out, float *p_rot_out, float *ptrace_out, float *kgain_out,
               int32_t *status, uint32_t flags, void *stream);
 
+/* os_kf_run with PER-TRAJECTORY noise: q_diag [12][B] and r_diag [10][B] (device) replace the context-wide Q / R of
+ * os_kf_set_noise, so filters tuned differently share one launch.  The reference sets Q and R per filter instance
+ * (data_collection/data_conversion_Kalman_to_Training.py:138-144: KF2.Q = Q, KF2.R = R with R[0:3] forced to 1e-4; both
+ * np.diag, :87,:103-105).  Diagonal noise only (sequential update); lane-per-trajectory kernels at every batch size. */
+int os_kf_run_noise(os_ctx *ctx, int32_t B, int32_t T,
+                    const float *p, const float *f, const float *dp, const float *imu, const uint32_t *contact,
+                    float *x, float *P, const float *q_diag, const float *r_diag,
+                    float *x_out, float *p_rot_out, float *ptrace_out, int32_t *status, uint32_t flags, void *stream);
+
 /* Single-instance pieces for the drop-in Kalman_Filter class (B = 1 views over the same kernels).
  * os_kf_odom   : get_odom + set_measurements (kalman_filter/kalman_filter.py:79-117) -> z [10][B]
  * os_kf_predict: predict(p, f) (kalman_filter/kalman_filter.py:119-138); p [12][B] is rotated in place.
@@ -117,6 +135,10 @@ size_t os_gru_param_count(const os_gru_dims *d);
 /* Replaces model.load_state_dict(...) (gru/gru_test.py:160): w_flat is a DEVICE float vector in the flat
  * layout above; the library re-packs it into MFMA fragment order in context scratch. */
 int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream);
+/* Counts os_gru_load calls on this context.  A context holds ONE loaded model; a host-side weight container that shares
+ * a context with others (several RNN modules on one GPU, gru/gru_train.py:205-217 trains num_models of them) compares
+ * this with the value it saw after its own load to know whether its weights are still the resident ones. */
+uint64_t os_gru_generation(const os_ctx *ctx);
 
 /* Replaces RNN.forward (gru/gru_model.py:25-49): x [B][T][I] (batch_first, as the reference passes it)
  * -> out [B][C]; h0 = 0; fc + sigmoid on the last step.  h_last (optional) [L][B][H]. */
@@ -152,6 +174,15 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
                     float *grad_flat, float *dx, void *stream);
 int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, float *v, float lr, float beta1, float beta2,
                  float eps, int32_t step, void *stream);
+/* The same forward / backward with the saved activations in a CALLER-OWNED workspace (os_gru_train_ws_floats floats), so
+ * that several forwards may be outstanding before their backwards run (loss(model(a)) + loss(model(b)), gradient
+ * accumulation, an evaluation forward in between: torch autograd allows all of these around gru/gru_train.py:236-248).
+ * os_gru_backward_ws takes the dims and the flat weights the forward ran with explicitly: it does not depend on what is
+ * loaded in the context at that time. */
+size_t os_gru_train_ws_floats(const os_gru_dims *d, int32_t B, int32_t T);
+int os_gru_forward_train_ws(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *ws, void *stream);
+int os_gru_backward_ws(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, int32_t B, int32_t T, const float *x,
+                       const float *out, const float *dout, const float *ws, float *grad_flat, float *dx, void *stream);
 
 /* ---- Optional ViT-encoder latent (transformer/transformer_model.py:113-135; BASELINE config 5).  PARITY UNPINNED: timm 0.3.2
  * (PatchEmbed, Block) and the trained weights are absent from the build image; this follows that release's published
@@ -197,12 +228,28 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
                   uint32_t flags, void *stream);
 
 /* Per-kernel device timing (HIP events recorded on the launch stream around each internal kernel), used by
- * bench.py for the roofline of the dominant kernel.  Phases: 0 Kalman kernel, 1 GRU layer kernels, 2 GRU head,
- * 3 fused Kalman+GRU kernel, 4 MPC force QP kernel.  os_profile_read synchronises on the recorded events, adds up the elapsed
- * milliseconds and launch counts per phase since os_profile_enable(ctx, 1), and resets them. */
-#define OS_PROF_PHASES 5
+ * bench.py for the roofline of the dominant kernel.  os_profile_read synchronises on the recorded events, adds up the
+ * elapsed milliseconds and launch counts per phase since os_profile_enable(ctx, 1), and resets them.
+ * os_profile_kernel_name: the kernel VARIANT most recently launched in a phase (e.g. "kf_run_rows_kernel" for a small
+ * batch, "kf_run_sym_kernel" for the paired-triangle fast path), so that a report names the kernel that actually ran. */
+#define OS_PROF_PHASES 12
+enum {
+    OS_PHASE_KF = 0,          /* Kalman kernels (os_kf_run and the Kalman half of the two-kernel fused path) */
+    OS_PHASE_GRU_LAYER = 1,   /* GRU layer kernels (inference and training forward) */
+    OS_PHASE_GRU_HEAD = 2,    /* fc + sigmoid head */
+    OS_PHASE_FUSED = 3,       /* fused Kalman+GRU kernel */
+    OS_PHASE_MPC = 4,         /* convex-MPC force QP kernels */
+    OS_PHASE_TRAIN_SWEEP = 5, /* backward-in-time sweep (bwd_sweep_kernel) */
+    OS_PHASE_TRAIN_DW = 6,    /* weight-gradient reductions (dw_kernel) */
+    OS_PHASE_TRAIN_MISC = 7,  /* loss, head backward, weight re-packs, bias column sums, Adam */
+    OS_PHASE_VIT_GEMM = 8,    /* ViT dense projections */
+    OS_PHASE_VIT_ATTN = 9,    /* ViT attention */
+    OS_PHASE_VIT_MISC = 10,   /* ViT patch extraction, LayerNorm, token assembly */
+    OS_PHASE_PACK = 11        /* layout conversions ([B][T][F] <-> [T][F][B]) */
+};
 int os_profile_enable(os_ctx *ctx, int enable);
 int os_profile_read(os_ctx *ctx, double *ms_sum /* host [OS_PROF_PHASES] */, int32_t *launches /* host [OS_PROF_PHASES] */);
+const char *os_profile_kernel_name(const os_ctx *ctx, int phase);
 
 /* Layout helper: [B][T][F] (the reference's per-trajectory row lists) -> [T][F][B]. */
 int os_pack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src_btf, float *dst_tfb, void *stream);

@@ -13,7 +13,11 @@ OS_FUSED_TWO_KERNEL = 8
 OS_KF_LANE_PER_TRAJECTORY = 32
 OS_MPC_COLD_START = 64
 OS_FUSED_ONE_KERNEL = 128
-OS_PROF_PHASES = 5          # include/optistate_hip.h
+OS_KF_P_FLOAT64 = 256
+OS_FUSED_SPLIT_BF16 = 512
+OS_PROF_PHASES = 12         # include/optistate_hip.h
+PHASE_NAMES = ("kf", "gru_layer", "gru_head", "fused", "mpc", "train_sweep", "train_dw", "train_misc", "vit_gemm",
+               "vit_attn", "vit_misc", "pack")
 
 # every symbol include/optistate_hip.h declares
 EXPORTS = [
@@ -22,6 +26,8 @@ EXPORTS = [
     "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream", "os_profile_enable", "os_profile_read",
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
     "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
+    "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
+    "os_profile_kernel_name",
 ]
 
 
@@ -100,6 +106,18 @@ def load():
     lib.os_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.os_profile_enable.restype = C.c_int
     lib.os_profile_read.restype = C.c_int
+    lib.os_profile_kernel_name.argtypes = [vp, C.c_int]
+    lib.os_profile_kernel_name.restype = C.c_char_p
+    lib.os_kf_run_noise.argtypes = [vp, i32, i32] + [f32p] * 5 + [f32p] * 4 + [f32p] * 3 + [vp, u32, vp]
+    lib.os_kf_run_noise.restype = C.c_int
+    lib.os_gru_generation.argtypes = [vp]
+    lib.os_gru_generation.restype = C.c_uint64
+    lib.os_gru_train_ws_floats.argtypes = [C.POINTER(OsGruDims), i32, i32]
+    lib.os_gru_train_ws_floats.restype = C.c_size_t
+    lib.os_gru_forward_train_ws.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp]
+    lib.os_gru_forward_train_ws.restype = C.c_int
+    lib.os_gru_backward_ws.argtypes = [vp, C.POINTER(OsGruDims), f32p, i32, i32, f32p, f32p, f32p, f32p, f32p, f32p, vp]
+    lib.os_gru_backward_ws.restype = C.c_int
     for n in ("os_kf_set_noise", "os_kf_run", "os_kf_odom", "os_kf_predict", "os_kf_update", "os_gru_load",
               "os_gru_forward", "os_gru_forward_soa", "os_fused_run", "os_pack_stream", "os_unpack_stream"):
         getattr(lib, n).restype = C.c_int

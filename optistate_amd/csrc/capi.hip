@@ -112,6 +112,14 @@ int os_profile_enable(os_ctx *ctx, int enable)
     return 0;
 }
 
+const char *os_profile_kernel_name(const os_ctx *ctx, int phase)
+{
+    if (!ctx || ctx->magic != OS_MAGIC || phase < 0 || phase >= OS_PROF_PHASES || !ctx->prof_name[phase]) return "";
+    return ctx->prof_name[phase];
+}
+
+uint64_t os_gru_generation(const os_ctx *ctx) { return (ctx && ctx->magic == OS_MAGIC) ? ctx->gru_generation : 0; }
+
 int os_profile_read(os_ctx *ctx, double *ms_sum, int32_t *launches)
 {
     OS_CHECK_CTX(ctx);

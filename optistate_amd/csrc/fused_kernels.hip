@@ -303,7 +303,7 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
         hipLaunchKernelGGL(osf::norm_prep_kernel, dim3(1), dim3(64), 0, s, minmax, ctx->nrm);
         fa.nrm = ctx->nrm;
         dim3 grid((B + 255) / 256), block(256);
-        const int slot = os_prof_begin(ctx, 3, s);
+        const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, "fused_kf_gru_kernel");
         if (ctx->q_is_diagonal) hipLaunchKernelGGL(osf::fused_kf_gru_kernel<true>, grid, block, osf::LDS_BYTES, s, fa);
         else hipLaunchKernelGGL(osf::fused_kf_gru_kernel<false>, grid, block, osf::LDS_BYTES, s, fa);
         os_prof_end(ctx, slot, s);

@@ -434,6 +434,7 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
     ctx->gru = *d;
     ctx->gru_flat = w_flat;
     ctx->gru_loaded = true;
+    ctx->gru_generation++;
     return 0;
 }
 
@@ -446,7 +447,7 @@ int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, f
     const int H = d.hidden_size;
     const int Cp = (d.num_classes + 7) & ~7;
     const size_t hlds = ((size_t)Cp * H + Cp) * sizeof(float);
-    const int hslot = os_prof_begin(ctx, 2, s);
+    const int hslot = os_prof_begin(ctx, OS_PHASE_GRU_HEAD, s, "gru_head_kernel");
     hipLaunchKernelGGL(gru_head_kernel, dim3((B + 63) / 64), dim3(64), hlds, s, B, H, d.num_classes, top, fcw,
                        fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
     os_prof_end(ctx, hslot, s);
@@ -476,7 +477,8 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     // measured (60,128,4), T = 100: B = 4096 35 -> 48, B = 8192 70 -> 92 TFLOP/s; from two tiles per CU on the plain kernel wins
     bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
     if (ctx->tune_gru_split == 0) split = false;
-    const int slot = os_prof_begin(ctx, 1, s);
+    const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s,
+                                   split ? "gru_layer_split_kernel" : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
     if (split) {
         const int parts = 8 / NCH;
         const size_t lds_s = ((size_t)2 * 32 * (H + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);

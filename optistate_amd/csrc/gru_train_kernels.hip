@@ -479,7 +479,14 @@ void os_train_destroy(os_ctx *ctx)
 
 extern "C" {
 
-int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, void *stream)
+size_t os_gru_train_ws_floats(const os_gru_dims *d, int32_t B, int32_t T)
+{
+    if (!d || B <= 0 || T <= 0) return 0;
+    return (size_t)d->num_layers * 5 * (size_t)T * B * d->hidden_size;      // r, z, n, gh_n, h_t per layer, [T][B][H] each
+}
+
+// ws == nullptr: activations go to context scratch (os_gru_forward_train); otherwise to the caller's workspace
+static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *ws, void *stream)
 {
     OS_CHECK_CTX(ctx);
     if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward_train: call os_gru_load first");
@@ -491,10 +498,14 @@ int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, floa
     const os_gru_dims &d = ctx->gru;
     const int H = d.hidden_size, L = d.num_layers, I = d.input_size;
     const size_t tbh = (size_t)T * B * H;
-    if (os_ensure_scratch(ctx, &ts->act, &ts->act_floats, (size_t)L * 5 * tbh)) return -10;
+    float *act = ws;
+    if (!act) {
+        if (os_ensure_scratch(ctx, &ts->act, &ts->act_floats, (size_t)L * 5 * tbh)) return -10;
+        act = ts->act;
+        ts->B = B; ts->T = T;
+    }
     if (os_ensure_scratch(ctx, &ts->seq, &ts->seq_floats, (size_t)L * tbh)) return -10;
     if (os_ensure_scratch(ctx, &ts->xs, &ts->xs_floats, (size_t)T * I * B)) return -10;
-    ts->B = B; ts->T = T;
     int rc = os_pack_stream(ctx, B, T, I, x, ts->xs, stream);
     if (rc) return rc;
     size_t woff = 0;
@@ -506,7 +517,7 @@ int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, floa
         a.xs = in; a.w = ctx->gru_packed + woff;
         a.seq_out = ts->seq + (size_t)l * tbh;
         a.h_last = nullptr;
-        float *base = ts->act + (size_t)l * 5 * tbh;
+        float *base = act + (size_t)l * 5 * tbh;
         a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
         if (os_gru_launch_layer(ctx, a, s)) return -10;
         in = a.seq_out;
@@ -516,6 +527,18 @@ int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, floa
     const float *top = ts->seq + (size_t)(L - 1) * tbh + (size_t)(T - 1) * H * B;
     const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
     return os_gru_head_launch(ctx, B, top, fcw, out, s);
+}
+
+int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, void *stream)
+{
+    return forward_train_impl(ctx, B, T, x, out, nullptr, stream);
+}
+
+int os_gru_forward_train_ws(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *ws, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ws) return os_fail(ctx, -2, "os_gru_forward_train_ws: null workspace");
+    return forward_train_impl(ctx, B, T, x, out, ws, stream);
 }
 
 int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float *target, float *dout, float *loss,
@@ -528,22 +551,21 @@ int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float 
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     OS_HIP(ctx, hipMemsetAsync(loss, 0, sizeof(float), s));
+    const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "loss_kernel");
     hipLaunchKernelGGL(loss_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, B, C, out, y, target, dout, loss);
+    os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }
 
-int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const float *out, const float *dout,
-                    float *grad_flat, float *dx_out, void *stream)
+static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat, const float *act, int32_t B, int32_t T,
+                         const float *x, const float *out, const float *dout, float *grad_flat, float *dx_out, void *stream)
 {
-    OS_CHECK_CTX(ctx);
-    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_backward: call os_gru_load first");
-    os_train_state *ts = (os_train_state *)ctx->train;
-    if (!ts || ts->B != B || ts->T != T) return os_fail(ctx, -5, "os_gru_backward: call os_gru_forward_train first (same B, T)");
-    if (!x || !out || !dout || !grad_flat) return os_fail(ctx, -2, "os_gru_backward: bad argument");
+    os_train_state *ts = train_state(ctx);
+    if (!ts) return os_fail(ctx, -13, "os_gru_backward: cannot create training state");
+    if (!x || !out || !dout || !grad_flat || !act || !w_flat) return os_fail(ctx, -2, "os_gru_backward: bad argument");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    const os_gru_dims &d = ctx->gru;
     const int H = d.hidden_size, L = d.num_layers, I = d.input_size, C = d.num_classes, H3 = 3 * H;
     const size_t tbh = (size_t)T * B * H, nparam = os_gru_param_count(&d);
     const int Kmax = I > H ? I : H;
@@ -561,13 +583,15 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
 
     // ---- head ----
     const size_t fc_off = nparam - ((size_t)C * H + C);
-    const float *fcw = ctx->gru_flat + fc_off;
+    const float *fcw = w_flat + fc_off;
     float *dhT = ts->dxy + 2 * (size_t)T * B * Kmax;
-    const float *hT = ts->act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
+    const float *hT = act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
     {
         const size_t lds = (size_t)(64 * C + 64 * (H + 1)) * sizeof(float);
+        const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "head_backward_kernel");
         hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(256), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
                            fcw, dhT, grad_flat + fc_off, grad_flat + fc_off + (size_t)C * H);
+        os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
     }
     // ---- layers, top to bottom ----
@@ -586,11 +610,15 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
     const float *dy = nullptr;
     for (int l = L - 1; l >= 0; l--) {
         const int K = l == 0 ? I : H;
-        const float *Wih = ctx->gru_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
+        const float *Wih = w_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
         float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
-        hipLaunchKernelGGL(pack_T_kernel, dim3((K + 31) / 32, 16), dim3(256), 0, s, K, H3, Wih, wihT);
-        hipLaunchKernelGGL(pack_T_kernel, dim3(H / 32, 16), dim3(256), 0, s, H, H3, Whh, whhT);
-        const float *base = ts->act + (size_t)l * 5 * tbh;
+        {
+            const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "pack_T_kernel");
+            hipLaunchKernelGGL(pack_T_kernel, dim3((K + 31) / 32, 16), dim3(256), 0, s, K, H3, Wih, wihT);
+            hipLaunchKernelGGL(pack_T_kernel, dim3(H / 32, 16), dim3(256), 0, s, H, H3, Whh, whhT);
+            os_prof_end(ctx, slot, s);
+        }
+        const float *base = act + (size_t)l * 5 * tbh;
         SweepArgs a;
         a.B = B; a.T = T; a.K = K; a.H = H;
         a.need_dx = (l > 0 || dx_out) ? 1 : 0;
@@ -610,9 +638,14 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
         dim3 grid((B + BM - 1) / BM);
         int nw = (RB == 1 && ((a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8 || (!a.need_dx && H / 32 >= 4))) ? 8 : 4;   // enough work items for eight waves
         if (ctx->tune_sweep_nw) nw = ctx->tune_sweep_nw == 8 && RB == 1 ? 8 : 4;
-        if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
-        else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((bwd_sweep_kernel<1, 4>), grid, dim3(256), lds, s, a);
+        {
+            const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_SWEEP, s,
+                                           RB == 2 ? "bwd_sweep_kernel<2,4>" : (nw == 8 ? "bwd_sweep_kernel<1,8>" : "bwd_sweep_kernel<1,4>"));
+            if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
+            else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((bwd_sweep_kernel<1, 4>), grid, dim3(256), lds, s, a);
+            os_prof_end(ctx, slot, s);
+        }
         OS_HIP(ctx, hipGetLastError());
         // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
@@ -622,7 +655,8 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
             d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.rows_per_slice = rps;
             d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
-            else { d1.X = ts->act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
+            else { d1.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
+            const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, s, "dw_kernel");
             if ((K & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
             else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
             // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
@@ -633,11 +667,14 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
                 if ((H & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
                 else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
             }
+            os_prof_end(ctx, dslot, s);
             // b_hh: dgh differs from dgi only in the n gate (da_n * r instead of da_n), so the r and z thirds of the two bias
             // gradients are the same sums: copy them from b_ih (complete after the dW_ih launch) and reduce the n third only
             OS_HIP(ctx, hipMemcpyAsync(gbhh, gbih, (size_t)2 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
             dim3 cg((H + 63) / 64, (unsigned)((rows + 255) / 256));
+            const int cslot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "colsum_kernel");
             hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, 2 * H, dgh, gbhh);
+            os_prof_end(ctx, cslot, s);
             OS_HIP(ctx, hipGetLastError());
         }
         dy = a.dx;
@@ -651,6 +688,26 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
     return 0;
 }
 
+int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const float *out, const float *dout,
+                    float *grad_flat, float *dx_out, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_backward: call os_gru_load first");
+    os_train_state *ts = (os_train_state *)ctx->train;
+    if (!ts || !ts->act || ts->B != B || ts->T != T) return os_fail(ctx, -5, "os_gru_backward: call os_gru_forward_train first (same B, T)");
+    return backward_impl(ctx, ctx->gru, ctx->gru_flat, ts->act, B, T, x, out, dout, grad_flat, dx_out, stream);
+}
+
+int os_gru_backward_ws(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, int32_t B, int32_t T, const float *x,
+                       const float *out, const float *dout, const float *ws, float *grad_flat, float *dx, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!d || B <= 0 || T <= 0) return os_fail(ctx, -2, "os_gru_backward_ws: bad argument");
+    const int H = d->hidden_size;
+    if (H != 32 && H != 64 && H != 128) return os_fail(ctx, -4, "os_gru_backward_ws: hidden_size must be 32, 64 or 128");
+    return backward_impl(ctx, *d, w_flat, ws, B, T, x, out, dout, grad_flat, dx, stream);
+}
+
 int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, float *v, float lr, float beta1, float beta2,
                  float eps, int32_t step, void *stream)
 {
@@ -658,8 +715,10 @@ int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, floa
     if (!n || !w || !g || !m || !v || step < 1) return os_fail(ctx, -2, "os_adam_step: bad argument");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, (hipStream_t)stream, "adam_kernel");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, w, g, m, v, lr,
                        beta1, beta2, eps, bc1, bc2);
+    os_prof_end(ctx, slot, (hipStream_t)stream);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -17,6 +17,8 @@ struct KfRunArgs {
     const float *minmax;     // [2][60]: mins, maxs
     float *feat_out;
     int feat_I;
+    // per-trajectory diagonal noise (os_kf_run_noise): q_diag [12][B], r_diag [10][B]; null = the context-wide Q / R in k
+    const float *q_diag = nullptr, *r_diag = nullptr;
     KfConst k;
 };
 

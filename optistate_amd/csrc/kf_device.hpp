@@ -245,42 +245,43 @@ __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p,
 
 // P <- F_d P F_d^T + Q with F_d = I + dt F, F[0:3,6:9] = R^T, F[3:6,9:12] = I
 // (kalman_filter/kalman_filter.py:124-128,135).  ~300 FMA instead of two dense 12^3 products.
-template <bool QDIAG>
-__device__ __forceinline__ void cov_predict(float *P, const Rot &r, const KfConst &k)
+template <bool QDIAG, typename PT = float>
+__device__ __forceinline__ void cov_predict(PT *P, const Rot &r, const KfConst &k)
 {
-    float g[9];   // g[i][kk] = dt * R^T[i][kk] = dt * R[kk][i]
+    PT g[9];   // g[i][kk] = dt * R^T[i][kk] = dt * R[kk][i]
+    const PT dt = (PT)k.dt;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * r.m[3 * kk + i];
+        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = dt * (PT)r.m[3 * kk + i];
     // rows: M = F_d P
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        float a6 = P[6 * NS + j], a7 = P[7 * NS + j], a8 = P[8 * NS + j];
+        PT a6 = P[6 * NS + j], a7 = P[7 * NS + j], a8 = P[8 * NS + j];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             P[i * NS + j] += g[3 * i] * a6 + g[3 * i + 1] * a7 + g[3 * i + 2] * a8;
-            P[(3 + i) * NS + j] += k.dt * P[(9 + i) * NS + j];
+            P[(3 + i) * NS + j] += dt * P[(9 + i) * NS + j];
         }
     }
     // columns: M F_d^T
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        float a6 = P[i * NS + 6], a7 = P[i * NS + 7], a8 = P[i * NS + 8];
+        PT a6 = P[i * NS + 6], a7 = P[i * NS + 7], a8 = P[i * NS + 8];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             P[i * NS + j] += g[3 * j] * a6 + g[3 * j + 1] * a7 + g[3 * j + 2] * a8;
-            P[i * NS + 3 + j] += k.dt * P[i * NS + 9 + j];
+            P[i * NS + 3 + j] += dt * P[i * NS + 9 + j];
         }
     }
     if (QDIAG) {
         // every Q the reference uses is diagonal (settings.py:28, np.diag at Kalman_to_Training.py:87): 12 scalars
         // instead of 144 keeps the noise terms in SGPRs without spilling
 #pragma unroll
-        for (int i = 0; i < NS; i++) P[i * NS + i] += k.Q[i * NS + i];
+        for (int i = 0; i < NS; i++) P[i * NS + i] += (PT)k.Q[i * NS + i];
     } else {
 #pragma unroll
-        for (int i = 0; i < NS * NS; i++) P[i] += k.Q[i];
+        for (int i = 0; i < NS * NS; i++) P[i] += (PT)k.Q[i];
     }
 }
 
@@ -335,7 +336,7 @@ __device__ __forceinline__ void cov_predict_dense(PT *P, const Rot &rb, const Kf
 // S^-1 is applied through the Cholesky factor S = L L^T (S is symmetric positive definite; unpivoted and
 // branch-free, which suits 64 lanes in lock-step).  Returns status bits.
 template <bool WANT_K, typename PT = float>
-__device__ __forceinline__ int update_batch(float *x, PT *P, const float *z, const KfConst &k, float *Kout,
+__device__ __forceinline__ int update_batch(float *x, PT *P, const float *z, const KfConst &k, PT *Kout,
                                             float *kgain)
 {
     int status = 0;
@@ -419,7 +420,7 @@ __device__ __forceinline__ int update_batch(float *x, PT *P, const float *z, con
     if (WANT_K) {
         if (Kout) {
 #pragma unroll
-            for (int i = 0; i < NS * NM; i++) Kout[i] = (float)K[i];
+            for (int i = 0; i < NS * NM; i++) Kout[i] = K[i];
         }
         PT t = 0;   // np.trace of the 12x10 K sums its 10 main-diagonal entries (kalman_filter.py:174)
 #pragma unroll

@@ -103,27 +103,43 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 }
 
 // Fast path: symmetric P storage (78 VGPRs), sequential update, predict(p,f) covariance.  OUT: 0 plain, 1 P_trace, 2 features.
-template <int OUT, bool QDIAG>
-__global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
+// status bit 3: the caller's P0 is not symmetric (checked once per launch against the lower triangle, 66 extra loads per
+// trajectory): the symmetric-storage kernels would silently run a different filter than the reference, which never
+// symmetrises P (kalman_filter/kalman_filter.py:172)
+template <typename LoadF>
+__device__ __forceinline__ int p0_asymmetry_status(LoadF ld)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.B) return;
+    float worst = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = i + 1; j < NS; j++) {
+            const float up = ld(i * NS + j), lo = ld(j * NS + i);
+            worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
+        }
+    return worst > 0.f ? 8 : 0;
+}
+
+template <int OUT, bool QDIAG>
+__device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfConst &kc, const int b)
+{
     const size_t B = (size_t)a.B;
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
     float x[NS];
     f2 U[NU];
+    int status = 0;
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
 #pragma unroll
         for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
-    int status = 0;
     StepIn in;
     load_step(a, 0, voff, rowB, in);
     for (int t = 0; t < a.T; t++) {
         float z[NM], pw[12];
-        kf_step_front_sym<QDIAG>(x, U, in, a.k, z, pw);
+        kf_step_front_sym<QDIAG>(x, U, in, kc, z, pw);
         rsrc_t rfeat;
         if (OUT == 2) {
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
         }
         const int tn = (t + 1 < a.T) ? t + 1 : t;
         load_step(a, tn, voff, rowB, in);           // prefetch underneath the update
-        status |= kf_step_back_sym(x, U, z, a.k);
+        status |= kf_step_back_sym(x, U, z, kc);
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
@@ -168,6 +184,31 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
             for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
     }
     a.status[b] = status;
+}
+
+template <int OUT, bool QDIAG>
+__global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    kf_run_sym_body<OUT, QDIAG>(a, a.k, b);
+}
+
+// Per-trajectory diagonal noise (os_kf_run_noise): each lane overwrites the diagonals of its own copy of the constants
+// with its trajectory's q_diag / r_diag (22 more VGPRs; every index is a compile-time constant, so the copy is registers).
+template <int OUT>
+__global__ __launch_bounds__(64, 1) void kf_run_sym_noise_kernel(const KfRunArgs a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    KfConst kc = a.k;
+    rsrc_t rq = make_rsrc(a.q_diag, 12 * rowB), rr = make_rsrc(a.r_diag, 10 * rowB);
+#pragma unroll
+    for (int i = 0; i < NS; i++) kc.Q[i * NS + i] = buf_load(rq, voff, i * rowB);
+#pragma unroll
+    for (int i = 0; i < NM; i++) kc.R[i * NM + i] = buf_load(rr, voff, i * rowB);
+    kf_run_sym_body<OUT, true>(a, kc, b);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -346,13 +387,14 @@ __global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uin
     for (int i = 0; i < NM; i++) z[(size_t)i * B + b] = zz[i];
 }
 
-template <bool DENSE>
+template <bool DENSE, typename PT>
 __global__ __launch_bounds__(64, 1) void kf_predict_kernel(int B, float *p, const float *f, const float *body_ref,
-                                                           float *x, float *P, float *ptrace_out, const KfConst k)
+                                                           float *x, PT *P, float *ptrace_out, const KfConst k)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    float xx[NS], PP[NS * NS], pp[12], ff[12], pw[12];
+    float xx[NS], pp[12], ff[12], pw[12];
+    PT PP[NS * NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) xx[i] = x[(size_t)i * B + b];
 #pragma unroll
@@ -364,7 +406,7 @@ __global__ __launch_bounds__(64, 1) void kf_predict_kernel(int B, float *p, cons
         Rot rb = rotation(body_ref[b], body_ref[(size_t)B + b], body_ref[(size_t)2 * B + b]);
         cov_predict_dense(PP, rb, k);
     } else {
-        cov_predict<false>(PP, r, k);
+        cov_predict<false, PT>(PP, r, k);
     }
     dynamics(xx, r, pp, ff, pw, k);
 #pragma unroll
@@ -376,14 +418,15 @@ __global__ __launch_bounds__(64, 1) void kf_predict_kernel(int B, float *p, cons
     if (ptrace_out) ptrace_out[b] = trace12(PP);
 }
 
-template <bool SEQ>
-__global__ __launch_bounds__(64, 1) void kf_update_kernel(int B, const float *z, float *x, float *P, float *K_out,
+template <bool SEQ, typename PT>
+__global__ __launch_bounds__(64, 1) void kf_update_kernel(int B, const float *z, float *x, PT *P, PT *K_out,
                                                           float *ptrace_out, float *kgain_out, int32_t *status,
                                                           const KfConst k)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    float xx[NS], PP[NS * NS], zz[NM];
+    float xx[NS], zz[NM];
+    PT PP[NS * NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) xx[i] = x[(size_t)i * B + b];
 #pragma unroll
@@ -395,8 +438,8 @@ __global__ __launch_bounds__(64, 1) void kf_update_kernel(int B, const float *z,
     if (SEQ) {
         st = update_sequential(xx, PP, zz, k);
     } else {
-        float K[NS * NM];
-        st = update_batch<true>(xx, PP, zz, k, K, &kg);
+        PT K[NS * NM];
+        st = update_batch<true, PT>(xx, PP, zz, k, K, &kg);
         if (K_out) {
 #pragma unroll
             for (int i = 0; i < NS * NM; i++) K_out[(size_t)i * B + b] = K[i];
@@ -453,18 +496,33 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool aux = a.ptrace_out || a.kgain_out, feat = a.feat_out != nullptr;
     if (feat && aux) return os_fail(ctx, -3, "os_kf_run: feature emission and P_trace/K_gain outputs are exclusive");
     hipError_t e;
-    const int slot = os_prof_begin(ctx, 0, s);
+    const bool noise = a.q_diag != nullptr;
+    if (noise && (!seq || dense || a.kgain_out || !a.r_diag))
+        return os_fail(ctx, -3, "os_kf_run_noise: per-trajectory noise needs the sequential update, predict(p,f) covariance, no K_gain");
+    const bool use_rows = !noise && seq && !dense && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
+                          a.B < ctx->rows_kernel_below && ctx->kf_qr;
+    const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise) && !a.kgain_out;
+    const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? "kf_run_rows_kernel" : use_sym ? "kf_run_sym_kernel"
+                        : dense ? (seq ? "kf_run_kernel<SEQ,DENSE_F64>" : "kf_run_kernel<BATCH,DENSE_F64>")
+                                : (seq ? "kf_run_kernel<SEQ>" : "kf_run_kernel<BATCH>");
+    const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, kname);
 #define OS_DISPATCH(SEQ, DENSE)                                                        \
     (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
           : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
-    if (seq && !dense && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) && a.B < ctx->rows_kernel_below && ctx->kf_qr) {
+    if (noise) {
+        dim3 grid((a.B + 63) / 64), block(64);
+        if (feat) hipLaunchKernelGGL((kf_run_sym_noise_kernel<2>), grid, block, 0, s, a);
+        else if (aux) hipLaunchKernelGGL((kf_run_sym_noise_kernel<1>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((kf_run_sym_noise_kernel<0>), grid, block, 0, s, a);
+        e = hipGetLastError();
+    } else if (use_rows) {
         // small batch: 16 lanes per trajectory so that every SIMD gets a wave
         dim3 grid((a.B + 15) / 16), block(256);                       // 4 waves x 4 trajectories per workgroup
         if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
         else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
         else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
         e = hipGetLastError();
-    } else if (seq && !dense && (flags & OS_KF_SYMMETRIC_P) && !a.kgain_out) {
+    } else if (use_sym) {
         dim3 grid((a.B + 63) / 64), block(64);
         const bool qd = ctx->q_is_diagonal;
 #define OS_SYM(OUT)                                                                                        \
@@ -505,6 +563,29 @@ int os_kf_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f,
     return os_kf_run_impl(ctx, a, flags, (hipStream_t)stream);
 }
 
+int os_kf_run_noise(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f, const float *dp, const float *imu,
+                    const uint32_t *contact, float *x, float *P, const float *q_diag, const float *r_diag, float *x_out,
+                    float *p_rot_out, float *ptrace_out, int32_t *status, uint32_t flags, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0) return os_fail(ctx, -2, "os_kf_run_noise: B and T must be positive");
+    if (!p || !f || !dp || !imu || !contact || !x || !P || !x_out || !status || !q_diag || !r_diag)
+        return os_fail(ctx, -2, "os_kf_run_noise: null required pointer");
+    if (flags & OS_KF_DENSE_FD) return os_fail(ctx, -3, "os_kf_run_noise: the predict_mpc covariance is not supported here");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    KfRunArgs a;
+    a.B = B; a.T = T; a.p = p; a.f = f; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = nullptr;
+    a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = p_rot_out; a.ptrace_out = ptrace_out; a.kgain_out = nullptr;
+    a.status = status; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
+    a.q_diag = q_diag; a.r_diag = r_diag;
+    // R is diagonal by construction here whatever the context-wide R is
+    const bool saved = ctx->r_is_diagonal;
+    ctx->r_is_diagonal = true;
+    const int rc = os_kf_run_impl(ctx, a, (flags | OS_KF_SEQUENTIAL_UPDATE | OS_KF_SYMMETRIC_P | OS_KF_LANE_PER_TRAJECTORY), (hipStream_t)stream);
+    ctx->r_is_diagonal = saved;
+    return rc;
+}
+
 int os_kf_odom(os_ctx *ctx, int32_t B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
                float *z, void *stream)
 {
@@ -525,8 +606,13 @@ int os_kf_predict(os_ctx *ctx, int32_t B, float *p, const float *f, const float 
     if (dense && !body_ref) return os_fail(ctx, -2, "os_kf_predict: OS_KF_DENSE_FD needs body_ref");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid((B + 63) / 64), block(64);
-    if (dense) hipLaunchKernelGGL(kf_predict_kernel<true>, grid, block, 0, (hipStream_t)stream, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
-    else hipLaunchKernelGGL(kf_predict_kernel<false>, grid, block, 0, (hipStream_t)stream, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
+    hipStream_t s = (hipStream_t)stream;
+    if (flags & OS_KF_P_FLOAT64) {
+        double *P64 = reinterpret_cast<double *>(P);
+        if (dense) hipLaunchKernelGGL((kf_predict_kernel<true, double>), grid, block, 0, s, B, p, f, body_ref, x, P64, ptrace_out, ctx->k);
+        else hipLaunchKernelGGL((kf_predict_kernel<false, double>), grid, block, 0, s, B, p, f, body_ref, x, P64, ptrace_out, ctx->k);
+    } else if (dense) hipLaunchKernelGGL((kf_predict_kernel<true, float>), grid, block, 0, s, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
+    else hipLaunchKernelGGL((kf_predict_kernel<false, float>), grid, block, 0, s, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -541,8 +627,13 @@ int os_kf_update(os_ctx *ctx, int32_t B, const float *z, float *x, float *P, flo
     if (seq && (K_out || kgain_out)) return os_fail(ctx, -3, "os_kf_update: K is only formed by the batch update");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid((B + 63) / 64), block(64);
-    if (seq) hipLaunchKernelGGL(kf_update_kernel<true>, grid, block, 0, (hipStream_t)stream, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
-    else hipLaunchKernelGGL(kf_update_kernel<false>, grid, block, 0, (hipStream_t)stream, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
+    hipStream_t s = (hipStream_t)stream;
+    if (flags & OS_KF_P_FLOAT64) {
+        double *P64 = reinterpret_cast<double *>(P), *K64 = reinterpret_cast<double *>(K_out);
+        if (seq) hipLaunchKernelGGL((kf_update_kernel<true, double>), grid, block, 0, s, B, z, x, P64, K64, ptrace_out, kgain_out, status, ctx->k);
+        else hipLaunchKernelGGL((kf_update_kernel<false, double>), grid, block, 0, s, B, z, x, P64, K64, ptrace_out, kgain_out, status, ctx->k);
+    } else if (seq) hipLaunchKernelGGL((kf_update_kernel<true, float>), grid, block, 0, s, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
+    else hipLaunchKernelGGL((kf_update_kernel<false, float>), grid, block, 0, s, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -48,6 +48,8 @@ struct os_ctx {
     int prof_phase[512];
     double prof_ms[OS_PROF_PHASES];
     int prof_cnt[OS_PROF_PHASES];
+    const char *prof_name[OS_PROF_PHASES];   // kernel variant most recently launched in each phase (static strings)
+    uint64_t gru_generation;                 // bumped by every os_gru_load (os_gru_generation)
 };
 
 // adds the elapsed times of the recorded event pairs to the per-phase sums (synchronises on them) and empties the ring
@@ -65,8 +67,9 @@ static inline void os_prof_drain(os_ctx *ctx)
 }
 
 // RAII-less helpers: bracket a kernel launch with events when profiling is on
-static inline int os_prof_begin(os_ctx *ctx, int phase, hipStream_t s)
+static inline int os_prof_begin(os_ctx *ctx, int phase, hipStream_t s, const char *kernel_name = nullptr)
 {
+    if (kernel_name) ctx->prof_name[phase] = kernel_name;
     if (!ctx->prof) return -1;
     if (ctx->prof_n >= 512) os_prof_drain(ctx);      // ring full (per-step launch loops): fold it into the sums
     const int i = ctx->prof_n;

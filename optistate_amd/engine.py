@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
-                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL)
+                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -39,7 +39,9 @@ class Engine:
         self._h = h
         self._gru_dims = None
         self._gru_flat = None      # keeps the flat weight tensor alive (the library references it for the head)
+        self._gru_owner = None     # who loaded the resident GRU weights (a context holds ONE model: see load_gru)
         self._diag_R = True
+        self._sym_Q = True
 
     def close(self):
         if getattr(self, "_h", None):
@@ -69,11 +71,16 @@ class Engine:
         self._check(self.lib.os_profile_enable(self._h, 1 if enable else 0), "os_profile_enable")
 
     def profile_read(self):
-        """Returns {phase: (ms_sum, launches)} for phases kf, gru_layer, gru_head, fused, mpc since the last read."""
+        """Returns {phase: (ms_sum, launches)} since the last read; phases as _capi.PHASE_NAMES (header enum OS_PHASE_*)."""
         ms = (C.c_double * _capi.OS_PROF_PHASES)()
         n = (C.c_int32 * _capi.OS_PROF_PHASES)()
         self._check(self.lib.os_profile_read(self._h, ms, n), "os_profile_read")
-        return {k: (ms[i], n[i]) for i, k in enumerate(("kf", "gru_layer", "gru_head", "fused", "mpc"))}
+        return {k: (ms[i], n[i]) for i, k in enumerate(_capi.PHASE_NAMES)}
+
+    def kernel_name(self, phase):
+        """The kernel variant most recently launched in `phase` (name from _capi.PHASE_NAMES or index)."""
+        i = _capi.PHASE_NAMES.index(phase) if isinstance(phase, str) else int(phase)
+        return self.lib.os_profile_kernel_name(self._h, i).decode()
 
     # ---- Kalman filter ----
     def set_noise(self, Q, R):
@@ -81,6 +88,9 @@ class Engine:
         Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(144)
         R = np.ascontiguousarray(R, dtype=np.float32).reshape(100)
         self._diag_R = bool(np.count_nonzero(R.reshape(10, 10) - np.diag(np.diag(R.reshape(10, 10)))) == 0)
+        # the symmetric-storage kernels replace Q by 0.5 (Q + Q^T) and read the upper triangle of P0; the reference never
+        # symmetrises anything (kalman_filter.py:135,172), so a non-symmetric Q takes the full-P kernels by default
+        self._sym_Q = bool(np.array_equal(Q.reshape(12, 12), Q.reshape(12, 12).T))
         self._check(self.lib.os_kf_set_noise(self._h, Q.ctypes.data_as(C.POINTER(C.c_float)),
                                              R.ctypes.data_as(C.POINTER(C.c_float))), "os_kf_set_noise")
 
@@ -114,12 +124,16 @@ class Engine:
     def kf_run(self, p, f, dp, imu, contact, x, P, body_ref=None, sequential=None, dense_fd=False,
                want_p_rot=False, want_trace=False, want_gain=False, symmetric=None, lane_per_trajectory=False):
         """Runs T filter steps for B trajectories.  All stream arguments are SoA device tensors; x [12][B] and
-        P [144][B] are updated in place.  Returns dict(x_out [T][12][B], status [B], p_rot?, P_trace?, K_gain?)."""
+        P [144][B] are updated in place.  Returns dict(x_out [T][12][B], status [B], p_rot?, P_trace?, K_gain?).
+        symmetric=None picks the symmetric-storage kernels (upper triangle of P in registers) when R is diagonal and Q is
+        symmetric.  They read only the upper triangle of the caller's P0 and write the final P back mirrored: a P0 that is
+        not symmetric sets status bit 3 (value 8) for that trajectory -- re-run it with symmetric=False, which keeps the
+        full P like the reference (kalman_filter.py:172 never symmetrises)."""
         T, _, B = p.shape
         if sequential is None:
             sequential = self._diag_R and not want_gain
         if symmetric is None:
-            symmetric = sequential and not dense_fd
+            symmetric = sequential and not dense_fd and self._sym_Q
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
                 (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_KF_LANE_PER_TRAJECTORY if lane_per_trajectory else 0)
         dev = self.device
@@ -133,16 +147,42 @@ class Engine:
                                        _ptr(status), flags, self._stream()), "os_kf_run")
         return dict(x_out=x_out, status=status, p_rot=p_rot, P_trace=ptr, K_gain=kg)
 
+    def kf_run_noise(self, p, f, dp, imu, contact, x, P, q_diag, r_diag, want_p_rot=False, want_trace=False):
+        """kf_run with per-trajectory diagonal noise: q_diag [12][B], r_diag [10][B] device tensors (each reference filter
+        instance carries its own Q and R: data_conversion_Kalman_to_Training.py:138-144)."""
+        T, _, B = p.shape
+        dev = self.device
+        q = q_diag.to(dev, dtype=torch.float32).contiguous(); r = r_diag.to(dev, dtype=torch.float32).contiguous()
+        if q.shape != (12, B) or r.shape != (10, B):
+            raise ValueError("q_diag must be [12][B] and r_diag [10][B]")
+        x_out = torch.empty((T, 12, B), dtype=torch.float32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        p_rot = torch.empty((T, 12, B), dtype=torch.float32, device=dev) if want_p_rot else None
+        ptr = torch.empty((T, B), dtype=torch.float32, device=dev) if want_trace else None
+        self._check(self.lib.os_kf_run_noise(self._h, B, T, _ptr(p), _ptr(f), _ptr(dp), _ptr(imu), _ptr(contact), _ptr(x), _ptr(P),
+                                             _ptr(q), _ptr(r), _ptr(x_out), _ptr(p_rot), _ptr(ptr), _ptr(status), 0,
+                                             self._stream()), "os_kf_run_noise")
+        return dict(x_out=x_out, status=status, p_rot=p_rot, P_trace=ptr)
+
     # ---- GRU ----
-    def load_gru(self, flat, input_size, hidden_size, num_layers, num_classes, use_sigmoid=True):
-        """flat: 1-D float32 device tensor in the flat layout of the header (see flatten_state_dict)."""
+    def load_gru(self, flat, input_size, hidden_size, num_layers, num_classes, use_sigmoid=True, owner=None):
+        """flat: 1-D float32 device tensor in the flat layout of the header (see flatten_state_dict).
+        A context holds ONE loaded model; `owner` records who loaded it so that several weight containers sharing this
+        engine (two RNN modules on one GPU, a trainer and its model) can tell whether their weights are the resident ones."""
         d = _capi.OsGruDims(input_size, hidden_size, num_layers, num_classes, 1 if use_sigmoid else 0)
         n = self.lib.os_gru_param_count(C.byref(d))
         flat = flat.to(self.device, dtype=torch.float32).contiguous()
         if flat.numel() != n:
             raise ValueError(f"flat weight vector has {flat.numel()} floats, expected {n}")
         self._check(self.lib.os_gru_load(self._h, C.byref(d), _ptr(flat), self._stream()), "os_gru_load")
-        self._gru_flat, self._gru_dims = flat, d
+        self._gru_flat, self._gru_dims, self._gru_owner = flat, d, owner
+
+    def gru_generation(self):
+        return int(self.lib.os_gru_generation(self._h))
+
+    def invalidate_gru(self):
+        """The flat weights were modified in place (optimiser step): whoever runs next must load again."""
+        self._gru_owner = None
 
     def gru_forward(self, x_bti, want_h_last=False):
         """RNN.forward on x (B, T, I) -> (B, C)  (gru/gru_model.py:25-49)."""
@@ -177,6 +217,33 @@ class Engine:
         self._check(self.lib.os_gru_forward_train(self._h, B, T, _ptr(x), _ptr(out), self._stream()), "os_gru_forward_train")
         return out
 
+    def gru_forward_train_ws(self, x_bti):
+        """Training forward with the saved activations in a workspace of its own (returned): any number of forwards may be
+        outstanding before their backwards run.  Returns (out, ws, flat, dims): everything gru_backward_ws needs."""
+        x = x_bti.to(self.device, dtype=torch.float32).contiguous()
+        B, T, I = x.shape
+        d = self._gru_dims
+        if d is None or I != d.input_size:
+            raise ValueError("load_gru first / input width mismatch")
+        n = self.lib.os_gru_train_ws_floats(C.byref(d), B, T)
+        ws = torch.empty((n,), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_gru_forward_train_ws(self._h, B, T, _ptr(x), _ptr(out), _ptr(ws), self._stream()),
+                    "os_gru_forward_train_ws")
+        return out, ws, self._gru_flat, _capi.OsGruDims(d.input_size, d.hidden_size, d.num_layers, d.num_classes, d.use_sigmoid)
+
+    def gru_backward_ws(self, dims, flat, ws, x_bti, out, dout, grad_flat=None, want_dx=False):
+        x = x_bti.to(self.device, dtype=torch.float32).contiguous()
+        B, T, I = x.shape
+        n = self.lib.os_gru_param_count(C.byref(dims))
+        if grad_flat is None:
+            grad_flat = torch.empty((n,), dtype=torch.float32, device=self.device)
+        dx = torch.empty_like(x) if want_dx else None
+        dout = dout.to(self.device, dtype=torch.float32).contiguous()
+        self._check(self.lib.os_gru_backward_ws(self._h, C.byref(dims), _ptr(flat), B, T, _ptr(x), _ptr(out), _ptr(dout), _ptr(ws),
+                                                _ptr(grad_flat), _ptr(dx), self._stream()), "os_gru_backward_ws")
+        return (grad_flat, dx) if want_dx else grad_flat
+
     def gru_loss(self, out, y, want_target=False):
         """target = [y | |out[:, :C/2] - y|] (detached), MSE; returns (loss (1,) device tensor, dout, target|None)."""
         B, Cc = out.shape
@@ -206,7 +273,7 @@ class Engine:
 
     # ---- fused ----
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
-                  dense_fd=False, symmetric=None, two_kernel=None):
+                  dense_fd=False, symmetric=None, two_kernel=None, split_bf16=False):
         """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B]).
         two_kernel: None = the library picks (single fused kernel from half a chip of trajectories up), True / False force
         the two-kernel / the single-kernel path (the latter only where the shapes allow it)."""
@@ -214,10 +281,10 @@ class Engine:
         if sequential is None:
             sequential = self._diag_R
         if symmetric is None:
-            symmetric = sequential and not dense_fd
+            symmetric = sequential and not dense_fd and self._sym_Q
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
                 (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_FUSED_TWO_KERNEL if two_kernel else 0) | \
-                (OS_FUSED_ONE_KERNEL if two_kernel is False else 0)
+                (OS_FUSED_ONE_KERNEL if two_kernel is False else 0) | (OS_FUSED_SPLIT_BF16 if split_bf16 else 0)
         d = self._gru_dims
         nl = 0 if latent is None else latent.shape[1]
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)

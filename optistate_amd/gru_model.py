@@ -29,11 +29,14 @@ class RNN(nn.Module):
         if self._engine is None or self._engine.device != dev:
             self._engine = default_engine(dev.index or 0)
             self._loaded_versions = None
+        # reload when this module's parameters changed OR somebody else loaded the (per-device, shared) engine since:
+        # a context holds ONE model, so two RNN instances on one GPU, or a trainer updating the flat bucket in place,
+        # must not leave this module running on foreign / stale packed weights
         versions = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if versions != self._loaded_versions:
+        if versions != self._loaded_versions or self._engine._gru_owner is not self:
             flat = flatten_state_dict(self.state_dict(), self.num_layers, device=dev)
             self._engine.load_gru(flat, self.input_size, self.hidden_size, self.num_layers, self.num_classes,
-                                  self.use_sigmoid)
+                                  self.use_sigmoid, owner=self)
             self._loaded_versions = versions
 
     def forward(self, x):

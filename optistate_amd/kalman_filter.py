@@ -16,7 +16,7 @@ Differences from the reference, all deliberate (SURVEY.md section 5 "race detect
 import numpy as np
 import torch
 
-from .engine import default_engine, _ptr, OS_KF_DENSE_FD
+from .engine import default_engine, _ptr, OS_KF_DENSE_FD, OS_KF_P_FLOAT64
 from . import synth
 
 
@@ -41,6 +41,10 @@ class Kalman_Filter:
         self.dt = 0.01
         self.x_model = self.x.copy()
         self.f = np.zeros((12, 5))
+        # predict_mpc leaves a covariance that float32 cannot carry to the next update within the 1e-4 bar (element-wise
+        # exp(dt F), kalman_filter.py:157): the split predict_mpc() -> update() sequence therefore keeps P in float64 on
+        # the device side too (OS_KF_P_FLOAT64), like the batched kernel does inside one launch
+        self._p64_pending = False
 
     # -- helpers --
     # Every call stages ALL its inputs in one host array -> one host-to-device copy, and reads ALL its outputs back with
@@ -95,21 +99,34 @@ class Kalman_Filter:
         self.z[3] = odom[0]
         self.z[7:10] = odom[1:]
 
+    @staticmethod
+    def _f64_words(a, n):
+        """float64 array carried bit-for-bit inside the float32 staging buffer (2 words per value; staged FIRST so that
+        the device address is 8-byte aligned)."""
+        return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(n)).view(np.float32)
+
     def _predict(self, p, f, body_ref=None):
         e = self._eng
         self._sync_noise()
+        dense = body_ref is not None
         br = np.zeros(12) if body_ref is None else np.asarray(body_ref).reshape(-1)[:12]
-        buf, o = self._stage(np.asarray(p).reshape(-1)[:12], np.asarray(f).reshape(-1)[:12], self.x,
-                             np.asarray(self.P, dtype=np.float64).reshape(144), np.zeros(1), br)
+        Pw = self._f64_words(self.P, 144) if dense else np.asarray(self.P, dtype=np.float64).reshape(144)
+        buf, o = self._stage(Pw, np.asarray(p).reshape(-1)[:12], np.asarray(f).reshape(-1)[:12], self.x, np.zeros(1), br)
         sg = lambda i: _ptr(self._seg(buf, o[i]))
-        e._check(e.lib.os_kf_predict(e._h, 1, sg(0), sg(1), sg(5) if body_ref is not None else None, sg(2), sg(3), sg(4),
-                                     OS_KF_DENSE_FD if body_ref is not None else 0, e._stream()), "os_kf_predict")
-        h = buf.cpu().numpy().astype(np.float64)
-        self.x = h[o[2][0]:o[2][0] + 12].reshape(12, 1)
-        self.P = h[o[3][0]:o[3][0] + 144].reshape(12, 12)
+        flags = (OS_KF_DENSE_FD | OS_KF_P_FLOAT64) if dense else 0
+        e._check(e.lib.os_kf_predict(e._h, 1, sg(1), sg(2), sg(5) if dense else None, sg(3), sg(0), sg(4),
+                                     flags, e._stream()), "os_kf_predict")
+        hb = buf.cpu().numpy()
+        h = hb.astype(np.float64)
+        self.x = h[o[3][0]:o[3][0] + 12].reshape(12, 1)
+        if dense:
+            self.P = hb[o[0][0]:o[0][0] + 288].view(np.float64).reshape(12, 12).copy()
+        else:
+            self.P = h[o[0][0]:o[0][0] + 144].reshape(12, 12)
+        self._p64_pending = dense
         # the reference rotates the caller's p in place (misc/force_controller.py:274-277)
         if isinstance(p, np.ndarray) and p.flags.writeable:
-            p[...] = h[0:12].astype(p.dtype).reshape(p.shape)
+            p[...] = h[o[1][0]:o[1][0] + 12].astype(p.dtype).reshape(p.shape)
         self.x_model = self.x.copy()
         self.P_trace = float(h[o[4][0]])
 
@@ -118,23 +135,34 @@ class Kalman_Filter:
         self._predict(p, f)
 
     def update(self):
-        """kalman_filter.py:164-174."""
+        """kalman_filter.py:164-174.  After predict_mpc the covariance stays in float64 through this call (see __init__)."""
         e = self._eng
         self._sync_noise()
-        buf, o = self._stage(self.z, self.x, np.asarray(self.P, dtype=np.float64).reshape(144), np.zeros(120), np.zeros(1),
-                             np.zeros(1), np.zeros(1))
+        f64 = self._p64_pending
+        self._p64_pending = False
+        if f64:
+            buf, o = self._stage(self._f64_words(self.P, 144), self._f64_words(np.zeros(120), 120), self.z, self.x, np.zeros(1),
+                                 np.zeros(1), np.zeros(1))
+        else:
+            buf, o = self._stage(np.asarray(self.P, dtype=np.float64).reshape(144), np.zeros(120), self.z, self.x, np.zeros(1),
+                                 np.zeros(1), np.zeros(1))
         sg = lambda i: _ptr(self._seg(buf, o[i]))
         st = self._seg(buf, o[6]).view(torch.int32)
-        e._check(e.lib.os_kf_update(e._h, 1, sg(0), sg(1), sg(2), sg(3), sg(4), sg(5), _ptr(st), 0, e._stream()), "os_kf_update")
+        e._check(e.lib.os_kf_update(e._h, 1, sg(2), sg(3), sg(0), sg(1), sg(4), sg(5), _ptr(st), OS_KF_P_FLOAT64 if f64 else 0,
+                                    e._stream()), "os_kf_update")
         hb = buf.cpu().numpy()
         status = int(hb[o[6][0]:o[6][0] + 1].view(np.int32)[0])
         if status & 1:
             # the reference's np.linalg.inv raises here (kalman_filter.py:168)
             raise np.linalg.LinAlgError("Singular matrix")
         h = hb.astype(np.float64)
-        self.x = h[o[1][0]:o[1][0] + 12].reshape(12, 1)
-        self.P = h[o[2][0]:o[2][0] + 144].reshape(12, 12)
-        self.K = h[o[3][0]:o[3][0] + 120].reshape(12, 10)
+        self.x = h[o[3][0]:o[3][0] + 12].reshape(12, 1)
+        if f64:
+            self.P = hb[o[0][0]:o[0][0] + 288].view(np.float64).reshape(12, 12).copy()
+            self.K = hb[o[1][0]:o[1][0] + 240].view(np.float64).reshape(12, 10).copy()
+        else:
+            self.P = h[o[0][0]:o[0][0] + 144].reshape(12, 12)
+            self.K = h[o[1][0]:o[1][0] + 120].reshape(12, 10)
         self.P_trace = float(h[o[4][0]])
         self.K_gain = float(h[o[5][0]])
 

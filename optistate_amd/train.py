@@ -24,22 +24,26 @@ def _flat_order_params(module):
 
 
 class _GruFn(torch.autograd.Function):
+    # Every forward owns its saved activations (a workspace tensor kept in the autograd ctx) and pins the flat weights
+    # and dims it ran with, so any number of graphs may be alive at once: loss(model(a)) + loss(model(b)), gradient
+    # accumulation, a second model or an evaluation forward in between (the engine's own scratch and its loaded
+    # weights are shared per device and would be overwritten).
     @staticmethod
     def forward(ctx, x, module, *params):
         module._sync_weights(x.device)
         eng = module._engine
         xd = x.detach().contiguous()
-        out = eng.gru_forward_train(xd)
-        ctx.module, ctx.x_req = module, x.requires_grad
-        ctx.save_for_backward(xd, out)
+        out, ws, flat, dims = eng.gru_forward_train_ws(xd)
+        ctx.module, ctx.x_req, ctx.dims = module, x.requires_grad, dims
+        ctx.save_for_backward(xd, out, ws, flat)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xd, out = ctx.saved_tensors
+        xd, out, ws, flat = ctx.saved_tensors
         module = ctx.module
         eng = module._engine
-        res = eng.gru_backward(xd, out, dout.contiguous(), want_dx=ctx.x_req)
+        res = eng.gru_backward_ws(ctx.dims, flat, ws, xd, out, dout.contiguous(), want_dx=ctx.x_req)
         flat, dx = res if ctx.x_req else (res, None)
         grads, off = [], 0
         for p in _flat_order_params(module):
@@ -107,11 +111,14 @@ class DataParallelTrainer:
 
     def step(self, x, y):
         m, e = self.model, self.eng
-        e.load_gru(self.bucket.w, m.input_size, m.hidden_size, m.num_layers, m.num_classes, m.use_sigmoid)
+        e.load_gru(self.bucket.w, m.input_size, m.hidden_size, m.num_layers, m.num_classes, m.use_sigmoid, owner=self)
         out = e.gru_forward_train(x)
         loss, dout, _ = e.gru_loss(out, y)
         e.gru_backward(x, out, dout, grad_flat=self.bucket.g)
         self.bucket.allreduce_mean_(self.group)
         self.t += 1
         e.adam_step(self.bucket.w, self.bucket.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        # the fused Adam wrote the flat bucket in place: the packed copy in the engine is stale now, and torch's version
+        # counters did not move -- make the next model(x) (evaluation between steps, gru_train.py:253-261) load again
+        e.invalidate_gru()
         return loss

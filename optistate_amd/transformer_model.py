@@ -100,13 +100,14 @@ class Transformer_Autoencoder(nn.Module):
             raise RuntimeError("optistate_amd Transformer_Autoencoder.forward_encoder needs a tensor on the MI355X (no CPU fallback)")
         eng = default_engine(x.device.index or 0)
         versions = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if self._loaded is None or self._loaded[0] != versions:
+        if self._loaded is None or self._loaded[0] != versions or getattr(eng, "_vit_owner", None) is not self:
             flat = self._flat(x.device)
             d = _capi.OsVitDims(self.img_size, self.patch_size, self.in_chans, self.embed_dim, self.depth, self.num_heads,
                                 self.mlp_hidden)
             assert flat.numel() == eng.lib.os_vit_param_count(C.byref(d)), "flat ViT weight vector has the wrong length"
             eng._check(eng.lib.os_vit_load(eng._h, C.byref(d), _ptr(flat)), "os_vit_load")
             self._loaded = (versions, flat)        # keep the flat tensor alive: the library references it
+            eng._vit_owner = self                  # a context holds ONE encoder: another module's load evicts this one
         N = x.shape[0]
         img = x.reshape(N, self.img_size, self.img_size).to(torch.float32).contiguous()
         lat = torch.empty((N, self.embed_dim), dtype=torch.float32, device=x.device)

@@ -19,3 +19,47 @@ def test_cpu_baseline_object_has_the_contract_keys():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["unit"] == "timesteps/s" and cb["value"] > 0 and cb["single_thread_value"] > 0
     assert cb["cores"] == bench.usable_cores()
+
+
+def test_cpu_baseline_carries_the_reference_python_figure():
+    import bench
+    cb = bench.cpu_baseline(64, 1, 0.3, kf_only=True)
+    assert cb["reference_python_steps_per_s"] == 3.05e3 and "build container" in cb["reference_python_note"]
+    assert "gru_half_torch_cpu" not in cb and "KF float64" in cb["sample"]
+
+
+def test_launch_command_is_the_contract_command():
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"], 29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29512"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+
+
+def test_gpus_2_starts_its_own_ranks_and_reports_the_process_group():
+    """`python bench.py --gpus 2` (not under torchrun) must start the two ranks itself, before any GPU call.  Without a GPU
+    the rendezvous self-test (--launch-check) runs the identical launch path over gloo: two rank processes join, all-reduce,
+    and rank 0 prints ONE JSON line with the world size the process group reports."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["launch_check"] is True and d["rccl_world_size"] == 2 and d["sum_of_ones"] == 2.0
+    assert sorted(x["rank"] for x in d["rank_devices"]) == [0, 1]
+    assert len({x["pid"] for x in d["rank_devices"]}) == 2            # two separate rank processes
+
+
+def test_a_rank_with_the_wrong_world_size_refuses():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -1,0 +1,194 @@
+"""GPU: regression tests for the round-1 advisor findings (shared per-device engine state, split predict_mpc -> update in
+float32, silent symmetric-storage assumptions, kernel names in reports) and for per-trajectory noise."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_out(m, x):
+    from oracle import c_oracle as orc
+    out, _, _ = orc.gru_forward(x.cpu().numpy(), orc.flatten_state_dict(m.state_dict(), m.num_layers), m.input_size,
+                                m.hidden_size, m.num_layers, m.num_classes)
+    return out
+
+
+def test_two_rnn_instances_on_one_gpu_do_not_share_weights():
+    """gru_train.py:205-217 trains num_models networks; two modules on one device share the per-device engine, whose single
+    loaded model must follow whoever calls forward."""
+    from optistate_amd import RNN
+    torch.manual_seed(0)
+    a = RNN(60, 64, 1, 24, torch.device("cuda")).to("cuda")
+    b = RNN(60, 64, 1, 24, torch.device("cuda")).to("cuda")
+    c = RNN(188, 128, 2, 24, torch.device("cuda")).to("cuda")          # different shape on the same engine
+    xa, xc = torch.rand(9, 10, 60).cuda(), torch.rand(5, 10, 188).cuda()
+    with torch.no_grad():
+        for _ in range(2):                                             # interleave: A, B, C, A, B, C
+            oa, ob, oc = a(xa), b(xa), c(xc)
+            assert np.abs(oa.cpu().numpy() - _ref_out(a, xa)).max() < 1e-5
+            assert np.abs(ob.cpu().numpy() - _ref_out(b, xa)).max() < 1e-5
+            assert np.abs(oc.cpu().numpy() - _ref_out(c, xc)).max() < 1e-5
+    assert (oa - ob).abs().max().item() > 1e-3                         # the two models really differ
+
+
+def test_two_forwards_before_backward_and_an_eval_forward_in_between():
+    """loss(model(a)) + loss(model(b)) with a no-grad forward of ANOTHER model in between: every graph keeps its own saved
+    activations and weights (they used to live in one engine-global buffer)."""
+    from optistate_amd import RNN
+    from test_gpu_train import torch_reference_grads
+    dims = (60, 64, 2, 24)
+    torch.manual_seed(4)
+    m = RNN(*dims, torch.device("cuda")).to("cuda")
+    other = RNN(60, 32, 1, 24, torch.device("cuda")).to("cuda")
+    xa, xb = torch.rand(40, 6, 60), torch.rand(23, 6, 60)              # different batch sizes on purpose
+    ya, yb = torch.rand(40, 12), torch.rand(23, 12)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    _, _, la, ga, _ = torch_reference_grads(sd, dims, xa, ya)
+    _, _, lb, gb, _ = torch_reference_grads(sd, dims, xb, yb)
+
+    def loss_of(x, y):
+        out = m(x.cuda())
+        tgt = torch.cat([y.cuda(), (out[:, :12].detach() - y.cuda()).abs()], dim=1)
+        return torch.nn.functional.mse_loss(out, tgt)
+    l1 = loss_of(xa, ya)
+    with torch.no_grad():
+        other(torch.rand(7, 6, 60).cuda())                             # evicts m's weights from the shared engine
+    l2 = loss_of(xb, yb)
+    (l1 + l2).backward()
+    assert abs(l1.item() - la) < 1e-6 and abs(l2.item() - lb) < 1e-6
+    for k, p in m.named_parameters():
+        r = ga[k] + gb[k]
+        scale = max(r.abs().max().item(), 1e-8)
+        assert (p.grad.cpu().double() - r).abs().max().item() < 2e-4 * scale + 1e-9, k
+
+
+def test_trainer_step_then_model_forward_uses_the_updated_weights():
+    """DataParallelTrainer's fused Adam writes the flat bucket in place (no torch version bump): an evaluation forward
+    between steps (gru_train.py:253-261) must run on the post-step weights, GRU and head alike."""
+    from optistate_amd import RNN
+    from optistate_amd.train import DataParallelTrainer
+    torch.manual_seed(1)
+    m = RNN(60, 64, 1, 24, torch.device("cuda")).to("cuda")
+    tr = DataParallelTrainer(m, lr=1e-2)                               # large step so stale weights are obvious
+    x, y = torch.rand(64, 10, 60).cuda(), torch.rand(64, 12).cuda()
+    with torch.no_grad():
+        before = m(x).clone()
+    for _ in range(3):
+        tr.step(x, y)
+    with torch.no_grad():
+        after = m(x)
+    assert np.abs(after.cpu().numpy() - _ref_out(m, x)).max() < 1e-5    # state_dict (views of the bucket) == what ran
+    assert (after - before).abs().max().item() > 1e-3
+
+
+def test_split_predict_mpc_then_update_meets_the_bar_g8():
+    """The sequence estimate_state_mpc is made of, called piecewise on the drop-in class (get_odom, set_measurements,
+    predict_mpc with logged forces, update): the covariance between the two calls stays float64 (OS_KF_P_FLOAT64)."""
+    from optistate_amd import Kalman_Filter
+    g = load_golden("kf_g8_mpc.npz")
+    for b in range(2):
+        kf = Kalman_Filter()
+        kf.x[:] = g["x0"][b].reshape(12, 1)
+        kf.Q = g["Q"].copy(); kf.R = g["R"].copy(); kf.P = g["Q"].copy()
+        for t in range(30):
+            p = g["p"][b, t].astype(np.float64).reshape(12, 1)
+            imu = g["imu"][b, t].reshape(6, 1)
+            odom = kf.get_odom(p, g["dp"][b, t].reshape(12, 1), g["contact"][b, t].reshape(4, 1), imu)
+            kf.set_measurements(imu, odom)
+            kf.predict_mpc(p, g["body_ref"][b, t].reshape(12, 1), g["contact"][b, t].reshape(4, 1), f=g["f"][b, t])
+            assert kf.P.dtype == np.float64 and kf._p64_pending
+            kf.update()
+            assert not kf._p64_pending
+            assert np.abs(kf.x.ravel() - g[f"b{b}_x"][t]).max() < 1e-4, (b, t)
+            assert np.abs(p.ravel() - g[f"b{b}_p_rot"][t]).max() < 1e-5
+            assert abs(kf.P_trace / g[f"b{b}_P_trace"][t] - 1) < 1e-3
+        if b == 0:
+            assert kf.K.shape == (12, 10)
+
+
+def test_asymmetric_p0_is_flagged_by_the_symmetric_storage_kernel():
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
+    eng = Engine(0)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    B, T = 12288, 3                                                    # above the small-batch kernel's range
+    d = synth_numpy(B, T, seed=5)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    P[1 * 12 + 7, 100] = 3e-3                                          # P[1][7] != P[7][1] for trajectory 100 only
+    r = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone())
+    assert eng.kernel_name("kf") == "kf_run_sym_kernel"
+    st = r["status"].cpu().numpy()
+    assert st[100] & 8 and (np.delete(st, 100) == 0).all()
+    r2 = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone(), symmetric=False)     # the reference's full P
+    assert eng.kernel_name("kf") == "kf_run_kernel<SEQ>" and (r2["status"].cpu().numpy() == 0).all()
+    # a non-symmetric Q switches the default to the full-P kernels
+    Qa = Q_DEFAULT.copy(); Qa[0, 5] = 1e-3
+    eng.set_noise(Qa, R_DEFAULT)
+    eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone())
+    assert eng.kernel_name("kf") == "kf_run_kernel<SEQ>"
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+
+
+def test_kernel_name_reports_the_variant_that_ran():
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
+    eng = Engine(0)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    d = synth_numpy(256, 2, seed=1)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, 256))).cuda()
+    eng.profile(True)
+    eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone())
+    assert eng.kernel_name("kf") == "kf_run_rows_kernel"               # B = 256 < 10,240: 16 lanes per trajectory
+    eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone(), sequential=False)
+    assert eng.kernel_name("kf") == "kf_run_kernel<BATCH>"
+    pr = eng.profile_read()
+    assert pr["kf"][1] == 2 and pr["kf"][0] > 0 and set(pr) == set(__import__("optistate_amd._capi", fromlist=["x"]).PHASE_NAMES)
+    eng.profile(False)
+
+
+@pytest.mark.parametrize("B", [192, 20000])
+def test_per_trajectory_noise_matches_the_oracle_looped_per_filter(B):
+    """os_kf_run_noise: every trajectory carries its own diagonal Q and R (each reference filter instance does:
+    data_conversion_Kalman_to_Training.py:138-144); the oracle is run once per noise set."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT, Q_FITTED, R_FITTED
+    from oracle import c_oracle as orc
+    eng = Engine(0)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)                                # context-wide values must NOT be used
+    T = 40
+    d = synth_numpy(B, T, seed=21)
+    rng = np.random.default_rng(0)
+    sets = [(Q_DEFAULT, R_DEFAULT), (Q_FITTED, R_FITTED), (Q_DEFAULT * 3.0, R_DEFAULT * 0.2)]
+    which = rng.integers(0, 3, B)
+    qd = np.stack([np.diag(sets[w][0]) for w in which]).astype(np.float32)     # [B][12]
+    rd = np.stack([np.diag(sets[w][1]) for w in which]).astype(np.float32)
+    P0 = np.stack([np.diag(q) for q in qd]).astype(np.float32)                 # P = Q.copy() per filter (:144)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(P0.reshape(B, 144).T.copy()).cuda()
+    r = eng.kf_run_noise(s["p"], s["f"], s["dp"], s["imu"], c, x, P, torch.as_tensor(qd.T.copy()).cuda(),
+                         torch.as_tensor(rd.T.copy()).cuda(), want_trace=True)
+    assert eng.kernel_name("kf") == "kf_run_sym_noise_kernel"
+    assert (r["status"].cpu().numpy() == 0).all()
+    xo = eng.unpack(r["x_out"]).cpu().numpy()
+    sample = np.arange(B) if B <= 256 else rng.choice(B, 96, replace=False)
+    for w in range(3):
+        idx = sample[which[sample] == w]
+        if idx.size == 0:
+            continue
+        Qw, Rw = np.diag(np.diag(sets[w][0]).astype(np.float32)).astype(np.float64), np.diag(np.diag(sets[w][1]).astype(np.float32)).astype(np.float64)
+        ref = orc.kf_run_batch(d["p"][idx], d["f"][idx], d["dp"][idx], d["imu"][idx], d["contact"][idx], d["x0"][idx],
+                               np.tile(Qw, (idx.size, 1, 1)), Qw, Rw)
+        assert np.abs(xo[idx] - ref["x"]).max() < 1e-4
+        ptr = r["P_trace"].cpu().numpy()[:, idx].T
+        assert np.abs(ptr / ref["P_trace"] - 1).max() < 1e-3

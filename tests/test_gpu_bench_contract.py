@@ -34,11 +34,37 @@ def test_default_mode_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["single_thread_value"] > 0 and cb["gru_half_torch_cpu"]["value"] > 0
     assert abs(d["value"] - 4096 * 20 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    # the metric's second half: state l-inf of the timed batch vs the CPU reference, outside the timed region
+    pa = d["parity"]
+    assert pa["trajectories"] == 128 and pa["state_linf"] < 1e-4 and pa["gru_linf"] < 1e-4 and pa["ok"] is True
+    assert cb["reference_python_steps_per_s"] == 3.05e3
+    assert d["rccl_world_size"] == 1 and d["rank_devices"][0]["device"] == 0
+    # B = 4096 takes the two-kernel path: the line names the kernels that actually ran
+    assert d["kernels"]["kf"]["kernel"] == "kf_run_rows_kernel" and d["kernels"]["gru_layer"]["kernel"].startswith("gru_layer")
 
 
-def test_other_modes_print_one_line():
-    assert _run(["--mode", "kf", "--batch", "4096", "--seq", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])["value"] > 0
-    d = _run(["--mode", "train", "--steps", "2", "--warmup", "1"])
+def _has_roofline_and_baseline(d):
+    ro, cb = d["roofline"], d["cpu_baseline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and "traffic" in ro
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["achieved"] > 0
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and "unit" in cb
+
+
+def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
+    k = _run(["--mode", "kf", "--batch", "4096", "--seq", "50", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    _has_roofline_and_baseline(k)
+    assert k["roofline"]["kernel"] == "kf_run_rows_kernel" and "latency" in k["roofline"]["limiter"]     # the kernel that RAN
+    assert k["parity"]["state_linf"] < 1e-4 and "gru_linf" not in k["parity"]
+    d = _run(["--mode", "train", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"])
+    _has_roofline_and_baseline(d)
     assert d["config"]["batch_per_gpu"] == 8192 and d["grad_bucket_bytes"] == 422424 * 4
-    m = _run(["--mode", "mpc", "--batch", "512", "--seq", "10", "--steps", "1", "--warmup", "1"])
-    assert m["value"] > 0 and m["status_nonzero_trajectories"] == 0 and m["kernels"]["mpc"][1] == 10
+    assert d["roofline"]["bound"] == "mfma" and set(d["kernels"]) >= {"gru_layer", "train_sweep", "train_dw"}
+    m = _run(["--mode", "mpc", "--batch", "512", "--seq", "10", "--steps", "1", "--warmup", "1", "--cpu-seconds", "2"])
+    _has_roofline_and_baseline(m)
+    assert m["value"] > 0 and m["status_nonzero_trajectories"] == 0 and m["kernels"]["mpc"]["launches_per_step"] == 10
+    f = _run(["--mode", "full", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    _has_roofline_and_baseline(f)
+    assert f["config"]["frames"] == 1024 and f["unit"] == "frames/s"
+    w = _run(["--mode", "windows", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    _has_roofline_and_baseline(w)
+    assert w["unit"] == "windows/s" and w["config"]["gru_timesteps_per_output"] == 10

@@ -84,3 +84,86 @@ def test_random_sample_matches_oracle(setup):
     rows = np.concatenate([ref["x"], g("accel"), g("f"), ref["p_rot"], g("dp"), g("imu")], axis=2)
     ro, _, _ = orc.gru_forward((rows + 30.0) / 60.0, orc.flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
     assert np.abs(full["out"][idx].cpu().numpy() - ro).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1]: Kalman only, B = 4096, T = 1000 (default dispatch = the 16-lanes-per-trajectory kernel)
+# ------------------------------------------------------------------------------------------------------------------
+def test_config2_kf_4096x1000_oracle_sample_and_slice_independence():
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    from oracle import c_oracle as orc
+    B2, T2 = 4096, 1000
+    eng = Engine(0)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    d = synth_torch(B2, T2, "cuda", seed=404)
+    cp = eng.contact_soa_to_packed(d["contact"])
+    x, P = d["x0"].clone(), d["P0"].clone()
+    full = eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], cp, x, P)
+    torch.cuda.synchronize()
+    assert eng.kernel_name("kf") == "kf_run_rows_kernel"
+    assert int((full["status"] != 0).sum()) == 0 and torch.isfinite(full["x_out"]).all()
+    # a contiguous slice alone reproduces the full run bit for bit (same kernel: B < 10,240)
+    idx = torch.arange(1024, 1024 + 512, device="cuda")
+    sl = lambda k: d[k][:, :, idx].contiguous()
+    xs, Ps = d["x0"][:, idx].contiguous(), d["P0"][:, idx].contiguous()
+    r = eng.kf_run(sl("p"), sl("f"), sl("dp"), sl("imu"), cp[:, idx].contiguous(), xs, Ps)
+    assert torch.equal(r["x_out"], full["x_out"][:, :, idx]) and torch.equal(Ps, P[:, idx])
+    # 64 random trajectories x 1000 steps against the float64 oracle
+    pick = torch.randperm(B2, generator=torch.Generator().manual_seed(5))[:64].cuda()
+    g = lambda k: d[k][:, :, pick].permute(2, 0, 1).cpu().numpy()
+    ref = orc.kf_run_batch(g("p"), g("f"), g("dp"), g("imu"), d["contact"][:, :, pick].permute(2, 0, 1).cpu().numpy(),
+                           d["x0"][:, pick].t().cpu().numpy(), np.tile(Q_DEFAULT, (64, 1, 1)), Q_DEFAULT, R_DEFAULT, aux=False)
+    err = np.abs(full["x_out"][:, :, pick].permute(2, 0, 1).cpu().numpy() - ref["x"])
+    assert err.max() < 1e-4, err.max()
+    Pf = P[:, pick].t().cpu().numpy().reshape(64, 12, 12)
+    assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: the gru_train.py step at 8192 windows x 10, RNN(188,128,4,24), forward + backward
+# ------------------------------------------------------------------------------------------------------------------
+def test_config4_train_step_8192_windows_vs_float64_autograd():
+    from optistate_amd import RNN
+    from test_gpu_train import torch_reference_grads
+    dims, Bt, Tt = (188, 128, 4, 24), 8192, 10
+    torch.manual_seed(11)
+    m = RNN(*dims, torch.device("cuda")).to("cuda")
+    x, y = torch.rand(Bt, Tt, dims[0]), torch.rand(Bt, 12)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    ref_out, _, ref_loss, ref_g, _ = torch_reference_grads(sd, dims, x, y)
+    out = m(x.cuda())
+    assert np.abs(out.detach().cpu().numpy() - ref_out.numpy()).max() < 1e-5
+    tgt = torch.cat([y.cuda(), (out[:, :12].detach() - y.cuda()).abs()], dim=1)
+    loss = torch.nn.functional.mse_loss(out, tgt)
+    loss.backward()
+    assert abs(loss.item() - ref_loss) < 1e-6
+    for k, p in m.named_parameters():
+        r = ref_g[k]
+        scale = max(r.abs().max().item(), 1e-8)
+        assert (p.grad.cpu().double() - r).abs().max().item() < 2e-4 * scale + 1e-9, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: 1024 depth frames through the ViT encoder (parity unpinned: own float64 restatement)
+# ------------------------------------------------------------------------------------------------------------------
+def test_config5_vit_1024_frames_slice_independence_and_oracle_sample():
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    vit = Transformer_Autoencoder().to("cuda")
+    with torch.no_grad():
+        for p in vit.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    frames = torch.rand(1024, 1, 224, 224, generator=torch.Generator().manual_seed(2)).cuda()
+    lat = vit.forward_encoder(frames)
+    assert lat.shape == (1024, 1, 128) and torch.isfinite(lat).all()
+    assert 0.0 < lat.min().item() and lat.max().item() < 1.0
+    sub = vit.forward_encoder(frames[100:132].contiguous())
+    assert (sub - lat[100:132]).abs().max().item() < 1e-6                  # a frame's latent does not depend on its batch
+    pick = torch.randperm(1024, generator=torch.Generator().manual_seed(9))[:32]
+    sd = {k: v.detach().cpu().numpy() for k, v in vit.state_dict().items()}
+    ref = vit_oracle.encode(frames[pick.cuda(), 0].cpu().numpy(), sd)
+    assert np.abs(lat[pick.cuda(), 0].cpu().numpy() - ref).max() < 2e-5

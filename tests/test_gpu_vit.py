@@ -28,9 +28,11 @@ def test_encoder_latent_matches_float64_restatement():
 
 def test_pos_embed_table_and_state_dict_keys():
     from optistate_amd.transformer_model import Transformer_Autoencoder
-    from oracle import vit_oracle
-    m = Transformer_Autoencoder()
-    assert np.abs(m.pos_embed[0].numpy() - vit_oracle.sincos_pos_embed(128, 14)).max() < 1e-6
+    from conftest import load_golden
+    m = Transformer_Autoencoder().to("cuda")
+    # G10: the reference's own transformer/pos_embed.py output (tools/gen_golden.py), not a twin of the product's formula
+    g10 = load_golden("vit_g10_pos_embed.npz")["enc_128_14"]
+    assert torch.equal(m.pos_embed[0].cpu(), torch.from_numpy(g10).float())
     keys = set(m.state_dict().keys())
     for k in ("patch_embed.proj.weight", "cls_token", "pos_embed", "blocks.0.attn.qkv.weight", "blocks.2.mlp.fc2.bias",
               "norm.weight"):

@@ -18,6 +18,8 @@ The files written are DATA (inputs + the reference's outputs), float64 unless no
   gru_g5_small.npz    G5  RNN(60,64,1,24)  seed 1, weights + x (8,100,60) -> out
   gru_g5_ref.npz      G5  RNN(188,128,4,24) seed 1, weights + x (8,10,188) -> out
   gru_g6_train.npz    G6  one Adam step (loss, target, post-step fc.bias) with gru_train.py's loop body
+  vit_g10_pos_embed.npz G10 the fixed 2-D sin-cos position table of the ViT encoder: transformer/pos_embed.py imported
+                          unmodified (it needs only numpy/torch), called as transformer_model.py:66 does
 """
 import copy
 import os
@@ -271,10 +273,27 @@ def g9():
                         contact=np.array(Cn), u=np.array(U))
 
 
+def g10():
+    """ViT position table: the reference's own transformer/pos_embed.py (imports numpy + torch only, so it runs here although
+    timm is absent), called exactly as Transformer_Autoencoder.initialize_weights does (transformer/transformer_model.py:64-67:
+    get_2d_sincos_pos_embed(embed_dim, int(num_patches ** .5), cls_token=True)) for the encoder (128, 14x14) and, for a second
+    shape, the decoder table (64)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_pos_embed", "/root/reference/transformer/pos_embed.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    enc = mod.get_2d_sincos_pos_embed(128, 14, cls_token=True)
+    dec = mod.get_2d_sincos_pos_embed(64, 14, cls_token=True)
+    small = mod.get_2d_sincos_pos_embed(32, 5, cls_token=True)
+    np.savez_compressed(os.path.join(OUT, "vit_g10_pos_embed.npz"), enc_128_14=enc, dec_64_14=dec, small_32_5=small)
+
+
 if __name__ == "__main__":
     if "--g9-only" in sys.argv:
         g9()
+    elif "--g10-only" in sys.argv:
+        g10()
     else:
-        g1(); g2(); g3_g7(); g4(); g8(); g5_g6(); g9()
+        g1(); g2(); g3_g7(); g4(); g8(); g5_g6(); g9(); g10()
     for fn in sorted(os.listdir(OUT)):
         print(f"{fn:28s} {os.path.getsize(os.path.join(OUT, fn)) / 1024:9.1f} KiB")
