@@ -34,6 +34,7 @@ struct FusedArgs {
     int C, use_sigmoid;
     float *out;                // [B][C]
     float *seq_out;            // [T][64][B] layer-0 output sequence for deeper stacks, or nullptr
+    float *h_last;             // v2 only: h_T [64][B] for the trailing head launch (when seq_out == nullptr)
 };
 
 // (v - min) * (1 / (max - min)); norm_prep_kernel forms [min | 1/(max-min)] once per call (IEEE division), the fused
@@ -241,12 +242,322 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
 }
 
 
+// =====================================================================================================================
+// fused_kf_gru_kernel_v2 -- the same path with the GRU cell TRANSPOSED and the hidden state in registers.
+//
+// gates^T[unit][trajectory] = [W_ih | W_hh] . [x_t | h]^T: the weights are the MFMA A operand (from LDS, one ds_read_b128 per
+// k-pair fetches the three gates' fragments), the activations the B operand.  The result tile puts the trajectory on
+// the lane (col = lane & 31) and 16 hidden units in the registers (unit = 32c + (e&3) + 8(e>>2) + 4(lane>>5)) -- and that is
+// exactly the B-operand layout of a k-pair whose two k values are the units (e, lane half 0) and (e, lane half 1).  The
+// recurrent weights are therefore packed with their k axis in THAT order (fused_pack_kernel), and h_t never leaves the 64
+// registers it is computed in: no LDS tile, no transpose, no barrier, no address arithmetic.  What else moved out of the loop:
+//   * the gate scale factors (-log2 e for r and z, 2 log2 e for n) and the min-max scale 1/(max-min) are folded into the
+//     packed weights, the four biases into the accumulators' initial value (read from LDS, 16 ds_read_b128 per chunk):
+//     sigmoid is exp2 + add + rcp, the normalisation one subtraction;
+//   * the fc + sigmoid head is a trailing launch (gru_head_kernel on h_T [64][B]), not 64 + 24 registers of this kernel;
+//   * the Kalman step runs on the paired upper triangle (kf_device.hpp: v_pk_fma_f32 on aligned pairs, no shuffles).
+// LDS: 2 chunks x (62 k-pairs x 64 lanes x 4 floats + 128 bias floats) = 129,024 B.
+// =====================================================================================================================
+constexpr int CHF2 = (KPX + KPH) * 256 + 128;
+
+// Values that live in the ACCUMULATOR half of the register file (AGPRs) and are only touched through these helpers.  gfx950
+// has 512 registers per lane, but only the 256 architectural VGPRs can be VALU operands; MFMA operands may come from either
+// half.  The B operands of the gate GEMM (the 60 features of a step, the 64 hidden-state registers) are written once and
+// then read by six MFMAs each, so they are kept in AGPRs by construction ("a" constraints): hipcc on its own puts the
+// accumulators there and shuffles ~700 values per step between the halves (v_accvgpr_read/write) to make room.
+__device__ __forceinline__ float agpr_put(float v)
+{
+    float a;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    return a;
+}
+__device__ __forceinline__ float agpr_get(float a)
+{
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+// acc (VGPRs) += W-fragment (VGPR, from LDS) x B-fragment (AGPR).  hipcc's hazard recogniser does not look inside inline asm:
+// successive MFMAs here never touch the same accumulator within five instructions (>= 320 cycles), and mfma_drain() below
+// covers the MFMA -> VALU read of the results.
+__device__ __forceinline__ void mfma_va(f32x16 &acc, float w, float b_agpr)
+{
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_agpr));
+}
+__device__ __forceinline__ float agpr_mov(float a)
+{
+    float d;
+    asm volatile("v_accvgpr_mov_b32 %0, %1" : "=a"(d) : "a"(a));
+    return d;
+}
+__device__ __forceinline__ void mfma_drain(f32x16 (&acc)[4])
+{
+    // 16-pass MFMA result -> VALU read: 18 wait states (cdna4 ISA, MFMA hazard table); the operands tie the nops to the values
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+constexpr size_t LDS2_BYTES = (size_t)2 * CHF2 * sizeof(float);
+
+__global__ void fused_pack_kernel(const float *__restrict__ w0 /* layer 0, torch layout */, const float *__restrict__ minmax,
+                                  float *__restrict__ img /* [2][CHF2] */, float *__restrict__ mins /* [60] */)
+{
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float *Wih = w0, *Whh = Wih + 3 * H * KX, *bih = Whh + 3 * H * H, *bhh = bih + 3 * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * CHF2; i += gridDim.x * blockDim.x) {
+        const int c = i / CHF2, r = i % CHF2;
+        float v = 0.f;
+        if (r < (KPX + KPH) * 256) {
+            const int q = r >> 8, lane = (r >> 2) & 63, g = r & 3, li = lane & 31, lh = lane >> 5;
+            if (g < 3) {
+                const int col = g * H + 32 * c + li;
+                const float gs = g < 2 ? -LOG2E : 2.0f * LOG2E;
+                if (q < KPX) {
+                    const int k = 2 * q + lh;
+                    v = Wih[col * KX + k] * (1.0f / (minmax[KX + k] - minmax[k])) * gs;
+                } else {
+                    const int qq = q - KPX, cp = qq >> 4, e = qq & 15;
+                    const int k = 32 * cp + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    v = Whh[col * H + k] * gs;
+                }
+            }
+        } else {
+            const int j = r - (KPX + KPH) * 256, lh = j >> 6, g4 = (j >> 4) & 3, e = j & 15;
+            const int u = 32 * c + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (g4 == 0) v = (bih[u] + bhh[u]) * -LOG2E;
+            else if (g4 == 1) v = (bih[H + u] + bhh[H + u]) * -LOG2E;
+            else if (g4 == 2) v = bih[2 * H + u] * (2.0f * LOG2E);
+            else v = bhh[2 * H + u] * (2.0f * LOG2E);
+        }
+        img[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < KX) mins[threadIdx.x] = minmax[threadIdx.x];
+}
+
+template <bool QDIAG, bool SEQOUT>
+__global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const KfRunArgs &k = a.kf;
+    const size_t B = (size_t)k.B;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.wpacked);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < 2 * CHF2 / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *__restrict__ mins = a.nrm;
+
+    const int wbase = blockIdx.x * 256 + (threadIdx.x & ~63);      // first trajectory of this wave
+    const int b = wbase + lane;
+    const bool live = b < k.B;
+    const int bb = live ? b : k.B - 1;                 // dead lanes shadow the last trajectory, stores masked
+    const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
+
+    float x[NS];
+    f2 U[NU];
+    int status = 0;
+    {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        // status bit 3: P0 not symmetric (the paired triangle reads the upper half only; see include/optistate_hip.h)
+        float worst = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i + 1; j < NS; j++) {
+                const float up = buf_load(rP, voff, (i * NS + j) * rowB), lo = buf_load(rP, voff, (j * NS + i) * rowB);
+                worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
+            }
+        status = worst > 0.f ? 8 : 0;
+        sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
+    }
+    // h_t of this wave's 64 trajectories: hreg[rb][c][e] = h[unit 32c + (e&3) + 8(e>>2) + 4 lh][trajectory wbase + 32 rb + li]
+    // (AGPR-resident: agpr_put / agpr_get)
+    float hreg[2][2][16];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) hreg[rb][c][e] = agpr_put(0.f);      // h0 = 0 (gru/gru_model.py:27)
+
+    StepIn in;
+    float acl[6];
+    load_step(k, 0, voff, rowB, in);
+    {
+        rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
+    }
+
+    for (int t = 0; t < k.T; t++) {
+        // ================= Kalman step (lane = trajectory) =================
+        float z[NM], pw[12], F[KX];
+        kf_step_front_sym<QDIAG>(x, U, in, k.k, z, pw);
+        // raw-input features [accel | f | p_world | dp | imu] minus their minimum (the 1/(max-min) scale sits in the weights);
+        // taken now so that the input registers are free during the update
+#pragma unroll
+        for (int i = 0; i < 6; i++) F[12 + i] = acl[i] - mins[12 + i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            F[18 + i] = in.f[i] - mins[18 + i];
+            F[30 + i] = pw[i] - mins[30 + i];
+            F[42 + i] = in.dp[i] - mins[42 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) F[54 + i] = in.imu[i] - mins[54 + i];
+        status |= kf_step_back_sym(x, U, z, k.k);
+        if (live) {
+            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) F[i] = x[i] - mins[i];
+
+        // ================= GRU cell, transposed: this wave's 64 trajectories are the MFMA columns =================
+        // after the swap F[2kp] is the B fragment of k-pair kp for trajectories 0-31 (lanes 0-31: feature 2kp, lanes 32-63:
+        // feature 2kp+1), F[2kp+1] the one for trajectories 32-63.  Two asm blocks of 15 swaps (30 operands each) with one
+        // leading / trailing s_nop for the VALU <-> permlane wait states; inline asm because hipcc (ROCm 7.2) drops the second
+        // result of __builtin_amdgcn_permlane32_swap here.
+#define OS_SW(n) "v_permlane32_swap_b32 %" #n ", %" #n "+1\n\t"
+#pragma unroll
+        for (int h5 = 0; h5 < 2; h5++) {
+            float *Fp = F + 30 * h5;
+            asm volatile("s_nop 1\n\t"
+                         "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+                         "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+                         "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\tv_permlane32_swap_b32 %16, %17\n\t"
+                         "v_permlane32_swap_b32 %18, %19\n\tv_permlane32_swap_b32 %20, %21\n\tv_permlane32_swap_b32 %22, %23\n\t"
+                         "v_permlane32_swap_b32 %24, %25\n\tv_permlane32_swap_b32 %26, %27\n\tv_permlane32_swap_b32 %28, %29\n\t"
+                         "s_nop 1"
+                         : "+v"(Fp[0]), "+v"(Fp[1]), "+v"(Fp[2]), "+v"(Fp[3]), "+v"(Fp[4]), "+v"(Fp[5]), "+v"(Fp[6]), "+v"(Fp[7]),
+                           "+v"(Fp[8]), "+v"(Fp[9]), "+v"(Fp[10]), "+v"(Fp[11]), "+v"(Fp[12]), "+v"(Fp[13]), "+v"(Fp[14]),
+                           "+v"(Fp[15]), "+v"(Fp[16]), "+v"(Fp[17]), "+v"(Fp[18]), "+v"(Fp[19]), "+v"(Fp[20]), "+v"(Fp[21]),
+                           "+v"(Fp[22]), "+v"(Fp[23]), "+v"(Fp[24]), "+v"(Fp[25]), "+v"(Fp[26]), "+v"(Fp[27]), "+v"(Fp[28]),
+                           "+v"(Fp[29]));
+        }
+#undef OS_SW
+        float FA[KX];                        // the swapped feature fragments, parked in AGPRs for the MFMAs
+#pragma unroll
+        for (int i = 0; i < KX; i++) FA[i] = agpr_put(F[i]);
+        // One 32-trajectory column block and one 32-unit chunk at a time: 64 accumulator registers, in VGPRs, where the cell
+        // update reads them directly (the weight fragments are simply read from LDS again for each of the four passes).  Chunk
+        // 0's new h waits in 16 spare AGPRs until chunk 1's MFMAs no longer need the old one.
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            float park[16];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float *Wc = lds + c * CHF2;
+                f32x16 acc[4];
+                {
+                    // accumulators start at the (pre-scaled) biases of this lane's 16 units
+                    const float4 *bc = reinterpret_cast<const float4 *>(Wc + (KPX + KPH) * 256 + lh * 64);
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int v4 = 0; v4 < 4; v4++) {
+                            const float4 bv = bc[g * 4 + v4];
+                            acc[g][4 * v4] = bv.x; acc[g][4 * v4 + 1] = bv.y; acc[g][4 * v4 + 2] = bv.z; acc[g][4 * v4 + 3] = bv.w;
+                        }
+                }
+                // two-deep software pipeline over the 62 k-pairs: the weight fragments of k-pair q+1 (one ds_read_b128: the three
+                // gates' fragments) are requested before the three MFMAs of k-pair q issue
+                const float4 *Wq = reinterpret_cast<const float4 *>(Wc) + lane;
+                float4 wb[2];
+                wb[0] = Wq[0];
+#pragma unroll
+                for (int q = 0; q < KPX + KPH; q++) {
+                    const int cur = q & 1, nxt = cur ^ 1;
+                    if (q + 1 < KPX + KPH) wb[nxt] = Wq[(q + 1) * 64];
+                    if (rb == 1 && c == 1 && q == KPX) {
+                        // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
+                        const int tn = (t + 1 < k.T) ? t + 1 : t;
+                        load_step(k, tn, voff, rowB, in);
+                        rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
+#pragma unroll
+                        for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
+                    }
+                    const float bv = q < KPX ? FA[2 * (q < KPX ? q : 0) + rb]
+                                             : hreg[rb][(q - KPX) >> 4 & 1][(q >= KPX ? q - KPX : 0) & 15];
+                    const int gn = q < KPX ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
+                    mfma_va(acc[0], wb[cur].x, bv);
+                    mfma_va(acc[1], wb[cur].y, bv);
+                    mfma_va(acc[gn], wb[cur].z, bv);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma_drain(acc);
+                // cell update on the accumulator layout (scales folded into the weights: sigmoid = rcp(1 + exp2(a)))
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][e]));
+                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][e]));
+                    const float u = fmaf(r, acc[3][e], acc[2][e]);
+                    const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)), 1.0f);
+                    const float hn = agpr_put(fmaf(zg, agpr_get(hreg[rb][c][e]) - n, n));          // (1 - z) n + z h
+                    if (c == 0) park[e] = hn;
+                    else hreg[rb][1][e] = hn;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) hreg[rb][0][e] = agpr_mov(park[e]);
+        }
+        if (SEQOUT) {
+            // layer-0 output sequence [T][64][B] for deeper stacks: lanes 0-31 / 32-63 write two 128-byte row segments
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const int tr = wbase + 32 * rb + li;
+                if (tr < k.B) {
+                    rsrc_t rs = make_rsrc(a.seq_out + (size_t)t * H * B, (uint32_t)H * rowB);
+                    const uint32_t vo = (uint32_t)tr * 4u + (uint32_t)(4 * lh) * rowB;
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            buf_store(rs, vo, (uint32_t)(32 * c + (e & 3) + 8 * (e >> 2)) * rowB, agpr_get(hreg[rb][c][e]));
+                }
+            }
+        }
+    }
+
+    // ---- final state, status, h_T for the head kernel ----
+    if (live) {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+        k.status[b] = status;
+    }
+    if (!SEQOUT) {
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            const int tr = wbase + 32 * rb + li;
+            if (tr < k.B) {
+                rsrc_t rs = make_rsrc(a.h_last, (uint32_t)H * rowB);
+                const uint32_t vo = (uint32_t)tr * 4u + (uint32_t)(4 * lh) * rowB;
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        buf_store(rs, vo, (uint32_t)(32 * c + (e & 3) + 8 * (e >> 2)) * rowB, agpr_get(hreg[rb][c][e]));
+            }
+        }
+    }
+}
+
 }  // namespace osf
 
 int os_kf_run_impl(os_ctx *ctx, osk::KfRunArgs &a, uint32_t flags, hipStream_t s);   // kf_kernels.hip
 int os_gru_scratch(os_ctx *ctx, int B, int T, float **seq0, float **seq1, float **hlast);   // gru_kernels.hip
 int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_layer, float *out, float *h_last_all,
                        hipStream_t s);
+int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s);
 
 extern "C" {
 
@@ -279,14 +590,47 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
     const bool single_kernel = shapes_ok && !(flags & OS_FUSED_TWO_KERNEL) &&
                                ((flags & OS_FUSED_ONE_KERNEL) || B > 128 * ctx->cu_count);
+    if (single_kernel && !ctx->tune_fused_v1) {
+        // v2: transposed GRU cell, h in registers, scales folded into a per-call LDS image, head as a trailing launch
+        osf::FusedArgs fa;
+        fa.kf = a; fa.kf.k = ctx->k;
+        fa.fcw = nullptr; fa.fcb = nullptr; fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out;
+        float *seq0 = nullptr, *seq1 = nullptr, *hlast = nullptr;
+        if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
+        fa.seq_out = d.num_layers > 1 ? seq0 : nullptr;
+        fa.h_last = d.num_layers > 1 ? nullptr : hlast;
+        if (!ctx->fused2_attr_set) {
+            const void *fns[4] = {(const void *)osf::fused_kf_gru_kernel_v2<true, false>, (const void *)osf::fused_kf_gru_kernel_v2<false, false>,
+                                  (const void *)osf::fused_kf_gru_kernel_v2<true, true>, (const void *)osf::fused_kf_gru_kernel_v2<false, true>};
+            for (const void *fn : fns)
+                OS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS2_BYTES));
+            ctx->fused2_attr_set = true;
+        }
+        if (!ctx->nrm) OS_HIP(ctx, hipMalloc((void **)&ctx->nrm, 120 * sizeof(float)));
+        if (!ctx->fused_img) OS_HIP(ctx, hipMalloc((void **)&ctx->fused_img, osf::LDS2_BYTES));
+        hipLaunchKernelGGL(osf::fused_pack_kernel, dim3(32), dim3(256), 0, s, ctx->gru_flat, minmax, ctx->fused_img, ctx->nrm);
+        fa.wpacked = ctx->fused_img; fa.nrm = ctx->nrm;
+        dim3 grid((B + 255) / 256), block(256);
+        const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, "fused_kf_gru_kernel_v2");
+        const bool so = d.num_layers > 1;
+        if (ctx->q_is_diagonal && !so) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<true, false>), grid, block, osf::LDS2_BYTES, s, fa);
+        else if (ctx->q_is_diagonal) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<true, true>), grid, block, osf::LDS2_BYTES, s, fa);
+        else if (!so) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<false, false>), grid, block, osf::LDS2_BYTES, s, fa);
+        else hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<false, true>), grid, block, osf::LDS2_BYTES, s, fa);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+        if (d.num_layers > 1) return os_gru_layers_impl(ctx, B, T, seq0, 1, out, nullptr, s);
+        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
+        return os_gru_head_launch(ctx, B, hlast, fcw, out, s);
+    }
     if (single_kernel) {
-        // the single-kernel path: features stay in registers
+        // round-1 kernel (h tile in LDS), kept for A/B runs (OS_FUSED_V1=1)
         osf::FusedArgs fa;
         fa.kf = a; fa.kf.k = ctx->k;
         fa.wpacked = ctx->gru_packed;
         const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
         fa.fcw = fcw; fa.fcb = fcw + (size_t)d.num_classes * 64;
-        fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out; fa.seq_out = nullptr;
+        fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out; fa.seq_out = nullptr; fa.h_last = nullptr;
         float *seq0 = nullptr, *seq1 = nullptr, *hlast = nullptr;
         if (d.num_layers > 1) {
             if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
