@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
 //     sigmoid is exp2 + add + rcp, the normalisation one subtraction;
 //   * the fc + sigmoid head is a trailing launch (gru_head_kernel on h_T [64][B]), not 64 + 24 registers of this kernel;
 //   * the Kalman step runs on the paired upper triangle (kf_device.hpp: v_pk_fma_f32 on aligned pairs, no shuffles).
-// LDS: 2 chunks x (62 k-pairs x 64 lanes x 4 floats + 128 bias floats) = 129,024 B.
+// LDS: 2 chunks x (62 k-pairs x 64 lanes x 4 floats + 128 bias floats) + 64 minima = 128,256 B.
 // =====================================================================================================================
 constexpr int CHF2 = (KPX + KPH) * 256 + 128;
 
@@ -284,6 +284,10 @@ __device__ __forceinline__ void mfma_va(f32x16 &acc, float w, float b_agpr)
 {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_agpr));
 }
+__device__ __forceinline__ void mfma_vv(f32x16 &acc, float w, float b_vgpr)
+{
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b_vgpr));
+}
 __device__ __forceinline__ float agpr_mov(float a)
 {
     float d;
@@ -295,10 +299,12 @@ __device__ __forceinline__ void mfma_drain(f32x16 (&acc)[4])
     // 16-pass MFMA result -> VALU read: 18 wait states (cdna4 ISA, MFMA hazard table); the operands tie the nops to the values
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 }
-constexpr size_t LDS2_BYTES = (size_t)2 * CHF2 * sizeof(float);
+constexpr bool FEAT_AGPR = true;          // park the 60 feature fragments in AGPRs (true) or leave them in VGPRs
+constexpr int IMG2 = 2 * CHF2 + 64;          // + the 60 feature minima (read per step with wave-uniform ds_read_b128)
+constexpr size_t LDS2_BYTES = (size_t)IMG2 * sizeof(float);
 
 __global__ void fused_pack_kernel(const float *__restrict__ w0 /* layer 0, torch layout */, const float *__restrict__ minmax,
-                                  float *__restrict__ img /* [2][CHF2] */, float *__restrict__ mins /* [60] */)
+                                  float *__restrict__ img /* [IMG2] */)
 {
     constexpr float LOG2E = 1.44269504088896341f;
     const float *Wih = w0, *Whh = Wih + 3 * H * KX, *bih = Whh + 3 * H * H, *bhh = bih + 3 * H;
@@ -329,7 +335,7 @@ __global__ void fused_pack_kernel(const float *__restrict__ w0 /* layer 0, torch
         }
         img[i] = v;
     }
-    if (blockIdx.x == 0 && threadIdx.x < KX) mins[threadIdx.x] = minmax[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 64) img[2 * CHF2 + threadIdx.x] = threadIdx.x < KX ? minmax[threadIdx.x] : 0.f;
 }
 
 template <bool QDIAG, bool SEQOUT>
@@ -343,10 +349,10 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.wpacked);
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < 2 * CHF2 / 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < IMG2 / 4; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    const float *__restrict__ mins = a.nrm;
+    const float4 *mins4 = reinterpret_cast<const float4 *>(lds + 2 * CHF2);      // minima from LDS: 60 SGPRs would spill
 
     const int wbase = blockIdx.x * 256 + (threadIdx.x & ~63);      // first trajectory of this wave
     const int b = wbase + lane;
@@ -394,55 +400,47 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 
     for (int t = 0; t < k.T; t++) {
         // ================= Kalman step (lane = trajectory) =================
-        float z[NM], pw[12], F[KX];
-        kf_step_front_sym<QDIAG>(x, U, in, k.k, z, pw);
-        // raw-input features [accel | f | p_world | dp | imu] minus their minimum (the 1/(max-min) scale sits in the weights);
-        // taken now so that the input registers are free during the update
+        // Order chosen for register pressure: everything that reads the step's 55 input registers runs first (measurement,
+        // dynamics, the 48 raw-input features, which go straight to AGPRs); the covariance predict and the update then work
+        // with the filter state alone.  (predict's F_d and next_state both use the PRIOR attitude: kalman_filter.py:124,133.)
+        float z[NM], pw[12], FA[KX];
+        measurement(in, z);
+        const Rot rot = rotation(x[0], x[1], x[2]);
+        dynamics(x, rot, in.p, in.f, pw, k.k);
+        // Features [x_post | accel | f | p_world | dp | imu] minus their minimum (the 1/(max-min) scale sits in the packed
+        // weights).  v_permlane32_swap turns a feature pair into the two B fragments of its k-pair: afterwards the first
+        // register holds trajectories 0-31 (lanes 0-31: feature 2kp, lanes 32-63: feature 2kp+1), the second trajectories
+        // 32-63.  Inline asm because hipcc (ROCm 7.2) drops the second result of __builtin_amdgcn_permlane32_swap here; six
+        // swaps per block share one leading / trailing s_nop for the VALU <-> permlane wait states.
+        auto feat6 = [&](int j0, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, float a9,
+                         float a10, float a11) {
+            float v[12] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11};
 #pragma unroll
-        for (int i = 0; i < 6; i++) F[12 + i] = acl[i] - mins[12 + i];
+            for (int i4 = 0; i4 < 3; i4++) {
+                const float4 mn = mins4[j0 / 4 + i4];
+                v[4 * i4] -= mn.x; v[4 * i4 + 1] -= mn.y; v[4 * i4 + 2] -= mn.z; v[4 * i4 + 3] -= mn.w;
+            }
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+                         "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\ts_nop 1"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                           "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            F[18 + i] = in.f[i] - mins[18 + i];
-            F[30 + i] = pw[i] - mins[30 + i];
-            F[42 + i] = in.dp[i] - mins[42 + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++) F[54 + i] = in.imu[i] - mins[54 + i];
-        status |= kf_step_back_sym(x, U, z, k.k);
+            for (int i = 0; i < 12; i++) FA[j0 + i] = FEAT_AGPR ? agpr_put(v[i]) : v[i];
+        };
+        feat6(12, acl[0], acl[1], acl[2], acl[3], acl[4], acl[5], in.f[0], in.f[1], in.f[2], in.f[3], in.f[4], in.f[5]);
+        feat6(24, in.f[6], in.f[7], in.f[8], in.f[9], in.f[10], in.f[11], pw[0], pw[1], pw[2], pw[3], pw[4], pw[5]);
+        feat6(36, pw[6], pw[7], pw[8], pw[9], pw[10], pw[11], in.dp[0], in.dp[1], in.dp[2], in.dp[3], in.dp[4], in.dp[5]);
+        feat6(48, in.dp[6], in.dp[7], in.dp[8], in.dp[9], in.dp[10], in.dp[11], in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
+              in.imu[5]);
+        cov_predict_sym_blk<QDIAG>(U, rot, k.k);
+        status |= update_sequential_sym(x, U, z, k.k);      // non-finite states stay non-finite: checked once after the loop
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
             for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
         }
-#pragma unroll
-        for (int i = 0; i < NS; i++) F[i] = x[i] - mins[i];
+        feat6(0, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], x[11]);
 
-        // ================= GRU cell, transposed: this wave's 64 trajectories are the MFMA columns =================
-        // after the swap F[2kp] is the B fragment of k-pair kp for trajectories 0-31 (lanes 0-31: feature 2kp, lanes 32-63:
-        // feature 2kp+1), F[2kp+1] the one for trajectories 32-63.  Two asm blocks of 15 swaps (30 operands each) with one
-        // leading / trailing s_nop for the VALU <-> permlane wait states; inline asm because hipcc (ROCm 7.2) drops the second
-        // result of __builtin_amdgcn_permlane32_swap here.
-#define OS_SW(n) "v_permlane32_swap_b32 %" #n ", %" #n "+1\n\t"
-#pragma unroll
-        for (int h5 = 0; h5 < 2; h5++) {
-            float *Fp = F + 30 * h5;
-            asm volatile("s_nop 1\n\t"
-                         "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
-                         "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
-                         "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\tv_permlane32_swap_b32 %16, %17\n\t"
-                         "v_permlane32_swap_b32 %18, %19\n\tv_permlane32_swap_b32 %20, %21\n\tv_permlane32_swap_b32 %22, %23\n\t"
-                         "v_permlane32_swap_b32 %24, %25\n\tv_permlane32_swap_b32 %26, %27\n\tv_permlane32_swap_b32 %28, %29\n\t"
-                         "s_nop 1"
-                         : "+v"(Fp[0]), "+v"(Fp[1]), "+v"(Fp[2]), "+v"(Fp[3]), "+v"(Fp[4]), "+v"(Fp[5]), "+v"(Fp[6]), "+v"(Fp[7]),
-                           "+v"(Fp[8]), "+v"(Fp[9]), "+v"(Fp[10]), "+v"(Fp[11]), "+v"(Fp[12]), "+v"(Fp[13]), "+v"(Fp[14]),
-                           "+v"(Fp[15]), "+v"(Fp[16]), "+v"(Fp[17]), "+v"(Fp[18]), "+v"(Fp[19]), "+v"(Fp[20]), "+v"(Fp[21]),
-                           "+v"(Fp[22]), "+v"(Fp[23]), "+v"(Fp[24]), "+v"(Fp[25]), "+v"(Fp[26]), "+v"(Fp[27]), "+v"(Fp[28]),
-                           "+v"(Fp[29]));
-        }
-#undef OS_SW
-        float FA[KX];                        // the swapped feature fragments, parked in AGPRs for the MFMAs
-#pragma unroll
-        for (int i = 0; i < KX; i++) FA[i] = agpr_put(F[i]);
         // One 32-trajectory column block and one 32-unit chunk at a time: 64 accumulator registers, in VGPRs, where the cell
         // update reads them directly (the weight fragments are simply read from LDS again for each of the four passes).  Chunk
         // 0's new h waits in 16 spare AGPRs until chunk 1's MFMAs no longer need the old one.
@@ -484,22 +482,52 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                     const float bv = q < KPX ? FA[2 * (q < KPX ? q : 0) + rb]
                                              : hreg[rb][(q - KPX) >> 4 & 1][(q >= KPX ? q - KPX : 0) & 15];
                     const int gn = q < KPX ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
-                    mfma_va(acc[0], wb[cur].x, bv);
-                    mfma_va(acc[1], wb[cur].y, bv);
-                    mfma_va(acc[gn], wb[cur].z, bv);
+                    if (q < KPX && !FEAT_AGPR) {
+                        mfma_vv(acc[0], wb[cur].x, bv);
+                        mfma_vv(acc[1], wb[cur].y, bv);
+                        mfma_vv(acc[gn], wb[cur].z, bv);
+                    } else {
+                        mfma_va(acc[0], wb[cur].x, bv);
+                        mfma_va(acc[1], wb[cur].y, bv);
+                        mfma_va(acc[gn], wb[cur].z, bv);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 mfma_drain(acc);
-                // cell update on the accumulator layout (scales folded into the weights: sigmoid = rcp(1 + exp2(a)))
+                // Cell update in place on the accumulator registers (scales folded into the weights: sigmoid = rcp(1 + exp2(a))),
+                // stage by stage over the 16 elements so that no instruction depends on its predecessor, the seven
+                // non-transcendental operations per element as v_pk_add/fma on register pairs: with one wavefront per SIMD an
+                // instruction costs an issue slot whether it is packed or not.
+                {
+                    f2 *A0 = reinterpret_cast<f2 *>(&acc[0]), *A1 = reinterpret_cast<f2 *>(&acc[1]), *A2 = reinterpret_cast<f2 *>(&acc[2]),
+                       *A3 = reinterpret_cast<f2 *>(&acc[3]);
+                    const f2 one = {1.0f, 1.0f};
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][e]));
-                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][e]));
-                    const float u = fmaf(r, acc[3][e], acc[2][e]);
-                    const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)), 1.0f);
-                    const float hn = agpr_put(fmaf(zg, agpr_get(hreg[rb][c][e]) - n, n));          // (1 - z) n + z h
-                    if (c == 0) park[e] = hn;
-                    else hreg[rb][1][e] = hn;
+                    for (int e = 0; e < 16; e++) { acc[0][e] = __builtin_amdgcn_exp2f(acc[0][e]); acc[1][e] = __builtin_amdgcn_exp2f(acc[1][e]); }
+#pragma unroll
+                    for (int p2 = 0; p2 < 8; p2++) { A0[p2] += one; A1[p2] += one; }
+#pragma unroll
+                    for (int e = 0; e < 16; e++) { acc[0][e] = __builtin_amdgcn_rcpf(acc[0][e]); acc[1][e] = __builtin_amdgcn_rcpf(acc[1][e]); }      // r, z
+#pragma unroll
+                    for (int p2 = 0; p2 < 8; p2++) A2[p2] = fma2(A0[p2], A3[p2], A2[p2]);                      // gi_n + r gh_n (pre-scaled)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[2][e] = __builtin_amdgcn_exp2f(acc[2][e]);
+#pragma unroll
+                    for (int p2 = 0; p2 < 8; p2++) A2[p2] += one;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) { acc[2][e] = __builtin_amdgcn_rcpf(acc[2][e]); acc[3][e] = agpr_get(hreg[rb][c][e]); }
+#pragma unroll
+                    for (int p2 = 0; p2 < 8; p2++) A2[p2] = fma2((f2){-2.0f, -2.0f}, A2[p2], one);             // n = tanh(.)
+#pragma unroll
+                    for (int p2 = 0; p2 < 8; p2++) A3[p2] = A3[p2] - A2[p2];                                   // h - n
+#pragma unroll
+                    for (int p2 = 0; p2 < 8; p2++) A3[p2] = fma2(A1[p2], A3[p2], A2[p2]);                      // (1 - z) n + z h
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const float hn = agpr_put(acc[3][e]);
+                        if (c == 0) park[e] = hn;                 // old h[0:32] is still an operand of chunk 1
+                        else hreg[rb][1][e] = hn;
+                    }
                 }
             }
 #pragma unroll
@@ -524,6 +552,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     }
 
     // ---- final state, status, h_T for the head kernel ----
+    status |= finite_status(x);
     if (live) {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
@@ -606,10 +635,9 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
                 OS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS2_BYTES));
             ctx->fused2_attr_set = true;
         }
-        if (!ctx->nrm) OS_HIP(ctx, hipMalloc((void **)&ctx->nrm, 120 * sizeof(float)));
         if (!ctx->fused_img) OS_HIP(ctx, hipMalloc((void **)&ctx->fused_img, osf::LDS2_BYTES));
-        hipLaunchKernelGGL(osf::fused_pack_kernel, dim3(32), dim3(256), 0, s, ctx->gru_flat, minmax, ctx->fused_img, ctx->nrm);
-        fa.wpacked = ctx->fused_img; fa.nrm = ctx->nrm;
+        hipLaunchKernelGGL(osf::fused_pack_kernel, dim3(32), dim3(256), 0, s, ctx->gru_flat, minmax, ctx->fused_img);
+        fa.wpacked = ctx->fused_img; fa.nrm = nullptr;
         dim3 grid((B + 255) / 256), block(256);
         const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, "fused_kf_gru_kernel_v2");
         const bool so = d.num_layers > 1;
