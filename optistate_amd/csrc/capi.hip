@@ -44,6 +44,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 512;      // 2 x 240 workgroups at the training batch: two per CU
         e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
         e = getenv("OS_FUSED_V1"); c->tune_fused_v1 = e ? atoi(e) : 0;
+        e = getenv("OS_BF16_TERMS"); c->tune_bf16_terms = e ? atoi(e) : 3;
     }
     if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc((void **)&c->kf_qr, 244 * sizeof(float)) != hipSuccess ||
         hipMemcpy(c->kf_qr, c->k.Q, 144 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
@@ -70,7 +71,7 @@ void os_destroy(os_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     os_train_destroy(ctx);
     os_vit_destroy(ctx);
-    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img};
+    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)

@@ -580,6 +580,328 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     }
 }
 
+// =====================================================================================================================
+// fused_kf_gru_bf16_kernel<QDIAG, SPL> -- OPT-IN reduced-precision gate GEMM (OS_FUSED_SPLIT_BF16), never the default.
+//
+// fp32 MFMA runs at 1/16 of the bf16 rate on gfx950.  Here every fp32 operand of the gate GEMM is split into SPL bf16 terms
+// (v = hi + mid + lo, 8 mantissa bits each: SPL = 3 represents an fp32 value exactly, SPL = 2 keeps 16 bits) and the products
+// are formed on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: SPL = 3 issues hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid
+// (every term down to 2^-16 of the product; what is dropped is below fp32 rounding), SPL = 2 issues hi.hi, hi.lo, lo.hi
+// (relative 2^-16 per product).  576 (288) matrix instructions of 32 cycles per step instead of 744 of 64.  The weights are
+// split once per call into the LDS image, the activations on the VALU just before use (5.5 / 3 instructions per value): the
+// kernel is VALU-bound; the Kalman step and the cell update are the fp32 code of v2.  Same transposed layout: trajectory on
+// the lane, h in AGPRs; a k-block is 16 features, or 16 hidden units in the order the accumulators hold them.
+// LDS: [2 chunks][8 k-blocks][3 gates][SPL terms][64 lanes][4 dwords of bf16 pairs] + biases + minima
+//      = 148,736 B (SPL = 3) / 99,584 B (SPL = 2).
+// =====================================================================================================================
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+constexpr int KBX = 4, KBH = 4, KBT = KBX + KBH;
+template <int SPL> struct Bf16Img {
+    static constexpr int CH = KBT * 3 * SPL * 256;                // dwords per chunk of weight fragments
+    static constexpr int BIAS = 2 * CH;                           // [2 chunks][2 lane halves][4 gate slots][16] floats
+    static constexpr int MINS = BIAS + 256;
+    static constexpr int TOTAL = MINS + 64;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)       // (low half = a, high half = b), round to nearest even
+{
+    const bf16x2_t v = __builtin_convertvector((f2){a, b}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// one pair of fp32 values -> SPL dwords of packed bf16 terms (hi [, mid], lo); the remainders are exact in fp32
+template <int SPL>
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t *t)
+{
+    t[0] = pack_bf16(a, b);
+    float ra = a - bf16_lo_f32(t[0]), rb = b - bf16_hi_f32(t[0]);
+    if (SPL == 3) {
+        t[1] = pack_bf16(ra, rb);
+        ra -= bf16_lo_f32(t[1]); rb -= bf16_hi_f32(t[1]);
+    }
+    t[SPL - 1] = pack_bf16(ra, rb);
+}
+
+template <int SPL>
+__global__ void fused_pack_bf16_kernel(const float *__restrict__ w0, const float *__restrict__ minmax, uint32_t *__restrict__ img)
+{
+    using I = Bf16Img<SPL>;
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float *Wih = w0, *Whh = Wih + 3 * H * KX, *bih = Whh + 3 * H * H, *bhh = bih + 3 * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * I::CH / SPL; i += gridDim.x * blockDim.x) {
+        // one thread per (chunk, k-block, gate, lane, dword): the SPL term dwords of two adjacent k values
+        int r = i;
+        const int jj = r & 3; r >>= 2;
+        const int lane = r & 63; r >>= 6;
+        const int g = r % 3; r /= 3;
+        const int kb = r % KBT, c = r / KBT;
+        const int li = lane & 31, lh = lane >> 5, col = g * H + 32 * c + li;
+        const float gs = g < 2 ? -LOG2E : 2.0f * LOG2E;
+        float w[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int j = 2 * jj + q;
+            if (kb < KBX) {
+                const int kk = 16 * kb + 8 * lh + j;
+                w[q] = kk < KX ? Wih[col * KX + kk] * (1.0f / (minmax[KX + kk] - minmax[kk])) * gs : 0.f;
+            } else {
+                const int kh = kb - KBX, cp = kh >> 1, e = 8 * (kh & 1) + j;
+                w[q] = Whh[col * H + 32 * cp + (e & 3) + 8 * (e >> 2) + 4 * lh] * gs;
+            }
+        }
+        uint32_t t[SPL];
+        split_pair<SPL>(w[0], w[1], t);
+#pragma unroll
+        for (int sp = 0; sp < SPL; sp++) img[c * I::CH + (((kb * 3 + g) * SPL + sp) * 64 + lane) * 4 + jj] = t[sp];
+    }
+    if (blockIdx.x == 0) {
+        float *fb = reinterpret_cast<float *>(img);
+        const int j = threadIdx.x;                     // 256 threads: [c][lh][g4][e]
+        const int lh = (j >> 6) & 1, g4 = (j >> 4) & 3, e = j & 15, u = 32 * (j >> 7) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v;
+        if (g4 == 0) v = (bih[u] + bhh[u]) * -LOG2E;
+        else if (g4 == 1) v = (bih[H + u] + bhh[H + u]) * -LOG2E;
+        else if (g4 == 2) v = bih[2 * H + u] * (2.0f * LOG2E);
+        else v = bhh[2 * H + u] * (2.0f * LOG2E);
+        fb[I::BIAS + j] = v;
+        if (j < 64) fb[I::MINS + j] = j < KX ? minmax[j] : 0.f;
+    }
+}
+
+// acc (VGPRs) += W-fragment x B-fragment, both 8 bf16 per lane in VGPRs.  Inline asm for the same reason as mfma_va: the
+// accumulators must stay in VGPRs for the cell update.  MFMAs on one accumulator are at least two instructions apart.
+__device__ __forceinline__ void mfma_bf16_vv(f32x16 &acc, i32x4 w, i32x4 b)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+}
+
+template <bool QDIAG, int SPL>
+__global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedArgs a)
+{
+    using I = Bf16Img<SPL>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const KfRunArgs &k = a.kf;
+    const size_t B = (size_t)k.B;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.wpacked);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < I::TOTAL / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float4 *mins4 = reinterpret_cast<const float4 *>(lds + I::MINS);
+    const i32x4 *Wl = reinterpret_cast<const i32x4 *>(lds) + lane;
+
+    const int wbase = blockIdx.x * 256 + (threadIdx.x & ~63);
+    const int b = wbase + lane;
+    const bool live = b < k.B;
+    const int bb = live ? b : k.B - 1;
+    const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
+
+    float x[NS];
+    f2 U[NU];
+    int status = 0;
+    {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        float worst = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i + 1; j < NS; j++) {
+                const float up = buf_load(rP, voff, (i * NS + j) * rowB), lo = buf_load(rP, voff, (j * NS + i) * rowB);
+                worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
+            }
+        status = worst > 0.f ? 8 : 0;
+        sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
+    }
+    float hreg[2][2][16];               // fp32 h_t (AGPR-resident), layout as in v2
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) hreg[rb][c][e] = agpr_put(0.f);
+
+    StepIn in;
+    float acl[6];
+    load_step(k, 0, voff, rowB, in);
+    {
+        rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
+    }
+
+    for (int t = 0; t < k.T; t++) {
+        float z[NM], pw[12], FA[2][KBX][8];        // FA[rb][kb][j]: feature 16 kb + 8 (lane half) + j of trajectory block rb (AGPRs)
+        measurement(in, z);
+        const Rot rot = rotation(x[0], x[1], x[2]);
+        dynamics(x, rot, in.p, in.f, pw, k.k);
+        // k-block kb = features 16 kb .. 16 kb + 15; v_permlane32_swap pairs feature j with feature j + 8 of the block, so that
+        // the first register serves trajectories 0-31 (lanes 0-31: feature j, lanes 32-63: feature j + 8), the second 32-63
+        auto feat8 = [&](int kb, float l0, float l1, float l2, float l3, float l4, float l5, float l6, float l7, float h0, float h1,
+                         float h2, float h3, float h4, float h5, float h6, float h7) {
+            float lo[8] = {l0, l1, l2, l3, l4, l5, l6, l7}, hi[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+#pragma unroll
+            for (int i4 = 0; i4 < 2; i4++) {
+                const float4 ml = mins4[4 * kb + i4], mh = mins4[4 * kb + 2 + i4];
+                lo[4 * i4] -= ml.x; lo[4 * i4 + 1] -= ml.y; lo[4 * i4 + 2] -= ml.z; lo[4 * i4 + 3] -= ml.w;
+                hi[4 * i4] -= mh.x; hi[4 * i4 + 1] -= mh.y; hi[4 * i4 + 2] -= mh.z; hi[4 * i4 + 3] -= mh.w;
+            }
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
+                         "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+                         "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\ts_nop 1"
+                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                           "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) { FA[0][kb][j] = agpr_put(lo[j]); FA[1][kb][j] = agpr_put(hi[j]); }
+        };
+        // feature order [x 0-11 | accel 12-17 | f 18-29 | p_world 30-41 | dp 42-53 | imu 54-59 | 60-63 zero padding]
+        feat8(1, acl[4], acl[5], in.f[0], in.f[1], in.f[2], in.f[3], in.f[4], in.f[5], in.f[6], in.f[7], in.f[8], in.f[9], in.f[10],
+              in.f[11], pw[0], pw[1]);
+        feat8(2, pw[2], pw[3], pw[4], pw[5], pw[6], pw[7], pw[8], pw[9], pw[10], pw[11], in.dp[0], in.dp[1], in.dp[2], in.dp[3],
+              in.dp[4], in.dp[5]);
+        feat8(3, in.dp[6], in.dp[7], in.dp[8], in.dp[9], in.dp[10], in.dp[11], in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
+              in.imu[5], 0.f, 0.f, 0.f, 0.f);
+        cov_predict_sym_blk<QDIAG>(U, rot, k.k);
+        status |= update_sequential_sym(x, U, z, k.k);
+        if (live) {
+            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
+        }
+        feat8(0, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], x[11], acl[0], acl[1], acl[2], acl[3]);
+
+        // ================= GRU cell: one 32-trajectory block at a time, both unit chunks together =================
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float4 *bc = reinterpret_cast<const float4 *>(lds + I::BIAS + c * 128 + lh * 64);
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; v4++) {
+                        const float4 bv = bc[g * 4 + v4];
+                        acc[c][g][4 * v4] = bv.x; acc[c][g][4 * v4 + 1] = bv.y; acc[c][g][4 * v4 + 2] = bv.z; acc[c][g][4 * v4 + 3] = bv.w;
+                    }
+            }
+            // weight fragments of (k-block, gate): 2 chunks x SPL terms, double-buffered one (k-block, gate) ahead
+            i32x4 W[2][2][SPL];
+            auto loadW = [&](int buf, int kb, int g) {
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int sp = 0; sp < SPL; sp++) W[buf][c][sp] = Wl[(c * I::CH) / 4 + ((kb * 3 + g) * SPL + sp) * 64];
+            };
+            loadW(0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < KBT; kb++) {
+                // the 8 fp32 B values of this lane for the k-block, split into SPL bf16 fragments just before use
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    v[j] = agpr_get(kb < KBX ? FA[rb][kb < KBX ? kb : 0][j] : hreg[rb][(kb - KBX) >> 1 & 1][8 * ((kb - KBX) & 1) + j]);
+                i32x4 Bf[SPL];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    uint32_t tt[SPL];
+                    split_pair<SPL>(v[2 * jj], v[2 * jj + 1], tt);
+#pragma unroll
+                    for (int sp = 0; sp < SPL; sp++) Bf[sp][jj] = (int)tt[sp];
+                }
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    const int u = kb * 3 + g, cur = u & 1;
+                    if (u + 1 < KBT * 3) loadW(cur ^ 1, (u + 1) / 3, (u + 1) % 3);
+                    const int gn = g < 2 ? g : (kb < KBX ? 2 : 3);        // input part feeds gi_n, recurrent part gh_n
+                    // (weight term, activation term), largest first; consecutive MFMAs alternate between the two chunks
+                    constexpr int NP = SPL == 3 ? 6 : 3;
+                    constexpr int PW[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+                    constexpr int PW2[3] = {0, 0, 1}, PB2[3] = {0, 1, 0};
+#pragma unroll
+                    for (int pi = 0; pi < NP; pi++) {
+                        const int wt = SPL == 3 ? PW[pi] : PW2[pi], bt = SPL == 3 ? PB[pi] : PB2[pi];
+                        mfma_bf16_vv(acc[0][gn], W[cur][0][wt], Bf[bt]);
+                        mfma_bf16_vv(acc[1][gn], W[cur][1][wt], Bf[bt]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]),
+                         "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+            if (rb == 1) {
+                const int tn = (t + 1 < k.T) ? t + 1 : t;
+                load_step(k, tn, voff, rowB, in);
+                rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
+#pragma unroll
+                for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
+            }
+            // cell update (fp32, as v2): every MFMA of this block is done, so h_t goes straight into its registers
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                f2 *A0 = reinterpret_cast<f2 *>(&acc[c][0]), *A1 = reinterpret_cast<f2 *>(&acc[c][1]), *A2 = reinterpret_cast<f2 *>(&acc[c][2]),
+                   *A3 = reinterpret_cast<f2 *>(&acc[c][3]);
+                const f2 one = {1.0f, 1.0f};
+#pragma unroll
+                for (int e = 0; e < 16; e++) { acc[c][0][e] = __builtin_amdgcn_exp2f(acc[c][0][e]); acc[c][1][e] = __builtin_amdgcn_exp2f(acc[c][1][e]); }
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) { A0[p2] += one; A1[p2] += one; }
+#pragma unroll
+                for (int e = 0; e < 16; e++) { acc[c][0][e] = __builtin_amdgcn_rcpf(acc[c][0][e]); acc[c][1][e] = __builtin_amdgcn_rcpf(acc[c][1][e]); }
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) A2[p2] = fma2(A0[p2], A3[p2], A2[p2]);
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[c][2][e] = __builtin_amdgcn_exp2f(acc[c][2][e]);
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) A2[p2] += one;
+#pragma unroll
+                for (int e = 0; e < 16; e++) { acc[c][2][e] = __builtin_amdgcn_rcpf(acc[c][2][e]); acc[c][3][e] = agpr_get(hreg[rb][c][e]); }
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) A2[p2] = fma2((f2){-2.0f, -2.0f}, A2[p2], one);
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) A3[p2] = A3[p2] - A2[p2];
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) A3[p2] = fma2(A1[p2], A3[p2], A2[p2]);
+#pragma unroll
+                for (int e = 0; e < 16; e++) hreg[rb][c][e] = agpr_put(acc[c][3][e]);
+            }
+        }
+    }
+
+    status |= finite_status(x);
+    if (live) {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+        k.status[b] = status;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const int tr = wbase + 32 * rb + li;
+        if (tr < k.B) {
+            rsrc_t rs = make_rsrc(a.h_last, (uint32_t)H * rowB);
+            const uint32_t vo = (uint32_t)tr * 4u + (uint32_t)(4 * lh) * rowB;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    buf_store(rs, vo, (uint32_t)(32 * c + (e & 3) + 8 * (e >> 2)) * rowB, agpr_get(hreg[rb][c][e]));
+        }
+    }
+}
+
 }  // namespace osf
 
 int os_kf_run_impl(os_ctx *ctx, osk::KfRunArgs &a, uint32_t flags, hipStream_t s);   // kf_kernels.hip
@@ -619,6 +941,42 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
     const bool single_kernel = shapes_ok && !(flags & OS_FUSED_TWO_KERNEL) &&
                                ((flags & OS_FUSED_ONE_KERNEL) || B > 128 * ctx->cu_count);
+    if (flags & OS_FUSED_SPLIT_BF16) {
+        // opt-in reduced-precision gate GEMM (never chosen by default): bf16 split terms on the bf16 MFMA, fp32 accumulate
+        if (!shapes_ok || d.num_layers != 1)
+            return os_fail(ctx, -4, "os_fused_run: OS_FUSED_SPLIT_BF16 needs the single-kernel shapes (60 features, hidden 64, one layer, "
+                                    "diagonal R, sequential + symmetric flags)");
+        const int spl = ctx->tune_bf16_terms == 2 ? 2 : 3;
+        const size_t bytes = spl == 3 ? osf::Bf16Img<3>::BYTES : osf::Bf16Img<2>::BYTES;
+        osf::FusedArgs fa;
+        fa.kf = a; fa.kf.k = ctx->k;
+        fa.fcw = nullptr; fa.fcb = nullptr; fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out; fa.seq_out = nullptr;
+        float *seq0 = nullptr, *seq1 = nullptr, *hlast = nullptr;
+        if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
+        fa.h_last = hlast; fa.nrm = nullptr;
+        if (!ctx->fusedbf_attr_set) {
+            const void *fns[4] = {(const void *)osf::fused_kf_gru_bf16_kernel<true, 3>, (const void *)osf::fused_kf_gru_bf16_kernel<false, 3>,
+                                  (const void *)osf::fused_kf_gru_bf16_kernel<true, 2>, (const void *)osf::fused_kf_gru_bf16_kernel<false, 2>};
+            for (const void *fn : fns)
+                OS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::Bf16Img<3>::BYTES));
+            ctx->fusedbf_attr_set = true;
+        }
+        if (!ctx->fused_img_bf) OS_HIP(ctx, hipMalloc((void **)&ctx->fused_img_bf, osf::Bf16Img<3>::BYTES));
+        if (spl == 3) hipLaunchKernelGGL(osf::fused_pack_bf16_kernel<3>, dim3(64), dim3(256), 0, s, ctx->gru_flat, minmax, (uint32_t *)ctx->fused_img_bf);
+        else hipLaunchKernelGGL(osf::fused_pack_bf16_kernel<2>, dim3(64), dim3(256), 0, s, ctx->gru_flat, minmax, (uint32_t *)ctx->fused_img_bf);
+        fa.wpacked = ctx->fused_img_bf;
+        dim3 grid((B + 255) / 256), block(256);
+        const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, spl == 3 ? "fused_kf_gru_bf16_kernel<3>" : "fused_kf_gru_bf16_kernel<2>");
+        const bool qd = ctx->q_is_diagonal;
+        if (spl == 3 && qd) hipLaunchKernelGGL((osf::fused_kf_gru_bf16_kernel<true, 3>), grid, block, bytes, s, fa);
+        else if (spl == 3) hipLaunchKernelGGL((osf::fused_kf_gru_bf16_kernel<false, 3>), grid, block, bytes, s, fa);
+        else if (qd) hipLaunchKernelGGL((osf::fused_kf_gru_bf16_kernel<true, 2>), grid, block, bytes, s, fa);
+        else hipLaunchKernelGGL((osf::fused_kf_gru_bf16_kernel<false, 2>), grid, block, bytes, s, fa);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
+        return os_gru_head_launch(ctx, B, hlast, fcw, out, s);
+    }
     if (single_kernel && !ctx->tune_fused_v1) {
         // v2: transposed GRU cell, h in registers, scales folded into a per-call LDS image, head as a trailing launch
         osf::FusedArgs fa;

@@ -12,12 +12,16 @@ from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
 
 B, T = int(os.environ.get("AB_B", 65536)), int(os.environ.get("AB_T", 100))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-variants = {}
-for name, env in (("v1", {"OS_FUSED_V1": "1"}), ("v2", {})):
-    os.environ.pop("OS_FUSED_V1", None)
+variants, kw = {}, {}
+for name, env, kws in (("v1", {"OS_FUSED_V1": "1"}, {}), ("v2", {}, {}), ("bf3", {}, {"split_bf16": True}),
+                       ("bf2", {"OS_BF16_TERMS": "2"}, {"split_bf16": True})):
+    for e in ("OS_FUSED_V1", "OS_BF16_TERMS"):
+        os.environ.pop(e, None)
     os.environ.update(env)
     variants[name] = Engine(0)
-os.environ.pop("OS_FUSED_V1", None)
+    kw[name] = kws
+for e in ("OS_FUSED_V1", "OS_BF16_TERMS"):
+    os.environ.pop(e, None)
 d = synth_torch(B, T, "cuda", seed=1)
 c = Engine.contact_soa_to_packed(d["contact"])
 torch.manual_seed(0)
@@ -30,7 +34,7 @@ for e in variants.values():
 for r in range(rounds + 1):
     for name, e in variants.items():
         x = d["x0"].clone(); P = d["P0"].clone()
-        res[name] = e.fused_run(d["p"], d["f"], d["dp"], d["imu"], c, d["accel"], mm, x, P, two_kernel=False)
+        res[name] = e.fused_run(d["p"], d["f"], d["dp"], d["imu"], c, d["accel"], mm, x, P, two_kernel=False, **kw[name])
         torch.cuda.synchronize()
         pr = e.profile_read()
         if r:
@@ -39,8 +43,10 @@ for name in variants:
     v = np.array(ms[name])
     print(f"{name}: kernel {variants[name].kernel_name('fused')}: median {np.median(v):.4f} ms  min {v.min():.4f}  max {v.max():.4f}  "
           f"-> {47616 * B * T / np.median(v) / 1e9:.1f} TFLOP/s = {47616 * B * T / np.median(v) / 1e9 / 157.3:.3f} of fp32 MFMA peak")
-print("v1 vs v2: state max abs diff %.3e, head max abs diff %.3e" % (float((res["v1"]["x_out"] - res["v2"]["x_out"]).abs().max()),
-                                                                      float((res["v1"]["out"] - res["v2"]["out"]).abs().max())))
+for name in variants:
+    if name != "v2":
+        print("%s vs v2: state max abs diff %.3e, head max abs diff %.3e" % (name, float((res[name]["x_out"] - res["v2"]["x_out"]).abs().max()),
+                                                                            float((res[name]["out"] - res["v2"]["out"]).abs().max())))
 from oracle import c_oracle as orc
 idx = torch.randperm(B, generator=torch.Generator().manual_seed(3))[:128].cuda()
 g = lambda k: d[k][:, :, idx].permute(2, 0, 1).double().cpu().numpy()
