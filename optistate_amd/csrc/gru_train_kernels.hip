@@ -17,6 +17,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gru_common.hpp"
 #include "kf_device.hpp"   // buffer addressing helpers
 
@@ -137,7 +139,78 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
     const int nchx = a.need_dx ? (K + 31) / 32 : 0, nchh = H / 32;
     const int Q = 3 * H / 2;                   // gate-unit pairs in the reduction
 
+    // Saved activations of a step, prefetched into registers: the loads of step t-1 are issued right after the barrier that
+    // ends step t's gate-derivative phase and fly underneath its MFMA phase (PMC on the 8192-window step: the waves of this
+    // kernel spent 44 % of their cycles waiting, most of it at the top of every step for these six streams).  Read-once /
+    // write-once streams are non-temporal so that they do not evict the L2-resident weights.
+    constexpr int EL = 32 * RB * 128 / NT;             // elements per thread at H = 128 (fewer iterations for smaller H)
+    constexpr bool PF = EL <= 8;                       // prefetch across the MFMA phase where it fits the register budget (eight waves)
+    const int lgH = 31 - __builtin_clz(H);             // H is 32, 64 or 128: shifts instead of integer division
+    const int nel = BM * H;
+    constexpr int ELP = PF ? EL : 1;
+    float pf_r[ELP], pf_z[ELP], pf_n[ELP], pf_g[ELP], pf_h[ELP], pf_d[ELP];
+    // buffer addressing: one wave-uniform descriptor per stream, ONE 32-bit offset register per element shared by the six
+    // streams (flat 64-bit addresses cost two registers per load in flight: 96 here, which spilled)
+    uint32_t pf_off[ELP];
+#pragma unroll
+    for (int e = 0; e < ELP; e++) {
+        const int i = threadIdx.x + e * NT, ic = i < nel ? i : 0;
+        const int r = ic >> lgH, c = ic & (H - 1), g = row0 + r;
+        pf_off[e] = (uint32_t)(((size_t)(g < a.B ? g : a.B - 1) * H + c) * 4);
+    }
+    auto prefetch = [&](int t) {
+        const uint32_t step = (uint32_t)((size_t)t * B * H * 4), bytes = (uint32_t)((size_t)a.T * B * H * 4);
+        const osk::rsrc_t rr_ = osk::make_rsrc(a.sv_r, bytes), rz_ = osk::make_rsrc(a.sv_z, bytes), rn_ = osk::make_rsrc(a.sv_n, bytes),
+                          rg_ = osk::make_rsrc(a.sv_g, bytes), rh_ = osk::make_rsrc(a.sv_h, bytes),
+                          rd_ = osk::make_rsrc(a.dy ? a.dy : a.sv_r, bytes);
+        const uint32_t hstep = t > 0 ? step - (uint32_t)(B * H * 4) : 0u;
+#pragma unroll
+        for (int e = 0; e < ELP; e++) {
+            pf_r[e] = osk::buf_load_nt(rr_, pf_off[e], step); pf_z[e] = osk::buf_load_nt(rz_, pf_off[e], step);
+            pf_n[e] = osk::buf_load_nt(rn_, pf_off[e], step); pf_g[e] = osk::buf_load_nt(rg_, pf_off[e], step);
+            pf_h[e] = osk::buf_load_nt(rh_, pf_off[e], hstep);
+            pf_d[e] = osk::buf_load_nt(rd_, pf_off[e], step);
+        }
+    };
+    if (PF) prefetch(a.T - 1);
+
     for (int t = a.T - 1; t >= 0; t--) {
+        if constexpr (PF) {
+        // ---- gate derivatives (VALU), coalesced over the hidden index ----
+        {
+            const float *__restrict__ pdl = a.dy_last;
+            float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
+            const bool last = (t == a.T - 1);
+#pragma unroll
+            for (int e = 0; e < ELP; e++) {
+                const int i = threadIdx.x + e * NT;
+                if (i >= nel) continue;
+                const int r = i >> lgH, c = i & (H - 1), g = row0 + r;
+                const bool ok = g < a.B;
+                const int gc = ok ? g : a.B - 1;
+                const float rr = pf_r[e], zz = pf_z[e], nn = pf_n[e], gg = pf_g[e], hp = t > 0 ? pf_h[e] : 0.f;
+                float dht = dh[r * HS + c] + (a.dy ? pf_d[e] : 0.f);
+                if (pdl && last) dht += pdl[(size_t)gc * H + c];
+                if (!ok) dht = 0.f;
+                const float dn = dht * (1.0f - zz);
+                const float dz = dht * (hp - nn);
+                const float dhc = dht * zz;
+                const float dan = dn * (1.0f - nn * nn);
+                const float danr = dan * rr;
+                const float dar = dan * gg * rr * (1.0f - rr);
+                const float daz = dz * zz * (1.0f - zz);
+                if (ok) {
+                    const size_t og = ((size_t)t * B + g) * (3 * H) + c;
+                    __builtin_nontemporal_store(dar, ogi + og); __builtin_nontemporal_store(daz, ogi + og + H);
+                    __builtin_nontemporal_store(dan, ogi + og + 2 * H);
+                    __builtin_nontemporal_store(dar, ogh + og); __builtin_nontemporal_store(daz, ogh + og + H);
+                    __builtin_nontemporal_store(danr, ogh + og + 2 * H);
+                }
+                dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
+                dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
+            }
+        }
+        } else {
         // ---- gate derivatives (VALU), coalesced over the hidden index.  Unrolled 8x with restrict-qualified streams so
         // that the loads of a batch are in flight together; read-once / write-once streams are non-temporal so they do
         // not evict the L2-resident weights ----
@@ -147,8 +220,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                         *__restrict__ pdl = a.dy_last;
             float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
             const bool last = (t == a.T - 1);
-            const int lgH = 31 - __builtin_clz(H);             // H is 32, 64 or 128: shifts instead of integer division
-#pragma unroll 8
+            #pragma unroll 8
             for (int i = threadIdx.x; i < BM * H; i += NT) {
                 const int r = i >> lgH, c = i & (H - 1), g = row0 + r;
                 const bool ok = g < a.B;
@@ -179,7 +251,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                 dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
             }
         }
+        }
         __syncthreads();
+        if (PF && t > 0) prefetch(t - 1);
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
         // work items: output chunks; with need_dx == 0 (layer 0: only the four recurrent chunks) every chunk's reduction is
         // split in two halves so that all eight waves have work, and the halves meet in dh through LDS atomics
@@ -195,43 +269,55 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             for (int rb = 0; rb < RB; rb++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[rb][e] = 0.f;
-            // DEPTH-deep software pipeline: B fragments by buffer loads (wave-uniform descriptor + SGPR offset), A fragments
-            // from the LDS tile; the n-part of the recurrent path reads the r-scaled section of the tile
-            constexpr int DEPTH = 16 / RB;     // one MFMA per k-pair and row block: 16 x 64 cycles cover an L2 round trip
+            // D-deep software pipeline in blocks of D k-pairs: B fragments by buffer loads (wave-uniform descriptor, SGPR block
+            // offset, the position inside the block in the instruction's immediate field), A fragments from the LDS tile with a
+            // per-block base pointer and immediate offsets; the n-part of the recurrent path reads the r-scaled section of the
+            // tile (columns >= 2H shift by H: H is a multiple of D, so a block never straddles that boundary).  No per-k-pair
+            // address arithmetic or bounds tests: the reduction length is a multiple of D by construction (PMC before: 19 VALU
+            // and 36 SALU instructions per MFMA in this loop, on the pipe the fp32 MFMA shares).
             const osk::rsrc_t rw = osk::make_rsrc(wp, (uint32_t)Q * 256u);
             const uint32_t wl = (uint32_t)lane * 4u;
-            float wbf[DEPTH], abf[DEPTH][RB];
-            auto acol = [&](int q) {
-                const int j = 2 * q + lh;
-                return (is_h && j >= 2 * H) ? j + H : j;
-            };
+            const float *arow[RB];
 #pragma unroll
-            for (int d = 0; d < DEPTH; d++) {
-                if (qlo + d < qhi) {
-                    wbf[d] = osk::buf_load(rw, wl, __builtin_amdgcn_readfirstlane((uint32_t)(qlo + d) * 256u));
-                    const int col = acol(qlo + d);
+            for (int rb = 0; rb < RB; rb++) arow[rb] = dG + (rb * 32 + li) * GS + lh;
+            auto run = [&](auto dc) {
+                constexpr int D = decltype(dc)::value;
+                float wbf[D], abf[D][RB];
+                auto fetch = [&](int qb) {                     // k-pairs qb .. qb + D - 1 into the ring
+                    const uint32_t wo = __builtin_amdgcn_readfirstlane((uint32_t)qb * 256u);
+                    const int sh = __builtin_amdgcn_readfirstlane(2 * qb + ((is_h && qb >= H) ? H : 0));
 #pragma unroll
-                    for (int rb = 0; rb < RB; rb++) abf[d][rb] = dG[(rb * 32 + li) * GS + col];
-                }
-            }
-            for (int q0 = qlo; q0 < qhi; q0 += DEPTH) {
+                    for (int d = 0; d < D; d++) {
+                        wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, wo);
 #pragma unroll
-                for (int d = 0; d < DEPTH; d++) {
-                    const int q = q0 + d;
-                    if (q < qhi) {
+                        for (int rb = 0; rb < RB; rb++) abf[d][rb] = arow[rb][sh + 2 * d];
+                    }
+                };
+                fetch(qlo);
+                for (int q0 = qlo; q0 + D < qhi; q0 += D) {
+                    const int qn = q0 + D;
+                    const uint32_t wo = __builtin_amdgcn_readfirstlane((uint32_t)qn * 256u);
+                    const int sh = __builtin_amdgcn_readfirstlane(2 * qn + ((is_h && qn >= H) ? H : 0));
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
 #pragma unroll
                         for (int rb = 0; rb < RB; rb++)
                             acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
-                        if (q + DEPTH < qhi) {
-                            wbf[d] = osk::buf_load(rw, wl, __builtin_amdgcn_readfirstlane((uint32_t)(q + DEPTH) * 256u));
-                            const int col = acol(q + DEPTH);
+                        wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, wo);
 #pragma unroll
-                            for (int rb = 0; rb < RB; rb++) abf[d][rb] = dG[(rb * 32 + li) * GS + col];
-                        }
+                        for (int rb = 0; rb < RB; rb++) abf[d][rb] = arow[rb][sh + 2 * d];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+#pragma unroll
+                for (int d = 0; d < D; d++)
+#pragma unroll
+                    for (int rb = 0; rb < RB; rb++)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
+            };
+            // one MFMA per k-pair and row block: 16 x 64 cycles cover an L2 round trip
+            if (((qhi - qlo) & 15) == 0 && RB == 1) run(std::integral_constant<int, 16>{});
+            else run(std::integral_constant<int, 8>{});
 #pragma unroll
             for (int rb = 0; rb < RB; rb++)
 #pragma unroll
@@ -270,12 +356,16 @@ struct DwArgs {
 // are in flight while tile i feeds 16 x 6 MFMAs per wave), so X is read from L2/HBM once per 4 gate chunks instead of once
 // per chunk; each wave streams its own dG column chunk straight from memory, one step ahead.
 constexpr int DW_TR = 32;            // rows per tile
-constexpr int DW_KMAX = 192;         // input columns held per pass (6 chunks of 32)
 
-// two workgroups per CU for the float4 variant (the scalar-staging fallback needs the full register file)
-template <bool VEC4>
+// two workgroups per CU for the float4 variant (the scalar-staging fallback needs the full register file).
+// NC = 32-column input chunks per pass (accumulators per wave): 6 for the 188-wide first layer, 4 for the 128-wide ones --
+// with a fixed 6 the 128-wide products issued half as many MFMAs again on zero columns (PMC: 2.8 M matrix instructions per
+// launch against 2.0 M algorithmic).
+template <bool VEC4, int NC>
 __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
 {
+    constexpr int DW_KMAX = NC * 32;     // input columns held per pass
+    constexpr int NV4 = DW_TR * DW_KMAX / 4 / 256, NV1 = DW_TR * DW_KMAX / 256;      // staging float4 / floats per thread
     __shared__ __attribute__((aligned(16))) float Xs[2][DW_TR][DW_KMAX];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
     const int j0 = (blockIdx.x * 4 + wave) * 32;
@@ -291,21 +381,21 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
         const uint32_t xr = (uint32_t)(rr - a.x_row_shift);            // row counts are far below 2^32: 32-bit div/mod
         return a.x_btf ? ((size_t)(xr % (uint32_t)a.B) * a.T + xr / (uint32_t)a.B) * (size_t)a.K : (size_t)xr * (size_t)a.K;
     };
-    for (int kc0 = 0; kc0 < nkc; kc0 += 6) {
+    for (int kc0 = 0; kc0 < nkc; kc0 += NC) {
         const int kbase = kc0 * 32, kw = (a.K - kbase) < DW_KMAX ? (a.K - kbase) : DW_KMAX;   // columns of this pass
-        f32x16 acc[6];
+        f32x16 acc[NC];
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < NC; c++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
         // staging registers: 32 rows x 192 columns / 256 threads = 24 floats per thread.  With K % 4 == 0 (every shape the
         // reference uses: 60, 64, 128, 188) a thread moves six float4 -- six row addresses per tile instead of 24 (the address
         // arithmetic was half of this kernel's VALU time, and VALU time is MFMA time lost: they share the pipe)
-        float stg[24];
+        float stg[NV1];
         auto stage_load = [&](int tile) {
             if (VEC4) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
+                for (int i = 0; i < NV4; i++) {
                     const int f4 = threadIdx.x + 256 * i;                           // 0 .. 1535
                     const int row = f4 / (DW_KMAX / 4), col = 4 * (f4 % (DW_KMAX / 4));
                     const size_t rr = r0 + (size_t)tile * DW_TR + row;
@@ -316,7 +406,7 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 24; i++) {
+                for (int i = 0; i < NV1; i++) {
                     const int flat = threadIdx.x + 256 * i;                         // 0 .. 6143
                     const int row = flat / DW_KMAX, col = flat % DW_KMAX;
                     const size_t rr = r0 + (size_t)tile * DW_TR + row;
@@ -328,14 +418,14 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
         auto stage_store = [&](int buf) {
             if (VEC4) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
+                for (int i = 0; i < NV4; i++) {
                     const int f4 = threadIdx.x + 256 * i;
                     *reinterpret_cast<float4 *>(&Xs[buf][f4 / (DW_KMAX / 4)][4 * (f4 % (DW_KMAX / 4))]) =
                         make_float4(stg[4 * i], stg[4 * i + 1], stg[4 * i + 2], stg[4 * i + 3]);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 24; i++) {
+                for (int i = 0; i < NV1; i++) {
                     const int flat = threadIdx.x + 256 * i;
                     Xs[buf][flat / DW_KMAX][flat % DW_KMAX] = stg[i];
                 }
@@ -368,7 +458,7 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
                         const float av = avb[half][st];
                         if (kc0 == 0) bsum += av;
 #pragma unroll
-                        for (int c = 0; c < 6; c++)
+                        for (int c = 0; c < NC; c++)
                             acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Xs[buf][2 * st + kk][c * 32 + li], acc[c], 0, 0, 0);
                         if (st & 1) __builtin_amdgcn_sched_barrier(0);      // keep the 96 LDS reads of a tile from being hoisted (spills)
                     }
@@ -379,7 +469,7 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
         }
         if (jok) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
+            for (int c = 0; c < NC; c++) {
                 const int k = kbase + c * 32 + li;
                 if (k < a.K) {
 #pragma unroll
@@ -445,6 +535,22 @@ __global__ void adam_kernel(size_t n, float *w, const float *g, float *m, float 
 
 using namespace ost;
 
+
+// picks the accumulator count for the input width: the smallest NC in {2, 4, 6} that covers K in one pass, else 6 per pass
+static void launch_dw(const DwArgs &d, int K, dim3 grid, hipStream_t s)
+{
+    const int nkc = (K + 31) / 32;
+    const bool v4 = (K & 3) == 0;
+#define OS_DW(NC)                                                                          \
+    do {                                                                                   \
+        if (v4) hipLaunchKernelGGL((dw_kernel<true, NC>), grid, dim3(256), 0, s, d);        \
+        else hipLaunchKernelGGL((dw_kernel<false, NC>), grid, dim3(256), 0, s, d);          \
+    } while (0)
+    if (nkc <= 2) OS_DW(2);
+    else if (nkc <= 4) OS_DW(4);
+    else OS_DW(6);
+#undef OS_DW
+}
 
 struct os_train_state {
     float *act;   size_t act_floats;     // saved activations: L x 5 x [T][B][H]
@@ -657,16 +763,12 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
             else { d1.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
             const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, s, "dw_kernel");
-            if ((K & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
-            else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), dim3(256), 0, s, d1);
+            launch_dw(d1, K, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), s);
             // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
             DwArgs d2 = d1;
             d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
             d2.dW = gWhh; d2.db = nullptr;
-            if (T > 1) {
-                if ((H & 3) == 0) hipLaunchKernelGGL(dw_kernel<true>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
-                else hipLaunchKernelGGL(dw_kernel<false>, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), dim3(256), 0, s, d2);
-            }
+            if (T > 1) launch_dw(d2, H, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), s);
             os_prof_end(ctx, dslot, s);
             // b_hh: dgh differs from dgi only in the n gate (da_n * r instead of da_n), so the r and z thirds of the two bias
             // gradients are the same sums: copy them from b_ih (complete after the dW_ih launch) and reduce the n third only
