@@ -488,6 +488,128 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
     }
 }
 
+// ---- dw2_kernel: the same reduction with (almost) no address arithmetic in the loop (K % 4 == 0) ----
+// PMC on dw_kernel at the training batch: 7.4 VALU + 3.4 SALU instructions per MFMA (register staging of the X tile with 64-bit
+// addresses, float4 repacking, double-buffer copies), on the pipe the fp32 MFMA shares.  Here:
+//   * the X tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write); a thread's
+//     16-byte pieces sit at fixed (row, column) positions of the tile, computed once; the LDS row pitch is the compile-time
+//     NC * 32 floats, so every B-fragment read is one base register + an immediate offset;
+//   * the dG fragments come through a buffer descriptor over the slice (rows past its end read as zero by the hardware's
+//     range check, which also neutralises whatever the tail tile holds), offset = constant per lane + SGPR;
+//   * the partial tiles are added with buffer atomics (SGPR row offsets).
+// One barrier per 32-row tile; tile i+1's DMA and dG loads fly underneath tile i's 16 x NC MFMAs per wave.
+// (non-template helpers: inside the kernel template hipcc's host pass silently drops the kernel's launch stub when it meets
+// these builtins)
+__device__ __forceinline__ void lds_dma16(const float *g, float *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+__device__ __forceinline__ void buf_atomic_add(float v, osk::rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, voff, soff, 0);
+}
+
+// (Tried and not kept: ONE 768-thread workgroup per CU holding all twelve gate chunks of H = 128, X staged once, cu_count
+// equal slices: 0.226 ms per layer against 0.196 -- twelve waves behind one barrier per tile lose more than the even split wins.)
+template <int NC>
+__global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
+{
+    constexpr int NWV = 4;
+    constexpr int PITCH = NC * 32;                       // floats per LDS row
+    constexpr int PPR = PITCH / 4;                       // 16-byte pieces per LDS row
+    constexpr int NTH = NWV == 12 ? 512 : 256;           // threads that stage X (the first eight waves of the 12-wave form)
+    constexpr int NP = DW_TR * PPR / NTH;                // pieces per staging thread per tile
+    __shared__ __attribute__((aligned(16))) float Xs[2][DW_TR * PITCH + 4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
+    const int j0 = (blockIdx.x * NWV + wave) * 32;
+    const bool jok = j0 < a.H3;
+    const size_t r0 = a.r_begin + (size_t)blockIdx.y * a.rows_per_slice;
+    size_t r1 = r0 + a.rows_per_slice;
+    if (r1 > a.r_end) r1 = a.r_end;
+    if (r0 >= r1) return;
+    const int nkc = (a.K + 31) / 32;
+    const int ntiles = (int)((r1 - r0 + DW_TR - 1) / DW_TR);
+    const uint32_t nrows = (uint32_t)(r1 - r0);
+    // this wave's dG column chunk of the slice: [nrows][H3] starting at row r0; a wave without a chunk reads zeros
+    const osk::rsrc_t rg = osk::make_rsrc(a.dG + r0 * a.H3, jok ? nrows * (uint32_t)a.H3 * 4u : 0u);
+    const uint32_t gl = (uint32_t)(kk * a.H3 + j0 + li) * 4u, grow = (uint32_t)a.H3 * 8u;     // two rows per step
+    float bsum = 0.f;
+    for (int kc0 = 0; kc0 < nkc; kc0 += NC) {
+        const int kbase = kc0 * 32, kw = (a.K - kbase) < PITCH ? (a.K - kbase) : PITCH;       // columns of this pass
+        // fixed tile positions of this thread's pieces; a piece in the padding of a row (or past the slice) re-reads a valid one
+        int prow[NP], pcol[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int p = (threadIdx.x & (NTH - 1)) + NTH * i;
+            prow[i] = p / PPR;
+            const int c4 = 4 * (p % PPR);
+            pcol[i] = kbase + (c4 < kw ? c4 : 0);
+        }
+        auto dma = [&](int tile, int buf) {
+            if (NWV == 12 && wave >= 8) return;          // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                size_t rr = r0 + (size_t)tile * DW_TR + prow[i];
+                if (rr >= r1) rr = r1 - 1;
+                const uint32_t xr = (uint32_t)(rr - a.x_row_shift);
+                const size_t off = a.x_btf ? ((size_t)(xr % (uint32_t)a.B) * a.T + xr / (uint32_t)a.B) * (size_t)a.K : (size_t)xr * (size_t)a.K;
+                // LDS destination: wave-uniform base + lane * 16 (the pieces of one instruction are contiguous in the tile image)
+                lds_dma16(a.X + off + pcol[i], &Xs[buf][(wave * 64 + NTH * i) * 4]);
+            }
+        };
+        f32x16 acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
+        float avb[2][DW_TR / 2];
+        auto dg_load = [&](int tile, float *dst) {
+            const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)tile * (uint32_t)(DW_TR / 2) * grow);
+#pragma unroll
+            for (int st = 0; st < DW_TR / 2; st++) dst[st] = osk::buf_load_nt(rg, gl, so + (uint32_t)st * grow);
+        };
+        const float bw = (kc0 == 0 && a.db) ? 1.0f : 0.0f;          // bias gradient rides along in the first pass
+        auto tile_mfma = [&](int buf, const float *av) {
+            const float *xb = &Xs[buf][kk * PITCH + li];
+#pragma unroll
+            for (int st = 0; st < DW_TR / 2; st++) {
+                bsum = fmaf(av[st], bw, bsum);
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], xb[2 * st * PITCH + c * 32], acc[c], 0, 0, 0);
+                if (st & 1) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of a tile from being hoisted (spills)
+            }
+        };
+        dma(0, 0);
+        dg_load(0, avb[0]);
+        for (int tile = 0; tile < ntiles; tile += 2) {
+            __syncthreads();                                        // tile `tile` landed (vmcnt(0) + barrier); buffer 1 is free
+            if (tile + 1 < ntiles) { dma(tile + 1, 1); dg_load(tile + 1, avb[1]); }
+            tile_mfma(0, avb[0]);
+            if (tile + 1 < ntiles) {
+                __syncthreads();
+                if (tile + 2 < ntiles) { dma(tile + 2, 0); dg_load(tile + 2, avb[0]); }
+                tile_mfma(1, avb[1]);
+            }
+        }
+        if (jok) {
+            const osk::rsrc_t rw = osk::make_rsrc(a.dW, (uint32_t)a.H3 * (uint32_t)a.K * 4u);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int k = kbase + c * 32 + li;
+                if (k < a.K) {
+                    const uint32_t vo = (uint32_t)((4 * kk) * a.K + k) * 4u;
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        buf_atomic_add(acc[c][e], rw, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.K) * 4u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.db && jok) {
+        bsum += __shfl_xor(bsum, 32, 64);            // the two row parities of the same gate unit
+        if (kk == 0) atomicAdd(&a.db[j0 + li], bsum);
+    }
+}
+
 // column sums of columns [n0, N) of a [R][N] row-major matrix into dst (bias gradients): 64 columns x 4 row-lanes per
 // workgroup, 256 rows per workgroup (64 loads per thread, eight in flight), one atomic per column per workgroup
 __global__ void colsum_kernel(size_t R, int N, int n0, const float *src, float *dst)
@@ -543,7 +665,7 @@ static void launch_dw(const DwArgs &d, int K, dim3 grid, hipStream_t s)
     const bool v4 = (K & 3) == 0;
 #define OS_DW(NC)                                                                          \
     do {                                                                                   \
-        if (v4) hipLaunchKernelGGL((dw_kernel<true, NC>), grid, dim3(256), 0, s, d);        \
+        if (v4) hipLaunchKernelGGL((dw2_kernel<NC>), grid, dim3(256), 0, s, d);             \
         else hipLaunchKernelGGL((dw_kernel<false, NC>), grid, dim3(256), 0, s, d);          \
     } while (0)
     if (nkc <= 2) OS_DW(2);
@@ -551,6 +673,7 @@ static void launch_dw(const DwArgs &d, int K, dim3 grid, hipStream_t s)
     else OS_DW(6);
 #undef OS_DW
 }
+
 
 struct os_train_state {
     float *act;   size_t act_floats;     // saved activations: L x 5 x [T][B][H]
@@ -560,7 +683,25 @@ struct os_train_state {
     float *dxy;   size_t dxy_floats;     // dx ping-pong [T][B][max(K,H)] x 2 + dh_T [B][H]
     float *wT;    size_t wT_floats;      // transposed-packed weights
     int B, T;
+    // weight-gradient reductions of layer l run on a side stream underneath the backward sweep of layer l-1 (they only
+    // depend on layer l's gate derivatives): non-blocking stream + events, created on first use
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_sweep[17], ev_dw[17];
+    bool side_ready;
 };
+
+static int train_side_stream(os_ctx *ctx, os_train_state *ts)
+{
+    if (ts->side_ready) return 0;
+    OS_HIP(ctx, hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking));
+    OS_HIP(ctx, hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 17; i++) {
+        OS_HIP(ctx, hipEventCreateWithFlags(&ts->ev_sweep[i], hipEventDisableTiming));
+        OS_HIP(ctx, hipEventCreateWithFlags(&ts->ev_dw[i], hipEventDisableTiming));
+    }
+    ts->side_ready = true;
+    return 0;
+}
 
 static os_train_state *train_state(os_ctx *ctx)
 {
@@ -579,6 +720,12 @@ void os_train_destroy(os_ctx *ctx)
     float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->wT};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
+    if (t->side_ready) {
+        (void)hipStreamSynchronize(t->side);
+        (void)hipStreamDestroy(t->side);
+        (void)hipEventDestroy(t->ev_fork);
+        for (int i = 0; i < 17; i++) { (void)hipEventDestroy(t->ev_sweep[i]); (void)hipEventDestroy(t->ev_dw[i]); }
+    }
     free(t);
     ctx->train = nullptr;
 }
@@ -675,7 +822,9 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     const int H = d.hidden_size, L = d.num_layers, I = d.input_size, C = d.num_classes, H3 = 3 * H;
     const size_t tbh = (size_t)T * B * H, nparam = os_gru_param_count(&d);
     const int Kmax = I > H ? I : H;
-    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, 2 * (size_t)T * B * H3)) return -10;
+    const bool overlap = ctx->tune_train_overlap != 0 && L > 1;
+    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (overlap ? 4 : 2) * (size_t)T * B * H3)) return -10;
+    if (overlap && train_side_stream(ctx, ts)) return -10;
     if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, 2 * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
     // transposed-packed weights (re-done every call: parameters change every optimiser step)
     size_t wT_total = 0;
@@ -711,11 +860,19 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             wo += (size_t)((K + 31) / 32 + H / 32) * (H3 / 2) * 64;
         }
     }
-    float *dgi = ts->dg, *dgh = ts->dg + (size_t)T * B * H3;
     float *dxbuf[2] = {ts->dxy, ts->dxy + (size_t)T * B * Kmax};
     const float *dy = nullptr;
+    hipStream_t sw = overlap ? ts->side : s;             // stream of the weight-gradient kernels
+    if (overlap) {
+        OS_HIP(ctx, hipEventRecord(ts->ev_fork, s));     // the side stream starts behind the memset / head backward
+        OS_HIP(ctx, hipStreamWaitEvent(ts->side, ts->ev_fork, 0));
+    }
     for (int l = L - 1; l >= 0; l--) {
         const int K = l == 0 ? I : H;
+        // gate derivatives: two buffer sets by layer parity when overlapping, so that the sweep of layer l-1 does not
+        // overwrite what the reductions of layer l are still reading; layer l reuses the set of layer l+2
+        float *dgi = ts->dg + (overlap ? (size_t)(l & 1) * 2 * T * B * H3 : 0), *dgh = dgi + (size_t)T * B * H3;
+        if (overlap && l + 2 < L) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[l + 2], 0));
         const float *Wih = w_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
         float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
         {
@@ -753,6 +910,10 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             os_prof_end(ctx, slot, s);
         }
         OS_HIP(ctx, hipGetLastError());
+        if (overlap) {
+            OS_HIP(ctx, hipEventRecord(ts->ev_sweep[l], s));
+            OS_HIP(ctx, hipStreamWaitEvent(sw, ts->ev_sweep[l], 0));
+        }
         // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
         {
@@ -762,25 +923,27 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
             else { d1.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
-            const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, s, "dw_kernel");
-            launch_dw(d1, K, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), s);
+            const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, "dw_kernel");
+            launch_dw(d1, K, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), sw);
             // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
             DwArgs d2 = d1;
             d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
             d2.dW = gWhh; d2.db = nullptr;
-            if (T > 1) launch_dw(d2, H, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), s);
-            os_prof_end(ctx, dslot, s);
+            if (T > 1) launch_dw(d2, H, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), sw);
+            os_prof_end(ctx, dslot, sw);
             // b_hh: dgh differs from dgi only in the n gate (da_n * r instead of da_n), so the r and z thirds of the two bias
             // gradients are the same sums: copy them from b_ih (complete after the dW_ih launch) and reduce the n third only
-            OS_HIP(ctx, hipMemcpyAsync(gbhh, gbih, (size_t)2 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            OS_HIP(ctx, hipMemcpyAsync(gbhh, gbih, (size_t)2 * H * sizeof(float), hipMemcpyDeviceToDevice, sw));
             dim3 cg((H + 63) / 64, (unsigned)((rows + 255) / 256));
-            const int cslot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "colsum_kernel");
-            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, s, rows, H3, 2 * H, dgh, gbhh);
-            os_prof_end(ctx, cslot, s);
+            const int cslot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, sw, "colsum_kernel");
+            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, sw, rows, H3, 2 * H, dgh, gbhh);
+            os_prof_end(ctx, cslot, sw);
             OS_HIP(ctx, hipGetLastError());
+            if (overlap) OS_HIP(ctx, hipEventRecord(ts->ev_dw[l], sw));
         }
         dy = a.dx;
     }
+    if (overlap) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[0], 0));      // join: the side stream is in order
     if (dx_out) {
         // dx of layer 0 is [T][B][I]; the caller's layout is (B, T, I)
         const size_t n = (size_t)B * T * I;

@@ -21,6 +21,7 @@ struct os_ctx {
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
     int tune_dw_rps;                     // rows per dW slice
     int tune_sweep_nw;                   // 0 automatic, 4 / 8 waves per backward-sweep workgroup
+    int tune_train_overlap;              // OS_TRAIN_OVERLAP=0: weight-gradient kernels on the caller's stream (no side stream)
     char err[512];
     // GRU state (owned scratch)
     os_gru_dims gru;
