@@ -32,4 +32,14 @@ __device__ __forceinline__ float tanhf_(float v)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0));
+// in the T-step loops of the layer / sweep kernels each phase ends with dozens of write-once global stores per thread that no
+// thread of the workgroup ever reads back, and waiting for them to land cost 1-2 us per barrier (write latency), twice per step.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 }  // namespace osg

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
                 }
             }
         }
-        __syncthreads();   // h_t complete; every wave is also done with h_{t-1}, which the NEXT epilogue overwrites
+        lds_barrier();   // h_t complete; every wave is also done with h_{t-1}, which the NEXT epilogue overwrites
     }
     const float *hT = hl2 + (a.T & 1) * BM * HS;
     if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
 #pragma unroll
                 for (int e = 0; e < 16; e++) dst[(g * 16 + e) * 64 + lane] = acc[0][g][e];
         }
-        __syncthreads();   // partial sums in place; every wave is done reading h_{t-1}'s A fragments
+        lds_barrier();   // partial sums in place; every wave is done reading h_{t-1}'s A fragments
         if (part == 0) {
 #pragma unroll
             for (int p = 0; p < PARTS - 1; p++) {
@@ -311,21 +311,30 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
                 }
             }
         }
-        __syncthreads();   // h_t complete (and the exchange buffers free again)
+        lds_barrier();   // h_t complete (and the exchange buffers free again)
     }
     const float *hT = hl2 + (a.T & 1) * BM * HS;
     if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
     if (a.h_last) write_back(hT, a.h_last);
 }
 
-// Re-pack one layer's torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order.
-__global__ void gru_pack_kernel(int K, int H, int KPx, int KPh, const float *Wih, const float *Whh, const float *bih,
-                                const float *bhh, float *dst)
+// Re-pack the torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order;
+// all layers in one launch (blockIdx.z = layer): the training step re-packs every optimisation step
+struct PackAll {
+    int n, H;
+    int K[16];
+    const float *Wih[16], *Whh[16], *bih[16], *bhh[16];
+    float *dst[16];
+};
+__global__ void gru_pack_all_kernel(const PackAll a)
 {
-    const int chunk = blockIdx.x;
-    float *d = dst + (size_t)chunk * chunk_floats(KPx, KPh);
+    const int l = blockIdx.z;
+    if (l >= a.n) return;
+    const int K = a.K[l], H = a.H, KPx = (K + 1) / 2, KPh = H / 2, chunk = blockIdx.x;
+    const float *Wih = a.Wih[l], *Whh = a.Whh[l], *bih = a.bih[l], *bhh = a.bhh[l];
+    float *d = a.dst[l] + (size_t)chunk * chunk_floats(KPx, KPh);
     const int nx = KPx * 3 * 64, nh = KPh * 3 * 64;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nx + nh + 128; i += gridDim.y * blockDim.x) {      // grid.y slices the chunk
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nx + nh + 128; i += gridDim.y * blockDim.x) {
         float v;
         if (i < nx + nh) {
             const bool isx = i < nx;
@@ -422,15 +431,18 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
     for (int l = 0; l < d->num_layers; l++) total += os_layer_packed_floats(l == 0 ? d->input_size : H, H);
     if (os_ensure_scratch(ctx, &ctx->gru_packed, &ctx->gru_packed_floats, total)) return -10;
     size_t src = 0, dst = 0;
+    PackAll pa;
+    pa.n = d->num_layers; pa.H = H;
     for (int l = 0; l < d->num_layers; l++) {
         const int K = l == 0 ? d->input_size : H;
-        const float *Wih = w_flat + src, *Whh = Wih + (size_t)3 * H * K, *bih = Whh + (size_t)3 * H * H, *bhh = bih + 3 * H;
-        hipLaunchKernelGGL(gru_pack_kernel, dim3(H / 32, 16), dim3(256), 0, (hipStream_t)stream, K, H, (K + 1) / 2, H / 2,
-                           Wih, Whh, bih, bhh, ctx->gru_packed + dst);
-        OS_HIP(ctx, hipGetLastError());
+        pa.K[l] = K;
+        pa.Wih[l] = w_flat + src; pa.Whh[l] = pa.Wih[l] + (size_t)3 * H * K; pa.bih[l] = pa.Whh[l] + (size_t)3 * H * H; pa.bhh[l] = pa.bih[l] + 3 * H;
+        pa.dst[l] = ctx->gru_packed + dst;
         src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;
         dst += os_layer_packed_floats(K, H);
     }
+    hipLaunchKernelGGL(gru_pack_all_kernel, dim3(H / 32, 16, d->num_layers), dim3(256), 0, (hipStream_t)stream, pa);
+    OS_HIP(ctx, hipGetLastError());
     ctx->gru = *d;
     ctx->gru_flat = w_flat;
     ctx->gru_loaded = true;

@@ -96,12 +96,20 @@ __global__ void head_backward_kernel(int B, int H, int C, int use_sigmoid, const
 // ---- transposed weight packing for the backward MFMAs --------------------------------------------------------
 // W [3H][K] row-major -> for each 32-wide output chunk c (columns of W) and each gate-unit pair q: 64 floats,
 // lane l -> W[2q + (l>>5)][c*32 + (l&31)] (0 beyond K).
-__global__ void pack_T_kernel(int K, int H3, const float *W, float *dst)
+// every layer's W_ih and W_hh in ONE launch (blockIdx.z = matrix): eight ~20 us launches per backward otherwise
+struct PackTAll {
+    int n;
+    int K[32], chunks[32];
+    const float *W[32];
+    float *dst[32];
+};
+__global__ void pack_T_all_kernel(const PackTAll a, int H3)
 {
-    const int chunk = blockIdx.x;
-    const int n = (H3 / 2) * 64;
-    float *d = dst + (size_t)chunk * n;
-    // grid.y slices of the chunk: a handful of workgroups looping over 12 k elements each were pure latency (22 us)
+    const int m = blockIdx.z;
+    if (m >= a.n || (int)blockIdx.x >= a.chunks[m]) return;
+    const int K = a.K[m], chunk = blockIdx.x, n = (H3 / 2) * 64;
+    const float *W = a.W[m];
+    float *d = a.dst[m] + (size_t)chunk * n;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         const int lane = i & 63, q = i >> 6;
         const int j = 2 * q + (lane >> 5), col = chunk * 32 + (lane & 31);
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             }
         }
         }
-        __syncthreads();
+        osg::lds_barrier();
         if (PF && t > 0) prefetch(t - 1);
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
         // work items: output chunks; with need_dx == 0 (layer 0: only the four recurrent chunks) every chunk's reduction is
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                     } else if (g < a.B && c < K) a.dx[((size_t)t * B + g) * K + c] = acc[rb][e];
                 }
         }
-        __syncthreads();
+        osg::lds_barrier();
     }
 }
 
@@ -343,6 +351,7 @@ struct DwArgs {
     int H3, K;                // gate units, input width
     size_t r_begin, r_end;    // rows of dG to reduce (row r of dG pairs with row r - x_row_shift of X)
     size_t x_row_shift;
+    size_t x_valid_from;      // dw2_kernel: rows below this pair with X = 0 (h_{-1}): they only count for the bias sum (multiple of 32)
     int rows_per_slice;
     const float *dG;          // [rows][H3]
     const float *X;           // [rows][K], or (B, T, K) batch_first when x_btf (row r = t*B + b lives at (b*T + t)*K)
@@ -566,27 +575,31 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
             for (int st = 0; st < DW_TR / 2; st++) dst[st] = osk::buf_load_nt(rg, gl, so + (uint32_t)st * grow);
         };
         const float bw = (kc0 == 0 && a.db) ? 1.0f : 0.0f;          // bias gradient rides along in the first pass
-        auto tile_mfma = [&](int buf, const float *av) {
+        // tiles whose rows pair with h_{-1} = 0 (first time step of the recurrent product) only feed the bias sum
+        auto xzero = [&](int tile) { return r0 + (size_t)tile * DW_TR < a.x_valid_from; };
+        auto tile_mfma = [&](int buf, const float *av, bool xz) {
             const float *xb = &Xs[buf][kk * PITCH + li];
 #pragma unroll
+            for (int st = 0; st < DW_TR / 2; st++) bsum = fmaf(av[st], bw, bsum);
+            if (xz) return;
+#pragma unroll
             for (int st = 0; st < DW_TR / 2; st++) {
-                bsum = fmaf(av[st], bw, bsum);
 #pragma unroll
                 for (int c = 0; c < NC; c++)
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], xb[2 * st * PITCH + c * 32], acc[c], 0, 0, 0);
                 if (st & 1) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of a tile from being hoisted (spills)
             }
         };
-        dma(0, 0);
+        if (!xzero(0)) dma(0, 0);
         dg_load(0, avb[0]);
         for (int tile = 0; tile < ntiles; tile += 2) {
             __syncthreads();                                        // tile `tile` landed (vmcnt(0) + barrier); buffer 1 is free
-            if (tile + 1 < ntiles) { dma(tile + 1, 1); dg_load(tile + 1, avb[1]); }
-            tile_mfma(0, avb[0]);
+            if (tile + 1 < ntiles) { if (!xzero(tile + 1)) dma(tile + 1, 1); dg_load(tile + 1, avb[1]); }
+            tile_mfma(0, avb[0], xzero(tile));
             if (tile + 1 < ntiles) {
                 __syncthreads();
-                if (tile + 2 < ntiles) { dma(tile + 2, 0); dg_load(tile + 2, avb[0]); }
-                tile_mfma(1, avb[1]);
+                if (tile + 2 < ntiles) { if (!xzero(tile + 2)) dma(tile + 2, 0); dg_load(tile + 2, avb[0]); }
+                tile_mfma(1, avb[1], xzero(tile + 1));
             }
         }
         if (jok) {
@@ -612,9 +625,12 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
 
 // column sums of columns [n0, N) of a [R][N] row-major matrix into dst (bias gradients): 64 columns x 4 row-lanes per
 // workgroup, 256 rows per workgroup (64 loads per thread, eight in flight), one atomic per column per workgroup
-__global__ void colsum_kernel(size_t R, int N, int n0, const float *src, float *dst)
+// copy_src / copy_n: block (0, 0) also copies copy_n floats copy_src -> dst (the r and z thirds of b_hh's gradient equal b_ih's)
+__global__ void colsum_kernel(size_t R, int N, int n0, const float *src, float *dst, const float *copy_src, int copy_n)
 {
     __shared__ float part[4][64];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && copy_src)
+        for (int i = threadIdx.x; i < copy_n; i += blockDim.x) dst[i] = copy_src[i];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int n = n0 + blockIdx.x * 64 + cx;
     const size_t r0 = (size_t)blockIdx.y * 256, r1 = r0 + 256 < R ? r0 + 256 : R;
@@ -860,6 +876,23 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             wo += (size_t)((K + 31) / 32 + H / 32) * (H3 / 2) * 64;
         }
     }
+    {
+        PackTAll pa;
+        pa.n = 0;
+        int maxch = 1;
+        for (int l = 0; l < L && pa.n + 2 <= 32; l++) {
+            const int K = l == 0 ? I : H;
+            const float *Wih = w_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
+            float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
+            pa.K[pa.n] = K; pa.chunks[pa.n] = (K + 31) / 32; pa.W[pa.n] = Wih; pa.dst[pa.n] = wihT; pa.n++;
+            pa.K[pa.n] = H; pa.chunks[pa.n] = H / 32; pa.W[pa.n] = Whh; pa.dst[pa.n] = whhT; pa.n++;
+            if ((K + 31) / 32 > maxch) maxch = (K + 31) / 32;
+        }
+        const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "pack_T_all_kernel");
+        hipLaunchKernelGGL(pack_T_all_kernel, dim3(maxch, 16, pa.n), dim3(256), 0, s, pa, H3);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+    }
     float *dxbuf[2] = {ts->dxy, ts->dxy + (size_t)T * B * Kmax};
     const float *dy = nullptr;
     hipStream_t sw = overlap ? ts->side : s;             // stream of the weight-gradient kernels
@@ -875,12 +908,6 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         if (overlap && l + 2 < L) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[l + 2], 0));
         const float *Wih = w_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
         float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
-        {
-            const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "pack_T_kernel");
-            hipLaunchKernelGGL(pack_T_kernel, dim3((K + 31) / 32, 16), dim3(256), 0, s, K, H3, Wih, wihT);
-            hipLaunchKernelGGL(pack_T_kernel, dim3(H / 32, 16), dim3(256), 0, s, H, H3, Whh, whhT);
-            os_prof_end(ctx, slot, s);
-        }
         const float *base = act + (size_t)l * 5 * tbh;
         SweepArgs a;
         a.B = B; a.T = T; a.K = K; a.H = H;
@@ -919,7 +946,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         {
             const int rps = ctx->tune_dw_rps;          // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
             DwArgs d1;
-            d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.rows_per_slice = rps;
+            d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.x_valid_from = 0; d1.rows_per_slice = rps;
             d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
             else { d1.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
@@ -929,15 +956,22 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             DwArgs d2 = d1;
             d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
             d2.dW = gWhh; d2.db = nullptr;
-            if (T > 1) launch_dw(d2, H, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), sw);
+            // dw2_kernel (H % 4 == 0) with whole 32-row tiles in the first time step: the launch covers ALL rows, the t = 0 tiles
+            // feed only the bias sum, and b_hh's gradient needs no separate column-sum launch
+            const bool bias_in_dw = (H & 3) == 0 && (B % DW_TR) == 0 && (rps % DW_TR) == 0;
+            if (bias_in_dw) {
+                d2.r_begin = 0; d2.x_valid_from = (size_t)B; d2.db = gbhh;
+                launch_dw(d2, H, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), sw);
+            } else if (T > 1) launch_dw(d2, H, dim3((H3 / 32 + 3) / 4, (unsigned)((rows - B + rps - 1) / rps)), sw);
             os_prof_end(ctx, dslot, sw);
             // b_hh: dgh differs from dgi only in the n gate (da_n * r instead of da_n), so the r and z thirds of the two bias
             // gradients are the same sums: copy them from b_ih (complete after the dW_ih launch) and reduce the n third only
-            OS_HIP(ctx, hipMemcpyAsync(gbhh, gbih, (size_t)2 * H * sizeof(float), hipMemcpyDeviceToDevice, sw));
-            dim3 cg((H + 63) / 64, (unsigned)((rows + 255) / 256));
-            const int cslot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, sw, "colsum_kernel");
-            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, sw, rows, H3, 2 * H, dgh, gbhh);
-            os_prof_end(ctx, cslot, sw);
+            if (!bias_in_dw) {
+                dim3 cg((H + 63) / 64, (unsigned)((rows + 255) / 256));
+                const int cslot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, sw, "colsum_kernel");
+                hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, sw, rows, H3, 2 * H, dgh, gbhh, (const float *)gbih, 2 * H);
+                os_prof_end(ctx, cslot, sw);
+            }
             OS_HIP(ctx, hipGetLastError());
             if (overlap) OS_HIP(ctx, hipEventRecord(ts->ev_dw[l], sw));
         }
