@@ -152,7 +152,10 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
     // kernel spent 44 % of their cycles waiting, most of it at the top of every step for these six streams).  Read-once /
     // write-once streams are non-temporal so that they do not evict the L2-resident weights.
     constexpr int EL = 32 * RB * 128 / NT;             // elements per thread at H = 128 (fewer iterations for smaller H)
-    constexpr bool PF = EL <= 8;                       // prefetch across the MFMA phase where it fits the register budget (eight waves)
+#ifndef OS_SWEEP_PF
+#define OS_SWEEP_PF 1
+#endif
+    constexpr bool PF = OS_SWEEP_PF && EL <= 8;        // prefetch across the MFMA phase where it fits the register budget (eight waves)
     const int lgH = 31 - __builtin_clz(H);             // H is 32, 64 or 128: shifts instead of integer division
     const int nel = BM * H;
     constexpr int ELP = PF ? EL : 1;
