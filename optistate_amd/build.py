@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -5,14 +5,14 @@
 // definition of that release -- parity UNPINNED, checked only against this repo's own float64
 // restatement (oracle/vit_oracle.py).
 //
-// Dense projections ([N*197 x 128] x [128 x 384/128/512], [.. x 512] x [512 x 128], patch embedding [N*196 x 256] x
-// [256 x 128]) are plain library GEMMs -> rocBLAS sgemm.  Hand-written here: patch extraction, token assembly (+cls,
-// +pos), LayerNorm, per-(image, head) attention with K/V in LDS and an online softmax per query lane, bias+GELU,
-// bias+residual, final LayerNorm+sigmoid of the cls token.
+// Everything on the path is a hand-written gfx950 kernel: the dense projections ([N*197 x 128] x [128 x 384/128/512],
+// [.. x 512] x [512 x 128], patch embedding [N*196 x 256] x [256 x 128]) run on ONE fp32-MFMA GEMM kernel with fused
+// prologue / epilogues (vit_gemm_kernel: patch extraction while staging, bias, bias + GELU, bias + residual, patch bias +
+// position table); LayerNorm, per-(image, head) attention on the matrix cores, and the final LayerNorm + sigmoid of the cls
+// token are separate kernels.  No vendor BLAS.
 #include "launch.hpp"
 
 #include <math.h>
-#include <rocblas/rocblas.h>
 
 namespace osv {
 
@@ -20,33 +20,6 @@ struct VitDims { int img, patch, dim, depth, heads, mlp; };
 
 __host__ __device__ inline int grid_of(const VitDims &d) { return d.img / d.patch; }
 __host__ __device__ inline int ntok(const VitDims &d) { return grid_of(d) * grid_of(d) + 1; }
-
-// images [N][img][img] -> patches [N*G*G][patch*patch] (row = one patch, pixel order (py, px) as Conv2d flattens it)
-__global__ void patchify_kernel(int N, VitDims d, const float *img, float *out)
-{
-    const int G = grid_of(d), PP = d.patch * d.patch;
-    const size_t total = (size_t)N * G * G * PP;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int pix = i % PP;
-        const size_t pr = i / PP;
-        const int gx = pr % G, gy = (pr / G) % G;
-        const size_t n = pr / ((size_t)G * G);
-        const int py = pix / d.patch, px = pix % d.patch;
-        out[i] = img[(n * d.img + (size_t)gy * d.patch + py) * d.img + (size_t)gx * d.patch + px];
-    }
-}
-
-// X [N][L][D]: row 0 = cls + pos[0]; row 1+i = tok[n][i] + patch_b + pos[1+i]   (transformer_model.py:115-123)
-__global__ void assemble_kernel(int N, int L, int D, const float *tok, const float *patch_b, const float *cls, const float *pos,
-                                float *X)
-{
-    const size_t total = (size_t)N * L * D;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = i % D, l = (i / D) % L;
-        const size_t n = i / ((size_t)L * D);
-        X[i] = (l == 0 ? cls[c] : tok[(n * (L - 1) + (l - 1)) * D + c] + patch_b[c]) + pos[(size_t)l * D + c];
-    }
-}
 
 // LayerNorm over rows of D (D <= 256, one wave per row, eps 1e-5)
 __global__ void layernorm_kernel(size_t M, int D, const float *X, const float *w, const float *b, float *Y, size_t x_stride)
@@ -69,7 +42,7 @@ __global__ void layernorm_kernel(size_t M, int D, const float *X, const float *w
     for (int j = 0; j < 4; j++) { const int c = lane + 64 * j; if (c < D) Y[row * D + c] = (v[j] - mean) * rstd * w[c] + b[c]; }
 }
 
-// Attention for one (image, head): QKV rows [L][3D] (+bias), head h owns columns h*hd..; K and V of the head staged in LDS,
+// Attention for one (image, head): QKV rows [L][3D] (bias already added by the projection's epilogue), head h owns columns h*hd..; K and V of the head staged in LDS,
 // one query per lane with an online softmax; output O[row][h*hd + :].  hd <= 64.
 template <int HD>
 __global__ void attention_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
@@ -80,15 +53,15 @@ __global__ void attention_kernel(int L, int D, int heads, const float *QKV, cons
     const float *base = QKV + (size_t)n * L * 3 * D;
     for (int i = threadIdx.x; i < L * HD; i += blockDim.x) {
         const int l = i / HD, c = i % HD;
-        Ks[l * (HD + 1) + c] = base[(size_t)l * 3 * D + D + h * HD + c] + qkv_b[D + h * HD + c];
-        Vs[l * (HD + 1) + c] = base[(size_t)l * 3 * D + 2 * D + h * HD + c] + qkv_b[2 * D + h * HD + c];
+        Ks[l * (HD + 1) + c] = base[(size_t)l * 3 * D + D + h * HD + c];
+        Vs[l * (HD + 1) + c] = base[(size_t)l * 3 * D + 2 * D + h * HD + c];
     }
     __syncthreads();
     const float scale = rsqrtf((float)HD);
     for (int qi = threadIdx.x; qi < L; qi += blockDim.x) {
         float q[HD], acc[HD];
 #pragma unroll
-        for (int c = 0; c < HD; c++) { q[c] = (base[(size_t)qi * 3 * D + h * HD + c] + qkv_b[h * HD + c]) * scale; acc[c] = 0.f; }
+        for (int c = 0; c < HD; c++) { q[c] = base[(size_t)qi * 3 * D + h * HD + c] * scale; acc[c] = 0.f; }
         float mx = -3.0e38f, den = 0.f;
         for (int l = 0; l < L; l++) {
             float s = 0.f;
@@ -128,15 +101,13 @@ __global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, in
     // it dominated the kernel)
     {
         const int c4 = (threadIdx.x & 7) * 4;                       // 8 float4 per 32-wide head row
-        const float4 kb = *reinterpret_cast<const float4 *>(qkv_b + D + h * ATT_HD + c4);
-        const float4 vb = *reinterpret_cast<const float4 *>(qkv_b + 2 * D + h * ATT_HD + c4);
 #pragma unroll 4
         for (int l = threadIdx.x >> 3; l < L; l += 32) {
             const float4 kv = *reinterpret_cast<const float4 *>(base + (size_t)l * 3 * D + D + h * ATT_HD + c4);
             const float4 vv = *reinterpret_cast<const float4 *>(base + (size_t)l * 3 * D + 2 * D + h * ATT_HD + c4);
             float *kd = Ks + l * ATT_KS + c4, *vd = Vs + l * ATT_KS + c4;
-            kd[0] = kv.x + kb.x; kd[1] = kv.y + kb.y; kd[2] = kv.z + kb.z; kd[3] = kv.w + kb.w;
-            vd[0] = vv.x + vb.x; vd[1] = vv.y + vb.y; vd[2] = vv.z + vb.z; vd[3] = vv.w + vb.w;
+            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+            vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
         }
     }
     __syncthreads();
@@ -148,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, in
         float qa[ATT_HD / 2];
 #pragma unroll
         for (int q = 0; q < ATT_HD / 2; q++)
-            qa[q] = (base[(size_t)qrow * 3 * D + h * ATT_HD + 2 * q + lh] + qkv_b[h * ATT_HD + 2 * q + lh]) * scale;
+            qa[q] = base[(size_t)qrow * 3 * D + h * ATT_HD + 2 * q + lh] * scale;
         // S tiles; the 16 K fragments of tile jt+1 are requested from LDS before the 16 MFMAs of tile jt issue
         f32x16v S[NT];
         float kb[2][ATT_HD / 2];
@@ -231,20 +202,169 @@ __global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, in
     }
 }
 
-// X += P + bias
-__global__ void bias_residual_kernel(size_t total, int D, const float *P, const float *bias, float *X)
+// ---- vit_gemm_kernel: C[M x N] = A[M x K] . W[N x K]^T on v_mfma_f32_32x32x2_f32 (exact fp32) with fused ends -----------------
+// Workgroup = 4 waves = a 128-row x 128-column tile; wave w owns column chunk w (32 columns) for all four 32-row blocks
+// (64 accumulator registers).  A is staged 128 columns at a time (K = 128: once; 256 / 512: two / four chunks, accumulators
+// kept) by LDS-DMA with the 16-byte slots of a row XOR-swizzled by (row & 7): the fragment read of 32 rows at one column is
+// 4-way instead of 32-way conflicted (the DMA destination must stay linear, so the swizzle is applied to the SOURCE
+// address and again on the read).  W is packed once per os_vit_load into B-fragment order (column chunk, k-pair, lane) and
+// streamed from L2 by coalesced buffer loads with an 8-deep software pipeline -- the layer kernel's scheme.  Two
+// workgroups per CU (64 KB LDS, <= 128 VGPRs) cover each other's staging.
+// SRC: 0 row-major A [M][lda]; 1 patches taken straight from the images (row = (frame, gy, gx), column = 16 py + px).
+// EPI: 0 C = acc + bias; 1 C = gelu(acc + bias) (exact erf form); 2 X += acc + bias (residual, in place);
+//      3 X[frame*L + 1 + p] = acc + bias + pos[1 + p] (patch embedding into the token matrix).
+struct GemmArgs {
+    size_t M;
+    int N, K, lda;
+    const float *A;            // SRC 0
+    const float *img;          // SRC 1: [frames][img][img]
+    int img_size, grid, patch; // SRC 1
+    const float *Wp;           // packed weights
+    const float *bias;         // [N]
+    float *C;                  // EPI 0/1: [M][N]; EPI 2/3: the token matrix X
+    const float *pos;          // EPI 3: [L][N]
+    int L;                     // EPI 3
+};
+
+constexpr int GM_BM = 128, GM_KC = 128;
+
+__device__ __forceinline__ void vit_lds_dma16(const float *g, float *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+__global__ void vit_pack_w_kernel(int N, int K, const float *W, float *dst)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        X[i] += P[i] + bias[i % D];
+    // dst[(c * K/2 + q) * 64 + lane] = W[c*32 + (lane & 31)][2q + (lane >> 5)]
+    const size_t total = (size_t)N * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        const size_t cq = i >> 6;
+        const int q = cq % (K / 2), c = cq / (K / 2);
+        dst[i] = W[(size_t)(c * 32 + (lane & 31)) * K + 2 * q + (lane >> 5)];
+    }
 }
 
-// H = gelu(H + bias), exact erf form (nn.GELU default of that release)
-__global__ void bias_gelu_kernel(size_t total, int D, const float *bias, float *Hm)
+// GELU in its exact erf form (nn.GELU default of that release) with erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, on
+// the hardware exp2 / rcp): ~15 VALU instructions instead of the ~40 of ocml's erff, which in a GEMM epilogue at two waves
+// per SIMD cost as much as the tile's MFMAs.
+__device__ __forceinline__ float gelu_erf(float v)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = Hm[i] + bias[i % D];
-        Hm[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    const float z = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erfz = fmaf(-poly, __builtin_amdgcn_exp2f(-1.44269504088896341f * z * z), 1.0f);
+    return 0.5f * v * (1.0f + copysignf(erfz, v));
+}
+
+template <int SRC, int EPI>
+__global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float As[GM_BM * GM_KC];          // 64 KB, rows of 32 swizzled 16-byte slots
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
+    const size_t row0 = (size_t)blockIdx.y * GM_BM;
+    const int chunk = blockIdx.x * 4 + wave;                                  // 32-column chunk of this wave
+    const bool cok = chunk * 32 < a.N;
+    const int KP = a.K / 2;
+    const osk::rsrc_t rw = osk::make_rsrc(a.Wp + (size_t)chunk * KP * 64, cok ? (uint32_t)KP * 256u : 0u);
+    const uint32_t wl = (uint32_t)lane * 4u;
+    // this thread's 16 staging pieces of a chunk: piece p = threadIdx.x + 256 i -> LDS row p / 32, slot p % 32, which receives
+    // the source slot (p % 32) ^ (row & 7)
+    f32x16v acc[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[rb][e] = 0.f;
+    for (int kc = 0; kc < a.K; kc += GM_KC) {
+        if (kc) __syncthreads();                                              // everyone is done reading the previous chunk
+        {
+            // piece p = threadIdx.x + 256 i sits in LDS row (threadIdx.x >> 5) + 8 i: the swizzled slot and the in-row offset are
+            // the same for all 16 pieces of a thread, the row advances by a wave-uniform stride
+            const int r_lo = threadIdx.x >> 5, slot = (threadIdx.x & 31) ^ (r_lo & 7), k = kc + 4 * slot;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                size_t row = row0 + r_lo + 8 * i;
+                const float *src;
+                if (SRC == 0) {
+                    const float *rowbase = a.A + (row0 + 8 * i) * (size_t)a.lda;        // wave-uniform
+                    src = rowbase + (size_t)r_lo * a.lda + k;
+                    if (row >= a.M) src = a.A + (a.M - 1) * (size_t)a.lda + k;
+                } else {
+                    if (row >= a.M) row = a.M - 1;
+                    const int G = a.grid, P = a.patch;                            // column k = P py + px of the patch
+                    const uint32_t m = (uint32_t)row, gx = m % G, gy = (m / G) % G, n = m / (G * G);
+                    src = a.img + ((size_t)n * a.img_size + gy * P + (k / P)) * a.img_size + gx * P + (k % P);
+                }
+                vit_lds_dma16(src, &As[(wave * 64 + 256 * i) * 4]);
+            }
+        }
+        __syncthreads();                                                      // vmcnt(0) + barrier: the chunk has landed
+        // Fully unrolled over the chunk's 64 k-pairs with an 8-deep ring: W fragments from L2 (descriptor + SGPR chunk offset +
+        // immediate), A fragments from LDS.  Element (row r, column c) of the chunk sits in 16-byte slot (c >> 2) ^ (r & 7) of row
+        // r; for k-pair q this lane needs column 2q + lh of rows rb*32 + li: slot (q >> 1) ^ (li & 7).  Only the low three slot bits
+        // depend on the lane, so eight per-lane base addresses (one per value of (q >> 1) & 7) plus immediates cover every
+        // fragment read of the kernel: no address arithmetic inside the MFMA stream.
+        constexpr int D8 = 8;
+        float wbf[D8], abf[D8][4];
+        const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(kc / 2) * 256u);
+        const float *lo8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) lo8[j] = As + li * GM_KC + ((j ^ (li & 7)) << 2) + lh;
+#define VIT_AFRAG(q, rb) lo8[((q) >> 1) & 7][(rb) * 32 * GM_KC + (((q) >> 1) >> 3) * 32 + ((q) & 1) * 2]
+#pragma unroll
+        for (int d = 0; d < D8; d++) {
+            wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, wbase);
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) abf[d][rb] = VIT_AFRAG(d, rb);
+        }
+#pragma unroll
+        for (int q = 0; q < GM_KC / 2; q++) {
+            const int d = q & (D8 - 1);
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
+            if (q + D8 < GM_KC / 2) {
+                wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, wbase);
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) abf[d][rb] = VIT_AFRAG(q + D8, rb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef VIT_AFRAG
     }
+    if (!cok) return;
+    // Epilogue through a buffer descriptor over the output: offset = per-lane constant + SGPR row offset, rows past M fall
+    // outside the descriptor's range and are dropped by the hardware (no per-element address arithmetic or bounds test).
+    const int col = chunk * 32 + li;
+    const float bv = a.bias[col];
+    if (EPI == 3) {
+        const uint32_t np = (uint32_t)(a.L - 1);
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const size_t row = row0 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row >= a.M) continue;
+                const uint32_t m = (uint32_t)row, n = m / np, pch = m % np;
+                a.C[((size_t)n * a.L + 1 + pch) * a.N + col] = acc[rb][e] + bv + a.pos[(size_t)(1 + pch) * a.N + col];
+            }
+        return;
+    }
+    const osk::rsrc_t rc = osk::make_rsrc(a.C, (uint32_t)(a.M * (size_t)a.N * 4));
+    const uint32_t vo = (uint32_t)((4 * lh) * a.N + col) * 4u, rowb = (uint32_t)a.N * 4u;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rb * 32 + (e & 3) + 8 * (e >> 2)) * rowb);
+            float v = acc[rb][e] + bv;
+            if (EPI == 1) v = gelu_erf(v);
+            if (EPI == 2) v += osk::buf_load(rc, vo, so);
+            osk::buf_store(rc, vo, so, v);
+        }
+}
+
+// row 0 of every frame: cls token + pos[0]   (transformer_model.py:119-123)
+__global__ void cls_row_kernel(int N, int L, int D, const float *cls, const float *pos, float *X)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * D) X[(size_t)(i / D) * L * D + (i % D)] = cls[i % D] + pos[i % D];
 }
 
 // latent[n] = sigmoid(LN(X[n][0]))   (transformer_model.py:127-133)
@@ -278,7 +398,7 @@ using namespace osv;
 struct os_vit_state {
     VitDims d;
     const float *w;          // caller-owned flat weights
-    rocblas_handle blas;
+    float *wp; size_t wp_floats;       // every projection matrix re-packed into B-fragment order (vit_pack_w_kernel)
     float *buf; size_t buf_floats;
     bool att_attr_set;
 };
@@ -296,19 +416,18 @@ void os_vit_destroy(os_ctx *ctx)
     os_vit_state *v = (os_vit_state *)ctx->vit;
     if (!v) return;
     if (v->buf) (void)hipFree(v->buf);
-    rocblas_destroy_handle(v->blas);
+    if (v->wp) (void)hipFree(v->wp);
     free(v);
     ctx->vit = nullptr;
 }
 
-// C[M x N] (row-major) = A[M x K] (row-major) . W[N x K]^T (row-major)
-static int gemm_nt(os_ctx *ctx, os_vit_state *v, size_t M, int N, int K, const float *A, const float *W, float *Cm)
+template <int SRC, int EPI>
+static void launch_gemm(os_ctx *ctx, const GemmArgs &g, hipStream_t s, const char *name)
 {
-    const float alpha = 1.0f, beta = 0.0f;
-    if (rocblas_sgemm(v->blas, rocblas_operation_transpose, rocblas_operation_none, N, (int)M, K, &alpha, W, K, A, K, &beta, Cm, N) !=
-        rocblas_status_success)
-        return os_fail(ctx, -20, "rocblas_sgemm failed (ViT)");
-    return 0;
+    dim3 grid((g.N + 127) / 128, (unsigned)((g.M + GM_BM - 1) / GM_BM));
+    const int slot = os_prof_begin(ctx, OS_PHASE_VIT_GEMM, s, name);
+    hipLaunchKernelGGL((vit_gemm_kernel<SRC, EPI>), grid, dim3(256), 0, s, g);
+    os_prof_end(ctx, slot, s);
 }
 
 extern "C" {
@@ -327,15 +446,37 @@ int os_vit_load(os_ctx *ctx, const os_vit_dims *d, const float *w_flat)
         return os_fail(ctx, -4, "os_vit_load: unsupported dimensions (embed_dim <= 256, one input channel)");
     const int hd = d->embed_dim / d->num_heads;
     if (hd != 32 && hd != 64) return os_fail(ctx, -4, "os_vit_load: head dimension must be 32 or 64");
+    if (d->embed_dim % 128 || d->mlp_hidden % 128 || (d->patch_size * d->patch_size) % 128 || d->patch_size % 4)
+        return os_fail(ctx, -4, "os_vit_load: embed_dim, mlp_hidden and patch_size^2 must be multiples of 128 (GEMM k-chunk)");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     os_vit_state *v = (os_vit_state *)ctx->vit;
     if (!v) {
         v = (os_vit_state *)calloc(1, sizeof(os_vit_state));
-        if (!v || rocblas_create_handle(&v->blas) != rocblas_status_success) { free(v); return os_fail(ctx, -13, "os_vit_load: no rocBLAS handle"); }
+        if (!v) return os_fail(ctx, -13, "os_vit_load: out of memory");
         ctx->vit = v;
     }
     v->d = VitDims{d->img_size, d->patch_size, d->embed_dim, d->depth, d->num_heads, d->mlp_hidden};
     v->w = w_flat;
+    // re-pack the projection matrices once (inference weights are static): [patch | per block: qkv, proj, fc1, fc2]
+    const size_t D = d->embed_dim, PP = (size_t)d->patch_size * d->patch_size, L = ntok(v->d), Mh = d->mlp_hidden;
+    const size_t total = D * PP + (size_t)d->depth * (3 * D * D + D * D + 2 * Mh * D);
+    if (os_ensure_scratch(ctx, &v->wp, &v->wp_floats, total)) return -10;
+    auto pack = [&](int N, int K, const float *W, float *dst) {
+        hipLaunchKernelGGL(vit_pack_w_kernel, dim3(256), dim3(256), 0, 0, N, K, W, dst);
+    };
+    const float *w = w_flat;
+    float *o = v->wp;
+    pack((int)D, (int)PP, w, o); o += D * PP; w += D * PP + D + D + L * D;
+    for (int blk = 0; blk < d->depth; blk++) {
+        w += 2 * D;
+        pack((int)(3 * D), (int)D, w, o); o += 3 * D * D; w += 3 * D * D + 3 * D;
+        pack((int)D, (int)D, w, o); o += D * D; w += D * D + D;
+        w += 2 * D;
+        pack((int)Mh, (int)D, w, o); o += Mh * D; w += Mh * D + Mh;
+        pack((int)D, (int)Mh, w, o); o += D * Mh; w += D * Mh + D;
+    }
+    OS_HIP(ctx, hipGetLastError());
+    OS_HIP(ctx, hipStreamSynchronize(0));
     return 0;
 }
 
@@ -347,38 +488,48 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
     if (N <= 0 || !images || !latent) return os_fail(ctx, -2, "os_vit_encode: bad argument");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    rocblas_set_stream(v->blas, s);
     const VitDims &d = v->d;
     const int D = d.dim, L = ntok(d), G = grid_of(d), PP = d.patch * d.patch, Mh = d.mlp, hd = D / d.heads;
     const size_t M = (size_t)N * L, Mp = (size_t)N * G * G;
-    // scratch: X [M][D] | Y [M][D] | tmp [M][D] | big [M][max(3D, mlp)] | patches [Mp][PP] | tok [Mp][D]
+    // scratch: X [M][D] (token matrix) | Y [M][D] | big [M][max(3D, mlp)]
     const size_t bigw = (size_t)(3 * D > Mh ? 3 * D : Mh);
-    const size_t need = M * D * 3 + M * bigw + Mp * PP + Mp * D;
+    const size_t need = M * D * 2 + M * bigw;
     if (os_ensure_scratch(ctx, &v->buf, &v->buf_floats, need)) return -10;
-    float *X = v->buf, *Y = X + M * D, *tmp = Y + M * D, *big = tmp + M * D;
-    float *patches = big + M * bigw, *tok = patches + Mp * PP;
-    // weights
+    float *X = v->buf, *Y = X + M * D, *big = Y + M * D;
     const float *w = v->w;
-    const float *patch_w = w; w += (size_t)D * PP;
-    const float *patch_b = w; w += D;
-    const float *cls = w; w += D;
-    const float *pos = w; w += (size_t)L * D;
-    const int TB = 256, GB = 4096;
-    hipLaunchKernelGGL(patchify_kernel, dim3(GB), dim3(TB), 0, s, N, d, images, patches);
-    if (gemm_nt(ctx, v, Mp, D, PP, patches, patch_w, tok)) return -20;
-    hipLaunchKernelGGL(assemble_kernel, dim3(GB), dim3(TB), 0, s, N, L, D, tok, patch_b, cls, pos, X);
+    const float *wp = v->wp;
+    const float *patch_b = w + (size_t)D * PP, *cls = patch_b + D, *pos = cls + D;
+    w = pos + (size_t)L * D;
+    GemmArgs g;
+    g.img = images; g.img_size = d.img; g.grid = G; g.pos = pos; g.L = L; g.A = nullptr; g.lda = 0;
+    // patch embedding straight from the images into the token matrix (+ patch bias + position table); cls rows beside it
+    g.M = Mp; g.N = D; g.K = PP; g.Wp = wp; g.bias = patch_b; g.C = X;
+    g.patch = d.patch;
+    launch_gemm<1, 3>(ctx, g, s, "vit_gemm_kernel<patch,+pos>");
+    wp += (size_t)D * PP;
+    {
+        const int slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "cls_row_kernel");
+        hipLaunchKernelGGL(cls_row_kernel, dim3((N * D + 255) / 256), dim3(256), 0, s, N, L, D, cls, pos, X);
+        os_prof_end(ctx, slot, s);
+    }
     OS_HIP(ctx, hipGetLastError());
+    g.M = M;
     for (int blk = 0; blk < d.depth; blk++) {
         const float *ln1w = w; w += D; const float *ln1b = w; w += D;
-        const float *qkvw = w; w += (size_t)3 * D * D; const float *qkvb = w; w += 3 * D;
-        const float *projw = w; w += (size_t)D * D; const float *projb = w; w += D;
+        w += (size_t)3 * D * D; const float *qkvb = w; w += 3 * D;
+        w += (size_t)D * D; const float *projb = w; w += D;
         const float *ln2w = w; w += D; const float *ln2b = w; w += D;
-        const float *fc1w = w; w += (size_t)Mh * D; const float *fc1b = w; w += Mh;
-        const float *fc2w = w; w += (size_t)D * Mh; const float *fc2b = w; w += D;
+        w += (size_t)Mh * D; const float *fc1b = w; w += Mh;
+        w += (size_t)D * Mh; const float *fc2b = w; w += D;
+        int slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
         hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln1w, ln1b, Y, (size_t)D);
-        if (gemm_nt(ctx, v, M, 3 * D, D, Y, qkvw, big)) return -20;
+        os_prof_end(ctx, slot, s);
+        g.A = Y; g.lda = D; g.N = 3 * D; g.K = D; g.Wp = wp; g.bias = qkvb; g.C = big;
+        launch_gemm<0, 0>(ctx, g, s, "vit_gemm_kernel<+bias>");
+        wp += (size_t)3 * D * D;
         const size_t alds = (size_t)2 * L * (hd + 1) * sizeof(float);
         const int ntl = (L + 31) / 32;
+        slot = os_prof_begin(ctx, OS_PHASE_VIT_ATTN, s, (hd == 32 && ntl == 7) ? "attention_mfma_kernel<7>" : "attention_kernel");
         if (hd == 32 && ntl == 7) {              // the reference's shape: 197 tokens, head_dim 32 -> matrix cores
             const size_t mlds = ((size_t)2 * L * 33 + 4 * 32 * 33) * sizeof(float);
             if (!v->att_attr_set) {
@@ -388,17 +539,25 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
             hipLaunchKernelGGL(attention_mfma_kernel<7>, dim3(N * d.heads), dim3(256), mlds, s, L, D, d.heads, big, qkvb, Y);
         } else if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         else hipLaunchKernelGGL(attention_kernel<64>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
-        if (gemm_nt(ctx, v, M, D, D, Y, projw, tmp)) return -20;
-        hipLaunchKernelGGL(bias_residual_kernel, dim3(GB), dim3(TB), 0, s, M * D, D, tmp, projb, X);
+        os_prof_end(ctx, slot, s);
+        g.A = Y; g.lda = D; g.N = D; g.K = D; g.Wp = wp; g.bias = projb; g.C = X;
+        launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
+        wp += (size_t)D * D;
+        slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
         hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln2w, ln2b, Y, (size_t)D);
-        if (gemm_nt(ctx, v, M, Mh, D, Y, fc1w, big)) return -20;
-        hipLaunchKernelGGL(bias_gelu_kernel, dim3(GB), dim3(TB), 0, s, M * Mh, Mh, fc1b, big);
-        if (gemm_nt(ctx, v, M, D, Mh, big, fc2w, tmp)) return -20;
-        hipLaunchKernelGGL(bias_residual_kernel, dim3(GB), dim3(TB), 0, s, M * D, D, tmp, fc2b, X);
+        os_prof_end(ctx, slot, s);
+        g.A = Y; g.lda = D; g.N = Mh; g.K = D; g.Wp = wp; g.bias = fc1b; g.C = big;
+        launch_gemm<0, 1>(ctx, g, s, "vit_gemm_kernel<+bias,gelu>");
+        wp += (size_t)Mh * D;
+        g.A = big; g.lda = Mh; g.N = D; g.K = Mh; g.Wp = wp; g.bias = fc2b; g.C = X;
+        launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
+        wp += (size_t)D * Mh;
         OS_HIP(ctx, hipGetLastError());
     }
     const float *nw = w; w += D; const float *nb = w;
+    const int slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "cls_head_kernel");
     hipLaunchKernelGGL(cls_head_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, L, D, X, nw, nb, latent);
+    os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }
