@@ -164,19 +164,17 @@ struct StepIn {
 // r = R(imu angles) (supplied by the caller: the 16-lanes-per-trajectory kernel shares its sincos across the lanes).
 __device__ __forceinline__ void measurement_r(const StepIn &in, const Rot &r, float *z /*10*/)
 {
-    float c[4];
-#pragma unroll
-    for (int l = 0; l < 4; l++) c[l] = (float)((in.contact >> (8 * l)) & 0xffu);
-    float sum_c = (c[0] + c[1]) + (c[2] + c[3]);
-    float vx = 0.f, vy = 0.f, vz = 0.f, pz = 0.f;
+    // per leg: stance weight (byte == 1), swing weight (byte == 0) as 0/1 floats, then plain multiply-adds
+    float sum_c = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, pz = 0.f;
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-        bool st = ((in.contact >> (8 * l)) & 0xffu) == 1u;
-        bool sw = ((in.contact >> (8 * l)) & 0xffu) == 0u;
-        vx += st ? in.dp[3 * l] : 0.f;
-        vy += st ? in.dp[3 * l + 1] : 0.f;
-        pz += st ? in.p[3 * l + 2] : 0.f;
-        vz += sw ? in.dp[3 * l + 2] : 0.f;
+        const uint32_t cb = (in.contact >> (8 * l)) & 0xffu;
+        const float st = cb == 1u ? 1.0f : 0.0f, sw = cb == 0u ? 1.0f : 0.0f;
+        sum_c += (float)cb;
+        vx = fmaf(st, in.dp[3 * l], vx);
+        vy = fmaf(st, in.dp[3 * l + 1], vy);
+        pz = fmaf(st, in.p[3 * l + 2], pz);
+        vz = fmaf(sw, in.dp[3 * l + 2], vz);
     }
     float inv = (sum_c != 0.f) ? (1.0f / sum_c) : 0.f;   // no stance leg -> odom = 0 (:97-98)
     float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;

@@ -162,7 +162,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         }
         const int tn = (t + 1 < a.T) ? t + 1 : t;
         load_step(a, tn, voff, rowB, in);           // prefetch underneath the update
-        status |= kf_step_back_sym(x, U, z, kc);
+        status |= update_sequential_sym(x, U, z, kc);        // non-finite states stay non-finite: checked once after the loop
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
 #pragma unroll
             for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
     }
-    a.status[b] = status;
+    a.status[b] = status | finite_status(x);
 }
 
 template <int OUT, bool QDIAG>

@@ -4,7 +4,7 @@ Same constructor signature and the same `state_dict` keys for the encoder (timm 
 cls_token, pos_embed, blocks.{i}.norm1/attn.qkv/attn.proj/norm2/mlp.fc1/mlp.fc2.*, norm.*), so a checkpoint saved by
 `transformer/autoencoder_training.py:128-131` loads with `load_state_dict(..., strict=False)` (decoder keys are
 ignored: the decoder and its loss are training-only and out of scope).  `forward_encoder(x)` takes (N,1,224,224) in [0,1]
-(gru/gru_test.py:49-53) and returns (N,1,128) like the reference; it runs `os_vit_encode` (rocBLAS GEMMs + HIP kernels).
+(gru/gru_test.py:49-53) and returns (N,1,128) like the reference; it runs `os_vit_encode` (hand-written HIP kernels only: fp32-MFMA GEMM with fused epilogues, MFMA attention).
 PARITY UNPINNED (timm and the trained weights are absent): checked against oracle/vit_oracle.py only.
 """
 import ctypes as C
