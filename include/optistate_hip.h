@@ -64,8 +64,8 @@ enum {
                                      normalised feature rows to context scratch, GRU kernels read them) even where
                                      the single-kernel path applies (60 features, hidden 64, sequential+symmetric). */
     OS_FUSED_ONE_KERNEL     = 128, /* os_fused_run: take the single fused kernel whenever the shapes allow it, also for batches
-                                     that fill less than half of the chip (default: the two-kernel path there, it is
-                                     faster below ~32 k trajectories; OS_FUSED_TWO_KERNEL forces that path) */
+                                     that fill less than a third of the chip (default: the two-kernel path there, it is
+                                     faster below ~20 k trajectories; OS_FUSED_TWO_KERNEL forces that path) */
     OS_MPC_COLD_START       = 64, /* os_kf_mpc_run: do not reuse the previous step's active set (development / tests) */
     OS_KF_LANE_PER_TRAJECTORY = 32, /* os_kf_run: never use the small-batch kernel (16 lanes per trajectory, row-parallel P),
                                      which is otherwise chosen for sequential updates when B < 10,240 (the measured crossover). */

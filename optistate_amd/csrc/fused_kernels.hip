@@ -934,13 +934,13 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
     a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = nullptr; a.ptrace_out = nullptr; a.kgain_out = nullptr;
     a.status = status; a.accel = accel; a.minmax = minmax; a.feat_out = nullptr; a.feat_I = I;
 
-    // The single kernel puts 256 trajectories on a CU and takes ~30 us per time step whatever the batch; below half a chip
-    // of workgroups (B <= 32 k on 256 CUs) the two-kernel path (Kalman kernel + layer kernel, ~24 us per step) is as fast
-    // or faster (measured, T = 100: B = 8192 1.49 vs 3.0 ms, B = 32768 3.0 vs 3.07 ms, B = 65536 4.4 vs 3.1 ms).
+    // The single kernel puts 256 trajectories on a CU and takes ~27 us per time step whatever the batch; below a third of a
+    // chip of workgroups the two-kernel path (Kalman kernel + layer kernel) is faster (measured, T = 100, ms two-kernel vs
+    // single: B = 8192 1.49 / 2.66, B = 16384 2.45 / 2.69, B = 32768 3.15 / 2.75, B = 65536 4.4 / 2.69): crossover ~80 per CU.
     const bool shapes_ok = (flags & OS_KF_SEQUENTIAL_UPDATE) && (flags & OS_KF_SYMMETRIC_P) && !(flags & OS_KF_DENSE_FD) &&
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
     const bool single_kernel = shapes_ok && !(flags & OS_FUSED_TWO_KERNEL) &&
-                               ((flags & OS_FUSED_ONE_KERNEL) || B > 128 * ctx->cu_count);
+                               ((flags & OS_FUSED_ONE_KERNEL) || B > 80 * ctx->cu_count);
     if (flags & OS_FUSED_SPLIT_BF16) {
         // opt-in reduced-precision gate GEMM (never chosen by default): bf16 split terms on the bf16 MFMA, fp32 accumulate
         if (!shapes_ok || d.num_layers != 1)

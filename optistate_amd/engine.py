@@ -275,7 +275,7 @@ class Engine:
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
                   dense_fd=False, symmetric=None, two_kernel=None, split_bf16=False):
         """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B]).
-        two_kernel: None = the library picks (single fused kernel from half a chip of trajectories up), True / False force
+        two_kernel: None = the library picks (single fused kernel from about a third of a chip of trajectories up: B > 80 per CU), True / False force
         the two-kernel / the single-kernel path (the latter only where the shapes allow it)."""
         T, _, B = p.shape
         if sequential is None:

@@ -117,7 +117,8 @@ class Kalman_Filter:
         e._check(e.lib.os_kf_predict(e._h, 1, sg(1), sg(2), sg(5) if dense else None, sg(3), sg(0), sg(4),
                                      flags, e._stream()), "os_kf_predict")
         hb = buf.cpu().numpy()
-        h = hb.astype(np.float64)
+        with np.errstate(invalid="ignore"):       # the float64 words of P, read as float32, may look like NaNs
+            h = hb.astype(np.float64)
         self.x = h[o[3][0]:o[3][0] + 12].reshape(12, 1)
         if dense:
             self.P = hb[o[0][0]:o[0][0] + 288].view(np.float64).reshape(12, 12).copy()
@@ -155,7 +156,8 @@ class Kalman_Filter:
         if status & 1:
             # the reference's np.linalg.inv raises here (kalman_filter.py:168)
             raise np.linalg.LinAlgError("Singular matrix")
-        h = hb.astype(np.float64)
+        with np.errstate(invalid="ignore"):
+            h = hb.astype(np.float64)
         self.x = h[o[3][0]:o[3][0] + 12].reshape(12, 1)
         if f64:
             self.P = hb[o[0][0]:o[0][0] + 288].view(np.float64).reshape(12, 12).copy()

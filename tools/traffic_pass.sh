@@ -18,7 +18,7 @@ for tag in ("cal", "run"):
         if not f: continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            acc[r["Kernel_Name"].split("(")[0][-40:]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].split("(")[0][-48:]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             res[k][c] = sum(v) / len(v)
 for k, d in res.items():
