@@ -624,7 +624,8 @@ def bench_hot_path(a, rk):
         fl = (gru_flops_per_step(I, H, L) if dom == "gru_layer" else gru_flops_per_step(I, H, 1)) * steps_per_pass / dk["launches_per_step"]
         ach = fl / (avg_ms * 1e-3) / 1e12
         peak = MFMA_BF16_PEAK_TF if (a.split_bf16 and dom == "fused") else MFMA_F32_PEAK_TF
-        insn = "v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if (a.split_bf16 and dom == "fused") else "v_mfma_f32_32x32x2_f32"
+        insn = ("v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if a.split_bf16 == 3 else "v_mfma_f32_32x32x16_bf16 x3 (hi/lo split)") \
+            if (a.split_bf16 and dom == "fused") else "v_mfma_f32_32x32x2_f32"
         roof = {"kernel": f"{dk['kernel']} ({insn})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": fl}
         if a.split_bf16 and dom == "fused":
@@ -657,7 +658,7 @@ def bench_hot_path(a, rk):
         if k == "kf":
             kernels[k]["algorithmic_GBps"] = BYTES_PER_STEP_KF * steps_per_pass / (kernels[k]["ms_per_launch"] * 1e-3) / 1e9
             kernels[k]["hbm_frac"] = kernels[k]["algorithmic_GBps"] / HBM_PEAK_GBS
-    dtype = "bf16x3-split operands, f32 accumulate (opt-in; KF in f32)" if a.split_bf16 else "f32"
+    dtype = f"bf16x{a.split_bf16}-split operands, f32 accumulate (opt-in; KF in f32)" if a.split_bf16 else "f32"
     out = base_line(a, rk, "KF+GRU timesteps/sec" if fused else "KF timesteps/sec", "timesteps/s", total / el, el, dtype,
                     {"workload": f"fused Kalman(12-state/10-meas)+GRU(in={I},hidden={H},layers={L},out=24) inference"
                                  if fused else "Kalman(12-state/10-meas) predict/update only",
@@ -707,7 +708,8 @@ def main(argv=None):
     ap.add_argument("--layers", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--parity-samples", type=int, default=128, help="trajectories of the timed batch checked against the oracle (0 = skip)")
-    ap.add_argument("--split-bf16", action="store_true", help="opt-in reduced-precision gate GEMM (second line; never the headline)")
+    ap.add_argument("--split-bf16", type=int, nargs="?", const=3, default=0, choices=[0, 2, 3],
+                    help="opt-in gate GEMM on the bf16 MFMA with 3 (default) or 2 bf16 terms per fp32 operand (second line; never the headline)")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")
     ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc", "windows"],
                     help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")

@@ -15,6 +15,7 @@ OS_MPC_COLD_START = 64
 OS_FUSED_ONE_KERNEL = 128
 OS_KF_P_FLOAT64 = 256
 OS_FUSED_SPLIT_BF16 = 512
+OS_FUSED_SPLIT_BF16_2 = 1024
 OS_PROF_PHASES = 12         # include/optistate_hip.h
 PHASE_NAMES = ("kf", "gru_layer", "gru_head", "fused", "mpc", "train_sweep", "train_dw", "train_misc", "vit_gemm",
                "vit_attn", "vit_misc", "pack")

@@ -45,7 +45,6 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
         e = getenv("OS_FUSED_V1"); c->tune_fused_v1 = e ? atoi(e) : 0;
         e = getenv("OS_TRAIN_OVERLAP"); c->tune_train_overlap = e ? atoi(e) : 0;   // measured: no gain (both kernels are bound by the shared fp32 pipe)
-        e = getenv("OS_BF16_TERMS"); c->tune_bf16_terms = e ? atoi(e) : 3;
     }
     if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc((void **)&c->kf_qr, 244 * sizeof(float)) != hipSuccess ||
         hipMemcpy(c->kf_qr, c->k.Q, 144 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||

@@ -284,10 +284,6 @@ __device__ __forceinline__ void mfma_va(f32x16 &acc, float w, float b_agpr)
 {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_agpr));
 }
-__device__ __forceinline__ void mfma_vv(f32x16 &acc, float w, float b_vgpr)
-{
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b_vgpr));
-}
 __device__ __forceinline__ float agpr_mov(float a)
 {
     float d;
@@ -299,7 +295,6 @@ __device__ __forceinline__ void mfma_drain(f32x16 (&acc)[4])
     // 16-pass MFMA result -> VALU read: 18 wait states (cdna4 ISA, MFMA hazard table); the operands tie the nops to the values
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 }
-constexpr bool FEAT_AGPR = true;          // park the 60 feature fragments in AGPRs (true) or leave them in VGPRs
 constexpr int IMG2 = 2 * CHF2 + 64;          // + the 60 feature minima (read per step with wave-uniform ds_read_b128)
 constexpr size_t LDS2_BYTES = (size_t)IMG2 * sizeof(float);
 
@@ -425,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                          : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
                            "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
 #pragma unroll
-            for (int i = 0; i < 12; i++) FA[j0 + i] = FEAT_AGPR ? agpr_put(v[i]) : v[i];
+            for (int i = 0; i < 12; i++) FA[j0 + i] = agpr_put(v[i]);
         };
         feat6(12, acl[0], acl[1], acl[2], acl[3], acl[4], acl[5], in.f[0], in.f[1], in.f[2], in.f[3], in.f[4], in.f[5]);
         feat6(24, in.f[6], in.f[7], in.f[8], in.f[9], in.f[10], in.f[11], pw[0], pw[1], pw[2], pw[3], pw[4], pw[5]);
@@ -470,7 +465,6 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
                 for (int q = 0; q < KPX + KPH; q++) {
                     const int cur = q & 1, nxt = cur ^ 1;
-                    if (q + 1 < KPX + KPH) wb[nxt] = Wq[(q + 1) * 64];
                     if (rb == 1 && c == 1 && q == KPX) {
                         // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
                         const int tn = (t + 1 < k.T) ? t + 1 : t;
@@ -482,15 +476,16 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                     const float bv = q < KPX ? FA[2 * (q < KPX ? q : 0) + rb]
                                              : hreg[rb][(q - KPX) >> 4 & 1][(q >= KPX ? q - KPX : 0) & 15];
                     const int gn = q < KPX ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
-                    if (q < KPX && !FEAT_AGPR) {
-                        mfma_vv(acc[0], wb[cur].x, bv);
-                        mfma_vv(acc[1], wb[cur].y, bv);
-                        mfma_vv(acc[gn], wb[cur].z, bv);
-                    } else {
-                        mfma_va(acc[0], wb[cur].x, bv);
-                        mfma_va(acc[1], wb[cur].y, bv);
-                        mfma_va(acc[gn], wb[cur].z, bv);
-                    }
+                    mfma_va(acc[0], wb[cur].x, bv);
+                    // Next k-pair's fragments: requested behind this k-pair's FIRST MFMA, never in front of it.  The matrix pipe reads
+                    // an MFMA's A/B registers when the instruction starts, not when it issues; a ds_read placed right behind the
+                    // previous k-pair's last MFMA can land in registers that MFMA has not read yet (seen in the split-bf16 kernel
+                    // below; tools/bf16_determinism.py), and hipcc does not guard inline-asm MFMAs.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + 1 < KPX + KPH) wb[nxt] = Wq[(q + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_va(acc[1], wb[cur].y, bv);
+                    mfma_va(acc[gn], wb[cur].z, bv);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 mfma_drain(acc);
@@ -820,7 +815,6 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
 #pragma unroll
                 for (int g = 0; g < 3; g++) {
                     const int u = kb * 3 + g, cur = u & 1;
-                    if (u + 1 < KBT * 3) loadW(cur ^ 1, (u + 1) / 3, (u + 1) % 3);
                     const int gn = g < 2 ? g : (kb < KBX ? 2 : 3);        // input part feeds gi_n, recurrent part gh_n
                     // (weight term, activation term), largest first; consecutive MFMAs alternate between the two chunks
                     constexpr int NP = SPL == 3 ? 6 : 3;
@@ -831,6 +825,12 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
                         const int wt = SPL == 3 ? PW[pi] : PW2[pi], bt = SPL == 3 ? PB[pi] : PB2[pi];
                         mfma_bf16_vv(acc[0][gn], W[cur][0][wt], Bf[bt]);
                         mfma_bf16_vv(acc[1][gn], W[cur][1][wt], Bf[bt]);
+                        // The next (k-block, gate)'s fragments are requested only AFTER this group's first MFMA pair: the matrix pipe
+                        // reads an MFMA's A/B registers when the instruction starts, not when it issues, and a ds_read that returns
+                        // into the registers of the previous group's last (still queued) MFMAs corrupted them -- measured with the
+                        // two-term split, whose groups are half as long (tools/bf16_determinism.py: hundreds of trajectories differed
+                        // from run to run; none since).  hipcc cannot see this hazard inside inline asm.
+                        if (pi == 0 && u + 1 < KBT * 3) { __builtin_amdgcn_sched_barrier(0); loadW(cur ^ 1, (u + 1) / 3, (u + 1) % 3); __builtin_amdgcn_sched_barrier(0); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -941,12 +941,12 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
     const bool single_kernel = shapes_ok && !(flags & OS_FUSED_TWO_KERNEL) &&
                                ((flags & OS_FUSED_ONE_KERNEL) || B > 80 * ctx->cu_count);
-    if (flags & OS_FUSED_SPLIT_BF16) {
+    if (flags & (OS_FUSED_SPLIT_BF16 | OS_FUSED_SPLIT_BF16_2)) {
         // opt-in reduced-precision gate GEMM (never chosen by default): bf16 split terms on the bf16 MFMA, fp32 accumulate
         if (!shapes_ok || d.num_layers != 1)
             return os_fail(ctx, -4, "os_fused_run: OS_FUSED_SPLIT_BF16 needs the single-kernel shapes (60 features, hidden 64, one layer, "
                                     "diagonal R, sequential + symmetric flags)");
-        const int spl = ctx->tune_bf16_terms == 2 ? 2 : 3;
+        const int spl = (flags & OS_FUSED_SPLIT_BF16_2) ? 2 : 3;
         const size_t bytes = spl == 3 ? osf::Bf16Img<3>::BYTES : osf::Bf16Img<2>::BYTES;
         osf::FusedArgs fa;
         fa.kf = a; fa.kf.k = ctx->k;

@@ -190,8 +190,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
         // ---- gate derivatives (VALU), coalesced over the hidden index ----
         {
             const float *__restrict__ pdl = a.dy_last;
-            float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
             const bool last = (t == a.T - 1);
+            const uint32_t gbytes = (uint32_t)((size_t)a.T * B * 3 * H * 4), gstep = (uint32_t)((size_t)t * B * 3 * H * 4), gH = (uint32_t)H * 4u;
+            const osk::rsrc_t rgi_ = osk::make_rsrc(a.dgi, gbytes), rgh_ = osk::make_rsrc(a.dgh, gbytes);
 #pragma unroll
             for (int e = 0; e < ELP; e++) {
                 const int i = threadIdx.x + e * NT;
@@ -211,11 +212,13 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                 const float dar = dan * gg * rr * (1.0f - rr);
                 const float daz = dz * zz * (1.0f - zz);
                 if (ok) {
-                    const size_t og = ((size_t)t * B + g) * (3 * H) + c;
-                    __builtin_nontemporal_store(dar, ogi + og); __builtin_nontemporal_store(daz, ogi + og + H);
-                    __builtin_nontemporal_store(dan, ogi + og + 2 * H);
-                    __builtin_nontemporal_store(dar, ogh + og); __builtin_nontemporal_store(daz, ogh + og + H);
-                    __builtin_nontemporal_store(danr, ogh + og + 2 * H);
+                    // buffer stores: the element's offset register is shared by the six streams (gate thirds through the SGPR
+                    // offset); flat 64-bit addresses for 48 stores in flight cost ~100 registers and spilled the prefetch
+                    const uint32_t og = (uint32_t)(((size_t)g * 3 * H + c) * 4);
+                    osk::buf_store_nt(rgi_, og, gstep, dar); osk::buf_store_nt(rgi_, og, gstep + gH, daz);
+                    osk::buf_store_nt(rgi_, og, gstep + 2 * gH, dan);
+                    osk::buf_store_nt(rgh_, og, gstep, dar); osk::buf_store_nt(rgh_, og, gstep + gH, daz);
+                    osk::buf_store_nt(rgh_, og, gstep + 2 * gH, danr);
                 }
                 dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
                 dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
@@ -329,6 +332,8 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             // one MFMA per k-pair and row block: 16 x 64 cycles cover an L2 round trip
             if (((qhi - qlo) & 15) == 0 && RB == 1) run(std::integral_constant<int, 16>{});
             else run(std::integral_constant<int, 8>{});
+            const osk::rsrc_t rdx = osk::make_rsrc(a.dx, (uint32_t)((size_t)a.T * B * K * 4));
+            const uint32_t dxl = (uint32_t)((4 * lh) * K + oc * 32 + li) * 4u;
 #pragma unroll
             for (int rb = 0; rb < RB; rb++)
 #pragma unroll
@@ -337,7 +342,11 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                     if (is_h) {
                         if (qsplit == 1) dh[r * HS + c] += acc[rb][e];
                         else atomicAdd(&dh[r * HS + c], acc[rb][e]);       // ds_add_f32: two waves share the chunk
-                    } else if (g < a.B && c < K) a.dx[((size_t)t * B + g) * K + c] = acc[rb][e];
+                    } else if (g < a.B && c < K) {
+                        const uint32_t so = __builtin_amdgcn_readfirstlane(
+                            (uint32_t)(((size_t)t * B + row0 + rb * 32 + (e & 3) + 8 * (e >> 2)) * K * 4));
+                        osk::buf_store(rdx, dxl, so, acc[rb][e]);
+                    }
                 }
         }
         osg::lds_barrier();

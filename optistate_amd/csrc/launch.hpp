@@ -37,7 +37,6 @@ struct os_ctx {
     int tune_fused_v1;                        // OS_FUSED_V1=1: the round-1 kernel (h in LDS) instead of v2
     bool fused2_attr_set, fusedbf_attr_set;
     float *fused_img_bf;                      // LDS image of the opt-in split-bf16 kernel
-    int tune_bf16_terms;                      // OS_BF16_TERMS=2: two-term split (hi, lo) instead of three
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;
     // convex-MPC force QP (mpc_kernels.hip): weights of kalman_filter.py:64-72, constraints of force_controller.py:143-155

@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
-                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16)
+                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16, OS_FUSED_SPLIT_BF16_2)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -275,6 +275,7 @@ class Engine:
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
                   dense_fd=False, symmetric=None, two_kernel=None, split_bf16=False):
         """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B]).
+        split_bf16: False (exact fp32 MFMA, the default) | True or 3 (three bf16 terms per operand) | 2 (two terms): opt-in.
         two_kernel: None = the library picks (single fused kernel from about a third of a chip of trajectories up: B > 80 per CU), True / False force
         the two-kernel / the single-kernel path (the latter only where the shapes allow it)."""
         T, _, B = p.shape
@@ -284,7 +285,8 @@ class Engine:
             symmetric = sequential and not dense_fd and self._sym_Q
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
                 (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_FUSED_TWO_KERNEL if two_kernel else 0) | \
-                (OS_FUSED_ONE_KERNEL if two_kernel is False else 0) | (OS_FUSED_SPLIT_BF16 if split_bf16 else 0)
+                (OS_FUSED_ONE_KERNEL if two_kernel is False else 0) | \
+                (OS_FUSED_SPLIT_BF16_2 if split_bf16 == 2 else (OS_FUSED_SPLIT_BF16 if split_bf16 else 0))
         d = self._gru_dims
         nl = 0 if latent is None else latent.shape[1]
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)

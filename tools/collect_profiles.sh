@@ -1,0 +1,41 @@
+#!/bin/bash
+# One GPU call that (re)collects the round's evidence under gpurun_out/<tag>/: PMC traffic -> profiles/traffic.json, the
+# default bench line, rocprofv3 --kernel-trace --stats of the same command, SQ counters of the fused kernel, and the other
+# bench lines.  usage: tools/collect_profiles.sh <tag>
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+bash tools/traffic_pass.sh > $O/traffic_pass.log 2>&1
+python3 tools/traffic_to_json.py > $O/traffic.json 2>> $O/traffic_pass.log
+cp profiles/traffic.json $O/traffic_profiles.json
+python3 bench.py > $O/bench.json 2> $O/bench.err
+stats() {   # $1 = name, rest = bench args
+  n=$1; shift
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/prof_$n --output-format csv -- python3 $R/bench.py "$@" > $O/bench_${n}_under_rocprof.json 2> $O/prof_$n.log)
+  python3 - <<PY > $O/${n}_kernel_stats.md
+import csv, glob
+f = glob.glob("$O/prof_$n/**/*kernel_stats.csv", recursive=True)
+print("# rocprofv3 --kernel-trace --stats -- python3 bench.py $*\n")
+print("| kernel | calls | total ms | avg us | min us | max us | % |")
+print("|---|---|---|---|---|---|---|")
+if f:
+    for r in list(csv.DictReader(open(f[0])))[:16]:
+        print("| %s | %s | %.3f | %.1f | %.1f | %.1f | %s |" % (r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+              float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+PY
+}
+stats default --cpu-seconds 0
+stats train --mode train --cpu-seconds 0
+stats full --mode full --cpu-seconds 0
+python3 bench.py --mode kf > $O/bench_kf_B65536.json 2>> $O/bench.err
+python3 bench.py --mode kf --batch 4096 --seq 1000 --steps 5 > $O/bench_kf_B4096_T1000.json 2>> $O/bench.err
+python3 bench.py --mode train > $O/bench_train.json 2>> $O/bench.err
+python3 bench.py --mode full > $O/bench_full.json 2>> $O/bench.err
+python3 bench.py --mode windows > $O/bench_windows.json 2>> $O/bench.err
+python3 bench.py --split-bf16 > $O/bench_split_bf16.json 2>> $O/bench.err
+python3 bench.py --mode mpc --steps 3 --cpu-seconds 5 > $O/bench_mpc.json 2>> $O/bench.err
+bash tools/pmc_pass.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY" > $O/pmc_sq.txt 2>&1
+bash tools/pmc_pass.sh ${TAG}_grbm "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES" > $O/pmc_grbm.txt 2>&1
+python3 tools/ab_fused.py 6 > $O/ab_fused.txt 2>&1
+ls $O
