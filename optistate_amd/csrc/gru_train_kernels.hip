@@ -126,15 +126,21 @@ struct SweepArgs {
     const float *wihT, *whhT;    // transposed-packed weights
     float *dgi, *dgh;            // [T][B][3H]
     float *dx;                   // [T][B][K]
+    int dbg;
 };
 
 // RB = 32-row blocks per workgroup (BM = 32*RB).  LDS: dh [BM][H+1] | dG [BM][4H+1] (sections da_r, da_z, da_n, da_n*r).
 // NW = wavefronts per workgroup.  The sweep is serial in T and a workgroup owns its rows, so at the training batch (8192
 // rows = one 32-row workgroup per CU) nothing else can hide a wave's stalls: eight waves (two per SIMD) split the gate
 // derivatives and the output chunks finer and cover each other's load / LDS latency.
-template <int RB, int NW>
+// WR = leading k-pairs of a wave's weight chunk held in REGISTERS for the whole launch (needs one work item per wave).
+// Vector-memory loads return in order per wave, so the first weight fragments of a step's MFMA phase used to queue behind
+// the 48 activation prefetches issued just before them and the phase started one HBM latency late (1.75 us of every step);
+// with 32 resident k-pairs the first 32 MFMAs need nothing from memory and that latency is covered.
+template <int RB, int NW, int WR = 0>
 __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a)
 {
+    static_assert(WR == 0 || (RB == 1 && WR % 16 == 0), "resident weights: one row block, whole 16-k-pair blocks");
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = a.H, K = a.K, HS = H + 1, GS = 4 * H + 1, BM = 32 * RB;
@@ -185,10 +191,23 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
     };
     if (PF) prefetch(a.T - 1);
 
+    // work items: output chunks; with need_dx == 0 (layer 0: only the four recurrent chunks) every chunk's reduction is
+    // split in two halves so that all eight waves have work, and the halves meet in dh through LDS atomics
+    const int qsplit = (!a.need_dx && NW > nchh) ? 2 : 1;
+    float wreg[WR > 0 ? WR : 1];
+    if constexpr (WR > 0) {
+        const int item = wave < (nchx + nchh) * qsplit ? wave : 0;
+        const int ch = item / qsplit, qh = item % qsplit;
+        const bool is_h = ch >= nchx;
+        const float *wp = (is_h ? a.whhT : a.wihT) + (size_t)(is_h ? ch - nchx : ch) * Q * 64 + (size_t)qh * (Q / qsplit) * 64;
+#pragma unroll
+        for (int d = 0; d < WR; d++) wreg[d] = wp[d * 64 + lane];
+    }
+
     for (int t = a.T - 1; t >= 0; t--) {
         if constexpr (PF) {
         // ---- gate derivatives (VALU), coalesced over the hidden index ----
-        {
+        if (!(a.dbg & 1)) {
             const float *__restrict__ pdl = a.dy_last;
             const bool last = (t == a.T - 1);
             const uint32_t gbytes = (uint32_t)((size_t)a.T * B * 3 * H * 4), gstep = (uint32_t)((size_t)t * B * 3 * H * 4), gH = (uint32_t)H * 4u;
@@ -267,11 +286,22 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
         }
         }
         osg::lds_barrier();
-        if (PF && t > 0) prefetch(t - 1);
+        if (PF && t > 0 && !(a.dbg & 8)) prefetch(t - 1);
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
-        // work items: output chunks; with need_dx == 0 (layer 0: only the four recurrent chunks) every chunk's reduction is
-        // split in two halves so that all eight waves have work, and the halves meet in dh through LDS atomics
-        const int qsplit = (!a.need_dx && NW > nchh) ? 2 : 1;
+        f32x16 deferred[RB];
+        int deferred_oc = -1;
+        auto dh_add = [&](int oc, const f32x16 (&v)[RB]) {
+            float *dhp = dh + (4 * lh) * HS + oc * 32 + li;
+            float old[RB][16];
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) old[rb][e] = dhp[(rb * 32 + (e & 3) + 8 * (e >> 2)) * HS];
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) dhp[(rb * 32 + (e & 3) + 8 * (e >> 2)) * HS] = old[rb][e] + v[rb][e];
+        };
         for (int item = wave; item < (nchx + nchh) * qsplit; item += NW) {
             const int ch = item / qsplit, qh = item % qsplit;
             const bool is_h = ch >= nchx;
@@ -294,6 +324,28 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             const float *arow[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) arow[rb] = dG + (rb * 32 + li) * GS + lh;
+            // resident part: k-pairs qlo .. qlo + WR - 1 against the register-held weights, A fragments one block of 16 ahead
+            const int qs = qlo + WR;                           // first streamed k-pair
+            auto resident = [&]() {
+                if constexpr (WR > 0) {
+                    constexpr int DA = 16;
+                    float ab[DA];
+                    const int sh0 = __builtin_amdgcn_readfirstlane(2 * qlo + ((is_h && qlo >= H) ? H : 0));
+#pragma unroll
+                    for (int d = 0; d < DA; d++) ab[d] = arow[0][sh0 + 2 * d];
+#pragma unroll
+                    for (int b = 0; b < WR / DA; b++) {
+                        const int qn = qlo + (b + 1) * DA;
+                        const int sh = __builtin_amdgcn_readfirstlane(2 * qn + ((is_h && qn >= H) ? H : 0));
+#pragma unroll
+                        for (int d = 0; d < DA; d++) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[d], wreg[b * DA + d], acc[0], 0, 0, 0);
+                            if (b + 1 < WR / DA) ab[d] = arow[0][sh + 2 * d];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            };
             auto run = [&](auto dc) {
                 constexpr int D = decltype(dc)::value;
                 float wbf[D], abf[D][RB];
@@ -307,8 +359,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                         for (int rb = 0; rb < RB; rb++) abf[d][rb] = arow[rb][sh + 2 * d];
                     }
                 };
-                fetch(qlo);
-                for (int q0 = qlo; q0 + D < qhi; q0 += D) {
+                fetch(qs);
+                resident();                                    // needs nothing from memory: the loads above fly underneath
+                for (int q0 = qs; q0 + D < qhi; q0 += D) {
                     const int qn = q0 + D;
                     const uint32_t wo = __builtin_amdgcn_readfirstlane((uint32_t)qn * 256u);
                     const int sh = __builtin_amdgcn_readfirstlane(2 * qn + ((is_h && qn >= H) ? H : 0));
@@ -330,24 +383,38 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
             };
             // one MFMA per k-pair and row block: 16 x 64 cycles cover an L2 round trip
-            if (((qhi - qlo) & 15) == 0 && RB == 1) run(std::integral_constant<int, 16>{});
+            if (a.dbg & 6) {} else if (qs >= qhi) resident();
+            else if (((qhi - qs) & 15) == 0 && RB == 1) run(std::integral_constant<int, 16>{});
             else run(std::integral_constant<int, 8>{});
             const osk::rsrc_t rdx = osk::make_rsrc(a.dx, (uint32_t)((size_t)a.T * B * K * 4));
             const uint32_t dxl = (uint32_t)((4 * lh) * K + oc * 32 + li) * 4u;
+            // dh += acc as sixteen LDS reads in flight, then sixteen writes.  (Element-wise read - wait - add - write behind
+            // four branches each cost 3 us of every step; ds_add_f32 is worse still -- LDS float atomics ran the whole launch
+            // 0.06 ms slower.)  The second half of a split chunk waits for the first behind a barrier, below the loop.
+            if (a.dbg & 32) continue;
+            if (is_h && qh == 1) {
 #pragma unroll
-            for (int rb = 0; rb < RB; rb++)
+                for (int rb = 0; rb < RB; rb++) deferred[rb] = acc[rb];
+                deferred_oc = oc;
+            } else if (is_h) {
+                dh_add(oc, acc);
+            } else {
+                const bool cok = oc * 32 + li < K;
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int r = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, c = oc * 32 + li, g = row0 + r;
-                    if (is_h) {
-                        if (qsplit == 1) dh[r * HS + c] += acc[rb][e];
-                        else atomicAdd(&dh[r * HS + c], acc[rb][e]);       // ds_add_f32: two waves share the chunk
-                    } else if (g < a.B && c < K) {
-                        const uint32_t so = __builtin_amdgcn_readfirstlane(
-                            (uint32_t)(((size_t)t * B + row0 + rb * 32 + (e & 3) + 8 * (e >> 2)) * K * 4));
-                        osk::buf_store(rdx, dxl, so, acc[rb][e]);
+                for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int rr = rb * 32 + (e & 3) + 8 * (e >> 2);
+                        if (cok && row0 + rr + 4 * lh < a.B) {
+                            const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(((size_t)t * B + row0 + rr) * K * 4));
+                            osk::buf_store(rdx, dxl, so, acc[rb][e]);
+                        }
                     }
-                }
+            }
+        }
+        if (qsplit == 2) {                                     // a wave has at most one item when chunks are split
+            osg::lds_barrier();
+            if (deferred_oc >= 0) dh_add(deferred_oc, deferred);
         }
         osg::lds_barrier();
     }
@@ -928,6 +995,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         a.dy = dy; a.dy_last = (l == L - 1) ? dhT : nullptr;
         a.wihT = wihT; a.whhT = whhT; a.dgi = dgi; a.dgh = dgh;
         a.dx = dxbuf[l & 1];
+        { const char *e = getenv("OS_SWEEP_DBG"); a.dbg = e ? atoi(e) : 0; }
         const int RB = H <= 64 ? 2 : 1;
         const int BM = 32 * RB;
         const size_t lds = (size_t)(BM * (H + 1) + BM * (4 * H + 1)) * sizeof(float);
@@ -935,15 +1003,23 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             ctx->sweep_attr_set = true;
         }
         dim3 grid((B + BM - 1) / BM);
         int nw = (RB == 1 && ((a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8 || (!a.need_dx && H / 32 >= 4))) ? 8 : 4;   // enough work items for eight waves
         if (ctx->tune_sweep_nw) nw = ctx->tune_sweep_nw == 8 && RB == 1 ? 8 : 4;
         {
+            // resident leading k-pairs: one work item per wave
+            const int nitems = ((a.need_dx ? (K + 31) / 32 : 0) + H / 32) * ((!a.need_dx && 8 > H / 32) ? 2 : 1);
+            const int wr = (nw == 8 && H == 128 && nitems <= 8) ? ctx->tune_sweep_wr : 0;
             const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_SWEEP, s,
-                                           RB == 2 ? "bwd_sweep_kernel<2,4>" : (nw == 8 ? "bwd_sweep_kernel<1,8>" : "bwd_sweep_kernel<1,4>"));
+                                           RB == 2 ? "bwd_sweep_kernel<2,4>" : wr == 32 ? "bwd_sweep_kernel<1,8,32>" : wr == 16 ? "bwd_sweep_kernel<1,8,16>" :
+                                           nw == 8 ? "bwd_sweep_kernel<1,8>" : "bwd_sweep_kernel<1,4>");
             if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
+            else if (wr == 32) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8, 32>), grid, dim3(512), lds, s, a);
+            else if (wr == 16) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8, 16>), grid, dim3(512), lds, s, a);
             else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
             else hipLaunchKernelGGL((bwd_sweep_kernel<1, 4>), grid, dim3(256), lds, s, a);
             os_prof_end(ctx, slot, s);
