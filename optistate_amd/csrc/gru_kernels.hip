@@ -31,10 +31,9 @@ using osk::rsrc_t;
 // L2-resident) and the A fragments (x part: one 128-B segment per k straight from the SoA stream; h part: LDS) of
 // k-pair q+DEPTH are requested right after the MFMAs of k-pair q issue, so DEPTH * 3 * RBW MFMAs (>= 1500 cycles) cover
 // each L2 round trip; a sched_barrier per k-pair keeps hipcc from hoisting every load to the top of the loop.
-template <int RBW, bool XPART, typename AF>
+template <int RBW, bool XPART, int DEPTH = 4, typename AF>
 __device__ __forceinline__ void mfma_part(f32x16 (*acc)[4], const float *wbase, int KP, int lane, AF afrag)
 {
-    constexpr int DEPTH = 4;
     float wb[DEPTH][3], ab[DEPTH][RBW];
     // weights: wave-uniform descriptor + SGPR offset (k-pair, gate) + constant per-lane offset -> no address VALU
     const rsrc_t w = make_rsrc(wbase, (uint32_t)KP * 3 * 256);
@@ -207,7 +206,7 @@ template <int NCH>
 __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
 {
     constexpr int PARTS = 8 / NCH;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][32][HS] h double buffer | [NCH][PARTS-1][64][64] exchange
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][32][HS] h double buffer | [2][32][XS] x tiles | [NCH][PARTS-1][64][64] exchange
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, HS = H + 1;
     constexpr int BM = 32;
@@ -215,10 +214,17 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
     const int tile_row0 = blockIdx.x * BM;
     const int li = lane & 31, lh = lane >> 5;
     const size_t B = (size_t)a.B;
+    // The x tile of a step is staged in LDS one step ahead (row-major [32][XS], XS = 2 KPx + 1: odd stride, and the pad
+    // column of an odd input width stays zero).  Fetching the A fragments of the x half straight from the SoA stream inside
+    // the MFMA loop ran that half at 0.112 ms per layer against 0.05 ms for its MFMAs: vector loads return in order per wave,
+    // so every HBM-latency x fragment held up the L2-resident weight fragments queued behind it.
+    const int XS = 2 * a.KPx + 1;
     float *hl2 = smem;
-    float *xch = smem + 2 * BM * HS + (size_t)chunk * (PARTS - 1) * 64 * 64;
+    float *xl2 = smem + 2 * BM * HS;
+    float *xch = xl2 + 2 * BM * XS + (size_t)chunk * (PARTS - 1) * 64 * 64;
 
     for (int i = threadIdx.x; i < BM * HS; i += 512) hl2[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
+    for (int i = threadIdx.x; i < 2 * BM * XS; i += 512) xl2[i] = 0.f;
 
     const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
     const float *wh = wx + (size_t)a.KPx * 3 * 64;
@@ -228,12 +234,35 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
     const uint32_t rowB = (uint32_t)a.B * 4u;
     const int g0 = tile_row0 + li;
     const int growc = g0 < a.B ? g0 : a.B - 1;
-    const uint32_t xoff = (uint32_t)growc * 4u + (uint32_t)lh * rowB;
     // this part's slice of the k-pair range: x k-pairs [xb, xe), h k-pairs [hb, he)
-    const int KPfull = a.K / 2, total = KPfull + a.KPh;
+    const int KPfull = a.KPx, total = KPfull + a.KPh;
     const int qb = (int)((long)total * part / PARTS), qe = (int)((long)total * (part + 1) / PARTS);
     const int xb = qb < KPfull ? qb : KPfull, xe = qe < KPfull ? qe : KPfull;
     const int hb = (qb > KPfull ? qb : KPfull) - KPfull, he = (qe > KPfull ? qe : KPfull) - KPfull;
+    // x tile staging: thread -> (input k0 + 16 e, row li), 128-byte segments of the [K][B] stream; inputs past K read zero
+    // through the descriptor's range check (and are not written to the tile)
+    constexpr int XE = 12;                                   // 16 inputs per pass: K <= 192
+    const int xk0 = threadIdx.x >> 5;
+    const uint32_t xsoff = (uint32_t)growc * 4u + (uint32_t)xk0 * rowB;
+    float xr[XE];
+    auto xfetch = [&](int t) {
+        const rsrc_t rx = make_rsrc(a.xs + (size_t)t * a.K * B, (uint32_t)a.K * rowB);
+#pragma unroll
+        for (int e = 0; e < XE; e++) {
+            if (e * 16 >= a.K) break;
+            xr[e] = buf_load(rx, xsoff, __builtin_amdgcn_readfirstlane((uint32_t)(e * 16) * rowB));
+        }
+    };
+    auto xstage = [&](float *xl) {
+#pragma unroll
+        for (int e = 0; e < XE; e++) {
+            if (e * 16 >= a.K) break;
+            if (xk0 + e * 16 < a.K) xl[li * XS + xk0 + e * 16] = xr[e];
+        }
+    };
+    __syncthreads();
+    xfetch(0);
+    xstage(xl2);
     __syncthreads();
 
     auto write_back = [&](const float *hsrc, float *dst) {
@@ -255,23 +284,13 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[0][g][e] = 0.f;
 
-        const float *xt = a.xs + (size_t)t * a.K * B;
-        if (xe > xb) {
-            const rsrc_t rx = make_rsrc(xt, (uint32_t)a.K * rowB);
-            mfma_part<1, true>(acc, wx + (size_t)xb * 3 * 64, xe - xb, lane, [&](int q, int) {
-                return buf_load(rx, xoff, __builtin_amdgcn_readfirstlane((uint32_t)(2 * (q + xb)) * rowB));
-            });
-        }
-        if (part == 0 && a.KPx > KPfull) {                  // odd input width: one masked tail pair
-            const int q = KPfull;
-            const float w_r = wx[(q * 3 + 0) * 64 + lane], w_z = wx[(q * 3 + 1) * 64 + lane], w_n = wx[(q * 3 + 2) * 64 + lane];
-            const float av = (lh == 0) ? xt[(size_t)(2 * q) * B + growc] : 0.f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_r, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_z, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[0][2], 0, 0, 0);
-        }
+        const float *xl = xl2 + (t & 1) * BM * XS;          // x_t
+        if (xe > xb)
+            mfma_part<1, true, 8>(acc, wx + (size_t)xb * 3 * 64, xe - xb, lane, [&](int q, int) { return xl[li * XS + 2 * (q + xb) + lh]; });
         if (he > hb)
-            mfma_part<1, false>(acc, wh + (size_t)hb * 3 * 64, he - hb, lane, [&](int q, int) { return hl[li * HS + 2 * (q + hb) + lh]; });
+            mfma_part<1, false, 8>(acc, wh + (size_t)hb * 3 * 64, he - hb, lane, [&](int q, int) { return hl[li * HS + 2 * (q + hb) + lh]; });
+        // x_{t+1}: requested behind the last weight fragment, lands underneath the exchange and the cell update
+        if (t + 1 < a.T) xfetch(t + 1);
         if (part > 0) {
             float *dst = xch + (size_t)(part - 1) * 64 * 64;
 #pragma unroll
@@ -311,7 +330,8 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
                 }
             }
         }
-        lds_barrier();   // h_t complete (and the exchange buffers free again)
+        if (t + 1 < a.T) xstage(xl2 + ((t + 1) & 1) * BM * XS);
+        lds_barrier();   // h_t and x_{t+1} complete (and the exchange buffers free again)
     }
     const float *hT = hl2 + (a.T & 1) * BM * HS;
     if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
@@ -355,35 +375,46 @@ __global__ void gru_pack_all_kernel(const PackAll a)
 }
 
 // fc + sigmoid on the last hidden state (gru/gru_model.py:43-48).  h_last [H][B] -> out [B][C].
-__global__ void gru_head_kernel(int B, int H, int C, const float *h_last, const float *fcw, const float *fcb,
+// blockIdx.y = group of eight classes.  A 256-thread workgroup covers 64 trajectories: wave q walks a quarter of the hidden
+// units (the loads of a quarter are all in flight together: one memory round trip instead of a chain of them), the four
+// partial sums meet in LDS.  The eight rows of fc weights are staged with coalesced reads, transposed to [H][8], so that
+// the eight weights of a k are two wave-uniform ds_read_b128.
+__global__ __launch_bounds__(256) void gru_head_kernel(int B, int H, int C, const float *h_last, const float *fcw, const float *fcb,
                                 int use_sigmoid, float *out)
 {
-    // fc weights transposed to [H][Cp] (Cp = C rounded up to 8): the eight weights a pass needs for one k are two
-    // ds_read_b128 at a wave-uniform address; bias [Cp] behind them
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    const int Cp = (C + 7) & ~7;
-    for (int i = threadIdx.x; i < H * Cp; i += blockDim.x) {
-        const int k = i / Cp, c = i % Cp;
-        sw[i] = c < C ? fcw[c * H + k] : 0.f;
+    extern __shared__ __attribute__((aligned(16))) float sw[];     // [H][8] weights | [8] bias | [3][8][64] partial sums
+    const int c0 = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < 8 * H; i += blockDim.x) {
+        const int j = i / H, k = i % H;                              // consecutive threads: consecutive k of one class row
+        sw[k * 8 + j] = c0 + j < C ? fcw[(size_t)(c0 + j) * H + k] : 0.f;
     }
-    for (int i = threadIdx.x; i < Cp; i += blockDim.x) sw[H * Cp + i] = i < C ? fcb[i] : 0.f;
+    if (threadIdx.x < 8) sw[8 * H + threadIdx.x] = c0 + threadIdx.x < C ? fcb[c0 + threadIdx.x] : 0.f;
     __syncthreads();
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    for (int c0 = 0; c0 < C; c0 += 8) {
-        float s[8];
+    float *ps = sw + 8 * H + 8;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane, bc = b < B ? b : B - 1;
+    const int k0 = q * (H / 4), k1 = q == 3 ? H : k0 + H / 4;
+    float s[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = sw[H * Cp + c0 + j];
-#pragma unroll 8
-        for (int k = 0; k < H; k++) {
-            const float hv = h_last[(size_t)k * B + b];
-            const float4 w0 = *reinterpret_cast<const float4 *>(&sw[k * Cp + c0]), w1 = *reinterpret_cast<const float4 *>(&sw[k * Cp + c0 + 4]);
-            s[0] = fmaf(w0.x, hv, s[0]); s[1] = fmaf(w0.y, hv, s[1]); s[2] = fmaf(w0.z, hv, s[2]); s[3] = fmaf(w0.w, hv, s[3]);
-            s[4] = fmaf(w1.x, hv, s[4]); s[5] = fmaf(w1.y, hv, s[5]); s[6] = fmaf(w1.z, hv, s[6]); s[7] = fmaf(w1.w, hv, s[7]);
+    for (int j = 0; j < 8; j++) s[j] = 0.f;
+#pragma unroll 16
+    for (int k = k0; k < k1; k++) {
+        const float hv = h_last[(size_t)k * B + bc];
+        const float4 w0 = *reinterpret_cast<const float4 *>(&sw[k * 8]), w1 = *reinterpret_cast<const float4 *>(&sw[k * 8 + 4]);
+        s[0] = fmaf(w0.x, hv, s[0]); s[1] = fmaf(w0.y, hv, s[1]); s[2] = fmaf(w0.z, hv, s[2]); s[3] = fmaf(w0.w, hv, s[3]);
+        s[4] = fmaf(w1.x, hv, s[4]); s[5] = fmaf(w1.y, hv, s[5]); s[6] = fmaf(w1.z, hv, s[6]); s[7] = fmaf(w1.w, hv, s[7]);
+    }
+    if (q > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) ps[((q - 1) * 8 + j) * 64 + lane] = s[j];
+    }
+    __syncthreads();
+    if (q == 0 && b < B) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float v = ((s[j] + ps[j * 64 + lane]) + (ps[(8 + j) * 64 + lane] + ps[(16 + j) * 64 + lane])) + sw[8 * H + j];
+            if (c0 + j < C) out[(size_t)b * C + c0 + j] = use_sigmoid ? sigmoidf_(v) : v;
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (c0 + j < C) out[(size_t)b * C + c0 + j] = use_sigmoid ? sigmoidf_(s[j]) : s[j];
     }
 }
 
@@ -457,10 +488,9 @@ int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, f
 {
     const os_gru_dims &d = ctx->gru;
     const int H = d.hidden_size;
-    const int Cp = (d.num_classes + 7) & ~7;
-    const size_t hlds = ((size_t)Cp * H + Cp) * sizeof(float);
+    const size_t hlds = ((size_t)8 * H + 8 + 3 * 8 * 64) * sizeof(float);
     const int hslot = os_prof_begin(ctx, OS_PHASE_GRU_HEAD, s, "gru_head_kernel");
-    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 63) / 64), dim3(64), hlds, s, B, H, d.num_classes, top, fcw,
+    hipLaunchKernelGGL(gru_head_kernel, dim3((B + 63) / 64, (d.num_classes + 7) / 8), dim3(256), hlds, s, B, H, d.num_classes, top, fcw,
                        fcw + (size_t)d.num_classes * H, d.use_sigmoid, out);
     os_prof_end(ctx, hslot, s);
     OS_HIP(ctx, hipGetLastError());
@@ -488,12 +518,13 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     // at most one 32-row tile per CU: eight waves on one tile (slices of the gate GEMM's reduction);
     // measured (60,128,4), T = 100: B = 4096 35 -> 48, B = 8192 70 -> 92 TFLOP/s; from two tiles per CU on the plain kernel wins
     bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
+    if (a.K > 192) split = false;                                    // its x tile staging covers 12 x 16 inputs
     if (ctx->tune_gru_split == 0) split = false;
     const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s,
                                    split ? "gru_layer_split_kernel" : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
     if (split) {
         const int parts = 8 / NCH;
-        const size_t lds_s = ((size_t)2 * 32 * (H + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
+        const size_t lds_s = ((size_t)2 * 32 * (H + 1) + (size_t)2 * 32 * (2 * a.KPx + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
         if (!ctx->split_attr_set) {
             OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -28,68 +28,114 @@ using osg::sigmoidf_;
 
 // ---- loss + d(out) -------------------------------------------------------------------------------------------
 // out [B][C], y [B][C/2]; target [B][C] (optional), dout [B][C]; loss_acc: one float, pre-zeroed.
-__global__ void loss_kernel(int B, int C, const float *out, const float *y, float *target, float *dout, float *loss_acc)
+__global__ __launch_bounds__(256) void loss_kernel(int B, int C, const float *out, const float *y, float *target, float *dout, float *loss_acc)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int half = C / 2;
+    __shared__ float part[4];
+    const int half = C / 2, n = B * C;
+    const float inv = 1.0f / (float)n;
     float sq = 0.f;
-    if (i < B * C) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int b = i / C, c = i % C;
         const float o = out[i];
         const float tgt = c < half ? y[b * half + c] : fabsf(out[b * C + (c - half)] - y[b * half + (c - half)]);
         const float d = o - tgt;
-        sq = d * d;
+        sq += d * d;
         if (target) target[i] = tgt;
-        dout[i] = 2.0f * d / (float)(B * C);       // the target is detached (gru_train.py:239): no gradient through |.|
+        dout[i] = 2.0f * d * inv;                  // the target is detached (gru_train.py:239): no gradient through |.|
     }
-    // wave reduction, then one atomic per wave
+    // wave reduction, workgroup reduction, ONE atomic per workgroup (an atomic per wave put 3,072 of them on one address at
+    // the training batch: 41 us for a 197 k-element pass)
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, sq / (float)(B * C));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (part[0] + part[1] + part[2] + part[3]) * inv);
+}
+
+// hardware float add at the L2 (atomicAdd(float *) without -munsafe-fp-atomics is a compare-and-swap loop, which under the
+// contention of B/64 workgroups on 3,096 addresses took most of head_backward_kernel's 45 us)
+__device__ __forceinline__ void global_fadd(float *base, uint32_t bytes, uint32_t index, float v)
+{
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, osk::make_rsrc(base, bytes), index * 4u, 0u, 0);
 }
 
 // ---- head backward -------------------------------------------------------------------------------------------
 // dpre = dout * out * (1 - out) (sigmoid) or dout; dh_T [B][H] = dpre . fcw; dfcw [C][H] += dpre^T h_T; dfcb += sum dpre.
-// One workgroup per 64 rows; partial dfcw/dfcb accumulated with float atomics (C*H is tiny).
-__global__ void head_backward_kernel(int B, int H, int C, int use_sigmoid, const float *out, const float *dout,
+// One workgroup per 64 rows, 256 threads = (hidden unit k: 128 at a time) x (2 halves).  Register blocking: for dh_T a
+// thread holds its column of fcw (C values) and walks its 32 rows with the row's dpre broadcast from LDS; for dfcw it holds
+// C/2 accumulators and walks the 64 rows.  (The first version did one LDS/global read per multiply-add and took 69 us at
+// the training batch.)  Partial dfcw / dfcb are added with float atomics: C*H + C addresses, B/64 contributions each.
+constexpr int HB_CMAX = 32;            // classes per pass, held in registers (the LDS tile is zero-padded to a multiple of it:
+                                       // straight-line inner loops -- with run-time class bounds hipcc put an
+                                       // s_waitcnt vmcnt(0) behind every LDS read and each row waited for the previous row's store)
+__global__ __launch_bounds__(256) void head_backward_kernel(int B, int H, int C, int use_sigmoid, const float *out, const float *dout,
                                      const float *hT /*[B][H]*/, const float *fcw, float *dhT /*[B][H]*/, float *dfcw,
                                      float *dfcb)
 {
-    extern __shared__ float sm[];          // dpre [64][C] , h [64][H+1]
-    float *dp = sm, *hs = sm + 64 * C;
+    extern __shared__ __attribute__((aligned(16))) float sm[];          // dpre [64][Cp] , h [64][H+1]
+    const int Cp = (C + HB_CMAX - 1) / HB_CMAX * HB_CMAX;
+    float *dp = sm, *hs = sm + 64 * Cp;
     const int row0 = blockIdx.x * 64;
-    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) {
-        const int r = i / C, c = i % C, g = row0 + r;
-        float v = 0.f;
-        if (g < B) {
-            const float o = out[(size_t)g * C + c];
-            v = dout[(size_t)g * C + c] * (use_sigmoid ? o * (1.0f - o) : 1.0f);
-        }
-        dp[i] = v;
+    // staging loops unrolled eight deep with range-checked buffer loads: rolled, every iteration was one HBM round trip
+    // (load - wait - LDS store), 32 of them in a row for the h tile
+    const osk::rsrc_t ro = osk::make_rsrc(out, (uint32_t)((size_t)B * C * 4)), rd = osk::make_rsrc(dout, (uint32_t)((size_t)B * C * 4)),
+                      rh = osk::make_rsrc(hT, (uint32_t)((size_t)B * H * 4));
+#pragma unroll 8
+    for (int i = threadIdx.x; i < 64 * Cp; i += 256) {
+        const int r = i / Cp, c = i % Cp;
+        const uint32_t off = c < C ? (uint32_t)(((size_t)(row0 + r) * C + c) * 4) : 0xffffffffu;      // pad columns: out of range -> 0
+        const float o = osk::buf_load(ro, off, 0u), dv = osk::buf_load(rd, off, 0u);
+        dp[i] = dv * (use_sigmoid ? o * (1.0f - o) : 1.0f);
     }
-    for (int i = threadIdx.x; i < 64 * H; i += blockDim.x) {
-        const int r = i / H, k = i % H, g = row0 + r;
-        hs[r * (H + 1) + k] = g < B ? hT[(size_t)g * H + k] : 0.f;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < 64 * H; i += 256) {
+        const int r = i / H, k = i % H;
+        hs[r * (H + 1) + k] = osk::buf_load(rh, (uint32_t)(((size_t)(row0 + r) * H + k) * 4), 0u);   // rows past B: 0
     }
     __syncthreads();
-    // dh_T
-    for (int i = threadIdx.x; i < 64 * H; i += blockDim.x) {
-        const int r = i / H, k = i % H, g = row0 + r;
-        if (g >= B) continue;
-        float s = 0.f;
-        for (int c = 0; c < C; c++) s += dp[r * C + c] * fcw[c * H + k];
-        dhT[(size_t)g * H + k] = s;
-    }
-    // dfcw, dfcb partials
-    for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
-        const int c = i / H, k = i % H;
-        float s = 0.f;
-        for (int r = 0; r < 64; r++) s += dp[r * C + c] * hs[r * (H + 1) + k];
-        atomicAdd(&dfcw[i], s);
+    const int half = threadIdx.x >> 7, kk = threadIdx.x & 127;
+    for (int k = kk; k < H; k += 128) {
+        for (int c0 = 0; c0 < Cp; c0 += HB_CMAX) {
+            // dh_T: rows half*32 .. +32
+            float w[HB_CMAX];
+#pragma unroll
+            for (int c = 0; c < HB_CMAX; c++) w[c] = c0 + c < C ? fcw[(size_t)(c0 + c) * H + k] : 0.f;
+            const osk::rsrc_t rdh = osk::make_rsrc(dhT, (uint32_t)((size_t)B * H * 4));      // rows past B: dropped by the range check
+#pragma unroll 4
+            for (int r = half * 32; r < half * 32 + 32; r++) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < HB_CMAX; c += 4) {
+                    const float4 d4 = *reinterpret_cast<const float4 *>(&dp[r * Cp + c0 + c]);     // wave-uniform: broadcast
+                    s = fmaf(d4.x, w[c], s); s = fmaf(d4.y, w[c + 1], s); s = fmaf(d4.z, w[c + 2], s); s = fmaf(d4.w, w[c + 3], s);
+                }
+                const uint32_t off = (uint32_t)(((size_t)(row0 + r) * H + k) * 4);
+                if (c0 == 0) osk::buf_store(rdh, off, 0u, s);
+                else __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(s, rdh, off, 0u, 0);
+            }
+            // dfcw: classes c0 + half*16 .. +16 over all 64 rows
+            float acc[HB_CMAX / 2];
+#pragma unroll
+            for (int c = 0; c < HB_CMAX / 2; c++) acc[c] = 0.f;
+            const int cb = c0 + half * (HB_CMAX / 2);
+#pragma unroll 4
+            for (int r = 0; r < 64; r++) {
+                const float hv = hs[r * (H + 1) + k];
+#pragma unroll
+                for (int c = 0; c < HB_CMAX / 2; c += 4) {
+                    const float4 d4 = *reinterpret_cast<const float4 *>(&dp[r * Cp + cb + c]);
+                    acc[c] = fmaf(d4.x, hv, acc[c]); acc[c + 1] = fmaf(d4.y, hv, acc[c + 1]);
+                    acc[c + 2] = fmaf(d4.z, hv, acc[c + 2]); acc[c + 3] = fmaf(d4.w, hv, acc[c + 3]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < HB_CMAX / 2; c++)
+                if (cb + c < C) global_fadd(dfcw, (uint32_t)(C * H) * 4u, (uint32_t)((cb + c) * H + k), acc[c]);
+        }
     }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (int r = 0; r < 64; r++) s += dp[r * C + c];
-        atomicAdd(&dfcb[c], s);
+        for (int r = 0; r < 64; r++) s += dp[r * Cp + c];
+        global_fadd(dfcb, (uint32_t)C * 4u, (uint32_t)c, s);
     }
 }
 
@@ -572,7 +618,7 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
     }
     if (a.db && jok) {
         bsum += __shfl_xor(bsum, 32, 64);            // the two row parities of the same gate unit
-        if (kk == 0) atomicAdd(&a.db[j0 + li], bsum);
+        if (kk == 0) global_fadd(a.db, (uint32_t)a.H3 * 4u, (uint32_t)(j0 + li), bsum);
     }
 }
 
@@ -698,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
     }
     if (a.db && jok) {
         bsum += __shfl_xor(bsum, 32, 64);            // the two row parities of the same gate unit
-        if (kk == 0) atomicAdd(&a.db[j0 + li], bsum);
+        if (kk == 0) global_fadd(a.db, (uint32_t)a.H3 * 4u, (uint32_t)(j0 + li), bsum);
     }
 }
 
@@ -900,7 +946,10 @@ int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float 
     hipStream_t s = (hipStream_t)stream;
     OS_HIP(ctx, hipMemsetAsync(loss, 0, sizeof(float), s));
     const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "loss_kernel");
-    hipLaunchKernelGGL(loss_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, B, C, out, y, target, dout, loss);
+    {
+        const int nblk = (B * C + 255) / 256;
+        hipLaunchKernelGGL(loss_kernel, dim3(nblk < 128 ? nblk : 128), dim3(256), 0, s, B, C, out, y, target, dout, loss);
+    }
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
@@ -937,7 +986,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     float *dhT = ts->dxy + 2 * (size_t)T * B * Kmax;
     const float *hT = act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
     {
-        const size_t lds = (size_t)(64 * C + 64 * (H + 1)) * sizeof(float);
+        const size_t lds = (size_t)(64 * ((C + 31) / 32 * 32) + 64 * (H + 1)) * sizeof(float);
         const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "head_backward_kernel");
         hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(256), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
                            fcw, dhT, grad_flat + fc_off, grad_flat + fc_off + (size_t)C * H);
