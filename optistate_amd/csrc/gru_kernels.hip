@@ -338,6 +338,170 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
     if (a.h_last) write_back(hT, a.h_last);
 }
 
+// H = 128 small-batch variant with the INPUT half of the gate GEMM running ahead of the recurrence.
+// gi = x_t W_ih^T does not depend on h, so nothing forces it into the same barrier-delimited phase as the recurrent half:
+// waves 4-7 ("x waves", one per 32-column chunk) compute it one to two steps AHEAD and hand the three partial gates to
+// waves 0-3 ("h waves") through LDS; the h waves do the recurrent half and the cell update.  What that buys: in
+// gru_layer_split_kernel a step was [both halves' MFMAs] -> barrier -> [cell update on four waves while the other four
+// sat at the barrier] (in-kernel timestamps at the training batch: 28 k cycles + 5.6 k of a 36.5 k-cycle step, for 24.6 k
+// cycles of MFMAs); here the x waves' MFMAs fill the SIMDs while the h waves are in the cell update, and the recurrent
+// MFMAs of step 0 (h_{-1} = 0) are skipped outright.  A step is three barrier-delimited phases:
+//   1   h waves: recurrent MFMAs of step t                    x waves: rest of the input MFMAs of step t+1, h_{t-1} -> seq_out
+//   W   h waves: pick up the partial gates P(t), stage x_{t+2} into the x tile (its registers were loaded in phase 2 of t-1)
+//   2   h waves: request x_{t+3}, cell update of step t       x waves: publish P(t+1), first part of the input MFMAs of t+2
+// LDS: h double buffer [2][32][129] | x tile [32][2 KPx + 1] | partial gates [4][48][64]  (96 KB at K = 128).
+__global__ __launch_bounds__(512, 1) void gru_layer_ahead_kernel(const LayerArgs a)
+{
+    constexpr int H = 128, HS = H + 1, BM = 32, XE = 24;          // x staging: 8 inputs per pass and thread row, K <= 192
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_x = wave >= 4;
+    const int chunk = wave & 3;
+    const int tile_row0 = blockIdx.x * BM;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t B = (size_t)a.B;
+    const int KPx = a.KPx, XS = 2 * KPx + 1;
+    float *hl2 = smem, *xl = smem + 2 * BM * HS, *xch = xl + BM * XS + (size_t)chunk * 48 * 64;
+
+    for (int i = threadIdx.x; i < BM * HS; i += 512) hl2[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
+    for (int i = threadIdx.x; i < BM * XS; i += 512) xl[i] = 0.f;    // the pad column of an odd input width stays zero
+
+    const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
+    const float *wh = wx + (size_t)a.KPx * 3 * 64;
+    const float *bias = wh + (size_t)a.KPh * 3 * 64;
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float nb_r = -LOG2E * bias[li], nb_z = -LOG2E * bias[32 + li], nb_n = 2.0f * LOG2E * bias[64 + li], b_hn = bias[96 + li];
+    const uint32_t rowB = (uint32_t)a.B * 4u;
+    const int g0 = tile_row0 + li;
+    const int growc = g0 < a.B ? g0 : a.B - 1;
+    // x tile staging by the h waves: thread -> (input k0 + 8 e, row li): 128-byte segments of the [K][B] stream; inputs past K
+    // read zero through the descriptor's range check and are not written
+    const int xk0 = (threadIdx.x >> 5) & 7;
+    const uint32_t xsoff = (uint32_t)growc * 4u + (uint32_t)xk0 * rowB;
+    float xr[XE];
+    auto xfetch = [&](int s) {
+        if (s >= a.T) return;
+        const rsrc_t rx = make_rsrc(a.xs + (size_t)s * a.K * B, (uint32_t)a.K * rowB);
+#pragma unroll
+        for (int e = 0; e < XE; e++) {
+            if (e * 8 >= a.K) break;
+            xr[e] = buf_load(rx, xsoff, __builtin_amdgcn_readfirstlane((uint32_t)(e * 8) * rowB));
+        }
+    };
+    auto xstage = [&]() {
+#pragma unroll
+        for (int e = 0; e < XE; e++) {
+            if (e * 8 >= a.K) break;
+            if (xk0 + e * 8 < a.K) xl[li * XS + xk0 + e * 8] = xr[e];
+        }
+    };
+    const int SP = KPx < 24 ? KPx : 24;                          // input k-pairs done in phase 2 (beside the cell update)
+    f32x16 acc[1][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[0][g][e] = 0.f;
+    };
+    auto xpart = [&](int lo, int hi) {
+        if (hi > lo)
+            mfma_part<1, true, 8>(acc, wx + (size_t)lo * 3 * 64, hi - lo, lane, [&](int q, int) { return xl[li * XS + 2 * (q + lo) + lh]; });
+    };
+    auto publish = [&]() {                                       // r, z, n_x partial gates -> LDS
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) xch[(g * 16 + e) * 64 + lane] = acc[0][g][e];
+    };
+    auto write_back = [&](const float *hsrc, float *dst, int first, int stride) {
+        for (int i = first; i < BM * H; i += stride) {
+            const int row = i % BM, k = i / BM;
+            const int g = tile_row0 + row;
+            if (g < a.B) dst[(size_t)k * B + g] = hsrc[row * HS + k];
+        }
+    };
+
+    // ---- prologue: P(0) published, first part of the input MFMAs of step 1 in the x waves' accumulators, x_1 in the tile,
+    // x_2 in the h waves' registers ----
+    __syncthreads();
+    if (!is_x) { xfetch(0); xstage(); }
+    __syncthreads();
+    if (is_x) { zero_acc(); xpart(0, KPx); publish(); }
+    else xfetch(1);
+    lds_barrier();
+    if (!is_x && 1 < a.T) xstage();
+    lds_barrier();
+    if (is_x) { zero_acc(); if (1 < a.T) xpart(0, SP); }
+    else xfetch(2);
+
+    for (int t = 0; t < a.T; t++) {
+        const float *hl = hl2 + (t & 1) * BM * HS;          // h_{t-1}
+        float *hn_buf = hl2 + ((t + 1) & 1) * BM * HS;       // h_t
+        // ---- phase 1 ----
+        if (is_x) {
+            if (t > 0 && a.seq_out) {
+                // h_{t-1} -> seq_out [T][H][B]: sixteen LDS reads in flight, then sixteen 128-byte-segment stores (thread ->
+                // hidden unit xk0 + 8 e, row li), ahead of the MFMAs so that they drain underneath them
+                const rsrc_t rq = make_rsrc(a.seq_out + (size_t)(t - 1) * H * B, (uint32_t)H * rowB);
+                float hv[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) hv[e] = hl[li * HS + xk0 + 8 * e];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (g0 < a.B) osk::buf_store(rq, xsoff, (uint32_t)(8 * e) * rowB, hv[e]);
+            }
+            if (t + 1 < a.T) xpart(SP, KPx);
+        } else {
+            zero_acc();
+            if (t > 0) mfma_part<1, false, 8>(acc, wh, a.KPh, lane, [&](int q, int) { return hl[li * HS + 2 * q + lh]; });
+        }
+        lds_barrier();   // every wave is done with the x tile; P(t) was published before the previous barrier
+        // ---- window ----
+        if (!is_x) {
+#pragma unroll
+            for (int g = 0; g < 3; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[0][g][e] += xch[(g * 16 + e) * 64 + lane];
+            if (t + 2 < a.T) xstage();
+        }
+        lds_barrier();   // P(t) consumed, x_{t+2} staged
+        // ---- phase 2 ----
+        if (is_x) {
+            if (t + 1 < a.T) publish();
+            zero_acc();
+            if (t + 2 < a.T) xpart(0, SP);
+        } else {
+            xfetch(t + 3);
+            const uint32_t svbytes = (uint32_t)((size_t)a.T * B * H * 4);       // host: < 4 GiB
+            const rsrc_t rs_r = make_rsrc(a.sv_r, svbytes), rs_z = make_rsrc(a.sv_z, svbytes), rs_n = make_rsrc(a.sv_n, svbytes),
+                         rs_g = make_rsrc(a.sv_g, svbytes), rs_h = make_rsrc(a.sv_h, svbytes);
+            const uint32_t svoff = (uint32_t)(((size_t)(tile_row0 + 4 * lh) * H + chunk * 32 + li) * 4);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int hidx = row * HS + chunk * 32 + li;
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][0][e], -LOG2E, nb_r)));
+                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][1][e], -LOG2E, nb_z)));
+                const float ghn = acc[0][3][e] + b_hn;
+                const float u = fmaf(r, ghn, acc[0][2][e]);
+                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
+                const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
+                hn_buf[hidx] = hn;
+                if (a.sv_r && tile_row0 + row < a.B) {
+                    // one per-lane offset register for the 80 stores of a step (flat addresses: two registers per store in flight)
+                    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(((size_t)t * B + (e & 3) + 8 * (e >> 2)) * H * 4));
+                    osk::buf_store_nt(rs_r, svoff, so, r); osk::buf_store_nt(rs_z, svoff, so, z); osk::buf_store_nt(rs_n, svoff, so, n);
+                    osk::buf_store_nt(rs_g, svoff, so, ghn); osk::buf_store_nt(rs_h, svoff, so, hn);
+                }
+            }
+        }
+        lds_barrier();   // h_t complete
+    }
+    const float *hT = hl2 + (a.T & 1) * BM * HS;
+    if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B, threadIdx.x, 512);
+    if (a.h_last) write_back(hT, a.h_last, threadIdx.x, 512);
+}
+
 // Re-pack the torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order;
 // all layers in one launch (blockIdx.z = layer): the training step re-packs every optimisation step
 struct PackAll {
@@ -520,9 +684,17 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
     if (a.K > 192) split = false;                                    // its x tile staging covers 12 x 16 inputs
     if (ctx->tune_gru_split == 0) split = false;
+    const bool ahead = split && NCH == 4 && a.K <= 192 && (size_t)a.T * a.B * H * 4 < ((size_t)1 << 32) && ctx->tune_gru_ahead != 0;
     const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s,
-                                   split ? "gru_layer_split_kernel" : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
-    if (split) {
+                                   ahead ? "gru_layer_ahead_kernel" : split ? "gru_layer_split_kernel" : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
+    if (ahead) {
+        const size_t lds_a = ((size_t)2 * 32 * (H + 1) + (size_t)32 * (2 * a.KPx + 1) + (size_t)4 * 48 * 64) * sizeof(float);
+        if (!ctx->ahead_attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_ahead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->ahead_attr_set = true;
+        }
+        hipLaunchKernelGGL(gru_layer_ahead_kernel, dim3((a.B + 31) / 32), dim3(512), lds_a, s, a);
+    } else if (split) {
         const int parts = 8 / NCH;
         const size_t lds_s = ((size_t)2 * 32 * (H + 1) + (size_t)2 * 32 * (2 * a.KPx + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
         if (!ctx->split_attr_set) {

@@ -19,6 +19,7 @@ struct os_ctx {
     int rows_kernel_below;               // use the 16-lanes-per-trajectory kernel when B is below this
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
+    int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
     int tune_dw_rps;                     // rows per dW slice
     int tune_sweep_wr;                   // backward sweep: leading k-pairs of a wave's weight chunk kept in registers (32, 16 or 0)
     int tune_sweep_nw;                   // 0 automatic, 4 / 8 waves per backward-sweep workgroup
@@ -44,7 +45,7 @@ struct os_ctx {
     double mpc_w[12], mpc_rw, mpc_mu, mpc_fzmax;
     double mass64, inertia64[3], gz64;
     float *mpc_scratch; size_t mpc_scratch_floats;
-    bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
+    bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set, ahead_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
     // per-kernel timing (os_profile_*): ring of event pairs
