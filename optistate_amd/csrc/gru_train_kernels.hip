@@ -635,6 +635,11 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
 // (non-template helpers: inside the kernel template hipcc's host pass silently drops the kernel's launch stub when it meets
 // these builtins)
 __device__ __forceinline__ void lds_dma16(const float *g, float *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+// buffer form: range-checked, the tile's row base in an SGPR offset, the piece's position inside the tile in one VGPR
+__device__ __forceinline__ void lds_dma16_buf(osk::rsrc_t r, float *l, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ void buf_atomic_add(float v, osk::rsrc_t r, uint32_t voff, uint32_t soff)
 {
     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, voff, soff, 0);
@@ -667,26 +672,30 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
     float bsum = 0.f;
     for (int kc0 = 0; kc0 < nkc; kc0 += NC) {
         const int kbase = kc0 * 32, kw = (a.K - kbase) < PITCH ? (a.K - kbase) : PITCH;       // columns of this pass
-        // fixed tile positions of this thread's pieces; a piece in the padding of a row (or past the slice) re-reads a valid one
-        int prow[NP], pcol[NP];
+        // Fixed position of this thread's pieces inside a tile: ONE byte offset each (rows of a tile are `rstride` floats
+        // apart: K, or T*K for the batch_first input, where a 32-row tile is 32 consecutive windows of one time step -- the
+        // host only picks this kernel for that layout when B and the slices are multiples of 32).  The tile's row base rides in
+        // the SGPR offset and the range check zero-fills what lies past X, so a tile costs a few scalar instructions instead of
+        // ~50 vector ones per piece (64-bit clamps, div/mod for the batch_first rows): measured 19 k of a workgroup's 105 k
+        // cycles, on the pipe the fp32 MFMAs need.  A piece in the padding columns of a pass points out of range (zeros).
+        const uint32_t rstride = a.x_btf ? (uint32_t)a.T * (uint32_t)a.K : (uint32_t)a.K;
+        uint32_t pvo[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int p = (threadIdx.x & (NTH - 1)) + NTH * i;
-            prow[i] = p / PPR;
-            const int c4 = 4 * (p % PPR);
-            pcol[i] = kbase + (c4 < kw ? c4 : 0);
+            const int prow = p / PPR, c4 = 4 * (p % PPR);
+            pvo[i] = c4 < kw ? ((uint32_t)prow * rstride + (uint32_t)(kbase + c4)) * 4u : 0x80000000u;
         }
+        const osk::rsrc_t rxs = osk::make_rsrc(a.X, (uint32_t)((size_t)a.T * a.B * a.K * 4));
         auto dma = [&](int tile, int buf) {
             if (NWV == 12 && wave >= 8) return;          // wave-uniform
+            const uint32_t xr0 = (uint32_t)(r0 - a.x_row_shift) + (uint32_t)tile * DW_TR;          // first X row of the tile
+            const uint32_t so = __builtin_amdgcn_readfirstlane(
+                (a.x_btf ? (xr0 % (uint32_t)a.B) * (uint32_t)a.T + xr0 / (uint32_t)a.B : xr0) * (uint32_t)a.K * 4u);
 #pragma unroll
-            for (int i = 0; i < NP; i++) {
-                size_t rr = r0 + (size_t)tile * DW_TR + prow[i];
-                if (rr >= r1) rr = r1 - 1;
-                const uint32_t xr = (uint32_t)(rr - a.x_row_shift);
-                const size_t off = a.x_btf ? ((size_t)(xr % (uint32_t)a.B) * a.T + xr / (uint32_t)a.B) * (size_t)a.K : (size_t)xr * (size_t)a.K;
+            for (int i = 0; i < NP; i++)
                 // LDS destination: wave-uniform base + lane * 16 (the pieces of one instruction are contiguous in the tile image)
-                lds_dma16(a.X + off + pcol[i], &Xs[buf][(wave * 64 + NTH * i) * 4]);
-            }
+                lds_dma16_buf(rxs, &Xs[buf][(wave * 64 + NTH * i) * 4], pvo[i], so);
         };
         f32x16 acc[NC];
 #pragma unroll
@@ -707,12 +716,20 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
 #pragma unroll
             for (int st = 0; st < DW_TR / 2; st++) bsum = fmaf(av[st], bw, bsum);
             if (xz) return;
+            // B fragments one 2-row step ahead of the MFMAs that use them (read - wait - MFMA in lockstep left the LDS latency
+            // of every step exposed whenever the other workgroup's wave on the SIMD was not there to cover it)
+            float xv[2][NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) xv[0][c] = xb[c * 32];
 #pragma unroll
             for (int st = 0; st < DW_TR / 2; st++) {
+                if (st + 1 < DW_TR / 2) {
 #pragma unroll
-                for (int c = 0; c < NC; c++)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], xb[2 * st * PITCH + c * 32], acc[c], 0, 0, 0);
-                if (st & 1) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of a tile from being hoisted (spills)
+                    for (int c = 0; c < NC; c++) xv[(st + 1) & 1][c] = xb[2 * (st + 1) * PITCH + c * 32];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], xv[st & 1][c], acc[c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                  // keep the LDS reads of a tile from being hoisted (spills)
             }
         };
         if (!xzero(0)) dma(0, 0);
@@ -803,7 +820,9 @@ using namespace ost;
 static void launch_dw(const DwArgs &d, int K, dim3 grid, hipStream_t s)
 {
     const int nkc = (K + 31) / 32;
-    const bool v4 = (K & 3) == 0;
+    // dw2_kernel: 16-byte pieces (K % 4), X within one 32-bit buffer, and for the batch_first input whole 32-window tiles
+    const bool v4 = (K & 3) == 0 && (size_t)d.T * d.B * K * 4 < ((size_t)1 << 31) &&
+                    (!d.x_btf || (d.B % DW_TR == 0 && d.rows_per_slice % DW_TR == 0 && (d.r_begin - d.x_row_shift) % DW_TR == 0));
 #define OS_DW(NC)                                                                          \
     do {                                                                                   \
         if (v4) hipLaunchKernelGGL((dw2_kernel<NC>), grid, dim3(256), 0, s, d);             \
