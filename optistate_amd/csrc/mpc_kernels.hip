@@ -263,39 +263,23 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     return L.pad ? 0.0 : u;
 }
 
-// NST = number of legs that carry force variables (contact byte != 0).  Swing legs are eliminated up front: a trot
-// problem has 30 variables, not 60 (elimination work ~ n^3), and each instance gets the register budget its row needs.
-// Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
+// Per-lane solver state that survives a call: the lane's variable and the face of its leg-step (warm start of the next step)
+struct QpLane {
+    double u;
+    int face;                 // (sx + 1) | (sy + 1) << 2 | sz << 4
+};
+
+// One QP on the calling wavefront.  x, ref, p: the problem data (wave-uniform); warm: start from io (same contact word as the
+// call that produced it).  Returns in `val` (lanes 0..59) the optimal control in the reference's variable order (12 per horizon
+// step, leg-major, swing legs zero), in io the state for the next warm start.
 template <int NST>
-__global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const MpcArgs a)
+__device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbits, const int (&legs)[4], const double (&x)[12],
+                                               const double (&ref)[12], const double (&p)[12], int max_iter, bool warm,
+                                               WaveMemT<15 * NST> &M, QpLane &io, float &val, int &iters_out, bool &converged_out)
 {
     constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST;
-    typedef WaveMemT<15 * NST> WaveMem;
-    __shared__ WaveMem M;
-    const MpcParams &P = a.prm;
-    const int b = blockIdx.x;
-    const size_t B = (size_t)a.B;
-    const uint32_t cbits = a.contact[b];
-    int legs[4] = {0, 0, 0, 0}, nst = 0;
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-        if (((cbits >> (8 * l)) & 0xffu) != 0u) {
-            if (nst == 0) legs[0] = l; else if (nst == 1) legs[1] = l; else if (nst == 2) legs[2] = l; else legs[3] = l;
-            nst++;
-        }
-    }
-    if (nst == 0 && NST == 1) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
-        const int t = threadIdx.x;
-        if (t < 12) a.f_out[(size_t)t * B + b] = 0.f;
-        if (a.u_out && t < 60) a.u_out[(size_t)t * B + b] = 0.f;
-        if (t == 0 && a.iters) a.iters[b] = 0;
-        if (t == 0 && a.warm_contact) a.warm_contact[b] = cbits;
-        return;
-    }
-    if (nst != NST) return;
-
     LaneCtx L;
-    L.lane = threadIdx.x;
+    L.lane = threadIdx.x & 63;
     L.pad = L.lane >= NV;
     L.v = L.pad ? NV - 1 : L.lane;
     L.i = L.v / NPS; L.c = L.v % 3; L.ls = L.v / 3;
@@ -305,13 +289,6 @@ __global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const M
     }
 
     // ---- problem data (wave-uniform) ----
-    double x[12], ref[12], p[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        x[j] = (double)a.x[(size_t)j * B + b];
-        ref[j] = (double)a.ref[(size_t)j * B + b];
-        p[j] = (double)a.p[(size_t)j * B + b];
-    }
     const uint32_t cleg = (cbits >> (8 * L.leg)) & 0xffu;
     const bool stance = cleg == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
 
@@ -395,14 +372,13 @@ __global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const M
     double u = 0.0;
     int iters = 0;
     bool first = true, done = false, converged = false;
-    if (a.warm_u && a.warm_contact[b] == cbits) {
-        u = a.warm_u[(size_t)b * 64 + L.lane];
-        const int st = a.warm_state[(size_t)b * 64 + L.lane];
-        sx = (st & 3) - 1; sy = ((st >> 2) & 3) - 1; sz = (st >> 4) & 3;
+    if (warm) {
+        u = io.u;
+        sx = (io.face & 3) - 1; sy = ((io.face >> 2) & 3) - 1; sz = (io.face >> 4) & 3;
         first = false;
     }
     constexpr double EPS = 1e-11, TOL = 1e-12;
-    while (!done && iters < a.max_iter) {
+    while (!done && iters < max_iter) {
         iters++;
         const double us = solve_face<NST>(L, P, M, sx, sy, sz, cw, cv);
         if (first) {
@@ -532,26 +508,78 @@ __global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const M
         }
     }
 
+
     // ---- outputs in the reference's variable order (12 per horizon step, leg-major); swing legs are zero ----
     __builtin_amdgcn_wave_barrier();
     if (!L.pad) M.vec[L.v] = u;
     __builtin_amdgcn_wave_barrier();
+    val = 0.f;
     if (L.lane < 60) {
         const int oi = L.lane / 12, oleg = (L.lane % 12) / 3, oc = L.lane % 3;
         int rank = -1;
 #pragma unroll
         for (int r = 0; r < NST; r++)
             if ((r == 0 ? legs[0] : (r == 1 ? legs[1] : (r == 2 ? legs[2] : legs[3]))) == oleg) rank = r;
-        const float val = rank < 0 ? 0.f : (float)M.vec[oi * NPS + 3 * rank + oc];
-        if (L.lane < 12) a.f_out[(size_t)L.lane * B + b] = val;
-        if (a.u_out) a.u_out[(size_t)L.lane * B + b] = val;
+        val = rank < 0 ? 0.f : (float)M.vec[oi * NPS + 3 * rank + oc];
     }
+    __builtin_amdgcn_wave_barrier();
+    io.u = L.pad ? 0.0 : u;
+    io.face = (sx + 1) | ((sy + 1) << 2) | (sz << 4);
+    iters_out = iters;
+    converged_out = converged;
+}
+
+// NST = number of legs that carry force variables (contact byte != 0).  Swing legs are eliminated up front: a trot
+// problem has 30 variables, not 60 (elimination work ~ n^3), and each instance gets the register budget its row needs.
+// Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
+template <int NST>
+__global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const MpcArgs a)
+{
+    typedef WaveMemT<15 * NST> WaveMem;
+    __shared__ WaveMem M;
+    const int b = blockIdx.x;
+    const size_t B = (size_t)a.B;
+    const uint32_t cbits = a.contact[b];
+    int legs[4] = {0, 0, 0, 0}, nst = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        if (((cbits >> (8 * l)) & 0xffu) != 0u) {
+            if (nst == 0) legs[0] = l; else if (nst == 1) legs[1] = l; else if (nst == 2) legs[2] = l; else legs[3] = l;
+            nst++;
+        }
+    }
+    if (nst == 0 && NST == 1) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
+        const int t = threadIdx.x;
+        if (t < 12) a.f_out[(size_t)t * B + b] = 0.f;
+        if (a.u_out && t < 60) a.u_out[(size_t)t * B + b] = 0.f;
+        if (t == 0 && a.iters) a.iters[b] = 0;
+        if (t == 0 && a.warm_contact) a.warm_contact[b] = cbits;
+        return;
+    }
+    if (nst != NST) return;
+    const int lane = threadIdx.x;
+    double x[12], ref[12], p[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        x[j] = (double)a.x[(size_t)j * B + b];
+        ref[j] = (double)a.ref[(size_t)j * B + b];
+        p[j] = (double)a.p[(size_t)j * B + b];
+    }
+    QpLane io = {0.0, 0};
+    const bool warm = a.warm_u && a.warm_contact[b] == cbits;
+    if (warm) { io.u = a.warm_u[(size_t)b * 64 + lane]; io.face = a.warm_state[(size_t)b * 64 + lane]; }
+    float val;
+    int iters;
+    bool converged;
+    mpc_solve_wave<NST>(a.prm, cbits, legs, x, ref, p, a.max_iter, warm, M, io, val, iters, converged);
+    if (lane < 12) a.f_out[(size_t)lane * B + b] = val;
+    if (a.u_out && lane < 60) a.u_out[(size_t)lane * B + b] = val;
     if (a.warm_u) {
-        a.warm_u[(size_t)b * 64 + L.lane] = L.pad ? 0.0 : u;
-        a.warm_state[(size_t)b * 64 + L.lane] = (uint8_t)((sx + 1) | ((sy + 1) << 2) | (sz << 4));
-        if (L.lane == 0) a.warm_contact[b] = cbits;
+        a.warm_u[(size_t)b * 64 + lane] = io.u;
+        a.warm_state[(size_t)b * 64 + lane] = (uint8_t)io.face;
+        if (lane == 0) a.warm_contact[b] = cbits;
     }
-    if (L.lane == 0) {
+    if (lane == 0) {
         if (a.iters) a.iters[b] = iters;
         if (!converged) a.status[b] |= 4;
     }
