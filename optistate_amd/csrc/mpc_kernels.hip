@@ -585,6 +585,284 @@ __global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const M
     }
 }
 
+// =====================================================================================================================
+// estimate_state_mpc as ONE persistent kernel: a wavefront owns a trajectory for all T steps -- QP (mpc_solve_wave, warm
+// start in registers) -> get_odom / set_measurements / next_state (float32, computed redundantly on every lane: a few
+// hundred instructions) -> predict_mpc covariance and the batch update with the 12 x 12 covariance in LDS, FLOAT64, spread
+// over the 64 lanes.  The per-step launch sequence (two to five kernels, a T = 1 filter launch whose one-trajectory-per-lane
+// float64 update is a ~100 k-cycle dependent chain, a status kernel) cost 215-280 us per step at the reference's own shape
+// (B = 8, T ~ 4000); here a step is the QP plus ~10 k cycles of filter.  P stays in float64 between steps, as in the
+// reference (the launch sequence rounded it to float32 at every step boundary).
+// =====================================================================================================================
+struct KfWave {
+    double P[144], Mt[144];      // covariance, scratch (F_d P)
+    double L[10][10];            // S, then its Cholesky factor (lower triangle)
+    double K[12][10];
+    double Q[144], R[100];       // symmetrised R
+    double cs[12], rs[12], dinv[10];
+    double e[10];                // exp(dt R^T_ij) - 1 of the body_ref rotation (9) and e^dt - 1
+    float xs[12];
+};
+
+struct MpcRunArgs {
+    osk::KfRunArgs kf;             // streams, state, outputs, noise (k)
+    float *f_out;                  // [T][12][B]
+    int32_t *iters;                // [T][B] or null
+    int max_iter, cold;
+    MpcParams prm;
+};
+
+// P <- F_d P F_d^T + Q with F_d = 1 1^T + E (cov_predict_dense in kf_device.hpp, same operation order per entry)
+__device__ __forceinline__ void cov_predict_dense_wave(KfWave &W, const osk::Rot &rb, float dt, int lane)
+{
+    if (lane < 9) W.e[lane] = expm1((double)dt * (double)rb.m[3 * (lane % 3) + lane / 3]);      // e[3 i + kk] = expm1(dt R[kk][i])
+    if (lane == 9) W.e[9] = expm1((double)dt);
+    if (lane < 12) {
+        double c = 0.0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) c += W.P[i * 12 + lane];
+        W.cs[lane] = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double ed = W.e[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int el = lane + 64 * r;
+        if (el < 144) {
+            const int i = el / 12, j = el % 12;
+            double m = W.cs[j];
+            if (i < 3) m += W.e[3 * i] * W.P[6 * 12 + j] + W.e[3 * i + 1] * W.P[7 * 12 + j] + W.e[3 * i + 2] * W.P[8 * 12 + j];
+            else if (i < 6) m += ed * W.P[(i + 6) * 12 + j];
+            W.Mt[el] = m;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 12) {
+        double c = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) c += W.Mt[lane * 12 + j];
+        W.rs[lane] = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int el = lane + 64 * r;
+        if (el < 144) {
+            const int i = el / 12, j = el % 12;
+            double v = W.rs[i] + W.Q[el];
+            if (j < 3) v += W.e[3 * j] * W.Mt[i * 12 + 6] + W.e[3 * j + 1] * W.Mt[i * 12 + 7] + W.e[3 * j + 2] * W.Mt[i * 12 + 8];
+            else if (j < 6) v += ed * W.Mt[i * 12 + j + 6];
+            W.P[el] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Batch update (update_batch in kf_device.hpp: y = z - x[sel]; S = P[sel,sel] + R; K = P[:,sel] S^-1; x += K y;
+// P <- P - K P[sel,:]) on the LDS-resident covariance.  x: the state, replicated on every lane.  Returns status bit 0
+// (S not positive definite) wave-uniformly; *kgain = sum of the ten main-diagonal entries of K, *ptrace = trace(P).
+__device__ __forceinline__ int update_batch_wave(float *x, KfWave &W, const float *z, int lane, float *kgain, float *ptrace,
+                                                 float *xnew_lane)
+{
+    using osk::SEL;
+    int status = 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int el = lane + 64 * r;
+        if (el < 100) {
+            const int a = el / 10, b = el % 10;
+            if (b <= a) W.L[a][b] = 0.5 * (W.P[SEL[a] * 12 + SEL[b]] + W.P[SEL[b] * 12 + SEL[a]]) + W.R[el];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // Cholesky, column by column: the pivot is recomputed by every lane (wave-uniform LDS reads), lane i > j updates L[i][j]
+    for (int j = 0; j < 10; j++) {
+        double d = W.L[j][j];
+        for (int q = 0; q < j; q++) d -= W.L[j][q] * W.L[j][q];
+        if (!(d > 0.0) || !(d < 3.0e38)) { status |= 1; d = 1.0; }
+        const double di = 1.0 / sqrt(d);
+        if (lane > j && lane < 10) {
+            double sacc = W.L[lane][j];
+            for (int q = 0; q < j; q++) sacc -= W.L[lane][q] * W.L[j][q];
+            W.L[lane][j] = sacc * di;
+        }
+        if (lane == 0) { W.dinv[j] = di; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) W.L[j][j] = d * di;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // K[i,:] = solve(S, P[i,sel]): lane i < 12 does row i (forward and back substitution against wave-uniform L entries)
+    double Krow[10];
+    {
+        const int i = lane < 12 ? lane : 0;
+        double y[10];
+#pragma unroll
+        for (int a = 0; a < 10; a++) {
+            double sacc = W.P[i * 12 + SEL[a]];
+#pragma unroll
+            for (int q = 0; q < a; q++) sacc -= W.L[a][q] * y[q];
+            y[a] = sacc * W.dinv[a];
+        }
+#pragma unroll
+        for (int a = 9; a >= 0; a--) {
+            double sacc = y[a];
+#pragma unroll
+            for (int q = a + 1; q < 10; q++) sacc -= W.L[q][a] * Krow[q];
+            Krow[a] = sacc * W.dinv[a];
+        }
+        if (lane < 12) {
+#pragma unroll
+            for (int a = 0; a < 10; a++) W.K[lane][a] = Krow[a];
+        }
+        double sx = 0.0;
+#pragma unroll
+        for (int a = 0; a < 10; a++) sx += Krow[a] * ((double)z[a] - (double)x[SEL[a]]);
+        // x[i] of this lane's row (replicated array: pick it through LDS)
+        if (lane < 12) W.xs[lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            if (lane == k) W.xs[k] = (float)((double)x[k] + sx);
+        __builtin_amdgcn_wave_barrier();
+        *xnew_lane = W.xs[i];
+#pragma unroll
+        for (int k = 0; k < 12; k++) x[k] = W.xs[k];
+    }
+    // P <- P - K P[sel,:]: every entry reads only OLD rows; all three values of a lane are formed before any is written
+    double pn[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int el = lane + 64 * r;
+        pn[r] = 0.0;
+        if (el < 144) {
+            const int i = el / 12, j = el % 12;
+            double sacc = 0.0;
+#pragma unroll
+            for (int a = 0; a < 10; a++) sacc += W.K[i][a] * W.P[SEL[a] * 12 + j];
+            pn[r] = W.P[el] - sacc;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int el = lane + 64 * r;
+        if (el < 144) W.P[el] = pn[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double tk = 0.0, tp = 0.0;
+#pragma unroll
+    for (int a = 0; a < 10; a++) tk += W.K[a][a];
+#pragma unroll
+    for (int i = 0; i < 12; i++) tp += W.P[i * 13];
+    *kgain = (float)tk;
+    *ptrace = (float)tp;
+    return status;
+}
+
+union QpMem {
+    WaveMemT<15> m1;
+    WaveMemT<30> m2;
+    WaveMemT<45> m3;
+    WaveMemT<60> m4;
+    __device__ QpMem() {}
+};
+
+__global__ __launch_bounds__(64, 2) void kf_mpc_persistent_kernel(const MpcRunArgs a)
+{
+    __shared__ QpMem QM;
+    __shared__ KfWave W;
+    using namespace osk;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t B = (size_t)a.kf.B;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.kf.B * 4u;
+    float x[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) x[i] = a.kf.x[(size_t)i * B + b];
+    for (int el = lane; el < 144; el += 64) {
+        W.P[el] = (double)a.kf.P[(size_t)el * B + b];
+        W.Q[el] = (double)a.kf.k.Q[el];
+    }
+    for (int el = lane; el < 100; el += 64) {
+        const int r = el / 10, c = el % 10;
+        W.R[el] = (double)(0.5f * (a.kf.k.R[r * 10 + c] + a.kf.k.R[c * 10 + r]));
+    }
+    __builtin_amdgcn_wave_barrier();
+    QpLane qio = {0.0, 0};
+    uint32_t prev_c = 0xffffffffu;
+    int status = 0;
+    // inputs of a step: every lane reads the same 55 dwords (broadcast); the next step's are requested before the QP and land
+    // underneath it (un-prefetched, their HBM round trips were 8-15 k cycles of every step)
+    StepIn in_n;
+    float bref_n[12];
+    auto fetch = [&](int t) {
+        load_step(a.kf, t, voff, rowB, in_n);
+        rsrc_t rb = make_rsrc(a.kf.body_ref + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+        for (int i = 0; i < 12; i++) bref_n[i] = buf_load_nt(rb, voff, i * rowB);
+    };
+    fetch(0);
+    for (int t = 0; t < a.kf.T; t++) {
+        StepIn in = in_n;
+        float bref[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) bref[i] = bref_n[i];
+        fetch(t + 1 < a.kf.T ? t + 1 : t);
+        // ---- forces from the state BEFORE this step's predict (kalman_filter.py:141-152) ----
+        const uint32_t cbits = __builtin_amdgcn_readfirstlane(in.contact);
+        int legs[4] = {0, 0, 0, 0}, nst = 0;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            if (((cbits >> (8 * l)) & 0xffu) != 0u) {
+                if (nst == 0) legs[0] = l; else if (nst == 1) legs[1] = l; else if (nst == 2) legs[2] = l; else legs[3] = l;
+                nst++;
+            }
+        }
+        float fval = 0.f;
+        int iters = 0;
+        if (nst > 0) {
+            double xd[12], rd[12], pd[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) { xd[j] = (double)x[j]; rd[j] = (double)bref[j]; pd[j] = (double)in.p[j]; }
+            const bool warm = !a.cold && cbits == prev_c;
+            bool conv = true;
+            if (nst == 1) mpc_solve_wave<1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
+            else if (nst == 2) mpc_solve_wave<2>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
+            else if (nst == 3) mpc_solve_wave<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
+            else mpc_solve_wave<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
+            if (!conv) status |= 4;
+        }
+        prev_c = cbits;
+        if (lane < 12) a.f_out[((size_t)t * 12 + lane) * B + b] = fval;
+        if (a.iters && lane == 0) a.iters[(size_t)t * B + b] = iters;
+#pragma unroll
+        for (int j = 0; j < 12; j++) in.f[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fval), j));
+        // ---- get_odom + set_measurements + predict_mpc + next_state + update (kalman_filter.py:176-182) ----
+        float z[NM], pw[12], kgain = 0.f, ptrace = 0.f, xl = 0.f;
+        measurement(in, z);
+        const Rot r = rotation(x[0], x[1], x[2]);
+        const Rot rb = rotation(bref[0], bref[1], bref[2]);
+        cov_predict_dense_wave(W, rb, a.kf.k.dt, lane);
+        dynamics(x, r, in.p, in.f, pw, a.kf.k);
+        status |= update_batch_wave(x, W, z, lane, &kgain, &ptrace, &xl);
+        status |= finite_status(x);
+        if (lane < 12) a.kf.x_out[((size_t)t * 12 + lane) * B + b] = xl;
+        if (lane == 0) {
+            if (a.kf.p_rot_out) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) a.kf.p_rot_out[((size_t)t * 12 + i) * B + b] = pw[i];
+            }
+            if (a.kf.ptrace_out) a.kf.ptrace_out[(size_t)t * B + b] = ptrace;
+            if (a.kf.kgain_out) a.kf.kgain_out[(size_t)t * B + b] = kgain;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) a.kf.x[(size_t)i * B + b] = x[i];
+        a.kf.status[b] = status;
+    }
+    for (int el = lane; el < 144; el += 64) a.kf.P[(size_t)el * B + b] = (float)W.P[el];
+}
+
 // which leg counts occur at each step of a [T][B] contact stream: flags[t] bit n set <=> some trajectory has n legs on the ground
 __global__ void nst_presence_kernel(int B, int T, const uint32_t *contact, uint32_t *flags)
 {
@@ -673,6 +951,26 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->tune_mpc_persistent) {
+        // one launch, one wavefront per trajectory for all T steps; nothing is read back, nothing synchronises
+        osm::MpcRunArgs m;
+        osk::KfRunArgs &a = m.kf;
+        a.B = B; a.T = T; a.p = p; a.f = f_out; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = body_ref;
+        a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = p_rot_out; a.ptrace_out = ptrace_out; a.kgain_out = kgain_out;
+        a.status = status; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
+        a.k = ctx->k;
+        m.f_out = f_out; m.iters = mpc_iters; m.max_iter = 200; m.cold = (flags & OS_MPC_COLD_START) ? 1 : 0;
+        {
+            osm::MpcArgs tmp;
+            osm::fill_args(ctx, tmp);
+            m.prm = tmp.prm;
+        }
+        const int slot = os_prof_begin(ctx, 4, s, "kf_mpc_persistent_kernel");
+        hipLaunchKernelGGL(osm::kf_mpc_persistent_kernel, dim3(B), dim3(64), 0, s, m);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     // scratch: warm-start store (u [B][64] doubles, faces [B][64] bytes, contact [B]) + per-step Kalman status [B] +
     // leg-count presence flags [T]
     const size_t need = (size_t)B * 128 + (size_t)B * 16 + (size_t)B + (size_t)B + (size_t)T;
