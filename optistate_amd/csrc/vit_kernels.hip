@@ -88,10 +88,41 @@ __global__ void attention_kernel(int L, int D, int heads, const float *QKV, cons
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 constexpr int ATT_HD = 32, ATT_KS = ATT_HD + 1, ATT_MAXT = 8;      // up to 256 tokens
 
-template <int NT /* key / query tiles = ceil(L / 32) */>
-__global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
+// Reduction over the 32 lanes of a wave half (the columns of a C-layout row) on the VALU's data-parallel-primitive paths:
+// two quad permutes, row_half_mirror, row_mirror (all fused into the max / add as DPP operands), then v_permlane16_swap
+// pairs the two 16-lane rows of the half.  The __shfl_xor form was five ds_bpermute round trips per reduction, 160 per
+// query tile.  (Inline asm for the swap: hipcc of ROCm 7.2 drops the second result of __builtin_amdgcn_permlane16_swap.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
 {
-    extern __shared__ float sm[];            // K [L][33] | V [L][33] | P tiles [4][32][33]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void rows_swap16(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+    float a = v, b = v;
+    rows_swap16(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_sum(float v)
+{
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    float a = v, b = v;
+    rows_swap16(a, b);
+    return a + b;
+}
+
+// NW waves per workgroup: with eight, the seven query tiles of the reference's 197 tokens run side by side (one per wave, two
+// waves per SIMD covering each other's softmax and LDS round trips) instead of two rounds over four waves with one idle in
+// the second, and the head's K / V are still staged once.
+template <int NT /* key / query tiles = ceil(L / 32) */, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 1) void attention_mfma_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
+{
+    extern __shared__ float sm[];            // K [L][33] | V [L][33] | P tiles [NW][32][33]
     float *Ks = sm, *Vs = sm + (size_t)L * ATT_KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     float *pt = sm + (size_t)2 * L * ATT_KS + (size_t)wave * 32 * ATT_KS;
@@ -102,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, in
     {
         const int c4 = (threadIdx.x & 7) * 4;                       // 8 float4 per 32-wide head row
 #pragma unroll 4
-        for (int l = threadIdx.x >> 3; l < L; l += 32) {
+        for (int l = threadIdx.x >> 3; l < L; l += NW * 8) {
             const float4 kv = *reinterpret_cast<const float4 *>(base + (size_t)l * 3 * D + D + h * ATT_HD + c4);
             const float4 vv = *reinterpret_cast<const float4 *>(base + (size_t)l * 3 * D + 2 * D + h * ATT_HD + c4);
             float *kd = Ks + l * ATT_KS + c4, *vd = Vs + l * ATT_KS + c4;
@@ -111,8 +142,9 @@ __global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, in
         }
     }
     __syncthreads();
-    const float scale = rsqrtf((float)ATT_HD);
-    for (int qt = wave; qt < NT; qt += 4) {
+    // 1/sqrt(d) and log2(e) folded into Q: the softmax numerators are exp2(S' - max'), one v_exp_f32 per score and no multiply
+    const float scale = rsqrtf((float)ATT_HD) * 1.44269504088896341f;
+    for (int qt = wave; qt < NT; qt += NW) {
         const int r0 = 32 * qt;
         // Q tile as A fragments: lane -> (row r0 + li, dim 2q + lh)
         const int qrow = r0 + li < L ? r0 + li : L - 1;
@@ -152,18 +184,14 @@ __global__ __launch_bounds__(256, 1) void attention_mfma_kernel(int L, int D, in
             float m = S[0][e];
 #pragma unroll
             for (int jt = 1; jt < NT; jt++) m = fmaxf(m, S[jt][e]);
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            mx[e] = m;
+            mx[e] = half_max(m);
         }
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             float d = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < NT; jt++) { const float pv = __expf(S[jt][e] - mx[e]); S[jt][e] = pv; d += pv; }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            den[e] = d;
+            for (int jt = 0; jt < NT; jt++) { const float pv = __builtin_amdgcn_exp2f(S[jt][e] - mx[e]); S[jt][e] = pv; d += pv; }
+            den[e] = half_sum(d);
         }
         // O = P V
         f32x16v acc;
@@ -531,12 +559,12 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         const int ntl = (L + 31) / 32;
         slot = os_prof_begin(ctx, OS_PHASE_VIT_ATTN, s, (hd == 32 && ntl == 7) ? "attention_mfma_kernel<7>" : "attention_kernel");
         if (hd == 32 && ntl == 7) {              // the reference's shape: 197 tokens, head_dim 32 -> matrix cores
-            const size_t mlds = ((size_t)2 * L * 33 + 4 * 32 * 33) * sizeof(float);
+            const size_t mlds = ((size_t)2 * L * 33 + 8 * 32 * 33) * sizeof(float);
             if (!v->att_attr_set) {
-                OS_HIP(ctx, hipFuncSetAttribute((const void *)attention_mfma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)attention_mfma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 v->att_attr_set = true;
             }
-            hipLaunchKernelGGL(attention_mfma_kernel<7>, dim3(N * d.heads), dim3(256), mlds, s, L, D, d.heads, big, qkvb, Y);
+            hipLaunchKernelGGL(attention_mfma_kernel<7>, dim3(N * d.heads), dim3(512), mlds, s, L, D, d.heads, big, qkvb, Y);
         } else if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         else hipLaunchKernelGGL(attention_kernel<64>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         os_prof_end(ctx, slot, s);
