@@ -170,7 +170,7 @@ struct SweepArgs {
     const float *dy;             // [T][B][H] gradient w.r.t. this layer's outputs, or null
     const float *dy_last;        // [B][H] gradient w.r.t. h_T only (top layer), or null
     const float *wihT, *whhT;    // transposed-packed weights
-    float *dgi, *dgh;            // [T][B][3H]
+    float *dg4;                  // [T][B][4H]: da_r | da_z | da_n | da_n * r  (W_ih's products read sections 0-2, W_hh's 0, 1, 3)
     float *dx;                   // [T][B][K]
     int dbg;
 };
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
         if (!(a.dbg & 1)) {
             const float *__restrict__ pdl = a.dy_last;
             const bool last = (t == a.T - 1);
-            const uint32_t gbytes = (uint32_t)((size_t)a.T * B * 3 * H * 4), gstep = (uint32_t)((size_t)t * B * 3 * H * 4), gH = (uint32_t)H * 4u;
-            const osk::rsrc_t rgi_ = osk::make_rsrc(a.dgi, gbytes), rgh_ = osk::make_rsrc(a.dgh, gbytes);
+            const uint32_t gbytes = (uint32_t)((size_t)a.T * B * 4 * H * 4), gstep = (uint32_t)((size_t)t * B * 4 * H * 4), gH = (uint32_t)H * 4u;
+            const osk::rsrc_t rg4_ = osk::make_rsrc(a.dg4, gbytes);
 #pragma unroll
             for (int e = 0; e < ELP; e++) {
                 const int i = threadIdx.x + e * NT;
@@ -279,11 +279,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                 if (ok) {
                     // buffer stores: the element's offset register is shared by the six streams (gate thirds through the SGPR
                     // offset); flat 64-bit addresses for 48 stores in flight cost ~100 registers and spilled the prefetch
-                    const uint32_t og = (uint32_t)(((size_t)g * 3 * H + c) * 4);
-                    osk::buf_store_nt(rgi_, og, gstep, dar); osk::buf_store_nt(rgi_, og, gstep + gH, daz);
-                    osk::buf_store_nt(rgi_, og, gstep + 2 * gH, dan);
-                    osk::buf_store_nt(rgh_, og, gstep, dar); osk::buf_store_nt(rgh_, og, gstep + gH, daz);
-                    osk::buf_store_nt(rgh_, og, gstep + 2 * gH, danr);
+                    const uint32_t og = (uint32_t)(((size_t)g * 4 * H + c) * 4);
+                    osk::buf_store_nt(rg4_, og, gstep, dar); osk::buf_store_nt(rg4_, og, gstep + gH, daz);
+                    osk::buf_store_nt(rg4_, og, gstep + 2 * gH, dan); osk::buf_store_nt(rg4_, og, gstep + 3 * gH, danr);
                 }
                 dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
                 dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
@@ -297,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             const float *__restrict__ pr = a.sv_r, *__restrict__ pz = a.sv_z, *__restrict__ pn = a.sv_n,
                         *__restrict__ pg = a.sv_g, *__restrict__ ph = a.sv_h, *__restrict__ pdy = a.dy,
                         *__restrict__ pdl = a.dy_last;
-            float *__restrict__ ogi = a.dgi, *__restrict__ ogh = a.dgh;
+            float *__restrict__ og4 = a.dg4;
             const bool last = (t == a.T - 1);
             #pragma unroll 8
             for (int i = threadIdx.x; i < BM * H; i += NT) {
@@ -320,11 +318,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                 const float dar = dan * gg * rr * (1.0f - rr);
                 const float daz = dz * zz * (1.0f - zz);
                 if (ok) {
-                    const size_t og = ((size_t)t * B + g) * (3 * H) + c;
-                    __builtin_nontemporal_store(dar, ogi + og); __builtin_nontemporal_store(daz, ogi + og + H);
-                    __builtin_nontemporal_store(dan, ogi + og + 2 * H);
-                    __builtin_nontemporal_store(dar, ogh + og); __builtin_nontemporal_store(daz, ogh + og + H);
-                    __builtin_nontemporal_store(danr, ogh + og + 2 * H);
+                    const size_t og = ((size_t)t * B + g) * (4 * H) + c;
+                    __builtin_nontemporal_store(dar, og4 + og); __builtin_nontemporal_store(daz, og4 + og + H);
+                    __builtin_nontemporal_store(dan, og4 + og + 2 * H); __builtin_nontemporal_store(danr, og4 + og + 3 * H);
                 }
                 dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
                 dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added below
@@ -478,7 +474,8 @@ struct DwArgs {
     size_t x_row_shift;
     size_t x_valid_from;      // dw2_kernel: rows below this pair with X = 0 (h_{-1}): they only count for the bias sum (multiple of 32)
     int rows_per_slice;
-    const float *dG;          // [rows][H3]
+    const float *dG;          // [rows][ldg]: gate unit j sits in column j (+ nshift for the n gate, j >= 2 H3 / 3)
+    int ldg, nshift;          // the sweep's four-section array: ldg = 4H; nshift = 0 for W_ih (da_n), H for W_hh (da_n * r)
     const float *X;           // [rows][K], or (B, T, K) batch_first when x_btf (row r = t*B + b lives at (b*T + t)*K)
     int x_btf, B, T;
     float *dW;                // [H3][K]
@@ -504,6 +501,7 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
     const int j0 = (blockIdx.x * 4 + wave) * 32;
     const bool jok = j0 < a.H3;
+    const int jc = j0 + (3 * j0 >= 2 * a.H3 ? a.nshift : 0);          // column of the chunk in dG
     const size_t r0 = a.r_begin + (size_t)blockIdx.y * a.rows_per_slice;
     size_t r1 = r0 + a.rows_per_slice;
     if (r1 > a.r_end) r1 = a.r_end;
@@ -576,7 +574,7 @@ __global__ __launch_bounds__(256, VEC4 ? 2 : 1) void dw_kernel(const DwArgs a)
 #pragma unroll
             for (int st = 0; st < DW_TR / 2; st++) {
                 const size_t rr = rt + 2 * st + kk;
-                dst[st] = (jok && tile < ntiles && rr < r1) ? __builtin_nontemporal_load(a.dG + rr * a.H3 + j0 + li) : 0.f;
+                dst[st] = (jok && tile < ntiles && rr < r1) ? __builtin_nontemporal_load(a.dG + rr * a.ldg + jc + li) : 0.f;
             }
         };
         dg_load(0, avb[0]);
@@ -667,8 +665,9 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
     const int ntiles = (int)((r1 - r0 + DW_TR - 1) / DW_TR);
     const uint32_t nrows = (uint32_t)(r1 - r0);
     // this wave's dG column chunk of the slice: [nrows][H3] starting at row r0; a wave without a chunk reads zeros
-    const osk::rsrc_t rg = osk::make_rsrc(a.dG + r0 * a.H3, jok ? nrows * (uint32_t)a.H3 * 4u : 0u);
-    const uint32_t gl = (uint32_t)(kk * a.H3 + j0 + li) * 4u, grow = (uint32_t)a.H3 * 8u;     // two rows per step
+    const int jc = j0 + (3 * j0 >= 2 * a.H3 ? a.nshift : 0);          // column of the chunk in dG
+    const osk::rsrc_t rg = osk::make_rsrc(a.dG + r0 * a.ldg, jok ? nrows * (uint32_t)a.ldg * 4u : 0u);
+    const uint32_t gl = (uint32_t)(kk * a.ldg + jc + li) * 4u, grow = (uint32_t)a.ldg * 8u;     // two rows per step
     float bsum = 0.f;
     for (int kc0 = 0; kc0 < nkc; kc0 += NC) {
         const int kbase = kc0 * 32, kw = (a.K - kbase) < PITCH ? (a.K - kbase) : PITCH;       // columns of this pass
@@ -768,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
 // column sums of columns [n0, N) of a [R][N] row-major matrix into dst (bias gradients): 64 columns x 4 row-lanes per
 // workgroup, 256 rows per workgroup (64 loads per thread, eight in flight), one atomic per column per workgroup
 // copy_src / copy_n: block (0, 0) also copies copy_n floats copy_src -> dst (the r and z thirds of b_hh's gradient equal b_ih's)
-__global__ void colsum_kernel(size_t R, int N, int n0, const float *src, float *dst, const float *copy_src, int copy_n)
+__global__ void colsum_kernel(size_t R, int N, int n0, const float *src /* [R][ld], column n + shift */, int ld, int shift, float *dst, const float *copy_src, int copy_n)
 {
     __shared__ float part[4][64];
     if (blockIdx.x == 0 && blockIdx.y == 0 && copy_src)
@@ -779,7 +778,7 @@ __global__ void colsum_kernel(size_t R, int N, int n0, const float *src, float *
     float s = 0.f;
     if (n < N) {
 #pragma unroll 8
-        for (size_t r = r0 + ry; r < r1; r += 4) s += __builtin_nontemporal_load(src + r * N + n);
+        for (size_t r = r0 + ry; r < r1; r += 4) s += __builtin_nontemporal_load(src + r * ld + n + shift);
     }
     part[ry][cx] = s;
     __syncthreads();
@@ -839,7 +838,7 @@ struct os_train_state {
     float *act;   size_t act_floats;     // saved activations: L x 5 x [T][B][H]
     float *seq;   size_t seq_floats;     // SoA layer outputs [L][T][H][B] (forward inputs of the next layer)
     float *xs;    size_t xs_floats;      // SoA copy of the input [T][I][B]
-    float *dg;    size_t dg_floats;      // dGI, dGH [T][B][3H] x 2
+    float *dg;    size_t dg_floats;      // gate derivatives [T][B][4H]: da_r | da_z | da_n | da_n * r
     float *dxy;   size_t dxy_floats;     // dx ping-pong [T][B][max(K,H)] x 2 + dh_T [B][H]
     float *wT;    size_t wT_floats;      // transposed-packed weights
     int B, T;
@@ -986,7 +985,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     const size_t tbh = (size_t)T * B * H, nparam = os_gru_param_count(&d);
     const int Kmax = I > H ? I : H;
     const bool overlap = ctx->tune_train_overlap != 0 && L > 1;
-    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (overlap ? 4 : 2) * (size_t)T * B * H3)) return -10;
+    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (overlap ? 2 : 1) * (size_t)T * B * 4 * H)) return -10;
     if (overlap && train_side_stream(ctx, ts)) return -10;
     if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, 2 * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
     // transposed-packed weights (re-done every call: parameters change every optimiser step)
@@ -1051,7 +1050,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         const int K = l == 0 ? I : H;
         // gate derivatives: two buffer sets by layer parity when overlapping, so that the sweep of layer l-1 does not
         // overwrite what the reductions of layer l are still reading; layer l reuses the set of layer l+2
-        float *dgi = ts->dg + (overlap ? (size_t)(l & 1) * 2 * T * B * H3 : 0), *dgh = dgi + (size_t)T * B * H3;
+        float *dg4 = ts->dg + (overlap ? (size_t)(l & 1) * T * B * 4 * H : 0);
         if (overlap && l + 2 < L) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[l + 2], 0));
         const float *Wih = w_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
         float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
@@ -1061,7 +1060,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         a.need_dx = (l > 0 || dx_out) ? 1 : 0;
         a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
         a.dy = dy; a.dy_last = (l == L - 1) ? dhT : nullptr;
-        a.wihT = wihT; a.whhT = whhT; a.dgi = dgi; a.dgh = dgh;
+        a.wihT = wihT; a.whhT = whhT; a.dg4 = dg4;
         a.dx = dxbuf[l & 1];
         { const char *e = getenv("OS_SWEEP_DBG"); a.dbg = e ? atoi(e) : 0; }
         const int RB = H <= 64 ? 2 : 1;
@@ -1103,14 +1102,14 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             const int rps = ctx->tune_dw_rps;          // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
             DwArgs d1;
             d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.x_valid_from = 0; d1.rows_per_slice = rps;
-            d1.dG = dgi; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
+            d1.dG = dg4; d1.ldg = 4 * H; d1.nshift = 0; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
             if (l == 0) { d1.X = x; d1.x_btf = 1; }
             else { d1.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d1.x_btf = 0; }
             const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, "dw_kernel");
             launch_dw(d1, K, dim3((H3 / 32 + 3) / 4, (unsigned)((rows + rps - 1) / rps)), sw);
             // recurrent weights: rows t >= 1 pair with h_{t-1}; the bias sum still runs over every row
             DwArgs d2 = d1;
-            d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.dG = dgh; d2.X = base + 4 * tbh; d2.x_btf = 0;
+            d2.K = H; d2.r_begin = (size_t)B; d2.x_row_shift = (size_t)B; d2.nshift = H; d2.X = base + 4 * tbh; d2.x_btf = 0;
             d2.dW = gWhh; d2.db = nullptr;
             // dw2_kernel (H % 4 == 0) with whole 32-row tiles in the first time step: the launch covers ALL rows, the t = 0 tiles
             // feed only the bias sum, and b_hh's gradient needs no separate column-sum launch
@@ -1125,7 +1124,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             if (!bias_in_dw) {
                 dim3 cg((H + 63) / 64, (unsigned)((rows + 255) / 256));
                 const int cslot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, sw, "colsum_kernel");
-                hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, sw, rows, H3, 2 * H, dgh, gbhh, (const float *)gbih, 2 * H);
+                hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, sw, rows, H3, 2 * H, (const float *)dg4, 4 * H, H, gbhh, (const float *)gbih, 2 * H);
                 os_prof_end(ctx, cslot, sw);
             }
             OS_HIP(ctx, hipGetLastError());
