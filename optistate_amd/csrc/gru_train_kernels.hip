@@ -764,6 +764,157 @@ __global__ __launch_bounds__(256, 2) void dw2_kernel(const DwArgs a)
     }
 }
 
+// ---- dw3_kernel: BOTH weight gradients of a layer in one pass over the gate derivatives ------------------------------
+// dW_ih += dG_i^T X and dW_hh += dG_h^T H_prev share everything but the n-gate third of dG (da_n against da_n * r) and the
+// right-hand matrix, so one launch reads the r and z sections once for both products, stages the X and the h_{t-1} tile of
+// a 32-row step side by side, and amortises a tile's barrier, its load issue and the launch itself over twice as many MFMAs
+// (NCX + NCH accumulators per wave).  Wave = one 32-wide gate chunk j: A fragment for W_ih from column j, for W_hh from
+// column j (+ H in the n gate: two loads per step there, one elsewhere).  Rows of the first time step pair with h_{-1} = 0:
+// their tiles skip the recurrent half (whole tiles: B and the slices are multiples of 32).
+struct Dw3Args {
+    int H3, Kx, H;
+    size_t rows;                 // T * B
+    int rows_per_slice, ngroups; // ngroups = workgroups (of four gate chunks) per row slice
+    const float *dG;             // [rows][ldg]
+    int ldg;
+    const float *X;              // [rows][Kx], or (B, T, Kx) batch_first when x_btf
+    int x_btf, B, T;
+    const float *Hp;             // [rows][H]: row r - B pairs with dG row r
+    float *dWih, *dWhh, *dbih, *dbhh;
+};
+
+template <int NCX, int NCH>
+__global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
+{
+    constexpr int PX = NCX * 32, PH = NCH * 32;             // floats per LDS row
+    __shared__ __attribute__((aligned(16))) float Xs[2][DW_TR * PX + 4];
+    __shared__ __attribute__((aligned(16))) float Hs[2][DW_TR * PH + 4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
+    // XCD-aware workgroup order: consecutive workgroup ids go round-robin to the eight XCDs, each with its own L2, and the
+    // column groups of one row slice all stream the same X / h tiles -- so ids i, i + 8, i + 16, ... (same XCD, dispatched
+    // together) are the column groups of ONE slice, and two of the three re-reads hit that XCD's L2 instead of HBM.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = slot % a.ngroups, by = (slot / a.ngroups) * 8 + xcd;
+    const int j0 = (bx * 4 + wave) * 32;
+    const bool jok = j0 < a.H3;
+    const bool ngate = 3 * j0 >= 2 * a.H3;
+    const size_t r0 = (size_t)by * a.rows_per_slice;
+    size_t r1 = r0 + a.rows_per_slice;
+    if (r1 > a.rows) r1 = a.rows;
+    if (r0 >= r1) return;
+    const int ntiles = (int)((r1 - r0 + DW_TR - 1) / DW_TR);
+    const uint32_t nrows = (uint32_t)(r1 - r0);
+    const osk::rsrc_t rg = osk::make_rsrc(a.dG + r0 * a.ldg, jok ? nrows * (uint32_t)a.ldg * 4u : 0u);
+    const uint32_t gli = (uint32_t)(kk * a.ldg + j0 + li) * 4u, glh = gli + (ngate ? (uint32_t)a.H * 4u : 0u), grow = (uint32_t)a.ldg * 8u;
+    // fixed position of this thread's 16-byte pieces inside the two tiles (see dw2_kernel)
+    const uint32_t xstride = a.x_btf ? (uint32_t)a.T * (uint32_t)a.Kx : (uint32_t)a.Kx;
+    uint32_t pvx[NCX], pvh[NCH];
+#pragma unroll
+    for (int i = 0; i < NCX; i++) {
+        const int p = threadIdx.x + 256 * i, prow = p / (PX / 4), c4 = 4 * (p % (PX / 4));
+        pvx[i] = c4 < a.Kx ? ((uint32_t)prow * xstride + (uint32_t)c4) * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int p = threadIdx.x + 256 * i, prow = p / (PH / 4), c4 = 4 * (p % (PH / 4));
+        pvh[i] = ((uint32_t)prow * (uint32_t)a.H + (uint32_t)c4) * 4u;
+    }
+    const osk::rsrc_t rxs = osk::make_rsrc(a.X, (uint32_t)((size_t)a.T * a.B * a.Kx * 4));
+    const osk::rsrc_t rhs = osk::make_rsrc(a.Hp, (uint32_t)((size_t)a.T * a.B * a.H * 4));
+    auto hzero = [&](int tile) { return r0 + (size_t)tile * DW_TR < (size_t)a.B; };
+    auto dma = [&](int tile, int buf) {
+        const uint32_t xr0 = (uint32_t)r0 + (uint32_t)tile * DW_TR;
+        const uint32_t sox = __builtin_amdgcn_readfirstlane(
+            (a.x_btf ? (xr0 % (uint32_t)a.B) * (uint32_t)a.T + xr0 / (uint32_t)a.B : xr0) * (uint32_t)a.Kx * 4u);
+#pragma unroll
+        for (int i = 0; i < NCX; i++) lds_dma16_buf(rxs, &Xs[buf][(wave * 64 + 256 * i) * 4], pvx[i], sox);
+        if (!hzero(tile)) {
+            const uint32_t soh = __builtin_amdgcn_readfirstlane((xr0 - (uint32_t)a.B) * (uint32_t)a.H * 4u);
+#pragma unroll
+            for (int i = 0; i < NCH; i++) lds_dma16_buf(rhs, &Hs[buf][(wave * 64 + 256 * i) * 4], pvh[i], soh);
+        }
+    };
+    f32x16 accx[NCX], acch[NCH];
+#pragma unroll
+    for (int c = 0; c < NCX; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) accx[c][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acch[c][e] = 0.f;
+    float avi[2][DW_TR / 2], avh[2][DW_TR / 2];
+    auto dg_load = [&](int tile, int buf) {
+        const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)tile * (uint32_t)(DW_TR / 2) * grow);
+#pragma unroll
+        for (int st = 0; st < DW_TR / 2; st++) avi[buf][st] = osk::buf_load_nt(rg, gli, so + (uint32_t)st * grow);
+        if (ngate) {
+#pragma unroll
+            for (int st = 0; st < DW_TR / 2; st++) avh[buf][st] = osk::buf_load_nt(rg, glh, so + (uint32_t)st * grow);
+        }
+    };
+    float bsi = 0.f, bsh = 0.f;
+    auto tile_mfma = [&](int buf, bool hz) {
+        const float *xb = &Xs[buf][kk * PX + li], *hb = &Hs[buf][kk * PH + li];
+#pragma unroll
+        for (int st = 0; st < DW_TR / 2; st++) {
+            const float ai = avi[buf][st], ah = ngate ? avh[buf][st] : ai;
+            bsi += ai; bsh += ah;
+            float xv[NCX], hv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCX; c++) xv[c] = xb[2 * st * PX + c * 32];
+            if (!hz) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) hv[c] = hb[2 * st * PH + c * 32];
+            }
+#pragma unroll
+            for (int c = 0; c < NCX; c++) accx[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, xv[c], accx[c], 0, 0, 0);
+            if (!hz) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) acch[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, hv[c], acch[c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    dma(0, 0);
+    dg_load(0, 0);
+    for (int tile = 0; tile < ntiles; tile += 2) {
+        __syncthreads();                                        // tile `tile` landed (vmcnt(0) + barrier); buffer 1 is free
+        if (tile + 1 < ntiles) { dma(tile + 1, 1); dg_load(tile + 1, 1); }
+        tile_mfma(0, hzero(tile));
+        if (tile + 1 < ntiles) {
+            __syncthreads();
+            if (tile + 2 < ntiles) { dma(tile + 2, 0); dg_load(tile + 2, 0); }
+            tile_mfma(1, hzero(tile + 1));
+        }
+    }
+    if (jok) {
+        const osk::rsrc_t rwx = osk::make_rsrc(a.dWih, (uint32_t)a.H3 * (uint32_t)a.Kx * 4u);
+        const osk::rsrc_t rwh = osk::make_rsrc(a.dWhh, (uint32_t)a.H3 * (uint32_t)a.H * 4u);
+#pragma unroll
+        for (int c = 0; c < NCX; c++) {
+            const int k = c * 32 + li;
+            if (k < a.Kx) {
+                const uint32_t vo = (uint32_t)((4 * kk) * a.Kx + k) * 4u;
+#pragma unroll
+                for (int e = 0; e < 16; e++) buf_atomic_add(accx[c][e], rwx, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.Kx) * 4u);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const uint32_t vo = (uint32_t)((4 * kk) * a.H + c * 32 + li) * 4u;
+#pragma unroll
+            for (int e = 0; e < 16; e++) buf_atomic_add(acch[c][e], rwh, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.H) * 4u);
+        }
+        bsi += __shfl_xor(bsi, 32, 64);              // the two row parities of the same gate unit
+        bsh += __shfl_xor(bsh, 32, 64);
+        if (kk == 0) {
+            global_fadd(a.dbih, (uint32_t)a.H3 * 4u, (uint32_t)(j0 + li), bsi);
+            global_fadd(a.dbhh, (uint32_t)a.H3 * 4u, (uint32_t)(j0 + li), bsh);
+        }
+    }
+}
+
 // column sums of columns [n0, N) of a [R][N] row-major matrix into dst (bias gradients): 64 columns x 4 row-lanes per
 // workgroup, 256 rows per workgroup (64 loads per thread, eight in flight), one atomic per column per workgroup
 // copy_src / copy_n: block (0, 0) also copies copy_n floats copy_src -> dst (the r and z thirds of b_hh's gradient equal b_ih's)
@@ -1098,7 +1249,29 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         }
         // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
-        {
+        // both products in one launch (dw3_kernel) when the tiles are whole and the accumulators fit two workgroups per CU
+        const int ncx = (K + 31) / 32 <= 2 ? 2 : 4, nchh = H / 32;
+        const bool fuse_dw = ctx->tune_dw_fused != 0 && K <= 128 && (K & 3) == 0 && (nchh == 4 || (nchh == 2 && ncx == 2)) && B % DW_TR == 0 &&
+                             ctx->tune_dw_rps % DW_TR == 0 && T > 1 && (size_t)T * B * (K > H ? K : H) * 4 < ((size_t)1 << 31);
+        if (fuse_dw) {
+            const int rps = ctx->tune_dw_rps;
+            Dw3Args d;
+            d.H3 = H3; d.Kx = K; d.H = H; d.rows = rows; d.rows_per_slice = rps; d.dG = dg4; d.ldg = 4 * H;
+            d.B = B; d.T = T; d.Hp = base + 4 * tbh;
+            if (l == 0) { d.X = x; d.x_btf = 1; }
+            else { d.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d.x_btf = 0; }
+            d.dWih = gWih; d.dWhh = gWhh; d.dbih = gbih; d.dbhh = gbhh;
+            d.ngroups = (H3 / 32 + 3) / 4;
+            const unsigned nslices = (unsigned)((rows + rps - 1) / rps);
+            const dim3 grid(8u * ((nslices + 7) / 8) * (unsigned)d.ngroups);       // see the XCD-aware order in the kernel
+            const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, "dw3_kernel");
+            if (nchh == 4 && ncx == 4) hipLaunchKernelGGL((dw3_kernel<4, 4>), grid, dim3(256), 0, sw, d);
+            else if (nchh == 4) hipLaunchKernelGGL((dw3_kernel<2, 4>), grid, dim3(256), 0, sw, d);
+            else hipLaunchKernelGGL((dw3_kernel<2, 2>), grid, dim3(256), 0, sw, d);
+            os_prof_end(ctx, dslot, sw);
+            OS_HIP(ctx, hipGetLastError());
+            if (overlap) OS_HIP(ctx, hipEventRecord(ts->ev_dw[l], sw));
+        } else {
             const int rps = ctx->tune_dw_rps;          // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
             DwArgs d1;
             d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.x_valid_from = 0; d1.rows_per_slice = rps;

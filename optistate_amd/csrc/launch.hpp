@@ -22,6 +22,7 @@ struct os_ctx {
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
     int tune_mpc_persistent;             // 1: os_kf_mpc_run is one persistent kernel (default), 0: the per-step launch sequence
     int tune_dw_rps;                     // rows per dW slice
+    int tune_dw_fused;                   // 1: W_ih and W_hh gradients of a layer in one launch (dw3_kernel) when eligible, 0: two launches
     int tune_sweep_wr;                   // backward sweep: leading k-pairs of a wave's weight chunk kept in registers (32, 16 or 0)
     int tune_sweep_nw;                   // 0 automatic, 4 / 8 waves per backward-sweep workgroup
     int tune_train_overlap;              // OS_TRAIN_OVERLAP=0: weight-gradient kernels on the caller's stream (no side stream)
