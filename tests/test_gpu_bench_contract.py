@@ -61,7 +61,8 @@ def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
     assert d["roofline"]["bound"] == "mfma" and set(d["kernels"]) >= {"gru_layer", "train_sweep", "train_dw"}
     m = _run(["--mode", "mpc", "--batch", "512", "--seq", "10", "--steps", "1", "--warmup", "1", "--cpu-seconds", "2"])
     _has_roofline_and_baseline(m)
-    assert m["value"] > 0 and m["status_nonzero_trajectories"] == 0 and m["kernels"]["mpc"]["launches_per_step"] == 10
+    assert m["value"] > 0 and m["status_nonzero_trajectories"] == 0 and m["kernels"]["mpc"]["launches_per_step"] == 1
+    assert m["kernels"]["mpc"]["kernel"] == "kf_mpc_persistent_kernel"        # one launch for all T steps, no per-step launches
     f = _run(["--mode", "full", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
     _has_roofline_and_baseline(f)
     assert f["config"]["frames"] == 1024 and f["unit"] == "frames/s"
