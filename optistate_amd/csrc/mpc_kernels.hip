@@ -525,6 +525,18 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
     converged_out = converged;
 }
 
+// The same solver behind a real call: its own register allocation instead of the union of four inlined instances and the
+// filter state around them (the persistent kernel at small batch: 1,100 SGPR and 50-370 VGPR spills inlined; B = 8:
+// 109 -> 92 us per step as a call.  At large batch the call's stack costs occupancy: 7.9e6 -> 5.8e6 steps/s, so the
+// two-waves-per-SIMD instantiation keeps the inlined form).
+template <int NST>
+__device__ __attribute__((noinline)) void mpc_solve_wave_call(const MpcParams &P, uint32_t cbits, const int (&legs)[4], const double (&x)[12],
+                                                             const double (&ref)[12], const double (&p)[12], int max_iter, bool warm,
+                                                             WaveMemT<15 * NST> &M, QpLane &io, float &val, int &iters_out, bool &converged_out)
+{
+    mpc_solve_wave<NST>(P, cbits, legs, x, ref, p, max_iter, warm, M, io, val, iters_out, converged_out);
+}
+
 // NST = number of legs that carry force variables (contact byte != 0).  Swing legs are eliminated up front: a trot
 // problem has 30 variables, not 60 (elimination work ~ n^3), and each instance gets the register budget its row needs.
 // Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
@@ -824,10 +836,17 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
             for (int j = 0; j < 12; j++) { xd[j] = (double)x[j]; rd[j] = (double)bref[j]; pd[j] = (double)in.p[j]; }
             const bool warm = !a.cold && cbits == prev_c;
             bool conv = true;
-            if (nst == 1) mpc_solve_wave<1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
-            else if (nst == 2) mpc_solve_wave<2>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
-            else if (nst == 3) mpc_solve_wave<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
-            else mpc_solve_wave<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
+            if constexpr (OCC == 1) {
+                if (nst == 1) mpc_solve_wave_call<1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
+                else if (nst == 2) mpc_solve_wave_call<2>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
+                else if (nst == 3) mpc_solve_wave_call<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
+                else mpc_solve_wave_call<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
+            } else {
+                if (nst == 1) mpc_solve_wave<1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
+                else if (nst == 2) mpc_solve_wave<2>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
+                else if (nst == 3) mpc_solve_wave<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
+                else mpc_solve_wave<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
+            }
             if (!conv) status |= 4;
         }
         prev_c = cbits;
