@@ -222,11 +222,13 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * (solved from the state before the predict), then get_odom + set_measurements + predict_mpc (dense F_d covariance,
  * next_state with f[:, 0]) + update.  Streams as os_kf_run; f_out [T][12][B] receives the forces (KF2.f[:, 0], the
  * feature columns 18..29 of :248-250), mpc_iters [T][B] (optional) the active-set iteration counts; status [B] is
- * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  ONE persistent kernel, a wavefront per trajectory for all T
- * steps (QP with its warm start in registers, then the filter step with the float64 covariance in LDS spread over the 64
- * lanes): no per-step launches, nothing read back, no stream synchronisation.  P is carried in float64 between steps, as in
- * the reference, and rounded to float32 only when it is written back at the end of the call.  (OS_MPC_PERSISTENT=0 in the
- * environment selects the round-1 sequence of two to five launches per step, kept for A/B.) */
+ * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  Up to 32 trajectories per compute unit (B <= 8192 on an
+ * MI355X) this is ONE persistent kernel, a wavefront per trajectory for all T steps (QP with its warm start in registers,
+ * then the filter step with the float64 covariance in LDS spread over the 64 lanes): no per-step launches, nothing read
+ * back, no stream synchronisation; P is carried in float64 between steps, as in the reference, and rounded to float32
+ * only when it is written back at the end of the call.  Larger batches take the launch sequence (QP instances + a T = 1
+ * filter launch per step, one trajectory per lane; the leg-count histogram is read back once at entry), which has the
+ * higher throughput there.  OS_MPC_PERSISTENT=0 / 2 in the environment forces the sequence / the persistent kernel. */
 int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
                   const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *f_out,
                   float *p_rot_out, float *ptrace_out, float *kgain_out, int32_t *mpc_iters, int32_t *status,

@@ -969,7 +969,9 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->tune_mpc_persistent) {
+    // persistent kernel up to 32 trajectories per CU (it spends a whole wavefront on one trajectory's filter step: measured
+    // crossover with the launch sequence at B = 8192 on 256 CUs -- 1.0e7 steps/s either way; 1.9e7 against 1.2e7 at 32,768)
+    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 32 * ctx->cu_count)) {
         // one launch, one wavefront per trajectory for all T steps; nothing is read back, nothing synchronises
         osm::MpcRunArgs m;
         osk::KfRunArgs &a = m.kf;
