@@ -10,7 +10,8 @@ namespace osg {
 struct LayerArgs {
     int B, T, K, H;            // K = input width of this layer
     int KPx, KPh;              // k-pairs of the x part (ceil(K/2)) and of the h part (H/2)
-    const float *xs;           // [T][K][B]
+    const float *xs;           // [T][K][B], or the caller's (B, T, K) batch_first tensor when xs_btf (gru_layer_ahead_kernel only)
+    int xs_btf = 0;
     const float *w;            // packed weights of this layer (see pack kernel)
     float *seq_out;            // [T][H][B] or null
     float *h_last;             // [H][B] or null

@@ -376,11 +376,26 @@ __global__ __launch_bounds__(512, 1) void gru_layer_ahead_kernel(const LayerArgs
     const int growc = g0 < a.B ? g0 : a.B - 1;
     // x tile staging by the h waves: thread -> (input k0 + 8 e, row li): 128-byte segments of the [K][B] stream; inputs past K
     // read zero through the descriptor's range check and are not written
+    // With xs_btf the layer reads the caller's (B, T, K) tensor itself (no [T][K][B] copy of the input: 27 us and 123 MB per
+    // training step at 8192 x 10 x 188): thread -> (row (tid >> 3) & 31, inputs (tid & 7) + 8 e), 32-byte runs of a window's row.
     const int xk0 = (threadIdx.x >> 5) & 7;
     const uint32_t xsoff = (uint32_t)growc * 4u + (uint32_t)xk0 * rowB;
+    const int brow = (threadIdx.x >> 3) & 31, bk0 = threadIdx.x & 7;
+    const int bg = tile_row0 + brow < a.B ? tile_row0 + brow : a.B - 1;
+    const uint32_t xboff = (uint32_t)(((size_t)bg * a.T * a.K + bk0) * 4);
     float xr[XE];
     auto xfetch = [&](int s) {
         if (s >= a.T) return;
+        if (a.xs_btf) {
+            const rsrc_t rx = make_rsrc(a.xs, (uint32_t)((size_t)a.B * a.T * a.K * 4));       // host: < 4 GiB
+            const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)s * (uint32_t)a.K * 4u);
+#pragma unroll
+            for (int e = 0; e < XE; e++) {
+                if (e * 8 >= a.K) break;
+                xr[e] = bk0 + e * 8 < a.K ? buf_load(rx, xboff + (uint32_t)e * 32u, so) : 0.f;
+            }
+            return;
+        }
         const rsrc_t rx = make_rsrc(a.xs + (size_t)s * a.K * B, (uint32_t)a.K * rowB);
 #pragma unroll
         for (int e = 0; e < XE; e++) {
@@ -389,6 +404,14 @@ __global__ __launch_bounds__(512, 1) void gru_layer_ahead_kernel(const LayerArgs
         }
     };
     auto xstage = [&]() {
+        if (a.xs_btf) {
+#pragma unroll
+            for (int e = 0; e < XE; e++) {
+                if (e * 8 >= a.K) break;
+                if (bk0 + e * 8 < a.K) xl[brow * XS + bk0 + e * 8] = xr[e];
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < XE; e++) {
             if (e * 8 >= a.K) break;
@@ -661,6 +684,16 @@ int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, f
     return 0;
 }
 
+// true when os_gru_launch_layer will pick gru_layer_ahead_kernel for this shape (the one kernel that can read a (B, T, K)
+// batch_first input directly: LayerArgs.xs_btf)
+static bool ahead_eligible(os_ctx *ctx, int B, int T, int K, int H)
+{
+    const bool split = H / 32 >= 2 && (B + 31) / 32 <= ctx->cu_count && K <= 192 && ctx->tune_gru_split != 0;
+    return split && H == 128 && (size_t)T * B * H * 4 < ((size_t)1 << 32) && (size_t)T * B * K * 4 < ((size_t)1 << 32) &&
+           ctx->tune_gru_ahead != 0;
+}
+bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H) { return ahead_eligible(ctx, B, T, K, H); }
+
 // Launches gru_layer_kernel for one layer (shared by inference and the training forward).
 int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
 {
@@ -684,7 +717,8 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
     if (a.K > 192) split = false;                                    // its x tile staging covers 12 x 16 inputs
     if (ctx->tune_gru_split == 0) split = false;
-    const bool ahead = split && NCH == 4 && a.K <= 192 && (size_t)a.T * a.B * H * 4 < ((size_t)1 << 32) && ctx->tune_gru_ahead != 0;
+    const bool ahead = ahead_eligible(ctx, a.B, a.T, a.K, H);
+    if (a.xs_btf && !ahead) return os_fail(ctx, -4, "os_gru_launch_layer: a batch_first input needs the ahead kernel's shape");
     const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s,
                                    ahead ? "gru_layer_ahead_kernel" : split ? "gru_layer_split_kernel" : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
     if (ahead) {

@@ -1068,16 +1068,20 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
         ts->B = B; ts->T = T;
     }
     if (os_ensure_scratch(ctx, &ts->seq, &ts->seq_floats, (size_t)L * tbh)) return -10;
-    if (os_ensure_scratch(ctx, &ts->xs, &ts->xs_floats, (size_t)T * I * B)) return -10;
-    int rc = os_pack_stream(ctx, B, T, I, x, ts->xs, stream);
-    if (rc) return rc;
+    // layer 0 reads the caller's (B, T, I) tensor itself where its kernel can (no SoA copy of the input)
+    const bool x_direct = os_gru_layer_takes_btf(ctx, B, T, I, H);
+    if (!x_direct) {
+        if (os_ensure_scratch(ctx, &ts->xs, &ts->xs_floats, (size_t)T * I * B)) return -10;
+        int rc = os_pack_stream(ctx, B, T, I, x, ts->xs, stream);
+        if (rc) return rc;
+    }
     size_t woff = 0;
-    const float *in = ts->xs;
+    const float *in = x_direct ? x : ts->xs;
     for (int l = 0; l < L; l++) {
         const int K = l == 0 ? I : H;
         osg::LayerArgs a;
         a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
-        a.xs = in; a.w = ctx->gru_packed + woff;
+        a.xs = in; a.xs_btf = (l == 0 && x_direct) ? 1 : 0; a.w = ctx->gru_packed + woff;
         a.seq_out = ts->seq + (size_t)l * tbh;
         a.h_last = nullptr;
         float *base = act + (size_t)l * 5 * tbh;

@@ -125,6 +125,7 @@ namespace osg { struct LayerArgs; }
 size_t os_layer_packed_floats(int K, int H);
 int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats);
 int os_gru_launch_layer(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s);
+bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H);   // gru_kernels.hip: the layer kernel for this shape reads (B, T, K) inputs itself
 int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s);
 void os_train_destroy(os_ctx *ctx);
 void os_vit_destroy(os_ctx *ctx);
