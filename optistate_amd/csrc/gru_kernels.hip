@@ -762,8 +762,8 @@ int os_gru_scratch(os_ctx *ctx, int B, int T, float **seq0, float **seq1, float 
 
 // Runs layers first_layer..L-1 and the head.  `in` is the SoA input of layer first_layer ([T][K][B]); for
 // first_layer > 0 it must be the ping-pong buffer seq[(first_layer-1)&1] returned by os_gru_scratch.
-int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_layer, float *out, float *h_last_all,
-                       hipStream_t s)
+static int gru_layers(os_ctx *ctx, int B, int T, const float *in, int in_btf, int first_layer, float *out, float *h_last_all,
+                      hipStream_t s)
 {
     const os_gru_dims &d = ctx->gru;
     const int H = d.hidden_size, L = d.num_layers, NCH = H / 32;
@@ -776,7 +776,7 @@ int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_lay
         const int K = l == 0 ? d.input_size : H;
         LayerArgs a;
         a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
-        a.xs = in; a.w = ctx->gru_packed + woff;
+        a.xs = in; a.xs_btf = (l == first_layer) ? in_btf : 0; a.w = ctx->gru_packed + woff;
         a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
         a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
         a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
@@ -787,6 +787,11 @@ int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_lay
     const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
     const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
     return os_gru_head_launch(ctx, B, top, fcw, out, s);
+}
+
+int os_gru_layers_impl(os_ctx *ctx, int B, int T, const float *in, int first_layer, float *out, float *h_last_all, hipStream_t s)
+{
+    return gru_layers(ctx, B, T, in, 0, first_layer, out, h_last_all, s);
 }
 
 extern "C" {
@@ -807,19 +812,24 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
     if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
     if (B <= 0 || T <= 0 || !x || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
     OS_HIP(ctx, hipSetDevice(ctx->device));
-    // (B, T, I) batch_first as the reference passes it -> SoA [T][I][B] in context scratch
+    // (B, T, I) batch_first as the reference passes it -> SoA [T][I][B] in context scratch, unless the first layer's kernel
+    // reads that layout itself (small batches at H = 128)
     const int I = ctx->gru.input_size;
-    if (os_ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;
-    int rc = os_pack_stream(ctx, B, T, I, x, ctx->gru_xs, stream);
-    if (rc) return rc;
+    const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
+    const bool x_direct = os_gru_layer_takes_btf(ctx, B, T, I, H);
+    int rc = 0;
+    if (!x_direct) {
+        if (os_ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;
+        rc = os_pack_stream(ctx, B, T, I, x, ctx->gru_xs, stream);
+        if (rc) return rc;
+    }
     // h_last is requested in torch layout [L][B][H]; produce SoA [L][H][B] then transpose
     float *hl_soa = nullptr;
-    const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
     if (h_last) {
         if (os_ensure_scratch(ctx, &ctx->gru_hl, &ctx->gru_hl_floats, (size_t)L * H * B)) return -10;
         hl_soa = ctx->gru_hl;
     }
-    rc = os_gru_forward_soa(ctx, B, T, ctx->gru_xs, out, hl_soa, stream);
+    rc = x_direct ? gru_layers(ctx, B, T, x, 1, 0, out, hl_soa, (hipStream_t)stream) : os_gru_forward_soa(ctx, B, T, ctx->gru_xs, out, hl_soa, stream);
     if (rc) return rc;
     if (h_last)
         for (int l = 0; l < L; l++) {
