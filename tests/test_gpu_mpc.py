@@ -262,3 +262,33 @@ def test_mpc_nonfinite_input_terminates_and_flags(eng):
     assert np.all(st[ok] == 0) and np.all(np.isfinite(u[ok]))
     # the poisoned problem must not hang the wavefront: it ends at the iteration cap (bit 2) or with non-finite forces
     assert (st[3] & 4) or not np.all(np.isfinite(u[3]))
+
+
+def test_persistent_kernel_agrees_with_the_launch_sequence(monkeypatch):
+    """os_kf_mpc_run has two forms (one persistent kernel up to 32 trajectories per CU, the per-step launch sequence above):
+    same forces and states on a trot with phase changes, to the state bar -- the persistent kernel carries P in float64
+    between steps, the sequence rounds it to float32 at every step."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    dev = torch.device("cuda:0")
+    B, T = 16, 60
+    d = synth_torch(B, T, dev, seed=5)
+    ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
+    out = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("OS_MPC_PERSISTENT", mode)
+        e = Engine(0); e.set_noise(Q_DEFAULT, R_DEFAULT)
+        contact = e.contact_soa_to_packed(d["contact"])
+        x, P = d["x0"].clone(), d["P0"].clone()
+        r = e.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True, want_trace=True)
+        e.profile(True)
+        e.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, d["x0"].clone(), d["P0"].clone())
+        prof = e.profile_read()
+        out[mode] = (r, x.clone(), prof)
+    rp, xp, pp = out["2"]; rs, xs_, ps = out["0"]
+    assert pp["mpc"][1] == 1 and ps["mpc"][1] >= T                              # one launch against at least one per step
+    assert int(rp["status"].abs().max()) == 0 and int(rs["status"].abs().max()) == 0
+    assert float((rp["x_out"] - rs["x_out"]).abs().max()) < 1e-4
+    assert float((rp["f"] - rs["f"]).abs().max()) < 5e-3
+    assert float((xp - xs_).abs().max()) < 1e-4
+    assert float((rp["ptrace"] - rs["ptrace"]).abs().max()) < 1e-3 * float(rs["ptrace"].abs().max())
