@@ -59,6 +59,37 @@ def test_ragged_batch_vs_oracle(dims):
     assert err < GRU_TOL, err
 
 
+@pytest.mark.parametrize("I,B,T", [(61, 1, 1), (60, 33, 2), (188, 40, 3), (128, 257, 5)])
+def test_run_ahead_layer_kernel_edges(I, B, T):
+    """H = 128 at small batch takes gru_layer_ahead_kernel (input half one to two steps ahead, (B, T, I) read directly): its
+    prologue / epilogue at T = 1, 2, 3, odd and 188-wide inputs, partial tiles; float64 oracle as truth, and the eight-wave
+    split kernel (OS_GRU_AHEAD=0) must give the same numbers up to summation order."""
+    import os
+    from optistate_amd import RNN, Engine
+    from optistate_amd import engine as eng_mod
+    from oracle import c_oracle as orc
+    H, L, C = 128, 2, 24
+    torch.manual_seed(11)
+    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda").eval()
+    x = torch.rand(B, T, I)
+    with torch.no_grad():
+        out = m(x.cuda()).cpu().numpy()
+    assert m._engine.kernel_name("gru_layer") == "gru_layer_ahead_kernel"
+    w = orc.flatten_state_dict(m.state_dict(), L)
+    ref, _, _ = orc.gru_forward(x.numpy(), w, I, H, L, C)
+    assert np.abs(out - ref).max() < GRU_TOL
+    os.environ["OS_GRU_AHEAD"] = "0"
+    try:
+        e2 = Engine(0)
+        e2.load_gru(torch.as_tensor(w, dtype=torch.float32).cuda(), I, H, L, C)
+        out2 = e2.gru_forward(x.cuda())
+        out2 = (out2[0] if isinstance(out2, (tuple, list)) else out2).cpu().numpy()
+        assert e2.kernel_name("gru_layer") == "gru_layer_split_kernel"
+    finally:
+        del os.environ["OS_GRU_AHEAD"]
+    assert np.abs(out2 - out).max() < 2e-6
+
+
 @pytest.mark.parametrize("two_kernel,L,B,T", [(False, 1, 200, 20), (True, 1, 200, 20), (False, 4, 333, 12),
                                                 (False, 1, 1000, 100)])
 def test_fused_matches_oracle_chain(two_kernel, L, B, T):
