@@ -29,6 +29,9 @@ def torch_reference_grads(sd, dims, x, y):
 
 @pytest.mark.parametrize("dims,B,T", [((60, 64, 1, 24), 50, 10), ((60, 64, 2, 24), 130, 7), ((188, 128, 4, 24), 70, 10),
                                       ((61, 32, 2, 6), 33, 5),
+                                      # whole 32-row tiles: the fused W_ih / W_hh gradient kernel (dw3_kernel<2,4>, <4,4>, <2,2>),
+                                      # its batch_first layer-0 input, and T = 1 (falls back to the two-launch form)
+                                      ((60, 128, 2, 24), 256, 6), ((60, 64, 2, 24), 96, 5), ((60, 128, 1, 24), 64, 1),
                                       # large ragged batches: 64-row layer kernel with activation saves, many dW slices
                                       ((60, 128, 2, 24), 20013, 4), ((60, 64, 2, 24), 40001, 3)])
 def test_backward_matches_torch_autograd(dims, B, T):
