@@ -79,16 +79,44 @@ __device__ __forceinline__ double rcp64(double a)
     return r;
 }
 
+// 1/sqrt(a) to full double precision: v_rsq_f64 + two Newton steps (1.0 / sqrt(a) in IEEE form is ~500 cycles of a
+// ten-column Cholesky's critical path here, this ~100)
+__device__ __forceinline__ double rsqrt64(double a)
+{
+    double r = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
 
+// sin / cos in double for the attitude angles of a walking robot: below 0.5 rad the Taylor series to theta^15 / theta^16 is
+// exact to 1e-16 (sixteen FMAs instead of the library's range reduction); anything larger takes the library (wave-uniform)
+__device__ __forceinline__ void sincos_small(double t, double *s, double *c)
+{
+    if (__builtin_amdgcn_ballot_w64(!(fabs(t) < 0.5)) != 0ull) { sincos(t, s, c); return; }
+    const double u = t * t;
+    double ps = -1.0 / 1307674368000.0;                                     // -1/15!
+    ps = fma(ps, u, 1.0 / 6227020800.0); ps = fma(ps, u, -1.0 / 39916800.0); ps = fma(ps, u, 1.0 / 362880.0);
+    ps = fma(ps, u, -1.0 / 5040.0); ps = fma(ps, u, 1.0 / 120.0); ps = fma(ps, u, -1.0 / 6.0); ps = fma(ps, u, 1.0);
+    double pc = 1.0 / 20922789888000.0;                                     // 1/16!
+    pc = fma(pc, u, -1.0 / 87178291200.0); pc = fma(pc, u, 1.0 / 479001600.0); pc = fma(pc, u, -1.0 / 3628800.0);
+    pc = fma(pc, u, 1.0 / 40320.0); pc = fma(pc, u, -1.0 / 720.0); pc = fma(pc, u, 1.0 / 24.0); pc = fma(pc, u, -0.5);
+    pc = fma(pc, u, 1.0);
+    *s = ps * t;
+    *c = pc;
+}
+
 __device__ __forceinline__ void rotation64(double tx, double ty, double tz, double *R)
 {
     double sx, cx, sy, cy, sz, cz;
-    sincos(tx, &sx, &cx); sincos(ty, &sy, &cy); sincos(tz, &sz, &cz);
+    sincos_small(tx, &sx, &cx); sincos_small(ty, &sy, &cy); sincos_small(tz, &sz, &cz);
     R[0] = cz * cy; R[1] = cz * sy * sx - sz * cx; R[2] = cz * sy * cx + sz * sx;
     R[3] = sz * cy; R[4] = sz * sy * sx + cz * cx; R[5] = sz * sy * cx - cz * sx;
     R[6] = -sy;     R[7] = cy * sx;                R[8] = cy * cx;
@@ -438,10 +466,16 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
             M.al[L.ls] = best; M.code[L.ls] = code;
         }
         __builtin_amdgcn_wave_barrier();
+        // all NLS (step length, code) pairs are requested from LDS at once, then scanned (a rolled read - compare loop was NLS
+        // dependent LDS round trips)
         double amin = 1.0; int lsmin = -1, cmin = 0;
-        for (int q = 0; q < NLS; q++) {
-            const double aq = M.al[q];
-            if (aq < amin) { amin = aq; lsmin = q; cmin = M.code[q]; }
+        {
+            double alq[NLS]; int cdq[NLS];
+#pragma unroll
+            for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
+#pragma unroll
+            for (int q = 0; q < NLS; q++)
+                if (alq[q] < amin) { amin = alq[q]; lsmin = q; cmin = cdq[q]; }
         }
         u += amin * d;
         if (lsmin >= 0) {
@@ -507,9 +541,13 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         }
         __builtin_amdgcn_wave_barrier();
         double rmax = TOL; int lsr = -1, cr = 0;
-        for (int q = 0; q < NLS; q++) {
-            const double aq = M.al[q];
-            if (M.code[q] != 0 && aq > rmax) { rmax = aq; lsr = q; cr = M.code[q]; }
+        {
+            double alq[NLS]; int cdq[NLS];
+#pragma unroll
+            for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
+#pragma unroll
+            for (int q = 0; q < NLS; q++)
+                if (cdq[q] != 0 && alq[q] > rmax) { rmax = alq[q]; lsr = q; cr = cdq[q]; }
         }
         if (lsr < 0) { done = true; converged = true; break; }
         if (L.ls == lsr && !L.pad) {
@@ -704,7 +742,7 @@ __device__ __forceinline__ int update_batch_wave(float *x, KfWave &W, const floa
         double d = W.L[j][j];
         for (int q = 0; q < j; q++) d -= W.L[j][q] * W.L[j][q];
         if (!(d > 0.0) || !(d < 3.0e38)) { status |= 1; d = 1.0; }
-        const double di = 1.0 / sqrt(d);
+        const double di = rsqrt64(d);
         if (lane > j && lane < 10) {
             double sacc = W.L[lane][j];
             for (int q = 0; q < j; q++) sacc -= W.L[lane][q] * W.L[j][q];
