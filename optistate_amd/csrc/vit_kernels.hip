@@ -388,6 +388,138 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
         }
 }
 
+// ---- vit_mlp_kernel: x += fc2(gelu(fc1(y))) for a 128-row tile without the hidden activations ever leaving the CU --------
+// fc1 and fc2 as two vit_gemm launches wrote and re-read the [M][mlp] hidden matrix: 2 x 413 MB per block at 1024 frames,
+// as much time as the 52.8 GFLOP of the two products.  Here the hidden dimension is walked in slices of 128: a slice of
+// gelu(y W1^T + b1) is formed (fc1, K = 128) into an LDS tile in the same swizzled A-operand layout as the input tile, and
+// immediately consumed as a K-slice of fc2, whose 128 x 128 accumulators stay in registers across the slices.  Eight waves:
+// wave = (32-column chunk w & 3, row-block pair w >> 2); per slice 128 + 128 MFMAs per wave, two barriers.
+// embed_dim = 128 only (one K-chunk of input, four output chunks); LDS: input tile 64 KB + hidden slice 64 KB.
+struct MlpArgs {
+    size_t M;
+    int Mh;                     // hidden width, a multiple of 128
+    const float *Y;             // [M][128] normalised input
+    float *X;                   // [M][128] residual stream, updated in place
+    const float *W1p, *b1;      // fc1 packed (vit_pack_w_kernel: N = Mh, K = 128), bias [Mh]
+    const float *W2p, *b2;      // fc2 packed (N = 128, K = Mh), bias [128]
+};
+
+__global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
+{
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(16))) float msm[];
+    float *As = msm, *Hs = msm + GM_BM * D;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
+    const int chunk = wave & 3, rbp = wave >> 2;
+    const size_t row0 = (size_t)blockIdx.x * GM_BM;
+    {
+        // input tile: piece p = threadIdx.x + 512 i -> LDS row (threadIdx.x >> 5) + 16 i, slot p % 32 receives source slot
+        // (p % 32) ^ (row & 7) (the row's low three bits do not change with i)
+        const int r_lo = threadIdx.x >> 5, slot = (threadIdx.x & 31) ^ (r_lo & 7);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            size_t row = row0 + r_lo + 16 * i;
+            if (row >= a.M) row = a.M - 1;
+            vit_lds_dma16(a.Y + row * D + 4 * slot, &As[(wave * 64 + 512 * i) * 4]);
+        }
+    }
+    f32x16v acc2[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc2[rb][e] = 0.f;
+    const uint32_t wl = (uint32_t)lane * 4u;
+    // eight per-lane base addresses cover every A-fragment read of a swizzled tile (see vit_gemm_kernel)
+    int lo8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) lo8[j] = (rbp * 64 + li) * D + ((j ^ (li & 7)) << 2) + lh;
+#define MLP_AFRAG(T, q, rb) (T)[lo8[((q) >> 1) & 7] + (rb) * 32 * D + (((q) >> 1) >> 3) * 32 + ((q) & 1) * 2]
+    // where this lane's accumulator elements go in the hidden tile: column chunk*32 + li of rows ... + (e & 3) + 8 (e >> 2) + 4 lh
+    int hoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) hoff[m] = ((((chunk * 32 + li) >> 2) ^ (m + 4 * lh)) << 2) + (li & 3);
+    __syncthreads();                                                      // vmcnt(0) + barrier: the input tile has landed
+    const int nsl = a.Mh / 128;
+    for (int s = 0; s < nsl; s++) {
+        constexpr int D8 = 8;
+        float wbf[D8], abf[D8][2];
+        // ---- fc1 slice: hidden columns s*128 + chunk*32 .. +31 for this wave's 64 rows ----
+        f32x16v acc1[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc1[rb][e] = 0.f;
+        {
+            const osk::rsrc_t rw = osk::make_rsrc(a.W1p + (size_t)(s * 4 + chunk) * (D / 2) * 64, (uint32_t)(D / 2) * 256u);
+#pragma unroll
+            for (int d = 0; d < D8; d++) {
+                wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, d, rb);
+            }
+#pragma unroll
+            for (int q = 0; q < D / 2; q++) {
+                const int d = q & (D8 - 1);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc1[rb], 0, 0, 0);
+                if (q + D8 < D / 2) {
+                    wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, q + D8, rb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            const float bv = a.b1[s * 128 + chunk * 32 + li];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    Hs[r * D + hoff[e & 3]] = gelu_erf(acc1[rb][e] + bv);
+                }
+        }
+        __syncthreads();                                                  // the hidden slice is complete
+        // ---- fc2 K-slice s: output columns chunk*32 .. +31 ----
+        {
+            const osk::rsrc_t rw = osk::make_rsrc(a.W2p + ((size_t)chunk * (a.Mh / 2) + (size_t)s * (D / 2)) * 64, (uint32_t)(D / 2) * 256u);
+#pragma unroll
+            for (int d = 0; d < D8; d++) {
+                wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(Hs, d, rb);
+            }
+#pragma unroll
+            for (int q = 0; q < D / 2; q++) {
+                const int d = q & (D8 - 1);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) acc2[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc2[rb], 0, 0, 0);
+                if (q + D8 < D / 2) {
+                    wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(Hs, q + D8, rb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (s + 1 < nsl) __syncthreads();                                 // everyone is done reading the hidden slice
+    }
+#undef MLP_AFRAG
+    // x += acc + b2: rows past M fall outside the descriptor's range
+    const int col = chunk * 32 + li;
+    const float bv = a.b2[col];
+    const osk::rsrc_t rc = osk::make_rsrc(a.X, (uint32_t)(a.M * (size_t)D * 4));
+    const uint32_t vo = (uint32_t)((4 * lh) * D + col) * 4u;
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(D * 4));
+            osk::buf_store(rc, vo, so, acc2[rb][e] + bv + osk::buf_load(rc, vo, so));
+        }
+}
+
 // row 0 of every frame: cls token + pos[0]   (transformer_model.py:119-123)
 __global__ void cls_row_kernel(int N, int L, int D, const float *cls, const float *pos, float *X)
 {
@@ -428,7 +560,7 @@ struct os_vit_state {
     const float *w;          // caller-owned flat weights
     float *wp; size_t wp_floats;       // every projection matrix re-packed into B-fragment order (vit_pack_w_kernel)
     float *buf; size_t buf_floats;
-    bool att_attr_set;
+    bool att_attr_set, mlp_attr_set;
 };
 
 static size_t vit_param_count(const VitDims &d)
@@ -574,12 +706,26 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
         hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln2w, ln2b, Y, (size_t)D);
         os_prof_end(ctx, slot, s);
-        g.A = Y; g.lda = D; g.N = Mh; g.K = D; g.Wp = wp; g.bias = fc1b; g.C = big;
-        launch_gemm<0, 1>(ctx, g, s, "vit_gemm_kernel<+bias,gelu>");
-        wp += (size_t)Mh * D;
-        g.A = big; g.lda = Mh; g.N = D; g.K = Mh; g.Wp = wp; g.bias = fc2b; g.C = X;
-        launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
-        wp += (size_t)D * Mh;
+        if (D == 128 && ctx->tune_vit_mlp_fused) {
+            // fc1 + GELU + fc2 + residual in one kernel: the hidden activations stay in LDS
+            MlpArgs ma;
+            ma.M = M; ma.Mh = Mh; ma.Y = Y; ma.X = X; ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
+            if (!v->mlp_attr_set) {
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)vit_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                v->mlp_attr_set = true;
+            }
+            slot = os_prof_begin(ctx, OS_PHASE_VIT_GEMM, s, "vit_mlp_kernel");
+            hipLaunchKernelGGL(vit_mlp_kernel, dim3((unsigned)((M + GM_BM - 1) / GM_BM)), dim3(512), (size_t)2 * GM_BM * 128 * sizeof(float), s, ma);
+            os_prof_end(ctx, slot, s);
+            wp += (size_t)2 * Mh * D;
+        } else {
+            g.A = Y; g.lda = D; g.N = Mh; g.K = D; g.Wp = wp; g.bias = fc1b; g.C = big;
+            launch_gemm<0, 1>(ctx, g, s, "vit_gemm_kernel<+bias,gelu>");
+            wp += (size_t)Mh * D;
+            g.A = big; g.lda = Mh; g.N = D; g.K = Mh; g.Wp = wp; g.bias = fc2b; g.C = X;
+            launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
+            wp += (size_t)D * Mh;
+        }
         OS_HIP(ctx, hipGetLastError());
     }
     const float *nw = w; w += D; const float *nb = w;
