@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
 struct MlpArgs {
     size_t M;
     int Mh;                     // hidden width, a multiple of 128
-    const float *Y;             // [M][128] normalised input
+    const float *Y;             // [M][128] input: already normalised (lnw == null), or the residual stream itself (LayerNorm applied here)
+    const float *lnw, *lnb;     // LayerNorm weight / bias [128], or null
     float *X;                   // [M][128] residual stream, updated in place
     const float *W1p, *b1;      // fc1 packed (vit_pack_w_kernel: N = Mh, K = 128), bias [Mh]
     const float *W2p, *b2;      // fc2 packed (N = 128, K = Mh), bias [128]
@@ -438,7 +439,43 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
     int hoff[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) hoff[m] = ((((chunk * 32 + li) >> 2) ^ (m + 4 * lh)) << 2) + (li & 3);
+    if (a.lnw && threadIdx.x < 64) {                                      // LayerNorm parameters -> the (still unused) hidden tile
+        const int c4 = 4 * (threadIdx.x & 31);
+        const float4 t = *reinterpret_cast<const float4 *>((threadIdx.x < 32 ? a.lnw : a.lnb) + c4);
+        *reinterpret_cast<float4 *>(&Hs[(threadIdx.x < 32 ? 0 : D) + c4]) = t;
+    }
     __syncthreads();                                                      // vmcnt(0) + barrier: the input tile has landed
+    if (a.lnw) {
+        // LayerNorm of the tile in place (layernorm_kernel's two passes: mean, then the centred second moment; eps 1e-5): four
+        // threads per row, each the eight stored 16-byte slots 8 qd .. 8 qd + 7 (stored slot s holds source slot s ^ (row & 7));
+        // the quarter sums meet through two quad permutes
+        const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+        float *rp = As + row * D + qd * 32;
+        float4 v4[8];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { v4[j] = *reinterpret_cast<const float4 *>(rp + 4 * j); sum += (v4[j].x + v4[j].y) + (v4[j].z + v4[j].w); }
+        sum += dpp_mov<0xB1>(sum); sum += dpp_mov<0x4E>(sum);
+        const float mean = sum * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v4[j].x -= mean; v4[j].y -= mean; v4[j].z -= mean; v4[j].w -= mean;
+            q += (v4[j].x * v4[j].x + v4[j].y * v4[j].y) + (v4[j].z * v4[j].z + v4[j].w * v4[j].w);
+        }
+        q += dpp_mov<0xB1>(q); q += dpp_mov<0x4E>(q);
+        const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int col = 4 * ((8 * qd + j) ^ (row & 7));
+            const float4 w4 = *reinterpret_cast<const float4 *>(&Hs[col]), b4 = *reinterpret_cast<const float4 *>(&Hs[D + col]);
+            float4 o;
+            o.x = v4[j].x * rstd * w4.x + b4.x; o.y = v4[j].y * rstd * w4.y + b4.y;
+            o.z = v4[j].z * rstd * w4.z + b4.z; o.w = v4[j].w * rstd * w4.w + b4.w;
+            *reinterpret_cast<float4 *>(rp + 4 * j) = o;
+        }
+        __syncthreads();
+    }
     const int nsl = a.Mh / 128;
     for (int s = 0; s < nsl; s++) {
         constexpr int D8 = 8;
@@ -703,13 +740,17 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         g.A = Y; g.lda = D; g.N = D; g.K = D; g.Wp = wp; g.bias = projb; g.C = X;
         launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
         wp += (size_t)D * D;
-        slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
-        hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln2w, ln2b, Y, (size_t)D);
-        os_prof_end(ctx, slot, s);
-        if (D == 128 && ctx->tune_vit_mlp_fused) {
-            // fc1 + GELU + fc2 + residual in one kernel: the hidden activations stay in LDS
+        const bool mlp_fused = D == 128 && ctx->tune_vit_mlp_fused;
+        if (!mlp_fused) {
+            slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
+            hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln2w, ln2b, Y, (size_t)D);
+            os_prof_end(ctx, slot, s);
+        }
+        if (mlp_fused) {
+            // LayerNorm + fc1 + GELU + fc2 + residual in one kernel: neither the normalised rows nor the hidden activations
+            // leave the CU
             MlpArgs ma;
-            ma.M = M; ma.Mh = Mh; ma.Y = Y; ma.X = X; ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
+            ma.M = M; ma.Mh = Mh; ma.Y = X; ma.lnw = ln2w; ma.lnb = ln2b; ma.X = X; ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
             if (!v->mlp_attr_set) {
                 OS_HIP(ctx, hipFuncSetAttribute((const void *)vit_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 v->mlp_attr_set = true;
