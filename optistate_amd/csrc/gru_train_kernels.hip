@@ -172,7 +172,6 @@ struct SweepArgs {
     const float *wihT, *whhT;    // transposed-packed weights
     float *dg4;                  // [T][B][4H]: da_r | da_z | da_n | da_n * r  (W_ih's products read sections 0-2, W_hh's 0, 1, 3)
     float *dx;                   // [T][B][K]
-    int dbg;
 };
 
 // RB = 32-row blocks per workgroup (BM = 32*RB).  LDS: dh [BM][H+1] | dG [BM][4H+1] (sections da_r, da_z, da_n, da_n*r).
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
     for (int t = a.T - 1; t >= 0; t--) {
         if constexpr (PF) {
         // ---- gate derivatives (VALU), coalesced over the hidden index ----
-        if (!(a.dbg & 1)) {
+        {
             const float *__restrict__ pdl = a.dy_last;
             const bool last = (t == a.T - 1);
             const uint32_t gbytes = (uint32_t)((size_t)a.T * B * 4 * H * 4), gstep = (uint32_t)((size_t)t * B * 4 * H * 4), gH = (uint32_t)H * 4u;
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
         }
         }
         osg::lds_barrier();
-        if (PF && t > 0 && !(a.dbg & 8)) prefetch(t - 1);
+        if (PF && t > 0) prefetch(t - 1);
         // ---- dx_t and dh_{t-1} (MFMA), output chunks dealt round-robin to the four waves ----
         f32x16 deferred[RB];
         int deferred_oc = -1;
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc[rb], 0, 0, 0);
             };
             // one MFMA per k-pair and row block: 16 x 64 cycles cover an L2 round trip
-            if (a.dbg & 6) {} else if (qs >= qhi) resident();
+            if (qs >= qhi) resident();
             else if (((qhi - qs) & 15) == 0 && RB == 1) run(std::integral_constant<int, 16>{});
             else run(std::integral_constant<int, 8>{});
             const osk::rsrc_t rdx = osk::make_rsrc(a.dx, (uint32_t)((size_t)a.T * B * K * 4));
@@ -433,7 +432,6 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             // dh += acc as sixteen LDS reads in flight, then sixteen writes.  (Element-wise read - wait - add - write behind
             // four branches each cost 3 us of every step; ds_add_f32 is worse still -- LDS float atomics ran the whole launch
             // 0.06 ms slower.)  The second half of a split chunk waits for the first behind a barrier, below the loop.
-            if (a.dbg & 32) continue;
             if (is_h && qh == 1) {
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++) deferred[rb] = acc[rb];
@@ -1217,7 +1215,6 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         a.dy = dy; a.dy_last = (l == L - 1) ? dhT : nullptr;
         a.wihT = wihT; a.whhT = whhT; a.dg4 = dg4;
         a.dx = dxbuf[l & 1];
-        { const char *e = getenv("OS_SWEEP_DBG"); a.dbg = e ? atoi(e) : 0; }
         const int RB = H <= 64 ? 2 : 1;
         const int BM = 32 * RB;
         const size_t lds = (size_t)(BM * (H + 1) + BM * (4 * H + 1)) * sizeof(float);
