@@ -35,6 +35,7 @@ python3 bench.py --mode full > $O/bench_full.json 2>> $O/bench.err
 python3 bench.py --mode windows > $O/bench_windows.json 2>> $O/bench.err
 python3 bench.py --split-bf16 > $O/bench_split_bf16.json 2>> $O/bench.err
 python3 bench.py --mode mpc --steps 3 --cpu-seconds 5 > $O/bench_mpc.json 2>> $O/bench.err
+python3 bench.py --mode mpc --batch 8 --seq 4000 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B8_T4000.json 2>> $O/bench.err
 bash tools/pmc_pass.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY" > $O/pmc_sq.txt 2>&1
 bash tools/pmc_pass.sh ${TAG}_grbm "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES" > $O/pmc_grbm.txt 2>&1
 python3 tools/ab_fused.py 6 > $O/ab_fused.txt 2>&1
