@@ -71,3 +71,34 @@ def test_config5_pipeline_latent_feeds_gru():
     r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P, latent=eng.pack(lat))
     torch.cuda.synchronize()
     assert np.abs(r["out"].cpu().numpy() - ref_out).max() < 2e-4
+
+
+def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
+    """The block MLP has two forms: vit_mlp_kernel (LayerNorm + fc1 + GELU + fc2 + residual in one kernel, default) and
+    layernorm_kernel + two vit_gemm launches (OS_VIT_MLP_FUSED=0).  Same latent up to summation order, on a frame count
+    whose token matrix ends in a partial 128-row tile."""
+    import ctypes as C
+    from optistate_amd import Engine, _capi
+    from optistate_amd.engine import _ptr
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    torch.manual_seed(4)
+    m = Transformer_Autoencoder().to("cuda")
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    flat = m._flat(torch.device("cuda:0"))
+    d = _capi.OsVitDims(m.img_size, m.patch_size, m.in_chans, m.embed_dim, m.depth, m.num_heads, m.mlp_hidden)
+    img = torch.rand(7, 224, 224, device="cuda")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OS_VIT_MLP_FUSED", mode)
+        e = Engine(0)
+        e._check(e.lib.os_vit_load(e._h, C.byref(d), _ptr(flat)), "os_vit_load")
+        lat = torch.empty((7, 128), dtype=torch.float32, device="cuda")
+        e.profile(True)
+        e._check(e.lib.os_vit_encode(e._h, 7, _ptr(img), _ptr(lat), e._stream()), "os_vit_encode")
+        torch.cuda.synchronize()
+        out[mode] = (lat.clone(), e.profile_read()["vit_gemm"][1])
+    assert out["1"][1] == 1 + 3 * 3 and out["0"][1] == 1 + 3 * 4          # patch + (qkv, proj, mlp | fc1, fc2) per block
+    assert float((out["1"][0] - out["0"][0]).abs().max()) < 5e-6
