@@ -21,7 +21,7 @@ struct os_ctx {
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
     int tune_mpc_persistent;             // os_kf_mpc_run: 1 = one persistent kernel up to 32 trajectories per CU (default), 2 = always, 0 = the per-step launch sequence
-    int tune_vit_mlp_fused;              // 1: ViT block MLP as one kernel (fc1 + GELU + fc2 + residual, hidden activations in LDS), 0: two GEMM launches
+    int tune_vit_mlp_fused;              // ViT block tail: 2 = projection + LayerNorm + MLP in one kernel (default), 1 = LayerNorm + MLP in one kernel, 0 = separate launches
     int tune_dw_rps;                     // rows per dW slice
     int tune_dw_fused;                   // 1: W_ih and W_hh gradients of a layer in one launch (dw3_kernel) when eligible, 0: two launches
     int tune_sweep_wr;                   // backward sweep: leading k-pairs of a wave's weight chunk kept in registers (32, 16 or 0)

@@ -398,8 +398,12 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
 struct MlpArgs {
     size_t M;
     int Mh;                     // hidden width, a multiple of 128
-    const float *Y;             // [M][128] input: already normalised (lnw == null), or the residual stream itself (LayerNorm applied here)
+    const float *Y;             // [M][128] input: already normalised (lnw == null), the residual stream itself (LayerNorm applied here),
+                                // or -- with Wpp -- the attention output that the projection below turns into the residual update
     const float *lnw, *lnb;     // LayerNorm weight / bias [128], or null
+    const float *Wpp, *bp;      // attention output projection (packed N = 128, K = 128; bias [128]), or null: x += y Wp^T + bp is
+                                // done HERE first (needs lnw), so that everything between the attention and the next block's qkv
+                                // is one pass over the rows (the projection as its own GEMM launch was three passes over X)
     float *X;                   // [M][128] residual stream, updated in place
     const float *W1p, *b1;      // fc1 packed (vit_pack_w_kernel: N = Mh, K = 128), bias [Mh]
     const float *W2p, *b2;      // fc2 packed (N = 128, K = Mh), bias [128]
@@ -439,12 +443,64 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
     int hoff[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) hoff[m] = ((((chunk * 32 + li) >> 2) ^ (m + 4 * lh)) << 2) + (li & 3);
+    // residual rows of this wave's output chunk (accumulator layout); rows past M read as zero
+    const osk::rsrc_t rcx = osk::make_rsrc(a.X, (uint32_t)(a.M * (size_t)D * 4));
+    const uint32_t vox = (uint32_t)((4 * lh) * D + chunk * 32 + li) * 4u;
+    f32x16v xres[2];
+    if (a.Wpp) {
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(D * 4));
+                xres[rb][e] = osk::buf_load(rcx, vox, so);
+            }
+    }
     if (a.lnw && threadIdx.x < 64) {                                      // LayerNorm parameters -> the (still unused) hidden tile
         const int c4 = 4 * (threadIdx.x & 31);
         const float4 t = *reinterpret_cast<const float4 *>((threadIdx.x < 32 ? a.lnw : a.lnb) + c4);
         *reinterpret_cast<float4 *>(&Hs[(threadIdx.x < 32 ? 0 : D) + c4]) = t;
     }
     __syncthreads();                                                      // vmcnt(0) + barrier: the input tile has landed
+    if (a.Wpp) {
+        // x_new = x + y Wp^T + bp for this wave's 64 rows x 32 columns, kept in registers until the final store; then the
+        // tile is replaced by x_new (same swizzled layout) for the LayerNorm below
+        constexpr int D8 = 8;
+        float wbf[D8], abf[D8][2];
+        const osk::rsrc_t rw = osk::make_rsrc(a.Wpp + (size_t)chunk * (D / 2) * 64, (uint32_t)(D / 2) * 256u);
+        const float bv = a.bp[chunk * 32 + li];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) xres[rb][e] += bv;
+#pragma unroll
+        for (int d = 0; d < D8; d++) {
+            wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, d, rb);
+        }
+#pragma unroll
+        for (int q = 0; q < D / 2; q++) {
+            const int d = q & (D8 - 1);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) xres[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], xres[rb], 0, 0, 0);
+            if (q + D8 < D / 2) {
+                wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, q + D8, rb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                                  // everyone is done reading the attention tile
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                As[r * D + hoff[e & 3]] = xres[rb][e];
+            }
+        __syncthreads();
+    }
     if (a.lnw) {
         // LayerNorm of the tile in place (layernorm_kernel's two passes: mean, then the centred second moment; eps 1e-5): four
         // threads per row, each the eight stored 16-byte slots 8 qd .. 8 qd + 7 (stored slot s holds source slot s ^ (row & 7));
@@ -543,17 +599,14 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
         if (s + 1 < nsl) __syncthreads();                                 // everyone is done reading the hidden slice
     }
 #undef MLP_AFRAG
-    // x += acc + b2: rows past M fall outside the descriptor's range
-    const int col = chunk * 32 + li;
-    const float bv = a.b2[col];
-    const osk::rsrc_t rc = osk::make_rsrc(a.X, (uint32_t)(a.M * (size_t)D * 4));
-    const uint32_t vo = (uint32_t)((4 * lh) * D + col) * 4u;
+    // x += acc + b2 (with the projection: x = x_new + acc + b2, no read): rows past M fall outside the descriptor's range
+    const float bv = a.b2[chunk * 32 + li];
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(D * 4));
-            osk::buf_store(rc, vo, so, acc2[rb][e] + bv + osk::buf_load(rc, vo, so));
+            osk::buf_store(rcx, vox, so, acc2[rb][e] + bv + (a.Wpp ? xres[rb][e] : osk::buf_load(rcx, vox, so)));
         }
 }
 
@@ -737,10 +790,13 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         } else if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         else hipLaunchKernelGGL(attention_kernel<64>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         os_prof_end(ctx, slot, s);
-        g.A = Y; g.lda = D; g.N = D; g.K = D; g.Wp = wp; g.bias = projb; g.C = X;
-        launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
-        wp += (size_t)D * D;
         const bool mlp_fused = D == 128 && ctx->tune_vit_mlp_fused;
+        const float *wproj = wp;
+        if (!(mlp_fused && ctx->tune_vit_mlp_fused >= 2)) {
+            g.A = Y; g.lda = D; g.N = D; g.K = D; g.Wp = wp; g.bias = projb; g.C = X;
+            launch_gemm<0, 2>(ctx, g, s, "vit_gemm_kernel<+bias,+residual>");
+        }
+        wp += (size_t)D * D;
         if (!mlp_fused) {
             slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
             hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln2w, ln2b, Y, (size_t)D);
@@ -750,7 +806,9 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
             // LayerNorm + fc1 + GELU + fc2 + residual in one kernel: neither the normalised rows nor the hidden activations
             // leave the CU
             MlpArgs ma;
-            ma.M = M; ma.Mh = Mh; ma.Y = X; ma.lnw = ln2w; ma.lnb = ln2b; ma.X = X; ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
+            ma.M = M; ma.Mh = Mh; ma.Y = X; ma.lnw = ln2w; ma.lnb = ln2b; ma.X = X; ma.Wpp = nullptr; ma.bp = nullptr;
+            ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
+            if (ctx->tune_vit_mlp_fused >= 2) { ma.Y = Y; ma.Wpp = wproj; ma.bp = projb; }      // attention output -> projection -> LN2 -> MLP in one pass
             if (!v->mlp_attr_set) {
                 OS_HIP(ctx, hipFuncSetAttribute((const void *)vit_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 v->mlp_attr_set = true;

@@ -74,9 +74,10 @@ def test_config5_pipeline_latent_feeds_gru():
 
 
 def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
-    """The block MLP has two forms: vit_mlp_kernel (LayerNorm + fc1 + GELU + fc2 + residual in one kernel, default) and
-    layernorm_kernel + two vit_gemm launches (OS_VIT_MLP_FUSED=0).  Same latent up to summation order, on a frame count
-    whose token matrix ends in a partial 128-row tile."""
+    """The block tail has three forms: vit_mlp_kernel with the attention projection inside (projection + residual + LayerNorm
+    + fc1 + GELU + fc2 + residual in one kernel, default), the same without the projection (OS_VIT_MLP_FUSED=1), and
+    layernorm_kernel + vit_gemm launches (OS_VIT_MLP_FUSED=0).  Same latent up to summation order, on a frame count whose
+    token matrix ends in a partial 128-row tile."""
     import ctypes as C
     from optistate_amd import Engine, _capi
     from optistate_amd.engine import _ptr
@@ -91,7 +92,7 @@ def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
     d = _capi.OsVitDims(m.img_size, m.patch_size, m.in_chans, m.embed_dim, m.depth, m.num_heads, m.mlp_hidden)
     img = torch.rand(7, 224, 224, device="cuda")
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         monkeypatch.setenv("OS_VIT_MLP_FUSED", mode)
         e = Engine(0)
         e._check(e.lib.os_vit_load(e._h, C.byref(d), _ptr(flat)), "os_vit_load")
@@ -100,5 +101,7 @@ def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
         e._check(e.lib.os_vit_encode(e._h, 7, _ptr(img), _ptr(lat), e._stream()), "os_vit_encode")
         torch.cuda.synchronize()
         out[mode] = (lat.clone(), e.profile_read()["vit_gemm"][1])
-    assert out["1"][1] == 1 + 3 * 3 and out["0"][1] == 1 + 3 * 4          # patch + (qkv, proj, mlp | fc1, fc2) per block
+    # GEMM-phase launches: patch + per block (qkv, proj+LN+mlp) | (qkv, proj, LN+mlp) | (qkv, proj, fc1, fc2)
+    assert out["2"][1] == 1 + 3 * 2 and out["1"][1] == 1 + 3 * 3 and out["0"][1] == 1 + 3 * 4
     assert float((out["1"][0] - out["0"][0]).abs().max()) < 5e-6
+    assert float((out["2"][0] - out["0"][0]).abs().max()) < 5e-6
