@@ -405,6 +405,8 @@ struct MlpArgs {
                                 // done HERE first (needs lnw), so that everything between the attention and the next block's qkv
                                 // is one pass over the rows (the projection as its own GEMM launch was three passes over X)
     float *X;                   // [M][128] residual stream, updated in place
+    const float *lnw_next, *lnb_next;   // the NEXT block's first LayerNorm, or null: its output rows are written to Ynext from
+    float *Ynext;                       // this kernel's epilogue (the row is complete here; no LayerNorm launch, no re-read of X)
     const float *W1p, *b1;      // fc1 packed (vit_pack_w_kernel: N = Mh, K = 128), bias [Mh]
     const float *W2p, *b2;      // fc2 packed (N = 128, K = Mh), bias [128]
 };
@@ -606,8 +608,55 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(D * 4));
-            osk::buf_store(rcx, vox, so, acc2[rb][e] + bv + (a.Wpp ? xres[rb][e] : osk::buf_load(rcx, vox, so)));
+            acc2[rb][e] += bv + (a.Wpp ? xres[rb][e] : osk::buf_load(rcx, vox, so));
+            osk::buf_store(rcx, vox, so, acc2[rb][e]);
         }
+    if (a.Ynext) {
+        // the next block's LayerNorm on the finished rows: tile -> LDS (both tiles are free after the barrier), four threads per
+        // row as above, normalised rows straight to Ynext
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                As[r * D + hoff[e & 3]] = acc2[rb][e];
+            }
+        if (threadIdx.x < 64) {
+            const int c4 = 4 * (threadIdx.x & 31);
+            *reinterpret_cast<float4 *>(&Hs[(threadIdx.x < 32 ? 0 : D) + c4]) =
+                *reinterpret_cast<const float4 *>((threadIdx.x < 32 ? a.lnw_next : a.lnb_next) + c4);
+        }
+        __syncthreads();
+        const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+        const float *rp = As + row * D + qd * 32;
+        float4 v4[8];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { v4[j] = *reinterpret_cast<const float4 *>(rp + 4 * j); sum += (v4[j].x + v4[j].y) + (v4[j].z + v4[j].w); }
+        sum += dpp_mov<0xB1>(sum); sum += dpp_mov<0x4E>(sum);
+        const float mean = sum * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v4[j].x -= mean; v4[j].y -= mean; v4[j].z -= mean; v4[j].w -= mean;
+            q += (v4[j].x * v4[j].x + v4[j].y * v4[j].y) + (v4[j].z * v4[j].z + v4[j].w * v4[j].w);
+        }
+        q += dpp_mov<0xB1>(q); q += dpp_mov<0x4E>(q);
+        const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
+        if (row0 + row < a.M) {
+            float *yp = a.Ynext + (row0 + row) * D;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int col = 4 * ((8 * qd + j) ^ (row & 7));
+                const float4 w4 = *reinterpret_cast<const float4 *>(&Hs[col]), b4 = *reinterpret_cast<const float4 *>(&Hs[D + col]);
+                float4 o;
+                o.x = v4[j].x * rstd * w4.x + b4.x; o.y = v4[j].y * rstd * w4.y + b4.y;
+                o.z = v4[j].z * rstd * w4.z + b4.z; o.w = v4[j].w * rstd * w4.w + b4.w;
+                *reinterpret_cast<float4 *>(yp + col) = o;
+            }
+        }
+    }
 }
 
 // row 0 of every frame: cls token + pos[0]   (transformer_model.py:119-123)
@@ -771,9 +820,13 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         const float *ln2w = w; w += D; const float *ln2b = w; w += D;
         w += (size_t)Mh * D; const float *fc1b = w; w += Mh;
         w += (size_t)D * Mh; const float *fc2b = w; w += D;
-        int slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
-        hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln1w, ln1b, Y, (size_t)D);
-        os_prof_end(ctx, slot, s);
+        int slot;
+        const bool tail_fused = D == 128 && ctx->tune_vit_mlp_fused >= 2;
+        if (!(tail_fused && blk > 0)) {                  // blocks after the first get their LayerNorm from the previous block's tail kernel
+            slot = os_prof_begin(ctx, OS_PHASE_VIT_MISC, s, "layernorm_kernel");
+            hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln1w, ln1b, Y, (size_t)D);
+            os_prof_end(ctx, slot, s);
+        }
         g.A = Y; g.lda = D; g.N = 3 * D; g.K = D; g.Wp = wp; g.bias = qkvb; g.C = big;
         launch_gemm<0, 0>(ctx, g, s, "vit_gemm_kernel<+bias>");
         wp += (size_t)3 * D * D;
@@ -808,6 +861,10 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
             MlpArgs ma;
             ma.M = M; ma.Mh = Mh; ma.Y = X; ma.lnw = ln2w; ma.lnb = ln2b; ma.X = X; ma.Wpp = nullptr; ma.bp = nullptr;
             ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
+            ma.lnw_next = ma.lnb_next = nullptr; ma.Ynext = nullptr;
+            if (tail_fused && blk + 1 < d.depth) {           // the next block's ln1 parameters follow this block's in the flat vector
+                ma.lnw_next = fc2b + D; ma.lnb_next = fc2b + 2 * D; ma.Ynext = Y;
+            }
             if (ctx->tune_vit_mlp_fused >= 2) { ma.Y = Y; ma.Wpp = wproj; ma.bp = projb; }      // attention output -> projection -> LN2 -> MLP in one pass
             if (!v->mlp_attr_set) {
                 OS_HIP(ctx, hipFuncSetAttribute((const void *)vit_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
