@@ -407,6 +407,8 @@ struct MlpArgs {
     float *X;                   // [M][128] residual stream, updated in place
     const float *lnw_next, *lnb_next;   // the NEXT block's first LayerNorm, or null: its output rows are written to Ynext from
     float *Ynext;                       // this kernel's epilogue (the row is complete here; no LayerNorm launch, no re-read of X)
+    const float *Wqp, *bq;              // with them: the next block's qkv projection (packed N = 384, K = 128; bias [384]) of the
+    float *QKVnext;                     // normalised tile straight into QKVnext [M][384] instead of Ynext (no qkv launch either)
     const float *W1p, *b1;      // fc1 packed (vit_pack_w_kernel: N = Mh, K = 128), bias [Mh]
     const float *W2p, *b2;      // fc2 packed (N = 128, K = Mh), bias [128]
 };
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
         if (s + 1 < nsl) __syncthreads();                                 // everyone is done reading the hidden slice
     }
 #undef MLP_AFRAG
+#define MLP_AFRAG2(T, q, rb) (T)[lo8[((q) >> 1) & 7] + (rb) * 32 * D + (((q) >> 1) >> 3) * 32 + ((q) & 1) * 2]
     // x += acc + b2 (with the projection: x = x_new + acc + b2, no read): rows past M fall outside the descriptor's range
     const float bv = a.b2[chunk * 32 + li];
 #pragma unroll
@@ -644,8 +647,8 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
         }
         q += dpp_mov<0xB1>(q); q += dpp_mov<0x4E>(q);
         const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
-        if (row0 + row < a.M) {
-            float *yp = a.Ynext + (row0 + row) * D;
+        if (a.Wqp || row0 + row < a.M) {
+            float *yp = a.Wqp ? As + row * D + qd * 32 : a.Ynext + (row0 + row) * D;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int col = 4 * ((8 * qd + j) ^ (row & 7));
@@ -653,7 +656,50 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
                 float4 o;
                 o.x = v4[j].x * rstd * w4.x + b4.x; o.y = v4[j].y * rstd * w4.y + b4.y;
                 o.z = v4[j].z * rstd * w4.z + b4.z; o.w = v4[j].w * rstd * w4.w + b4.w;
-                *reinterpret_cast<float4 *>(yp + col) = o;
+                *reinterpret_cast<float4 *>(a.Wqp ? yp + 4 * j : yp + col) = o;          // back into the swizzled tile, or out
+            }
+        }
+        if (a.Wqp) {
+            // qkv of the next block: three passes of four 32-column chunks over the normalised tile
+            __syncthreads();
+            const osk::rsrc_t rq = osk::make_rsrc(a.QKVnext, (uint32_t)(a.M * (size_t)(3 * D) * 4));
+            for (int p = 0; p < 3; p++) {
+                constexpr int D8 = 8;
+                float wbf[D8], abf[D8][2];
+                const int c = p * 4 + chunk;
+                const osk::rsrc_t rw = osk::make_rsrc(a.Wqp + (size_t)c * (D / 2) * 64, (uint32_t)(D / 2) * 256u);
+                f32x16v aq[2];
+                const float bq = a.bq[c * 32 + li];
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) aq[rb][e] = bq;
+#pragma unroll
+                for (int d = 0; d < D8; d++) {
+                    wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG2(As, d, rb);
+                }
+#pragma unroll
+                for (int qq = 0; qq < D / 2; qq++) {
+                    const int d = qq & (D8 - 1);
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) aq[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], aq[rb], 0, 0, 0);
+                    if (qq + D8 < D / 2) {
+                        wbf[d] = osk::buf_load(rw, wl + (uint32_t)(qq + D8) * 256u, 0u);
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG2(As, qq + D8, rb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const uint32_t voq = (uint32_t)((4 * lh) * 3 * D + c * 32 + li) * 4u;
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(3 * D * 4));
+                        osk::buf_store(rq, voq, so, aq[rb][e]);
+                    }
             }
         }
     }
@@ -827,8 +873,10 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
             hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, M, D, X, ln1w, ln1b, Y, (size_t)D);
             os_prof_end(ctx, slot, s);
         }
-        g.A = Y; g.lda = D; g.N = 3 * D; g.K = D; g.Wp = wp; g.bias = qkvb; g.C = big;
-        launch_gemm<0, 0>(ctx, g, s, "vit_gemm_kernel<+bias>");
+        if (!(tail_fused && blk > 0 && ctx->tune_vit_mlp_fused >= 3)) {     // later blocks: qkv already produced by the previous tail kernel
+            g.A = Y; g.lda = D; g.N = 3 * D; g.K = D; g.Wp = wp; g.bias = qkvb; g.C = big;
+            launch_gemm<0, 0>(ctx, g, s, "vit_gemm_kernel<+bias>");
+        }
         wp += (size_t)3 * D * D;
         const size_t alds = (size_t)2 * L * (hd + 1) * sizeof(float);
         const int ntl = (L + 31) / 32;
@@ -862,8 +910,12 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
             ma.M = M; ma.Mh = Mh; ma.Y = X; ma.lnw = ln2w; ma.lnb = ln2b; ma.X = X; ma.Wpp = nullptr; ma.bp = nullptr;
             ma.W1p = wp; ma.b1 = fc1b; ma.W2p = wp + (size_t)Mh * D; ma.b2 = fc2b;
             ma.lnw_next = ma.lnb_next = nullptr; ma.Ynext = nullptr;
+            ma.Wqp = nullptr; ma.bq = nullptr; ma.QKVnext = nullptr;
             if (tail_fused && blk + 1 < d.depth) {           // the next block's ln1 parameters follow this block's in the flat vector
                 ma.lnw_next = fc2b + D; ma.lnb_next = fc2b + 2 * D; ma.Ynext = Y;
+                if (ctx->tune_vit_mlp_fused >= 3) {          // ... and its qkv weights / bias: [ln1w ln1b | Wqkv (3D x D) | bqkv]
+                    ma.Wqp = wp + (size_t)2 * Mh * D; ma.bq = fc2b + 3 * D + (size_t)3 * D * D; ma.QKVnext = big;
+                }
             }
             if (ctx->tune_vit_mlp_fused >= 2) { ma.Y = Y; ma.Wpp = wproj; ma.bp = projb; }      // attention output -> projection -> LN2 -> MLP in one pass
             if (!v->mlp_attr_set) {

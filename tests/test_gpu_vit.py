@@ -92,7 +92,7 @@ def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
     d = _capi.OsVitDims(m.img_size, m.patch_size, m.in_chans, m.embed_dim, m.depth, m.num_heads, m.mlp_hidden)
     img = torch.rand(7, 224, 224, device="cuda")
     out = {}
-    for mode in ("2", "1", "0"):
+    for mode in ("3", "2", "1", "0"):
         monkeypatch.setenv("OS_VIT_MLP_FUSED", mode)
         e = Engine(0)
         e._check(e.lib.os_vit_load(e._h, C.byref(d), _ptr(flat)), "os_vit_load")
@@ -103,5 +103,7 @@ def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
         out[mode] = (lat.clone(), e.profile_read()["vit_gemm"][1])
     # GEMM-phase launches: patch + per block (qkv, proj+LN+mlp) | (qkv, proj, LN+mlp) | (qkv, proj, fc1, fc2)
     assert out["2"][1] == 1 + 3 * 2 and out["1"][1] == 1 + 3 * 3 and out["0"][1] == 1 + 3 * 4
+    assert out["3"][1] == 1 + 2 + 2                                      # default: later blocks' LayerNorm + qkv ride in the previous tail
+    assert float((out["3"][0] - out["0"][0]).abs().max()) < 5e-6
     assert float((out["1"][0] - out["0"][0]).abs().max()) < 5e-6
     assert float((out["2"][0] - out["0"][0]).abs().max()) < 5e-6
