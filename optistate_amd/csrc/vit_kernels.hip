@@ -81,10 +81,10 @@ __global__ void attention_kernel(int L, int D, int heads, const float *QKV, cons
 }
 
 // The same attention on the matrix cores for head_dim = 32 (the reference's ViT: 4 heads x 32).  One workgroup per
-// (image, head), K and V (+bias) of the head in LDS; a wave owns 32-query tiles.  Per tile: S = Q K^T as seven 32x32
-// v_mfma_f32_32x32x2_f32 tiles (exact fp32), keys beyond L masked, row max / row sum by in-lane reduction over the tiles
-// plus five xor-shuffles inside each 32-lane half (a C-layout row lives in one half), P = exp(S - max) handed from the
-// C layout to the A layout through a wave-private LDS tile, O = P V accumulated over the key tiles, scaled by 1 / sum.
+// (image, head), K and V (+bias) of the head in LDS; a wave owns a 32-query tile.  Per tile: S^T = K Q^T as seven 32x32
+// v_mfma_f32_32x32x2_f32 tiles (exact fp32), keys beyond L masked, the softmax statistics of a lane's query in-lane plus one
+// exchange between the wave halves, O^T = V^T P^T with P^T taken straight from the accumulator registers, scaled by 1 / sum
+// (details at the tile loop).
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 constexpr int ATT_HD = 32, ATT_KS = ATT_HD + 1, ATT_MAXT = 8;      // up to 256 tokens
 
@@ -100,6 +100,12 @@ __device__ __forceinline__ float dpp_mov(float v)
 __device__ __forceinline__ void rows_swap16(float &a, float &b)
 {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// lanes 32-63 of a <-> lanes 0-31 of b (a = b = v on entry: afterwards a holds the low half's value in both halves, b the high
+// half's); inline asm for the same reason as rows_swap16
+__device__ __forceinline__ void halves_swap32(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ float half_max(float v)
 {
@@ -122,10 +128,9 @@ __device__ __forceinline__ float half_sum(float v)
 template <int NT /* key / query tiles = ceil(L / 32) */, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
 {
-    extern __shared__ float sm[];            // K [L][33] | V [L][33] | P tiles [NW][32][33]
+    extern __shared__ float sm[];            // K [L][33] | V [L][33]
     float *Ks = sm, *Vs = sm + (size_t)L * ATT_KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-    float *pt = sm + (size_t)2 * L * ATT_KS + (size_t)wave * 32 * ATT_KS;
     const int n = blockIdx.x / heads, h = blockIdx.x % heads;
     const float *base = QKV + (size_t)n * L * 3 * D;
     // staging with float4 loads, four in flight per thread (a scalar loop here was one exposed HBM round trip per element:
@@ -152,7 +157,15 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_kernel(int L, int D
 #pragma unroll
         for (int q = 0; q < ATT_HD / 2; q++)
             qa[q] = base[(size_t)qrow * 3 * D + h * ATT_HD + 2 * q + lh] * scale;
-        // S tiles; the 16 K fragments of tile jt+1 are requested from LDS before the 16 MFMAs of tile jt issue
+        // TRANSPOSED score tiles S^T = K Q^T (A = K rows, B = Q^T): in the C layout a lane then owns ONE query (column li) and
+        // its registers run over the keys, (e & 3) + 8 (e >> 2) + 4 lh of each 32-key tile.  The softmax statistics of a query
+        // are in-lane reductions over 7 x 16 registers plus one exchange between the two wave halves (v_permlane32_swap) --
+        // not sixteen cross-lane reductions per tile -- and P^T never leaves the registers: O^T = V^T P^T takes it as its B
+        // operand directly, with the reduction's k-pairs renumbered to the C layout's key order (pair e = keys a_e, a_e + 4
+        // with a_e = (e & 3) + 8 (e >> 2); a sum does not care about the order) and the V^T fragments fetched in that order.
+        // (The P tile used to go through LDS, 16 writes + 16 reads per key tile, and the row statistics were ~290 VALU
+        // instructions per query tile on the pipe the MFMAs need.)  The 16 K fragments of tile jt+1 are requested from LDS
+        // before the 16 MFMAs of tile jt issue.
         f32x16v S[NT];
         float kb[2][ATT_HD / 2];
         {
@@ -170,62 +183,64 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_kernel(int L, int D
 #pragma unroll
             for (int e = 0; e < 16; e++) S[jt][e] = 0.f;
 #pragma unroll
-            for (int q = 0; q < ATT_HD / 2; q++) S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q], kb[jt & 1][q], S[jt], 0, 0, 0);
-            if (32 * jt + li >= L) {                     // this lane's key column does not exist
+            for (int q = 0; q < ATT_HD / 2; q++) S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[jt & 1][q], qa[q], S[jt], 0, 0, 0);
+            if (32 * jt + 32 > L) {                      // tile with keys past L: mask them (register index = key)
 #pragma unroll
-                for (int e = 0; e < 16; e++) S[jt][e] = -3.0e38f;
+                for (int e = 0; e < 16; e++)
+                    if (32 * jt + (e & 3) + 8 * (e >> 2) + 4 * lh >= L) S[jt][e] = -3.0e38f;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // row statistics: element e of a lane belongs to row (e&3) + 8(e>>2) + 4 lh, its 32 columns sit in the 32 lanes of the half
-        float mx[16], den[16];
+        // softmax statistics of this lane's query: in-lane over the keys it holds, then the other wave half's share
+        float m = S[0][0];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            float m = S[0][e];
+        for (int jt = 0; jt < NT; jt++)
 #pragma unroll
-            for (int jt = 1; jt < NT; jt++) m = fmaxf(m, S[jt][e]);
-            mx[e] = half_max(m);
+            for (int e = 0; e < 16; e++) m = fmaxf(m, S[jt][e]);
+        {
+            float ma = m, mb = m;
+            halves_swap32(ma, mb);
+            m = fmaxf(ma, mb);
         }
+        float den = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            float d = 0.f;
+        for (int jt = 0; jt < NT; jt++)
 #pragma unroll
-            for (int jt = 0; jt < NT; jt++) { const float pv = __builtin_amdgcn_exp2f(S[jt][e] - mx[e]); S[jt][e] = pv; d += pv; }
-            den[e] = half_sum(d);
+            for (int e = 0; e < 16; e++) { const float pv = __builtin_amdgcn_exp2f(S[jt][e] - m); S[jt][e] = pv; den += pv; }
+        {
+            float da = den, db = den;
+            halves_swap32(da, db);
+            den = da + db;
         }
-        // O = P V
+        // O^T = V^T P^T: A fragment (dim li, keys a_e + 4 lh of the tile) from LDS, B fragment = S[jt][e]
         f32x16v acc;
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[e] = 0.f;
         float vbf[2][16];
         {
 #pragma unroll
-            for (int q = 0; q < 16; q++) { const int key = 2 * q + lh < L ? 2 * q + lh : L - 1; vbf[0][q] = Vs[key * ATT_KS + li]; }
+            for (int e = 0; e < 16; e++) { const int key = (e & 3) + 8 * (e >> 2) + 4 * lh; vbf[0][e] = Vs[(key < L ? key : L - 1) * ATT_KS + li]; }
         }
 #pragma unroll
         for (int jt = 0; jt < NT; jt++) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < 16; e++) pt[((e & 3) + 8 * (e >> 2) + 4 * lh) * ATT_KS + li] = S[jt][e];
-            __builtin_amdgcn_wave_barrier();
-            float pa[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) pa[q] = pt[li * ATT_KS + 2 * q + lh];
             if (jt + 1 < NT) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int key = 32 * (jt + 1) + 2 * q + lh < L ? 32 * (jt + 1) + 2 * q + lh : L - 1;      // P is 0 there
-                    vbf[(jt + 1) & 1][q] = Vs[key * ATT_KS + li];
+                for (int e = 0; e < 16; e++) {
+                    const int key = 32 * (jt + 1) + (e & 3) + 8 * (e >> 2) + 4 * lh;                            // P is 0 past L
+                    vbf[(jt + 1) & 1][e] = Vs[(key < L ? key : L - 1) * ATT_KS + li];
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[q], vbf[jt & 1][q], acc, 0, 0, 0);
+            for (int e = 0; e < 16; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vbf[jt & 1][e], S[jt][e], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // lane = query r0 + li, registers = head dims (e & 3) + 8 (e >> 2) + 4 lh: four 16-byte stores per lane
+        if (r0 + li < L) {
+            const float inv = 1.0f / den;
+            float *op = O + ((size_t)n * L + r0 + li) * D + h * ATT_HD + 4 * lh;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (row < L) O[((size_t)n * L + row) * D + h * ATT_HD + li] = acc[e] / den[e];
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4 *>(op + 8 * g) = make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv);
         }
     }
 }
@@ -882,7 +897,7 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         const int ntl = (L + 31) / 32;
         slot = os_prof_begin(ctx, OS_PHASE_VIT_ATTN, s, (hd == 32 && ntl == 7) ? "attention_mfma_kernel<7>" : "attention_kernel");
         if (hd == 32 && ntl == 7) {              // the reference's shape: 197 tokens, head_dim 32 -> matrix cores
-            const size_t mlds = ((size_t)2 * L * 33 + 8 * 32 * 33) * sizeof(float);
+            const size_t mlds = (size_t)2 * L * 33 * sizeof(float);
             if (!v->att_attr_set) {
                 OS_HIP(ctx, hipFuncSetAttribute((const void *)attention_mfma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 v->att_attr_set = true;
