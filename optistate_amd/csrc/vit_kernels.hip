@@ -297,6 +297,27 @@ __device__ __forceinline__ float gelu_erf(float v)
     return 0.5f * v * (1.0f + copysignf(erfz, v));
 }
 
+// the same on a pair of values: the polynomial and the affine steps as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32), only the
+// reciprocal and the exponential per component -- the tail kernel's GELU is ~10 % of its time on the pipe its MFMAs need
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v gelu_erf2(f2v v)
+{
+    const f2v one = {1.0f, 1.0f};
+    const f2v z = __builtin_elementwise_abs(v) * 0.70710678118654752f;
+    const f2v den = z * 0.3275911f + one;
+    const f2v t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f2v poly = t * 1.061405429f + (f2v){-1.453152027f, -1.453152027f};
+    poly = poly * t + (f2v){1.421413741f, 1.421413741f};
+    poly = poly * t + (f2v){-0.284496736f, -0.284496736f};
+    poly = poly * t + (f2v){0.254829592f, 0.254829592f};
+    poly = poly * t;
+    const f2v zz = z * z * -1.44269504088896341f;
+    const f2v ex = {__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)};
+    const f2v erfz = one - poly * ex;
+    const f2v sg = {copysignf(erfz.x, v.x), copysignf(erfz.y, v.y)};
+    return v * 0.5f * (one + sg);
+}
+
 template <int SRC, int EPI>
 __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
 {
@@ -587,9 +608,11 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
+                for (int e = 0; e < 16; e += 2) {
                     const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    Hs[r * D + hoff[e & 3]] = gelu_erf(acc1[rb][e] + bv);
+                    const f2v g = gelu_erf2((f2v){acc1[rb][e] + bv, acc1[rb][e + 1] + bv});
+                    Hs[r * D + hoff[e & 3]] = g.x;
+                    Hs[(r + 1) * D + hoff[(e + 1) & 3]] = g.y;
                 }
         }
         __syncthreads();                                                  // the hidden slice is complete
