@@ -228,7 +228,9 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * back, no stream synchronisation; P is carried in float64 between steps, as in the reference, and rounded to float32
  * only when it is written back at the end of the call.  Larger batches take the launch sequence (QP instances + a T = 1
  * filter launch per step, one trajectory per lane; the leg-count histogram is read back once at entry), which has the
- * higher throughput there.  OS_MPC_PERSISTENT=0 / 2 in the environment forces the sequence / the persistent kernel. */
+ * higher throughput there.  OS_MPC_PERSISTENT=0 / 2 in the environment forces the sequence / the persistent kernel.
+ * OS_KF_SEQUENTIAL_UPDATE in `flags` selects the scalar-update form in the launch sequence only; the persistent kernel always
+ * uses the batch (Cholesky) form of kalman_filter.py:166-172 -- the same posterior for the diagonal R the flag requires. */
 int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
                   const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *f_out,
                   float *p_rot_out, float *ptrace_out, float *kgain_out, int32_t *mpc_iters, int32_t *status,
