@@ -27,10 +27,16 @@ namespace ost {
 using osg::sigmoidf_;
 
 // ---- loss + d(out) -------------------------------------------------------------------------------------------
-// out [B][C], y [B][C/2]; target [B][C] (optional), dout [B][C]; loss_acc: one float, pre-zeroed.
-__global__ __launch_bounds__(256) void loss_kernel(int B, int C, const float *out, const float *y, float *target, float *dout, float *loss_acc)
+// out [B][C], y [B][C/2]; target [B][C] (optional), dout [B][C]; loss: one float, written (not accumulated) by the LAST
+// workgroup to finish, which adds the per-workgroup partial sums in index order: no memset in front of the launch (4.5 us
+// of a 2.2 ms training step) and a loss that does not depend on the order the workgroups retire in.
+// scratch: [LOSS_MAXBLK] partial sums + one ticket counter (zero before the first launch; atomicInc wraps it back to zero).
+constexpr int LOSS_MAXBLK = 128;
+__global__ __launch_bounds__(256) void loss_kernel(int B, int C, const float *out, const float *y, float *target, float *dout, float *loss,
+                                                   float *scratch)
 {
     __shared__ float part[4];
+    __shared__ bool last;
     const int half = C / 2, n = B * C;
     const float inv = 1.0f / (float)n;
     float sq = 0.f;
@@ -48,7 +54,24 @@ __global__ __launch_bounds__(256) void loss_kernel(int B, int C, const float *ou
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_acc, (part[0] + part[1] + part[2] + part[3]) * inv);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&scratch[blockIdx.x], (part[0] + part[1] + part[2] + part[3]) * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned ticket = __hip_atomic_fetch_add((unsigned *)(scratch + LOSS_MAXBLK), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    float v = 0.f;
+    if (threadIdx.x < 64) {                  // gridDim.x <= LOSS_MAXBLK = 2 x 64: fixed order, fixed tree
+        const unsigned i0 = threadIdx.x, i1 = threadIdx.x + 64;
+        if (i0 < gridDim.x) v = __hip_atomic_load(&scratch[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i1 < gridDim.x) v += __hip_atomic_load(&scratch[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) {
+            *loss = v;
+            __hip_atomic_store((unsigned *)(scratch + LOSS_MAXBLK), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // hardware float add at the L2 (atomicAdd(float *) without -munsafe-fp-atomics is a compare-and-swap loop, which under the
@@ -149,8 +172,15 @@ struct PackTAll {
     const float *W[32];
     float *dst[32];
 };
-__global__ void pack_T_all_kernel(const PackTAll a, int H3)
+// The launch is the first of a backward pass, so it also clears the flat gradient vector the later kernels add into (a
+// separate hipMemsetAsync cost a 4.5 us launch of its own).
+__global__ void pack_T_all_kernel(const PackTAll a, int H3, float *zero, size_t nzero)
 {
+    {
+        const size_t nth = (size_t)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+        const size_t tid = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        for (size_t i = tid; i < nzero; i += nth) zero[i] = 0.f;
+    }
     const int m = blockIdx.z;
     if (m >= a.n || (int)blockIdx.x >= a.chunks[m]) return;
     const int K = a.K[m], chunk = blockIdx.x, n = (H3 / 2) * 64;
@@ -781,12 +811,16 @@ struct Dw3Args {
     float *dWih, *dWhh, *dbih, *dbhh;
 };
 
-template <int NCX, int NCH>
+// TR = rows per tile: 32, or 16 for the ten-accumulator form of the 188-wide first layer (160 accumulator registers leave
+// room for one 8-step set of gate-derivative fragments per buffer, not for 16)
+template <int NCX, int NCH, int TR = DW_TR>
 __global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
 {
     constexpr int PX = NCX * 32, PH = NCH * 32;             // floats per LDS row
-    __shared__ __attribute__((aligned(16))) float Xs[2][DW_TR * PX + 4];
-    __shared__ __attribute__((aligned(16))) float Hs[2][DW_TR * PH + 4];
+    constexpr int NPX = TR * NCX / 32, NPH = TR * NCH / 32;  // 16-byte pieces per thread per tile
+    static_assert(TR * NCX % 32 == 0 && TR * NCH % 32 == 0, "whole pieces per thread");
+    __shared__ __attribute__((aligned(16))) float Xs[2][TR * PX + 4];
+    __shared__ __attribute__((aligned(16))) float Hs[2][TR * PH + 4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
     // XCD-aware workgroup order: consecutive workgroup ids go round-robin to the eight XCDs, each with its own L2, and the
     // column groups of one row slice all stream the same X / h tiles -- so ids i, i + 8, i + 16, ... (same XCD, dispatched
@@ -800,36 +834,36 @@ __global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
     size_t r1 = r0 + a.rows_per_slice;
     if (r1 > a.rows) r1 = a.rows;
     if (r0 >= r1) return;
-    const int ntiles = (int)((r1 - r0 + DW_TR - 1) / DW_TR);
+    const int ntiles = (int)((r1 - r0 + TR - 1) / TR);
     const uint32_t nrows = (uint32_t)(r1 - r0);
     const osk::rsrc_t rg = osk::make_rsrc(a.dG + r0 * a.ldg, jok ? nrows * (uint32_t)a.ldg * 4u : 0u);
     const uint32_t gli = (uint32_t)(kk * a.ldg + j0 + li) * 4u, glh = gli + (ngate ? (uint32_t)a.H * 4u : 0u), grow = (uint32_t)a.ldg * 8u;
     // fixed position of this thread's 16-byte pieces inside the two tiles (see dw2_kernel)
     const uint32_t xstride = a.x_btf ? (uint32_t)a.T * (uint32_t)a.Kx : (uint32_t)a.Kx;
-    uint32_t pvx[NCX], pvh[NCH];
+    uint32_t pvx[NPX], pvh[NPH];
 #pragma unroll
-    for (int i = 0; i < NCX; i++) {
+    for (int i = 0; i < NPX; i++) {
         const int p = threadIdx.x + 256 * i, prow = p / (PX / 4), c4 = 4 * (p % (PX / 4));
         pvx[i] = c4 < a.Kx ? ((uint32_t)prow * xstride + (uint32_t)c4) * 4u : 0x80000000u;
     }
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
+    for (int i = 0; i < NPH; i++) {
         const int p = threadIdx.x + 256 * i, prow = p / (PH / 4), c4 = 4 * (p % (PH / 4));
         pvh[i] = ((uint32_t)prow * (uint32_t)a.H + (uint32_t)c4) * 4u;
     }
     const osk::rsrc_t rxs = osk::make_rsrc(a.X, (uint32_t)((size_t)a.T * a.B * a.Kx * 4));
     const osk::rsrc_t rhs = osk::make_rsrc(a.Hp, (uint32_t)((size_t)a.T * a.B * a.H * 4));
-    auto hzero = [&](int tile) { return r0 + (size_t)tile * DW_TR < (size_t)a.B; };
+    auto hzero = [&](int tile) { return r0 + (size_t)tile * TR < (size_t)a.B; };
     auto dma = [&](int tile, int buf) {
-        const uint32_t xr0 = (uint32_t)r0 + (uint32_t)tile * DW_TR;
+        const uint32_t xr0 = (uint32_t)r0 + (uint32_t)tile * TR;
         const uint32_t sox = __builtin_amdgcn_readfirstlane(
             (a.x_btf ? (xr0 % (uint32_t)a.B) * (uint32_t)a.T + xr0 / (uint32_t)a.B : xr0) * (uint32_t)a.Kx * 4u);
 #pragma unroll
-        for (int i = 0; i < NCX; i++) lds_dma16_buf(rxs, &Xs[buf][(wave * 64 + 256 * i) * 4], pvx[i], sox);
+        for (int i = 0; i < NPX; i++) lds_dma16_buf(rxs, &Xs[buf][(wave * 64 + 256 * i) * 4], pvx[i], sox);
         if (!hzero(tile)) {
             const uint32_t soh = __builtin_amdgcn_readfirstlane((xr0 - (uint32_t)a.B) * (uint32_t)a.H * 4u);
 #pragma unroll
-            for (int i = 0; i < NCH; i++) lds_dma16_buf(rhs, &Hs[buf][(wave * 64 + 256 * i) * 4], pvh[i], soh);
+            for (int i = 0; i < NPH; i++) lds_dma16_buf(rhs, &Hs[buf][(wave * 64 + 256 * i) * 4], pvh[i], soh);
         }
     };
     f32x16 accx[NCX], acch[NCH];
@@ -841,21 +875,21 @@ __global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
     for (int c = 0; c < NCH; c++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acch[c][e] = 0.f;
-    float avi[2][DW_TR / 2], avh[2][DW_TR / 2];
+    float avi[2][TR / 2], avh[2][TR / 2];
     auto dg_load = [&](int tile, int buf) {
-        const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)tile * (uint32_t)(DW_TR / 2) * grow);
+        const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)tile * (uint32_t)(TR / 2) * grow);
 #pragma unroll
-        for (int st = 0; st < DW_TR / 2; st++) avi[buf][st] = osk::buf_load_nt(rg, gli, so + (uint32_t)st * grow);
+        for (int st = 0; st < TR / 2; st++) avi[buf][st] = osk::buf_load_nt(rg, gli, so + (uint32_t)st * grow);
         if (ngate) {
 #pragma unroll
-            for (int st = 0; st < DW_TR / 2; st++) avh[buf][st] = osk::buf_load_nt(rg, glh, so + (uint32_t)st * grow);
+            for (int st = 0; st < TR / 2; st++) avh[buf][st] = osk::buf_load_nt(rg, glh, so + (uint32_t)st * grow);
         }
     };
     float bsi = 0.f, bsh = 0.f;
     auto tile_mfma = [&](int buf, bool hz) {
         const float *xb = &Xs[buf][kk * PX + li], *hb = &Hs[buf][kk * PH + li];
 #pragma unroll
-        for (int st = 0; st < DW_TR / 2; st++) {
+        for (int st = 0; st < TR / 2; st++) {
             const float ai = avi[buf][st], ah = ngate ? avh[buf][st] : ai;
             bsi += ai; bsh += ah;
             float xv[NCX], hv[NCH];
@@ -990,6 +1024,7 @@ struct os_train_state {
     float *dg;    size_t dg_floats;      // gate derivatives [T][B][4H]: da_r | da_z | da_n | da_n * r
     float *dxy;   size_t dxy_floats;     // dx ping-pong [T][B][max(K,H)] x 2 + dh_T [B][H]
     float *wT;    size_t wT_floats;      // transposed-packed weights
+    float *lossp; size_t lossp_floats;   // loss_kernel: per-workgroup partial sums + ticket counter
     int B, T;
     // weight-gradient reductions of layer l run on a side stream underneath the backward sweep of layer l-1 (they only
     // depend on layer l's gate derivatives): non-blocking stream + events, created on first use
@@ -1025,7 +1060,7 @@ void os_train_destroy(os_ctx *ctx)
 {
     os_train_state *t = (os_train_state *)ctx->train;
     if (!t) return;
-    float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->wT};
+    float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->wT, t->lossp};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (t->side_ready) {
@@ -1115,11 +1150,16 @@ int os_gru_loss(os_ctx *ctx, int32_t B, const float *out, const float *y, float 
     if (C % 2) return os_fail(ctx, -4, "os_gru_loss: num_classes must be even (state | error bands)");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    OS_HIP(ctx, hipMemsetAsync(loss, 0, sizeof(float), s));
+    os_train_state *ts = train_state(ctx);
+    if (!ts) return os_fail(ctx, -13, "os_gru_loss: cannot create training state");
+    if (!ts->lossp) {
+        if (os_ensure_scratch(ctx, &ts->lossp, &ts->lossp_floats, LOSS_MAXBLK + 1)) return -10;
+        OS_HIP(ctx, hipMemsetAsync(ts->lossp, 0, (LOSS_MAXBLK + 1) * sizeof(float), s));       // the ticket counter, once
+    }
     const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "loss_kernel");
     {
         const int nblk = (B * C + 255) / 256;
-        hipLaunchKernelGGL(loss_kernel, dim3(nblk < 128 ? nblk : 128), dim3(256), 0, s, B, C, out, y, target, dout, loss);
+        hipLaunchKernelGGL(loss_kernel, dim3(nblk < LOSS_MAXBLK ? nblk : LOSS_MAXBLK), dim3(256), 0, s, B, C, out, y, target, dout, loss, ts->lossp);
     }
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
@@ -1149,22 +1189,6 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     }
     if (os_ensure_scratch(ctx, &ts->wT, &ts->wT_floats, wT_total)) return -10;
     const size_t rows = (size_t)T * B;
-    OS_HIP(ctx, hipMemsetAsync(grad_flat, 0, nparam * sizeof(float), s));
-
-    // ---- head ----
-    const size_t fc_off = nparam - ((size_t)C * H + C);
-    const float *fcw = w_flat + fc_off;
-    float *dhT = ts->dxy + 2 * (size_t)T * B * Kmax;
-    const float *hT = act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
-    {
-        const size_t lds = (size_t)(64 * ((C + 31) / 32 * 32) + 64 * (H + 1)) * sizeof(float);
-        const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "head_backward_kernel");
-        hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(256), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
-                           fcw, dhT, grad_flat + fc_off, grad_flat + fc_off + (size_t)C * H);
-        os_prof_end(ctx, slot, s);
-        OS_HIP(ctx, hipGetLastError());
-    }
-    // ---- layers, top to bottom ----
     size_t poff[17], wToff[17];
     {
         size_t po = 0, wo = 0;
@@ -1188,15 +1212,29 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             if ((K + 31) / 32 > maxch) maxch = (K + 31) / 32;
         }
         const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "pack_T_all_kernel");
-        hipLaunchKernelGGL(pack_T_all_kernel, dim3(maxch, 16, pa.n), dim3(256), 0, s, pa, H3);
+        hipLaunchKernelGGL(pack_T_all_kernel, dim3(maxch, 16, pa.n), dim3(256), 0, s, pa, H3, grad_flat, nparam);
         os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
     }
+    // ---- head ----
+    const size_t fc_off = nparam - ((size_t)C * H + C);
+    const float *fcw = w_flat + fc_off;
+    float *dhT = ts->dxy + 2 * (size_t)T * B * Kmax;
+    const float *hT = act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
+    {
+        const size_t lds = (size_t)(64 * ((C + 31) / 32 * 32) + 64 * (H + 1)) * sizeof(float);
+        const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "head_backward_kernel");
+        hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(256), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
+                           fcw, dhT, grad_flat + fc_off, grad_flat + fc_off + (size_t)C * H);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+    }
+    // ---- layers, top to bottom ----
     float *dxbuf[2] = {ts->dxy, ts->dxy + (size_t)T * B * Kmax};
     const float *dy = nullptr;
     hipStream_t sw = overlap ? ts->side : s;             // stream of the weight-gradient kernels
     if (overlap) {
-        OS_HIP(ctx, hipEventRecord(ts->ev_fork, s));     // the side stream starts behind the memset / head backward
+        OS_HIP(ctx, hipEventRecord(ts->ev_fork, s));     // the side stream starts behind the gradient clear / head backward
         OS_HIP(ctx, hipStreamWaitEvent(ts->side, ts->ev_fork, 0));
     }
     for (int l = L - 1; l >= 0; l--) {
@@ -1251,8 +1289,12 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         // ---- weight and bias gradients: one launch each for W_ih (+b_ih) and W_hh (+b_hh) ----
         float *gWih = grad_flat + poff[l], *gWhh = gWih + (size_t)H3 * K, *gbih = gWhh + (size_t)H3 * H, *gbhh = gbih + H3;
         // both products in one launch (dw3_kernel) when the tiles are whole and the accumulators fit two workgroups per CU
-        const int ncx = (K + 31) / 32 <= 2 ? 2 : 4, nchh = H / 32;
-        const bool fuse_dw = ctx->tune_dw_fused != 0 && K <= 128 && (K & 3) == 0 && (nchh == 4 || (nchh == 2 && ncx == 2)) && B % DW_TR == 0 &&
+        // An input of 129..192 columns (the 188-wide first layer) takes the ten-accumulator form on 16-row tiles.  (Tried and not
+        // kept: its leading 128 columns in dw3_kernel<4,4> and the rest through dw2_kernel<2>: 0.177 + 0.071 ms against 0.237 for
+        // the two separate products -- two MFMAs per gate-derivative load leave the second launch waiting on memory.)
+        const bool wide = K > 128 && K <= 192 && H == 128;
+        const int ncx = wide ? 6 : (K + 31) / 32 <= 2 ? 2 : 4, nchh = H / 32;
+        const bool fuse_dw = ctx->tune_dw_fused != 0 && (K <= 128 || (wide && ctx->tune_dw_fused != 2)) && (K & 3) == 0 && (nchh == 4 || (nchh == 2 && ncx == 2)) && B % DW_TR == 0 &&
                              ctx->tune_dw_rps % DW_TR == 0 && T > 1 && (size_t)T * B * (K > H ? K : H) * 4 < ((size_t)1 << 31);
         if (fuse_dw) {
             const int rps = ctx->tune_dw_rps;
@@ -1266,7 +1308,8 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             const unsigned nslices = (unsigned)((rows + rps - 1) / rps);
             const dim3 grid(8u * ((nslices + 7) / 8) * (unsigned)d.ngroups);       // see the XCD-aware order in the kernel
             const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, "dw3_kernel");
-            if (nchh == 4 && ncx == 4) hipLaunchKernelGGL((dw3_kernel<4, 4>), grid, dim3(256), 0, sw, d);
+            if (wide) hipLaunchKernelGGL((dw3_kernel<6, 4, 16>), grid, dim3(256), 0, sw, d);
+            else if (nchh == 4 && ncx == 4) hipLaunchKernelGGL((dw3_kernel<4, 4>), grid, dim3(256), 0, sw, d);
             else if (nchh == 4) hipLaunchKernelGGL((dw3_kernel<2, 4>), grid, dim3(256), 0, sw, d);
             else hipLaunchKernelGGL((dw3_kernel<2, 2>), grid, dim3(256), 0, sw, d);
             os_prof_end(ctx, dslot, sw);

@@ -23,7 +23,8 @@ struct os_ctx {
     int tune_mpc_persistent;             // os_kf_mpc_run: 1 = one persistent kernel up to 32 trajectories per CU (default), 2 = always, 0 = the per-step launch sequence
     int tune_vit_mlp_fused;              // ViT block tail: 2 = projection + LayerNorm + MLP in one kernel (default), 1 = LayerNorm + MLP in one kernel, 0 = separate launches
     int tune_dw_rps;                     // rows per dW slice
-    int tune_dw_fused;                   // 1: W_ih and W_hh gradients of a layer in one launch (dw3_kernel) when eligible, 0: two launches
+    int tune_dw_fused;                   // 1: W_ih and W_hh gradients of a layer in one launch (dw3_kernel) when eligible, 0: two launches,
+                                         // 2: one launch only for inputs of at most 128 columns (the round-2d state)
     int tune_sweep_wr;                   // backward sweep: leading k-pairs of a wave's weight chunk kept in registers (32, 16 or 0)
     int tune_sweep_nw;                   // 0 automatic, 4 / 8 waves per backward-sweep workgroup
     int tune_train_overlap;              // OS_TRAIN_OVERLAP=0: weight-gradient kernels on the caller's stream (no side stream)
