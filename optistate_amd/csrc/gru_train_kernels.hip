@@ -83,14 +83,15 @@ __device__ __forceinline__ void global_fadd(float *base, uint32_t bytes, uint32_
 
 // ---- head backward -------------------------------------------------------------------------------------------
 // dpre = dout * out * (1 - out) (sigmoid) or dout; dh_T [B][H] = dpre . fcw; dfcw [C][H] += dpre^T h_T; dfcb += sum dpre.
-// One workgroup per 64 rows, 256 threads = (hidden unit k: 128 at a time) x (2 halves).  Register blocking: for dh_T a
-// thread holds its column of fcw (C values) and walks its 32 rows with the row's dpre broadcast from LDS; for dfcw it holds
-// C/2 accumulators and walks the 64 rows.  (The first version did one LDS/global read per multiply-add and took 69 us at
+// One workgroup per 64 rows, 512 threads = (hidden unit k: 128 at a time) x (4 quarters).  Register blocking: for dh_T a
+// thread holds its column of fcw (C values) and walks its 16 rows with the row's dpre broadcast from LDS; for dfcw it holds
+// C/4 accumulators and walks the 64 rows.  (Two halves on 256 threads: 21.7 us at the training batch, one wave per SIMD
+// with nothing to cover its LDS reads.)  (The first version did one LDS/global read per multiply-add and took 69 us at
 // the training batch.)  Partial dfcw / dfcb are added with float atomics: C*H + C addresses, B/64 contributions each.
 constexpr int HB_CMAX = 32;            // classes per pass, held in registers (the LDS tile is zero-padded to a multiple of it:
                                        // straight-line inner loops -- with run-time class bounds hipcc put an
                                        // s_waitcnt vmcnt(0) behind every LDS read and each row waited for the previous row's store)
-__global__ __launch_bounds__(256) void head_backward_kernel(int B, int H, int C, int use_sigmoid, const float *out, const float *dout,
+__global__ __launch_bounds__(512) void head_backward_kernel(int B, int H, int C, int use_sigmoid, const float *out, const float *dout,
                                      const float *hT /*[B][H]*/, const float *fcw, float *dhT /*[B][H]*/, float *dfcw,
                                      float *dfcb)
 {
@@ -103,28 +104,28 @@ __global__ __launch_bounds__(256) void head_backward_kernel(int B, int H, int C,
     const osk::rsrc_t ro = osk::make_rsrc(out, (uint32_t)((size_t)B * C * 4)), rd = osk::make_rsrc(dout, (uint32_t)((size_t)B * C * 4)),
                       rh = osk::make_rsrc(hT, (uint32_t)((size_t)B * H * 4));
 #pragma unroll 8
-    for (int i = threadIdx.x; i < 64 * Cp; i += 256) {
+    for (int i = threadIdx.x; i < 64 * Cp; i += 512) {
         const int r = i / Cp, c = i % Cp;
         const uint32_t off = c < C ? (uint32_t)(((size_t)(row0 + r) * C + c) * 4) : 0xffffffffu;      // pad columns: out of range -> 0
         const float o = osk::buf_load(ro, off, 0u), dv = osk::buf_load(rd, off, 0u);
         dp[i] = dv * (use_sigmoid ? o * (1.0f - o) : 1.0f);
     }
 #pragma unroll 8
-    for (int i = threadIdx.x; i < 64 * H; i += 256) {
+    for (int i = threadIdx.x; i < 64 * H; i += 512) {
         const int r = i / H, k = i % H;
         hs[r * (H + 1) + k] = osk::buf_load(rh, (uint32_t)(((size_t)(row0 + r) * H + k) * 4), 0u);   // rows past B: 0
     }
     __syncthreads();
-    const int half = threadIdx.x >> 7, kk = threadIdx.x & 127;
+    const int qtr = threadIdx.x >> 7, kk = threadIdx.x & 127;
     for (int k = kk; k < H; k += 128) {
         for (int c0 = 0; c0 < Cp; c0 += HB_CMAX) {
-            // dh_T: rows half*32 .. +32
+            // dh_T: rows qtr*16 .. +16
             float w[HB_CMAX];
 #pragma unroll
             for (int c = 0; c < HB_CMAX; c++) w[c] = c0 + c < C ? fcw[(size_t)(c0 + c) * H + k] : 0.f;
             const osk::rsrc_t rdh = osk::make_rsrc(dhT, (uint32_t)((size_t)B * H * 4));      // rows past B: dropped by the range check
 #pragma unroll 4
-            for (int r = half * 32; r < half * 32 + 32; r++) {
+            for (int r = qtr * 16; r < qtr * 16 + 16; r++) {
                 float s = 0.f;
 #pragma unroll
                 for (int c = 0; c < HB_CMAX; c += 4) {
@@ -135,23 +136,23 @@ __global__ __launch_bounds__(256) void head_backward_kernel(int B, int H, int C,
                 if (c0 == 0) osk::buf_store(rdh, off, 0u, s);
                 else __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(s, rdh, off, 0u, 0);
             }
-            // dfcw: classes c0 + half*16 .. +16 over all 64 rows
-            float acc[HB_CMAX / 2];
+            // dfcw: classes c0 + qtr*8 .. +8 over all 64 rows
+            float acc[HB_CMAX / 4];
 #pragma unroll
-            for (int c = 0; c < HB_CMAX / 2; c++) acc[c] = 0.f;
-            const int cb = c0 + half * (HB_CMAX / 2);
+            for (int c = 0; c < HB_CMAX / 4; c++) acc[c] = 0.f;
+            const int cb = c0 + qtr * (HB_CMAX / 4);
 #pragma unroll 4
             for (int r = 0; r < 64; r++) {
                 const float hv = hs[r * (H + 1) + k];
 #pragma unroll
-                for (int c = 0; c < HB_CMAX / 2; c += 4) {
+                for (int c = 0; c < HB_CMAX / 4; c += 4) {
                     const float4 d4 = *reinterpret_cast<const float4 *>(&dp[r * Cp + cb + c]);
                     acc[c] = fmaf(d4.x, hv, acc[c]); acc[c + 1] = fmaf(d4.y, hv, acc[c + 1]);
                     acc[c + 2] = fmaf(d4.z, hv, acc[c + 2]); acc[c + 3] = fmaf(d4.w, hv, acc[c + 3]);
                 }
             }
 #pragma unroll
-            for (int c = 0; c < HB_CMAX / 2; c++)
+            for (int c = 0; c < HB_CMAX / 4; c++)
                 if (cb + c < C) global_fadd(dfcw, (uint32_t)(C * H) * 4u, (uint32_t)((cb + c) * H + k), acc[c]);
         }
     }
@@ -1224,7 +1225,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     {
         const size_t lds = (size_t)(64 * ((C + 31) / 32 * 32) + 64 * (H + 1)) * sizeof(float);
         const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "head_backward_kernel");
-        hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(256), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
+        hipLaunchKernelGGL(head_backward_kernel, dim3((B + 63) / 64), dim3(512), lds, s, B, H, C, d.use_sigmoid, out, dout, hT,
                            fcw, dhT, grad_flat + fc_off, grad_flat + fc_off + (size_t)C * H);
         os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
