@@ -526,7 +526,7 @@ def bench_mpc(a, rk):
         out["roofline"] = {"kernel": kernels.get("mpc", {}).get("kernel", "mpc_solve_kernel"), "bound": "hbm", "achieved": ach,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "algorithmic_bytes_per_step": bps,
-                           "limiter": "latency: dependent LDS round trips per pivot, one QP per wavefront (not a roofline kernel)"}
+                           "limiter": "latency: a dependent float64 elimination per active-set iteration, one QP per wavefront (not a roofline kernel)"}
         out.update(qp_iterations_mean=float(it.mean()), qp_iterations_max=int(it.max()),
                    status_nonzero_trajectories=int((last["status"] != 0).sum()), kernels=kernels, **info)
         out["cpu_baseline"] = cpu_baseline_mpc(min(a.cpu_seconds, 20.0)) if (a.cpu_seconds > 0 and rk.world == 1) else None

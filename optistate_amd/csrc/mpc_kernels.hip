@@ -1005,7 +1005,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
     a.warm_u = nullptr; a.warm_state = nullptr; a.warm_contact = nullptr;
     osm::fill_args(ctx, a);
     hipStream_t s = (hipStream_t)stream;
-    const int slot = os_prof_begin(ctx, 4, s);
+    const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
     osm::launch_instances(a, 31u, s);       // all leg counts: a wavefront whose problem has another count exits at once
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
@@ -1082,7 +1082,7 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         // forces from the state BEFORE this step's predict (kalman_filter.py:141-152) ...
         m.ref = body_ref + o12; m.p = p + o12; m.contact = contact + o1; m.f_out = f_out + o12;
         m.iters = mpc_iters ? mpc_iters + o1 : nullptr;
-        const int slot = os_prof_begin(ctx, 4, s);
+        const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
         osm::launch_instances(m, flags_h[t], s);
         os_prof_end(ctx, slot, s);
         // ... then get_odom + set_measurements + predict_mpc covariance + next_state + update (kalman_filter.py:176-182)
