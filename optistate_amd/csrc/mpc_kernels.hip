@@ -170,28 +170,42 @@ __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams
     }
 }
 
-// sum_w form(g, G[w]) * vec[w]
-template <int NPS>
-__device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P, const double *g, const double (*G)[6], const double *vec)
+// sum_w form(g, G[w]) * vec[w].  form() depends on the column w only through its generator and, via (al, be), its horizon
+// step, so the sum over the NPS columns of a step factors: sum_w (zA . a_w + zB . b_w) vec[w] = zA . A_l + zB . B_l with the
+// per-step sums (A_l | B_l) = sum_{w in step l} G[w] vec[w].  Thirty lanes form the 5 x 6 sums (NPS loads in flight each),
+// then every lane needs five steps x six products instead of 15 NST columns x seven behind a rolled, LDS-latency-bound
+// loop (~10 k -> ~2 k cycles per multiplier check; the rounding differs from the column-by-column sum at the 1e-16 level).
+template <int NPS, typename WaveMem>
+__device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P, const double *g, const double (*G)[6], const double *vec,
+                                           WaveMem &M)
 {
+    double *S = &M.rows[0][0];                 // scratch: the row staging area is idle here (>= 96 doubles)
+    __builtin_amdgcn_wave_barrier();
+    if (L.lane < 30) {
+        const int l = L.lane / 6, r = L.lane % 6;
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NPS; j++) sum = fma(G[NPS * l + j][r], vec[NPS * l + j], sum);
+        S[L.lane] = sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // opaque copy of the step index (see form_row_block): keeps the five (al, be) sets out of the active-set loop's live range
+    int li = L.i;
+    asm volatile("" : "+v"(li));
     double acc = 0.0;
-#pragma clang loop unroll(disable)
+#pragma clang loop unroll(disable)              // unrolled, the thirty sums are all read up front: spills in the 168-register instances
     for (int l = 0; l < 5; l++) {
         double al, be;
-        alpha_beta(L.i, l, P.dt, al, be);
-        double zA[3], zB[3];
+        alpha_beta(li, l, P.dt, al, be);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
-            zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
-        }
-#pragma clang loop unroll(disable)
-        for (int j = 0; j < NPS; j++) {
-            const int w = NPS * l + j;
-            const double *gw = G[w];
-            acc += (zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5]) * vec[w];
+            const double zA = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
+            const double zB = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+            acc = fma(zA, S[6 * l + r], acc);
+            acc = fma(zB, S[6 * l + 3 + r], acc);
         }
     }
+    __builtin_amdgcn_wave_barrier();
     return acc;
 }
 
@@ -234,7 +248,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
 
     // ---- row of the reduced system ----
     double rhs = -(g[0] * cw[0] + g[1] * cw[1] + g[2] * cw[2] + g[3] * cv[0] + g[4] * cv[1] + g[5] * cv[2]);
-    if (any_u0) rhs -= form_dot<NPS>(L, P, g, M.gen0, M.vec);
+    if (any_u0) rhs -= form_dot<NPS>(L, P, g, M.gen0, M.vec, M);
     double A[NV + 1];
 #pragma unroll
     for (int l = 0; l < 5; l++) {
@@ -513,7 +527,7 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
 #pragma unroll
         for (int r = 0; r < 6; r++) g0[r] = M.gen0[L.v][r];
         const double q0 = g0[0] * cw[0] + g0[1] * cw[1] + g0[2] * cw[2] + g0[3] * cv[0] + g0[4] * cv[1] + g0[5] * cv[2];
-        const double grad = 2.0 * (form_dot<NPS>(L, P, g0, M.gen0, M.vec) + P.rw * u + q0);
+        const double grad = 2.0 * (form_dot<NPS>(L, P, g0, M.gen0, M.vec, M) + P.rw * u + q0);
         __builtin_amdgcn_wave_barrier();
         if (!L.pad) M.rowbuf[L.v] = grad;
         __builtin_amdgcn_wave_barrier();
