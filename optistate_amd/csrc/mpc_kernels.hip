@@ -159,7 +159,7 @@ __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams
         zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
         zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
     }
-#pragma clang loop unroll(disable)
+#pragma unroll 3
     for (int j = 0; j < NPS; j++) {
         const int w = NPS * l + j;
         const double *gw = M.gent[w];
