@@ -142,8 +142,11 @@ struct LaneCtx {
 
 // One horizon-step block (NPS columns, step l) of the reduced system's row for face generator g (6) at horizon step L.i
 // against the face generators M.gent[w], staged in M.rows[j][lane] (the caller then reads it into registers).
-// Deliberately a ROLLED loop over the columns: unrolled, hipcc hoists all generator loads to the top and spills them.
-template <int NPS, typename WaveMem>
+// UNR columns at a time: fully unrolled, hipcc hoists all generator loads to the top and spills them; rolled, every column is
+// one exposed LDS round trip.  Three where the instantiation has registers to spare (the stand-alone instances and the
+// one-wave-per-SIMD persistent kernel: B = 8 50.4 -> 49.3 us per step, B = 65,536 2.71e7 -> 2.90e7 steps/s), one in the
+// two-waves-per-SIMD persistent kernel, whose spills grow otherwise (B = 4096: 1.17e7 against 1.04e7 steps/s).
+template <int NPS, int UNR, typename WaveMem>
 __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams &P, const double *g, bool live, double diag_add,
                                                int l, WaveMem &M)
 {
@@ -159,7 +162,7 @@ __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams
         zA[r] = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
         zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
     }
-#pragma unroll 3
+#pragma clang loop unroll_count(UNR)
     for (int j = 0; j < NPS; j++) {
         const int w = NPS * l + j;
         const double *gw = M.gent[w];
@@ -210,7 +213,7 @@ __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P,
 }
 
 // Minimiser of the QP restricted to the face (sx, sy, sz of this lane's leg-step); returns this lane's component.
-template <int NST, typename WaveMem>
+template <int NST, int UNR, typename WaveMem>
 __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &P, WaveMem &M, int sx, int sy, int sz,
                                              const double *cw, const double *cv /* this lane's step */)
 {
@@ -252,7 +255,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     double A[NV + 1];
 #pragma unroll
     for (int l = 0; l < 5; l++) {
-        form_row_block<NPS>(L, P, g, live, P.rw * tt, l, M);
+        form_row_block<NPS, UNR>(L, P, g, live, P.rw * tt, l, M);
 #pragma unroll
         for (int j = 0; j < NPS; j++) A[NPS * l + j] = M.rows[j][L.lane & (WaveMem::LW - 1)];
         __builtin_amdgcn_sched_barrier(0);
@@ -326,7 +329,7 @@ struct QpLane {
 // One QP on the calling wavefront.  x, ref, p: the problem data (wave-uniform); warm: start from io (same contact word as the
 // call that produced it).  Returns in `val` (lanes 0..59) the optimal control in the reference's variable order (12 per horizon
 // step, leg-major, swing legs zero), in io the state for the next warm start.
-template <int NST>
+template <int NST, int UNR = 3>
 __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbits, const int (&legs)[4], const double (&x)[12],
                                                const double (&ref)[12], const double (&p)[12], int max_iter, bool warm,
                                                WaveMemT<15 * NST> &M, QpLane &io, float &val, int &iters_out, bool &converged_out)
@@ -434,7 +437,7 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
     constexpr double EPS = 1e-11, TOL = 1e-12;
     while (!done && iters < max_iter) {
         iters++;
-        const double us = solve_face<NST>(L, P, M, sx, sy, sz, cw, cv);
+        const double us = solve_face<NST, UNR>(L, P, M, sx, sy, sz, cw, cv);
         if (first) {
             // clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
             first = false;
@@ -910,10 +913,10 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
                 else if (nst == 3) mpc_solve_wave_call<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
                 else mpc_solve_wave_call<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
             } else {
-                if (nst == 1) mpc_solve_wave<1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
-                else if (nst == 2) mpc_solve_wave<2>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
-                else if (nst == 3) mpc_solve_wave<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
-                else mpc_solve_wave<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
+                if (nst == 1) mpc_solve_wave<1, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
+                else if (nst == 2) mpc_solve_wave<2, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
+                else if (nst == 3) mpc_solve_wave<3, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
+                else mpc_solve_wave<4, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
             }
             if (!conv) status |= 4;
         }
@@ -1037,9 +1040,10 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    // persistent kernel up to 32 trajectories per CU (it spends a whole wavefront on one trajectory's filter step: measured
-    // crossover with the launch sequence at B = 8192 on 256 CUs -- 1.0e7 steps/s either way; 1.9e7 against 1.2e7 at 32,768)
-    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 32 * ctx->cu_count)) {
+    // persistent kernel up to 24 trajectories per CU (it spends a whole wavefront on one trajectory's filter step and
+    // saturates at ~1.2e7 steps/s; measured on 256 CUs, persistent / launch sequence: B = 4096 1.16e7 / 0.83e7, 8192
+    // 1.23e7 / 1.31e7, 16,384 1.26e7 / 1.95e7, 32,768 1.29e7 / 2.53e7)
+    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 24 * ctx->cu_count)) {
         // one launch, one wavefront per trajectory for all T steps; nothing is read back, nothing synchronises
         osm::MpcRunArgs m;
         osk::KfRunArgs &a = m.kf;
