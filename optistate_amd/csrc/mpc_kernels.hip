@@ -147,8 +147,7 @@ struct LaneCtx {
 // one-wave-per-SIMD persistent kernel: B = 8 50.4 -> 49.3 us per step, B = 65,536 2.71e7 -> 2.90e7 steps/s), one in the
 // two-waves-per-SIMD persistent kernel, whose spills grow otherwise (B = 4096: 1.17e7 against 1.04e7 steps/s).
 template <int NPS, int UNR, typename WaveMem>
-__device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams &P, const double *g, bool live, double diag_add,
-                                               int l, WaveMem &M)
+__device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams &P, const double *g, int l, WaveMem &M)
 {
     // opaque copy of the step index: otherwise the (al, be) x weight products of all five blocks are hoisted out of the
     // active-set loop and spilled
@@ -166,9 +165,9 @@ __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams
     for (int j = 0; j < NPS; j++) {
         const int w = NPS * l + j;
         const double *gw = M.gent[w];
-        double val = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
-        if (w == L.v) val = live ? val + diag_add : 1.0;       // dead slots: identity row
-        else if (!live) val = 0.0;
+        // a dead slot's generator is zero, so its row is zero here; the diagonal (r + ..., or 1 for a dead slot) is added
+        // where the elimination reads the pivot -- not by a compare and two selects per column
+        const double val = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
         if (L.lane < WaveMem::LW) M.rows[j][L.lane] = val;
     }
 }
@@ -255,7 +254,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     double A[NV + 1];
 #pragma unroll
     for (int l = 0; l < 5; l++) {
-        form_row_block<NPS, UNR>(L, P, g, live, P.rw * tt, l, M);
+        form_row_block<NPS, UNR>(L, P, g, l, M);
 #pragma unroll
         for (int j = 0; j < NPS; j++) A[NPS * l + j] = M.rows[j][L.lane & (WaveMem::LW - 1)];
         __builtin_amdgcn_sched_barrier(0);
@@ -266,11 +265,12 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     // ---- forward elimination, one row per lane; the pivot row is broadcast straight from lane k's registers (k is a
     // compile-time lane index here: two v_readlane_b32 per entry into an SGPR pair that the FMA reads) -- no LDS round
     // trip and no barrier per pivot ----
+    const double dsel = live ? P.rw * tt : 1.0;            // this lane's diagonal term (see form_row_block)
     double dinv = 1.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         if (!((live_mask >> k) & 1ull)) continue;          // wave-uniform
-        const double inv = rcp64(readlane_f64(A[k], k));
+        const double inv = rcp64(readlane_f64(A[k] + dsel, k));
         if (L.lane == k) dinv = inv;
         const double f = (L.lane > k && L.lane < NV) ? A[k] * inv : 0.0;
 #pragma unroll
