@@ -68,6 +68,8 @@ struct WaveMemT {
     double vec[64];          // broadcast vector (solution / u / u0)
     double al[NLSMAX];
     int code[NLSMAX];
+    double ab[25][2];        // (al, be) of alpha_beta() for the horizon-step pairs (i, l) at [5 i + l]: one LDS read instead of ~25
+                             // integer / conversion instructions per block of the row formation
 };
 
 // 1/a to full double precision: v_rcp_f64 + two Newton steps (an IEEE division costs ~4x as many instructions)
@@ -153,8 +155,7 @@ __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams
     // active-set loop and spilled
     int li = L.i;
     asm volatile("" : "+v"(li));
-    double al, be;
-    alpha_beta(li, l, P.dt, al, be);
+    const double al = M.ab[5 * li + l][0], be = M.ab[5 * li + l][1];
     double zA[3], zB[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -197,8 +198,7 @@ __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P,
     double acc = 0.0;
 #pragma clang loop unroll(disable)              // unrolled, the thirty sums are all read up front: spills in the 168-register instances
     for (int l = 0; l < 5; l++) {
-        double al, be;
-        alpha_beta(li, l, P.dt, al, be);
+        const double al = M.ab[5 * li + l][0], be = M.ab[5 * li + l][1];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const double zA = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
@@ -421,6 +421,11 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
                 cv[r] += dt * P.w[9 + r] * ev[r] + dt * dt * lev * P.w[3 + r] * er[r];
             }
         }
+    }
+    if (L.lane < 25) {
+        double al, be;
+        alpha_beta(L.lane / 5, L.lane % 5, P.dt, al, be);
+        M.ab[L.lane][0] = al; M.ab[L.lane][1] = be;
     }
     __builtin_amdgcn_wave_barrier();
 
