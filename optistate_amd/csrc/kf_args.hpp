@@ -42,5 +42,44 @@ __device__ __forceinline__ void load_step(const KfRunArgs &a, int t, uint32_t vo
     in.contact = buf_load_u32_nt(rc, voff, 0);
 }
 
+// The same 43 dwords by LDS-DMA (buffer_load_dword ... lds: no destination registers): row i of the step lands in
+// lds[i * 64 + lane].  A one-wave workgroup can request step t + 1 at the TOP of step t and pick it up a whole step later
+// (read_step_lds after s_waitcnt vmcnt(0)); with register destinations hipcc sinks the prefetch to ~100 instructions ahead
+// of its first use (43 more live registers through the update otherwise) and a step then waits ~1.9 k of its 8.9 k cycles.
+__device__ __forceinline__ void lds_dma4(rsrc_t r, float *l, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 4, voff, soff, 0, 2);
+}
+constexpr int STEP_DWORDS = 43;
+__device__ __forceinline__ void load_step_dma(const KfRunArgs &a, int t, uint32_t voff, uint32_t rowB, float *lds /* [43][64] */)
+{
+    const size_t B = (size_t)a.B;
+    rsrc_t rp = make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t rf = make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t rd = make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t ri = make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB);
+    rsrc_t rc = make_rsrc(a.contact + (size_t)t * B, rowB);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lds_dma4(rp, lds + i * 64, voff, i * rowB);
+        lds_dma4(rf, lds + (12 + i) * 64, voff, i * rowB);
+        lds_dma4(rd, lds + (24 + i) * 64, voff, i * rowB);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) lds_dma4(ri, lds + (36 + i) * 64, voff, i * rowB);
+    lds_dma4(rc, lds + 42 * 64, voff, 0);
+}
+__device__ __forceinline__ void read_step_lds(const float *lds, int lane, StepIn &in)
+{
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        in.p[i] = lds[i * 64 + lane];
+        in.f[i] = lds[(12 + i) * 64 + lane];
+        in.dp[i] = lds[(24 + i) * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.imu[i] = lds[(36 + i) * 64 + lane];
+    in.contact = __builtin_bit_cast(uint32_t, lds[42 * 64 + lane]);
+}
 
 }  // namespace osk

@@ -135,9 +135,19 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
+    // step inputs: LDS-DMA double buffer, step t + 1 requested at the top of step t (see load_step_dma)
+    __shared__ float stage[2][STEP_DWORDS * 64];
+    const int lane = threadIdx.x & 63;
     StepIn in;
-    load_step(a, 0, voff, rowB, in);
+    load_step_dma(a, 0, voff, rowB, stage[0]);
     for (int t = 0; t < a.T; t++) {
+        // vmcnt(12): step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in issue order
+        // with the loads, and the twelve x_out stores of step t - 1 were issued a few instructions ago -- everything older
+        // than the last twelve operations includes every DMA load.
+        __builtin_amdgcn_s_waitcnt(0x0f7c);
+        __builtin_amdgcn_wave_barrier();
+        read_step_lds(stage[t & 1], lane, in);
+        load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, stage[(t + 1) & 1]);
         float z[NM], pw[12];
         kf_step_front_sym<QDIAG>(x, U, in, kc, z, pw);
         rsrc_t rfeat;
@@ -160,8 +170,6 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
 #pragma unroll
             for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw[i]);
         }
-        const int tn = (t + 1 < a.T) ? t + 1 : t;
-        load_step(a, tn, voff, rowB, in);           // prefetch underneath the update
         status |= update_sequential_sym(x, U, z, kc);        // non-finite states stay non-finite: checked once after the loop
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
