@@ -32,6 +32,8 @@ def torch_reference_grads(sd, dims, x, y):
                                       # whole 32-row tiles: the fused W_ih / W_hh gradient kernel (dw3_kernel<2,4>, <4,4>, <2,2>),
                                       # its batch_first layer-0 input, and T = 1 (falls back to the two-launch form)
                                       ((60, 128, 2, 24), 256, 6), ((60, 64, 2, 24), 96, 5), ((60, 128, 1, 24), 64, 1),
+                                      # the 188-wide first layer in whole tiles: the ten-accumulator form dw3_kernel<6,4,16>
+                                      ((188, 128, 2, 24), 64, 3),
                                       # large ragged batches: 64-row layer kernel with activation saves, many dW slices
                                       ((60, 128, 2, 24), 20013, 4), ((60, 64, 2, 24), 40001, 3)])
 def test_backward_matches_torch_autograd(dims, B, T):
@@ -102,3 +104,33 @@ def test_device_side_loss_and_fused_adam_trainer():
     # a second step must keep working (activations re-saved, weights re-packed)
     loss2 = tr.step(torch.as_tensor(g["inputs"]).cuda(), torch.as_tensor(g["labels"]).cuda())
     assert loss2.item() < loss.item() + 1e-3
+
+
+def test_loss_is_order_independent_and_backward_clears_its_gradient_vector():
+    """os_gru_loss: the last workgroup adds the per-workgroup partial sums in index order and WRITES the loss (no pre-zeroed
+    accumulator, no atomics on the result): repeated calls give bit-identical values, whatever the loss tensor held before.
+    os_gru_backward: the flat gradient vector is cleared by the launch itself (its first kernel), so stale contents do not leak."""
+    from optistate_amd import RNN, flatten_state_dict
+    from optistate_amd.engine import default_engine
+    torch.manual_seed(5)
+    I, H, L, C, B, T = 60, 64, 2, 24, 4096, 4
+    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda")
+    eng = default_engine(0)
+    eng.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    x = torch.rand(B, T, I, device="cuda"); y = torch.rand(B, C // 2, device="cuda")
+    out = eng.gru_forward_train(x)
+    losses = []
+    for _ in range(5):
+        loss, dout, tgt = eng.gru_loss(out, y, want_target=True)
+        losses.append(loss.cpu().numpy().view(np.uint32)[0])
+    assert len(set(losses)) == 1, losses
+    ref = torch.nn.functional.mse_loss(out.double(), tgt.double()).item()
+    assert abs(float(np.array(losses[0], dtype=np.uint32).view(np.float32)) - ref) < 1e-6
+    n = sum(p.numel() for p in m.parameters())
+    g_clean = torch.zeros(n, device="cuda")
+    eng.gru_backward(x, out, dout, grad_flat=g_clean)
+    g_dirty = torch.full((n,), 1.0e6, device="cuda")
+    out2 = eng.gru_forward_train(x)
+    eng.gru_backward(x, out2, dout, grad_flat=g_dirty)
+    scale = g_clean.abs().max().item()
+    assert scale > 0 and (g_clean - g_dirty).abs().max().item() < 1e-4 * scale      # float atomics: summation order only
