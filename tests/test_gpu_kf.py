@@ -266,3 +266,20 @@ def test_rotation_accuracy_for_large_angles(eng):
         od = orc.get_odom(p[i].astype(np.float64), dp[i].astype(np.float64), contact[i], imu[i].astype(np.float64))
         worst = max(worst, abs(zz[i, 3] - od[0]), np.abs(zz[i, 7:10] - od[1:]).max())
     assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (65, 1), (65, 2), (130, 3), (200, 7)])
+def test_sym_lane_kernel_short_and_ragged(eng, B, T):
+    """kf_run_sym_kernel takes its step inputs through an LDS-DMA double buffer requested one step ahead: the first step,
+    T = 1 (nothing to prefetch), odd / even buffer parity and partly filled wavefronts against the float64 C oracle."""
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    from oracle import c_oracle as orc
+    d = synth_numpy(B, T, seed=11 + B + T)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)),
+                           Q_FITTED, R_FITTED, aux=False)
+    r = run(eng, dict(d), Q_FITTED, R_FITTED, B, sequential=True, symmetric=True, lane_per_trajectory=True)
+    xo = eng.unpack(r["x_out"]).cpu().numpy()
+    assert np.abs(xo - ref["x"]).max() < STATE_TOL
+    Pf = r["P_final"].cpu().numpy().T.reshape(B, 12, 12)
+    assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
+    assert int(r["status"].abs().sum()) == 0
