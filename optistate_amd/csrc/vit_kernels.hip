@@ -447,22 +447,30 @@ struct MlpArgs {
     float *QKVnext;                     // normalised tile straight into QKVnext [M][384] instead of Ynext (no qkv launch either)
     const float *W1p, *b1;      // fc1 packed (vit_pack_w_kernel: N = Mh, K = 128), bias [Mh]
     const float *W2p, *b2;      // fc2 packed (N = 128, K = Mh), bias [128]
+    // Workgroups below nfull own 128-row tiles; the rest own `small_rows`-row tiles (32 or 64) behind them.  1024 frames are
+    // 1576 full tiles = 6.16 rounds over 256 CUs, i.e. a seventh round with 40 CUs busy; as 160 quarter tiles that round costs
+    // about a third of a full one (a wave skips the row blocks its tile does not have).
+    int nfull, small_rows;
 };
 
-__global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
+// NRB = 32-row blocks this wave owns in its tile (2 in a 128-row tile; 1 or 0 in the short tiles of the last round): a template
+// parameter, not a run-time bound -- with `if (rb < nrb)` around the MFMAs of the unrolled loops the kernel ran at half speed
+// (a scalar branch in front of every matrix instruction).  Every instantiation executes the same sequence of barriers.
+template <int NRB>
+__device__ __forceinline__ void vit_mlp_tile(const MlpArgs &a, const size_t row0, const int nrows)
 {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) float msm[];
     float *As = msm, *Hs = msm + GM_BM * D;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
     const int chunk = wave & 3, rbp = wave >> 2;
-    const size_t row0 = (size_t)blockIdx.x * GM_BM;
     {
         // input tile: piece p = threadIdx.x + 512 i -> LDS row (threadIdx.x >> 5) + 16 i, slot p % 32 receives source slot
         // (p % 32) ^ (row & 7) (the row's low three bits do not change with i)
         const int r_lo = threadIdx.x >> 5, slot = (threadIdx.x & 31) ^ (r_lo & 7);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
+            if (16 * i >= nrows) break;                                   // wave-uniform
             size_t row = row0 + r_lo + 16 * i;
             if (row >= a.M) row = a.M - 1;
             vit_lds_dma16(a.Y + row * D + 4 * slot, &As[(wave * 64 + 512 * i) * 4]);
@@ -489,12 +497,18 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
     f32x16v xres[2];
     if (a.Wpp) {
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++)
+        for (int rb = 0; rb < 2; rb++) {
+            if (rb >= NRB) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) xres[rb][e] = 0.f;
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(D * 4));
                 xres[rb][e] = osk::buf_load(rcx, vox, so);
             }
+        }
     }
     if (a.lnw && threadIdx.x < 64) {                                      // LayerNorm parameters -> the (still unused) hidden tile
         const int c4 = 4 * (threadIdx.x & 31);
@@ -515,30 +529,32 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
             for (int e = 0; e < 16; e++) xres[rb][e] += bv;
 #pragma unroll
         for (int d = 0; d < D8; d++) {
-            wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+            if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, d, rb);
+            for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG(As, d, rb);
         }
 #pragma unroll
         for (int q = 0; q < D / 2; q++) {
             const int d = q & (D8 - 1);
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) xres[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], xres[rb], 0, 0, 0);
+            for (int rb = 0; rb < 2; rb++) if (rb < NRB) xres[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], xres[rb], 0, 0, 0);
             if (q + D8 < D / 2) {
-                wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
+                if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, q + D8, rb);
+                for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG(As, q + D8, rb);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                                  // everyone is done reading the attention tile
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++)
+        for (int rb = 0; rb < 2; rb++) {
+            if (rb >= NRB) continue;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 As[r * D + hoff[e & 3]] = xres[rb][e];
             }
+        }
         __syncthreads();
     }
     if (a.lnw) {
@@ -586,19 +602,19 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
             const osk::rsrc_t rw = osk::make_rsrc(a.W1p + (size_t)(s * 4 + chunk) * (D / 2) * 64, (uint32_t)(D / 2) * 256u);
 #pragma unroll
             for (int d = 0; d < D8; d++) {
-                wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+                if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, d, rb);
+                for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG(As, d, rb);
             }
 #pragma unroll
             for (int q = 0; q < D / 2; q++) {
                 const int d = q & (D8 - 1);
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc1[rb], 0, 0, 0);
+                for (int rb = 0; rb < 2; rb++) if (rb < NRB) acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc1[rb], 0, 0, 0);
                 if (q + D8 < D / 2) {
-                    wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
+                    if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(As, q + D8, rb);
+                    for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG(As, q + D8, rb);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -606,7 +622,8 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
         {
             const float bv = a.b1[s * 128 + chunk * 32 + li];
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++)
+            for (int rb = 0; rb < 2; rb++) {
+                if (rb >= NRB) continue;
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -614,6 +631,7 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
                     Hs[r * D + hoff[e & 3]] = g.x;
                     Hs[(r + 1) * D + hoff[(e + 1) & 3]] = g.y;
                 }
+            }
         }
         __syncthreads();                                                  // the hidden slice is complete
         // ---- fc2 K-slice s: output columns chunk*32 .. +31 ----
@@ -621,19 +639,19 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
             const osk::rsrc_t rw = osk::make_rsrc(a.W2p + ((size_t)chunk * (a.Mh / 2) + (size_t)s * (D / 2)) * 64, (uint32_t)(D / 2) * 256u);
 #pragma unroll
             for (int d = 0; d < D8; d++) {
-                wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+                if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(Hs, d, rb);
+                for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG(Hs, d, rb);
             }
 #pragma unroll
             for (int q = 0; q < D / 2; q++) {
                 const int d = q & (D8 - 1);
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) acc2[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc2[rb], 0, 0, 0);
+                for (int rb = 0; rb < 2; rb++) if (rb < NRB) acc2[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], acc2[rb], 0, 0, 0);
                 if (q + D8 < D / 2) {
-                    wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
+                    if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)(q + D8) * 256u, 0u);
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG(Hs, q + D8, rb);
+                    for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG(Hs, q + D8, rb);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -645,24 +663,28 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
     // x += acc + b2 (with the projection: x = x_new + acc + b2, no read): rows past M fall outside the descriptor's range
     const float bv = a.b2[chunk * 32 + li];
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++)
+    for (int rb = 0; rb < 2; rb++) {
+        if (rb >= NRB) continue;                 // rows of another tile: never stored from here
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(D * 4));
             acc2[rb][e] += bv + (a.Wpp ? xres[rb][e] : osk::buf_load(rcx, vox, so));
             osk::buf_store(rcx, vox, so, acc2[rb][e]);
         }
+    }
     if (a.Ynext) {
         // the next block's LayerNorm on the finished rows: tile -> LDS (both tiles are free after the barrier), four threads per
         // row as above, normalised rows straight to Ynext
         __syncthreads();
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++)
+        for (int rb = 0; rb < 2; rb++) {
+            if (rb >= NRB) continue;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int r = rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 As[r * D + hoff[e & 3]] = acc2[rb][e];
             }
+        }
         if (threadIdx.x < 64) {
             const int c4 = 4 * (threadIdx.x & 31);
             *reinterpret_cast<float4 *>(&Hs[(threadIdx.x < 32 ? 0 : D) + c4]) =
@@ -685,7 +707,7 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
         }
         q += dpp_mov<0xB1>(q); q += dpp_mov<0x4E>(q);
         const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
-        if (a.Wqp || row0 + row < a.M) {
+        if (a.Wqp || (row < nrows && row0 + row < a.M)) {
             float *yp = a.Wqp ? As + row * D + qd * 32 : a.Ynext + (row0 + row) * D;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -714,33 +736,49 @@ __global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
                     for (int e = 0; e < 16; e++) aq[rb][e] = bq;
 #pragma unroll
                 for (int d = 0; d < D8; d++) {
-                    wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
+                    if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)d * 256u, 0u);
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG2(As, d, rb);
+                    for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG2(As, d, rb);
                 }
 #pragma unroll
                 for (int qq = 0; qq < D / 2; qq++) {
                     const int d = qq & (D8 - 1);
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++) aq[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], aq[rb], 0, 0, 0);
+                    for (int rb = 0; rb < 2; rb++) if (rb < NRB) aq[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(abf[d][rb], wbf[d], aq[rb], 0, 0, 0);
                     if (qq + D8 < D / 2) {
-                        wbf[d] = osk::buf_load(rw, wl + (uint32_t)(qq + D8) * 256u, 0u);
+                        if (NRB > 0) wbf[d] = osk::buf_load(rw, wl + (uint32_t)(qq + D8) * 256u, 0u);
 #pragma unroll
-                        for (int rb = 0; rb < 2; rb++) abf[d][rb] = MLP_AFRAG2(As, qq + D8, rb);
+                        for (int rb = 0; rb < 2; rb++) if (rb < NRB) abf[d][rb] = MLP_AFRAG2(As, qq + D8, rb);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const uint32_t voq = (uint32_t)((4 * lh) * 3 * D + c * 32 + li) * 4u;
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++)
+                for (int rb = 0; rb < 2; rb++) {
+                    if (rb >= NRB) continue;
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(row0 + rbp * 64 + rb * 32 + (e & 3) + 8 * (e >> 2)) * (uint32_t)(3 * D * 4));
                         osk::buf_store(rq, voq, so, aq[rb][e]);
                     }
+                }
             }
         }
     }
+}
+
+
+__global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
+{
+    const int rbp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >> 2;
+    const bool fullt = (int)blockIdx.x < a.nfull;
+    const size_t row0 = fullt ? (size_t)blockIdx.x * GM_BM : (size_t)a.nfull * GM_BM + (size_t)((int)blockIdx.x - a.nfull) * a.small_rows;
+    const int nrows = fullt ? GM_BM : a.small_rows;                     // rows of this tile (rows past M are masked as before)
+    const int left = nrows - rbp * 64;                                  // rows of the tile in this wave's 64-row half
+    if (left >= 64) vit_mlp_tile<2>(a, row0, nrows);
+    else if (left > 32) vit_mlp_tile<2>(a, row0, nrows);
+    else if (left > 0) vit_mlp_tile<1>(a, row0, nrows);
+    else vit_mlp_tile<0>(a, row0, nrows);
 }
 
 // row 0 of every frame: cls token + pos[0]   (transformer_model.py:119-123)
@@ -961,7 +999,20 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
                 v->mlp_attr_set = true;
             }
             slot = os_prof_begin(ctx, OS_PHASE_VIT_GEMM, s, "vit_mlp_kernel");
-            hipLaunchKernelGGL(vit_mlp_kernel, dim3((unsigned)((M + GM_BM - 1) / GM_BM)), dim3(512), (size_t)2 * GM_BM * 128 * sizeof(float), s, ma);
+            // tiles: whole rounds of 128-row tiles over the CUs, then the remainder as 32- or 64-row tiles when those fit one more
+            // (short) round -- otherwise the last round runs a full tile's time on a fraction of the chip
+            const size_t ntiles = (M + GM_BM - 1) / GM_BM;
+            const size_t cu = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+            size_t nfull = ntiles, nsmall = 0;
+            int small_rows = GM_BM;
+            const size_t rem = ntiles % cu;
+            if (rem != 0 && ctx->tune_vit_tail_split) {
+                const size_t rows_rem = M - (ntiles - rem) * GM_BM;
+                small_rows = (rows_rem + 31) / 32 <= cu ? 32 : ((rows_rem + 63) / 64 <= cu ? 64 : GM_BM);
+                if (small_rows != GM_BM) { nfull = ntiles - rem; nsmall = (rows_rem + small_rows - 1) / small_rows; }
+            }
+            ma.nfull = (int)nfull; ma.small_rows = small_rows;
+            hipLaunchKernelGGL(vit_mlp_kernel, dim3((unsigned)(nfull + nsmall)), dim3(512), (size_t)2 * GM_BM * 128 * sizeof(float), s, ma);
             os_prof_end(ctx, slot, s);
             wp += (size_t)2 * Mh * D;
         } else {
