@@ -245,6 +245,168 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_kernel(int L, int D
     }
 }
 
+__device__ __forceinline__ void vit_lds_dma16(const float *g, float *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+// barrier that waits for this wave's LDS traffic only (a __syncthreads() also waits for the output stores just issued)
+__device__ __forceinline__ void vit_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// The same attention as a PERSISTENT workgroup: K and V of the NEXT (image, head) arrive by LDS-DMA (global_load_lds, no staging
+// registers) into the other half of a double buffer while the current one is being consumed.  In attention_mfma_kernel the
+// staging of a head's K / V was 7.2 k of a workgroup's ~60 k cycles with everything else idle (one workgroup per CU: 256
+// registers per lane); prefetching into registers instead spilled (131).  The DMA writes whole 16-byte pieces at consecutive
+// LDS addresses, so K's rows are NINE pieces long with the ninth lane of every nine switched off: a pitch of 36 floats makes
+// the fragment read of 32 keys at one column 2-way conflicted (32 floats: 32-way; an XOR swizzle: 4-way and eight more
+// address registers).  V is read along its rows: pitch 32.
+// K / V of one (image, head) -> dst by LDS-DMA (a real call: inlined, its address arithmetic shares the register allocation of
+// the attention body, which has none to spare)
+template <int NW, int KP>
+__device__ __attribute__((noinline)) void attention_stage_dma(const float *QKV, int L, int D, int heads, int item, float *dst)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int npk = L * (KP / 4), npieces = npk + L * 8;
+    const int n = item / heads, h = item % heads;
+    const float *base = QKV + (size_t)n * L * 3 * D + h * ATT_HD;
+    for (int g0 = wave * 64; g0 < npieces; g0 += NW * 64) {               // wave-uniform: one DMA instruction = 64 consecutive piece slots
+        const int g = g0 + lane;
+        if (g < npieces) {
+            const bool isv = g >= npk;
+            const int l = isv ? (g - npk) >> 3 : g / (KP / 4), pc = isv ? (g - npk) & 7 : g % (KP / 4);
+            const float *src = base + (size_t)l * 3 * D + (isv ? 2 * D : D) + 4 * pc;
+            if (pc < 8) vit_lds_dma16(src, dst + (size_t)g0 * 4);          // the ninth slot of a K row is padding
+        }
+    }
+}
+
+template <int NT, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 1) void attention_mfma_dma_kernel(int L, int D, int heads, int nitems, const float *QKV, float *O)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];            // 2 x (K [L][36] | V [L][32])
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
+    constexpr int KP = 36;                                                // K row pitch in floats
+    const int bufw = L * (KP + 32);                                       // floats per buffer
+    int item = blockIdx.x;
+    if (item < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item, sm);
+    bool stored = false;                                                  // this wave issued output stores in the previous item
+    for (int it = 0; item < nitems; item += gridDim.x, it++) {
+        // my DMA pieces of this item have landed: they are older than the (at most four) output stores of the previous item,
+        // which need not be waited for (loads and stores retire in issue order)
+        if (stored) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f70);
+        vit_lds_barrier();
+        float *Kb = sm + (it & 1) * bufw, *Vb = Kb + L * KP;
+        if (item + (int)gridDim.x < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item + gridDim.x, sm + ((it + 1) & 1) * bufw);
+        const int n = item / heads, h = item % heads;
+        const float *base = QKV + (size_t)n * L * 3 * D;
+        stored = false;
+        // opaque per-iteration copies: everything below that depends only on (L, lane) -- 112 clamped V row addresses, the key
+        // masks -- is invariant across the item loop, and hoisted out of it it stays live across the whole body (60 spills)
+        int L_ = L, li_ = li, lh_ = lh;
+        asm volatile("" : "+s"(L_));
+        asm volatile("" : "+v"(li_), "+v"(lh_));
+        // 1/sqrt(d) and log2(e) folded into Q: the softmax numerators are exp2(S' - max'), one v_exp_f32 per score and no multiply
+        const float scale = rsqrtf((float)ATT_HD) * 1.44269504088896341f;
+        for (int qt = wave; qt < NT; qt += NW) {
+            const int r0 = 32 * qt;
+            // Q tile as A fragments: lane -> (row r0 + li_, dim 2q + lh_)
+            const int qrow = r0 + li_ < L_ ? r0 + li_ : L_ - 1;
+            float qa[ATT_HD / 2];
+#pragma unroll
+            for (int q = 0; q < ATT_HD / 2; q++)
+                qa[q] = base[(size_t)qrow * 3 * D + h * ATT_HD + 2 * q + lh_] * scale;
+            // TRANSPOSED score tiles S^T = K Q^T (A = K rows, B = Q^T): in the C layout a lane then owns ONE query (column li_) and
+            // its registers run over the keys, (e & 3) + 8 (e >> 2) + 4 lh_ of each 32-key tile.  The softmax statistics of a query
+            // are in-lane reductions over 7 x 16 registers plus one exchange between the two wave halves (v_permlane32_swap) --
+            // not sixteen cross-lane reductions per tile -- and P^T never leaves the registers: O^T = V^T P^T takes it as its B
+            // operand directly, with the reduction's k-pairs renumbered to the C layout's key order (pair e = keys a_e, a_e + 4
+            // with a_e = (e & 3) + 8 (e >> 2); a sum does not care about the order) and the V^T fragments fetched in that order.
+            // (The P tile used to go through LDS, 16 writes + 16 reads per key tile, and the row statistics were ~290 VALU
+            // instructions per query tile on the pipe the MFMAs need.)  The 16 K fragments of tile jt+1 are requested from LDS
+            // before the 16 MFMAs of tile jt issue.
+            f32x16v S[NT];
+            float kb[2][ATT_HD / 2];
+            {
+                const int key = li_ < L_ ? li_ : L_ - 1;
+#pragma unroll
+                for (int q = 0; q < ATT_HD / 2; q++) kb[0][q] = Kb[key * KP + 2 * q + lh_];
+            }
+#pragma unroll
+            for (int jt = 0; jt < NT; jt++) {
+                if (jt + 1 < NT) {
+                    const int key = 32 * (jt + 1) + li_ < L_ ? 32 * (jt + 1) + li_ : L_ - 1;
+#pragma unroll
+                    for (int q = 0; q < ATT_HD / 2; q++) kb[(jt + 1) & 1][q] = Kb[key * KP + 2 * q + lh_];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++) S[jt][e] = 0.f;
+#pragma unroll
+                for (int q = 0; q < ATT_HD / 2; q++) S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[jt & 1][q], qa[q], S[jt], 0, 0, 0);
+                if (32 * jt + 32 > L_) {                      // tile with keys past L_: mask them (register index = key)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        if (32 * jt + (e & 3) + 8 * (e >> 2) + 4 * lh_ >= L_) S[jt][e] = -3.0e38f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // softmax statistics of this lane's query: in-lane over the keys it holds, then the other wave half's share
+            float m = S[0][0];
+#pragma unroll
+            for (int jt = 0; jt < NT; jt++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) m = fmaxf(m, S[jt][e]);
+            {
+                float ma = m, mb = m;
+                halves_swap32(ma, mb);
+                m = fmaxf(ma, mb);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; jt++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const float pv = __builtin_amdgcn_exp2f(S[jt][e] - m); S[jt][e] = pv; den += pv; }
+            {
+                float da = den, db = den;
+                halves_swap32(da, db);
+                den = da + db;
+            }
+            // O^T = V^T P^T: A fragment (dim li_, keys a_e + 4 lh_ of the tile) from LDS, B fragment = S[jt][e]
+            f32x16v acc;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            float vbf[2][16];
+            {
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const int key = (e & 3) + 8 * (e >> 2) + 4 * lh_; vbf[0][e] = Vb[(key < L_ ? key : L_ - 1) * 32 + li_]; }
+            }
+#pragma unroll
+            for (int jt = 0; jt < NT; jt++) {
+                if (jt + 1 < NT) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int key = 32 * (jt + 1) + (e & 3) + 8 * (e >> 2) + 4 * lh_;                            // P is 0 past L_
+                        vbf[(jt + 1) & 1][e] = Vb[(key < L_ ? key : L_ - 1) * 32 + li_];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vbf[jt & 1][e], S[jt][e], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // lane = query r0 + li_, registers = head dims (e & 3) + 8 (e >> 2) + 4 lh_: four 16-byte stores per lane
+            stored = true;
+            if (r0 + li_ < L_) {
+                const float inv = 1.0f / den;
+                float *op = O + ((size_t)n * L_ + r0 + li_) * D + h * ATT_HD + 4 * lh_;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *reinterpret_cast<float4 *>(op + 8 * g) = make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv);
+            }
+        }
+
+    }
+}
+
 // ---- vit_gemm_kernel: C[M x N] = A[M x K] . W[N x K]^T on v_mfma_f32_32x32x2_f32 (exact fp32) with fused ends -----------------
 // Workgroup = 4 waves = a 128-row x 128-column tile; wave w owns column chunk w (32 columns) for all four 32-row blocks
 // (64 accumulator registers).  A is staged 128 columns at a time (K = 128: once; 256 / 512: two / four chunks, accumulators
@@ -271,7 +433,6 @@ struct GemmArgs {
 
 constexpr int GM_BM = 128, GM_KC = 128;
 
-__device__ __forceinline__ void vit_lds_dma16(const float *g, float *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 
 __global__ void vit_pack_w_kernel(int N, int K, const float *W, float *dst)
 {
@@ -956,13 +1117,19 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
         wp += (size_t)3 * D * D;
         const size_t alds = (size_t)2 * L * (hd + 1) * sizeof(float);
         const int ntl = (L + 31) / 32;
-        slot = os_prof_begin(ctx, OS_PHASE_VIT_ATTN, s, (hd == 32 && ntl == 7) ? "attention_mfma_kernel<7>" : "attention_kernel");
+        slot = os_prof_begin(ctx, OS_PHASE_VIT_ATTN, s, (hd == 32 && ntl == 7) ? (ctx->tune_vit_att_dma ? "attention_mfma_dma_kernel<7>" : "attention_mfma_kernel<7>") : "attention_kernel");
         if (hd == 32 && ntl == 7) {              // the reference's shape: 197 tokens, head_dim 32 -> matrix cores
             const size_t mlds = (size_t)2 * L * 33 * sizeof(float);
             if (!v->att_attr_set) {
                 OS_HIP(ctx, hipFuncSetAttribute((const void *)attention_mfma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)attention_mfma_dma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 v->att_attr_set = true;
             }
+            const int nitems = N * d.heads, cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+            if (ctx->tune_vit_att_dma) {          // persistent workgroups, K / V of the next head by LDS-DMA underneath the current one
+                const size_t dlds = (size_t)2 * L * (36 + 32) * sizeof(float);
+                hipLaunchKernelGGL(attention_mfma_dma_kernel<7>, dim3(nitems < cus ? nitems : cus), dim3(512), dlds, s, L, D, d.heads, nitems, big, Y);
+            } else
             hipLaunchKernelGGL(attention_mfma_kernel<7>, dim3(N * d.heads), dim3(512), mlds, s, L, D, d.heads, big, qkvb, Y);
         } else if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
         else hipLaunchKernelGGL(attention_kernel<64>, dim3(N * d.heads), dim3(256), alds, s, L, D, d.heads, big, qkvb, Y);
