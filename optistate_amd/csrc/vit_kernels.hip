@@ -291,6 +291,19 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_dma_kernel(int L, i
     int item = blockIdx.x;
     if (item < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item, sm);
     bool stored = false;                                                  // this wave issued output stores in the previous item
+    // This wave's Q tile (NT <= NW: one tile per wave and head), RAW: the fragments of the NEXT head are requested right after
+    // the score MFMAs of the current one (their registers are dead from there on) and scaled when that head starts -- the
+    // sixteen strided loads used to sit exposed at the top of every tile (2-5 k of its ~50 k cycles).
+    static_assert(NT <= NW, "one query tile per wave");
+    float qa[ATT_HD / 2];
+    auto loadq = [&](int it_) {
+        const int n_ = it_ / heads, h_ = it_ % heads;
+        const int qrow = 32 * wave + li < L ? 32 * wave + li : L - 1;
+        const float *qp = QKV + (size_t)n_ * L * 3 * D + (size_t)qrow * 3 * D + h_ * ATT_HD + lh;
+#pragma unroll
+        for (int q = 0; q < ATT_HD / 2; q++) qa[q] = qp[2 * q];
+    };
+    if (item < nitems && wave < NT) loadq(item);
     for (int it = 0; item < nitems; item += gridDim.x, it++) {
         // my DMA pieces of this item have landed: they are older than the (at most four) output stores of the previous item,
         // which need not be waited for (loads and stores retire in issue order)
@@ -310,12 +323,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_dma_kernel(int L, i
         const float scale = rsqrtf((float)ATT_HD) * 1.44269504088896341f;
         for (int qt = wave; qt < NT; qt += NW) {
             const int r0 = 32 * qt;
-            // Q tile as A fragments: lane -> (row r0 + li_, dim 2q + lh_)
-            const int qrow = r0 + li_ < L_ ? r0 + li_ : L_ - 1;
-            float qa[ATT_HD / 2];
+            // Q tile as A fragments: lane -> (row r0 + li_, dim 2q + lh_), prefetched raw (see loadq)
 #pragma unroll
-            for (int q = 0; q < ATT_HD / 2; q++)
-                qa[q] = base[(size_t)qrow * 3 * D + h * ATT_HD + 2 * q + lh_] * scale;
+            for (int q = 0; q < ATT_HD / 2; q++) qa[q] *= scale;
             // TRANSPOSED score tiles S^T = K Q^T (A = K rows, B = Q^T): in the C layout a lane then owns ONE query (column li_) and
             // its registers run over the keys, (e & 3) + 8 (e >> 2) + 4 lh_ of each 32-key tile.  The softmax statistics of a query
             // are in-lane reductions over 7 x 16 registers plus one exchange between the two wave halves (v_permlane32_swap) --
@@ -361,6 +371,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_dma_kernel(int L, i
                 halves_swap32(ma, mb);
                 m = fmaxf(ma, mb);
             }
+            // every score MFMA has delivered (the maximum consumed their results): the Q registers are free for the next head
+            __builtin_amdgcn_sched_barrier(0);
+            if (item + (int)gridDim.x < nitems) loadq(item + gridDim.x);
+            __builtin_amdgcn_sched_barrier(0);
             float den = 0.f;
 #pragma unroll
             for (int jt = 0; jt < NT; jt++)
