@@ -479,7 +479,7 @@ def bench_full(a, rk):
             dk = kernels[dom]
             fl_launch = phase_flops[dom] / dk["launches_per_step"]
             ach = fl_launch / (dk["ms_per_launch"] * 1e-3) / 1e12
-            kname = dk["kernel"] if dom != "vit_gemm" else "ViT projections: vit_gemm_kernel<...> (patch, first qkv) + vit_mlp_kernel (proj + LN + fc1 + GELU + fc2 + next LN + next qkv)"
+            kname = dk["kernel"] if dom != "vit_gemm" else "ViT projections: vit_gemm_kernel<...> (patch, first qkv) + vit_mlp_kernel[_bm64] (proj + LN + fc1 + GELU + fc2 + next LN + next qkv)"
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": dk["ms_per_launch"],
                                "algorithmic_flops_per_launch": fl_launch, "phase": dom,

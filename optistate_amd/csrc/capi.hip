@@ -48,6 +48,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_DW_FUSED"); c->tune_dw_fused = e ? atoi(e) : 1;
         e = getenv("OS_VIT_TAIL_SPLIT"); c->tune_vit_tail_split = e ? atoi(e) : 1;
         e = getenv("OS_VIT_ATT_DMA"); c->tune_vit_att_dma = e ? atoi(e) : 1;
+        e = getenv("OS_VIT_MLP_BM"); c->tune_vit_mlp_bm = e ? atoi(e) : 64;
         e = getenv("OS_SWEEP_WR"); c->tune_sweep_wr = e ? atoi(e) : 32;
         e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
         e = getenv("OS_FUSED_V1"); c->tune_fused_v1 = e ? atoi(e) : 0;

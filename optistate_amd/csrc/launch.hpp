@@ -24,6 +24,7 @@ struct os_ctx {
     int tune_vit_mlp_fused;              // ViT block tail: 2 = projection + LayerNorm + MLP in one kernel (default), 1 = LayerNorm + MLP in one kernel, 0 = separate launches
     int tune_dw_rps;                     // rows per dW slice
     int tune_vit_att_dma;                // 1: persistent attention workgroups with LDS-DMA K / V double buffering (OS_VIT_ATT_DMA=0: one workgroup per head)
+    int tune_vit_mlp_bm;                 // rows per vit_mlp tile: 128 (one eight-wave workgroup per CU) or 64 (two four-wave workgroups) (OS_VIT_MLP_BM)
     int tune_vit_tail_split;             // 1: the last partial round of vit_mlp_kernel tiles runs as 32- / 64-row tiles (OS_VIT_TAIL_SPLIT=0: full tiles)
     int tune_dw_fused;                   // 1: W_ih and W_hh gradients of a layer in one launch (dw3_kernel) when eligible, 0: two launches,
                                          // 2: one launch only for inputs of at most 128 columns (the round-2d state)

@@ -631,12 +631,15 @@ struct MlpArgs {
 // NRB = 32-row blocks this wave owns in its tile (2 in a 128-row tile; 1 or 0 in the short tiles of the last round): a template
 // parameter, not a run-time bound -- with `if (rb < nrb)` around the MFMAs of the unrolled loops the kernel ran at half speed
 // (a scalar branch in front of every matrix instruction).  Every instantiation executes the same sequence of barriers.
-template <int NRB>
+// BM = rows per tile = 4 x the workgroup's threads: 128 (eight waves, one workgroup per CU) or 64 (four waves, two workgroups per
+// CU, whose staging, LayerNorm and GELU phases then overlap each other's MFMA phases).
+template <int NRB, int BM>
 __device__ __forceinline__ void vit_mlp_tile(const MlpArgs &a, const size_t row0, const int nrows)
 {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) float msm[];
-    float *As = msm, *Hs = msm + GM_BM * D;
+    constexpr int NTHR = BM * 4;
+    float *As = msm, *Hs = msm + BM * D;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
     const int chunk = wave & 3, rbp = wave >> 2;
     {
@@ -645,10 +648,10 @@ __device__ __forceinline__ void vit_mlp_tile(const MlpArgs &a, const size_t row0
         const int r_lo = threadIdx.x >> 5, slot = (threadIdx.x & 31) ^ (r_lo & 7);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            if (16 * i >= nrows) break;                                   // wave-uniform
-            size_t row = row0 + r_lo + 16 * i;
+            if ((NTHR / 32) * i >= nrows) break;                          // wave-uniform
+            size_t row = row0 + r_lo + (NTHR / 32) * i;
             if (row >= a.M) row = a.M - 1;
-            vit_lds_dma16(a.Y + row * D + 4 * slot, &As[(wave * 64 + 512 * i) * 4]);
+            vit_lds_dma16(a.Y + row * D + 4 * slot, &As[(wave * 64 + NTHR * i) * 4]);
         }
     }
     f32x16v acc2[2];
@@ -943,18 +946,20 @@ __device__ __forceinline__ void vit_mlp_tile(const MlpArgs &a, const size_t row0
 }
 
 
-__global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a)
+template <int BM>
+__device__ __forceinline__ void vit_mlp_dispatch(const MlpArgs &a)
 {
     const int rbp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >> 2;
     const bool fullt = (int)blockIdx.x < a.nfull;
-    const size_t row0 = fullt ? (size_t)blockIdx.x * GM_BM : (size_t)a.nfull * GM_BM + (size_t)((int)blockIdx.x - a.nfull) * a.small_rows;
-    const int nrows = fullt ? GM_BM : a.small_rows;                     // rows of this tile (rows past M are masked as before)
+    const size_t row0 = fullt ? (size_t)blockIdx.x * BM : (size_t)a.nfull * BM + (size_t)((int)blockIdx.x - a.nfull) * a.small_rows;
+    const int nrows = fullt ? BM : a.small_rows;                        // rows of this tile (rows past M are masked as before)
     const int left = nrows - rbp * 64;                                  // rows of the tile in this wave's 64-row half
-    if (left >= 64) vit_mlp_tile<2>(a, row0, nrows);
-    else if (left > 32) vit_mlp_tile<2>(a, row0, nrows);
-    else if (left > 0) vit_mlp_tile<1>(a, row0, nrows);
-    else vit_mlp_tile<0>(a, row0, nrows);
+    if (left > 32) vit_mlp_tile<2, BM>(a, row0, nrows);
+    else if (left > 0) vit_mlp_tile<1, BM>(a, row0, nrows);
+    else vit_mlp_tile<0, BM>(a, row0, nrows);
 }
+__global__ __launch_bounds__(512, 1) void vit_mlp_kernel(const MlpArgs a) { vit_mlp_dispatch<128>(a); }
+__global__ __launch_bounds__(256, 2) void vit_mlp_kernel_bm64(const MlpArgs a) { vit_mlp_dispatch<64>(a); }
 
 // row 0 of every frame: cls token + pos[0]   (transformer_model.py:119-123)
 __global__ void cls_row_kernel(int N, int L, int D, const float *cls, const float *pos, float *X)
@@ -1177,23 +1182,27 @@ int os_vit_encode(os_ctx *ctx, int32_t N, const float *images, float *latent, vo
             if (ctx->tune_vit_mlp_fused >= 2) { ma.Y = Y; ma.Wpp = wproj; ma.bp = projb; }      // attention output -> projection -> LN2 -> MLP in one pass
             if (!v->mlp_attr_set) {
                 OS_HIP(ctx, hipFuncSetAttribute((const void *)vit_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)vit_mlp_kernel_bm64, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
                 v->mlp_attr_set = true;
             }
-            slot = os_prof_begin(ctx, OS_PHASE_VIT_GEMM, s, "vit_mlp_kernel");
-            // tiles: whole rounds of 128-row tiles over the CUs, then the remainder as 32- or 64-row tiles when those fit one more
-            // (short) round -- otherwise the last round runs a full tile's time on a fraction of the chip
-            const size_t ntiles = (M + GM_BM - 1) / GM_BM;
-            const size_t cu = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+            slot = os_prof_begin(ctx, OS_PHASE_VIT_GEMM, s, ctx->tune_vit_mlp_bm == 64 ? "vit_mlp_kernel_bm64" : "vit_mlp_kernel");
+            // tiles: whole rounds of full tiles over the workgroup slots, then the remainder as 32- or 64-row tiles when those fit
+            // one more (short) round -- otherwise the last round runs a full tile's time on a fraction of the chip
+            const int TB = ctx->tune_vit_mlp_bm == 64 ? 64 : GM_BM;
+            const size_t ntiles = (M + TB - 1) / TB;
+            const size_t cu = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * (TB == 64 ? 2 : 1);      // workgroup slots
             size_t nfull = ntiles, nsmall = 0;
-            int small_rows = GM_BM;
+            int small_rows = TB;
             const size_t rem = ntiles % cu;
             if (rem != 0 && ctx->tune_vit_tail_split) {
-                const size_t rows_rem = M - (ntiles - rem) * GM_BM;
-                small_rows = (rows_rem + 31) / 32 <= cu ? 32 : ((rows_rem + 63) / 64 <= cu ? 64 : GM_BM);
-                if (small_rows != GM_BM) { nfull = ntiles - rem; nsmall = (rows_rem + small_rows - 1) / small_rows; }
+                const size_t rows_rem = M - (ntiles - rem) * TB;
+                small_rows = (rows_rem + 31) / 32 <= cu ? 32 : ((rows_rem + 63) / 64 <= cu ? 64 : TB);
+                if (small_rows < TB) { nfull = ntiles - rem; nsmall = (rows_rem + small_rows - 1) / small_rows; }
+                else small_rows = TB;
             }
             ma.nfull = (int)nfull; ma.small_rows = small_rows;
-            hipLaunchKernelGGL(vit_mlp_kernel, dim3((unsigned)(nfull + nsmall)), dim3(512), (size_t)2 * GM_BM * 128 * sizeof(float), s, ma);
+            if (TB == 64) hipLaunchKernelGGL(vit_mlp_kernel_bm64, dim3((unsigned)(nfull + nsmall)), dim3(256), (size_t)2 * 64 * 128 * sizeof(float), s, ma);
+            else hipLaunchKernelGGL(vit_mlp_kernel, dim3((unsigned)(nfull + nsmall)), dim3(512), (size_t)2 * GM_BM * 128 * sizeof(float), s, ma);
             os_prof_end(ctx, slot, s);
             wp += (size_t)2 * Mh * D;
         } else {
