@@ -517,6 +517,17 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
             // piece p = threadIdx.x + 256 i sits in LDS row (threadIdx.x >> 5) + 8 i: the swizzled slot and the in-row offset are
             // the same for all 16 pieces of a thread, the row advances by a wave-uniform stride
             const int r_lo = threadIdx.x >> 5, slot = (threadIdx.x & 31) ^ (r_lo & 7), k = kc + 4 * slot;
+            // SRC 1: (frame, gy, gx) of the thread's first row by division ONCE; the other fifteen pieces are eight rows apart each,
+            // i.e. gx + 8 with at most one carry into gy and n when the grid is at least eight wide (three runtime divisions per
+            // piece were ~40 VALU instructions each, ~1,300 per thread and tile on the pipe the MFMAs share)
+            const int G = SRC == 1 ? a.grid : 1, P = SRC == 1 ? a.patch : 1;
+            uint32_t gx = 0, gy = 0, fn = 0;
+            const bool carry8 = G >= 8;
+            if (SRC == 1) {
+                const uint32_t m0 = (uint32_t)(row0 + r_lo);
+                gx = m0 % G; gy = (m0 / G) % G; fn = m0 / (G * G);
+            }
+            const int kpy = SRC == 1 ? k / P : 0, kpx = SRC == 1 ? k % P : 0;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 size_t row = row0 + r_lo + 8 * i;
@@ -526,10 +537,15 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
                     src = rowbase + (size_t)r_lo * a.lda + k;
                     if (row >= a.M) src = a.A + (a.M - 1) * (size_t)a.lda + k;
                 } else {
-                    if (row >= a.M) row = a.M - 1;
-                    const int G = a.grid, P = a.patch;                            // column k = P py + px of the patch
-                    const uint32_t m = (uint32_t)row, gx = m % G, gy = (m / G) % G, n = m / (G * G);
-                    src = a.img + ((size_t)n * a.img_size + gy * P + (k / P)) * a.img_size + gx * P + (k % P);
+                    uint32_t cx = gx, cy = gy, cn = fn;
+                    if (row >= a.M || !carry8) {                                  // tail rows / narrow grids: by division
+                        if (row >= a.M) row = a.M - 1;
+                        const uint32_t m = (uint32_t)row;
+                        cx = m % G; cy = (m / G) % G; cn = m / (G * G);
+                    }
+                    src = a.img + ((size_t)cn * a.img_size + cy * P + kpy) * a.img_size + cx * P + kpx;   // column k = P py + px of the patch
+                    gx += 8;
+                    if (gx >= (uint32_t)G) { gx -= G; gy++; if (gy >= (uint32_t)G) { gy = 0; fn++; } }
                 }
                 vit_lds_dma16(src, &As[(wave * 64 + 256 * i) * 4]);
             }
@@ -573,14 +589,20 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(const GemmArgs a)
     const int col = chunk * 32 + li;
     const float bv = a.bias[col];
     if (EPI == 3) {
+        // (frame, patch) of the lane's first row by division once; its other 63 rows lie at most 127 further on, so with at
+        // least 128 patches per frame there is at most one carry (a division per element was ~30 instructions x 64)
         const uint32_t np = (uint32_t)(a.L - 1);
+        const uint32_t m0 = (uint32_t)(row0 + 4 * lh), n0 = m0 / np, p0 = m0 % np;
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const size_t row = row0 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const uint32_t off = (uint32_t)(rb * 32 + (e & 3) + 8 * (e >> 2));
+                const size_t row = row0 + 4 * lh + off;
                 if (row >= a.M) continue;
-                const uint32_t m = (uint32_t)row, n = m / np, pch = m % np;
+                uint32_t n = n0, pch = p0 + off;
+                if (np >= 128u) { if (pch >= np) { pch -= np; n++; } }
+                else { n = (uint32_t)row / np; pch = (uint32_t)row % np; }
                 a.C[((size_t)n * a.L + 1 + pch) * a.N + col] = acc[rb][e] + bv + a.pos[(size_t)(1 + pch) * a.N + col];
             }
         return;
