@@ -40,6 +40,13 @@ KF_FLOPS_STRUCTURED = 7500   # ~7-8 kflop per step exploiting th
 REFERENCE_PYTHON_STEPS_PER_S = 3.05e3
 
 
+NOISE_NOTE = {"default": "settings.py:28-31 defaults (Q diag 1e-2 / 1e-4, R = 1e-2 I), P0 = Q",
+              "fitted": "Q_R.pkl fitted values with R[0:3] = 1e-4 (data_conversion_Kalman_to_Training.py:139-144), P0 = Q"}
+INPUT_NOTE = {"nominal": "SURVEY 8(d) distributions: trot contacts (2 stance legs), attitude within +-0.15 rad",
+              "hostile": "0-4 stance legs per step in random segments (standing and flight included), yaw unwrapping past +-pi, "
+                         "roll / pitch to +-1 rad, exact-zero and k*pi/2 attitude starts (synth.py: hostile=True)"}
+
+
 def gru_flops_per_step(I, H, L):
     return sum(2 * 3 * H * ((I if l == 0 else H) + H) for l in range(L))
 
@@ -213,10 +220,12 @@ def load_traffic(kernel_name, shape_ok):
 # CPU baselines and the parity block: the ONLY users of oracle/ in this file (checker / reported baseline, never the
 # thing measured as `value`)
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(H, L, target_seconds, kf_only=False):
+def cpu_baseline(H, L, target_seconds, kf_only=False, all_cores=None):
     """The float64 C oracle (oracle/kf_oracle.c + gru_oracle.c: a port of the reference's algorithm) timed on the host
     cores over a bounded sample of the same workload (same distributions, T = 100): trajectories split over all cores
-    (OpenMP), plus the single-thread figure of the scalar port."""
+    (OpenMP), plus the single-thread figure of the scalar port.
+    all_cores: the all-cores figure when oracle_pass() has already run the port over the timed batch itself (one run
+    serves the parity block and this baseline); only the single-thread sample is timed here then."""
     import numpy as np
     import torch
     from oracle import c_oracle as orc
@@ -248,13 +257,20 @@ def cpu_baseline(H, L, target_seconds, kf_only=False):
     t_probe = run(probe_B)
     B1 = min(max(probe_B, int(probe_B * 0.3 * target_seconds / max(t_probe, 1e-6))), 20000)
     el1 = run(B1)
-    cores = orc.set_threads(usable_cores())
-    Bs = min(max(cores * probe_B, int(B1 * cores * 0.7 / 0.3)), 65536)      # at most the GPU workload's own batch
-    el = run(Bs)
-    orc.set_threads(1)
     what = "KF float64 C oracle" if kf_only else "KF + GRU float64 C oracle"
-    out = {"value": Bs * T / el, "unit": "timesteps/s", "cores": cores, "kind": "port",
-           "sample": f"{Bs} trajectories x {T} steps ({what}, {cores} threads, {el:.1f} s)",
+    if all_cores is None:
+        cores = orc.set_threads(usable_cores())
+        Bs = min(max(cores * probe_B, int(B1 * cores * 0.7 / 0.3)), 65536)      # at most the GPU workload's own batch
+        el = run(Bs)
+        orc.set_threads(1)
+        Tb = T
+        sample = f"{Bs} trajectories x {T} steps ({what}, {cores} threads, {el:.1f} s)"
+    else:
+        Bs, Tb, el, cores = all_cores["trajectories"], all_cores["timesteps_each"], all_cores["seconds"], all_cores["cores"]
+        sample = (f"{Bs} trajectories x {Tb} steps of the TIMED batch itself ({what}, {cores} threads, {el:.1f} s in the C entry "
+                  "points; the same run is the parity block's reference)")
+    out = {"value": Bs * Tb / el, "unit": "timesteps/s", "cores": cores, "kind": "port",
+           "sample": sample,
            "single_thread_value": B1 * T / el1,
            "single_thread_sample": f"{B1} trajectories x {T} steps, 1 thread, {el1:.1f} s",
            "reference_python_steps_per_s": REFERENCE_PYTHON_STEPS_PER_S,
@@ -352,30 +368,63 @@ def cpu_baseline_mpc(target_seconds):
                       "the reference solves them with qpOASES (absent here: parity unpinned)"}
 
 
-def parity_block(d, idx, x_out, out, model, H, L, kf_only=False, windows=None):
-    """state_linf / gru_linf of a sample of the TIMED batch against the float64 oracle, outside the timed region
-    (BASELINE.json's metric is 'timesteps/s ...; state l-inf vs CPU ref').  d: the device input streams [T][F][B];
-    idx: the sampled trajectory indices; x_out [T][12][B], out [B][C] from the last timed pass."""
+def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only=False):
+    """The float64 C oracle over the TIMED batch itself (rank 0's shard), outside the timed region, split over all usable
+    host cores: state_linf / gru_linf over EVERY (trajectory, timestep) it covers (BASELINE.json's metric is 'timesteps/s
+    ...; state l-inf vs CPU ref', SURVEY 8(d): over all B x T), and the seconds the C entry points took -- the same run is
+    the all-cores cpu_baseline.  d: the device input streams [T][F][B]; x_out [T][12][B], out [B][C] from the last timed
+    pass; want: trajectories to cover (B = all).  Chunks of 8192 trajectories in a seeded random order, so a run that hits
+    cap_seconds (a box with few cores) still reports an unbiased sample and says how many trajectories it covered."""
     import numpy as np
     import torch
     from oracle import c_oracle as orc
-    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
-    n = int(idx.numel())
-    g = lambda k: d[k][:, :, idx].permute(2, 0, 1).double().cpu().numpy()
-    contact = d["contact"][:, :, idx].permute(2, 0, 1).cpu().numpy()
-    ref = orc.kf_run_batch(g("p"), g("f"), g("dp"), g("imu"), contact, d["x0"][:, idx].t().double().cpu().numpy(),
-                           np.tile(Q_DEFAULT, (n, 1, 1)), Q_DEFAULT, R_DEFAULT)
-    xo = x_out[:, :, idx].permute(2, 0, 1).cpu().numpy()
-    res = {"trajectories": n, "timesteps_each": int(xo.shape[1]), "state_linf": float(np.abs(xo - ref["x"]).max()),
-           "state_bar": 1e-4, "reference": "oracle/kf_oracle.c + gru_oracle.c (float64; pinned to reference-generated goldens)"}
+    B, T = int(d["p"].shape[2]), int(d["p"].shape[0])
+    cores = orc.set_threads(usable_cores())
+    order = torch.randperm(B, generator=torch.Generator().manual_seed(3))[:max(1, min(want, B))]
+    w = None if kf_only else orc.flatten_state_dict(model.state_dict(), L)
+    CH = 8192
+    done, secs, s_linf, g_linf, bad = 0, 0.0, 0.0, 0.0, 0
+    worst = None
+    for c0 in range(0, int(order.numel()), CH):
+        idx = order[c0:c0 + CH].sort().values.to(d["p"].device)
+        n = int(idx.numel())
+        g = lambda k: d[k][:, :, idx].permute(2, 0, 1).double().cpu().numpy()
+        a = {k: g(k) for k in (("p", "f", "dp", "imu") if kf_only else ("p", "f", "dp", "imu", "accel"))}
+        contact = d["contact"][:, :, idx].permute(2, 0, 1).contiguous().cpu().numpy()
+        x0 = d["x0"][:, idx].t().double().cpu().numpy()
+        P0n = np.tile(np.asarray(P0, dtype=np.float64), (n, 1, 1))
+        t0 = time.perf_counter()
+        ref = orc.kf_run_batch(a["p"], a["f"], a["dp"], a["imu"], contact, x0, P0n, Q, R, aux=not kf_only)
+        secs += time.perf_counter() - t0
+        bad += int((ref["status"] != 0).sum())
+        err = np.abs(x_out[:, :, idx].permute(2, 0, 1).cpu().numpy() - ref["x"])
+        if err.max() > s_linf or worst is None:
+            bi, ti, ci = np.unravel_index(int(err.argmax()), err.shape)
+            worst = {"trajectory": int(idx[bi].item()), "timestep": int(ti), "component": int(ci)}
+        s_linf = max(s_linf, float(err.max()))
+        if not kf_only:
+            rows = np.concatenate([ref["x"], a["accel"], a["f"], ref["p_rot"], a["dp"], a["imu"]], axis=2)
+            rows = (rows + 30.0) / 60.0
+            t0 = time.perf_counter()
+            ro, _, _ = orc.gru_forward(rows, w, 60, H, L, 24)
+            secs += time.perf_counter() - t0
+            g_linf = max(g_linf, float(np.abs(out[idx].cpu().numpy() - ro).max()))
+        done += n
+        del a, ref, err
+        if secs > cap_seconds:
+            break
+    orc.set_threads(1)
+    res = {"trajectories": done, "timesteps_each": T, "of_batch": B, "whole_tensor": bool(done == B),
+           "state_linf": s_linf, "state_linf_at": worst, "state_bar": 1e-4, "oracle_status_nonzero": bad,
+           "reference": "oracle/kf_oracle.c + gru_oracle.c (float64; pinned to reference-generated goldens)"}
+    if done < min(want, B):
+        res["note"] = f"stopped after {secs:.0f} s of oracle time on {cores} cores (cap {cap_seconds:.0f} s): seeded random sample"
     if not kf_only:
-        rows = np.concatenate([ref["x"], g("accel"), g("f"), ref["p_rot"], g("dp"), g("imu")], axis=2)
-        ro, _, _ = orc.gru_forward((rows + 30.0) / 60.0, orc.flatten_state_dict(model.state_dict(), L), 60, H, L, 24)
-        res["gru_linf"] = float(np.abs(out[idx].cpu().numpy() - ro).max())
+        res["gru_linf"] = g_linf
         res["gru_bar"] = 1e-5
         res["fused_chain_bar"] = 1e-4
-    res["ok"] = bool(res["state_linf"] < 1e-4 and res.get("gru_linf", 0.0) < 1e-4)
-    return res
+    res["ok"] = bool(s_linf < 1e-4 and g_linf < 1e-4)
+    return res, {"trajectories": done, "timesteps_each": T, "seconds": secs, "cores": cores}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -580,33 +629,43 @@ def bench_windows(a, rk):
 
 def bench_hot_path(a, rk):
     """--mode fused (default, BASELINE configs[2]) and --mode kf (configs[1]-style)."""
+    import numpy as np
     import torch
     from optistate_amd import Engine, RNN, flatten_state_dict
-    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    from optistate_amd.synth import synth_torch, NOISE_SETS
     B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60
     fused = a.mode == "fused"
     eng = Engine(rk.local_rank)
-    eng.set_noise(Q_DEFAULT, R_DEFAULT)
     dev = eng.device
-    d = synth_torch(B, T, dev, seed=1000 + rk.rank)
+    d = synth_torch(B, T, dev, seed=1000 + rk.rank, hostile=a.hostile)
     contact = eng.contact_soa_to_packed(d["contact"])
     torch.manual_seed(0)
     model = RNN(I, H, L, 24, dev)                       # random-init weights of the named architecture
     eng.load_gru(flatten_state_dict(model.state_dict(), L, dev), I, H, L, 24)
     # min-max constants for the synthetic distributions (every feature lands in (0,1) like the reference's scaling)
     minmax = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).to(dev)
-    x0, P0 = d["x0"], d["P0"]
-    x, P = x0.clone(), P0.clone()
+    x0 = d["x0"]
+    x, P = x0.clone(), d["P0"].clone()
 
-    def one_step():
-        x.copy_(x0); P.copy_(P0)                        # device-to-device reset of the 40 MB filter state
-        if fused:
-            return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, split_bf16=a.split_bf16)
-        return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
+    def run_set(noise, warmup, steps):
+        """One timed run under a noise set: Q / R into the context, P0 = Q as the reference's callers start
+        (settings.py:31 `P = Q`; data_conversion_Kalman_to_Training.py:144 `KF2.P = copy.deepcopy(Q)`)."""
+        Q, R = NOISE_SETS[noise]
+        eng.set_noise(Q, R)
+        P0 = torch.tensor(np.asarray(Q, dtype=np.float32).reshape(144, 1), device=dev).repeat(1, B).contiguous()
 
-    # one to three launches per pass here: the per-kernel HIP events stay on over the timed region itself (two event records
-    # per launch against milliseconds of kernel; the modes with dozens of short launches per step use a second pass instead)
-    el, r, kernels = timed_region(rk, a.warmup, a.steps, one_step, eng=eng)
+        def one_step():
+            x.copy_(x0); P.copy_(P0)                    # device-to-device reset of the 40 MB filter state
+            if fused:
+                return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, split_bf16=a.split_bf16)
+            return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
+        # one to three launches per pass here: the per-kernel HIP events stay on over the timed region itself (two event
+        # records per launch against milliseconds of kernel; the modes with dozens of short launches per step use a second
+        # pass instead)
+        el, r, kernels = timed_region(rk, warmup, steps, one_step, eng=eng)
+        return el, r, kernels, Q, R
+
+    el, r, kernels, Q, R = run_set(a.noise, a.warmup, a.steps)
     bad = int((r["status"] != 0).sum().item())
     info = rk.report()
     if rk.rank != 0:
@@ -646,8 +705,9 @@ def bench_hot_path(a, rk):
         tf = KF_FLOPS_STRUCTURED * steps_per_pass / (avg_ms * 1e-3) / 1e12
         roof["valu_structured_TFLOPs"] = tf
         roof["valu_frac_of_fp32_vector_peak"] = tf / MFMA_F32_PEAK_TF
-        if dk["kernel"].startswith("kf_run_rows_kernel"):
-            waves = (B + 3) // 4
+        if dk["kernel"].startswith(("kf_run_rows_kernel", "kf_run_wave_kernel")):
+            per = 4 if dk["kernel"].startswith("kf_run_rows_kernel") else 1
+            waves = (B + per - 1) // per
             roof["limiter"] = (f"latency: {waves} wavefronts on 1024 SIMDs, each a serial chain of T = {T} dependent steps "
                                f"({avg_ms * 1e3 / T:.2f} us per step); neither HBM nor the vector pipe is the bound at this batch")
         else:
@@ -665,22 +725,36 @@ def bench_hot_path(a, rk):
                                  if fused else "Kalman(12-state/10-meas) predict/update only",
                      "batch_per_gpu": B, "seq_len": T, "global_batch": B * rk.world,
                      "parallelism": f"trajectory-sharded x{rk.world}, no collective",
+                     "noise": NOISE_NOTE[a.noise], "inputs": INPUT_NOTE["hostile" if a.hostile else "nominal"],
                      "baseline_config": "BASELINE.json configs[2]" if fused else "BASELINE.json configs[1] (true dims 12/10)"})
     out["roofline"] = roof
     out["kernels"] = kernels
     out["kernel_events"] = "HIP events on the launch stream, recorded over the timed region (the wall time includes them)"
     out["status_nonzero_trajectories"] = bad
     out.update(info)
-    # parity of the timed batch itself (rank 0's shard), outside the timed region
-    if a.parity_samples > 0:
-        n = min(a.parity_samples, B)
-        idx = torch.randperm(B, generator=torch.Generator().manual_seed(3))[:n].to(dev)
-        out["parity"] = parity_block(d, idx, r["x_out"], r.get("out"), model, H, L, kf_only=not fused)
+    # parity of the timed batch itself (rank 0's shard) over ALL of its (trajectory, timestep) pairs, outside the timed
+    # region; the oracle's seconds double as the all-cores cpu_baseline (one run serves both)
+    all_cores = None
+    cap = max(4.0 * a.cpu_seconds, 60.0)
+    if a.parity_samples != 0:
+        want = B if a.parity_samples < 0 else min(a.parity_samples, B)
+        out["parity"], timing = oracle_pass(d, r["x_out"], r.get("out"), model, H, L, Q, R, Q, want, cap, kf_only=not fused)
+        if timing["trajectories"] >= 2048:
+            all_cores = timing
         if a.split_bf16:
             out["parity"]["gru_bar"] = 1e-5
             out["parity"]["note"] = "opt-in split-bf16 gate GEMM: the GRU bar stays 1e-5, the fused chain < 1e-4"
+    if a.second_noise and a.noise == "default" and rk.world == 1 and not a.split_bf16:
+        # "second run with Q_R.pkl values" -- the reference's fitted Q / R (cond(S) ~ 1e6) on the same inputs
+        el2, r2, k2, Q2, R2 = run_set("fitted", 1, 3)
+        sec = {"noise": NOISE_NOTE["fitted"], "steps": 3, "ms_per_step": el2 / 3 * 1e3, "value": steps_per_pass * rk.world * 3 / el2,
+               "status_nonzero_trajectories": int((r2["status"] != 0).sum().item())}
+        if a.parity_samples != 0:
+            want2 = B if a.parity_samples < 0 else min(a.parity_samples, B)
+            sec["parity"], _ = oracle_pass(d, r2["x_out"], r2.get("out"), model, H, L, Q2, R2, Q2, want2, cap, kf_only=not fused)
+        out["second_noise_set"] = sec
     if a.cpu_seconds > 0 and rk.world == 1:
-        out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds, kf_only=not fused)
+        out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds, kf_only=not fused, all_cores=all_cores)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
@@ -708,7 +782,14 @@ def main(argv=None):
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
-    ap.add_argument("--parity-samples", type=int, default=128, help="trajectories of the timed batch checked against the oracle (0 = skip)")
+    ap.add_argument("--parity-samples", type=int, default=-1,
+                    help="trajectories of the timed batch checked against the oracle over all their timesteps (-1 = the whole batch, 0 = skip)")
+    ap.add_argument("--noise", default="default", choices=["default", "fitted"],
+                    help="Q / R set: settings.py defaults, or the reference's fitted Q_R.pkl values with R[0:3] = 1e-4")
+    ap.add_argument("--no-second-noise", dest="second_noise", action="store_false",
+                    help="skip the short second run under the fitted noise set that the default line carries as second_noise_set")
+    ap.add_argument("--hostile", action="store_true",
+                    help="inputs that leave the fast branches: 0-4 stance legs per step, yaw unwrapping past +-pi, wide roll / pitch")
     ap.add_argument("--split-bf16", type=int, nargs="?", const=3, default=0, choices=[0, 2, 3],
                     help="opt-in gate GEMM on the bf16 MFMA with 3 (default) or 2 bf16 terms per fp32 operand (second line; never the headline)")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")

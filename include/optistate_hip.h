@@ -86,6 +86,28 @@ const char *os_last_error(const os_ctx *ctx);
 /* Library/ABI version and build target string ("gfx950"). */
 int os_version(void);
 const char *os_build_arch(void);
+/* "<hash of the sources, headers and compile flags>-<hash of `hipcc --version`>", stamped by optistate_amd/build.py;
+ * the Python loader refuses a library whose first half does not match the sources it sits beside. */
+const char *os_build_id(void);
+
+/* ONE filter step of ONE trajectory with every argument in HOST memory (plain float64 arrays): replaces, for a single
+ * `Kalman_Filter` instance, any combination of
+ *   OS_STEP_ODOM     odom = get_odom(p, dp, contact, imu); set_measurements(imu, odom)   (kalman_filter/kalman_filter.py:79-117) -> z
+ *   OS_STEP_PREDICT  predict(p, f) (:119-138) or, with OS_STEP_DENSE_FD, the covariance / next_state half of
+ *                    predict_mpc(p, body_ref, .) with the forces supplied (:153-161) -> x, P, p_rot (p rotated in place by
+ *                    next_state, misc/force_controller.py:274-277), x_model, P_trace
+ *   OS_STEP_UPDATE   update() (:164-174) -> x, P, K (12 x 10), P_trace, K_gain
+ * in ONE kernel launch and ONE stream synchronise (the caller loop data_conversion_Kalman_to_Training.py:193-199 is these
+ * four calls per time step).  The call is SYNCHRONOUS: results are in the caller's arrays when it returns.  All arithmetic is
+ * float64 (one wavefront, covariance in LDS); Q (144) and R (100) come with the call, like the reference's per-instance
+ * attributes.  model: {dt, mass, Ixx, Iyy, Izz, g_z} in float64 or NULL for the context's (float32) configuration.
+ * contact: 4 bytes (0/1).  status: bit 0 S not positive definite (the reference's np.linalg.inv raises), bit 1 non-finite x.
+ * Unused pointers may be NULL (e.g. K, p_rot). */
+enum { OS_STEP_ODOM = 1, OS_STEP_PREDICT = 2, OS_STEP_UPDATE = 4, OS_STEP_DENSE_FD = 8 };
+int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *f, const double *dp,
+               const double *imu, const uint8_t *contact, const double *body_ref, const double *Q, const double *R,
+               double *x, double *P, double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain,
+               int32_t *status, void *stream);
 
 /* Replaces the attribute writes KF.Q = Q; KF.R = R (data_collection/data_conversion_Kalman_to_Training.py:139-143).
  * Q host float[144], R host float[100], row-major. */

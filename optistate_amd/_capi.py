@@ -16,6 +16,7 @@ OS_FUSED_ONE_KERNEL = 128
 OS_KF_P_FLOAT64 = 256
 OS_FUSED_SPLIT_BF16 = 512
 OS_FUSED_SPLIT_BF16_2 = 1024
+OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD = 1, 2, 4, 8
 OS_PROF_PHASES = 12         # include/optistate_hip.h
 PHASE_NAMES = ("kf", "gru_layer", "gru_head", "fused", "mpc", "train_sweep", "train_dw", "train_misc", "vit_gemm",
                "vit_attn", "vit_misc", "pack")
@@ -28,7 +29,7 @@ EXPORTS = [
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
     "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
-    "os_profile_kernel_name",
+    "os_profile_kernel_name", "os_build_id", "os_kf_step",
 ]
 
 
@@ -64,6 +65,13 @@ def load():
                            "(there is no CPU fallback for the OptiState hot path)")
     lib = C.CDLL(path)
     vp, i32, u32, f32p = C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p
+    lib.os_build_id.restype = C.c_char_p
+    if "OPTISTATE_HIP_LIB" not in os.environ:
+        # the .so is a git-ignored artefact that travels as a file: make sure it was built from THESE sources and flags
+        from . import build as _build
+        have, want = lib.os_build_id().decode().split("-")[0], _build.source_id()
+        if have != want:
+            raise RuntimeError(f"{path} is stale: built from sources {have}, the tree is {want}; run `python -m optistate_amd.build`")
     lib.os_create.argtypes = [C.POINTER(OsKfConfig), C.POINTER(vp)]
     lib.os_create.restype = C.c_int
     lib.os_destroy.argtypes = [vp]
@@ -111,6 +119,8 @@ def load():
     lib.os_profile_kernel_name.restype = C.c_char_p
     lib.os_kf_run_noise.argtypes = [vp, i32, i32] + [f32p] * 5 + [f32p] * 4 + [f32p] * 3 + [vp, u32, vp]
     lib.os_kf_run_noise.restype = C.c_int
+    lib.os_kf_step.argtypes = [vp, u32] + [vp] * 19
+    lib.os_kf_step.restype = C.c_int
     lib.os_gru_generation.argtypes = [vp]
     lib.os_gru_generation.restype = C.c_uint64
     lib.os_gru_train_ws_floats.argtypes = [C.POINTER(OsGruDims), i32, i32]

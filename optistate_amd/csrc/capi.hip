@@ -8,6 +8,10 @@ extern "C" {
 
 int os_version(void) { return 1; }
 const char *os_build_arch(void) { return "gfx950"; }
+#ifndef OS_BUILD_ID
+#define OS_BUILD_ID "unstamped"
+#endif
+const char *os_build_id(void) { return OS_BUILD_ID; }
 
 int os_create(const os_kf_config *cfg, os_ctx **out)
 {
@@ -78,6 +82,7 @@ void os_destroy(os_ctx *ctx)
     if (!ctx || ctx->magic != OS_MAGIC) return;
     (void)hipSetDevice(ctx->device);
     os_train_destroy(ctx);
+    os_step_destroy(ctx);
     os_vit_destroy(ctx);
     float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)

@@ -77,10 +77,13 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
     const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
 
     float x[NS], U[NT];
+    int status;
     {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
         for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        // status bit 3: P0 not symmetric (only the upper triangle is read; see include/optistate_hip.h)
+        status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -88,7 +91,6 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
     }
     constexpr float LOG2E = 1.44269504088896341f;
 
-    int status = 0;
     StepIn in;
     float acl[6];
     load_step(k, 0, voff, rowB, in);
@@ -363,15 +365,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
         for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
         // status bit 3: P0 not symmetric (the paired triangle reads the upper half only; see include/optistate_hip.h)
-        float worst = 0.f;
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i + 1; j < NS; j++) {
-                const float up = buf_load(rP, voff, (i * NS + j) * rowB), lo = buf_load(rP, voff, (j * NS + i) * rowB);
-                worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
-            }
-        status = worst > 0.f ? 8 : 0;
+        status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
     // h_t of this wave's 64 trajectories: hreg[rb][c][e] = h[unit 32c + (e&3) + 8(e>>2) + 4 lh][trajectory wbase + 32 rb + li]
@@ -705,15 +699,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
         for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
-        float worst = 0.f;
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i + 1; j < NS; j++) {
-                const float up = buf_load(rP, voff, (i * NS + j) * rowB), lo = buf_load(rP, voff, (j * NS + i) * rowB);
-                worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
-            }
-        status = worst > 0.f ? 8 : 0;
+        status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
     float hreg[2][2][16];               // fp32 h_t (AGPR-resident), layout as in v2

@@ -1178,6 +1178,12 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     const int H = d.hidden_size, L = d.num_layers, I = d.input_size, C = d.num_classes, H3 = 3 * H;
     const size_t tbh = (size_t)T * B * H, nparam = os_gru_param_count(&d);
     const int Kmax = I > H ? I : H;
+    // bwd_sweep_kernel addresses the saved activations, the gate derivatives and dx through buffer descriptors whose sizes
+    // and per-step offsets are 32-bit byte counts: past 4 GiB they would wrap, out-of-range loads would read 0 and stores
+    // be dropped -- silently wrong gradients.  Refuse instead (split the batch: the gradients of the parts add up).
+    if ((size_t)T * B * 4 * H * sizeof(float) >= ((size_t)1 << 32) || (size_t)T * B * Kmax * sizeof(float) >= ((size_t)1 << 32))
+        return os_fail(ctx, -2, "os_gru_backward: T*B*4*hidden_size (or T*B*input_size) floats reach 4 GiB, beyond the backward "
+                                "sweep's 32-bit buffer offsets; split the batch");
     const bool overlap = ctx->tune_train_overlap != 0 && L > 1;
     if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (overlap ? 2 : 1) * (size_t)T * B * 4 * H)) return -10;
     if (overlap && train_side_stream(ctx, ts)) return -10;

@@ -182,17 +182,19 @@ struct StepIn {
 // r = R(imu angles) (supplied by the caller: the 16-lanes-per-trajectory kernel shares its sincos across the lanes).
 __device__ __forceinline__ void measurement_r(const StepIn &in, const Rot &r, float *z /*10*/)
 {
-    // per leg: stance weight (byte == 1), swing weight (byte == 0) as 0/1 floats, then plain multiply-adds
+    // per leg: stance (byte == 1) entries feed vx, vy, pz, swing (byte == 0) entries feed vz.  SELECTS, not 0/1 weights: the
+    // reference's `if contact_cur[i] == 1 / == 0` (:83-90) never touches the other entries, so a NaN / Inf in a swing leg's
+    // dp_x must not reach z (0 * NaN = NaN would poison the whole trajectory)
     float sum_c = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, pz = 0.f;
 #pragma unroll
     for (int l = 0; l < 4; l++) {
         const uint32_t cb = (in.contact >> (8 * l)) & 0xffu;
-        const float st = cb == 1u ? 1.0f : 0.0f, sw = cb == 0u ? 1.0f : 0.0f;
+        const bool st = cb == 1u, sw = cb == 0u;
         sum_c += (float)cb;
-        vx = fmaf(st, in.dp[3 * l], vx);
-        vy = fmaf(st, in.dp[3 * l + 1], vy);
-        pz = fmaf(st, in.p[3 * l + 2], pz);
-        vz = fmaf(sw, in.dp[3 * l + 2], vz);
+        vx += st ? in.dp[3 * l] : 0.f;
+        vy += st ? in.dp[3 * l + 1] : 0.f;
+        pz += st ? in.p[3 * l + 2] : 0.f;
+        vz += sw ? in.dp[3 * l + 2] : 0.f;
     }
     float inv = (sum_c != 0.f) ? (1.0f / sum_c) : 0.f;   // no stance leg -> odom = 0 (:97-98)
     float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
@@ -741,6 +743,21 @@ __device__ __forceinline__ float trace_sym(const f2 *U)
 #pragma unroll
     for (int i = 0; i < NS; i++) t += OSK_SYM(U, i, i);
     return t;
+}
+
+// status bit 3 for the symmetric-storage kernels: the caller's P0 against its own transpose (66 extra loads, once per launch)
+template <typename LoadF>
+__device__ __forceinline__ int p0_asymmetry_status(LoadF ld)
+{
+    float worst = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = i + 1; j < NS; j++) {
+            const float up = ld(i * NS + j), lo = ld(j * NS + i);
+            worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
+        }
+    return worst > 0.f ? 8 : 0;
 }
 
 // state load / store of the paired triangle from / to the row-major P [144][B] stream

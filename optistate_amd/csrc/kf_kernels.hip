@@ -106,20 +106,6 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 // status bit 3: the caller's P0 is not symmetric (checked once per launch against the lower triangle, 66 extra loads per
 // trajectory): the symmetric-storage kernels would silently run a different filter than the reference, which never
 // symmetrises P (kalman_filter/kalman_filter.py:172)
-template <typename LoadF>
-__device__ __forceinline__ int p0_asymmetry_status(LoadF ld)
-{
-    float worst = 0.f;
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = i + 1; j < NS; j++) {
-            const float up = ld(i * NS + j), lo = ld(j * NS + i);
-            worst = fmaxf(worst, fabsf(up - lo) - 1e-5f * fmaxf(fabsf(up), fabsf(lo)));
-        }
-    return worst > 0.f ? 8 : 0;
-}
-
 template <int OUT, bool QDIAG>
 __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfConst &kc, const int b)
 {

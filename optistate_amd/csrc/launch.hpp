@@ -20,8 +20,9 @@ struct os_ctx {
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
-    int tune_mpc_persistent;             // os_kf_mpc_run: 1 = one persistent kernel up to 32 trajectories per CU (default), 2 = always, 0 = the per-step launch sequence
-    int tune_vit_mlp_fused;              // ViT block tail: 2 = projection + LayerNorm + MLP in one kernel (default), 1 = LayerNorm + MLP in one kernel, 0 = separate launches
+    int tune_mpc_persistent;             // os_kf_mpc_run: 1 = one persistent kernel up to 24 trajectories per CU (default), 2 = always, 0 = the per-step launch sequence
+    int tune_vit_mlp_fused;              // ViT block tail: 3 = projection + LayerNorm + MLP + the next block's LayerNorm / qkv in one kernel (default),
+                                         // 2 = projection + LayerNorm + MLP, 1 = LayerNorm + MLP, 0 = separate launches
     int tune_dw_rps;                     // rows per dW slice
     int tune_vit_att_dma;                // 1: persistent attention workgroups with LDS-DMA K / V double buffering (OS_VIT_ATT_DMA=0: one workgroup per head)
     int tune_vit_mlp_bm;                 // rows per vit_mlp tile: 128 (one eight-wave workgroup per CU) or 64 (two four-wave workgroups) (OS_VIT_MLP_BM)
@@ -55,6 +56,7 @@ struct os_ctx {
     bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set, ahead_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
+    void *step;                          // os_step_state (kf_step.hip): pinned, device-mapped staging block of os_kf_step
     // per-kernel timing (os_profile_*): ring of event pairs
     bool prof;
     int prof_n;                          // recorded pairs
@@ -133,4 +135,5 @@ int os_gru_launch_layer(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s);
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H);   // gru_kernels.hip: the layer kernel for this shape reads (B, T, K) inputs itself
 int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s);
 void os_train_destroy(os_ctx *ctx);
+void os_step_destroy(os_ctx *ctx);
 void os_vit_destroy(os_ctx *ctx);

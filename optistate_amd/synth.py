@@ -25,8 +25,35 @@ R_FITTED = np.diag([1e-4, 1e-4, 1e-4, 7.81921020e-02, 2.42114010e-01, 2.60983908
                     7.05195918e-02, 1.10483579e-01, 3.73801504e-02])
 
 
-def synth_numpy(B, T, seed=0, theta0_noise=True, dtype=np.float32):
+NOISE_SETS = {"default": (Q_DEFAULT, R_DEFAULT), "fitted": (Q_FITTED, R_FITTED)}
+
+# ---- "hostile" streams: everything the nominal distributions never exercise (VERDICT r2: contact patterns, unwrapped yaw) ----
+# contacts: random 4-bit words held for 16-step segments (0, 1, 2, 3 or 4 stance legs: standing and flight included, a
+# quarter of the trajectories stand on all four legs for the whole first half); attitude: yaw = yaw0 + rate t with |rate| up
+# to 8 rad/s (passes +-pi and keeps going: the Cody-Waite branch of the kernels' sincos, every quadrant), roll / pitch
+# sinusoids up to 1 rad; the first 5/16 of the batch start at exact attitudes (0, and theta_z / theta_y = float32(pi/2), +-pi)
+# with the IMU agreeing at t = 0, so the int64-truncation predicate (misc/force_controller.py:248-251,271) sees entries of R
+# at or next to +-1.
+HOSTILE_SEG = 16
+
+
+def _hostile_exact_starts(B):
+    """[(first, last, (thx, thy, thz))]: index ranges of the batch that start at exact attitudes."""
+    n = max(1, B // 16)
+    pi2, pi = float(np.float32(np.pi / 2)), float(np.float32(np.pi))
+    return [(0, n, (0.0, 0.0, 0.0)), (n, 2 * n, (0.0, 0.0, pi2)), (2 * n, 3 * n, (0.0, 0.0, pi)),
+            (3 * n, 4 * n, (0.0, 0.0, -pi)), (4 * n, 5 * n, (0.0, pi2, 0.0))]
+
+
+def synth_numpy(B, T, seed=0, theta0_noise=True, dtype=np.float32, hostile=False):
     """Returns dict of [B][T][field] arrays (float32-representable) + x0 [B][12], P0 [B][12][12]."""
+    if hostile:
+        import torch
+        d = synth_torch(B, T, "cpu", seed=seed, soa=False, hostile=True)
+        out = {k: v.numpy().astype(dtype) for k, v in d.items() if k not in ("contact", "P0")}
+        out["contact"] = d["contact"].numpy().astype(np.uint8)
+        out["P0"] = np.tile(Q_DEFAULT, (B, 1, 1)).astype(dtype)
+        return out
     rng = np.random.default_rng(seed)
     t = np.arange(T)[None, :, None] * 0.01
     p = NOMINAL_P[None, None, :] + rng.normal(0, 0.01, (B, T, 12))
@@ -55,9 +82,9 @@ def synth_numpy(B, T, seed=0, theta0_noise=True, dtype=np.float32):
     return out
 
 
-def synth_torch(B, T, device, seed=0, soa=True):
+def synth_torch(B, T, device, seed=0, soa=True, hostile=False):
     """Same distributions generated on `device` with torch, directly in the kernel's SoA layout
-    [T][field][B] (float32) when soa=True.  Used by bench.py at BASELINE sizes."""
+    [T][field][B] (float32) when soa=True.  Used by bench.py at BASELINE sizes.  hostile=True: see HOSTILE_SEG above."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -84,7 +111,29 @@ def synth_torch(B, T, device, seed=0, soa=True):
     contact[:, 2] = phase == 1
     accel = rn(T, 6, B)
     x0 = torch.tensor(X0, dtype=torch.float32, device=device)[:, None].repeat(1, B).contiguous()
-    x0[0:3, B // 2:] += rn(3, B - B // 2, std=0.02)
+    if hostile:
+        nseg = (T + HOSTILE_SEG - 1) // HOSTILE_SEG + 1
+        word = torch.randint(0, 16, (nseg, B), device=device, generator=g)
+        kind = ru(nseg, B)
+        word = torch.where(kind < 0.2, torch.full_like(word, 15), word)             # standing
+        word = torch.where(kind > 0.92, torch.zeros_like(word), word)               # flight
+        off = torch.randint(0, HOSTILE_SEG, (1, B), device=device, generator=g)
+        seg = (torch.arange(T, device=device)[:, None] + off) // HOSTILE_SEG        # [T][B]
+        wt = torch.gather(word, 0, seg)
+        wt[: T // 2, (B // 2): (B // 2 + B // 4)] = 15                               # long all-stance stretch
+        contact = torch.stack([(wt >> l) & 1 for l in range(4)], dim=1).to(torch.uint8).contiguous()
+        rate = ru(1, 1, B, lo=-8.0, hi=8.0)
+        yaw = ru(1, 1, B, lo=-3.0, hi=3.0) + rate * tt + 0.05 * torch.sin(ru(1, 1, B, lo=1.0, hi=3.0) * tt)
+        rp = ru(1, 2, B, lo=0.3, hi=1.0) * torch.sin(ru(1, 2, B, lo=1.0, hi=3.0) * tt + ru(1, 2, B, hi=6.2831853))
+        imu = torch.cat([rp, yaw, imu[:, 3:6] + torch.cat([torch.zeros(1, 2, B, device=device), rate], dim=1)], dim=1) \
+            + torch.cat([rn(T, 3, B, std=0.005), torch.zeros(T, 3, B, device=device)], dim=1)
+        x0[0:3] = imu[0, 0:3]                                                        # the filter starts on the first IMU attitude
+        for lo, hi, th in _hostile_exact_starts(B):
+            for c in range(3):
+                x0[c, lo:hi] = th[c]
+                imu[0, c, lo:hi] = th[c]
+    else:
+        x0[0:3, B // 2:] += rn(3, B - B // 2, std=0.02)
     P0 = torch.tensor(Q_DEFAULT, dtype=torch.float32, device=device).reshape(144, 1).repeat(1, B).contiguous()
     d = dict(p=p, f=f, dp=dp, imu=imu, contact=contact, accel=accel, x0=x0, P0=P0)
     if not soa:

@@ -87,6 +87,75 @@ def test_random_sample_matches_oracle(setup):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# Hostile inputs at full size: everything the nominal bench data never exercises (VERDICT r2 "what's weak" 2, 3)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("noise", ["default", "fitted"])
+def test_hostile_contacts_and_unwrapped_yaw_through_every_kernel_family(noise):
+    """0...4 stance legs per step (standing and flight stretches), yaw unwrapping past +-pi at up to 8 rad/s, roll / pitch
+    to 1 rad, exact 0 / k pi/2 attitude starts (the int64-truncation predicates): 65,536 x 100 through
+    fused_kf_gru_kernel_v2 and kf_run_sym_kernel, a 4,096-slice through kf_run_rows_kernel, each against the float64
+    oracle (16,384 random trajectories x all 100 steps + the whole exact-start block), under both reference noise sets."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.synth import synth_torch, NOISE_SETS, _hostile_exact_starts
+    from oracle import c_oracle as orc
+    Q, R = NOISE_SETS[noise]
+    eng = Engine(0)
+    eng.set_noise(Q, R)
+    d = synth_torch(B, T, "cuda", seed=77, hostile=True)
+    cp = eng.contact_soa_to_packed(d["contact"])
+    stance = d["contact"].sum(dim=1)
+    assert all(int((stance == k).sum()) > B for k in range(5))                     # every count 0..4 really occurs, often
+    assert d["imu"][:, 2].abs().max().item() > 6.0                                  # yaw leaves (-pi, pi]
+    P0 = torch.tensor(np.asarray(Q, dtype=np.float32).reshape(144, 1), device="cuda").repeat(1, B).contiguous()
+    torch.manual_seed(0)
+    m = RNN(60, 64, 1, 24, torch.device("cpu"))
+    eng.load_gru(flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    mm = torch.stack([torch.full((60,), -60.0), torch.full((60,), 60.0)]).cuda()    # fitted-noise omega_z reaches +-55
+    x, P = d["x0"].clone(), P0.clone()
+    fz = eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], cp, d["accel"], mm, x, P, two_kernel=False)
+    assert eng.kernel_name("fused").startswith("fused_kf_gru_kernel_v2")
+    x, P = d["x0"].clone(), P0.clone()
+    sy = eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], cp, x, P)
+    assert eng.kernel_name("kf") == "kf_run_sym_kernel"
+    sl = torch.arange(2048, 2048 + 4096, device="cuda")                             # covers exact-start trajectories too
+    g4 = lambda k: d[k][:, :, sl].contiguous()
+    xs, Ps = d["x0"][:, sl].contiguous(), P0[:, sl].contiguous()
+    rw = eng.kf_run(g4("p"), g4("f"), g4("dp"), g4("imu"), cp[:, sl].contiguous(), xs, Ps)
+    assert eng.kernel_name("kf") == "kf_run_rows_kernel"
+    torch.cuda.synchronize()
+    for r in (fz, sy, rw):
+        assert int((r["status"] != 0).sum()) == 0 and torch.isfinite(r["x_out"]).all()
+    # the two lane kernels run the same arithmetic on the filter state
+    assert (fz["x_out"] - sy["x_out"]).abs().max().item() < 2e-5
+    n_exact = _hostile_exact_starts(B)[-1][1]
+    pick = torch.cat([torch.arange(n_exact), n_exact + torch.randperm(B - n_exact, generator=torch.Generator().manual_seed(9))[:16384 - 4096],
+                      ]).unique().cuda()
+    orc.set_threads(orc.max_threads())
+    g = lambda k: d[k][:, :, pick].permute(2, 0, 1).double().cpu().numpy()
+    n = int(pick.numel())
+    ref = orc.kf_run_batch(g("p"), g("f"), g("dp"), g("imu"), d["contact"][:, :, pick].permute(2, 0, 1).contiguous().cpu().numpy(),
+                           d["x0"][:, pick].t().double().cpu().numpy(), np.tile(Q, (n, 1, 1)), Q, R)
+    orc.set_threads(1)
+    assert int(ref["status"].sum()) == 0
+    for name, r in (("fused_v2", fz), ("sym", sy)):
+        err = np.abs(r["x_out"][:, :, pick].permute(2, 0, 1).cpu().numpy() - ref["x"])
+        assert err.max() < 1e-4, (name, float(err.max()), np.unravel_index(int(err.argmax()), err.shape))
+    # rows kernel: its slice against the oracle rows of the same trajectories
+    pos = {int(v): i for i, v in enumerate(pick.cpu().tolist())}
+    both = [v for v in sl.cpu().tolist() if v in pos]
+    assert len(both) > 1500
+    a = rw["x_out"][:, :, torch.tensor([v - 2048 for v in both], device="cuda")].permute(2, 0, 1).cpu().numpy()
+    b = ref["x"][[pos[v] for v in both]]
+    assert np.abs(a - b).max() < 1e-4, float(np.abs(a - b).max())
+    # GRU head of the fused kernel on the oracle's feature rows
+    rows = np.concatenate([ref["x"], g("accel"), g("f"), ref["p_rot"], g("dp"), g("imu")], axis=2)
+    orc.set_threads(orc.max_threads())
+    ro, _, _ = orc.gru_forward((rows + 60.0) / 120.0, orc.flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    orc.set_threads(1)
+    assert np.abs(fz["out"][pick].cpu().numpy() - ro).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[1]: Kalman only, B = 4096, T = 1000 (default dispatch = the 16-lanes-per-trajectory kernel)
 # ------------------------------------------------------------------------------------------------------------------
 def test_config2_kf_4096x1000_oracle_sample_and_slice_independence():

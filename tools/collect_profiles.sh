@@ -4,11 +4,12 @@
 # bench lines.  usage: tools/collect_profiles.sh <tag>
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG
+export GRAFT_REPO_ROOT=$R          # the sub-scripts below resolve their paths from it
 mkdir -p $O
 cd $R
 bash tools/traffic_pass.sh > $O/traffic_pass.log 2>&1
 python3 tools/traffic_to_json.py > $O/traffic.json 2>> $O/traffic_pass.log
-cp profiles/traffic.json $O/traffic_profiles.json
+[ -s $O/traffic.json ] && cp profiles/traffic.json $O/traffic_profiles.json
 python3 bench.py > $O/bench.json 2> $O/bench.err
 stats() {   # $1 = name, rest = bench args
   n=$1; shift

@@ -2,6 +2,7 @@
 # usage: tools/pmc_any.sh <tag> "<counters...>" <python-script> [args...]   -- one rocprofv3 --pmc pass, per-kernel means
 TAG=$1; CNT=$2; shift 2
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CNT --output-format csv -d $OUT -- python3 "$@" > $OUT.log 2>&1
 python3 - <<PY

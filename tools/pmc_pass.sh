@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage: tools/pmc_pass.sh <tag> "<counters...>"   -- one rocprofv3 --pmc pass over tools/run_fused_once.py
 TAG=$1; shift
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_$TAG
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $@ --output-format csv -d $OUT -- python3 $R/tools/run_fused_once.py 2 > $OUT.log 2>&1
 tail -2 $OUT.log

@@ -1,8 +1,9 @@
 #!/bin/bash
 # HBM traffic of the bench kernels from PMC counters, one counter per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do
 # not fit one pass), plus the calibration kernels with known byte counts.
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/traffic
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/traffic
 mkdir -p $OUT
+rm -f $OUT/traffic_raw.json          # never leave a stale result for traffic_to_json.py to pick up
 [ -x $R/tools/micro/traffic_cal ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/micro/traffic_cal.hip -o $R/tools/micro/traffic_cal
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -10,7 +10,12 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-raw = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "traffic", "traffic_raw.json")))
+raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "traffic", "traffic_raw.json")
+if not os.path.exists(raw_path):        # tools/traffic_pass.sh deletes the previous result first: a failed pass must not publish stale traffic
+    sys.exit(f"traffic_to_json: {raw_path} is missing (did tools/traffic_pass.sh fail?)")
+raw = json.load(open(raw_path))
+if "rd_dword" not in raw or "wr_dword" not in raw:
+    sys.exit("traffic_to_json: calibration kernels missing from the raw counters")
 GiB_KiB = float(1 << 20)
 fr = raw["rd_dword"]["FETCH_SIZE"] / GiB_KiB
 wr = raw["wr_dword"]["WRITE_SIZE"] / GiB_KiB
