@@ -159,6 +159,11 @@ size_t os_gru_param_count(const os_gru_dims *d);
 /* Replaces model.load_state_dict(...) (gru/gru_test.py:160): w_flat is a DEVICE float vector in the flat
  * layout above; the library re-packs it into MFMA fragment order in context scratch. */
 int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream);
+/* The same with a caller-chosen key != 0 naming (these weights, in this state): the context keeps the packed images of the
+ * four most recently used keys, so models that alternate on one context (the ensemble of gru/gru_train.py:205-217,
+ * `num_models`) are re-selected without re-packing.  The caller must use a NEW key whenever the weights behind w_flat
+ * change (and keep w_flat alive while the key is in use); os_gru_generation counts the packs actually done. */
+int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, uint64_t key, void *stream);
 /* Counts os_gru_load calls on this context.  A context holds ONE loaded model; a host-side weight container that shares
  * a context with others (several RNN modules on one GPU, gru/gru_train.py:205-217 trains num_models of them) compares
  * this with the value it saw after its own load to know whether its weights are still the resident ones. */

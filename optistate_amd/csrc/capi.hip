@@ -84,7 +84,9 @@ void os_destroy(os_ctx *ctx)
     os_train_destroy(ctx);
     os_step_destroy(ctx);
     os_vit_destroy(ctx);
-    float *bufs[] = {ctx->gru_packed, ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
+    for (auto &sl : ctx->gru_slots)
+        if (sl.packed) (void)hipFree(sl.packed);
+    float *bufs[] = {ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)

@@ -636,7 +636,9 @@ size_t os_gru_param_count(const os_gru_dims *d)
     return n + (size_t)d->num_classes * d->hidden_size + d->num_classes;
 }
 
-int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream)
+// key != 0: the caller's name for (these weights, in this state).  A slot holding the same key, dimensions and flat pointer is
+// re-selected without packing; otherwise the least recently used of the four slots is (re)packed.  key == 0: always pack.
+int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, uint64_t key, void *stream)
 {
     OS_CHECK_CTX(ctx);
     if (!d || !w_flat) return os_fail(ctx, -2, "os_gru_load: null pointer");
@@ -645,27 +647,45 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
     if (d->input_size <= 0 || d->num_layers <= 0 || d->num_layers > 16 || d->num_classes <= 0 || d->num_classes > 256)
         return os_fail(ctx, -4, "os_gru_load: unsupported dimensions");
     OS_HIP(ctx, hipSetDevice(ctx->device));
-    size_t total = 0;
-    for (int l = 0; l < d->num_layers; l++) total += os_layer_packed_floats(l == 0 ? d->input_size : H, H);
-    if (os_ensure_scratch(ctx, &ctx->gru_packed, &ctx->gru_packed_floats, total)) return -10;
-    size_t src = 0, dst = 0;
-    PackAll pa;
-    pa.n = d->num_layers; pa.H = H;
-    for (int l = 0; l < d->num_layers; l++) {
-        const int K = l == 0 ? d->input_size : H;
-        pa.K[l] = K;
-        pa.Wih[l] = w_flat + src; pa.Whh[l] = pa.Wih[l] + (size_t)3 * H * K; pa.bih[l] = pa.Whh[l] + (size_t)3 * H * H; pa.bhh[l] = pa.bih[l] + 3 * H;
-        pa.dst[l] = ctx->gru_packed + dst;
-        src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;
-        dst += os_layer_packed_floats(K, H);
+    os_ctx::GruSlot *slot = nullptr;
+    if (key)
+        for (auto &sl : ctx->gru_slots)
+            if (sl.packed && sl.key == key && sl.flat == w_flat && memcmp(&sl.d, d, sizeof(*d)) == 0) slot = &sl;
+    const bool hit = slot != nullptr;
+    if (!hit) {
+        slot = &ctx->gru_slots[0];
+        for (auto &sl : ctx->gru_slots)
+            if (sl.stamp < slot->stamp) slot = &sl;           // an empty slot has stamp 0
+        size_t total = 0;
+        for (int l = 0; l < d->num_layers; l++) total += os_layer_packed_floats(l == 0 ? d->input_size : H, H);
+        if (os_ensure_scratch(ctx, &slot->packed, &slot->cap, total)) return -10;
+        size_t src = 0, dst = 0;
+        PackAll pa;
+        pa.n = d->num_layers; pa.H = H;
+        for (int l = 0; l < d->num_layers; l++) {
+            const int K = l == 0 ? d->input_size : H;
+            pa.K[l] = K;
+            pa.Wih[l] = w_flat + src; pa.Whh[l] = pa.Wih[l] + (size_t)3 * H * K; pa.bih[l] = pa.Whh[l] + (size_t)3 * H * H; pa.bhh[l] = pa.bih[l] + 3 * H;
+            pa.dst[l] = slot->packed + dst;
+            src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;
+            dst += os_layer_packed_floats(K, H);
+        }
+        hipLaunchKernelGGL(gru_pack_all_kernel, dim3(H / 32, 16, d->num_layers), dim3(256), 0, (hipStream_t)stream, pa);
+        OS_HIP(ctx, hipGetLastError());
+        slot->key = key; slot->d = *d; slot->flat = w_flat;
+        ctx->gru_generation++;                                  // counts packs (os_gru_generation): a cache hit does not bump it
     }
-    hipLaunchKernelGGL(gru_pack_all_kernel, dim3(H / 32, 16, d->num_layers), dim3(256), 0, (hipStream_t)stream, pa);
-    OS_HIP(ctx, hipGetLastError());
+    slot->stamp = ++ctx->gru_clock;
+    ctx->gru_packed = slot->packed;
     ctx->gru = *d;
     ctx->gru_flat = w_flat;
     ctx->gru_loaded = true;
-    ctx->gru_generation++;
     return 0;
+}
+
+int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream)
+{
+    return os_gru_load_keyed(ctx, d, w_flat, 0, stream);
 }
 
 }  // extern "C"

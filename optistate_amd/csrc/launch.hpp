@@ -36,8 +36,11 @@ struct os_ctx {
     // GRU state (owned scratch)
     os_gru_dims gru;
     bool gru_loaded;
-    float *gru_packed;        // device: weights re-packed into MFMA fragment order
-    size_t gru_packed_floats;
+    float *gru_packed;        // device: weights re-packed into MFMA fragment order (the active slot of gru_slots)
+    // LRU of packed images (os_gru_load_keyed): an ensemble of models alternating on one context (gru_train.py:205-217
+    // `num_models`) re-selects its image instead of re-packing it on every forward
+    struct GruSlot { uint64_t key; os_gru_dims d; const float *flat; float *packed; size_t cap; uint64_t stamp; } gru_slots[4];
+    uint64_t gru_clock;
     const float *gru_flat;    // caller-owned flat weights (kept for the head / biases)
     float *gru_seq;  size_t gru_seq_floats;   // inter-layer sequences [T][H][B] x2 + h_last
     float *gru_xs;   size_t gru_xs_floats;    // SoA copy of a (B,T,I) input

@@ -42,6 +42,9 @@ class Engine:
         self._gru_owner = None     # who loaded the resident GRU weights (a context holds ONE model: see load_gru)
         self._diag_R = True
         self._sym_Q = True
+        self._keyed_flats = {}
+        self._next_key = 0
+        self._inval_epoch = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -165,24 +168,36 @@ class Engine:
         return dict(x_out=x_out, status=status, p_rot=p_rot, P_trace=ptr)
 
     # ---- GRU ----
-    def load_gru(self, flat, input_size, hidden_size, num_layers, num_classes, use_sigmoid=True, owner=None):
+    def load_gru(self, flat, input_size, hidden_size, num_layers, num_classes, use_sigmoid=True, owner=None, key=0):
         """flat: 1-D float32 device tensor in the flat layout of the header (see flatten_state_dict).
-        A context holds ONE loaded model; `owner` records who loaded it so that several weight containers sharing this
-        engine (two RNN modules on one GPU, a trainer and its model) can tell whether their weights are the resident ones."""
+        A context runs ONE model at a time; `owner` records who selected it so that several weight containers sharing this
+        engine (two RNN modules on one GPU, a trainer and its model) can tell whether their weights are the active ones.
+        key != 0 (a name for these weights in this state, new_gru_key()): the library keeps the packed images of the four
+        most recently used keys, so alternating models are re-selected without re-packing (os_gru_load_keyed)."""
         d = _capi.OsGruDims(input_size, hidden_size, num_layers, num_classes, 1 if use_sigmoid else 0)
         n = self.lib.os_gru_param_count(C.byref(d))
         flat = flat.to(self.device, dtype=torch.float32).contiguous()
         if flat.numel() != n:
             raise ValueError(f"flat weight vector has {flat.numel()} floats, expected {n}")
-        self._check(self.lib.os_gru_load(self._h, C.byref(d), _ptr(flat), self._stream()), "os_gru_load")
+        self._check(self.lib.os_gru_load_keyed(self._h, C.byref(d), _ptr(flat), int(key), self._stream()), "os_gru_load")
         self._gru_flat, self._gru_dims, self._gru_owner = flat, d, owner
+        if key:
+            self._keyed_flats[int(key)] = flat                 # keep every cached image's flat weights alive (head / biases read them)
+            while len(self._keyed_flats) > 8:
+                self._keyed_flats.pop(next(iter(self._keyed_flats)))
+
+    def new_gru_key(self):
+        self._next_key += 1
+        return self._next_key
 
     def gru_generation(self):
         return int(self.lib.os_gru_generation(self._h))
 
     def invalidate_gru(self):
-        """The flat weights were modified in place (optimiser step): whoever runs next must load again."""
+        """The flat weights were modified in place (optimiser step; torch's version counters did not move): whoever runs
+        next must flatten and pack again, cached images included."""
         self._gru_owner = None
+        self._inval_epoch += 1
 
     def gru_forward(self, x_bti, want_h_last=False):
         """RNN.forward on x (B, T, I) -> (B, C)  (gru/gru_model.py:25-49)."""

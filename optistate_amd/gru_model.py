@@ -23,6 +23,7 @@ class RNN(nn.Module):
         self.use_sigmoid = use_sigmoid
         self.sigmoid = nn.Sigmoid()
         self._loaded_versions = None
+        self._epoch = -1
         self._engine = None
 
     def _sync_weights(self, dev):
@@ -33,11 +34,16 @@ class RNN(nn.Module):
         # a context holds ONE model, so two RNN instances on one GPU, or a trainer updating the flat bucket in place,
         # must not leave this module running on foreign / stale packed weights
         versions = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if versions != self._loaded_versions or self._engine._gru_owner is not self:
-            flat = flatten_state_dict(self.state_dict(), self.num_layers, device=dev)
-            self._engine.load_gru(flat, self.input_size, self.hidden_size, self.num_layers, self.num_classes,
-                                  self.use_sigmoid, owner=self)
-            self._loaded_versions = versions
+        if versions != self._loaded_versions or self._epoch != self._engine._inval_epoch:
+            # new weights: flatten once and give them a new key; while they stay unchanged, coming back to this module after
+            # another one ran (an ensemble alternating on one GPU, gru_train.py:205-217) re-selects the cached packed image
+            self._flat = flatten_state_dict(self.state_dict(), self.num_layers, device=dev)
+            self._key = self._engine.new_gru_key()
+            self._loaded_versions, self._epoch = versions, self._engine._inval_epoch
+            self._engine._gru_owner = None
+        if self._engine._gru_owner is not self:
+            self._engine.load_gru(self._flat, self.input_size, self.hidden_size, self.num_layers, self.num_classes,
+                                  self.use_sigmoid, owner=self, key=self._key)
 
     def forward(self, x):
         if not x.is_cuda:

@@ -46,6 +46,7 @@ class Kalman_Filter:
         self.dt = 0.01
         self.x_model = self.x.copy()
         self.f = np.zeros((12, 5))
+        self._buffers()
 
     # -- helpers --
     # Every method is ONE os_kf_step call: the library copies the float64 arrays into its pinned, device-mapped staging
@@ -53,51 +54,59 @@ class Kalman_Filter:
     # (no torch tensors, no hipMemcpy: B = 1 is pure latency).
     _MODEL = np.array([0.01, 8.8, 55303643.08 / 1e9, 60119440.34 / 1e9, 105304340.05 / 1e9, -9.81])   # settings.py:5-23, :56
 
-    @staticmethod
-    def _d(a):
-        return a.ctypes.data_as(C.POINTER(C.c_double))
-
-    @staticmethod
-    def _c64(a, n):
-        return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1)[:n])
+    def _buffers(self):
+        """Per-instance staging arrays and their ctypes pointers, made once: a step then costs a few small copies and ONE
+        foreign call (at B = 1 the Python side is as much of the latency as the launch)."""
+        dp = C.POINTER(C.c_double)
+        b = {k: np.zeros(n) for k, n in (("x", 12), ("P", 144), ("z", 10), ("p", 12), ("f", 12), ("dp", 12), ("imu", 6), ("br", 12),
+                                          ("Q", 144), ("R", 100), ("prot", 12), ("xm", 12), ("K", 120), ("pt", 1), ("kg", 1))}
+        b["c"] = np.zeros(4, dtype=np.uint8)
+        b["st"] = np.zeros(1, dtype=np.int32)
+        b["model"] = self._MODEL.copy()
+        ptr = {k: v.ctypes.data_as(dp) for k, v in b.items() if v.dtype == np.float64}
+        ptr["c"] = b["c"].ctypes.data_as(C.POINTER(C.c_uint8))
+        ptr["st"] = b["st"].ctypes.data_as(C.POINTER(C.c_int32))
+        self._b, self._ptr = b, ptr
 
     def _step(self, what, p=None, f=None, dp=None, imu=None, contact=None, body_ref=None, want_K=False):
-        """One launch of the fused step kernel; returns (p_rot or None).  Reads / writes self.x, self.P, self.z."""
+        """One launch of the step kernel on self.x, self.P, self.z (read and written as `what` says); returns the
+        world-rotated p (a view of a staging array: copy it if you keep it)."""
         e = self._eng
-        lib = e.lib
-        x = self._c64(self.x, 12); P = self._c64(self.P, 144); z = self._c64(self.z, 10)
-        Q = self._c64(self.Q, 144); R = self._c64(self.R, 100)
-        pc = None if p is None else self._c64(p, 12)
-        fc = None if f is None else self._c64(f, 12)
-        dpc = None if dp is None else self._c64(dp, 12)
-        ic = None if imu is None else self._c64(imu, 6)
-        br = None if body_ref is None else self._c64(body_ref, 12)
-        cc = None if contact is None else np.ascontiguousarray(np.asarray(contact).reshape(-1)[:4].astype(np.uint8))
-        p_rot = np.empty(12); x_model = np.empty(12)
-        K = np.empty(120) if want_K else None
-        ptrace, kgain, status = C.c_double(np.nan), C.c_double(np.nan), C.c_int32(0)
-        ptr = lambda a: None if a is None else self._d(a)
-        rc = lib.os_kf_step(e._h, what, self._d(self._MODEL), ptr(pc), ptr(fc), ptr(dpc), ptr(ic),
-                            None if cc is None else cc.ctypes.data_as(C.POINTER(C.c_uint8)), ptr(br), self._d(Q), self._d(R),
-                            self._d(x), self._d(P), self._d(z), self._d(p_rot), self._d(x_model), ptr(K),
-                            C.byref(ptrace), C.byref(kgain), C.byref(status), e._stream())
-        e._check(rc, "os_kf_step")
+        b, q = self._b, self._ptr
+        b["x"][:] = np.asarray(self.x, dtype=np.float64).reshape(-1)
+        b["P"][:] = np.asarray(self.P, dtype=np.float64).reshape(-1)
+        b["Q"][:] = np.asarray(self.Q, dtype=np.float64).reshape(-1)
+        b["R"][:] = np.asarray(self.R, dtype=np.float64).reshape(-1)
+        if not what & OS_STEP_ODOM:
+            b["z"][:] = np.asarray(self.z, dtype=np.float64).reshape(-1)
+        for key, v, n in (("p", p, 12), ("f", f, 12), ("dp", dp, 12), ("imu", imu, 6), ("br", body_ref, 12)):
+            if v is not None:
+                b[key][:] = np.asarray(v, dtype=np.float64).reshape(-1)[:n]
+        if contact is not None:
+            b["c"][:] = np.asarray(contact).reshape(-1)[:4]
+        rc = e.lib.os_kf_step(e._h, what, q["model"], q["p"] if p is not None else None, q["f"] if f is not None else None,
+                              q["dp"] if dp is not None else None, q["imu"] if imu is not None else None,
+                              q["c"] if contact is not None else None, q["br"] if body_ref is not None else None, q["Q"], q["R"],
+                              q["x"], q["P"], q["z"], q["prot"], q["xm"], q["K"] if want_K else None, q["pt"], q["kg"], q["st"],
+                              e._stream())
+        if rc:
+            e._check(rc, "os_kf_step")
         if what & OS_STEP_ODOM:
-            self.z = z.reshape(10, 1)
+            self.z = b["z"].reshape(10, 1).copy()
         if what & OS_STEP_PREDICT:
-            self.x = x.reshape(12, 1); self.P = P.reshape(12, 12)
-            self.x_model = x_model.reshape(12, 1)
+            self.x = b["x"].reshape(12, 1).copy(); self.P = b["P"].reshape(12, 12).copy()
+            self.x_model = b["xm"].reshape(12, 1).copy()
             if not (what & OS_STEP_DENSE_FD):
-                self.P_trace = float(ptrace.value)                    # predict_mpc leaves P_trace alone (kalman_filter.py:140-162)
+                self.P_trace = float(b["pt"][0])                      # predict_mpc leaves P_trace alone (kalman_filter.py:140-162)
         if what & OS_STEP_UPDATE:
-            if status.value & 1:
+            if b["st"][0] & 1:
                 # the reference's np.linalg.inv raises here (kalman_filter.py:168)
                 raise np.linalg.LinAlgError("Singular matrix")
-            self.x = x.reshape(12, 1); self.P = P.reshape(12, 12)
+            self.x = b["x"].reshape(12, 1).copy(); self.P = b["P"].reshape(12, 12).copy()
             if want_K:
-                self.K = K.reshape(12, 10)
-            self.P_trace = float(ptrace.value); self.K_gain = float(kgain.value)
-        return p_rot
+                self.K = b["K"].reshape(12, 10).copy()
+            self.P_trace = float(b["pt"][0]); self.K_gain = float(b["kg"][0])
+        return b["prot"]
 
     def rotation_matrix_body_world(self, thx, thy, thz):
         # closed form of Rz Ry Rx (kalman_filter.py:184-193); host helper, not on the hot path

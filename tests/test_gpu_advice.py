@@ -274,3 +274,30 @@ def test_backward_refuses_sizes_beyond_its_32_bit_buffer_offsets():
     # dummy pointers either -- a null x is refused first
     rc = eng.lib.os_gru_backward_ws(eng._h, C.byref(d), ptr, 2 * 1024 * 1024 - 1, 1, None, ptr, ptr, ptr, ptr, None, eng._stream())
     assert rc == -2 and b"32-bit" not in eng.lib.os_last_error(eng._h)
+
+
+def test_alternating_models_reselect_their_packed_image_instead_of_repacking():
+    """gru_train.py:205-217 trains / evaluates `num_models` networks: models alternating on one context are re-selected from
+    the library's LRU of packed images (os_gru_load_keyed), a changed model is packed again, a fifth model evicts the least
+    recently used one -- and every forward still runs on the right weights."""
+    from optistate_amd import RNN
+    torch.manual_seed(3)
+    ms = [RNN(60, 64, 1, 24, torch.device("cuda")).to("cuda") for _ in range(5)]
+    x = torch.rand(7, 10, 60).cuda()
+    eng = None
+    with torch.no_grad():
+        outs = [m(x) for m in ms[:3]]
+        eng = ms[0]._engine
+        g0 = eng.gru_generation()
+        for _ in range(3):                                             # A, B, C, A, B, C, ...: no pack at all
+            for m, o in zip(ms[:3], outs):
+                assert torch.equal(m(x), o)
+        assert eng.gru_generation() == g0
+        ms[1].fc.bias.add_(0.5)                                        # torch bumps the version: new key, one pack
+        o1 = ms[1](x)
+        assert eng.gru_generation() == g0 + 1 and (o1 - outs[1]).abs().max().item() > 1e-3
+        assert np.abs(o1.cpu().numpy() - _ref_out(ms[1], x)).max() < 1e-5
+        assert torch.equal(ms[0](x), outs[0]) and torch.equal(ms[2](x), outs[2]) and eng.gru_generation() == g0 + 1
+        for m in ms:                                                   # five models through four slots: still correct
+            assert np.abs(m(x).cpu().numpy() - _ref_out(m, x)).max() < 1e-5
+        assert eng.gru_generation() > g0 + 1

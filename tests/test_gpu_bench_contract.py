@@ -36,7 +36,14 @@ def test_default_mode_contract():
     assert abs(d["value"] - 4096 * 20 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
     # the metric's second half: state l-inf of the timed batch vs the CPU reference, outside the timed region
     pa = d["parity"]
-    assert pa["trajectories"] == 128 and pa["state_linf"] < 1e-4 and pa["gru_linf"] < 1e-4 and pa["ok"] is True
+    # ... over EVERY (trajectory, timestep) of the timed batch, the oracle run doubling as the all-cores baseline
+    assert pa["trajectories"] == 4096 and pa["whole_tensor"] is True and pa["timesteps_each"] == 20
+    assert pa["state_linf"] < 1e-4 and pa["gru_linf"] < 1e-4 and pa["ok"] is True
+    assert "TIMED batch" in cb["sample"]
+    # the second Q / R set of SURVEY 8(d) rides along (Q_R.pkl values with R[0:3] = 1e-4)
+    sn = d["second_noise_set"]
+    assert "Q_R.pkl" in sn["noise"] and sn["parity"]["ok"] is True and sn["parity"]["trajectories"] == 4096 and sn["value"] > 0
+    assert "settings.py" in d["config"]["noise"]
     assert cb["reference_python_steps_per_s"] == 3.05e3
     assert d["rccl_world_size"] == 1 and d["rank_devices"][0]["device"] == 0
     # B = 4096 takes the two-kernel path: the line names the kernels that actually ran

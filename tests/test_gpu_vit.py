@@ -1,5 +1,7 @@
-"""GPU: ViT-encoder latent (optional row A10 / config 5).  PARITY UNPINNED with respect to the reference (timm 0.3.2 and
-the trained weights are absent): the HIP path is compared with this repo's own float64 restatement (oracle/vit_oracle.py)."""
+"""GPU: ViT-encoder latent (optional row A10 / config 5).  The transformer BLOCKS are parity unpinned with respect to the
+reference (timm 0.3.2 and the trained weights are absent): the HIP path is compared with this repo's own float64
+restatement (oracle/vit_oracle.py).  The reference-owned GLUE around them (forward_encoder, initialize_weights) is pinned by
+G11: the reference's own class run with a timm stand-in (tests/test_vit_glue_golden.py explains the label)."""
 import numpy as np
 import pytest
 import torch
@@ -24,6 +26,23 @@ def test_encoder_latent_matches_float64_restatement():
     err = np.abs(lat.cpu().numpy()[:, 0] - ref).max()
     assert err < 2e-5, err
     assert 0.0 < lat.min().item() and lat.max().item() < 1.0
+
+
+def test_hip_encoder_matches_the_reference_glue_fixture_g11():
+    """G11 ("blocks = stand-in, glue = reference"): the reference's Transformer_Autoencoder.forward_encoder
+    (transformer/transformer_model.py:113-135) on 8 seeded frames under seeded weights; the HIP encoder gets the same weights
+    through the reference's state_dict keys (load_state_dict) and must reproduce the latents."""
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    from conftest import load_golden
+    from golden_recipes import g11_encoder_state, g11_frames
+    g = load_golden("vit_g11_glue.npz")
+    m = Transformer_Autoencoder()
+    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in g11_encoder_state().items()}, strict=False)
+    assert res.missing_keys == ["pos_embed"] and not res.unexpected_keys          # the fixed table is the constructor's (= G10)
+    m = m.to("cuda")
+    lat = m.forward_encoder(torch.from_numpy(g11_frames()).unsqueeze(1).cuda())[:, 0].cpu().numpy()
+    assert np.abs(lat - g["latent_f64"]).max() < 2e-5, np.abs(lat - g["latent_f64"]).max()
+    assert np.abs(lat - g["latent_f32"]).max() < 2e-5
 
 
 def test_pos_embed_table_and_state_dict_keys():

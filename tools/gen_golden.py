@@ -20,6 +20,12 @@ The files written are DATA (inputs + the reference's outputs), float64 unless no
   gru_g6_train.npz    G6  one Adam step (loss, target, post-step fc.bias) with gru_train.py's loop body
   vit_g10_pos_embed.npz G10 the fixed 2-D sin-cos position table of the ViT encoder: transformer/pos_embed.py imported
                           unmodified (it needs only numpy/torch), called as transformer_model.py:66 does
+  vit_g11_glue.npz    G11 "blocks = stand-in, glue = reference": the reference's own Transformer_Autoencoder
+                          (transformer/transformer_model.py, imported unmodified) with tools/timm_standin.py providing the two
+                          timm 0.3.2 classes it imports: forward_encoder latents of 8 seeded frames under seeded weights
+                          (tests/golden_recipes.py rebuilds both from the seed), float32 as the reference runs and float64;
+                          plus what initialize_weights (:54-82) leaves in a freshly constructed instance (seed 0):
+                          position table, bias / LayerNorm constants, Xavier bounds, cls-token statistics
 """
 import copy
 import os
@@ -288,12 +294,59 @@ def g10():
     np.savez_compressed(os.path.join(OUT, "vit_g10_pos_embed.npz"), enc_128_14=enc, dec_64_14=dec, small_32_5=small)
 
 
+def g11():
+    """The reference-owned glue of the optional ViT row (A10), pinned through the reference's own class."""
+    import torch
+    import timm_standin
+    standin = timm_standin.install()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_recipes import g11_encoder_state, g11_frames, G11_SEED
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from transformer.transformer_model import Transformer_Autoencoder as RefViT
+    # (a) initialisation as the reference leaves it
+    torch.manual_seed(0)
+    m = RefViT()
+    sd0 = {k: v.detach().double().numpy() for k, v in m.state_dict().items()}
+    enc_keys = [k for k in sd0 if not k.startswith("decoder")]
+    lin_w = [k for k in enc_keys if k.endswith(".weight") and sd0[k].ndim == 2]
+    init = dict(
+        init_pos_embed=sd0["pos_embed"][0],
+        init_bias_absmax=np.array([max(np.abs(sd0[k]).max() for k in enc_keys if k.endswith(".bias") and not k.startswith("patch_embed"))]),
+        # _init_weights (:71-82) touches nn.Linear and nn.LayerNorm only: the Conv2d bias keeps torch's default U(-1/sqrt(fan_in), ..)
+        init_patch_bias_absmax_over_bound=np.array([np.abs(sd0["patch_embed.proj.bias"]).max() * 16.0]),
+        init_ln_weight_dev=np.array([max(np.abs(sd0[k] - 1).max() for k in enc_keys if "norm" in k and k.endswith("weight"))]),
+        init_linear_absmax_over_bound=np.array([np.abs(sd0[k]).max() / np.sqrt(6.0 / sum(sd0[k].shape)) for k in lin_w]),
+        init_linear_keys=np.array(lin_w),
+        init_patch_absmax_over_bound=np.array([np.abs(sd0["patch_embed.proj.weight"]).max() / np.sqrt(6.0 / (256 + 128))]),
+        init_cls_std=np.array([sd0["cls_token"].std()]),
+        init_encoder_keys=np.array(sorted(enc_keys)),
+        init_encoder_shapes=np.array([str(tuple(sd0[k].shape)) for k in sorted(enc_keys)]))
+    # (b) forward_encoder under seeded weights, float32 (as the reference runs it) and float64
+    w = g11_encoder_state()
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    assert all(k.startswith("decoder") or k == "pos_embed" for k in missing.missing_keys), missing.missing_keys
+    assert not missing.unexpected_keys
+    fr = torch.from_numpy(g11_frames()).unsqueeze(1)
+    m.eval()
+    with torch.no_grad():
+        lat32 = m.forward_encoder(fr).numpy()
+        lat64 = m.double().forward_encoder(fr.double()).numpy()
+    assert lat32.shape == (8, 1, 128)
+    np.savez_compressed(os.path.join(OUT, "vit_g11_glue.npz"), latent_f32=lat32[:, 0], latent_f64=lat64[:, 0], seed=np.array([G11_SEED]),
+                        blocks=np.array(["tools/timm_standin.py (timm 0.3.2 as published)" if standin else "timm " + __import__("timm").__version__]),
+                        **init)
+    print("G11: |f32 - f64| max", np.abs(lat32 - lat64).max(), "latent range", lat64.min(), lat64.max())
+
+
 if __name__ == "__main__":
     if "--g9-only" in sys.argv:
         g9()
+    elif "--g11-only" in sys.argv:
+        g11()
     elif "--g10-only" in sys.argv:
         g10()
     else:
-        g1(); g2(); g3_g7(); g4(); g8(); g5_g6(); g9(); g10()
+        g1(); g2(); g3_g7(); g4(); g8(); g5_g6(); g9(); g10(); g11()
     for fn in sorted(os.listdir(OUT)):
         print(f"{fn:28s} {os.path.getsize(os.path.join(OUT, fn)) / 1024:9.1f} KiB")
