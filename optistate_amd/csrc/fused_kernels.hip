@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
 
 
 // =====================================================================================================================
+// element i = 3 leg + component of a per-leg quantity stored as leg pairs (StepInP, kf_device.hpp); state element i of the pairs
+#define OSF_LEG(v, i) (v)[((i) / 3) >> 1][(i) % 3][((i) / 3) & 1]
+#define OSF_X(i) X[(i) >> 1][(i) & 1]
+
 // fused_kf_gru_kernel_v2 -- the same path with the GRU cell TRANSPOSED and the hidden state in registers.
 //
 // gates^T[unit][trajectory] = [W_ih | W_hh] . [x_t | h]^T: the weights are the MFMA A operand (from LDS, one ds_read_b128 per
@@ -357,13 +361,14 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     const int bb = live ? b : k.B - 1;                 // dead lanes shadow the last trajectory, stores masked
     const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
 
-    float x[NS];
+    f2 X[6];                       // the filter state as pairs (x[2i], x[2i+1])
     f2 U[NU];
     int status = 0;
+    bool bad = false;
     {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        for (int i = 0; i < 6; i++) X[i] = (f2){buf_load(rx, voff, 2 * i * rowB), buf_load(rx, voff, (2 * i + 1) * rowB)};
         // status bit 3: P0 not symmetric (the paired triangle reads the upper half only; see include/optistate_hip.h)
         status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
@@ -378,9 +383,9 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
             for (int e = 0; e < 16; e++) hreg[rb][c][e] = agpr_put(0.f);      // h0 = 0 (gru/gru_model.py:27)
 
-    StepIn in;
+    StepInP in;
     float acl[6];
-    load_step(k, 0, voff, rowB, in);
+    load_step_p(k, 0, voff, rowB, in);
     {
         rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
 #pragma unroll
@@ -392,10 +397,11 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         // Order chosen for register pressure: everything that reads the step's 55 input registers runs first (measurement,
         // dynamics, the 48 raw-input features, which go straight to AGPRs); the covariance predict and the update then work
         // with the filter state alone.  (predict's F_d and next_state both use the PRIOR attitude: kalman_filter.py:124,133.)
-        float z[NM], pw[12], FA[KX];
-        measurement(in, z);
-        const Rot rot = rotation(x[0], x[1], x[2]);
-        dynamics(x, rot, in.p, in.f, pw, k.k);
+        float z[NM], FA[KX];
+        f2 PW[2][3];
+        float g9[9];
+        kf_step_inputs_sym(X, in, k.k, z, PW, g9);
+        __builtin_amdgcn_sched_barrier(0);
         // Features [x_post | accel | f | p_world | dp | imu] minus their minimum (the 1/(max-min) scale sits in the packed
         // weights).  v_permlane32_swap turns a feature pair into the two B fragments of its k-pair: afterwards the first
         // register holds trajectories 0-31 (lanes 0-31: feature 2kp, lanes 32-63: feature 2kp+1), the second trajectories
@@ -416,19 +422,21 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
             for (int i = 0; i < 12; i++) FA[j0 + i] = agpr_put(v[i]);
         };
-        feat6(12, acl[0], acl[1], acl[2], acl[3], acl[4], acl[5], in.f[0], in.f[1], in.f[2], in.f[3], in.f[4], in.f[5]);
-        feat6(24, in.f[6], in.f[7], in.f[8], in.f[9], in.f[10], in.f[11], pw[0], pw[1], pw[2], pw[3], pw[4], pw[5]);
-        feat6(36, pw[6], pw[7], pw[8], pw[9], pw[10], pw[11], in.dp[0], in.dp[1], in.dp[2], in.dp[3], in.dp[4], in.dp[5]);
-        feat6(48, in.dp[6], in.dp[7], in.dp[8], in.dp[9], in.dp[10], in.dp[11], in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
+        feat6(12, acl[0], acl[1], acl[2], acl[3], acl[4], acl[5], OSF_LEG(in.f, 0), OSF_LEG(in.f, 1), OSF_LEG(in.f, 2), OSF_LEG(in.f, 3), OSF_LEG(in.f, 4), OSF_LEG(in.f, 5));
+        feat6(24, OSF_LEG(in.f, 6), OSF_LEG(in.f, 7), OSF_LEG(in.f, 8), OSF_LEG(in.f, 9), OSF_LEG(in.f, 10), OSF_LEG(in.f, 11), OSF_LEG(PW, 0), OSF_LEG(PW, 1), OSF_LEG(PW, 2), OSF_LEG(PW, 3), OSF_LEG(PW, 4), OSF_LEG(PW, 5));
+        feat6(36, OSF_LEG(PW, 6), OSF_LEG(PW, 7), OSF_LEG(PW, 8), OSF_LEG(PW, 9), OSF_LEG(PW, 10), OSF_LEG(PW, 11), OSF_LEG(in.dp, 0), OSF_LEG(in.dp, 1), OSF_LEG(in.dp, 2), OSF_LEG(in.dp, 3), OSF_LEG(in.dp, 4), OSF_LEG(in.dp, 5));
+        feat6(48, OSF_LEG(in.dp, 6), OSF_LEG(in.dp, 7), OSF_LEG(in.dp, 8), OSF_LEG(in.dp, 9), OSF_LEG(in.dp, 10), OSF_LEG(in.dp, 11), in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
               in.imu[5]);
-        cov_predict_sym_blk<QDIAG>(U, rot, k.k);
-        status |= update_sequential_sym(x, U, z, k.k);      // non-finite states stay non-finite: checked once after the loop
+        __builtin_amdgcn_sched_barrier(0);          // the inputs are in AGPRs now: the covariance work below starts with their registers free
+        cov_predict_sym_blk<QDIAG>(U, g9, k.k);
+        __builtin_amdgcn_sched_barrier(0);
+        bad |= update_sequential_sym(X, U, z, k.k);      // non-finite states stay non-finite: checked once after the loop
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, OSF_X(i));
         }
-        feat6(0, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], x[11]);
+        feat6(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
 
         // One 32-trajectory column block and one 32-unit chunk at a time: 64 accumulator registers, in VGPRs, where the cell
         // update reads them directly (the weight fragments are simply read from LDS again for each of the four passes).  Chunk
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                     if (rb == 1 && c == 1 && q == KPX) {
                         // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
                         const int tn = (t + 1 < k.T) ? t + 1 : t;
-                        load_step(k, tn, voff, rowB, in);
+                        load_step_p(k, tn, voff, rowB, in);
                         rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
 #pragma unroll
                         for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
@@ -541,11 +549,11 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     }
 
     // ---- final state, status, h_T for the head kernel ----
-    status |= finite_status(x);
+    status |= (bad ? 1 : 0) | finite_status_p(X);
     if (live) {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, OSF_X(i));
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -692,13 +700,14 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
     const int bb = live ? b : k.B - 1;
     const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
 
-    float x[NS];
+    f2 X[6];
     f2 U[NU];
     int status = 0;
+    bool bad = false;
     {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        for (int i = 0; i < 6; i++) X[i] = (f2){buf_load(rx, voff, 2 * i * rowB), buf_load(rx, voff, (2 * i + 1) * rowB)};
         status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
@@ -710,9 +719,9 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
 #pragma unroll
             for (int e = 0; e < 16; e++) hreg[rb][c][e] = agpr_put(0.f);
 
-    StepIn in;
+    StepInP in;
     float acl[6];
-    load_step(k, 0, voff, rowB, in);
+    load_step_p(k, 0, voff, rowB, in);
     {
         rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
 #pragma unroll
@@ -720,10 +729,11 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
     }
 
     for (int t = 0; t < k.T; t++) {
-        float z[NM], pw[12], FA[2][KBX][8];        // FA[rb][kb][j]: feature 16 kb + 8 (lane half) + j of trajectory block rb (AGPRs)
-        measurement(in, z);
-        const Rot rot = rotation(x[0], x[1], x[2]);
-        dynamics(x, rot, in.p, in.f, pw, k.k);
+        float z[NM], FA[2][KBX][8];        // FA[rb][kb][j]: feature 16 kb + 8 (lane half) + j of trajectory block rb (AGPRs)
+        f2 PW[2][3];
+        float g9[9];
+        kf_step_inputs_sym(X, in, k.k, z, PW, g9);
+        __builtin_amdgcn_sched_barrier(0);
         // k-block kb = features 16 kb .. 16 kb + 15; v_permlane32_swap pairs feature j with feature j + 8 of the block, so that
         // the first register serves trajectories 0-31 (lanes 0-31: feature j, lanes 32-63: feature j + 8), the second 32-63
         auto feat8 = [&](int kb, float l0, float l1, float l2, float l3, float l4, float l5, float l6, float l7, float h0, float h1,
@@ -744,20 +754,22 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
             for (int j = 0; j < 8; j++) { FA[0][kb][j] = agpr_put(lo[j]); FA[1][kb][j] = agpr_put(hi[j]); }
         };
         // feature order [x 0-11 | accel 12-17 | f 18-29 | p_world 30-41 | dp 42-53 | imu 54-59 | 60-63 zero padding]
-        feat8(1, acl[4], acl[5], in.f[0], in.f[1], in.f[2], in.f[3], in.f[4], in.f[5], in.f[6], in.f[7], in.f[8], in.f[9], in.f[10],
-              in.f[11], pw[0], pw[1]);
-        feat8(2, pw[2], pw[3], pw[4], pw[5], pw[6], pw[7], pw[8], pw[9], pw[10], pw[11], in.dp[0], in.dp[1], in.dp[2], in.dp[3],
-              in.dp[4], in.dp[5]);
-        feat8(3, in.dp[6], in.dp[7], in.dp[8], in.dp[9], in.dp[10], in.dp[11], in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
+        feat8(1, acl[4], acl[5], OSF_LEG(in.f, 0), OSF_LEG(in.f, 1), OSF_LEG(in.f, 2), OSF_LEG(in.f, 3), OSF_LEG(in.f, 4), OSF_LEG(in.f, 5), OSF_LEG(in.f, 6), OSF_LEG(in.f, 7), OSF_LEG(in.f, 8), OSF_LEG(in.f, 9), OSF_LEG(in.f, 10),
+              OSF_LEG(in.f, 11), OSF_LEG(PW, 0), OSF_LEG(PW, 1));
+        feat8(2, OSF_LEG(PW, 2), OSF_LEG(PW, 3), OSF_LEG(PW, 4), OSF_LEG(PW, 5), OSF_LEG(PW, 6), OSF_LEG(PW, 7), OSF_LEG(PW, 8), OSF_LEG(PW, 9), OSF_LEG(PW, 10), OSF_LEG(PW, 11), OSF_LEG(in.dp, 0), OSF_LEG(in.dp, 1), OSF_LEG(in.dp, 2), OSF_LEG(in.dp, 3),
+              OSF_LEG(in.dp, 4), OSF_LEG(in.dp, 5));
+        feat8(3, OSF_LEG(in.dp, 6), OSF_LEG(in.dp, 7), OSF_LEG(in.dp, 8), OSF_LEG(in.dp, 9), OSF_LEG(in.dp, 10), OSF_LEG(in.dp, 11), in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
               in.imu[5], 0.f, 0.f, 0.f, 0.f);
-        cov_predict_sym_blk<QDIAG>(U, rot, k.k);
-        status |= update_sequential_sym(x, U, z, k.k);
+        __builtin_amdgcn_sched_barrier(0);          // the inputs are in AGPRs now: the covariance work below starts with their registers free
+        cov_predict_sym_blk<QDIAG>(U, g9, k.k);
+        __builtin_amdgcn_sched_barrier(0);
+        bad |= update_sequential_sym(X, U, z, k.k);
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, OSF_X(i));
         }
-        feat8(0, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], x[11], acl[0], acl[1], acl[2], acl[3]);
+        feat8(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11), acl[0], acl[1], acl[2], acl[3]);
 
         // ================= GRU cell: one 32-trajectory block at a time, both unit chunks together =================
 #pragma unroll
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
                          "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
             if (rb == 1) {
                 const int tn = (t + 1 < k.T) ? t + 1 : t;
-                load_step(k, tn, voff, rowB, in);
+                load_step_p(k, tn, voff, rowB, in);
                 rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
 #pragma unroll
                 for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
@@ -862,11 +874,11 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         }
     }
 
-    status |= finite_status(x);
+    status |= (bad ? 1 : 0) | finite_status_p(X);
     if (live) {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, OSF_X(i));
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll

@@ -82,4 +82,45 @@ __device__ __forceinline__ void read_step_lds(const float *lds, int lane, StepIn
     in.contact = __builtin_bit_cast(uint32_t, lds[42 * 64 + lane]);
 }
 
+// The paired form the symmetric-storage kernels consume (StepInP: legs (0,1) and (2,3) side by side).  Row r and row r + 3
+// of a stream are two components of neighbouring legs; from LDS the two dwords of a pair arrive with one ds_read2st64_b32.
+__device__ __forceinline__ void read_step_lds_p(const float *lds, int lane, StepInP &in)
+{
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int r = 6 * q + c;
+            in.p[q][c] = (f2){lds[r * 64 + lane], lds[(r + 3) * 64 + lane]};
+            in.f[q][c] = (f2){lds[(12 + r) * 64 + lane], lds[(12 + r + 3) * 64 + lane]};
+            in.dp[q][c] = (f2){lds[(24 + r) * 64 + lane], lds[(24 + r + 3) * 64 + lane]};
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.imu[i] = lds[(36 + i) * 64 + lane];
+    in.contact = __builtin_bit_cast(uint32_t, lds[42 * 64 + lane]);
+}
+
+// the same from global memory straight into the pairs' halves (fused kernel: 43 loads in flight underneath the GRU cell)
+__device__ __forceinline__ void load_step_p(const KfRunArgs &a, int t, uint32_t voff, uint32_t rowB, StepInP &in)
+{
+    const size_t B = (size_t)a.B;
+    rsrc_t rp = make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t rf = make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t rd = make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB);
+    rsrc_t ri = make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB);
+    rsrc_t rc = make_rsrc(a.contact + (size_t)t * B, rowB);
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const uint32_t r = 6 * q + c;
+            in.p[q][c] = (f2){buf_load_nt(rp, voff, r * rowB), buf_load_nt(rp, voff, (r + 3) * rowB)};
+            in.f[q][c] = (f2){buf_load_nt(rf, voff, r * rowB), buf_load_nt(rf, voff, (r + 3) * rowB)};
+            in.dp[q][c] = (f2){buf_load_nt(rd, voff, r * rowB), buf_load_nt(rd, voff, (r + 3) * rowB)};
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.imu[i] = buf_load_nt(ri, voff, i * rowB);
+    in.contact = buf_load_u32_nt(rc, voff, 0);
+}
+
 }  // namespace osk

@@ -582,86 +582,53 @@ __host__ __device__ constexpr int pidx(int i, int jp) { return prow0(i) + (jp - 
 __device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// (P[k][2jp], P[k][2jp+1]) for any row k: the stored pair where it exists, otherwise gathered through symmetry
-#define OSK_ROWPAIR(U, k, jp) ((jp) >= (k) / 2 ? (U)[pidx((k), (jp))] : (f2){OSK_SYM(U, k, 2 * (jp)), OSK_SYM(U, k, 2 * (jp) + 1)})
 
-// P <- F_d P F_d^T + Q, F_d = I + G with G[0:3,6:9] = dt R^T, G[3:6,9:12] = dt I (kalman_filter.py:124-135):
-//   P' = P + M + M^T + M G^T,  M = G P (rows 0..5 only).
-template <bool QDIAG>
-__device__ __forceinline__ void cov_predict_sym(f2 *U, const Rot &r, const KfConst &k)
+// (a[IA], b[IB]) in ONE instruction: v_pk_mov_b32 picks a half of each source pair (op_sel bit set = upper half).  hipcc
+// builds such a pair with two v_mov_b32 more often than not, and the ~50 pairs a filter step assembles across the diagonal of
+// the triangle were ~100 of its instructions.  Inline asm is invisible to hipcc's hazard recogniser; the only VALU hazard
+// that could apply here (a transcendental result read by the next instruction) cannot: the sources are covariance entries,
+// results of v_pk_fma_f32.
+template <int IA, int IB>
+__device__ __forceinline__ f2 pkmov(f2 a, f2 b)
 {
-    float g[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * r.m[3 * kk + i];
-    // M rows as pairs over all 12 columns
-    f2 M[6][6];
-#pragma unroll
-    for (int jp = 0; jp < 6; jp++) {
-        const f2 a6 = OSK_ROWPAIR(U, 6, jp), a7 = OSK_ROWPAIR(U, 7, jp), a8 = OSK_ROWPAIR(U, 8, jp);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            M[i][jp] = fma2(splat2(g[3 * i + 2]), a8, fma2(splat2(g[3 * i + 1]), a7, splat2(g[3 * i]) * a6));
-            const f2 a9 = OSK_ROWPAIR(U, 9 + i, jp);
-            M[3 + i][jp] = splat2(k.dt) * a9;
-        }
-    }
-    // (M G^T)[i][j], j < 6, per row i as three pairs: columns (0,1), (2,3), (4,5)
-    const f2 ga = {g[0], g[3]}, gb = {g[1], g[4]}, gc = {g[2], g[5]};          // G[j][6..8] for j = 0, 1
-    const f2 gd = {g[6], 0.f}, ge = {g[7], 0.f}, gf = {g[8], 0.f}, gt = {0.f, k.dt};   // j = 2 | j = 3 takes dt M[i][9]
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const float m6 = M[i][3][0], m7 = M[i][3][1], m8 = M[i][4][0], m9 = M[i][4][1];
-        f2 mg[3];
-        mg[0] = fma2(splat2(m8), gc, fma2(splat2(m7), gb, splat2(m6) * ga));
-        mg[1] = fma2(splat2(m9), gt, fma2(splat2(m8), gf, fma2(splat2(m7), ge, splat2(m6) * gd)));
-        mg[2] = splat2(k.dt) * M[i][5];
-#pragma unroll
-        for (int jp = i / 2; jp < 6; jp++) {
-            f2 v = U[pidx(i, jp)] + M[i][jp];
-            if (jp < 3) {
-                const f2 mt = {M[2 * jp][i / 2][i & 1], M[2 * jp + 1][i / 2][i & 1]};     // M[j][i] for the pair's two j
-                v = v + mt + mg[jp];
-            }
-            U[pidx(i, jp)] = v;
-        }
-    }
-    if (QDIAG) {
-#pragma unroll
-        for (int i = 0; i < NS; i++) U[pidx(i, i / 2)][i & 1] += k.Q[i * NS + i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int jp = i / 2; jp < 6; jp++) {
-                const int j0 = 2 * jp, j1 = 2 * jp + 1;
-                U[pidx(i, jp)] += (f2){0.5f * (k.Q[i * NS + j0] + k.Q[j0 * NS + i]), 0.5f * (k.Q[i * NS + j1] + k.Q[j1 * NS + i])};
-            }
-    }
+    f2 d;
+    if constexpr (IA == 0 && IB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (IA == 1 && IB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (IA == 0 && IB == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 pkmov_rt(int ia, int ib, f2 a, f2 b)      // ia / ib: compile-time constants once the loops are unrolled
+{
+    if (ia == 0 && ib == 0) return pkmov<0, 0>(a, b);
+    if (ia == 1 && ib == 0) return pkmov<1, 0>(a, b);
+    if (ia == 0 && ib == 1) return pkmov<0, 1>(a, b);
+    return pkmov<1, 1>(a, b);
+}
+// (P[k][2jp], P[k][2jp+1]) for any row k: the stored pair where it exists, otherwise assembled through symmetry from rows
+// 2jp and 2jp+1 (k, jp: compile-time constants after unrolling)
+__device__ __forceinline__ f2 rowpair(const f2 *U, int k, int jp)
+{
+    if (jp >= k / 2) return U[pidx(k, jp)];
+    return pkmov_rt(k & 1, k & 1, U[pidx(2 * jp, k / 2)], U[pidx(2 * jp + 1, k / 2)]);
 }
 
-// The same predict in BLOCK form: with a = rows 0-5 (theta, r), b = rows 6-11 (omega, v) and Gs = [[dt R^T, 0], [0, dt I]],
+// P <- F_d P F_d^T + Q, F_d = I + Gs with Gs = [[dt R^T, 0], [0, dt I]] (kalman_filter.py:124-135), in BLOCK form: with
+// a = rows 0-5 (theta, r) and b = rows 6-11 (omega, v),
 //   P_ab' = P_ab + Gs P_bb,      P_aa' = P_aa + Gs P_ba + P_ab' Gs^T      (P_bb unchanged),
 // because Gs P_ba + P_ab Gs^T + Gs P_bb Gs^T = Gs P_ba + (P_ab + Gs P_bb) Gs^T.  156 multiply-adds instead of the ~300 of
-// M = G P over all twelve columns followed by P + M + M^T + M G^T, and far fewer gathers across the diagonal (P_ab is
-// stored whole; only 6 + 13 pairs are assembled through symmetry).
+// M = G P over all twelve columns followed by P + M + M^T + M G^T, and only 18 + 6 pairs assembled through symmetry.
+// g[3 i + kk] = Gs[i][kk] = dt R[kk][i]   (i, kk < 3).
 template <bool QDIAG>
-__device__ __forceinline__ void cov_predict_sym_blk(f2 *U, const Rot &r, const KfConst &k)
+__device__ __forceinline__ void cov_predict_sym_blk(f2 *U, const float *g, const KfConst &k)
 {
-    float g[9];                    // g[3 i + kk] = Gs[i][kk] = dt R[kk][i]   (i, kk < 3)
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * r.m[3 * kk + i];
     const float dt = k.dt;
-#define OSK_AB(j, kk) U[pidx((j), 3 + (kk) / 2)][(kk) & 1]        /* P_ab[j][kk] = P[j][6 + kk] */
     // 1. P_aa += Gs P_ba with the OLD P_ab: the pair (2jp, 2jp+1) of row i takes sum_k Gs[i][k] (P_ab[2jp][k], P_ab[2jp+1][k])
 #pragma unroll
     for (int jp = 0; jp < 3; jp++) {
         f2 c[6];
 #pragma unroll
-        for (int kk = 0; kk < 6; kk++) c[kk] = (f2){OSK_AB(2 * jp, kk), OSK_AB(2 * jp + 1, kk)};
+        for (int kk = 0; kk < 6; kk++) c[kk] = pkmov_rt(kk & 1, kk & 1, U[pidx(2 * jp, 3 + kk / 2)], U[pidx(2 * jp + 1, 3 + kk / 2)]);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             if (jp < i / 2) continue;
@@ -672,15 +639,16 @@ __device__ __forceinline__ void cov_predict_sym_blk(f2 *U, const Rot &r, const K
     // 2. P_ab += Gs P_bb
 #pragma unroll
     for (int jp = 3; jp < 6; jp++) {
-        const f2 r6 = OSK_ROWPAIR(U, 6, jp), r7 = OSK_ROWPAIR(U, 7, jp), r8 = OSK_ROWPAIR(U, 8, jp);
+        const f2 r6 = rowpair(U, 6, jp), r7 = rowpair(U, 7, jp), r8 = rowpair(U, 8, jp);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             U[pidx(i, jp)] = fma2(splat2(g[3 * i + 2]), r8, fma2(splat2(g[3 * i + 1]), r7, fma2(splat2(g[3 * i]), r6, U[pidx(i, jp)])));
-            const f2 r9 = OSK_ROWPAIR(U, 9 + i, jp);
+            const f2 r9 = rowpair(U, 9 + i, jp);
             U[pidx(3 + i, jp)] = fma2(splat2(dt), r9, U[pidx(3 + i, jp)]);
         }
     }
     // 3. P_aa += P_ab' Gs^T
+#define OSK_AB(j, kk) U[pidx((j), 3 + (kk) / 2)][(kk) & 1]        /* P_ab[j][kk] = P[j][6 + kk] */
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const float b0 = OSK_AB(i, 0), b1 = OSK_AB(i, 1), b2 = OSK_AB(i, 2), b3 = OSK_AB(i, 3);
@@ -711,30 +679,196 @@ __device__ __forceinline__ void cov_predict_sym_blk(f2 *U, const Rot &r, const K
     }
 }
 
-// Sequential scalar updates on the paired upper triangle (diagonal R).
-__device__ __forceinline__ int update_sequential_sym(float *x, f2 *U, const float *z, const KfConst &k)
+// Ten sequential scalar updates on the paired upper triangle (diagonal R).  The state rides along as six pairs
+// X[jp] = (x[2jp], x[2jp+1]): per measurement 1 add (s) + 1 class test + 1 reciprocal + 1 subtract (innovation) + 6 + 6 + 42
+// packed multiply-adds (w = -c / s; x += w (x_s - z); P += c_i w) + the pairs assembled through symmetry.
+// v_rcp_f32 is accurate to 1 ulp: the gain's relative error of ~1e-7 is that of any other float32 operation of the step.
+// Returns true when some S entry was not a positive finite number (status bit 0; nothing is patched up: the state of that
+// trajectory is then garbage or non-finite, which status bit 1 reports as well).
+template <int A>
+__device__ __forceinline__ bool update_one_sym(f2 *X, f2 *U, const float *z, const KfConst &k)
 {
-    int status = 0;
+    constexpr int sa = SEL[A];
+    const float s = OSK_SYM(U, sa, sa) + k.R[A * NM + A];
+    const bool bad = !__builtin_amdgcn_classf(s, 0x180);          // not (+normal | +denormal)
+    const float ninv = -__builtin_amdgcn_rcpf(s);
+    const float ninnov = X[sa / 2][sa & 1] - z[A];
+    f2 c[6], w[6];
 #pragma unroll
-    for (int a = 0; a < NM; a++) {
-        const int sa = SEL[a];
-        float s = OSK_SYM(U, sa, sa) + k.R[a * NM + a];
-        if (!(s > 0.f) || !(s < 3.0e38f)) { status |= 1; s = 1.0f; }
-        float inv = __builtin_amdgcn_rcpf(s);
-        inv = inv * (2.0f - s * inv);          // one Newton step: <= 1 ulp, 3 instructions instead of the ~10 of a division
-        const float innov = z[a] - x[sa];
-        f2 c[6], kc[6];
+    for (int jp = 0; jp < 6; jp++) { c[jp] = rowpair(U, sa, jp); w[jp] = c[jp] * splat2(ninv); }
 #pragma unroll
-        for (int jp = 0; jp < 6; jp++) { c[jp] = OSK_ROWPAIR(U, sa, jp); kc[jp] = c[jp] * splat2(inv); }
+    for (int jp = 0; jp < 6; jp++) X[jp] = fma2(w[jp], splat2(ninnov), X[jp]);
 #pragma unroll
-        for (int i = 0; i < NS; i++) {
-            const float ki = kc[i / 2][i & 1];
-            x[i] = fmaf(ki, innov, x[i]);
+    for (int i = 0; i < NS; i++) {
+        const float ci = c[i / 2][i & 1];
 #pragma unroll
-            for (int jp = i / 2; jp < 6; jp++) U[pidx(i, jp)] = fma2(splat2(-ki), c[jp], U[pidx(i, jp)]);
+        for (int jp = i / 2; jp < 6; jp++) U[pidx(i, jp)] = fma2(splat2(ci), w[jp], U[pidx(i, jp)]);
+    }
+    return bad;
+}
+__device__ __forceinline__ bool update_sequential_sym(f2 *X, f2 *U, const float *z, const KfConst &k)
+{
+    bool bad = update_one_sym<0>(X, U, z, k);
+    bad |= update_one_sym<1>(X, U, z, k); bad |= update_one_sym<2>(X, U, z, k); bad |= update_one_sym<3>(X, U, z, k);
+    bad |= update_one_sym<4>(X, U, z, k); bad |= update_one_sym<5>(X, U, z, k); bad |= update_one_sym<6>(X, U, z, k);
+    bad |= update_one_sym<7>(X, U, z, k); bad |= update_one_sym<8>(X, U, z, k); bad |= update_one_sym<9>(X, U, z, k);
+    return bad;
+}
+
+// ---- the part of a step that consumes its inputs, hand-packed: legs in pairs (0,1) and (2,3), the step's two rotations (prior
+// attitude | IMU attitude) side by side in one register pair.  hipcc's SLP vectoriser packs this code too, but pays for
+// every pair with two v_mov_b32; here the pairs are the natural layout (the loaders deliver them) ----
+struct StepInP {
+    f2 p[2][3], f[2][3], dp[2][3];     // [leg pair q][component c] = (value of leg 2q, value of leg 2q + 1)
+    float imu[6];
+    uint32_t contact;                  // 4 packed bytes
+};
+__device__ __forceinline__ f2 lo2(f2 v) { return (f2){v[0], v[0]}; }
+
+// sincos_small_f32 on a pair: identical polynomials in identical order, so each half has the bits of the scalar form
+__device__ __forceinline__ void sincos_small2(f2 v, f2 *s, f2 *c)
+{
+    const f2 z = v * v;
+    const f2 ps = fma2(z, fma2(z, splat2(-1.9515295891e-4f), splat2(8.3321608736e-3f)), splat2(-1.6666654611e-1f));
+    *s = fma2(v * z, ps, v);
+    const f2 pc = fma2(z, fma2(z, splat2(2.443315711809948e-5f), splat2(-1.388731625493765e-3f)), splat2(4.166664568298827e-2f));
+    *c = fma2(z * z, pc, fma2(splat2(-0.5f), z, splat2(1.0f)));
+}
+
+// Rp[i] = (R(prior attitude)[i], R(IMU attitude)[i]), R = Rz Ry Rx (kalman_filter.py:184-193)
+__device__ __forceinline__ void rotation2(const float *xs, const float *im, f2 *Rp)
+{
+    f2 s[3], c[3];
+    // wave-uniform small-angle path as in rotation(): all six angles of every lane below pi/4
+    const bool big = !(fabsf(xs[0]) < 0.785f && fabsf(xs[1]) < 0.785f && fabsf(xs[2]) < 0.785f &&
+                       fabsf(im[0]) < 0.785f && fabsf(im[1]) < 0.785f && fabsf(im[2]) < 0.785f);       // NaN counts as big
+    if (__builtin_amdgcn_ballot_w64(big) == 0ull) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) sincos_small2((f2){xs[i], im[i]}, &s[i], &c[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            float s0, c0, s1, c1;
+            sincos_f32(xs[i], &s0, &c0); sincos_f32(im[i], &s1, &c1);
+            s[i] = (f2){s0, s1}; c[i] = (f2){c0, c1};
         }
     }
-    return status;
+    const f2 sx = s[0], cx = c[0], sy = s[1], cy = c[1], sz = s[2], cz = c[2];
+    const f2 t1 = sy * sx, t2 = sy * cx;
+    Rp[0] = cz * cy; Rp[1] = fma2(cz, t1, -(sz * cx)); Rp[2] = fma2(cz, t2, sz * sx);
+    Rp[3] = sz * cy; Rp[4] = fma2(sz, t1, cz * cx);    Rp[5] = fma2(sz, t2, -(cz * sx));
+    Rp[6] = -sy;     Rp[7] = cy * sx;                  Rp[8] = cy * cx;
+}
+
+// get_odom + set_measurements (kalman_filter/kalman_filter.py:79-117) on the paired inputs; the IMU rotation is the upper
+// half of Rp.  Selects, not 0/1 weights (see measurement_r).
+__device__ __forceinline__ void measurement_p(const StepInP &in, const f2 *Rp, float *z /*10*/)
+{
+    float sum_c = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, pz = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const uint32_t cb = (in.contact >> (8 * l)) & 0xffu;
+        const bool st = cb == 1u, sw = cb == 0u;
+        sum_c += (float)cb;
+        vx += st ? in.dp[l >> 1][0][l & 1] : 0.f;
+        vy += st ? in.dp[l >> 1][1][l & 1] : 0.f;
+        pz += st ? in.p[l >> 1][2][l & 1] : 0.f;
+        vz += sw ? in.dp[l >> 1][2][l & 1] : 0.f;
+    }
+    const float inv = (sum_c != 0.f) ? (1.0f / sum_c) : 0.f;   // no stance leg -> odom = 0 (:97-98)
+    const float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
+    z[0] = in.imu[0]; z[1] = in.imu[1]; z[2] = in.imu[2];
+    z[3] = -pz * inv;
+    z[4] = in.imu[3]; z[5] = in.imu[4]; z[6] = in.imu[5];
+    z[7] = Rp[0][1] * bx + Rp[1][1] * by + Rp[2][1] * bz;
+    z[8] = Rp[3][1] * bx + Rp[4][1] * by + Rp[5][1] * bz;
+    z[9] = Rp[6][1] * bx + Rp[7][1] * by + Rp[8][1] * bz;
+}
+
+// next_state (misc/force_controller.py:269-291) on paired legs: X in/out, PW[q][c] = world-frame foot positions of legs
+// (2q, 2q+1) (the reference mutates the caller's p, :274-277).  Same equations as dynamics().
+__device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &in, f2 (*PW)[3], const KfConst &k)
+{
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            PW[q][c] = fma2(lo2(Rp[3 * c + 2]), in.p[q][2], fma2(lo2(Rp[3 * c + 1]), in.p[q][1], lo2(Rp[3 * c]) * in.p[q][0]));
+    float tau[3], fs[3], r[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        f2 t = PW[0][c1] * in.f[0][c2];                     // sum over the four legs of (pw x f)[c], two legs per half
+        t = fma2(-PW[0][c2], in.f[0][c1], t);
+        t = fma2(PW[1][c1], in.f[1][c2], t);
+        t = fma2(-PW[1][c2], in.f[1][c1], t);
+        const f2 fsum = in.f[0][c] + in.f[1][c];
+        tau[c] = t[0] + t[1];
+        fs[c] = fsum[0] + fsum[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) r[i] = Rp[i][0];
+    // body-frame torque, scaled by 1/I, back to world: I_hat^-1 = R diag(1/I) R^T (R orthogonal)
+    const float tb0 = (r[0] * tau[0] + r[3] * tau[1] + r[6] * tau[2]) * k.inv_inertia[0];
+    const float tb1 = (r[1] * tau[0] + r[4] * tau[1] + r[7] * tau[2]) * k.inv_inertia[1];
+    const float tb2 = (r[2] * tau[0] + r[5] * tau[1] + r[8] * tau[2]) * k.inv_inertia[2];
+    const float aw0 = r[0] * tb0 + r[1] * tb1 + r[2] * tb2;
+    const float aw1 = r[3] * tb0 + r[4] * tb1 + r[5] * tb2;
+    const float aw2 = r[6] * tb0 + r[7] * tb1 + r[8] * tb2;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) amax = fmaxf(amax, fabsf(r[i]));
+    float x[NS];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { x[2 * i] = X[i][0]; x[2 * i + 1] = X[i][1]; }
+    const float w0 = x[6], w1 = x[7], w2 = x[8];
+    // theta: A[0:3,6:9] = trunc(R^T) -- zero unless an entry of R reaches +-1 in float64 (see trunc_block_f64)
+    if (amax >= 0.9999995f) {
+        float A[9];
+        trunc_block_f64(x[0], x[1], x[2], A);
+        x[0] += k.dt * (A[0] * w0 + A[1] * w1 + A[2] * w2);
+        x[1] += k.dt * (A[3] * w0 + A[4] * w1 + A[5] * w2);
+        x[2] += k.dt * (A[6] * w0 + A[7] * w1 + A[8] * w2);
+    }
+    x[3] += k.dt * x[9]; x[4] += k.dt * x[10]; x[5] += k.dt * x[11];      // position integrates the PRIOR velocity
+    x[6] = w0 + k.dt * aw0; x[7] = w1 + k.dt * aw1; x[8] = w2 + k.dt * aw2;
+    x[9] += k.dt * (fs[0] * k.inv_mass);
+    x[10] += k.dt * (fs[1] * k.inv_mass);
+    x[11] += k.dt * (fs[2] * k.inv_mass) + k.dt * k.gz;
+#pragma unroll
+    for (int i = 0; i < 6; i++) X[i] = (f2){x[2 * i], x[2 * i + 1]};
+}
+
+// Everything of a step that reads its inputs: measurement vector, next_state, and g = dt R^T of the PRIOR attitude for the
+// covariance predict (kalman_filter.py:124: F_d and next_state both use the prior state).  The callers run the predict
+// (cov_predict_sym_blk(U, g, k)) afterwards, when the input registers are free again.
+__device__ __forceinline__ void kf_step_inputs_sym(f2 *X, const StepInP &in, const KfConst &k, float *z, f2 (*PW)[3], float *g /*9*/)
+{
+    f2 Rp[9];
+    const float xs[3] = {X[0][0], X[0][1], X[1][0]};
+    rotation2(xs, in.imu, Rp);
+    measurement_p(in, Rp, z);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * Rp[3 * kk + i][0];     // g[3 i + kk] = dt R[kk][i]
+    dynamics_p(X, Rp, in, PW, k);
+}
+
+template <bool QDIAG>
+__device__ __forceinline__ void kf_step_front_sym(f2 *X, f2 *U, const StepInP &in, const KfConst &k, float *z, f2 (*PW)[3])
+{
+    float g[9];
+    kf_step_inputs_sym(X, in, k, z, PW, g);
+    cov_predict_sym_blk<QDIAG>(U, g, k);
+}
+
+__device__ __forceinline__ int finite_status_p(const f2 *X)
+{
+    f2 s = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; i++) s = fma2(X[i], splat2(0.f), s);   // NaN / Inf propagate
+    return (s[0] + s[1] == 0.f) ? 0 : 2;
 }
 
 __device__ __forceinline__ float trace_sym(const f2 *U)
@@ -803,22 +937,6 @@ __device__ __forceinline__ void kf_step_front(float *x, PT *P, const StepIn &in,
         if constexpr (sizeof(PT) == 4) cov_predict<QDIAG>(P, r, k);
     }
     dynamics(x, r, in.p, in.f, pw, k);
-}
-
-// Symmetric-storage halves (fast path: sequential update, predict(p,f) covariance).
-template <bool QDIAG>
-__device__ __forceinline__ void kf_step_front_sym(float *x, f2 *U, const StepIn &in, const KfConst &k, float *z,
-                                                  float *pw)
-{
-    measurement(in, z);
-    Rot r = rotation(x[0], x[1], x[2]);
-    cov_predict_sym_blk<QDIAG>(U, r, k);
-    dynamics(x, r, in.p, in.f, pw, k);
-}
-
-__device__ __forceinline__ int kf_step_back_sym(float *x, f2 *U, const float *z, const KfConst &k)
-{
-    return update_sequential_sym(x, U, z, k) | finite_status(x);
 }
 
 // the same halves on the scalar triangle (fused kernel)

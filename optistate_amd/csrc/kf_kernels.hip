@@ -111,20 +111,21 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
 {
     const size_t B = (size_t)a.B;
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
-    float x[NS];
+    f2 X[6];                       // the state as pairs (x[2i], x[2i+1])
     f2 U[NU];
     int status = 0;
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
+        for (int i = 0; i < 6; i++) X[i] = (f2){buf_load(rx, voff, 2 * i * rowB), buf_load(rx, voff, (2 * i + 1) * rowB)};
         status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
     // step inputs: LDS-DMA double buffer, step t + 1 requested at the top of step t (see load_step_dma)
     __shared__ float stage[2][STEP_DWORDS * 64];
     const int lane = threadIdx.x & 63;
-    StepIn in;
+    StepInP in;
+    bool bad = false;
     load_step_dma(a, 0, voff, rowB, stage[0]);
     for (int t = 0; t < a.T; t++) {
         // vmcnt(12): step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in issue order
@@ -132,10 +133,13 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         // than the last twelve operations includes every DMA load.
         __builtin_amdgcn_s_waitcnt(0x0f7c);
         __builtin_amdgcn_wave_barrier();
-        read_step_lds(stage[t & 1], lane, in);
+        read_step_lds_p(stage[t & 1], lane, in);
         load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, stage[(t + 1) & 1]);
-        float z[NM], pw[12];
-        kf_step_front_sym<QDIAG>(x, U, in, kc, z, pw);
+        float z[NM];
+        f2 PW[2][3];
+        kf_step_front_sym<QDIAG>(X, U, in, kc, z, PW);
+        auto pw = [&](int i) { return PW[(i / 3) >> 1][i % 3][(i / 3) & 1]; };          // world-frame foot position 3 leg + component
+        auto lg = [](const f2 (*v)[3], int i) { return v[(i / 3) >> 1][i % 3][(i / 3) & 1]; };
         rsrc_t rfeat;
         if (OUT == 2) {
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
@@ -144,9 +148,9 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load_nt(ra, voff, i * rowB));
 #pragma unroll
             for (int i = 0; i < 12; i++) {
-                store_feat(rfeat, a.minmax, voff, rowB, 18 + i, in.f[i]);
-                store_feat(rfeat, a.minmax, voff, rowB, 30 + i, pw[i]);
-                store_feat(rfeat, a.minmax, voff, rowB, 42 + i, in.dp[i]);
+                store_feat(rfeat, a.minmax, voff, rowB, 18 + i, lg(in.f, i));
+                store_feat(rfeat, a.minmax, voff, rowB, 30 + i, pw(i));
+                store_feat(rfeat, a.minmax, voff, rowB, 42 + i, lg(in.dp, i));
             }
 #pragma unroll
             for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 54 + i, in.imu[i]);
@@ -154,30 +158,30 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         if (a.p_rot_out) {
             rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw[i]);
+            for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw(i));
         }
-        status |= update_sequential_sym(x, U, z, kc);        // non-finite states stay non-finite: checked once after the loop
+        bad |= update_sequential_sym(X, U, z, kc);            // non-finite states stay non-finite: checked once after the loop
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, X[i / 2][i & 1]);
         }
         if (OUT == 2) {
 #pragma unroll
-            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, x[i]);
+            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, X[i / 2][i & 1]);
         }
         if (OUT == 1 && a.ptrace_out) a.ptrace_out[(size_t)t * B + b] = trace_sym(U);
     }
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, X[i / 2][i & 1]);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
             for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
     }
-    a.status[b] = status | finite_status(x);
+    a.status[b] = status | (bad ? 1 : 0) | finite_status_p(X);
 }
 
 template <int OUT, bool QDIAG>

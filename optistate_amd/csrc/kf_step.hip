@@ -20,6 +20,8 @@
 //   update                         kalman_filter/kalman_filter.py:164-174   (K returned; P <- (I - K H) P, unsymmetrised)
 #include "launch.hpp"
 
+#include <stddef.h>
+
 namespace oss {
 
 using osk::SEL;
@@ -34,6 +36,8 @@ struct StepIO {
     int32_t status, pad;
 };
 constexpr int IO_DOUBLES = sizeof(StepIO) / 8;
+constexpr int IO_INOUT_DOUBLES = 12 + 144 + 10 + 12;                 // x, P, z, p: read and written
+constexpr int IO_IN_DOUBLES = offsetof(StepIO, x_model) / 8;         // everything the kernel reads
 
 struct StepMem {
     StepIO io;
@@ -64,9 +68,17 @@ __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
     const int lane = threadIdx.x;
     StepIO &io = M.io;
     {
+        // the staging block lives in host memory: every load is a PCIe round trip, so all of them go out before the first
+        // one is waited for (fully unrolled: eight loads per lane in flight)
         const double *src = reinterpret_cast<const double *>(g);
         double *dst = reinterpret_cast<double *>(&io);
-        for (int i = lane; i < IO_DOUBLES; i += 64) dst[i] = src[i];
+        constexpr int NIT = (IO_IN_DOUBLES + 63) / 64;
+        double v[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) v[i] = (lane + 64 * i < IO_IN_DOUBLES) ? __builtin_nontemporal_load(src + lane + 64 * i) : 0.0;
+#pragma unroll
+        for (int i = 0; i < NIT; i++)
+            if (lane + 64 * i < IO_IN_DOUBLES) dst[lane + 64 * i] = v[i];
     }
     __syncthreads();
     const uint32_t what = io.what;
@@ -310,10 +322,11 @@ __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
     if (lane == 0) io.status = status;
     __syncthreads();
     {
-        // write back everything behind the constant inputs (x, P, z, p are in/out: the whole block is small)
+        // write back the in/out head of the block (x, P, z, p) and the outputs behind the constant inputs
         double *dst = reinterpret_cast<double *>(g);
         const double *src = reinterpret_cast<const double *>(&io);
-        for (int i = lane; i < IO_DOUBLES; i += 64) dst[i] = src[i];
+        for (int i = lane; i < IO_INOUT_DOUBLES; i += 64) dst[i] = src[i];
+        for (int i = IO_IN_DOUBLES + lane; i < IO_DOUBLES; i += 64) dst[i] = src[i];
     }
 }
 

@@ -125,8 +125,8 @@ def test_hostile_contacts_and_unwrapped_yaw_through_every_kernel_family(noise):
     torch.cuda.synchronize()
     for r in (fz, sy, rw):
         assert int((r["status"] != 0).sum()) == 0 and torch.isfinite(r["x_out"]).all()
-    # the two lane kernels run the same arithmetic on the filter state
-    assert (fz["x_out"] - sy["x_out"]).abs().max().item() < 2e-5
+    # the two lane kernels run the same arithmetic on the filter state (omega_z reaches +-55 under the fitted set: 1 ulp = 4e-6)
+    assert (fz["x_out"] - sy["x_out"]).abs().max().item() < 5e-5
     n_exact = _hostile_exact_starts(B)[-1][1]
     pick = torch.cat([torch.arange(n_exact), n_exact + torch.randperm(B - n_exact, generator=torch.Generator().manual_seed(9))[:16384 - 4096],
                       ]).unique().cuda()
