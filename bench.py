@@ -705,8 +705,8 @@ def bench_hot_path(a, rk):
         tf = KF_FLOPS_STRUCTURED * steps_per_pass / (avg_ms * 1e-3) / 1e12
         roof["valu_structured_TFLOPs"] = tf
         roof["valu_frac_of_fp32_vector_peak"] = tf / MFMA_F32_PEAK_TF
-        if dk["kernel"].startswith(("kf_run_rows_kernel", "kf_run_wave_kernel")):
-            per = 4 if dk["kernel"].startswith("kf_run_rows_kernel") else 1
+        if dk["kernel"].startswith("kf_run_rows"):
+            per = 4
             waves = (B + per - 1) // per
             roof["limiter"] = (f"latency: {waves} wavefronts on 1024 SIMDs, each a serial chain of T = {T} dependent steps "
                                f"({avg_ms * 1e3 / T:.2f} us per step); neither HBM nor the vector pipe is the bound at this batch")

@@ -366,6 +366,165 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// kf_run_rows2_kernel -- the same 16-lanes-per-trajectory layout with half the instructions (round 3).
+// The first version (above, kept behind OS_KF_ROWS_V1=1 for A/B runs) issues ~800 VALU instructions per dependent step at
+// exactly one wave per SIMD (B = 4096 trajectories = 1024 waves), i.e. its 1.97 us per step are instruction issue.  Here:
+//   * every row broadcast is FUSED into the multiply-add that consumes it: `v_fmac_f32_dpp acc, src row_newbcast:S, m` reads
+//     src from lane S of the 16-lane row inside the instruction, so a rank-1 update of a row is 12 instructions, not 12 moves +
+//     12 FMAs (hipcc keeps the DPP move separate and then pairs the FMAs: 18), and the covariance predict needs no
+//     ds_bpermute (row r + 6 arrives by `row_shl:6`);
+//   * the part every lane computes redundantly (rotations, odometry, next_state: ~350 instructions) is the hand-packed
+//     form of kf_device.hpp (legs in pairs, both rotations side by side: ~190);
+//   * class test instead of two compares and a select per measurement, no Newton step after v_rcp_f32 (as the lane kernels).
+// DPP hazards (inline asm is invisible to hipcc's hazard recogniser): a VALU result must be two instructions old before a
+// DPP operand reads it, an EXEC write five.  Within a chain every source was written at least twelve instructions
+// earlier; the blocks start behind hipcc's own (hazard-checked) DPP moves, and one s_nop 4 separates the update from
+// whatever branchy code precedes it.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SRC>
+__device__ __forceinline__ void fmac_bcast(float &acc, float src, float m)     // acc += (src of lane SRC of this 16-lane row) * m
+{
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(SRC));
+}
+template <int N>
+__device__ __forceinline__ void fmac_shl(float &acc, float src, float m)       // acc += (src of lane + N, 0 past the row's end) * m
+{
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+}
+
+template <bool AUX, bool FEAT>
+__global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+    const int b_raw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + grp;
+    const bool live = b_raw < a.B;
+    const int b = live ? b_raw : a.B - 1;
+    const int rr = r < 12 ? r : 11;                    // idle lanes 12-15 shadow row 11 (never broadcast from, never stored)
+    const size_t B = (size_t)a.B;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    const KfConst &k = a.k;
+
+    float Prow[NS], qrow[NS], xr;
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+        xr = buf_load(rx, voff, (uint32_t)rr * rowB);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            Prow[j] = buf_load(rP, voff, (uint32_t)(rr * NS + j) * rowB);
+            qrow[j] = qmat[rr * NS + j];
+        }
+    }
+    const bool top = r < 3, mid = r >= 3 && r < 6;
+    bool bad = false;
+    StepInP in;
+    load_step_p(a, 0, voff, rowB, in);
+    for (int t = 0; t < a.T; t++) {
+        // ---- the prior state, replicated per lane, as pairs ----
+        f2 X[6];
+        X[0] = (f2){row_bcast<0>(xr), row_bcast<1>(xr)}; X[1] = (f2){row_bcast<2>(xr), row_bcast<3>(xr)};
+        X[2] = (f2){row_bcast<4>(xr), row_bcast<5>(xr)}; X[3] = (f2){row_bcast<6>(xr), row_bcast<7>(xr)};
+        X[4] = (f2){row_bcast<8>(xr), row_bcast<9>(xr)}; X[5] = (f2){row_bcast<10>(xr), row_bcast<11>(xr)};
+        float z[NM], g[9];
+        f2 PW[2][3];
+        kf_step_inputs_sym(X, in, k, z, PW, g);          // measurement, next_state, g = dt R^T of the prior attitude
+        // ---- covariance predict, row-parallel: M = F_d P (rows: lane r needs rows 6..8 or row r + 6), then P' = M F_d^T + Q (local) ----
+        const float cg0 = top ? (r == 0 ? g[0] : (r == 1 ? g[3] : g[6])) : 0.f;
+        const float cg1 = top ? (r == 0 ? g[1] : (r == 1 ? g[4] : g[7])) : 0.f;
+        const float cg2 = top ? (r == 0 ? g[2] : (r == 1 ? g[5] : g[8])) : 0.f;
+        const float cd = mid ? k.dt : 0.f;
+        float M[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) M[j] = Prow[j];
+        asm volatile("s_nop 1");
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            fmac_bcast<6>(M[j], Prow[j], cg0);
+            fmac_bcast<7>(M[j], Prow[j], cg1);
+            fmac_bcast<8>(M[j], Prow[j], cg2);
+            fmac_shl<6>(M[j], Prow[j], cd);                            // row r + 6 (rows 9..11 for lanes 3..5)
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8] + qrow[j];
+            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j] + qrow[3 + j];
+        }
+#pragma unroll
+        for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
+        // ---- this lane's component of the predicted state and of the step's by-products ----
+        // element rr of a twelve-vector held as compile-time-indexed registers: a select chain (a lambda with a loop inside
+        // would index the array at run time, and hipcc then moves it to LDS)
+#define OS_PICK12(E) ((rr == 11) ? E(11) : (rr == 10) ? E(10) : (rr == 9) ? E(9) : (rr == 8) ? E(8) : (rr == 7) ? E(7) : (rr == 6) ? E(6) : \
+                      (rr == 5) ? E(5) : (rr == 4) ? E(4) : (rr == 3) ? E(3) : (rr == 2) ? E(2) : (rr == 1) ? E(1) : E(0))
+#define OS_LEGV(v, i) (v)[((i) / 3) >> 1][(i) % 3][((i) / 3) & 1]
+#define OS_EX(i) X[(i) >> 1][(i) & 1]
+#define OS_EPW(i) OS_LEGV(PW, i)
+#define OS_EF(i) OS_LEGV(in.f, i)
+#define OS_EDP(i) OS_LEGV(in.dp, i)
+        xr = OS_PICK12(OS_EX);
+        if (a.p_rot_out && live && r < 12) a.p_rot_out[((size_t)t * 12 + r) * B + b] = OS_PICK12(OS_EPW);
+        if (FEAT && live && r < 12) {
+            const float fv = OS_PICK12(OS_EF), pv = OS_PICK12(OS_EPW), dv = OS_PICK12(OS_EDP);
+            float *fo = a.feat_out + (size_t)t * a.feat_I * B + b;
+            const float *mm = a.minmax;
+            auto put = [&](int j, float v) { __builtin_nontemporal_store((v - mm[j]) / (mm[60 + j] - mm[j]), fo + (size_t)j * B); };
+            put(18 + r, fv); put(30 + r, pv); put(42 + r, dv);
+            if (r < 6) {
+                float iv = in.imu[0];
+#pragma unroll
+                for (int i = 1; i < 6; i++) iv = (r == i) ? in.imu[i] : iv;
+                put(54 + r, iv);
+                put(12 + r, a.accel[((size_t)t * 6 + r) * B + b]);
+            }
+        }
+#undef OS_PICK12
+#undef OS_LEGV
+#undef OS_EX
+#undef OS_EPW
+#undef OS_EF
+#undef OS_EDP
+        // prefetch the next step's inputs underneath the update
+        load_step_p(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, in);
+        // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
+        asm volatile("s_nop 4");
+#define OS_ROW_UPDATE2(A, S)                                                                          \
+        {                                                                                             \
+            const float sv = row_bcast<S>(Prow[S]) + k.R[A * NM + A];                                 \
+            bad |= !__builtin_amdgcn_classf(sv, 0x180);                                               \
+            const float nkc = -Prow[S] * __builtin_amdgcn_rcpf(sv);                                   \
+            xr = fmaf(nkc, row_bcast<S>(xr) - z[A], xr);                                              \
+            fmac_bcast<S>(Prow[0], Prow[0], nkc); fmac_bcast<S>(Prow[1], Prow[1], nkc); fmac_bcast<S>(Prow[2], Prow[2], nkc);   \
+            fmac_bcast<S>(Prow[3], Prow[3], nkc); fmac_bcast<S>(Prow[4], Prow[4], nkc); fmac_bcast<S>(Prow[5], Prow[5], nkc);   \
+            fmac_bcast<S>(Prow[6], Prow[6], nkc); fmac_bcast<S>(Prow[7], Prow[7], nkc); fmac_bcast<S>(Prow[8], Prow[8], nkc);   \
+            fmac_bcast<S>(Prow[9], Prow[9], nkc); fmac_bcast<S>(Prow[10], Prow[10], nkc); fmac_bcast<S>(Prow[11], Prow[11], nkc); \
+        }
+        OS_ROW_UPDATE2(0, 0) OS_ROW_UPDATE2(1, 1) OS_ROW_UPDATE2(2, 2) OS_ROW_UPDATE2(3, 5) OS_ROW_UPDATE2(4, 6)
+        OS_ROW_UPDATE2(5, 7) OS_ROW_UPDATE2(6, 8) OS_ROW_UPDATE2(7, 9) OS_ROW_UPDATE2(8, 10) OS_ROW_UPDATE2(9, 11)
+#undef OS_ROW_UPDATE2
+        if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
+        if (FEAT && live && r < 12)
+            __builtin_nontemporal_store((xr - a.minmax[r]) / (a.minmax[60 + r] - a.minmax[r]), a.feat_out + ((size_t)t * a.feat_I + r) * B + b);
+        if (AUX && a.ptrace_out) {
+            float dg = Prow[0];
+#pragma unroll
+            for (int i = 1; i < NS; i++) dg = (r == i) ? Prow[i] : dg;
+            dg = r < 12 ? dg : 0.f;
+            dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
+            if (live && r == 0) a.ptrace_out[(size_t)t * B + b] = dg;
+        }
+    }
+    // ---- final state: lane r writes x[r] and row r of P; the status word is OR-reduced over the 16 lanes ----
+    int status = (bad ? 1 : 0) | ((xr * 0.f == 0.f) ? 0 : 2);
+    status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
+    status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
+    if (live && r < 12) {
+        a.x[(size_t)r * B + b] = xr;
+#pragma unroll
+        for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = Prow[j];
+        if (r == 0) a.status[b] = status;
+    }
+}
+
 // ---- single pieces for the drop-in Kalman_Filter class (B is tiny there; latency-bound by design) ----
 
 __global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
@@ -500,7 +659,7 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool use_rows = !noise && seq && !dense && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
                           a.B < ctx->rows_kernel_below && ctx->kf_qr;
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise) && !a.kgain_out;
-    const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? "kf_run_rows_kernel" : use_sym ? "kf_run_sym_kernel"
+    const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
                         : dense ? (seq ? "kf_run_kernel<SEQ,DENSE_F64>" : "kf_run_kernel<BATCH,DENSE_F64>")
                                 : (seq ? "kf_run_kernel<SEQ>" : "kf_run_kernel<BATCH>");
     const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, kname);
@@ -516,9 +675,13 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     } else if (use_rows) {
         // small batch: 16 lanes per trajectory so that every SIMD gets a wave
         dim3 grid((a.B + 15) / 16), block(256);                       // 4 waves x 4 trajectories per workgroup
-        if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        if (ctx->tune_rows_v1) {
+            if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+            else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+            else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        } else if (feat) hipLaunchKernelGGL((kf_run_rows2_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else if (aux) hipLaunchKernelGGL((kf_run_rows2_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else hipLaunchKernelGGL((kf_run_rows2_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
         e = hipGetLastError();
     } else if (use_sym) {
         dim3 grid((a.B + 63) / 64), block(64);

@@ -47,7 +47,7 @@ def test_default_mode_contract():
     assert cb["reference_python_steps_per_s"] == 3.05e3
     assert d["rccl_world_size"] == 1 and d["rank_devices"][0]["device"] == 0
     # B = 4096 takes the two-kernel path: the line names the kernels that actually ran
-    assert d["kernels"]["kf"]["kernel"] == "kf_run_rows_kernel" and d["kernels"]["gru_layer"]["kernel"].startswith("gru_layer")
+    assert d["kernels"]["kf"]["kernel"] == "kf_run_rows2_kernel" and d["kernels"]["gru_layer"]["kernel"].startswith("gru_layer")
 
 
 def _has_roofline_and_baseline(d):
@@ -60,7 +60,7 @@ def _has_roofline_and_baseline(d):
 def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
     k = _run(["--mode", "kf", "--batch", "4096", "--seq", "50", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
     _has_roofline_and_baseline(k)
-    assert k["roofline"]["kernel"] == "kf_run_rows_kernel" and "latency" in k["roofline"]["limiter"]     # the kernel that RAN
+    assert k["roofline"]["kernel"] == "kf_run_rows2_kernel" and "latency" in k["roofline"]["limiter"]     # the kernel that RAN
     assert k["parity"]["state_linf"] < 1e-4 and "gru_linf" not in k["parity"]
     d = _run(["--mode", "train", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"])
     _has_roofline_and_baseline(d)

@@ -93,7 +93,7 @@ def test_random_sample_matches_oracle(setup):
 def test_hostile_contacts_and_unwrapped_yaw_through_every_kernel_family(noise):
     """0...4 stance legs per step (standing and flight stretches), yaw unwrapping past +-pi at up to 8 rad/s, roll / pitch
     to 1 rad, exact 0 / k pi/2 attitude starts (the int64-truncation predicates): 65,536 x 100 through
-    fused_kf_gru_kernel_v2 and kf_run_sym_kernel, a 4,096-slice through kf_run_rows_kernel, each against the float64
+    fused_kf_gru_kernel_v2 and kf_run_sym_kernel, a 4,096-slice through kf_run_rows2_kernel, each against the float64
     oracle (16,384 random trajectories x all 100 steps + the whole exact-start block), under both reference noise sets."""
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_torch, NOISE_SETS, _hostile_exact_starts
@@ -121,7 +121,7 @@ def test_hostile_contacts_and_unwrapped_yaw_through_every_kernel_family(noise):
     g4 = lambda k: d[k][:, :, sl].contiguous()
     xs, Ps = d["x0"][:, sl].contiguous(), P0[:, sl].contiguous()
     rw = eng.kf_run(g4("p"), g4("f"), g4("dp"), g4("imu"), cp[:, sl].contiguous(), xs, Ps)
-    assert eng.kernel_name("kf") == "kf_run_rows_kernel"
+    assert eng.kernel_name("kf") == "kf_run_rows2_kernel"
     torch.cuda.synchronize()
     for r in (fz, sy, rw):
         assert int((r["status"] != 0).sum()) == 0 and torch.isfinite(r["x_out"]).all()
@@ -170,7 +170,7 @@ def test_config2_kf_4096x1000_oracle_sample_and_slice_independence():
     x, P = d["x0"].clone(), d["P0"].clone()
     full = eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], cp, x, P)
     torch.cuda.synchronize()
-    assert eng.kernel_name("kf") == "kf_run_rows_kernel"
+    assert eng.kernel_name("kf") == "kf_run_rows2_kernel"
     assert int((full["status"] != 0).sum()) == 0 and torch.isfinite(full["x_out"]).all()
     # a contiguous slice alone reproduces the full run bit for bit (same kernel: B < 10,240)
     idx = torch.arange(1024, 1024 + 512, device="cuda")
