@@ -123,4 +123,61 @@ __device__ __forceinline__ void load_step_p(const KfRunArgs &a, int t, uint32_t 
     in.contact = buf_load_u32_nt(rc, voff, 0);
 }
 
+// ---- rows kernels (16 lanes per trajectory, four trajectories per wave): the step's 4 x 43 input dwords by FIVE LDS-DMA
+// instructions per wave (one per stream; lane L fetches one dword of one trajectory) instead of 43 loads per lane that every
+// one of a trajectory's 16 lanes repeats; the lanes then pick their trajectory's values up with 13 broadcast LDS reads.
+// No destination registers, so a step can be requested two steps ahead.  Stage layout (dwords): [p 64][f 64][dp 64][imu 64][contact 64],
+// a 12-vector stored in PAIR order (0,3,1,4,2,5,6,9,7,10,8,11) so that the leg pairs of StepInP are adjacent.
+constexpr int ROWS_STAGE = 5 * 64;
+struct RowsDma { uint32_t vo12, vo6, vo1; };      // per-lane byte offsets inside one step's block of a 12-, 6-, 1-row stream
+__device__ __forceinline__ RowsDma rows_dma_setup(int lane, int first_traj, int B)
+{
+    const int ord[12] = {0, 3, 1, 4, 2, 5, 6, 9, 7, 10, 8, 11};
+    RowsDma d;
+    const int l12 = lane < 48 ? lane : 0, l6 = lane < 24 ? lane : 0, l1 = lane < 4 ? lane : 0;
+    int row = ord[0];
+#pragma unroll
+    for (int i = 1; i < 12; i++) row = (l12 % 12 == i) ? ord[i] : row;
+    auto tr = [&](int g) { const int b = first_traj + g; return b < B ? b : B - 1; };
+    d.vo12 = (uint32_t)(row * B + tr(l12 / 12)) * 4u;
+    d.vo6 = (uint32_t)((l6 % 6) * B + tr(l6 / 6)) * 4u;
+    d.vo1 = (uint32_t)tr(l1) * 4u;
+    return d;
+}
+__device__ __forceinline__ void rows_dma_request(const KfRunArgs &a, int t, const RowsDma &d, uint32_t rowB, float *stage)
+{
+    const size_t B = (size_t)a.B;
+    lds_dma4(make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB), stage, d.vo12, 0);
+    lds_dma4(make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB), stage + 64, d.vo12, 0);
+    lds_dma4(make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB), stage + 128, d.vo12, 0);
+    lds_dma4(make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB), stage + 192, d.vo6, 0);
+    lds_dma4(make_rsrc(a.contact + (size_t)t * B, rowB), stage + 256, d.vo1, 0);
+}
+__device__ __forceinline__ void rows_dma_read(const float *stage, int grp, StepInP &in)
+{
+    const float4 *p4 = reinterpret_cast<const float4 *>(stage + grp * 12), *f4 = reinterpret_cast<const float4 *>(stage + 64 + grp * 12),
+                 *d4 = reinterpret_cast<const float4 *>(stage + 128 + grp * 12);
+    float v[3][12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float4 a = p4[i], b = f4[i], c = d4[i];
+        v[0][4 * i] = a.x; v[0][4 * i + 1] = a.y; v[0][4 * i + 2] = a.z; v[0][4 * i + 3] = a.w;
+        v[1][4 * i] = b.x; v[1][4 * i + 1] = b.y; v[1][4 * i + 2] = b.z; v[1][4 * i + 3] = b.w;
+        v[2][4 * i] = c.x; v[2][4 * i + 1] = c.y; v[2][4 * i + 2] = c.z; v[2][4 * i + 3] = c.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int j = 2 * (3 * q + c);
+            in.p[q][c] = (f2){v[0][j], v[0][j + 1]};
+            in.f[q][c] = (f2){v[1][j], v[1][j + 1]};
+            in.dp[q][c] = (f2){v[2][j], v[2][j + 1]};
+        }
+    const float2 *i2 = reinterpret_cast<const float2 *>(stage + 192 + grp * 6);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const float2 w = i2[i]; in.imu[2 * i] = w.x; in.imu[2 * i + 1] = w.y; }
+    in.contact = __builtin_bit_cast(uint32_t, stage[256 + grp]);
+}
+
 }  // namespace osk

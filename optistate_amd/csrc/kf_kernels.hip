@@ -396,8 +396,9 @@ __device__ __forceinline__ void fmac_shl(float &acc, float src, float m)       /
 template <bool AUX, bool FEAT>
 __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
 {
-    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
-    const int b_raw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + grp;
+    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+    const int first = (blockIdx.x * (blockDim.x >> 6) + wv) * 4;        // this wave's first trajectory
+    const int b_raw = first + grp;
     const bool live = b_raw < a.B;
     const int b = live ? b_raw : a.B - 1;
     const int rr = r < 12 ? r : 11;                    // idle lanes 12-15 shadow row 11 (never broadcast from, never stored)
@@ -417,9 +418,28 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     }
     const bool top = r < 3, mid = r >= 3 && r < 6;
     bool bad = false;
+    // step inputs: three LDS stages per wave, step t + 2 requested at the top of step t (rows_dma_*: kf_args.hpp)
+    __shared__ __attribute__((aligned(16))) float stage_all[4][3][ROWS_STAGE];
+    float (*stage)[ROWS_STAGE] = stage_all[wv];
+    const RowsDma dma = rows_dma_setup(lane, first, a.B);
+    // the plain variant issues exactly one store per step (x_out), so the wait below can leave step t + 1's five DMA loads and
+    // the last two stores in flight (loads and stores retire in issue order): vmcnt(7).  With optional outputs the store
+    // count is not a compile-time constant: wait for everything (one step of latency hiding instead of two).
+    const bool plain = !AUX && !FEAT && !a.p_rot_out;
     StepInP in;
-    load_step_p(a, 0, voff, rowB, in);
+    rows_dma_request(a, 0, dma, rowB, stage[0]);
+    rows_dma_request(a, a.T > 1 ? 1 : 0, dma, rowB, stage[1]);
     for (int t = 0; t < a.T; t++) {
+        // issued after DMA(t): t = 0: DMA(1); t = 1: DMA(2), store(0); t >= 2: store(t-2), DMA(t+1), store(t-1)
+        if (plain && t > 1) __builtin_amdgcn_s_waitcnt(0x0f77);            // vmcnt(7), nothing else waited for
+        else if (plain) __builtin_amdgcn_s_waitcnt(0x0f75);                 // vmcnt(5)
+        else __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        rows_dma_read(stage[t % 3], grp, in);
+        {
+            const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
+            rows_dma_request(a, tn, dma, rowB, stage[(t + 2) % 3]);
+        }
         // ---- the prior state, replicated per lane, as pairs ----
         f2 X[6];
         X[0] = (f2){row_bcast<0>(xr), row_bcast<1>(xr)}; X[1] = (f2){row_bcast<2>(xr), row_bcast<3>(xr)};
@@ -483,8 +503,6 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
 #undef OS_EPW
 #undef OS_EF
 #undef OS_EDP
-        // prefetch the next step's inputs underneath the update
-        load_step_p(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, in);
         // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
         asm volatile("s_nop 4");
 #define OS_ROW_UPDATE2(A, S)                                                                          \
