@@ -368,7 +368,7 @@ def cpu_baseline_mpc(target_seconds):
                       "the reference solves them with qpOASES (absent here: parity unpinned)"}
 
 
-def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only=False):
+def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only=False, latent=None):
     """The float64 C oracle over the TIMED batch itself (rank 0's shard), outside the timed region, split over all usable
     host cores: state_linf / gru_linf over EVERY (trajectory, timestep) it covers (BASELINE.json's metric is 'timesteps/s
     ...; state l-inf vs CPU ref', SURVEY 8(d): over all B x T), and the seconds the C entry points took -- the same run is
@@ -405,8 +405,10 @@ def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only
         if not kf_only:
             rows = np.concatenate([ref["x"], a["accel"], a["f"], ref["p_rot"], a["dp"], a["imu"]], axis=2)
             rows = (rows + 30.0) / 60.0
+            if latent is not None:          # the latent stream is appended un-normalised (it is in (0, 1) already: gru_test.py:135-136)
+                rows = np.concatenate([rows, latent[:, :, idx].permute(2, 0, 1).double().cpu().numpy()], axis=2)
             t0 = time.perf_counter()
-            ro, _, _ = orc.gru_forward(rows, w, 60, H, L, 24)
+            ro, _, _ = orc.gru_forward(rows, w, rows.shape[2], H, L, 24)
             secs += time.perf_counter() - t0
             g_linf = max(g_linf, float(np.abs(out[idx].cpu().numpy() - ro).max()))
         done += n
@@ -633,7 +635,7 @@ def bench_hot_path(a, rk):
     import torch
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_torch, NOISE_SETS
-    B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60
+    B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60 + a.latent
     fused = a.mode == "fused"
     eng = Engine(rk.local_rank)
     dev = eng.device
@@ -646,6 +648,8 @@ def bench_hot_path(a, rk):
     minmax = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).to(dev)
     x0 = d["x0"]
     x, P = x0.clone(), d["P0"].clone()
+    # the ViT latent stream of the reference's real model (188 = 60 + 128 inputs, gru/gru_train.py:30-34): already in (0, 1)
+    latent = torch.rand((T, a.latent, B), device=dev, generator=torch.Generator(device=dev).manual_seed(7)) if a.latent else None
 
     def run_set(noise, warmup, steps):
         """One timed run under a noise set: Q / R into the context, P0 = Q as the reference's callers start
@@ -657,7 +661,8 @@ def bench_hot_path(a, rk):
         def one_step():
             x.copy_(x0); P.copy_(P0)                    # device-to-device reset of the 40 MB filter state
             if fused:
-                return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, split_bf16=a.split_bf16)
+                return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, latent=latent,
+                                     split_bf16=a.split_bf16)
             return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
         # one to three launches per pass here: the per-kernel HIP events stay on over the timed region itself (two event
         # records per launch against milliseconds of kernel; the modes with dozens of short launches per step use a second
@@ -677,11 +682,14 @@ def bench_hot_path(a, rk):
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
     dk = kernels[dom]
     avg_ms = dk["ms_per_launch"]
-    default_shape = B == 65536 and T == 100 and H == 64 and L == 1
+    default_shape = B == 65536 and T == 100 and H == 64 and L == 1 and a.latent == 0
     if dom in ("gru_layer", "fused"):
         # MFMA-bound kernels: algorithmic flops = the GRU cell's matrix flops the launch performs (the Kalman
         # arithmetic of the fused kernel runs on the VALU and is not counted)
         fl = (gru_flops_per_step(I, H, L) if dom == "gru_layer" else gru_flops_per_step(I, H, 1)) * steps_per_pass / dk["launches_per_step"]
+        if dom == "gru_layer" and "fused" in kernels:
+            # the single fused kernel ran layer 0 (H = 64 stacks): the layer launches are layers 1 .. L-1
+            fl = (gru_flops_per_step(I, H, L) - gru_flops_per_step(I, H, 1)) * steps_per_pass / dk["launches_per_step"]
         ach = fl / (avg_ms * 1e-3) / 1e12
         peak = MFMA_BF16_PEAK_TF if (a.split_bf16 and dom == "fused") else MFMA_F32_PEAK_TF
         insn = ("v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if a.split_bf16 == 3 else "v_mfma_f32_32x32x16_bf16 x3 (hi/lo split)") \
@@ -738,7 +746,7 @@ def bench_hot_path(a, rk):
     cap = max(4.0 * a.cpu_seconds, 60.0)
     if a.parity_samples != 0:
         want = B if a.parity_samples < 0 else min(a.parity_samples, B)
-        out["parity"], timing = oracle_pass(d, r["x_out"], r.get("out"), model, H, L, Q, R, Q, want, cap, kf_only=not fused)
+        out["parity"], timing = oracle_pass(d, r["x_out"], r.get("out"), model, H, L, Q, R, Q, want, cap, kf_only=not fused, latent=latent)
         if timing["trajectories"] >= 2048:
             all_cores = timing
         if a.split_bf16:
@@ -751,10 +759,12 @@ def bench_hot_path(a, rk):
                "status_nonzero_trajectories": int((r2["status"] != 0).sum().item())}
         if a.parity_samples != 0:
             want2 = B if a.parity_samples < 0 else min(a.parity_samples, B)
-            sec["parity"], _ = oracle_pass(d, r2["x_out"], r2.get("out"), model, H, L, Q2, R2, Q2, want2, cap, kf_only=not fused)
+            sec["parity"], _ = oracle_pass(d, r2["x_out"], r2.get("out"), model, H, L, Q2, R2, Q2, want2, cap, kf_only=not fused, latent=latent)
         out["second_noise_set"] = sec
     if a.cpu_seconds > 0 and rk.world == 1:
-        out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds, kf_only=not fused, all_cores=all_cores)
+        out["cpu_baseline"] = cpu_baseline(H, L, a.cpu_seconds, kf_only=not fused, all_cores=all_cores if a.latent == 0 else None)
+        if a.latent:
+            out["cpu_baseline"]["note"] = "sampled on the 60-wide input (no latent stream)"
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
@@ -781,6 +791,7 @@ def main(argv=None):
     ap.add_argument("--seq", type=int, default=100)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--latent", type=int, default=0, help="width of a latent stream appended to the 60 Kalman features (128: the reference's 188-wide GRU input)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--parity-samples", type=int, default=-1,
                     help="trajectories of the timed batch checked against the oracle over all their timesteps (-1 = the whole batch, 0 = skip)")

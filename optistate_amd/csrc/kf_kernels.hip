@@ -393,6 +393,23 @@ __device__ __forceinline__ void fmac_shl(float &acc, float src, float m)       /
     asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
 
+// Development build only (-DOS_ROWS_TS, tools/rows_ts.sh): shader-clock stamps at the phase boundaries of a step, summed over the
+// steps by lane 0 of workgroup 0 and written to kgain_out (unused by this kernel) as 8 x uint64.
+#ifdef OS_ROWS_TS
+#define OS_TS_DECL unsigned long long ts_prev = 0, ts_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define OS_TS(i)                                                                   \
+    {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        const unsigned long long now = __builtin_readcyclecounter();               \
+        if ((i) > 0) ts_sum[i] += now - ts_prev;                                   \
+        ts_prev = now;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    }
+#else
+#define OS_TS_DECL
+#define OS_TS(i)
+#endif
+
 template <bool AUX, bool FEAT>
 __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
 {
@@ -427,9 +444,11 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     // count is not a compile-time constant: wait for everything (one step of latency hiding instead of two).
     const bool plain = !AUX && !FEAT && !a.p_rot_out;
     StepInP in;
+    OS_TS_DECL
     rows_dma_request(a, 0, dma, rowB, stage[0]);
     rows_dma_request(a, a.T > 1 ? 1 : 0, dma, rowB, stage[1]);
     for (int t = 0; t < a.T; t++) {
+        OS_TS(0)
         // issued after DMA(t): t = 0: DMA(1); t = 1: DMA(2), store(0); t >= 2: store(t-2), DMA(t+1), store(t-1)
         if (plain && t > 1) __builtin_amdgcn_s_waitcnt(0x0f77);            // vmcnt(7), nothing else waited for
         else if (plain) __builtin_amdgcn_s_waitcnt(0x0f75);                 // vmcnt(5)
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
             rows_dma_request(a, tn, dma, rowB, stage[(t + 2) % 3]);
         }
+        OS_TS(1)                                        // wait + LDS reads + next request
         // ---- the prior state, replicated per lane, as pairs ----
         f2 X[6];
         X[0] = (f2){row_bcast<0>(xr), row_bcast<1>(xr)}; X[1] = (f2){row_bcast<2>(xr), row_bcast<3>(xr)};
@@ -448,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         float z[NM], g[9];
         f2 PW[2][3];
         kf_step_inputs_sym(X, in, k, z, PW, g);          // measurement, next_state, g = dt R^T of the prior attitude
+        OS_TS(2)                                        // state broadcast + rotations + odometry + next_state
         // ---- covariance predict, row-parallel: M = F_d P (rows: lane r needs rows 6..8 or row r + 6), then P' = M F_d^T + Q (local) ----
         const float cg0 = top ? (r == 0 ? g[0] : (r == 1 ? g[3] : g[6])) : 0.f;
         const float cg1 = top ? (r == 0 ? g[1] : (r == 1 ? g[4] : g[7])) : 0.f;
@@ -471,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         }
 #pragma unroll
         for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
+        OS_TS(3)                                        // covariance predict
         // ---- this lane's component of the predicted state and of the step's by-products ----
         // element rr of a twelve-vector held as compile-time-indexed registers: a select chain (a lambda with a loop inside
         // would index the array at run time, and hipcc then moves it to LDS)
@@ -503,6 +525,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
 #undef OS_EPW
 #undef OS_EF
 #undef OS_EDP
+        OS_TS(4)                                        // component selects, optional outputs
         // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
         asm volatile("s_nop 4");
 #define OS_ROW_UPDATE2(A, S)                                                                          \
@@ -519,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         OS_ROW_UPDATE2(0, 0) OS_ROW_UPDATE2(1, 1) OS_ROW_UPDATE2(2, 2) OS_ROW_UPDATE2(3, 5) OS_ROW_UPDATE2(4, 6)
         OS_ROW_UPDATE2(5, 7) OS_ROW_UPDATE2(6, 8) OS_ROW_UPDATE2(7, 9) OS_ROW_UPDATE2(8, 10) OS_ROW_UPDATE2(9, 11)
 #undef OS_ROW_UPDATE2
+        OS_TS(5)                                        // ten measurement updates
         if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
         if (FEAT && live && r < 12)
             __builtin_nontemporal_store((xr - a.minmax[r]) / (a.minmax[60 + r] - a.minmax[r]), a.feat_out + ((size_t)t * a.feat_I + r) * B + b);
@@ -531,6 +555,12 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
             if (live && r == 0) a.ptrace_out[(size_t)t * B + b] = dg;
         }
     }
+#ifdef OS_ROWS_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.kgain_out) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.kgain_out);
+        for (int i = 0; i < 8; i++) o[i] = ts_sum[i];
+    }
+#endif
     // ---- final state: lane r writes x[r] and row r of P; the status word is OR-reduced over the 16 lanes ----
     int status = (bad ? 1 : 0) | ((xr * 0.f == 0.f) ? 0 : 2);
     status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
@@ -665,16 +695,27 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE, dense = flags & OS_KF_DENSE_FD;
     if (dense && !a.body_ref) return os_fail(ctx, -2, "os_kf_run: OS_KF_DENSE_FD needs body_ref");
     if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_run: sequential update needs a diagonal R");
+#ifndef OS_ROWS_TS
     if (seq && a.kgain_out) return os_fail(ctx, -3, "os_kf_run: K_gain is only defined by the batch update");
+#endif
     if ((size_t)a.B * 144 * 4 >= 0xffffffffull) return os_fail(ctx, -2, "os_kf_run: B too large for 32-bit buffer offsets");
     a.k = ctx->k;
+#ifdef OS_ROWS_TS
+    const bool aux = a.ptrace_out != nullptr, feat = a.feat_out != nullptr;
+#else
     const bool aux = a.ptrace_out || a.kgain_out, feat = a.feat_out != nullptr;
+#endif
     if (feat && aux) return os_fail(ctx, -3, "os_kf_run: feature emission and P_trace/K_gain outputs are exclusive");
     hipError_t e;
     const bool noise = a.q_diag != nullptr;
     if (noise && (!seq || dense || a.kgain_out || !a.r_diag))
         return os_fail(ctx, -3, "os_kf_run_noise: per-trajectory noise needs the sequential update, predict(p,f) covariance, no K_gain");
-    const bool use_rows = !noise && seq && !dense && !a.kgain_out && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
+#ifdef OS_ROWS_TS
+    const bool no_gain = true;                 // development build: kgain_out carries the timestamp sums
+#else
+    const bool no_gain = !a.kgain_out;
+#endif
+    const bool use_rows = !noise && seq && !dense && no_gain && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
                           a.B < ctx->rows_kernel_below && ctx->kf_qr;
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise) && !a.kgain_out;
     const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
