@@ -71,8 +71,11 @@ class FlatBucket:
         params = list(params)
         device = device or params[0].device
         n = sum(p.numel() for p in params)
+        self.n = n
         self.w = torch.empty(n, dtype=torch.float32, device=device)
-        self.g = torch.zeros(n, dtype=torch.float32, device=device)
+        # one extra slot behind the gradients: the rank's sample count rides in the same all-reduce (allreduce_weighted_)
+        self._gbuf = torch.zeros(n + 1, dtype=torch.float32, device=device)
+        self.g = self._gbuf[:n]
         off = 0
         for p in params:
             k = p.numel()
@@ -89,6 +92,20 @@ class FlatBucket:
             if world > 1:
                 dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group)
                 self.g.div_(world)
+        return self.g
+
+    def allreduce_weighted_(self, n_local, group=None):
+        """g holds the gradient of this rank's LOCAL mean loss over n_local samples (what the loss kernel produces).  The
+        gradient of the GLOBAL mean is sum_r n_r g_r / sum_r n_r: equal to the plain mean over ranks only when the shards are
+        equal, so ragged last shards (a dataset that does not divide by the world size, gru_train.py:216 random_split) are
+        weighted by their size.  ONE collective: the count travels in the bucket's extra slot."""
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+            if world > 1:
+                self.g.mul_(float(n_local))
+                self._gbuf[self.n] = float(n_local)
+                dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
+                self.g.div_(self._gbuf[self.n])
         return self.g
 
 
@@ -115,7 +132,7 @@ class DataParallelTrainer:
         out = e.gru_forward_train(x)
         loss, dout, _ = e.gru_loss(out, y)
         e.gru_backward(x, out, dout, grad_flat=self.bucket.g)
-        self.bucket.allreduce_mean_(self.group)
+        self.bucket.allreduce_weighted_(x.shape[0], self.group)      # equal shards: the plain mean; ragged shards: weighted by size
         self.t += 1
         e.adam_step(self.bucket.w, self.bucket.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
         # the fused Adam wrote the flat bucket in place: the packed copy in the engine is stale now, and torch's version

@@ -71,6 +71,58 @@ def test_flat_bucket_allreduce_equals_full_batch_gradient():
         assert ret[r][3]
 
 
+def _worker_weighted(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from optistate_amd.train import FlatBucket, shard_range
+        torch.manual_seed(0)
+        gru = torch.nn.GRU(12, 16, 2, batch_first=True); fc = torch.nn.Linear(16, 8)
+        params = list(gru.parameters()) + list(fc.parameters())
+        B = 41                                             # 14 + 14 + 13 over three ranks
+        g = torch.Generator().manual_seed(2)
+        x = torch.rand(B, 5, 12, generator=g); y = torch.rand(B, 4, generator=g)
+
+        def local_mean_loss(xs, ys):                       # what DataParallelTrainer's loss kernel computes: MSE over the rank's own samples
+            o, _ = gru(xs)
+            out = torch.sigmoid(fc(o[:, -1, :]))
+            tgt = torch.cat([ys, (out[:, :4].detach() - ys).abs()], dim=1)
+            return torch.nn.functional.mse_loss(out, tgt)
+
+        bucket = FlatBucket(params)
+        lo, hi = shard_range(B, rank, world)
+        grads = torch.autograd.grad(local_mean_loss(x[lo:hi], y[lo:hi]), params)
+        off = 0
+        for p, gr in zip(params, grads):
+            bucket.g[off:off + p.numel()].copy_(gr.reshape(-1)); off += p.numel()
+        plain = bucket.g.clone()
+        bucket.allreduce_weighted_(hi - lo)
+        ref = torch.cat([t.reshape(-1) for t in torch.autograd.grad(local_mean_loss(x, y), params)])
+        err_w = (bucket.g - ref).abs().max().item()
+        # the unweighted mean of the local-mean gradients is NOT the full-batch gradient when shards differ
+        dist.all_reduce(plain); plain /= world
+        err_plain = (plain - ref).abs().max().item()
+        ret[rank] = (err_w, err_plain, hi - lo, float(ref.abs().max()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weighted_bucket_allreduce_with_ragged_shards_world_3():
+    """Three ranks, 41 samples (14 / 14 / 13): the size-weighted single all-reduce reproduces the full-batch mean gradient
+    from the ranks' LOCAL-mean gradients (what the loss kernel produces); the plain mean over ranks does not."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29600 + os.getpid() % 1000
+    mp.spawn(_worker_weighted, args=(world, port, ret), nprocs=world, join=True)
+    assert sorted(ret[r][2] for r in range(world)) == [13, 14, 14]
+    for r in range(world):
+        err_w, err_plain, _, scale = ret[r]
+        assert err_w < 1e-6 * max(1.0, scale), ret[r]
+        assert err_plain > 10 * err_w                      # the test would notice a trainer that averaged unweighted
+
+
 def test_shard_range_covers_every_unit_once():
     from optistate_amd.train import shard_range
     for n in (0, 1, 7, 64, 65536, 65537):
