@@ -100,6 +100,38 @@ __device__ __forceinline__ void read_step_lds_p(const float *lds, int lane, Step
     in.contact = __builtin_bit_cast(uint32_t, lds[42 * 64 + lane]);
 }
 
+// Asynchronous form for a software-pipelined loop: lds_issue_step starts the 22 LDS reads of a staged step into a StepRaw
+// WITHOUT waiting for them (inline asm: hipcc would put an s_waitcnt in front of the first use, wherever its scheduler moved
+// that); lds_fence_step is the matching wait and hands the values over as a StepInP.  Between the two calls nothing reads the
+// raw registers: the fence takes them as read-write operands, so every use is ordered behind it (a compiler-made copy in
+// front of the wait would read registers whose data has not arrived).
+struct StepRaw { f2 v[21]; float c; };
+__device__ __forceinline__ void lds_issue_step(const float *stage, int lane, StepRaw &r)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)stage + (uint32_t)lane * 4u;
+#define OSK_RD2(i, o0, o1) asm volatile("ds_read2st64_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(r.v[i]) : "v"(addr))
+    OSK_RD2(0, 0, 3);    OSK_RD2(1, 1, 4);    OSK_RD2(2, 2, 5);    OSK_RD2(3, 6, 9);    OSK_RD2(4, 7, 10);   OSK_RD2(5, 8, 11);     // p
+    OSK_RD2(6, 12, 15);  OSK_RD2(7, 13, 16);  OSK_RD2(8, 14, 17);  OSK_RD2(9, 18, 21);  OSK_RD2(10, 19, 22); OSK_RD2(11, 20, 23);   // f
+    OSK_RD2(12, 24, 27); OSK_RD2(13, 25, 28); OSK_RD2(14, 26, 29); OSK_RD2(15, 30, 33); OSK_RD2(16, 31, 34); OSK_RD2(17, 32, 35);   // dp
+    OSK_RD2(18, 36, 37); OSK_RD2(19, 38, 39); OSK_RD2(20, 40, 41);                                                                    // imu
+#undef OSK_RD2
+    asm volatile("ds_read_b32 %0, %1 offset:10752" : "=v"(r.c) : "v"(addr));       // row 42: the contact word
+}
+__device__ __forceinline__ void lds_fence_step(StepRaw &r, StepInP &in)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+                   "+v"(r.v[8]), "+v"(r.v[9]), "+v"(r.v[10]), "+v"(r.v[11]), "+v"(r.v[12]), "+v"(r.v[13]), "+v"(r.v[14]), "+v"(r.v[15]),
+                   "+v"(r.v[16]), "+v"(r.v[17]), "+v"(r.v[18]), "+v"(r.v[19]), "+v"(r.v[20]), "+v"(r.c));
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { in.p[q][c] = r.v[3 * q + c]; in.f[q][c] = r.v[6 + 3 * q + c]; in.dp[q][c] = r.v[12 + 3 * q + c]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { in.imu[2 * i] = r.v[18 + i][0]; in.imu[2 * i + 1] = r.v[18 + i][1]; }
+    in.contact = __builtin_bit_cast(uint32_t, r.c);
+}
+
 // the same from global memory straight into the pairs' halves (fused kernel: 43 loads in flight underneath the GRU cell)
 __device__ __forceinline__ void load_step_p(const KfRunArgs &a, int t, uint32_t voff, uint32_t rowB, StepInP &in)
 {

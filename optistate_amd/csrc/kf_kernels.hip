@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 // status bit 3: the caller's P0 is not symmetric (checked once per launch against the lower triangle, 66 extra loads per
 // trajectory): the symmetric-storage kernels would silently run a different filter than the reference, which never
 // symmetrises P (kalman_filter/kalman_filter.py:172)
-template <int OUT, bool QDIAG>
+template <int OUT, bool QDIAG, bool PRE = false>
 __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfConst &kc, const int b)
 {
     const size_t B = (size_t)a.B;
@@ -121,20 +121,38 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
         sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
     }
-    // step inputs: LDS-DMA double buffer, step t + 1 requested at the top of step t (see load_step_dma)
-    __shared__ float stage[2][STEP_DWORDS * 64];
+    // Step inputs by LDS-DMA.  General form: double buffer, step t + 1 requested at the top of step t, picked up at the top of
+    // step t + 1.  PRE (plain runs: x_out the only output, so the number of stores per step is known): THREE stages, step
+    // t + 2 requested at the top of step t, and step t + 1's LDS reads issued in the middle of step t (asynchronously, into
+    // registers of their own: lds_issue_step) so that they complete underneath the measurement update -- the top of a step
+    // used to wait out the 22 dependent LDS reads with nothing else to issue (~0.9 k of a step's 6.3 k cycles, PMC).
+    constexpr int NSTAGE = PRE ? 3 : 2;
+    __shared__ float stage[NSTAGE][STEP_DWORDS * 64];
     const int lane = threadIdx.x & 63;
     StepInP in;
+    StepRaw raw;
     bool bad = false;
     load_step_dma(a, 0, voff, rowB, stage[0]);
-    for (int t = 0; t < a.T; t++) {
-        // vmcnt(12): step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in issue order
-        // with the loads, and the twelve x_out stores of step t - 1 were issued a few instructions ago -- everything older
-        // than the last twelve operations includes every DMA load.
-        __builtin_amdgcn_s_waitcnt(0x0f7c);
+    if (PRE) {
+        load_step_dma(a, a.T > 1 ? 1 : 0, voff, rowB, stage[1]);
+        __builtin_amdgcn_s_waitcnt(0x8f7b);                            // vmcnt(43): step 0 has landed, step 1 may be in flight
         __builtin_amdgcn_wave_barrier();
-        read_step_lds_p(stage[t & 1], lane, in);
-        load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, stage[(t + 1) & 1]);
+        lds_issue_step(stage[0], lane, raw);
+    }
+    for (int t = 0; t < a.T; t++) {
+        if (PRE) {
+            lds_fence_step(raw, in);
+            const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
+            load_step_dma(a, tn, voff, rowB, stage[(t + 2) % 3]);
+        } else {
+            // vmcnt(12): step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in issue
+            // order with the loads, and the twelve x_out stores of step t - 1 were issued a few instructions ago -- everything
+            // older than the last twelve operations includes every DMA load.
+            __builtin_amdgcn_s_waitcnt(0x0f7c);
+            __builtin_amdgcn_wave_barrier();
+            read_step_lds_p(stage[t & 1], lane, in);
+            load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, stage[(t + 1) & 1]);
+        }
         float z[NM];
         f2 PW[2][3];
         kf_step_front_sym<QDIAG>(X, U, in, kc, z, PW);
@@ -160,6 +178,13 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
 #pragma unroll
             for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw(i));
         }
+        if (PRE) {
+            // step t + 1 (requested at the top of step t - 1): issued before it are only step t + 2's 43 loads and nothing
+            // younger matters, so vmcnt(43) -- which also covers step t - 1's twelve stores, issued long ago
+            __builtin_amdgcn_s_waitcnt(0x8f7b);
+            __builtin_amdgcn_wave_barrier();
+            lds_issue_step(stage[(t + 1) % 3], lane, raw);
+        }
         bad |= update_sequential_sym(X, U, z, kc);            // non-finite states stay non-finite: checked once after the loop
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
@@ -184,12 +209,12 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
     a.status[b] = status | (bad ? 1 : 0) | finite_status_p(X);
 }
 
-template <int OUT, bool QDIAG>
+template <int OUT, bool QDIAG, bool PRE = false>
 __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
-    kf_run_sym_body<OUT, QDIAG>(a, a.k, b);
+    kf_run_sym_body<OUT, QDIAG, PRE>(a, a.k, b);
 }
 
 // Per-trajectory diagonal noise (os_kf_run_noise): each lane overwrites the diagonals of its own copy of the constants
@@ -750,7 +775,11 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
         if (qd) hipLaunchKernelGGL((kf_run_sym_kernel<OUT, true>), grid, block, 0, s, a);                  \
         else hipLaunchKernelGGL((kf_run_sym_kernel<OUT, false>), grid, block, 0, s, a);                    \
     } while (0)
-        if (feat) OS_SYM(2); else if (aux) OS_SYM(1); else OS_SYM(0);
+        if (feat) OS_SYM(2);
+        else if (aux) OS_SYM(1);
+        else if (a.p_rot_out || ctx->tune_sym_pre == 0) OS_SYM(0);
+        else if (qd) hipLaunchKernelGGL((kf_run_sym_kernel<0, true, true>), grid, block, 0, s, a);      // plain run: inputs picked up half a step ahead
+        else hipLaunchKernelGGL((kf_run_sym_kernel<0, false, true>), grid, block, 0, s, a);
 #undef OS_SYM
         e = hipGetLastError();
     } else if (seq && !dense && ctx->q_is_diagonal)   // sequential update, diagonal Q and R, full P

@@ -17,6 +17,7 @@ struct os_ctx {
     bool r_is_diagonal, q_is_diagonal;
     float *kf_qr;                        // device copy of Q (144) and R (100) for per-lane indexing (small-batch kernel)
     int rows_kernel_below;               // use the 16-lanes-per-trajectory kernel when B is below this
+    int tune_sym_pre;                    // OS_KF_SYM_PRE=0: kf_run_sym_kernel without the half-step-ahead LDS pick-up of the inputs (A/B runs)
     int tune_rows_v1;                    // OS_KF_ROWS_V1=1: the first 16-lanes-per-trajectory kernel instead of kf_run_rows2_kernel (A/B runs)
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
