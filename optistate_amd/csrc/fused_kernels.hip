@@ -339,6 +339,23 @@ __global__ void fused_pack_kernel(const float *__restrict__ w0 /* layer 0, torch
     if (blockIdx.x == 0 && threadIdx.x < 64) img[2 * CHF2 + threadIdx.x] = threadIdx.x < KX ? minmax[threadIdx.x] : 0.f;
 }
 
+// Development build only (-DOS_FUSED_TS, tools/fused_ts.sh): shader-clock stamps between the phases of a step, summed over the
+// steps by lane 0 of workgroup 0 and printed at the end of the kernel.
+#ifdef OS_FUSED_TS
+#define OSF_TS_DECL unsigned long long ts_prev = 0, ts_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define OSF_TS(i)                                                                  \
+    {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        const unsigned long long now = __builtin_readcyclecounter();               \
+        if ((i) > 0) ts_sum[i] += now - ts_prev;                                   \
+        ts_prev = now;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    }
+#else
+#define OSF_TS_DECL
+#define OSF_TS(i)
+#endif
+
 template <bool QDIAG, bool SEQOUT>
 __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs a)
 {
@@ -392,7 +409,9 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
     }
 
+    OSF_TS_DECL
     for (int t = 0; t < k.T; t++) {
+        OSF_TS(0)
         // ================= Kalman step (lane = trajectory) =================
         // Order chosen for register pressure: everything that reads the step's 55 input registers runs first (measurement,
         // dynamics, the 48 raw-input features, which go straight to AGPRs); the covariance predict and the update then work
@@ -402,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         float g9[9];
         kf_step_inputs_sym(X, in, k.k, z, PW, g9);
         __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(1)                                        // wait for the prefetched inputs + rotations, odometry, next_state
         // Features [x_post | accel | f | p_world | dp | imu] minus their minimum (the 1/(max-min) scale sits in the packed
         // weights).  v_permlane32_swap turns a feature pair into the two B fragments of its k-pair: afterwards the first
         // register holds trajectories 0-31 (lanes 0-31: feature 2kp, lanes 32-63: feature 2kp+1), the second trajectories
@@ -428,8 +448,10 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         feat6(48, OSF_LEG(in.dp, 6), OSF_LEG(in.dp, 7), OSF_LEG(in.dp, 8), OSF_LEG(in.dp, 9), OSF_LEG(in.dp, 10), OSF_LEG(in.dp, 11), in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
               in.imu[5]);
         __builtin_amdgcn_sched_barrier(0);          // the inputs are in AGPRs now: the covariance work below starts with their registers free
+        OSF_TS(2)                                        // 48 raw features: subtract, swap, AGPR
         cov_predict_sym_blk<QDIAG>(U, g9, k.k);
         __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(3)                                        // covariance predict
         bad |= update_sequential_sym(X, U, z, k.k);      // non-finite states stay non-finite: checked once after the loop
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
@@ -437,6 +459,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
             for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, OSF_X(i));
         }
         feat6(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
+        OSF_TS(4)                                        // ten measurement updates, x_out stores, 12 state features
 
         // One 32-trajectory column block and one 32-unit chunk at a time: 64 accumulator registers, in VGPRs, where the cell
         // update reads them directly (the weight fragments are simply read from LDS again for each of the four passes).  Chunk
@@ -490,6 +513,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                     mfma_va(acc[gn], wb[cur].z, bv);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                OSF_TS(5)                                // bias init + 186 MFMAs (x 4 passes)
                 mfma_drain(acc);
                 // Cell update in place on the accumulator registers (scales folded into the weights: sigmoid = rcp(1 + exp2(a))),
                 // stage by stage over the 16 elements so that no instruction depends on its predecessor, the seven
@@ -526,10 +550,12 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                         else hreg[rb][1][e] = hn;
                     }
                 }
+                OSF_TS(6)                                // drain + cell update (x 4 passes)
             }
 #pragma unroll
             for (int e = 0; e < 16; e++) hreg[rb][0][e] = agpr_mov(park[e]);
         }
+        OSF_TS(7)
         if (SEQOUT) {
             // layer-0 output sequence [T][64][B] for deeper stacks: lanes 0-31 / 32-63 write two 128-byte row segments
 #pragma unroll
@@ -548,6 +574,11 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         }
     }
 
+#ifdef OS_FUSED_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("fused_v2 cycles per step: inputs %llu | features %llu | predict %llu | update %llu | mfma(4 passes) %llu | cell(4 passes) %llu | park %llu\n",
+               ts_sum[1] / k.T, ts_sum[2] / k.T, ts_sum[3] / k.T, ts_sum[4] / k.T, ts_sum[5] / k.T, ts_sum[6] / k.T, ts_sum[7] / k.T);
+#endif
     // ---- final state, status, h_T for the head kernel ----
     status |= (bad ? 1 : 0) | finite_status_p(X);
     if (live) {
