@@ -649,7 +649,13 @@ def bench_hot_path(a, rk):
     x0 = d["x0"]
     x, P = x0.clone(), d["P0"].clone()
     # the ViT latent stream of the reference's real model (188 = 60 + 128 inputs, gru/gru_train.py:30-34): already in (0, 1)
-    latent = torch.rand((T, a.latent, B), device=dev, generator=torch.Generator(device=dev).manual_seed(7)) if a.latent else None
+    # (generated straight into rows 60.. of the GRU input buffer [T][60 + NL][B]: the Kalman kernel fills rows 0..59 in place,
+    # Engine.gru_input_with_latent does the same from the encoder's (B, T, NL) output)
+    gru_in = latent = None
+    if a.latent:
+        gru_in = torch.empty((T, 60 + a.latent, B), device=dev)
+        gru_in[:, 60:] = torch.rand((T, a.latent, B), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+        latent = gru_in[:, 60:]
 
     def run_set(noise, warmup, steps):
         """One timed run under a noise set: Q / R into the context, P0 = Q as the reference's callers start
@@ -661,7 +667,7 @@ def bench_hot_path(a, rk):
         def one_step():
             x.copy_(x0); P.copy_(P0)                    # device-to-device reset of the 40 MB filter state
             if fused:
-                return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, latent=latent,
+                return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, gru_input=gru_in,
                                      split_bf16=a.split_bf16)
             return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
         # one to three launches per pass here: the per-kernel HIP events stay on over the timed region itself (two event

@@ -76,7 +76,11 @@ enum {
     OS_FUSED_SPLIT_BF16     = 512, /* os_fused_run: opt-in gate GEMM on the bf16 MFMA (fp32 operands split into THREE bf16
                                      terms = all 24 mantissa bits, six MFMAs per product block, fp32 accumulate); NOT the
                                      exact-fp32 default.  Measured GRU head l-inf vs the float64 oracle: 8e-8. */
-    OS_FUSED_SPLIT_BF16_2   = 1024 /* the same with TWO bf16 terms (16 mantissa bits, three MFMAs per block): 5e-7. */
+    OS_FUSED_SPLIT_BF16_2   = 1024, /* the same with TWO bf16 terms (16 mantissa bits, three MFMAs per block): 5e-7. */
+    OS_FUSED_LATENT_IN_PLACE = 2048 /* os_fused_run with n_latent > 0: `latent` is the caller's WHOLE GRU input buffer [T][60 + NL][B]
+                                     with rows 60.. already holding the latent stream (os_pack_stream_rows writes them there);
+                                     the Kalman kernel fills rows 0..59 in place and the GRU reads the buffer directly -- no
+                                     feature scratch, no copy of the latent (1 KB per step at NL = 128).  The buffer is WRITTEN. */
 };
 
 /* Replaces Kalman_Filter.__init__ (kalman_filter/kalman_filter.py:8-62): creates a context on cfg->device. */
@@ -181,6 +185,11 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
  * (gru/gru_test.py:99-101; minmax = device float[2][60]: mins then maxs) + optional latent [T][NL][B] appended
  * (gru/gru_test.py:135-136) + GRU over the T-step sequence + head, without writing feature rows to HBM.
  * Requires os_gru_load with input_size == 60 + n_latent.  out [B][C]. */
+/* os_pack_stream into rows [row0, row0 + F) of a wider stream: src [B][T][F] (batch-major, e.g. the ViT encoder's latent
+ * (N, 128) = (B, T, 128)) -> dst [T][F_total][B].  With row0 = 60, F_total = 60 + F this builds the OS_FUSED_LATENT_IN_PLACE input. */
+int os_pack_stream_rows(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src, float *dst, int32_t F_total, int32_t row0,
+                        void *stream);
+
 int os_fused_run(os_ctx *ctx, int32_t B, int32_t T,
                  const float *p, const float *f, const float *dp, const float *imu, const uint32_t *contact,
                  const float *accel, const float *body_ref, const float *latent, int32_t n_latent,

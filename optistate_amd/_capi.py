@@ -16,6 +16,7 @@ OS_FUSED_ONE_KERNEL = 128
 OS_KF_P_FLOAT64 = 256
 OS_FUSED_SPLIT_BF16 = 512
 OS_FUSED_SPLIT_BF16_2 = 1024
+OS_FUSED_LATENT_IN_PLACE = 2048
 OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD = 1, 2, 4, 8
 OS_PROF_PHASES = 12         # include/optistate_hip.h
 PHASE_NAMES = ("kf", "gru_layer", "gru_head", "fused", "mpc", "train_sweep", "train_dw", "train_misc", "vit_gemm",
@@ -29,7 +30,7 @@ EXPORTS = [
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
     "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
-    "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed",
+    "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows",
 ]
 
 
@@ -95,6 +96,8 @@ def load():
     lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]
     lib.os_pack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
     lib.os_unpack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
+    lib.os_pack_stream_rows.argtypes = [vp, i32, i32, i32, f32p, f32p, i32, i32, vp]
+    lib.os_pack_stream_rows.restype = C.c_int
     lib.os_gru_forward_train.argtypes = [vp, i32, i32, f32p, f32p, vp]
     lib.os_gru_loss.argtypes = [vp, i32, f32p, f32p, f32p, f32p, f32p, vp]
     lib.os_gru_backward.argtypes = [vp, i32, i32, f32p, f32p, f32p, f32p, f32p, vp]

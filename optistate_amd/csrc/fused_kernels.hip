@@ -1071,6 +1071,14 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
         return 0;
     }
 
+    if (n_latent > 0 && (flags & OS_FUSED_LATENT_IN_PLACE)) {
+        // the caller's buffer IS the GRU input [T][I][B] (rows 60.. = latent): features written in place, nothing copied
+        float *buf = const_cast<float *>(latent);
+        a.feat_out = buf;
+        const int rc = os_kf_run_impl(ctx, a, flags & ~(OS_FUSED_TWO_KERNEL | OS_FUSED_LATENT_IN_PLACE), s);
+        if (rc) return rc;
+        return os_gru_layers_impl(ctx, B, T, buf, 0, out, nullptr, s);
+    }
     // general path: Kalman kernel emits normalised feature rows [T][I][B] into context scratch, GRU kernels consume them
     const size_t need = (size_t)T * I * B;
     if (ctx->feat_floats < need) {

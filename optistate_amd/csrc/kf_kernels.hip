@@ -702,6 +702,22 @@ __global__ void pack_btf_to_tfb(int B, int TF, const float *__restrict__ src, fl
     }
 }
 
+// src [B][T][F] -> rows [row0, row0 + F) of dst [T][F_total][B]; blockIdx.z = time step
+__global__ void pack_btf_rows(int B, int T, int F, int F_total, int row0, const float *__restrict__ src, float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const int fx = blockIdx.x * 32, by = blockIdx.y * 32, t = blockIdx.z;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int bb = by + r, c = fx + threadIdx.x;
+        if (bb < B && c < F) tile[r][threadIdx.x] = src[((size_t)bb * T + t) * F + c];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int c = fx + r, bb = by + threadIdx.x;
+        if (bb < B && c < F) dst[((size_t)t * F_total + row0 + c) * B + bb] = tile[threadIdx.x][r];
+    }
+}
+
 }  // namespace osk
 
 using namespace osk;
@@ -895,6 +911,19 @@ int os_pack_stream(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *sr
     const int TF = T * F;
     dim3 grid((TF + 31) / 32, (B + 31) / 32), block(32, 8);
     hipLaunchKernelGGL(pack_btf_to_tfb, grid, block, 0, (hipStream_t)stream, B, TF, src, dst);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int os_pack_stream_rows(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src, float *dst, int32_t F_total, int32_t row0,
+                        void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || T <= 0 || F <= 0 || !src || !dst || row0 < 0 || row0 + F > F_total)
+        return os_fail(ctx, -2, "os_pack_stream_rows: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid((F + 31) / 32, (B + 31) / 32, T), block(32, 8);
+    hipLaunchKernelGGL(pack_btf_rows, grid, block, 0, (hipStream_t)stream, B, T, F, F_total, row0, src, dst);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -14,7 +14,8 @@ import torch
 
 from . import _capi
 from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
-                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16, OS_FUSED_SPLIT_BF16_2)
+                    OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16, OS_FUSED_SPLIT_BF16_2,
+                    OS_FUSED_LATENT_IN_PLACE)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -104,6 +105,16 @@ class Engine:
         out = torch.empty((T, F, B), dtype=torch.float32, device=self.device)
         self._check(self.lib.os_pack_stream(self._h, B, T, F, _ptr(a), _ptr(out), self._stream()), "os_pack_stream")
         return out
+
+    def gru_input_with_latent(self, latent_btn):
+        """The GRU input buffer [T][60 + NL][B] with the latent stream (B, T, NL) -- e.g. the ViT encoder's output -- packed
+        straight into rows 60.. (os_pack_stream_rows); pass it as fused_run(..., gru_input=buf): the Kalman kernel fills rows
+        0..59 in place and no copy of the latent is made (gru/gru_test.py:135-136 concatenates per window on the host)."""
+        a = self._f32(latent_btn)
+        B, T, NL = a.shape
+        buf = torch.empty((T, 60 + NL, B), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_pack_stream_rows(self._h, B, T, NL, _ptr(a), _ptr(buf), 60 + NL, 60, self._stream()), "os_pack_stream_rows")
+        return buf
 
     def unpack(self, a_tfb):
         T, F, B = a_tfb.shape
@@ -288,7 +299,7 @@ class Engine:
 
     # ---- fused ----
     def fused_run(self, p, f, dp, imu, contact, accel, minmax, x, P, body_ref=None, latent=None, sequential=None,
-                  dense_fd=False, symmetric=None, two_kernel=None, split_bf16=False):
+                  dense_fd=False, symmetric=None, two_kernel=None, split_bf16=False, gru_input=None):
         """KF + feature pack + normalise + GRU.  Returns dict(out [B][C], x_out [T][12][B], status [B]).
         split_bf16: False (exact fp32 MFMA, the default) | True or 3 (three bf16 terms per operand) | 2 (two terms): opt-in.
         two_kernel: None = the library picks (single fused kernel from about a third of a chip of trajectories up: B > 80 per CU), True / False force
@@ -303,7 +314,13 @@ class Engine:
                 (OS_FUSED_ONE_KERNEL if two_kernel is False else 0) | \
                 (OS_FUSED_SPLIT_BF16_2 if split_bf16 == 2 else (OS_FUSED_SPLIT_BF16 if split_bf16 else 0))
         d = self._gru_dims
-        nl = 0 if latent is None else latent.shape[1]
+        if gru_input is not None:          # [T][60 + NL][B] with the latent rows in place (gru_input_with_latent): written by this call
+            if latent is not None or gru_input.shape[1] <= 60 or gru_input.shape[0] != T or gru_input.shape[2] != B:
+                raise ValueError("gru_input must be [T][60 + NL][B] and excludes latent=")
+            latent, flags = gru_input, flags | OS_FUSED_LATENT_IN_PLACE
+            nl = gru_input.shape[1] - 60
+        else:
+            nl = 0 if latent is None else latent.shape[1]
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
         x_out = torch.empty((T, 12, B), dtype=torch.float32, device=self.device)
         status = torch.empty((B,), dtype=torch.int32, device=self.device)

@@ -301,3 +301,35 @@ def test_alternating_models_reselect_their_packed_image_instead_of_repacking():
         for m in ms:                                                   # five models through four slots: still correct
             assert np.abs(m(x).cpu().numpy() - _ref_out(m, x)).max() < 1e-5
         assert eng.gru_generation() > g0 + 1
+
+
+def test_latent_in_place_equals_the_copying_path():
+    """fused_run(gru_input=...) -- the ViT latent packed straight into rows 60.. of the GRU input buffer, Kalman features written
+    in place -- against fused_run(latent=...) (feature scratch + a copy of the latent) and against the oracle."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
+    from oracle import c_oracle as orc
+    B, T, NL = 96, 12, 128
+    eng = Engine(0); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    d = synth_numpy(B, T, seed=21)
+    torch.manual_seed(5)
+    m = RNN(60 + NL, 128, 2, 24, torch.device("cpu"))
+    eng.load_gru(flatten_state_dict(m.state_dict(), 2), 60 + NL, 128, 2, 24)
+    lat = torch.rand(B, T, NL)
+    s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
+    c = eng.pack_contact(torch.as_tensor(d["contact"]))
+    mm = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).cuda()
+    st = lambda: (torch.as_tensor(d["x0"].T.copy()).cuda(), torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, B))).cuda())
+    x, P = st()
+    a = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P, latent=eng.pack(lat))
+    buf = eng.gru_input_with_latent(lat.cuda())
+    assert buf.shape == (T, 60 + NL, B) and torch.equal(buf[:, 60:], eng.pack(lat))
+    x, P = st()
+    b = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P, gru_input=buf)
+    assert torch.equal(a["out"], b["out"]) and torch.equal(a["x_out"], b["x_out"])
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_DEFAULT, (B, 1, 1)), Q_DEFAULT, R_DEFAULT)
+    rows = np.concatenate([(np.concatenate([ref["x"], d["accel"], d["f"], ref["p_rot"], d["dp"], d["imu"]], axis=2) + 30.0) / 60.0,
+                           lat.numpy().astype(np.float64)], axis=2)
+    ro, _, _ = orc.gru_forward(rows, orc.flatten_state_dict(m.state_dict(), 2), 60 + NL, 128, 2, 24)
+    assert np.abs(b["out"].cpu().numpy() - ro).max() < 1e-5
+    assert np.abs(buf[:, :60].permute(2, 0, 1).cpu().numpy() - rows[:, :, :60]).max() < 1e-5       # the features landed in rows 0..59
