@@ -2,7 +2,7 @@
 # One GPU call that (re)collects the round's evidence under gpurun_out/<tag>/: PMC traffic -> profiles/traffic.json, the
 # default bench line, rocprofv3 --kernel-trace --stats of the same command, SQ counters of the fused kernel, and the other
 # bench lines.  usage: tools/collect_profiles.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG
 export GRAFT_REPO_ROOT=$R          # the sub-scripts below resolve their paths from it
 mkdir -p $O
@@ -26,11 +26,14 @@ if f:
               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
 PY
 }
-stats default --cpu-seconds 0
+stats default --cpu-seconds 0 --parity-samples 0 --no-second-noise
 stats train --mode train --cpu-seconds 0
 stats full --mode full --cpu-seconds 0
+python3 bench.py --noise fitted > $O/bench_noise_fitted.json 2>> $O/bench.err
+python3 bench.py --hostile > $O/bench_hostile.json 2>> $O/bench.err
 python3 bench.py --mode kf > $O/bench_kf_B65536.json 2>> $O/bench.err
 python3 bench.py --mode kf --batch 4096 --seq 1000 --steps 5 > $O/bench_kf_B4096_T1000.json 2>> $O/bench.err
+python3 tools/dropin_latency.py 2000 > $O/dropin_latency.json 2>> $O/bench.err
 python3 bench.py --mode train > $O/bench_train.json 2>> $O/bench.err
 python3 bench.py --mode full > $O/bench_full.json 2>> $O/bench.err
 python3 bench.py --mode windows > $O/bench_windows.json 2>> $O/bench.err
