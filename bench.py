@@ -113,9 +113,10 @@ class Ranks:
             self.dev = torch.device("cuda", self.local_rank)
         else:
             self.dev = torch.device("cpu")
-        if self.world > 1:
+        if self.world > 1 or getattr(a, "force_dist", False):
             import torch.distributed as dist
             self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
             if self.cpu_only:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
@@ -442,7 +443,7 @@ def bench_train(a, rk):
     B, T, I, H, L, C = 8192, 10, 188, 128, 4, 24
     torch.manual_seed(0)
     model = RNN(I, H, L, C, dev).to(dev)
-    tr = DataParallelTrainer(model, lr=1e-4)
+    tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=("force" if a.force_dist else (not a.no_split_allreduce)))
     g = torch.Generator(device=dev); g.manual_seed(100 + rk.rank)
     x = torch.rand(B, T, I, device=dev, generator=g); y = torch.rand(B, C // 2, device=dev, generator=g)
     el, loss, _ = timed_region(rk, a.warmup, a.steps, lambda: tr.step(x, y))
@@ -482,7 +483,9 @@ def bench_train(a, rk):
                                           "frac": tot / (el / a.steps) / 1e12 / MFMA_F32_PEAK_TF}}
         out["kernels"] = kernels
         out["kernel_events"] = "HIP events in a second, untimed pass of the same step"
-        out.update(allreduce_us=ar_us, grad_bucket_bytes=int(tr.bucket.g.numel() * 4), final_loss=float(loss.item()), **info)
+        out.update(allreduce_us=ar_us, grad_bucket_bytes=int(tr.bucket.g.numel() * 4), final_loss=float(loss.item()),
+                   allreduce="two halves: layers L/2..L-1 + head on a side stream behind their dW kernel, the rest on the main stream"
+                   if tr.split is not None else "one bucket behind the backward", **info)
         out["cpu_baseline"] = cpu_baseline_train(a.cpu_seconds) if (a.cpu_seconds > 0 and rk.world == 1) else None
         print(json.dumps(out), flush=True)
 
@@ -752,6 +755,8 @@ def bench_hot_path(a, rk):
     cap = max(4.0 * a.cpu_seconds, 60.0)
     if a.parity_samples != 0:
         want = B if a.parity_samples < 0 else min(a.parity_samples, B)
+        if rk.world > 1 and a.parity_samples < 0:
+            want = min(B, 8192)            # N ranks share the host cores (torchrun pins OMP_NUM_THREADS): a sample of rank 0's shard
         out["parity"], timing = oracle_pass(d, r["x_out"], r.get("out"), model, H, L, Q, R, Q, want, cap, kf_only=not fused, latent=latent)
         if timing["trajectories"] >= 2048:
             all_cores = timing
@@ -809,6 +814,9 @@ def main(argv=None):
                     help="inputs that leave the fast branches: 0-4 stance legs per step, yaw unwrapping past +-pi, wide roll / pitch")
     ap.add_argument("--split-bf16", type=int, nargs="?", const=3, default=0, choices=[0, 2, 3],
                     help="opt-in gate GEMM on the bf16 MFMA with 3 (default) or 2 bf16 terms per fp32 operand (second line; never the headline)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--mode train on ONE GPU with a one-rank RCCL process group: exercises (and prices) the split all-reduce path")
+    ap.add_argument("--no-split-allreduce", action="store_true", help="--mode train: one all-reduce behind the whole backward")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")
     ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc", "windows"],
                     help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")

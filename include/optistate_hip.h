@@ -163,6 +163,12 @@ size_t os_gru_param_count(const os_gru_dims *d);
 /* Replaces model.load_state_dict(...) (gru/gru_test.py:160): w_flat is a DEVICE float vector in the flat
  * layout above; the library re-packs it into MFMA fragment order in context scratch. */
 int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *stream);
+/* Every following os_gru_backward / os_gru_backward_ws on this context records `event` (a hipEvent_t; NULL switches it off) on
+ * its stream right behind the weight-gradient kernel of GRU layer `layer`: from then on the gradients of layers layer..L-1 and
+ * of the head (the tail of the flat gradient vector from that layer's offset) are complete, while the layers below are still
+ * being swept.  The data-parallel step (gru/gru_train.py:232-251 over RCCL) starts the all-reduce of that half on a side
+ * stream there. */
+int os_gru_backward_mark(os_ctx *ctx, int32_t layer, void *event);
 /* The same with a caller-chosen key != 0 naming (these weights, in this state): the context keeps the packed images of the
  * four most recently used keys, so models that alternate on one context (the ensemble of gru/gru_train.py:205-217,
  * `num_models`) are re-selected without re-packing.  The caller must use a NEW key whenever the weights behind w_flat

@@ -30,7 +30,7 @@ EXPORTS = [
     "os_gru_forward_train", "os_gru_loss", "os_gru_backward", "os_adam_step",
     "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
-    "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows",
+    "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows", "os_gru_backward_mark",
 ]
 
 
@@ -89,6 +89,8 @@ def load():
     lib.os_gru_param_count.argtypes = [C.POINTER(OsGruDims)]
     lib.os_gru_param_count.restype = C.c_size_t
     lib.os_gru_load.argtypes = [vp, C.POINTER(OsGruDims), f32p, vp]
+    lib.os_gru_backward_mark.argtypes = [vp, i32, vp]
+    lib.os_gru_backward_mark.restype = C.c_int
     lib.os_gru_load_keyed.argtypes = [vp, C.POINTER(OsGruDims), f32p, C.c_uint64, vp]
     lib.os_gru_load_keyed.restype = C.c_int
     lib.os_gru_forward.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp]

@@ -1354,6 +1354,8 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             OS_HIP(ctx, hipGetLastError());
             if (overlap) OS_HIP(ctx, hipEventRecord(ts->ev_dw[l], sw));
         }
+        // os_gru_backward_mark: layers l .. L-1 (and the head, done first) have their gradients in the flat vector from here on
+        if (ctx->bwd_mark_event && l == ctx->bwd_mark_layer) OS_HIP(ctx, hipEventRecord((hipEvent_t)ctx->bwd_mark_event, sw));
         dy = a.dx;
     }
     if (overlap) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[0], 0));      // join: the side stream is in order
@@ -1374,6 +1376,15 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
     os_train_state *ts = (os_train_state *)ctx->train;
     if (!ts || !ts->act || ts->B != B || ts->T != T) return os_fail(ctx, -5, "os_gru_backward: call os_gru_forward_train first (same B, T)");
     return backward_impl(ctx, ctx->gru, ctx->gru_flat, ts->act, B, T, x, out, dout, grad_flat, dx_out, stream);
+}
+
+int os_gru_backward_mark(os_ctx *ctx, int32_t layer, void *event)
+{
+    OS_CHECK_CTX(ctx);
+    if (layer < 0) return os_fail(ctx, -2, "os_gru_backward_mark: bad layer");
+    ctx->bwd_mark_layer = layer;
+    ctx->bwd_mark_event = event;
+    return 0;
 }
 
 int os_gru_backward_ws(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, int32_t B, int32_t T, const float *x,

@@ -61,6 +61,7 @@ struct os_ctx {
     bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set, ahead_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
+    int bwd_mark_layer; void *bwd_mark_event;   // os_gru_backward_mark: event recorded behind this layer's weight-gradient kernel
     void *step;                          // os_step_state (kf_step.hip): pinned, device-mapped staging block of os_kf_step
     // per-kernel timing (os_profile_*): ring of event pairs
     bool prof;

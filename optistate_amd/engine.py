@@ -293,6 +293,11 @@ class Engine:
                                              self._stream()), "os_gru_backward")
         return (grad_flat, dx) if want_dx else grad_flat
 
+    def gru_backward_mark(self, layer, event):
+        """event: a recorded torch.cuda.Event (or None to switch off): see os_gru_backward_mark."""
+        self._check(self.lib.os_gru_backward_mark(self._h, int(layer), None if event is None else C.c_void_p(event.cuda_event)),
+                    "os_gru_backward_mark")
+
     def adam_step(self, w, g, m, v, lr, beta1, beta2, eps, step):
         self._check(self.lib.os_adam_step(self._h, w.numel(), _ptr(w), _ptr(g), _ptr(m), _ptr(v), lr, beta1, beta2, eps, step,
                                           self._stream()), "os_adam_step")

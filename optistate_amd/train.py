@@ -112,7 +112,7 @@ class FlatBucket:
 class DataParallelTrainer:
     """One optimisation step = forward, device-side target + MSE, backward, bucket all-reduce, fused Adam."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, split_allreduce=True):
         from .engine import default_engine
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -123,16 +123,52 @@ class DataParallelTrainer:
         self.m = torch.zeros_like(self.bucket.w)
         self.v = torch.zeros_like(self.bucket.w)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or split_allreduce == "force")
+        if self.distributed and dist.get_world_size(group) > 1:
             dist.broadcast(self.bucket.w, src=0, group=group)   # identical replicas
+        # Two halves of the one bucket: the backward runs top layer first, so the gradients of layers L/2 .. L-1 and of the
+        # head -- the TAIL of the flat vector, the count slot included -- are final while layers L/2-1 .. 0 are still being
+        # swept.  Their all-reduce starts on a side stream at that point (os_gru_backward_mark) and travels underneath the
+        # rest of the backward; the head of the vector follows on the main stream.  Latency-bound at 1.69 MB either way: what
+        # this buys is the first half's launch + ring latency.
+        self.split = None
+        L = model.num_layers
+        if self.distributed and split_allreduce and L > 1:
+            per_layer = [sum(getattr(model.gru, f"{k}_l{l}").numel() for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")) for l in range(L)]
+            self.split = dict(layer=L // 2, off=sum(per_layer[:L // 2]), side=torch.cuda.Stream(device=dev),
+                              ev_top=torch.cuda.Event(), ev_done=torch.cuda.Event())
+            self.split["ev_top"].record(); self.split["ev_done"].record()       # materialise the hipEvent handles
+
+    def _allreduce_split(self, n_local):
+        """allreduce_weighted_ in two collectives: the tail [off:] (top layers + head + count) on the side stream as soon as
+        its gradients exist, the head [:off] on the main stream behind the whole backward."""
+        sp, b = self.split, self.bucket
+        main = torch.cuda.current_stream(b.g.device)
+        top, low = b._gbuf[sp["off"]:], b._gbuf[:sp["off"]]
+        sp["side"].wait_event(sp["ev_top"])                      # recorded by the library behind layer L/2's dW kernel
+        with torch.cuda.stream(sp["side"]):
+            top[:-1].mul_(n_local); top[-1:].fill_(n_local)
+            dist.all_reduce(top, op=dist.ReduceOp.SUM, group=self.group)
+            sp["ev_done"].record(sp["side"])
+        low.mul_(n_local)
+        dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group)
+        main.wait_event(sp["ev_done"])
+        b.g.div_(b._gbuf[b.n])
 
     def step(self, x, y):
         m, e = self.model, self.eng
         e.load_gru(self.bucket.w, m.input_size, m.hidden_size, m.num_layers, m.num_classes, m.use_sigmoid, owner=self)
         out = e.gru_forward_train(x)
         loss, dout, _ = e.gru_loss(out, y)
+        if self.split is not None:
+            e.gru_backward_mark(self.split["layer"], self.split["ev_top"])      # per call: the context is shared with other users
         e.gru_backward(x, out, dout, grad_flat=self.bucket.g)
-        self.bucket.allreduce_weighted_(x.shape[0], self.group)      # equal shards: the plain mean; ragged shards: weighted by size
+        if self.split is not None:
+            e.gru_backward_mark(0, None)
+        if self.split is None:
+            self.bucket.allreduce_weighted_(x.shape[0], self.group)  # equal shards: the plain mean; ragged shards: weighted by size
+        else:
+            self._allreduce_split(float(x.shape[0]))
         self.t += 1
         e.adam_step(self.bucket.w, self.bucket.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
         # the fused Adam wrote the flat bucket in place: the packed copy in the engine is stale now, and torch's version

@@ -134,3 +134,33 @@ def test_loss_is_order_independent_and_backward_clears_its_gradient_vector():
     eng.gru_backward(x, out2, dout, grad_flat=g_dirty)
     scale = g_clean.abs().max().item()
     assert scale > 0 and (g_clean - g_dirty).abs().max().item() < 1e-4 * scale      # float atomics: summation order only
+
+
+def test_split_allreduce_on_a_side_stream_gives_the_same_step():
+    """DataParallelTrainer with the gradient bucket reduced in two halves (top layers + head on a side stream behind their dW
+    kernel: os_gru_backward_mark; the rest behind the backward) against the plain single-process step: same loss, same weights
+    after three steps.  One-rank RCCL group: the collectives really run, on the streams the N-rank job uses."""
+    import socket
+    import torch.distributed as dist
+    from optistate_amd import RNN
+    from optistate_amd.train import DataParallelTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dims, B, T = (188, 128, 4, 24), 512, 10
+    x, y = torch.rand(B, T, dims[0]).cuda(), torch.rand(B, 12).cuda()
+
+    def run(split):
+        torch.manual_seed(7)
+        m = RNN(*dims, torch.device("cuda")).to("cuda")
+        tr = DataParallelTrainer(m, lr=1e-3, split_allreduce=split)
+        losses = [float(tr.step(x, y).item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        return losses, tr.bucket.w.clone(), tr
+    l0, w0, _ = run(False)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l1, w1, tr = run("force")
+        assert tr.split is not None and tr.split["layer"] == 2 and tr.split["off"] == 3 * 128 * (188 + 128 + 2) + 3 * 128 * (128 + 128 + 2)
+    finally:
+        dist.destroy_process_group()
+    assert l0 == l1
+    assert torch.equal(w0, w1)
