@@ -775,7 +775,9 @@ __device__ __forceinline__ void measurement_p(const StepInP &in, const f2 *Rp, f
         pz += st ? in.p[l >> 1][2][l & 1] : 0.f;
         vz += sw ? in.dp[l >> 1][2][l & 1] : 0.f;
     }
-    const float inv = (sum_c != 0.f) ? (1.0f / sum_c) : 0.f;   // no stance leg -> odom = 0 (:97-98)
+    // no stance leg -> odom = 0 (:97-98).  sum_c is 1, 2, 3 or 4 here: v_rcp_f32 (1 ulp) instead of the ~10 instructions of an
+    // IEEE division
+    const float inv = (sum_c != 0.f) ? __builtin_amdgcn_rcpf(sum_c) : 0.f;
     const float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
     z[0] = in.imu[0]; z[1] = in.imu[1]; z[2] = in.imu[2];
     z[3] = -pz * inv;

@@ -102,6 +102,23 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
     a.status[b] = status;
 }
 
+// Development builds only (-DOS_ROWS_TS: tools/rows_ts.sh, kf_run_rows2_kernel; -DOS_SYM_TS: kf_run_sym_kernel): shader-clock stamps at the
+// phase boundaries of a step, summed over the steps by lane 0 of workgroup 0 (written to kgain_out as 8 x uint64 / printed).
+#if defined(OS_ROWS_TS) || defined(OS_SYM_TS)
+#define OS_TS_DECL unsigned long long ts_prev = 0, ts_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define OS_TS(i)                                                                   \
+    {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        const unsigned long long now = __builtin_readcyclecounter();               \
+        if ((i) > 0) ts_sum[i] += now - ts_prev;                                   \
+        ts_prev = now;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    }
+#else
+#define OS_TS_DECL
+#define OS_TS(i)
+#endif
+
 // Fast path: symmetric P storage (78 VGPRs), sequential update, predict(p,f) covariance.  OUT: 0 plain, 1 P_trace, 2 features.
 // status bit 3: the caller's P0 is not symmetric (checked once per launch against the lower triangle, 66 extra loads per
 // trajectory): the symmetric-storage kernels would silently run a different filter than the reference, which never
@@ -139,7 +156,14 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         __builtin_amdgcn_wave_barrier();
         lds_issue_step(stage[0], lane, raw);
     }
+#ifdef OS_SYM_TS
+    OS_TS_DECL
+#define OS_STS(i) OS_TS(i)
+#else
+#define OS_STS(i)
+#endif
     for (int t = 0; t < a.T; t++) {
+        OS_STS(0)
         if (PRE) {
             lds_fence_step(raw, in);
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
@@ -153,9 +177,14 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             read_step_lds_p(stage[t & 1], lane, in);
             load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, stage[(t + 1) & 1]);
         }
+        OS_STS(1)                                       // input pick-up + next request
         float z[NM];
         f2 PW[2][3];
-        kf_step_front_sym<QDIAG>(X, U, in, kc, z, PW);
+        float g9[9];
+        kf_step_inputs_sym(X, in, kc, z, PW, g9);
+        OS_STS(2)                                       // rotations, odometry, next_state
+        cov_predict_sym_blk<QDIAG>(U, g9, kc);
+        OS_STS(3)                                       // covariance predict
         auto pw = [&](int i) { return PW[(i / 3) >> 1][i % 3][(i / 3) & 1]; };          // world-frame foot position 3 leg + component
         auto lg = [](const f2 (*v)[3], int i) { return v[(i / 3) >> 1][i % 3][(i / 3) & 1]; };
         rsrc_t rfeat;
@@ -185,12 +214,15 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             __builtin_amdgcn_wave_barrier();
             lds_issue_step(stage[(t + 1) % 3], lane, raw);
         }
+        OS_STS(4)                                       // optional outputs, LDS reads of the next step issued
         bad |= update_sequential_sym(X, U, z, kc);            // non-finite states stay non-finite: checked once after the loop
+        OS_STS(5)                                       // ten measurement updates
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
             for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, X[i / 2][i & 1]);
         }
+        OS_STS(6)                                       // x_out stores
         if (OUT == 2) {
 #pragma unroll
             for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, X[i / 2][i & 1]);
@@ -206,6 +238,12 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
 #pragma unroll
             for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
     }
+#ifdef OS_SYM_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("kf_run_sym cycles per step: pick-up %llu | front %llu | predict %llu | outputs+issue %llu | update %llu | stores %llu\n",
+               ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T, ts_sum[6] / a.T);
+#endif
+#undef OS_STS
     a.status[b] = status | (bad ? 1 : 0) | finite_status_p(X);
 }
 
@@ -417,23 +455,6 @@ __device__ __forceinline__ void fmac_shl(float &acc, float src, float m)       /
 {
     asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
-
-// Development build only (-DOS_ROWS_TS, tools/rows_ts.sh): shader-clock stamps at the phase boundaries of a step, summed over the
-// steps by lane 0 of workgroup 0 and written to kgain_out (unused by this kernel) as 8 x uint64.
-#ifdef OS_ROWS_TS
-#define OS_TS_DECL unsigned long long ts_prev = 0, ts_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define OS_TS(i)                                                                   \
-    {                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-        const unsigned long long now = __builtin_readcyclecounter();               \
-        if ((i) > 0) ts_sum[i] += now - ts_prev;                                   \
-        ts_prev = now;                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-    }
-#else
-#define OS_TS_DECL
-#define OS_TS(i)
-#endif
 
 template <bool AUX, bool FEAT>
 __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
