@@ -50,24 +50,44 @@ __device__ __forceinline__ void lds_dma4(rsrc_t r, float *l, uint32_t voff, uint
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 4, voff, soff, 0, 2);
 }
-constexpr int STEP_DWORDS = 43;
-__device__ __forceinline__ void load_step_dma(const KfRunArgs &a, int t, uint32_t voff, uint32_t rowB, float *lds /* [43][64] */)
+// Round 3: SIXTEEN-byte LDS-DMA (buffer_load_dwordx4 ... lds, gfx950).  A lane fetches four consecutive trajectories' values of
+// one row, 16 lanes cover a row of the wave's 64 trajectories and an instruction covers four rows: 12 instructions per step
+// instead of 43 (in-kernel timestamps: a VMEM instruction costs ~16 issue cycles at one wave per SIMD, and the 43 + 12 of a step
+// were ~0.9 k of its 6.3 k cycles).  The LDS layout stays [row][64]: rows 0-11 p, 12-23 f, 24-35 dp, 36-41 imu (42, 43: the
+// zeros the second imu instruction reads past its six rows), 44 contact (45-47 likewise).  EVERY lane of the wave must take
+// part (a lane fetches other lanes' values): the callers keep lanes past the end of the batch alive and mask their stores.
+// vo4: per-lane byte offset = (lane >> 4) rows + the first of the lane's four trajectories (step_dma_offset).
+constexpr int STEP_DWORDS = 48;
+constexpr int STEP_CONTACT_ROW = 44;
+__device__ __forceinline__ uint32_t step_dma_offset(int lane, int wave_first_traj, uint32_t rowB)
 {
+    return (uint32_t)(lane >> 4) * rowB + (uint32_t)(wave_first_traj + 4 * (lane & 15)) * 4u;
+}
+__device__ __forceinline__ void lds_dma16(rsrc_t r, float *l, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, 2);
+}
+__device__ __forceinline__ void load_step_dma(const KfRunArgs &a, int t, uint32_t vo4, uint32_t rowB, float *lds /* [48][64] */)
+{
+    // The range check of a raw buffer access covers the VGPR offset only (not the SGPR offset), so every access here carries
+    // its whole offset in the VGPR and each descriptor spans exactly the rows it may touch: a lane whose trajectories lie past
+    // the end of the batch reads the next row (harmless) or, in the last row, nothing (zeros) -- never past the allocation.
     const size_t B = (size_t)a.B;
+    const uint32_t vo[3] = {vo4, vo4 + 4u * rowB, vo4 + 8u * rowB};
     rsrc_t rp = make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB);
     rsrc_t rf = make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB);
     rsrc_t rd = make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB);
     rsrc_t ri = make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB);
     rsrc_t rc = make_rsrc(a.contact + (size_t)t * B, rowB);
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        lds_dma4(rp, lds + i * 64, voff, i * rowB);
-        lds_dma4(rf, lds + (12 + i) * 64, voff, i * rowB);
-        lds_dma4(rd, lds + (24 + i) * 64, voff, i * rowB);
+    for (int i = 0; i < 3; i++) {
+        lds_dma16(rp, lds + 4 * i * 64, vo[i], 0);
+        lds_dma16(rf, lds + (12 + 4 * i) * 64, vo[i], 0);
+        lds_dma16(rd, lds + (24 + 4 * i) * 64, vo[i], 0);
     }
-#pragma unroll
-    for (int i = 0; i < 6; i++) lds_dma4(ri, lds + (36 + i) * 64, voff, i * rowB);
-    lds_dma4(rc, lds + 42 * 64, voff, 0);
+    lds_dma16(ri, lds + 36 * 64, vo[0], 0);
+    lds_dma16(ri, lds + 40 * 64, vo[1], 0);                 // rows 4, 5; the lanes of rows 6, 7 are out of range: zeros
+    lds_dma16(rc, lds + STEP_CONTACT_ROW * 64, vo[0], 0);   // row 0; rows 1-3 out of range
 }
 __device__ __forceinline__ void read_step_lds(const float *lds, int lane, StepIn &in)
 {
@@ -97,7 +117,7 @@ __device__ __forceinline__ void read_step_lds_p(const float *lds, int lane, Step
         }
 #pragma unroll
     for (int i = 0; i < 6; i++) in.imu[i] = lds[(36 + i) * 64 + lane];
-    in.contact = __builtin_bit_cast(uint32_t, lds[42 * 64 + lane]);
+    in.contact = __builtin_bit_cast(uint32_t, lds[STEP_CONTACT_ROW * 64 + lane]);
 }
 
 // Asynchronous form for a software-pipelined loop: lds_issue_step starts the 22 LDS reads of a staged step into a StepRaw
@@ -115,7 +135,7 @@ __device__ __forceinline__ void lds_issue_step(const float *stage, int lane, Ste
     OSK_RD2(12, 24, 27); OSK_RD2(13, 25, 28); OSK_RD2(14, 26, 29); OSK_RD2(15, 30, 33); OSK_RD2(16, 31, 34); OSK_RD2(17, 32, 35);   // dp
     OSK_RD2(18, 36, 37); OSK_RD2(19, 38, 39); OSK_RD2(20, 40, 41);                                                                    // imu
 #undef OSK_RD2
-    asm volatile("ds_read_b32 %0, %1 offset:10752" : "=v"(r.c) : "v"(addr));       // row 42: the contact word
+    asm volatile("ds_read_b32 %0, %1 offset:11264" : "=v"(r.c) : "v"(addr));       // row 44 (STEP_CONTACT_ROW): the contact word
 }
 __device__ __forceinline__ void lds_fence_step(StepRaw &r, StepInP &in)
 {

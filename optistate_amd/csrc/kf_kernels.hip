@@ -124,10 +124,18 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
 // trajectory): the symmetric-storage kernels would silently run a different filter than the reference, which never
 // symmetrises P (kalman_filter/kalman_filter.py:172)
 template <int OUT, bool QDIAG, bool PRE = false>
-__device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfConst &kc, const int b)
+__device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfConst &kc, const int b_raw)
 {
+    // lanes past the end of the batch stay alive (the 16-byte input DMA needs every lane of the wave) as shadows of the last
+    // trajectory with their stores masked
+    const bool live = b_raw < a.B;
+    const int b = live ? b_raw : a.B - 1;
     const size_t B = (size_t)a.B;
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    const uint32_t vo4 = step_dma_offset(threadIdx.x & 63, b_raw - (int)(threadIdx.x & 63), rowB);
+    // stores of the shadow lanes: an offset no descriptor covers (dropped by the range check) instead of a branch around every
+    // group of stores -- branches cut the straight-line step into blocks and cost ~300 instructions of register shuffling
+    const uint32_t vst = live ? voff : 0x7ffffff0u;
     f2 X[6];                       // the state as pairs (x[2i], x[2i+1])
     f2 U[NU];
     int status = 0;
@@ -149,10 +157,10 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
     StepInP in;
     StepRaw raw;
     bool bad = false;
-    load_step_dma(a, 0, voff, rowB, stage[0]);
+    load_step_dma(a, 0, vo4, rowB, stage[0]);
     if (PRE) {
-        load_step_dma(a, a.T > 1 ? 1 : 0, voff, rowB, stage[1]);
-        __builtin_amdgcn_s_waitcnt(0x8f7b);                            // vmcnt(43): step 0 has landed, step 1 may be in flight
+        load_step_dma(a, a.T > 1 ? 1 : 0, vo4, rowB, stage[1]);
+        __builtin_amdgcn_s_waitcnt(0x0f7c);                            // vmcnt(12): step 0 has landed, step 1's twelve loads may be in flight
         __builtin_amdgcn_wave_barrier();
         lds_issue_step(stage[0], lane, raw);
     }
@@ -167,7 +175,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         if (PRE) {
             lds_fence_step(raw, in);
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
-            load_step_dma(a, tn, voff, rowB, stage[(t + 2) % 3]);
+            load_step_dma(a, tn, vo4, rowB, stage[(t + 2) % 3]);
         } else {
             // vmcnt(12): step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in issue
             // order with the loads, and the twelve x_out stores of step t - 1 were issued a few instructions ago -- everything
@@ -175,7 +183,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             __builtin_amdgcn_s_waitcnt(0x0f7c);
             __builtin_amdgcn_wave_barrier();
             read_step_lds_p(stage[t & 1], lane, in);
-            load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, voff, rowB, stage[(t + 1) & 1]);
+            load_step_dma(a, (t + 1 < a.T) ? t + 1 : t, vo4, rowB, stage[(t + 1) & 1]);
         }
         OS_STS(1)                                       // input pick-up + next request
         float z[NM];
@@ -192,25 +200,25 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
             rsrc_t ra = make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB);
 #pragma unroll
-            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load_nt(ra, voff, i * rowB));
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, vst, rowB, 12 + i, buf_load_nt(ra, voff, i * rowB));
 #pragma unroll
             for (int i = 0; i < 12; i++) {
-                store_feat(rfeat, a.minmax, voff, rowB, 18 + i, lg(in.f, i));
-                store_feat(rfeat, a.minmax, voff, rowB, 30 + i, pw(i));
-                store_feat(rfeat, a.minmax, voff, rowB, 42 + i, lg(in.dp, i));
+                store_feat(rfeat, a.minmax, vst, rowB, 18 + i, lg(in.f, i));
+                store_feat(rfeat, a.minmax, vst, rowB, 30 + i, pw(i));
+                store_feat(rfeat, a.minmax, vst, rowB, 42 + i, lg(in.dp, i));
             }
 #pragma unroll
-            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 54 + i, in.imu[i]);
+            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, vst, rowB, 54 + i, in.imu[i]);
         }
         if (a.p_rot_out) {
             rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw(i));
+            for (int i = 0; i < 12; i++) buf_store_nt(ro, vst, i * rowB, pw(i));
         }
         if (PRE) {
-            // step t + 1 (requested at the top of step t - 1): issued before it are only step t + 2's 43 loads and nothing
-            // younger matters, so vmcnt(43) -- which also covers step t - 1's twelve stores, issued long ago
-            __builtin_amdgcn_s_waitcnt(0x8f7b);
+            // step t + 1 (requested at the top of step t - 1): younger than it are step t - 1's twelve stores and step t + 2's
+            // twelve loads; vmcnt(12) waits for the stores too (issued most of a step ago)
+            __builtin_amdgcn_s_waitcnt(0x0f7c);
             __builtin_amdgcn_wave_barrier();
             lds_issue_step(stage[(t + 1) % 3], lane, raw);
         }
@@ -220,23 +228,23 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, X[i / 2][i & 1]);
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, vst, i * rowB, X[i / 2][i & 1]);
         }
         OS_STS(6)                                       // x_out stores
         if (OUT == 2) {
 #pragma unroll
-            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, X[i / 2][i & 1]);
+            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, vst, rowB, i, X[i / 2][i & 1]);
         }
-        if (OUT == 1 && a.ptrace_out) a.ptrace_out[(size_t)t * B + b] = trace_sym(U);
+        if (OUT == 1 && a.ptrace_out && live) a.ptrace_out[(size_t)t * B + b] = trace_sym(U);
     }
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
 #pragma unroll
-        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, X[i / 2][i & 1]);
+        for (int i = 0; i < NS; i++) buf_store(rx, vst, i * rowB, X[i / 2][i & 1]);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+            for (int j = 0; j < NS; j++) buf_store(rP, vst, (i * NS + j) * rowB, OSK_SYM(U, i, j));
     }
 #ifdef OS_SYM_TS
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -244,15 +252,13 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
                ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T, ts_sum[6] / a.T);
 #endif
 #undef OS_STS
-    a.status[b] = status | (bad ? 1 : 0) | finite_status_p(X);
+    if (live) a.status[b] = status | (bad ? 1 : 0) | finite_status_p(X);
 }
 
 template <int OUT, bool QDIAG, bool PRE = false>
 __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.B) return;
-    kf_run_sym_body<OUT, QDIAG, PRE>(a, a.k, b);
+    kf_run_sym_body<OUT, QDIAG, PRE>(a, a.k, blockIdx.x * 64 + threadIdx.x);
 }
 
 // Per-trajectory diagonal noise (os_kf_run_noise): each lane overwrites the diagonals of its own copy of the constants
@@ -260,8 +266,8 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_kernel(const KfRunArgs a)
 template <int OUT>
 __global__ __launch_bounds__(64, 1) void kf_run_sym_noise_kernel(const KfRunArgs a)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.B) return;
+    const int b_raw = blockIdx.x * 64 + threadIdx.x;
+    const int b = b_raw < a.B ? b_raw : a.B - 1;          // lanes past the end shadow the last trajectory (stores masked in the body)
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
     KfConst kc = a.k;
     rsrc_t rq = make_rsrc(a.q_diag, 12 * rowB), rr = make_rsrc(a.r_diag, 10 * rowB);
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_noise_kernel(const KfRunArgs
     for (int i = 0; i < NS; i++) kc.Q[i * NS + i] = buf_load(rq, voff, i * rowB);
 #pragma unroll
     for (int i = 0; i < NM; i++) kc.R[i * NM + i] = buf_load(rr, voff, i * rowB);
-    kf_run_sym_body<OUT, true>(a, kc, b);
+    kf_run_sym_body<OUT, true>(a, kc, b_raw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
