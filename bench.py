@@ -197,6 +197,27 @@ def events_pass(eng, steps, one_step):
     return _kernel_table(eng, prof, steps)
 
 
+_JSON_FD = None
+
+
+def protect_stdout():
+    """RCCL writes a version banner to the process's STDOUT (file descriptor 1) when a communicator is created: with ranks
+    involved, everything that goes to fd 1 is sent to stderr and the ONE JSON line is written to the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    if _JSON_FD is None:
+        print(line, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_JSON_FD, (line + "\n").encode())
+
+
 def base_line(a, rk, metric, unit, value, el, dtype, config):
     out = {"metric": metric, "value": value, "unit": unit, "n_gpus": rk.world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -443,7 +464,7 @@ def bench_train(a, rk):
     B, T, I, H, L, C = 8192, 10, 188, 128, 4, 24
     torch.manual_seed(0)
     model = RNN(I, H, L, C, dev).to(dev)
-    tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=("force" if a.force_dist else (not a.no_split_allreduce)))
+    tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=not a.no_split_allreduce, force_distributed=a.force_dist)
     g = torch.Generator(device=dev); g.manual_seed(100 + rk.rank)
     x = torch.rand(B, T, I, device=dev, generator=g); y = torch.rand(B, C // 2, device=dev, generator=g)
     el, loss, _ = timed_region(rk, a.warmup, a.steps, lambda: tr.step(x, y))
@@ -487,7 +508,7 @@ def bench_train(a, rk):
                    allreduce="two halves: layers L/2..L-1 + head on a side stream behind their dW kernel, the rest on the main stream"
                    if tr.split is not None else "one bucket behind the backward", **info)
         out["cpu_baseline"] = cpu_baseline_train(a.cpu_seconds) if (a.cpu_seconds > 0 and rk.world == 1) else None
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
 
 def bench_full(a, rk):
@@ -542,7 +563,7 @@ def bench_full(a, rk):
         out["kernel_events"] = "HIP events in a second, untimed pass of the same step"
         out.update(info)
         out["cpu_baseline"] = cpu_baseline_full(a.cpu_seconds) if (a.cpu_seconds > 0 and rk.world == 1) else None
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
 
 def bench_mpc(a, rk):
@@ -584,7 +605,7 @@ def bench_mpc(a, rk):
         out.update(qp_iterations_mean=float(it.mean()), qp_iterations_max=int(it.max()),
                    status_nonzero_trajectories=int((last["status"] != 0).sum()), kernels=kernels, **info)
         out["cpu_baseline"] = cpu_baseline_mpc(min(a.cpu_seconds, 20.0)) if (a.cpu_seconds > 0 and rk.world == 1) else None
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
 
 def bench_windows(a, rk):
@@ -629,7 +650,7 @@ def bench_windows(a, rk):
                                              "the reference script itself runs batch 1: 2.09 ms/window = 478 windows/s (SURVEY section 6)"}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
 
 def bench_hot_path(a, rk):
@@ -778,7 +799,7 @@ def bench_hot_path(a, rk):
             out["cpu_baseline"]["note"] = "sampled on the 60-wide input (no latent stream)"
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
 
 
 def launch_check(a, rk):
@@ -789,7 +810,7 @@ def launch_check(a, rk):
         rk.dist.all_reduce(v)
     info = rk.report()
     if rk.rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "sum_of_ones": float(v.item()), **info}), flush=True)
+        emit(json.dumps({"launch_check": True, "n_gpus": a.gpus, "sum_of_ones": float(v.item()), **info}))
 
 
 def main(argv=None):
@@ -828,6 +849,8 @@ def main(argv=None):
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a.gpus, argv))
 
+    if "WORLD_SIZE" in os.environ or a.force_dist:
+        protect_stdout()
     rk = Ranks(a)
     try:
         if a.launch_check:

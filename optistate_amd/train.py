@@ -94,14 +94,14 @@ class FlatBucket:
                 self.g.div_(world)
         return self.g
 
-    def allreduce_weighted_(self, n_local, group=None):
+    def allreduce_weighted_(self, n_local, group=None, force=False):
         """g holds the gradient of this rank's LOCAL mean loss over n_local samples (what the loss kernel produces).  The
         gradient of the GLOBAL mean is sum_r n_r g_r / sum_r n_r: equal to the plain mean over ranks only when the shards are
         equal, so ragged last shards (a dataset that does not divide by the world size, gru_train.py:216 random_split) are
         weighted by their size.  ONE collective: the count travels in the bucket's extra slot."""
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
-            if world > 1:
+            if world > 1 or force:
                 self.g.mul_(float(n_local))
                 self._gbuf[self.n] = float(n_local)
                 dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
@@ -112,7 +112,7 @@ class FlatBucket:
 class DataParallelTrainer:
     """One optimisation step = forward, device-side target + MSE, backward, bucket all-reduce, fused Adam."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, split_allreduce=True):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, split_allreduce=True, force_distributed=False):
         from .engine import default_engine
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -123,7 +123,9 @@ class DataParallelTrainer:
         self.m = torch.zeros_like(self.bucket.w)
         self.v = torch.zeros_like(self.bucket.w)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
-        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or split_allreduce == "force")
+        # force_distributed: run the collectives on a one-rank group too (tests and bench.py --force-dist price the machinery)
+        self.force = bool(force_distributed) or split_allreduce == "force"
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force)
         if self.distributed and dist.get_world_size(group) > 1:
             dist.broadcast(self.bucket.w, src=0, group=group)   # identical replicas
         # Two halves of the one bucket: the backward runs top layer first, so the gradients of layers L/2 .. L-1 and of the
@@ -166,7 +168,7 @@ class DataParallelTrainer:
         if self.split is not None:
             e.gru_backward_mark(0, None)
         if self.split is None:
-            self.bucket.allreduce_weighted_(x.shape[0], self.group)  # equal shards: the plain mean; ragged shards: weighted by size
+            self.bucket.allreduce_weighted_(x.shape[0], self.group, force=self.force)  # equal shards: the plain mean; ragged: weighted by size
         else:
             self._allreduce_split(float(x.shape[0]))
         self.t += 1
