@@ -453,11 +453,8 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         __builtin_amdgcn_sched_barrier(0);
         OSF_TS(3)                                        // covariance predict
         bad |= update_sequential_sym(X, U, z, k.k);      // non-finite states stay non-finite: checked once after the loop
-        if (live) {
-            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
-#pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, OSF_X(i));
-        }
+        // (the twelve x_out stores of this step are issued inside the first MFMA pass below: a VMEM instruction costs ~16 issue
+        // cycles here, free underneath the matrix pipe; X does not change until the next step's filter phase)
         feat6(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
         OSF_TS(4)                                        // ten measurement updates, x_out stores, 12 state features
 
@@ -490,6 +487,13 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
                 for (int q = 0; q < KPX + KPH; q++) {
                     const int cur = q & 1, nxt = cur ^ 1;
+                    if (rb == 0 && c == 0 && q == 8) {
+                        // shadow lanes: an offset no descriptor covers (the range check drops the store) instead of a branch
+                        const uint32_t vst = live ? voff : 0x7ffffff0u;
+                        rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+                        for (int i = 0; i < NS; i++) buf_store_nt(ro, vst, i * rowB, OSF_X(i));
+                    }
                     if (rb == 1 && c == 1 && q == KPX) {
                         // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
                         const int tn = (t + 1 < k.T) ? t + 1 : t;
@@ -795,10 +799,12 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         cov_predict_sym_blk<QDIAG>(U, g9, k.k);
         __builtin_amdgcn_sched_barrier(0);
         bad |= update_sequential_sym(X, U, z, k.k);
-        if (live) {
+        {
+            // shadow lanes: an offset no descriptor covers (the range check drops the store) instead of a branch around the stores
+            const uint32_t vst = live ? voff : 0x7ffffff0u;
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, OSF_X(i));
+            for (int i = 0; i < NS; i++) buf_store_nt(ro, vst, i * rowB, OSF_X(i));
         }
         feat8(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11), acl[0], acl[1], acl[2], acl[3]);
 
