@@ -530,13 +530,15 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
 #pragma unroll
         for (int j = 0; j < NS; j++) M[j] = Prow[j];
         asm volatile("s_nop 1");
+        // four multiply-adds per column, issued column-interleaved: consecutive instructions never touch the same accumulator
 #pragma unroll
-        for (int j = 0; j < NS; j++) {
-            fmac_bcast<6>(M[j], Prow[j], cg0);
-            fmac_bcast<7>(M[j], Prow[j], cg1);
-            fmac_bcast<8>(M[j], Prow[j], cg2);
-            fmac_shl<6>(M[j], Prow[j], cd);                            // row r + 6 (rows 9..11 for lanes 3..5)
-        }
+        for (int j = 0; j < NS; j++) fmac_bcast<6>(M[j], Prow[j], cg0);
+#pragma unroll
+        for (int j = 0; j < NS; j++) fmac_bcast<7>(M[j], Prow[j], cg1);
+#pragma unroll
+        for (int j = 0; j < NS; j++) fmac_bcast<8>(M[j], Prow[j], cg2);
+#pragma unroll
+        for (int j = 0; j < NS; j++) fmac_shl<6>(M[j], Prow[j], cd);       // row r + 6 (rows 9..11 for lanes 3..5)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8] + qrow[j];
@@ -580,19 +582,23 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         OS_TS(4)                                        // component selects, optional outputs
         // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
         asm volatile("s_nop 4");
-#define OS_ROW_UPDATE2(A, S)                                                                          \
+        // The column the NEXT measurement reads (SN) is updated first, so that its scalar chain (row broadcast -> add -> class
+        // test -> v_rcp_f32 -> gain) starts while this measurement's other eleven multiply-adds are still issuing.
+#define OS_ROW_FMAC(S, J, SN) if (J != SN) fmac_bcast<S>(Prow[J], Prow[J], nkc);
+#define OS_ROW_UPDATE2(A, S, SN)                                                                      \
         {                                                                                             \
             const float sv = row_bcast<S>(Prow[S]) + k.R[A * NM + A];                                 \
             bad |= !__builtin_amdgcn_classf(sv, 0x180);                                               \
             const float nkc = -Prow[S] * __builtin_amdgcn_rcpf(sv);                                   \
+            fmac_bcast<S>(Prow[SN], Prow[SN], nkc);                                                   \
             xr = fmaf(nkc, row_bcast<S>(xr) - z[A], xr);                                              \
-            fmac_bcast<S>(Prow[0], Prow[0], nkc); fmac_bcast<S>(Prow[1], Prow[1], nkc); fmac_bcast<S>(Prow[2], Prow[2], nkc);   \
-            fmac_bcast<S>(Prow[3], Prow[3], nkc); fmac_bcast<S>(Prow[4], Prow[4], nkc); fmac_bcast<S>(Prow[5], Prow[5], nkc);   \
-            fmac_bcast<S>(Prow[6], Prow[6], nkc); fmac_bcast<S>(Prow[7], Prow[7], nkc); fmac_bcast<S>(Prow[8], Prow[8], nkc);   \
-            fmac_bcast<S>(Prow[9], Prow[9], nkc); fmac_bcast<S>(Prow[10], Prow[10], nkc); fmac_bcast<S>(Prow[11], Prow[11], nkc); \
+            OS_ROW_FMAC(S, 0, SN) OS_ROW_FMAC(S, 1, SN) OS_ROW_FMAC(S, 2, SN) OS_ROW_FMAC(S, 3, SN)   \
+            OS_ROW_FMAC(S, 4, SN) OS_ROW_FMAC(S, 5, SN) OS_ROW_FMAC(S, 6, SN) OS_ROW_FMAC(S, 7, SN)   \
+            OS_ROW_FMAC(S, 8, SN) OS_ROW_FMAC(S, 9, SN) OS_ROW_FMAC(S, 10, SN) OS_ROW_FMAC(S, 11, SN) \
         }
-        OS_ROW_UPDATE2(0, 0) OS_ROW_UPDATE2(1, 1) OS_ROW_UPDATE2(2, 2) OS_ROW_UPDATE2(3, 5) OS_ROW_UPDATE2(4, 6)
-        OS_ROW_UPDATE2(5, 7) OS_ROW_UPDATE2(6, 8) OS_ROW_UPDATE2(7, 9) OS_ROW_UPDATE2(8, 10) OS_ROW_UPDATE2(9, 11)
+        OS_ROW_UPDATE2(0, 0, 1) OS_ROW_UPDATE2(1, 1, 2) OS_ROW_UPDATE2(2, 2, 5) OS_ROW_UPDATE2(3, 5, 6) OS_ROW_UPDATE2(4, 6, 7)
+        OS_ROW_UPDATE2(5, 7, 8) OS_ROW_UPDATE2(6, 8, 9) OS_ROW_UPDATE2(7, 9, 10) OS_ROW_UPDATE2(8, 10, 11) OS_ROW_UPDATE2(9, 11, 0)
+#undef OS_ROW_FMAC
 #undef OS_ROW_UPDATE2
         OS_TS(5)                                        // ten measurement updates
         if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
