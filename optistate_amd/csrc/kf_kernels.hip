@@ -548,10 +548,18 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
         OS_TS(3)                                        // covariance predict
         // ---- this lane's component of the predicted state and of the step's by-products ----
-        // element rr of a twelve-vector held as compile-time-indexed registers: a select chain (a lambda with a loop inside
-        // would index the array at run time, and hipcc then moves it to LDS)
-#define OS_PICK12(E) ((rr == 11) ? E(11) : (rr == 10) ? E(10) : (rr == 9) ? E(9) : (rr == 8) ? E(8) : (rr == 7) ? E(7) : (rr == 6) ? E(6) : \
-                      (rr == 5) ? E(5) : (rr == 4) ? E(4) : (rr == 3) ? E(3) : (rr == 2) ? E(2) : (rr == 1) ? E(1) : E(0))
+        // element rr of a twelve-vector held as compile-time-indexed registers, as a chain of SELECTS on a running value.  (As
+        // nested ternaries hipcc built a tree of divergent branches and sank the computation of each component into its
+        // branch: twelve serial paths, 1,350 of a step's 3,970 cycles by the in-kernel timestamps.)
+#define OS_PICK12(E)                                                                                             \
+    ({                                                                                                           \
+        float pick_ = E(0);                                                                                      \
+        pick_ = (rr == 1) ? E(1) : pick_; pick_ = (rr == 2) ? E(2) : pick_; pick_ = (rr == 3) ? E(3) : pick_;    \
+        pick_ = (rr == 4) ? E(4) : pick_; pick_ = (rr == 5) ? E(5) : pick_; pick_ = (rr == 6) ? E(6) : pick_;    \
+        pick_ = (rr == 7) ? E(7) : pick_; pick_ = (rr == 8) ? E(8) : pick_; pick_ = (rr == 9) ? E(9) : pick_;    \
+        pick_ = (rr == 10) ? E(10) : pick_; pick_ = (rr == 11) ? E(11) : pick_;                                  \
+        pick_;                                                                                                   \
+    })
 #define OS_LEGV(v, i) (v)[((i) / 3) >> 1][(i) % 3][((i) / 3) & 1]
 #define OS_EX(i) X[(i) >> 1][(i) & 1]
 #define OS_EPW(i) OS_LEGV(PW, i)
