@@ -181,55 +181,89 @@ __device__ __forceinline__ void load_step_p(const KfRunArgs &a, int t, uint32_t 
 // No destination registers, so a step can be requested two steps ahead.  Stage layout (dwords): [p 64][f 64][dp 64][imu 64][contact 64],
 // a 12-vector stored in PAIR order (0,3,1,4,2,5,6,9,7,10,8,11) so that the leg pairs of StepInP are adjacent.
 constexpr int ROWS_STAGE = 5 * 64;
+// Every stream's block is laid out [trajectory of the wave (4)][12 dwords]: lane L < 48 fetches dword L % 12 of trajectory L / 12
+// (p, f, dp: the pair-ordered component; imu: component (L % 12) % 6; contact: the word, twelve times), so that ONE per-lane
+// address (stage + 48 grp bytes) plus immediate offsets reads everything.  Lanes 48-63 repeat lane 0's fetch into the block's tail.
 struct RowsDma { uint32_t vo12, vo6, vo1; };      // per-lane byte offsets inside one step's block of a 12-, 6-, 1-row stream
 __device__ __forceinline__ RowsDma rows_dma_setup(int lane, int first_traj, int B)
 {
     const int ord[12] = {0, 3, 1, 4, 2, 5, 6, 9, 7, 10, 8, 11};
     RowsDma d;
-    const int l12 = lane < 48 ? lane : 0, l6 = lane < 24 ? lane : 0, l1 = lane < 4 ? lane : 0;
+    const int l = lane < 48 ? lane : 0, i = l % 12, g = l / 12;
     int row = ord[0];
 #pragma unroll
-    for (int i = 1; i < 12; i++) row = (l12 % 12 == i) ? ord[i] : row;
-    auto tr = [&](int g) { const int b = first_traj + g; return b < B ? b : B - 1; };
-    d.vo12 = (uint32_t)(row * B + tr(l12 / 12)) * 4u;
-    d.vo6 = (uint32_t)((l6 % 6) * B + tr(l6 / 6)) * 4u;
-    d.vo1 = (uint32_t)tr(l1) * 4u;
+    for (int q = 1; q < 12; q++) row = (i == q) ? ord[q] : row;
+    const int tr = first_traj + g < B ? first_traj + g : B - 1;
+    d.vo12 = (uint32_t)(row * B + tr) * 4u;
+    d.vo6 = (uint32_t)((i < 6 ? i : i - 6) * B + tr) * 4u;
+    d.vo1 = (uint32_t)tr * 4u;
     return d;
 }
-__device__ __forceinline__ void rows_dma_request(const KfRunArgs &a, int t, const RowsDma &d, uint32_t rowB, float *stage)
+// Constant descriptors over the whole streams, the step's position added to the lane's VGPR offset: t * 48 B bytes, so the host
+// only picks this kernel while T * 48 B < 2^32.  (Measured: with one-step descriptors and the step's position in the SGPR
+// offset, every step but the first came back as zeros -- the range check took the SGPR offset into account there.)
+struct RowsSrc { rsrc_t p, f, dp, imu, contact; };
+__device__ __forceinline__ RowsSrc rows_src(const KfRunArgs &a, uint32_t rowB)
 {
-    const size_t B = (size_t)a.B;
-    lds_dma4(make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB), stage, d.vo12, 0);
-    lds_dma4(make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB), stage + 64, d.vo12, 0);
-    lds_dma4(make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB), stage + 128, d.vo12, 0);
-    lds_dma4(make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB), stage + 192, d.vo6, 0);
-    lds_dma4(make_rsrc(a.contact + (size_t)t * B, rowB), stage + 256, d.vo1, 0);
+    const uint32_t T = (uint32_t)a.T;
+    return RowsSrc{make_rsrc(a.p, T * 12u * rowB), make_rsrc(a.f, T * 12u * rowB), make_rsrc(a.dp, T * 12u * rowB),
+                   make_rsrc(a.imu, T * 6u * rowB), make_rsrc(a.contact, T * rowB)};
 }
-__device__ __forceinline__ void rows_dma_read(const float *stage, int grp, StepInP &in)
+__device__ __forceinline__ void lds_dma4_at(rsrc_t r, uint32_t lds_byte, uint32_t voff)      // lds_byte: wave-uniform
 {
-    const float4 *p4 = reinterpret_cast<const float4 *>(stage + grp * 12), *f4 = reinterpret_cast<const float4 *>(stage + 64 + grp * 12),
-                 *d4 = reinterpret_cast<const float4 *>(stage + 128 + grp * 12);
-    float v[3][12];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float4 a = p4[i], b = f4[i], c = d4[i];
-        v[0][4 * i] = a.x; v[0][4 * i + 1] = a.y; v[0][4 * i + 2] = a.z; v[0][4 * i + 3] = a.w;
-        v[1][4 * i] = b.x; v[1][4 * i + 1] = b.y; v[1][4 * i + 2] = b.z; v[1][4 * i + 3] = b.w;
-        v[2][4 * i] = c.x; v[2][4 * i + 1] = c.y; v[2][4 * i + 2] = c.z; v[2][4 * i + 3] = c.w;
-    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(uintptr_t)lds_byte, 4, voff, 0, 0, 2);
+}
+__device__ __forceinline__ void rows_dma_request(const RowsSrc &src, uint32_t t, const RowsDma &d, uint32_t rowB, uint32_t stage)
+{
+    const uint32_t s1 = t * rowB, s6 = 6u * s1, s12 = 12u * s1;
+    const uint32_t v12 = d.vo12 + s12;
+    lds_dma4_at(src.p, stage, v12);
+    lds_dma4_at(src.f, stage + 256u, v12);
+    lds_dma4_at(src.dp, stage + 512u, v12);
+    lds_dma4_at(src.imu, stage + 768u, d.vo6 + s6);
+    lds_dma4_at(src.contact, stage + 1024u, d.vo1 + s1);
+}
+// The pick-up as inline assembly: hipcc orders an LDS read it can see behind EVERY outstanding LDS-DMA (s_waitcnt vmcnt(0): the
+// request of the step after next and the last x_out store included), which would undo the two-step prefetch.  rows_issue starts
+// the eleven reads, rows_fence waits for them and hands the registers over as a StepInP.
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct RowsRaw { f4 p[3], f[3], d[3], i4; f2 i2; float c, il; };
+template <bool ALL_IMU>
+__device__ __forceinline__ void rows_issue(uint32_t addr /* stage + 48 grp */, uint32_t addr_imu /* the lane's own IMU entry */, RowsRaw &r)
+{
+#define OSK_RD4(dst, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+    OSK_RD4(r.p[0], 0);   OSK_RD4(r.p[1], 16);  OSK_RD4(r.p[2], 32);
+    OSK_RD4(r.f[0], 256); OSK_RD4(r.f[1], 272); OSK_RD4(r.f[2], 288);
+    OSK_RD4(r.d[0], 512); OSK_RD4(r.d[1], 528); OSK_RD4(r.d[2], 544);
+    OSK_RD4(r.i4, 768);
+#undef OSK_RD4
+    if (ALL_IMU) asm volatile("ds_read_b64 %0, %1 offset:784" : "=v"(r.i2) : "v"(addr));
+    else r.i2 = (f2){0.f, 0.f};                     // imu[4], imu[5]: only the feature rows read them
+    asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(r.c) : "v"(addr));
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r.il) : "v"(addr_imu));
+}
+template <bool ALL_IMU>
+__device__ __forceinline__ void rows_fence(RowsRaw &r, StepInP &in)
+{
+    if (ALL_IMU)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.f[0]), "+v"(r.f[1]), "+v"(r.f[2]), "+v"(r.d[0]), "+v"(r.d[1]),
+                       "+v"(r.d[2]), "+v"(r.i4), "+v"(r.i2), "+v"(r.c), "+v"(r.il));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.f[0]), "+v"(r.f[1]), "+v"(r.f[2]), "+v"(r.d[0]), "+v"(r.d[1]),
+                       "+v"(r.d[2]), "+v"(r.i4), "+v"(r.c), "+v"(r.il));
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int j = 2 * (3 * q + c);
-            in.p[q][c] = (f2){v[0][j], v[0][j + 1]};
-            in.f[q][c] = (f2){v[1][j], v[1][j + 1]};
-            in.dp[q][c] = (f2){v[2][j], v[2][j + 1]};
+            in.p[q][c] = (f2){r.p[j / 4][j % 4], r.p[j / 4][j % 4 + 1]};
+            in.f[q][c] = (f2){r.f[j / 4][j % 4], r.f[j / 4][j % 4 + 1]};
+            in.dp[q][c] = (f2){r.d[j / 4][j % 4], r.d[j / 4][j % 4 + 1]};
         }
-    const float2 *i2 = reinterpret_cast<const float2 *>(stage + 192 + grp * 6);
-#pragma unroll
-    for (int i = 0; i < 3; i++) { const float2 w = i2[i]; in.imu[2 * i] = w.x; in.imu[2 * i + 1] = w.y; }
-    in.contact = __builtin_bit_cast(uint32_t, stage[256 + grp]);
+    in.imu[0] = r.i4[0]; in.imu[1] = r.i4[1]; in.imu[2] = r.i4[2]; in.imu[3] = r.i4[3]; in.imu[4] = r.i2[0]; in.imu[5] = r.i2[1];
+    in.contact = __builtin_bit_cast(uint32_t, r.c);
 }
 
 }  // namespace osk

@@ -787,16 +787,18 @@ __device__ __forceinline__ void measurement_p(const StepInP &in, const f2 *Rp, f
     z[9] = Rp[6][1] * bx + Rp[7][1] * by + Rp[8][1] * bz;
 }
 
-// next_state (misc/force_controller.py:269-291) on paired legs: X in/out, PW[q][c] = world-frame foot positions of legs
-// (2q, 2q+1) (the reference mutates the caller's p, :274-277).  Same equations as dynamics().
-__device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &in, f2 (*PW)[3], const KfConst &k)
+// The input-dependent half of next_state (misc/force_controller.py:269-291) on paired legs: PW[q][c] = world-frame foot
+// positions of legs (2q, 2q+1) (the reference mutates the caller's p, :274-277), aw = I_hat^-1 sum(pw x f) (world frame),
+// fs = sum f, amax = the largest |entry| of the prior rotation (the int64-truncation predicate).  Same equations as dynamics().
+__device__ __forceinline__ void dynamics_rates_p(const f2 *Rp, const StepInP &in, f2 (*PW)[3], const KfConst &k, float *aw, float *fs,
+                                                 float &amax)
 {
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int c = 0; c < 3; c++)
             PW[q][c] = fma2(lo2(Rp[3 * c + 2]), in.p[q][2], fma2(lo2(Rp[3 * c + 1]), in.p[q][1], lo2(Rp[3 * c]) * in.p[q][0]));
-    float tau[3], fs[3], r[9];
+    float tau[3], r[9];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
@@ -814,12 +816,20 @@ __device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &i
     const float tb0 = (r[0] * tau[0] + r[3] * tau[1] + r[6] * tau[2]) * k.inv_inertia[0];
     const float tb1 = (r[1] * tau[0] + r[4] * tau[1] + r[7] * tau[2]) * k.inv_inertia[1];
     const float tb2 = (r[2] * tau[0] + r[5] * tau[1] + r[8] * tau[2]) * k.inv_inertia[2];
-    const float aw0 = r[0] * tb0 + r[1] * tb1 + r[2] * tb2;
-    const float aw1 = r[3] * tb0 + r[4] * tb1 + r[5] * tb2;
-    const float aw2 = r[6] * tb0 + r[7] * tb1 + r[8] * tb2;
-    float amax = 0.f;
+    aw[0] = r[0] * tb0 + r[1] * tb1 + r[2] * tb2;
+    aw[1] = r[3] * tb0 + r[4] * tb1 + r[5] * tb2;
+    aw[2] = r[6] * tb0 + r[7] * tb1 + r[8] * tb2;
+    amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; i++) amax = fmaxf(amax, fabsf(r[i]));
+}
+
+// next_state on the replicated state: X in/out.
+__device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &in, f2 (*PW)[3], const KfConst &k)
+{
+    float aw[3], fs[3], amax;
+    dynamics_rates_p(Rp, in, PW, k, aw, fs, amax);
+    const float aw0 = aw[0], aw1 = aw[1], aw2 = aw[2];
     float x[NS];
 #pragma unroll
     for (int i = 0; i < 6; i++) { x[2 * i] = X[i][0]; x[2 * i + 1] = X[i][1]; }

@@ -308,11 +308,12 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
 
     float Prow[NS], qrow[NS], xr;
     {
+        // (the row is per lane: in the VGPR offset -- as an SGPR offset hipcc wraps every load in a waterfall loop)
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
-        xr = buf_load(rx, voff, (uint32_t)rr * rowB);
+        xr = buf_load(rx, voff + (uint32_t)rr * rowB, 0);
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            Prow[j] = buf_load(rP, voff, (uint32_t)(rr * NS + j) * rowB);
+            Prow[j] = buf_load(rP, voff + (uint32_t)(rr * NS + j) * rowB, 0);
             qrow[j] = qmat[rr * NS + j];
         }
     }
@@ -462,7 +463,7 @@ __device__ __forceinline__ void fmac_shl(float &acc, float src, float m)       /
     asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
 
-template <bool AUX, bool FEAT>
+template <bool AUX, bool FEAT, bool PROT>
 __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
@@ -477,28 +478,54 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
 
     float Prow[NS], qrow[NS], xr;
     {
+        // (the row is per lane: in the VGPR offset -- as an SGPR offset hipcc wraps every load in a waterfall loop)
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
-        xr = buf_load(rx, voff, (uint32_t)rr * rowB);
+        xr = buf_load(rx, voff + (uint32_t)rr * rowB, 0);
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            Prow[j] = buf_load(rP, voff, (uint32_t)(rr * NS + j) * rowB);
+            Prow[j] = buf_load(rP, voff + (uint32_t)(rr * NS + j) * rowB, 0);
             qrow[j] = qmat[rr * NS + j];
         }
     }
-    const bool top = r < 3, mid = r >= 3 && r < 6;
     bool bad = false;
-    // step inputs: three LDS stages per wave, step t + 2 requested at the top of step t (rows_dma_*: kf_args.hpp)
+    // Per-lane constants (one-hot in the lane's row r, scaled): each lane integrates ITS component of next_state and holds ITS
+    // measurement, by multiply-adds with these weights instead of selects (a select chain costs an SGPR mask pair per
+    // comparison, and hipcc kept spilling SGPRs in this loop).  Opaque to the optimiser, or it rebuilds them from masks per step.
+    const KfConst &kk = a.k;
+    float e0 = r == 0 ? 1.f : 0.f, e1 = r == 1 ? 1.f : 0.f, e2 = r == 2 ? 1.f : 0.f;             // rows 0..2: theta
+    float cd = (r >= 3 && r < 6) ? kk.dt : 0.f;                                                  // rows 3..5: position += dt * velocity
+    float wa0 = r == 6 ? kk.dt : 0.f, wa1 = r == 7 ? kk.dt : 0.f, wa2 = r == 8 ? kk.dt : 0.f;    // rows 6..8: omega += dt * aw
+    float wf0 = r == 9 ? kk.dt * kk.inv_mass : 0.f, wf1 = r == 10 ? kk.dt * kk.inv_mass : 0.f, wf2 = rr == 11 ? kk.dt * kk.inv_mass : 0.f;
+    float wg = rr == 11 ? kk.dt * kk.gz : 0.f;                                                   // (rr: the idle lanes shadow row 11)
+    float zi = (r < 3 || (r >= 6 && r < 9)) ? 1.f : 0.f, z5 = r == 5 ? 1.f : 0.f;                // measurement held by the lane
+    float z9 = r == 9 ? 1.f : 0.f, z10 = r == 10 ? 1.f : 0.f, z11 = rr == 11 ? 1.f : 0.f;
+    asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(cd), "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wf0), "+v"(wf1), "+v"(wf2), "+v"(wg));
+    asm volatile("" : "+v"(zi), "+v"(z5), "+v"(z9), "+v"(z10), "+v"(z11));
+    float Rd[NM];                                      // diag R in registers: the DPP add that forms S = P[s][s] + R takes no SGPR
+#pragma unroll
+    for (int i = 0; i < NM; i++) { Rd[i] = kk.R[i * NM + i]; asm volatile("" : "+v"(Rd[i])); }
+    // step inputs: three LDS stages per wave, step t + 2 requested at the top of step t (rows_*: kf_args.hpp).  The stage
+    // addresses live in SGPRs and rotate; the descriptors are loop constants.
     __shared__ __attribute__((aligned(16))) float stage_all[4][3][ROWS_STAGE];
-    float (*stage)[ROWS_STAGE] = stage_all[wv];
+    const uint32_t stage0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)stage_all[wv][0]);
+    uint32_t st_cur = stage0, st_nxt = stage0 + 4u * ROWS_STAGE, st_nn = stage0 + 8u * ROWS_STAGE;
+    const uint32_t rd_lane = (uint32_t)grp * 48u;
+    // the lane's own IMU measurement: imu[r] on rows 0..2, imu[r - 3] on rows 6..8 (anything finite elsewhere: weight 0)
+    const uint32_t rd_imu = rd_lane + 768u + 4u * (uint32_t)(r < 3 ? r : (r >= 6 && r < 9) ? r - 3 : 0);
     const RowsDma dma = rows_dma_setup(lane, first, a.B);
+    const RowsSrc src = rows_src(a, rowB);
     // the plain variant issues exactly one store per step (x_out), so the wait below can leave step t + 1's five DMA loads and
     // the last two stores in flight (loads and stores retire in issue order): vmcnt(7).  With optional outputs the store
     // count is not a compile-time constant: wait for everything (one step of latency hiding instead of two).
-    const bool plain = !AUX && !FEAT && !a.p_rot_out;
+    constexpr bool plain = !AUX && !FEAT && !PROT;
     StepInP in;
     OS_TS_DECL
-    rows_dma_request(a, 0, dma, rowB, stage[0]);
-    rows_dma_request(a, a.T > 1 ? 1 : 0, dma, rowB, stage[1]);
+    // (the prologue's loads retire here: otherwise hipcc re-checks them with a dozen s_waitcnt in every iteration)
+    __builtin_amdgcn_s_waitcnt(0x0070);
+#pragma unroll
+    for (int j = 0; j < NS; j++) asm volatile("" : "+v"(qrow[j]), "+v"(Prow[j]));
+    rows_dma_request(src, 0, dma, rowB, st_cur);
+    rows_dma_request(src, a.T > 1 ? 1 : 0, dma, rowB, st_nxt);
     for (int t = 0; t < a.T; t++) {
         OS_TS(0)
         // issued after DMA(t): t = 0: DMA(1); t = 1: DMA(2), store(0); t >= 2: store(t-2), DMA(t+1), store(t-1)
@@ -506,29 +533,40 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         else if (plain) __builtin_amdgcn_s_waitcnt(0x0f75);                 // vmcnt(5)
         else __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        rows_dma_read(stage[t % 3], grp, in);
+        float imu_lane;
         {
+            RowsRaw raw;
+            rows_issue<FEAT>(st_cur + rd_lane, st_cur + rd_imu, raw);
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
-            rows_dma_request(a, tn, dma, rowB, stage[(t + 2) % 3]);
+            rows_dma_request(src, (uint32_t)tn, dma, rowB, st_nn);
+            rows_fence<FEAT>(raw, in);
+            imu_lane = raw.il;
+            const uint32_t st_old = st_cur;
+            st_cur = st_nxt; st_nxt = st_nn; st_nn = st_old;
         }
         OS_TS(1)                                        // wait + LDS reads + next request
-        // ---- the prior state, replicated per lane, as pairs ----
-        f2 X[6];
-        X[0] = (f2){row_bcast<0>(xr), row_bcast<1>(xr)}; X[1] = (f2){row_bcast<2>(xr), row_bcast<3>(xr)};
-        X[2] = (f2){row_bcast<4>(xr), row_bcast<5>(xr)}; X[3] = (f2){row_bcast<6>(xr), row_bcast<7>(xr)};
-        X[4] = (f2){row_bcast<8>(xr), row_bcast<9>(xr)}; X[5] = (f2){row_bcast<10>(xr), row_bcast<11>(xr)};
-        float z[NM], g[9];
-        f2 PW[2][3];
-        kf_step_inputs_sym(X, in, k, z, PW, g);          // measurement, next_state, g = dt R^T of the prior attitude
-        OS_TS(2)                                        // state broadcast + rotations + odometry + next_state
+        // ---- everything of the step that every lane needs: both rotations, the odometry, the torque / force sums ----
+        const float th[3] = {row_bcast<0>(xr), row_bcast<1>(xr), row_bcast<2>(xr)};      // the prior attitude
+        f2 Rp[9], PW[2][3];
+        float z[NM], g[9], aw[3], fs[3], amax;
+        rotation2(th, in.imu, Rp);
+        measurement_p(in, Rp, z);                        // z[3], z[7..9] are used; the IMU entries come per lane (imu_lane)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) g[3 * i + q] = k.dt * Rp[3 * q + i][0];           // g[3 i + q] = dt R[q][i]
+        dynamics_rates_p(Rp, in, PW, k, aw, fs, amax);
+        const float zr = fmaf(z11, z[9], fmaf(z10, z[8], fmaf(z9, z[7], fmaf(z5, z[3], zi * imu_lane))));
+        OS_TS(2)                                        // rotations + odometry + torque / force sums
         // ---- covariance predict, row-parallel: M = F_d P (rows: lane r needs rows 6..8 or row r + 6), then P' = M F_d^T + Q (local) ----
-        const float cg0 = top ? (r == 0 ? g[0] : (r == 1 ? g[3] : g[6])) : 0.f;
-        const float cg1 = top ? (r == 0 ? g[1] : (r == 1 ? g[4] : g[7])) : 0.f;
-        const float cg2 = top ? (r == 0 ? g[2] : (r == 1 ? g[5] : g[8])) : 0.f;
-        const float cd = mid ? k.dt : 0.f;
+        const float cg0 = fmaf(e2, g[6], fmaf(e1, g[3], e0 * g[0]));
+        const float cg1 = fmaf(e2, g[7], fmaf(e1, g[4], e0 * g[1]));
+        const float cg2 = fmaf(e2, g[8], fmaf(e1, g[5], e0 * g[2]));
         float M[NS];
 #pragma unroll
         for (int j = 0; j < NS; j++) M[j] = Prow[j];
+        // this lane's component of next_state (misc/force_controller.py:269-291): the PRIOR state everywhere on the right
+        float xn = fmaf(wa0, aw[0], fmaf(wa1, aw[1], fmaf(wa2, aw[2], fmaf(wf0, fs[0], fmaf(wf1, fs[1], fmaf(wf2, fs[2], xr + wg))))));
         asm volatile("s_nop 1");
         // four multiply-adds per column, issued column-interleaved: consecutive instructions never touch the same accumulator
 #pragma unroll
@@ -539,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         for (int j = 0; j < NS; j++) fmac_bcast<8>(M[j], Prow[j], cg2);
 #pragma unroll
         for (int j = 0; j < NS; j++) fmac_shl<6>(M[j], Prow[j], cd);       // row r + 6 (rows 9..11 for lanes 3..5)
+        fmac_shl<6>(xn, xr, cd);                                           // position += dt * the prior velocity
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8] + qrow[j];
@@ -546,11 +585,19 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         }
 #pragma unroll
         for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
-        OS_TS(3)                                        // covariance predict
-        // ---- this lane's component of the predicted state and of the step's by-products ----
-        // element rr of a twelve-vector held as compile-time-indexed registers, as a chain of SELECTS on a running value.  (As
-        // nested ternaries hipcc built a tree of divergent branches and sank the computation of each component into its
-        // branch: twelve serial paths, 1,350 of a step's 3,970 cycles by the in-kernel timestamps.)
+        // theta += dt trunc(R^T) omega: zero unless an entry of R reaches +-1 in float64 (see trunc_block_f64)
+        if (__builtin_amdgcn_ballot_w64(amax >= 0.9999995f) != 0ull) {
+            float A[9];
+            trunc_block_f64(th[0], th[1], th[2], A);
+            const float w0 = row_bcast<6>(xr), w1 = row_bcast<7>(xr), w2 = row_bcast<8>(xr);
+            const float d0 = A[0] * w0 + A[1] * w1 + A[2] * w2, d1 = A[3] * w0 + A[4] * w1 + A[5] * w2, d2 = A[6] * w0 + A[7] * w1 + A[8] * w2;
+            const float dth = k.dt * (r == 0 ? d0 : r == 1 ? d1 : r == 2 ? d2 : 0.f);
+            xn += (amax >= 0.9999995f) ? dth : 0.f;
+        }
+        OS_TS(3)                                        // covariance predict + this lane's component of next_state
+        // ---- optional outputs: element rr of a twelve-vector held as compile-time-indexed registers, as a chain of SELECTS on a
+        // running value.  (As nested ternaries hipcc built a tree of divergent branches and sank the computation of each
+        // component into its branch.)
 #define OS_PICK12(E)                                                                                             \
     ({                                                                                                           \
         float pick_ = E(0);                                                                                      \
@@ -561,12 +608,10 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         pick_;                                                                                                   \
     })
 #define OS_LEGV(v, i) (v)[((i) / 3) >> 1][(i) % 3][((i) / 3) & 1]
-#define OS_EX(i) X[(i) >> 1][(i) & 1]
 #define OS_EPW(i) OS_LEGV(PW, i)
 #define OS_EF(i) OS_LEGV(in.f, i)
 #define OS_EDP(i) OS_LEGV(in.dp, i)
-        xr = OS_PICK12(OS_EX);
-        if (a.p_rot_out && live && r < 12) a.p_rot_out[((size_t)t * 12 + r) * B + b] = OS_PICK12(OS_EPW);
+        if (PROT && a.p_rot_out && live && r < 12) a.p_rot_out[((size_t)t * 12 + r) * B + b] = OS_PICK12(OS_EPW);
         if (FEAT && live && r < 12) {
             const float fv = OS_PICK12(OS_EF), pv = OS_PICK12(OS_EPW), dv = OS_PICK12(OS_EDP);
             float *fo = a.feat_out + (size_t)t * a.feat_I * B + b;
@@ -583,7 +628,6 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         }
 #undef OS_PICK12
 #undef OS_LEGV
-#undef OS_EX
 #undef OS_EPW
 #undef OS_EF
 #undef OS_EDP
@@ -593,21 +637,37 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         // The column the NEXT measurement reads (SN) is updated first, so that its scalar chain (row broadcast -> add -> class
         // test -> v_rcp_f32 -> gain) starts while this measurement's other eleven multiply-adds are still issuing.
 #define OS_ROW_FMAC(S, J, SN) if (J != SN) fmac_bcast<S>(Prow[J], Prow[J], nkc);
-#define OS_ROW_UPDATE2(A, S, SN)                                                                      \
+#define OS_ROW_SADD(AN, SN)                                                                           \
+        asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+                     : "=v"(sv) : "v"(Prow[SN]), "v"(Rd[AN]), "n"(SN));
+        // The innovation of measurement A sits in lane S (= the lane's state component minus the lane's measurement, taken when
+        // the previous update of xn is done and twelve instructions before its DPP read: in assembly so that it stays there).
+        // S = P[s][s] + R[a][a] of the NEXT measurement (column SN, row SN) by one DPP add, two instructions behind the
+        // multiply-add that finishes P[.][SN], so that its chain (class test, v_rcp_f32, gain) runs under this measurement's
+        // other multiply-adds.
+#define OS_ROW_UPDATE2(A, S, SN, AN)                                                                  \
         {                                                                                             \
-            const float sv = row_bcast<S>(Prow[S]) + k.R[A * NM + A];                                 \
+            float dz;                                                                                 \
             bad |= !__builtin_amdgcn_classf(sv, 0x180);                                               \
             const float nkc = -Prow[S] * __builtin_amdgcn_rcpf(sv);                                   \
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(xn), "v"(zr));                       \
             fmac_bcast<S>(Prow[SN], Prow[SN], nkc);                                                   \
-            xr = fmaf(nkc, row_bcast<S>(xr) - z[A], xr);                                              \
-            OS_ROW_FMAC(S, 0, SN) OS_ROW_FMAC(S, 1, SN) OS_ROW_FMAC(S, 2, SN) OS_ROW_FMAC(S, 3, SN)   \
+            OS_ROW_FMAC(S, 0, SN) OS_ROW_FMAC(S, 1, SN) OS_ROW_FMAC(S, 2, SN)                         \
+            if (AN < NM) { OS_ROW_SADD(AN, SN) }                                                      \
+            OS_ROW_FMAC(S, 3, SN)                                                                     \
             OS_ROW_FMAC(S, 4, SN) OS_ROW_FMAC(S, 5, SN) OS_ROW_FMAC(S, 6, SN) OS_ROW_FMAC(S, 7, SN)   \
             OS_ROW_FMAC(S, 8, SN) OS_ROW_FMAC(S, 9, SN) OS_ROW_FMAC(S, 10, SN) OS_ROW_FMAC(S, 11, SN) \
+            fmac_bcast<S>(xn, dz, nkc);                                                               \
         }
-        OS_ROW_UPDATE2(0, 0, 1) OS_ROW_UPDATE2(1, 1, 2) OS_ROW_UPDATE2(2, 2, 5) OS_ROW_UPDATE2(3, 5, 6) OS_ROW_UPDATE2(4, 6, 7)
-        OS_ROW_UPDATE2(5, 7, 8) OS_ROW_UPDATE2(6, 8, 9) OS_ROW_UPDATE2(7, 9, 10) OS_ROW_UPDATE2(8, 10, 11) OS_ROW_UPDATE2(9, 11, 0)
+        float sv;
+        OS_ROW_SADD(0, 0)
+        OS_ROW_UPDATE2(0, 0, 1, 1) OS_ROW_UPDATE2(1, 1, 2, 2) OS_ROW_UPDATE2(2, 2, 5, 3) OS_ROW_UPDATE2(3, 5, 6, 4)
+        OS_ROW_UPDATE2(4, 6, 7, 5) OS_ROW_UPDATE2(5, 7, 8, 6) OS_ROW_UPDATE2(6, 8, 9, 7) OS_ROW_UPDATE2(7, 9, 10, 8)
+        OS_ROW_UPDATE2(8, 10, 11, 9) OS_ROW_UPDATE2(9, 11, 0, 10)
+#undef OS_ROW_SADD
 #undef OS_ROW_FMAC
 #undef OS_ROW_UPDATE2
+        xr = xn;
         OS_TS(5)                                        // ten measurement updates
         if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
         if (FEAT && live && r < 12)
@@ -797,8 +857,9 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
 #else
     const bool no_gain = !a.kgain_out;
 #endif
+    // (the rows kernel carries a step's position in a 32-bit SGPR offset: T * 48 B bytes must fit)
     const bool use_rows = !noise && seq && !dense && no_gain && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
-                          a.B < ctx->rows_kernel_below && ctx->kf_qr;
+                          a.B < ctx->rows_kernel_below && ctx->kf_qr && (uint64_t)a.T * 48ull * (uint64_t)a.B < 0xffffffffull;
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise) && !a.kgain_out;
     const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
                         : dense ? (seq ? "kf_run_kernel<SEQ,DENSE_F64>" : "kf_run_kernel<BATCH,DENSE_F64>")
@@ -820,9 +881,10 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
             if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
             else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
             else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        } else if (feat) hipLaunchKernelGGL((kf_run_rows2_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else if (aux) hipLaunchKernelGGL((kf_run_rows2_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else hipLaunchKernelGGL((kf_run_rows2_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        } else if (feat) hipLaunchKernelGGL((kf_run_rows2_kernel<false, true, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else if (aux) hipLaunchKernelGGL((kf_run_rows2_kernel<true, false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else if (a.p_rot_out) hipLaunchKernelGGL((kf_run_rows2_kernel<false, false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
+        else hipLaunchKernelGGL((kf_run_rows2_kernel<false, false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
         e = hipGetLastError();
     } else if (use_sym) {
         dim3 grid((a.B + 63) / 64), block(64);

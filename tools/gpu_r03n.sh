@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03n; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_kf.py tests/test_gpu_fullsize.py tests/test_gpu_advice.py tests/test_gpu_bench_contract.py -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6 | cut -c1-250 > $O/pytest.log
+timeout 900 python -m pytest tests/test_gpu_kf.py tests/test_gpu_fullsize.py tests/test_gpu_advice.py tests/test_gpu_bench_contract.py tests/test_gpu_pipeline.py -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6 | cut -c1-250 > $O/pytest.log
 timeout 600 python bench.py --mode kf --batch 4096 --seq 1000 --steps 5 --no-second-noise --cpu-seconds 0 > $O/bench_kf_4096.json 2>> $O/bench.err
 bash tools/rows_ts.sh > $O/rows_ts.txt 2>&1
 cat $O/pytest.log; python3 -c "

@@ -28,8 +28,8 @@ for rep in range(2):
     assert rc == 0, eng.lib.os_last_error(eng._h)
     torch.cuda.synchronize()
 v = ts.cpu().numpy()[:8].astype(np.float64) / T
-names = ["-", "wait + LDS reads + next DMA request", "state broadcast + rotations + odometry + next_state", "covariance predict",
-         "component selects / optional outputs", "ten measurement updates", "(unused)", "(unused)"]
+names = ["-", "wait + LDS reads + next DMA request", "attitude broadcast + rotations + odometry + torque/force sums", "covariance predict + own component of next_state",
+         "optional outputs", "ten measurement updates", "(unused)", "(unused)"]
 print("kernel", eng.kernel_name("kf"), " cycles per step by phase (lane 0 of workgroup 0, mean over", T, "steps; the x_out store and loop overhead are in phase 1 of the next step):")
 for i in range(1, 6):
     print(f"  {names[i]:55s} {v[i]:8.0f}")
