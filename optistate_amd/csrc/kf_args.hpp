@@ -182,19 +182,15 @@ __device__ __forceinline__ void load_step_p(const KfRunArgs &a, int t, uint32_t 
 // a 12-vector stored in PAIR order (0,3,1,4,2,5,6,9,7,10,8,11) so that the leg pairs of StepInP are adjacent.
 constexpr int ROWS_STAGE = 5 * 64;
 // Every stream's block is laid out [trajectory of the wave (4)][12 dwords]: lane L < 48 fetches dword L % 12 of trajectory L / 12
-// (p, f, dp: the pair-ordered component; imu: component (L % 12) % 6; contact: the word, twelve times), so that ONE per-lane
-// address (stage + 48 grp bytes) plus immediate offsets reads everything.  Lanes 48-63 repeat lane 0's fetch into the block's tail.
+// (p, f, dp: component L % 12, leg-major; imu: component (L % 12) % 6; contact: the word, twelve times), so a lane reaches
+// everything of its trajectory from stage + 48 grp bytes plus immediate offsets.  Lanes 48-63 repeat lane 0's fetch into the tail.
 struct RowsDma { uint32_t vo12, vo6, vo1; };      // per-lane byte offsets inside one step's block of a 12-, 6-, 1-row stream
 __device__ __forceinline__ RowsDma rows_dma_setup(int lane, int first_traj, int B)
 {
-    const int ord[12] = {0, 3, 1, 4, 2, 5, 6, 9, 7, 10, 8, 11};
     RowsDma d;
     const int l = lane < 48 ? lane : 0, i = l % 12, g = l / 12;
-    int row = ord[0];
-#pragma unroll
-    for (int q = 1; q < 12; q++) row = (i == q) ? ord[q] : row;
     const int tr = first_traj + g < B ? first_traj + g : B - 1;
-    d.vo12 = (uint32_t)(row * B + tr) * 4u;
+    d.vo12 = (uint32_t)(i * B + tr) * 4u;
     d.vo6 = (uint32_t)((i < 6 ? i : i - 6) * B + tr) * 4u;
     d.vo1 = (uint32_t)tr * 4u;
     return d;
@@ -225,45 +221,78 @@ __device__ __forceinline__ void rows_dma_request(const RowsSrc &src, uint32_t t,
 }
 // The pick-up as inline assembly: hipcc orders an LDS read it can see behind EVERY outstanding LDS-DMA (s_waitcnt vmcnt(0): the
 // request of the step after next and the last x_out store included), which would undo the two-step prefetch.  rows_issue starts
-// the eleven reads, rows_fence waits for them and hands the registers over as a StepInP.
+// the reads, rows_fence waits for them.  A lane picks up ONE leg (leg = lane & 3: every quad of the 16-lane row holds the four
+// legs, the sums over the legs are two quad-permute adds), the IMU attitude, the contact word and its own measurement; the
+// variants with optional outputs add the lane's own row of f / dp / imu and the leg of its row of the rotated foot positions.
 typedef float f4 __attribute__((ext_vector_type(4)));
-struct RowsRaw { f4 p[3], f[3], d[3], i4; f2 i2; float c, il; };
-template <bool ALL_IMU>
-__device__ __forceinline__ void rows_issue(uint32_t addr /* stage + 48 grp */, uint32_t addr_imu /* the lane's own IMU entry */, RowsRaw &r)
+struct RowsLane { uint32_t leg, grp, imu, row, rleg; };   // byte offsets inside a stage (rows_lane)
+__device__ __forceinline__ RowsLane rows_lane(int grp, int r, int rr)
 {
-#define OSK_RD4(dst, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-    OSK_RD4(r.p[0], 0);   OSK_RD4(r.p[1], 16);  OSK_RD4(r.p[2], 32);
-    OSK_RD4(r.f[0], 256); OSK_RD4(r.f[1], 272); OSK_RD4(r.f[2], 288);
-    OSK_RD4(r.d[0], 512); OSK_RD4(r.d[1], 528); OSK_RD4(r.d[2], 544);
-    OSK_RD4(r.i4, 768);
-#undef OSK_RD4
-    if (ALL_IMU) asm volatile("ds_read_b64 %0, %1 offset:784" : "=v"(r.i2) : "v"(addr));
-    else r.i2 = (f2){0.f, 0.f};                     // imu[4], imu[5]: only the feature rows read them
-    asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(r.c) : "v"(addr));
-    asm volatile("ds_read_b32 %0, %1" : "=v"(r.il) : "v"(addr_imu));
+    RowsLane a;
+    a.grp = (uint32_t)grp * 48u;
+    a.leg = a.grp + 12u * (uint32_t)(r & 3);
+    // the lane's own IMU measurement: imu[r] on rows 0..2, imu[r - 3] on rows 6..8 (anything finite elsewhere: weight 0)
+    a.imu = a.grp + 768u + 4u * (uint32_t)(r < 3 ? r : (r >= 6 && r < 9) ? r - 3 : 0);
+    a.row = a.grp + 4u * (uint32_t)rr;
+    a.rleg = a.grp + 12u * (uint32_t)(rr / 3);
+    return a;
 }
-template <bool ALL_IMU>
-__device__ __forceinline__ void rows_fence(RowsRaw &r, StepInP &in)
+struct RowsRaw {
+    f2 pxy, fxy, dxy; float pz, fz, dz;       // the lane's leg
+    f4 i4; float c, il;                       // imu[0..3], contact word, the lane's IMU measurement
+    f2 qxy; float qz;                         // PROT: p of leg rr / 3
+    float fr, dr, ir;                         // FEAT: f[rr], dp[rr], imu[rr] (rr < 6)
+};
+template <bool FEAT, bool PROT>
+__device__ __forceinline__ void rows_issue(uint32_t stage, const RowsLane &a, RowsRaw &r)
 {
-    if (ALL_IMU)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.f[0]), "+v"(r.f[1]), "+v"(r.f[2]), "+v"(r.d[0]), "+v"(r.d[1]),
-                       "+v"(r.d[2]), "+v"(r.i4), "+v"(r.i2), "+v"(r.c), "+v"(r.il));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.f[0]), "+v"(r.f[1]), "+v"(r.f[2]), "+v"(r.d[0]), "+v"(r.d[1]),
-                       "+v"(r.d[2]), "+v"(r.i4), "+v"(r.c), "+v"(r.il));
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int j = 2 * (3 * q + c);
-            in.p[q][c] = (f2){r.p[j / 4][j % 4], r.p[j / 4][j % 4 + 1]};
-            in.f[q][c] = (f2){r.f[j / 4][j % 4], r.f[j / 4][j % 4 + 1]};
-            in.dp[q][c] = (f2){r.d[j / 4][j % 4], r.d[j / 4][j % 4 + 1]};
-        }
-    in.imu[0] = r.i4[0]; in.imu[1] = r.i4[1]; in.imu[2] = r.i4[2]; in.imu[3] = r.i4[3]; in.imu[4] = r.i2[0]; in.imu[5] = r.i2[1];
-    in.contact = __builtin_bit_cast(uint32_t, r.c);
+    const uint32_t aleg = stage + a.leg, agrp = stage + a.grp, aimu = stage + a.imu;
+    asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(r.pxy) : "v"(aleg));
+    asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(r.pz) : "v"(aleg));
+    asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:65" : "=v"(r.fxy) : "v"(aleg));
+    asm volatile("ds_read_b32 %0, %1 offset:264" : "=v"(r.fz) : "v"(aleg));
+    asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:129" : "=v"(r.dxy) : "v"(aleg));
+    asm volatile("ds_read_b32 %0, %1 offset:520" : "=v"(r.dz) : "v"(aleg));
+    asm volatile("ds_read_b128 %0, %1 offset:768" : "=v"(r.i4) : "v"(agrp));
+    asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(r.c) : "v"(agrp));
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r.il) : "v"(aimu));
+    if (PROT) {
+        const uint32_t arl = stage + a.rleg;
+        asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(r.qxy) : "v"(arl));
+        asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(r.qz) : "v"(arl));
+    }
+    if (FEAT) {
+        const uint32_t arow = stage + a.row;
+        asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(r.fr) : "v"(arow));
+        asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(r.dr) : "v"(arow));
+        asm volatile("ds_read_b32 %0, %1 offset:768" : "=v"(r.ir) : "v"(arow));
+    }
 }
+template <bool FEAT, bool PROT>
+__device__ __forceinline__ void rows_fence(RowsRaw &r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r.pxy), "+v"(r.pz), "+v"(r.fxy), "+v"(r.fz), "+v"(r.dxy), "+v"(r.dz), "+v"(r.i4), "+v"(r.c), "+v"(r.il));
+    if (PROT) asm volatile("" : "+v"(r.qxy), "+v"(r.qz));
+    if (FEAT) asm volatile("" : "+v"(r.fr), "+v"(r.dr), "+v"(r.ir));
+}
+// v = sum over the four lanes of the quad, in every lane: v += v of lane ^ 1, then v += v of lane ^ 2 (DPP reads need the
+// source two instructions old: the values interleave, and one s_nop covers whatever the compiler put in front)
+#define OSK_QADD(i, perm) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:" perm " row_mask:0xf bank_mask:0xf\n"
+__device__ __forceinline__ void quad_sum5(float &a, float &b, float &c, float &d, float &e)
+{
+    asm volatile("s_nop 1\n" OSK_QADD(0, "[1,0,3,2]") OSK_QADD(1, "[1,0,3,2]") OSK_QADD(2, "[1,0,3,2]") OSK_QADD(3, "[1,0,3,2]")
+                 OSK_QADD(4, "[1,0,3,2]") OSK_QADD(0, "[2,3,0,1]") OSK_QADD(1, "[2,3,0,1]") OSK_QADD(2, "[2,3,0,1]")
+                 OSK_QADD(3, "[2,3,0,1]") OSK_QADD(4, "[2,3,0,1]")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+__device__ __forceinline__ void quad_sum6(float &a, float &b, float &c, float &d, float &e, float &f)
+{
+    asm volatile("s_nop 1\n" OSK_QADD(0, "[1,0,3,2]") OSK_QADD(1, "[1,0,3,2]") OSK_QADD(2, "[1,0,3,2]") OSK_QADD(3, "[1,0,3,2]")
+                 OSK_QADD(4, "[1,0,3,2]") OSK_QADD(5, "[1,0,3,2]") OSK_QADD(0, "[2,3,0,1]") OSK_QADD(1, "[2,3,0,1]")
+                 OSK_QADD(2, "[2,3,0,1]") OSK_QADD(3, "[2,3,0,1]") OSK_QADD(4, "[2,3,0,1]") OSK_QADD(5, "[2,3,0,1]")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+#undef OSK_QADD
 
 }  // namespace osk

@@ -509,16 +509,16 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     __shared__ __attribute__((aligned(16))) float stage_all[4][3][ROWS_STAGE];
     const uint32_t stage0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)stage_all[wv][0]);
     uint32_t st_cur = stage0, st_nxt = stage0 + 4u * ROWS_STAGE, st_nn = stage0 + 8u * ROWS_STAGE;
-    const uint32_t rd_lane = (uint32_t)grp * 48u;
-    // the lane's own IMU measurement: imu[r] on rows 0..2, imu[r - 3] on rows 6..8 (anything finite elsewhere: weight 0)
-    const uint32_t rd_imu = rd_lane + 768u + 4u * (uint32_t)(r < 3 ? r : (r >= 6 && r < 9) ? r - 3 : 0);
+    const RowsLane rd = rows_lane(grp, r, rr);
+    uint32_t sh8 = 8u * (uint32_t)(r & 3);                              // the lane's leg in the contact word
+    float rw0 = rr % 3 == 0 ? 1.f : 0.f, rw1 = rr % 3 == 1 ? 1.f : 0.f, rw2 = rr % 3 == 2 ? 1.f : 0.f;    // PROT: row rr % 3 of R
+    asm volatile("" : "+v"(sh8), "+v"(rw0), "+v"(rw1), "+v"(rw2));
     const RowsDma dma = rows_dma_setup(lane, first, a.B);
     const RowsSrc src = rows_src(a, rowB);
     // the plain variant issues exactly one store per step (x_out), so the wait below can leave step t + 1's five DMA loads and
     // the last two stores in flight (loads and stores retire in issue order): vmcnt(7).  With optional outputs the store
     // count is not a compile-time constant: wait for everything (one step of latency hiding instead of two).
     constexpr bool plain = !AUX && !FEAT && !PROT;
-    StepInP in;
     OS_TS_DECL
     // (the prologue's loads retire here: otherwise hipcc re-checks them with a dozen s_waitcnt in every iteration)
     __builtin_amdgcn_s_waitcnt(0x0070);
@@ -533,40 +533,70 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         else if (plain) __builtin_amdgcn_s_waitcnt(0x0f75);                 // vmcnt(5)
         else __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        float imu_lane;
+        RowsRaw in;
         {
-            RowsRaw raw;
-            rows_issue<FEAT>(st_cur + rd_lane, st_cur + rd_imu, raw);
+            rows_issue<FEAT, PROT>(st_cur, rd, in);
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
             rows_dma_request(src, (uint32_t)tn, dma, rowB, st_nn);
-            rows_fence<FEAT>(raw, in);
-            imu_lane = raw.il;
+            rows_fence<FEAT, PROT>(in);
             const uint32_t st_old = st_cur;
             st_cur = st_nxt; st_nxt = st_nn; st_nn = st_old;
         }
         OS_TS(1)                                        // wait + LDS reads + next request
-        // ---- everything of the step that every lane needs: both rotations, the odometry, the torque / force sums ----
+        // ---- both rotations (every lane), then ONE LEG per lane (leg = lane & 3) and quad sums over the legs ----
         const float th[3] = {row_bcast<0>(xr), row_bcast<1>(xr), row_bcast<2>(xr)};      // the prior attitude
-        f2 Rp[9], PW[2][3];
-        float z[NM], g[9], aw[3], fs[3], amax;
-        rotation2(th, in.imu, Rp);
-        measurement_p(in, Rp, z);                        // z[3], z[7..9] are used; the IMU entries come per lane (imu_lane)
+        const float im[3] = {in.i4[0], in.i4[1], in.i4[2]};
+        f2 Rp[9];
+        rotation2(th, im, Rp);
+        float R0[9], g[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R0[i] = Rp[i][0];
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) g[3 * i + q] = k.dt * Rp[3 * q + i][0];           // g[3 i + q] = dt R[q][i]
-        dynamics_rates_p(Rp, in, PW, k, aw, fs, amax);
-        const float zr = fmaf(z11, z[9], fmaf(z10, z[8], fmaf(z9, z[7], fmaf(z5, z[3], zi * imu_lane))));
+            for (int q = 0; q < 3; q++) g[3 * i + q] = k.dt * R0[3 * q + i];              // g[3 i + q] = dt R[q][i]
+        // get_odom (kalman_filter/kalman_filter.py:79-100): stance legs vote on v_xy and height, swing legs on v_z; selects,
+        // not 0/1 weights (a NaN in an entry the reference never reads must stay out)
+        const uint32_t cb = __builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, in.c), sh8, 8u);
+        const bool st = cb == 1u, sw = cb == 0u;
+        float sum_c = (float)cb, vx = st ? in.dxy[0] : 0.f, vy = st ? in.dxy[1] : 0.f, vz = sw ? in.dz : 0.f, hz = st ? in.pz : 0.f;
+        // next_state's input half (misc/force_controller.py:269-291): world-frame foot position, torque of the lane's leg
+        const float pw0 = fmaf(R0[2], in.pz, fmaf(R0[1], in.pxy[1], R0[0] * in.pxy[0]));
+        const float pw1 = fmaf(R0[5], in.pz, fmaf(R0[4], in.pxy[1], R0[3] * in.pxy[0]));
+        const float pw2 = fmaf(R0[8], in.pz, fmaf(R0[7], in.pxy[1], R0[6] * in.pxy[0]));
+        float tau0 = fmaf(-pw2, in.fxy[1], pw1 * in.fz), tau1 = fmaf(-pw0, in.fz, pw2 * in.fxy[0]), tau2 = fmaf(-pw1, in.fxy[0], pw0 * in.fxy[1]);
+        float fs0 = in.fxy[0], fs1 = in.fxy[1], fs2 = in.fz;
+        quad_sum5(sum_c, vx, vy, vz, hz);
+        quad_sum6(tau0, tau1, tau2, fs0, fs1, fs2);
+        // no stance leg -> odom = 0 (:97-98).  sum_c is 1, 2, 3 or 4 here: v_rcp_f32 (1 ulp) instead of an IEEE division
+        const float inv = (sum_c != 0.f) ? __builtin_amdgcn_rcpf(sum_c) : 0.f;
+        const float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
+        const float zh = -hz * inv;
+        const float zv0 = Rp[0][1] * bx + Rp[1][1] * by + Rp[2][1] * bz;                   // body velocity to world: the IMU rotation
+        const float zv1 = Rp[3][1] * bx + Rp[4][1] * by + Rp[5][1] * bz;
+        const float zv2 = Rp[6][1] * bx + Rp[7][1] * by + Rp[8][1] * bz;
+        const float zr = fmaf(z11, zv2, fmaf(z10, zv1, fmaf(z9, zv0, fmaf(z5, zh, zi * in.il))));
+        // body-frame torque, scaled by 1/I, back to world: I_hat^-1 = R diag(1/I) R^T (R orthogonal)
+        const float tb0 = (R0[0] * tau0 + R0[3] * tau1 + R0[6] * tau2) * k.inv_inertia[0];
+        const float tb1 = (R0[1] * tau0 + R0[4] * tau1 + R0[7] * tau2) * k.inv_inertia[1];
+        const float tb2 = (R0[2] * tau0 + R0[5] * tau1 + R0[8] * tau2) * k.inv_inertia[2];
+        const float aw0 = R0[0] * tb0 + R0[1] * tb1 + R0[2] * tb2;
+        const float aw1 = R0[3] * tb0 + R0[4] * tb1 + R0[5] * tb2;
+        const float aw2 = R0[6] * tb0 + R0[7] * tb1 + R0[8] * tb2;
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i++) amax = fmaxf(amax, fabsf(R0[i]));
         OS_TS(2)                                        // rotations + odometry + torque / force sums
         // ---- covariance predict, row-parallel: M = F_d P (rows: lane r needs rows 6..8 or row r + 6), then P' = M F_d^T + Q (local) ----
         const float cg0 = fmaf(e2, g[6], fmaf(e1, g[3], e0 * g[0]));
         const float cg1 = fmaf(e2, g[7], fmaf(e1, g[4], e0 * g[1]));
         const float cg2 = fmaf(e2, g[8], fmaf(e1, g[5], e0 * g[2]));
         float M[NS];
+        // (columns 0..5 of M are not multiplied again: Q goes in with the copy the multiply-adds need anyway)
 #pragma unroll
-        for (int j = 0; j < NS; j++) M[j] = Prow[j];
+        for (int j = 0; j < NS; j++) M[j] = j < 6 ? Prow[j] + qrow[j] : Prow[j];
         // this lane's component of next_state (misc/force_controller.py:269-291): the PRIOR state everywhere on the right
-        float xn = fmaf(wa0, aw[0], fmaf(wa1, aw[1], fmaf(wa2, aw[2], fmaf(wf0, fs[0], fmaf(wf1, fs[1], fmaf(wf2, fs[2], xr + wg))))));
+        float xn = fmaf(wa0, aw0, fmaf(wa1, aw1, fmaf(wa2, aw2, fmaf(wf0, fs0, fmaf(wf1, fs1, fmaf(wf2, fs2, xr + wg))))));
         asm volatile("s_nop 1");
         // four multiply-adds per column, issued column-interleaved: consecutive instructions never touch the same accumulator
 #pragma unroll
@@ -580,8 +610,8 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         fmac_shl<6>(xn, xr, cd);                                           // position += dt * the prior velocity
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8] + qrow[j];
-            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j] + qrow[3 + j];
+            Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8];
+            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j];
         }
 #pragma unroll
         for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
@@ -595,42 +625,25 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
             xn += (amax >= 0.9999995f) ? dth : 0.f;
         }
         OS_TS(3)                                        // covariance predict + this lane's component of next_state
-        // ---- optional outputs: element rr of a twelve-vector held as compile-time-indexed registers, as a chain of SELECTS on a
-        // running value.  (As nested ternaries hipcc built a tree of divergent branches and sank the computation of each
-        // component into its branch.)
-#define OS_PICK12(E)                                                                                             \
-    ({                                                                                                           \
-        float pick_ = E(0);                                                                                      \
-        pick_ = (rr == 1) ? E(1) : pick_; pick_ = (rr == 2) ? E(2) : pick_; pick_ = (rr == 3) ? E(3) : pick_;    \
-        pick_ = (rr == 4) ? E(4) : pick_; pick_ = (rr == 5) ? E(5) : pick_; pick_ = (rr == 6) ? E(6) : pick_;    \
-        pick_ = (rr == 7) ? E(7) : pick_; pick_ = (rr == 8) ? E(8) : pick_; pick_ = (rr == 9) ? E(9) : pick_;    \
-        pick_ = (rr == 10) ? E(10) : pick_; pick_ = (rr == 11) ? E(11) : pick_;                                  \
-        pick_;                                                                                                   \
-    })
-#define OS_LEGV(v, i) (v)[((i) / 3) >> 1][(i) % 3][((i) / 3) & 1]
-#define OS_EPW(i) OS_LEGV(PW, i)
-#define OS_EF(i) OS_LEGV(in.f, i)
-#define OS_EDP(i) OS_LEGV(in.dp, i)
-        if (PROT && a.p_rot_out && live && r < 12) a.p_rot_out[((size_t)t * 12 + r) * B + b] = OS_PICK12(OS_EPW);
+        // ---- optional outputs: the lane's own row of f / dp / imu came straight from the stage; its row of the rotated foot
+        // positions (leg rr / 3, component rr % 3) = row rr % 3 of R, picked by one-hot weights, times that leg's p ----
+        float pv = 0.f;
+        if (PROT) {
+            const float q0 = fmaf(rw2, R0[6], fmaf(rw1, R0[3], rw0 * R0[0])), q1 = fmaf(rw2, R0[7], fmaf(rw1, R0[4], rw0 * R0[1])),
+                        q2 = fmaf(rw2, R0[8], fmaf(rw1, R0[5], rw0 * R0[2]));
+            pv = fmaf(q2, in.qz, fmaf(q1, in.qxy[1], q0 * in.qxy[0]));
+        }
+        if (PROT && a.p_rot_out && live && r < 12) a.p_rot_out[((size_t)t * 12 + r) * B + b] = pv;
         if (FEAT && live && r < 12) {
-            const float fv = OS_PICK12(OS_EF), pv = OS_PICK12(OS_EPW), dv = OS_PICK12(OS_EDP);
             float *fo = a.feat_out + (size_t)t * a.feat_I * B + b;
             const float *mm = a.minmax;
             auto put = [&](int j, float v) { __builtin_nontemporal_store((v - mm[j]) / (mm[60 + j] - mm[j]), fo + (size_t)j * B); };
-            put(18 + r, fv); put(30 + r, pv); put(42 + r, dv);
+            put(18 + r, in.fr); put(30 + r, pv); put(42 + r, in.dr);
             if (r < 6) {
-                float iv = in.imu[0];
-#pragma unroll
-                for (int i = 1; i < 6; i++) iv = (r == i) ? in.imu[i] : iv;
-                put(54 + r, iv);
+                put(54 + r, in.ir);
                 put(12 + r, a.accel[((size_t)t * 6 + r) * B + b]);
             }
         }
-#undef OS_PICK12
-#undef OS_LEGV
-#undef OS_EPW
-#undef OS_EF
-#undef OS_EDP
         OS_TS(4)                                        // component selects, optional outputs
         // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
         asm volatile("s_nop 4");
