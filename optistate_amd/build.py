@@ -17,10 +17,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liboptistate_hip.so")
-SOURCES = ["capi.hip", "kf_kernels.hip", "kf_step.hip", "gru_kernels.hip", "fused_kernels.hip", "gru_train_kernels.hip", "vit_kernels.hip", "mpc_kernels.hip"]
+SOURCES = ["capi.hip", "kf_kernels.hip", "kf_rows_kernel.hip", "kf_step.hip", "gru_kernels.hip", "fused_kernels.hip", "gru_train_kernels.hip", "vit_kernels.hip", "mpc_kernels.hip"]
 HEADERS = ["kf_device.hpp", "kf_args.hpp", "gru_common.hpp", "launch.hpp", os.path.join("..", "..", "include", "optistate_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
+# per-file additions (the reason is in the file's header)
+EXTRA_FLAGS = {"kf_rows_kernel.hip": ["-fno-slp-vectorize"]}
+
+
+def _all_flags():
+    return " ".join(FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(EXTRA_FLAGS.items())])
 
 
 def source_id():
@@ -31,7 +37,7 @@ def source_id():
         h.update(os.path.basename(f).encode() + b"\0")
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(_all_flags().encode())
     return h.hexdigest()[:16]
 
 
@@ -71,7 +77,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + [f'-DOS_BUILD_ID="{bid}"', "-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + [f'-DOS_BUILD_ID="{bid}"', "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -88,7 +94,7 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(os.path.join(objdir, "flags.txt"), "w") as fh:
-        fh.write(" ".join(FLAGS))
+        fh.write(_all_flags())
     with open(stamp, "w") as fh:
         fh.write(bid)
     return LIB
@@ -96,7 +102,7 @@ def build(force=False, verbose=False):
 
 def _flags_changed(objdir):
     f = os.path.join(objdir, "flags.txt")
-    return not os.path.exists(f) or open(f).read() != " ".join(FLAGS)
+    return not os.path.exists(f) or open(f).read() != _all_flags()
 
 
 if __name__ == "__main__":

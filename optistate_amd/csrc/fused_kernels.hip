@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     f2 X[6];                       // the filter state as pairs (x[2i], x[2i+1])
     f2 U[NU];
     int status = 0;
-    bool bad = false;
+    float smin = 3.0e38f;                  // the smallest innovation variance of the run (status bit 0)
     {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         cov_predict_sym_blk<QDIAG>(U, g9, k.k);
         __builtin_amdgcn_sched_barrier(0);
         OSF_TS(3)                                        // covariance predict
-        bad |= update_sequential_sym(X, U, z, k.k);      // non-finite states stay non-finite: checked once after the loop
+        smin = fminf(smin, update_sequential_sym(X, U, z, k.k));      // non-finite states stay non-finite: checked once after the loop
         // (the twelve x_out stores of this step are issued inside the first MFMA pass below: a VMEM instruction costs ~16 issue
         // cycles here, free underneath the matrix pipe; X does not change until the next step's filter phase)
         feat6(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                ts_sum[1] / k.T, ts_sum[2] / k.T, ts_sum[3] / k.T, ts_sum[4] / k.T, ts_sum[5] / k.T, ts_sum[6] / k.T, ts_sum[7] / k.T);
 #endif
     // ---- final state, status, h_T for the head kernel ----
-    status |= (bad ? 1 : 0) | finite_status_p(X);
+    status |= singular_status(smin) | finite_status_p(X);
     if (live) {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
     f2 X[6];
     f2 U[NU];
     int status = 0;
-    bool bad = false;
+    float smin = 3.0e38f;                  // the smallest innovation variance of the run (status bit 0)
     {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         __builtin_amdgcn_sched_barrier(0);          // the inputs are in AGPRs now: the covariance work below starts with their registers free
         cov_predict_sym_blk<QDIAG>(U, g9, k.k);
         __builtin_amdgcn_sched_barrier(0);
-        bad |= update_sequential_sym(X, U, z, k.k);
+        smin = fminf(smin, update_sequential_sym(X, U, z, k.k));
         {
             // shadow lanes: an offset no descriptor covers (the range check drops the store) instead of a branch around the stores
             const uint32_t vst = live ? voff : 0x7ffffff0u;
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         }
     }
 
-    status |= (bad ? 1 : 0) | finite_status_p(X);
+    status |= singular_status(smin) | finite_status_p(X);
     if (live) {
         rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
 #pragma unroll

@@ -295,4 +295,7 @@ __device__ __forceinline__ void quad_sum6(float &a, float &b, float &c, float &d
 }
 #undef OSK_QADD
 
+// kf_rows_kernel.hip (its own translation unit: compile flags): picks kf_run_rows2_kernel's instantiation and launches it
+hipError_t launch_kf_rows2(const KfRunArgs &a, const float *qmat, bool feat, bool aux, hipStream_t s);
+
 }  // namespace osk

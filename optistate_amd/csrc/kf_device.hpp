@@ -685,12 +685,13 @@ __device__ __forceinline__ void cov_predict_sym_blk(f2 *U, const float *g, const
 // v_rcp_f32 is accurate to 1 ulp: the gain's relative error of ~1e-7 is that of any other float32 operation of the step.
 // Returns true when some S entry was not a positive finite number (status bit 0; nothing is patched up: the state of that
 // trajectory is then garbage or non-finite, which status bit 1 reports as well).
+// Returns the innovation variance S: the callers keep the smallest one of the whole run and test it once at the end (status
+// bit 0: not +normal / +denormal; a NaN S drops out of the minimum and turns the state into NaN, which the final check reports)
 template <int A>
-__device__ __forceinline__ bool update_one_sym(f2 *X, f2 *U, const float *z, const KfConst &k)
+__device__ __forceinline__ float update_one_sym(f2 *X, f2 *U, const float *z, const KfConst &k)
 {
     constexpr int sa = SEL[A];
     const float s = OSK_SYM(U, sa, sa) + k.R[A * NM + A];
-    const bool bad = !__builtin_amdgcn_classf(s, 0x180);          // not (+normal | +denormal)
     const float ninv = -__builtin_amdgcn_rcpf(s);
     const float ninnov = X[sa / 2][sa & 1] - z[A];
     f2 c[6], w[6];
@@ -704,16 +705,17 @@ __device__ __forceinline__ bool update_one_sym(f2 *X, f2 *U, const float *z, con
 #pragma unroll
         for (int jp = i / 2; jp < 6; jp++) U[pidx(i, jp)] = fma2(splat2(ci), w[jp], U[pidx(i, jp)]);
     }
-    return bad;
+    return s;
 }
-__device__ __forceinline__ bool update_sequential_sym(f2 *X, f2 *U, const float *z, const KfConst &k)
+__device__ __forceinline__ float update_sequential_sym(f2 *X, f2 *U, const float *z, const KfConst &k)      // -> the smallest S
 {
-    bool bad = update_one_sym<0>(X, U, z, k);
-    bad |= update_one_sym<1>(X, U, z, k); bad |= update_one_sym<2>(X, U, z, k); bad |= update_one_sym<3>(X, U, z, k);
-    bad |= update_one_sym<4>(X, U, z, k); bad |= update_one_sym<5>(X, U, z, k); bad |= update_one_sym<6>(X, U, z, k);
-    bad |= update_one_sym<7>(X, U, z, k); bad |= update_one_sym<8>(X, U, z, k); bad |= update_one_sym<9>(X, U, z, k);
-    return bad;
+    const float s0 = update_one_sym<0>(X, U, z, k), s1 = update_one_sym<1>(X, U, z, k), s2 = update_one_sym<2>(X, U, z, k);
+    const float s3 = update_one_sym<3>(X, U, z, k), s4 = update_one_sym<4>(X, U, z, k), s5 = update_one_sym<5>(X, U, z, k);
+    const float s6 = update_one_sym<6>(X, U, z, k), s7 = update_one_sym<7>(X, U, z, k), s8 = update_one_sym<8>(X, U, z, k);
+    const float s9 = update_one_sym<9>(X, U, z, k);
+    return fminf(fminf(fminf(fminf(s0, s1), s2), fminf(fminf(s3, s4), s5)), fminf(fminf(fminf(s6, s7), s8), s9));
 }
+__device__ __forceinline__ int singular_status(float smin) { return __builtin_amdgcn_classf(smin, 0x180) ? 0 : 1; }
 
 // ---- the part of a step that consumes its inputs, hand-packed: legs in pairs (0,1) and (2,3), the step's two rotations (prior
 // attitude | IMU attitude) side by side in one register pair.  hipcc's SLP vectoriser packs this code too, but pays for
@@ -740,8 +742,9 @@ __device__ __forceinline__ void rotation2(const float *xs, const float *im, f2 *
 {
     f2 s[3], c[3];
     // wave-uniform small-angle path as in rotation(): all six angles of every lane below pi/4
-    const bool big = !(fabsf(xs[0]) < 0.785f && fabsf(xs[1]) < 0.785f && fabsf(xs[2]) < 0.785f &&
-                       fabsf(im[0]) < 0.785f && fabsf(im[1]) < 0.785f && fabsf(im[2]) < 0.785f);       // NaN counts as big
+    // (two v_max3_f32 and one compare; a NaN angle drops out of the maximum and gives NaN on either path)
+    const float amax3 = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fabsf(xs[2])), imax3 = fmaxf(fmaxf(fabsf(im[0]), fabsf(im[1])), fabsf(im[2]));
+    const bool big = !(fmaxf(amax3, imax3) < 0.785f);
     if (__builtin_amdgcn_ballot_w64(big) == 0ull) {
 #pragma unroll
         for (int i = 0; i < 3; i++) sincos_small2((f2){xs[i], im[i]}, &s[i], &c[i]);

@@ -156,7 +156,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
     const int lane = threadIdx.x & 63;
     StepInP in;
     StepRaw raw;
-    bool bad = false;
+    float smin = 3.0e38f;                  // the smallest innovation variance of the run (status bit 0)
     load_step_dma(a, 0, vo4, rowB, stage[0]);
     if (PRE) {
         load_step_dma(a, a.T > 1 ? 1 : 0, vo4, rowB, stage[1]);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             lds_issue_step(stage[(t + 1) % 3], lane, raw);
         }
         OS_STS(4)                                       // optional outputs, LDS reads of the next step issued
-        bad |= update_sequential_sym(X, U, z, kc);            // non-finite states stay non-finite: checked once after the loop
+        smin = fminf(smin, update_sequential_sym(X, U, z, kc));            // non-finite states stay non-finite: checked once after the loop
         OS_STS(5)                                       // ten measurement updates
         {
             rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
                ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T, ts_sum[6] / a.T);
 #endif
 #undef OS_STS
-    if (live) a.status[b] = status | (bad ? 1 : 0) | finite_status_p(X);
+    if (live) a.status[b] = status | singular_status(smin) | finite_status_p(X);
 }
 
 template <int OUT, bool QDIAG, bool PRE = false>
@@ -436,281 +436,6 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// kf_run_rows2_kernel -- the same 16-lanes-per-trajectory layout with half the instructions (round 3).
-// The first version (above, kept behind OS_KF_ROWS_V1=1 for A/B runs) issues ~800 VALU instructions per dependent step at
-// exactly one wave per SIMD (B = 4096 trajectories = 1024 waves), i.e. its 1.97 us per step are instruction issue.  Here:
-//   * every row broadcast is FUSED into the multiply-add that consumes it: `v_fmac_f32_dpp acc, src row_newbcast:S, m` reads
-//     src from lane S of the 16-lane row inside the instruction, so a rank-1 update of a row is 12 instructions, not 12 moves +
-//     12 FMAs (hipcc keeps the DPP move separate and then pairs the FMAs: 18), and the covariance predict needs no
-//     ds_bpermute (row r + 6 arrives by `row_shl:6`);
-//   * the part every lane computes redundantly (rotations, odometry, next_state: ~350 instructions) is the hand-packed
-//     form of kf_device.hpp (legs in pairs, both rotations side by side: ~190);
-//   * class test instead of two compares and a select per measurement, no Newton step after v_rcp_f32 (as the lane kernels).
-// DPP hazards (inline asm is invisible to hipcc's hazard recogniser): a VALU result must be two instructions old before a
-// DPP operand reads it, an EXEC write five.  Within a chain every source was written at least twelve instructions
-// earlier; the blocks start behind hipcc's own (hazard-checked) DPP moves, and one s_nop 4 separates the update from
-// whatever branchy code precedes it.
-// ---------------------------------------------------------------------------------------------------------------
-template <int SRC>
-__device__ __forceinline__ void fmac_bcast(float &acc, float src, float m)     // acc += (src of lane SRC of this 16-lane row) * m
-{
-    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(SRC));
-}
-template <int N>
-__device__ __forceinline__ void fmac_shl(float &acc, float src, float m)       // acc += (src of lane + N, 0 past the row's end) * m
-{
-    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
-}
-
-template <bool AUX, bool FEAT, bool PROT>
-__global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
-{
-    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
-    const int first = (blockIdx.x * (blockDim.x >> 6) + wv) * 4;        // this wave's first trajectory
-    const int b_raw = first + grp;
-    const bool live = b_raw < a.B;
-    const int b = live ? b_raw : a.B - 1;
-    const int rr = r < 12 ? r : 11;                    // idle lanes 12-15 shadow row 11 (never broadcast from, never stored)
-    const size_t B = (size_t)a.B;
-    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
-    const KfConst &k = a.k;
-
-    float Prow[NS], qrow[NS], xr;
-    {
-        // (the row is per lane: in the VGPR offset -- as an SGPR offset hipcc wraps every load in a waterfall loop)
-        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
-        xr = buf_load(rx, voff + (uint32_t)rr * rowB, 0);
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            Prow[j] = buf_load(rP, voff + (uint32_t)(rr * NS + j) * rowB, 0);
-            qrow[j] = qmat[rr * NS + j];
-        }
-    }
-    bool bad = false;
-    // Per-lane constants (one-hot in the lane's row r, scaled): each lane integrates ITS component of next_state and holds ITS
-    // measurement, by multiply-adds with these weights instead of selects (a select chain costs an SGPR mask pair per
-    // comparison, and hipcc kept spilling SGPRs in this loop).  Opaque to the optimiser, or it rebuilds them from masks per step.
-    const KfConst &kk = a.k;
-    float e0 = r == 0 ? 1.f : 0.f, e1 = r == 1 ? 1.f : 0.f, e2 = r == 2 ? 1.f : 0.f;             // rows 0..2: theta
-    float cd = (r >= 3 && r < 6) ? kk.dt : 0.f;                                                  // rows 3..5: position += dt * velocity
-    float wa0 = r == 6 ? kk.dt : 0.f, wa1 = r == 7 ? kk.dt : 0.f, wa2 = r == 8 ? kk.dt : 0.f;    // rows 6..8: omega += dt * aw
-    float wf0 = r == 9 ? kk.dt * kk.inv_mass : 0.f, wf1 = r == 10 ? kk.dt * kk.inv_mass : 0.f, wf2 = rr == 11 ? kk.dt * kk.inv_mass : 0.f;
-    float wg = rr == 11 ? kk.dt * kk.gz : 0.f;                                                   // (rr: the idle lanes shadow row 11)
-    float zi = (r < 3 || (r >= 6 && r < 9)) ? 1.f : 0.f, z5 = r == 5 ? 1.f : 0.f;                // measurement held by the lane
-    float z9 = r == 9 ? 1.f : 0.f, z10 = r == 10 ? 1.f : 0.f, z11 = rr == 11 ? 1.f : 0.f;
-    asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(cd), "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wf0), "+v"(wf1), "+v"(wf2), "+v"(wg));
-    asm volatile("" : "+v"(zi), "+v"(z5), "+v"(z9), "+v"(z10), "+v"(z11));
-    float Rd[NM];                                      // diag R in registers: the DPP add that forms S = P[s][s] + R takes no SGPR
-#pragma unroll
-    for (int i = 0; i < NM; i++) { Rd[i] = kk.R[i * NM + i]; asm volatile("" : "+v"(Rd[i])); }
-    // step inputs: three LDS stages per wave, step t + 2 requested at the top of step t (rows_*: kf_args.hpp).  The stage
-    // addresses live in SGPRs and rotate; the descriptors are loop constants.
-    __shared__ __attribute__((aligned(16))) float stage_all[4][3][ROWS_STAGE];
-    const uint32_t stage0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)stage_all[wv][0]);
-    uint32_t st_cur = stage0, st_nxt = stage0 + 4u * ROWS_STAGE, st_nn = stage0 + 8u * ROWS_STAGE;
-    const RowsLane rd = rows_lane(grp, r, rr);
-    uint32_t sh8 = 8u * (uint32_t)(r & 3);                              // the lane's leg in the contact word
-    float rw0 = rr % 3 == 0 ? 1.f : 0.f, rw1 = rr % 3 == 1 ? 1.f : 0.f, rw2 = rr % 3 == 2 ? 1.f : 0.f;    // PROT: row rr % 3 of R
-    asm volatile("" : "+v"(sh8), "+v"(rw0), "+v"(rw1), "+v"(rw2));
-    const RowsDma dma = rows_dma_setup(lane, first, a.B);
-    const RowsSrc src = rows_src(a, rowB);
-    // the plain variant issues exactly one store per step (x_out), so the wait below can leave step t + 1's five DMA loads and
-    // the last two stores in flight (loads and stores retire in issue order): vmcnt(7).  With optional outputs the store
-    // count is not a compile-time constant: wait for everything (one step of latency hiding instead of two).
-    constexpr bool plain = !AUX && !FEAT && !PROT;
-    OS_TS_DECL
-    // (the prologue's loads retire here: otherwise hipcc re-checks them with a dozen s_waitcnt in every iteration)
-    __builtin_amdgcn_s_waitcnt(0x0070);
-#pragma unroll
-    for (int j = 0; j < NS; j++) asm volatile("" : "+v"(qrow[j]), "+v"(Prow[j]));
-    rows_dma_request(src, 0, dma, rowB, st_cur);
-    rows_dma_request(src, a.T > 1 ? 1 : 0, dma, rowB, st_nxt);
-    for (int t = 0; t < a.T; t++) {
-        OS_TS(0)
-        // issued after DMA(t): t = 0: DMA(1); t = 1: DMA(2), store(0); t >= 2: store(t-2), DMA(t+1), store(t-1)
-        if (plain && t > 1) __builtin_amdgcn_s_waitcnt(0x0f77);            // vmcnt(7), nothing else waited for
-        else if (plain) __builtin_amdgcn_s_waitcnt(0x0f75);                 // vmcnt(5)
-        else __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        RowsRaw in;
-        {
-            rows_issue<FEAT, PROT>(st_cur, rd, in);
-            const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
-            rows_dma_request(src, (uint32_t)tn, dma, rowB, st_nn);
-            rows_fence<FEAT, PROT>(in);
-            const uint32_t st_old = st_cur;
-            st_cur = st_nxt; st_nxt = st_nn; st_nn = st_old;
-        }
-        OS_TS(1)                                        // wait + LDS reads + next request
-        // ---- both rotations (every lane), then ONE LEG per lane (leg = lane & 3) and quad sums over the legs ----
-        const float th[3] = {row_bcast<0>(xr), row_bcast<1>(xr), row_bcast<2>(xr)};      // the prior attitude
-        const float im[3] = {in.i4[0], in.i4[1], in.i4[2]};
-        f2 Rp[9];
-        rotation2(th, im, Rp);
-        float R0[9], g[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) R0[i] = Rp[i][0];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) g[3 * i + q] = k.dt * R0[3 * q + i];              // g[3 i + q] = dt R[q][i]
-        // get_odom (kalman_filter/kalman_filter.py:79-100): stance legs vote on v_xy and height, swing legs on v_z; selects,
-        // not 0/1 weights (a NaN in an entry the reference never reads must stay out)
-        const uint32_t cb = __builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, in.c), sh8, 8u);
-        const bool st = cb == 1u, sw = cb == 0u;
-        float sum_c = (float)cb, vx = st ? in.dxy[0] : 0.f, vy = st ? in.dxy[1] : 0.f, vz = sw ? in.dz : 0.f, hz = st ? in.pz : 0.f;
-        // next_state's input half (misc/force_controller.py:269-291): world-frame foot position, torque of the lane's leg
-        const float pw0 = fmaf(R0[2], in.pz, fmaf(R0[1], in.pxy[1], R0[0] * in.pxy[0]));
-        const float pw1 = fmaf(R0[5], in.pz, fmaf(R0[4], in.pxy[1], R0[3] * in.pxy[0]));
-        const float pw2 = fmaf(R0[8], in.pz, fmaf(R0[7], in.pxy[1], R0[6] * in.pxy[0]));
-        float tau0 = fmaf(-pw2, in.fxy[1], pw1 * in.fz), tau1 = fmaf(-pw0, in.fz, pw2 * in.fxy[0]), tau2 = fmaf(-pw1, in.fxy[0], pw0 * in.fxy[1]);
-        float fs0 = in.fxy[0], fs1 = in.fxy[1], fs2 = in.fz;
-        quad_sum5(sum_c, vx, vy, vz, hz);
-        quad_sum6(tau0, tau1, tau2, fs0, fs1, fs2);
-        // no stance leg -> odom = 0 (:97-98).  sum_c is 1, 2, 3 or 4 here: v_rcp_f32 (1 ulp) instead of an IEEE division
-        const float inv = (sum_c != 0.f) ? __builtin_amdgcn_rcpf(sum_c) : 0.f;
-        const float bx = -vx * inv, by = -vy * inv, bz = -vz * inv;
-        const float zh = -hz * inv;
-        const float zv0 = Rp[0][1] * bx + Rp[1][1] * by + Rp[2][1] * bz;                   // body velocity to world: the IMU rotation
-        const float zv1 = Rp[3][1] * bx + Rp[4][1] * by + Rp[5][1] * bz;
-        const float zv2 = Rp[6][1] * bx + Rp[7][1] * by + Rp[8][1] * bz;
-        const float zr = fmaf(z11, zv2, fmaf(z10, zv1, fmaf(z9, zv0, fmaf(z5, zh, zi * in.il))));
-        // body-frame torque, scaled by 1/I, back to world: I_hat^-1 = R diag(1/I) R^T (R orthogonal)
-        const float tb0 = (R0[0] * tau0 + R0[3] * tau1 + R0[6] * tau2) * k.inv_inertia[0];
-        const float tb1 = (R0[1] * tau0 + R0[4] * tau1 + R0[7] * tau2) * k.inv_inertia[1];
-        const float tb2 = (R0[2] * tau0 + R0[5] * tau1 + R0[8] * tau2) * k.inv_inertia[2];
-        const float aw0 = R0[0] * tb0 + R0[1] * tb1 + R0[2] * tb2;
-        const float aw1 = R0[3] * tb0 + R0[4] * tb1 + R0[5] * tb2;
-        const float aw2 = R0[6] * tb0 + R0[7] * tb1 + R0[8] * tb2;
-        float amax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 9; i++) amax = fmaxf(amax, fabsf(R0[i]));
-        OS_TS(2)                                        // rotations + odometry + torque / force sums
-        // ---- covariance predict, row-parallel: M = F_d P (rows: lane r needs rows 6..8 or row r + 6), then P' = M F_d^T + Q (local) ----
-        const float cg0 = fmaf(e2, g[6], fmaf(e1, g[3], e0 * g[0]));
-        const float cg1 = fmaf(e2, g[7], fmaf(e1, g[4], e0 * g[1]));
-        const float cg2 = fmaf(e2, g[8], fmaf(e1, g[5], e0 * g[2]));
-        float M[NS];
-        // (columns 0..5 of M are not multiplied again: Q goes in with the copy the multiply-adds need anyway)
-#pragma unroll
-        for (int j = 0; j < NS; j++) M[j] = j < 6 ? Prow[j] + qrow[j] : Prow[j];
-        // this lane's component of next_state (misc/force_controller.py:269-291): the PRIOR state everywhere on the right
-        float xn = fmaf(wa0, aw0, fmaf(wa1, aw1, fmaf(wa2, aw2, fmaf(wf0, fs0, fmaf(wf1, fs1, fmaf(wf2, fs2, xr + wg))))));
-        asm volatile("s_nop 1");
-        // four multiply-adds per column, issued column-interleaved: consecutive instructions never touch the same accumulator
-#pragma unroll
-        for (int j = 0; j < NS; j++) fmac_bcast<6>(M[j], Prow[j], cg0);
-#pragma unroll
-        for (int j = 0; j < NS; j++) fmac_bcast<7>(M[j], Prow[j], cg1);
-#pragma unroll
-        for (int j = 0; j < NS; j++) fmac_bcast<8>(M[j], Prow[j], cg2);
-#pragma unroll
-        for (int j = 0; j < NS; j++) fmac_shl<6>(M[j], Prow[j], cd);       // row r + 6 (rows 9..11 for lanes 3..5)
-        fmac_shl<6>(xn, xr, cd);                                           // position += dt * the prior velocity
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8];
-            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j];
-        }
-#pragma unroll
-        for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
-        // theta += dt trunc(R^T) omega: zero unless an entry of R reaches +-1 in float64 (see trunc_block_f64)
-        if (__builtin_amdgcn_ballot_w64(amax >= 0.9999995f) != 0ull) {
-            float A[9];
-            trunc_block_f64(th[0], th[1], th[2], A);
-            const float w0 = row_bcast<6>(xr), w1 = row_bcast<7>(xr), w2 = row_bcast<8>(xr);
-            const float d0 = A[0] * w0 + A[1] * w1 + A[2] * w2, d1 = A[3] * w0 + A[4] * w1 + A[5] * w2, d2 = A[6] * w0 + A[7] * w1 + A[8] * w2;
-            const float dth = k.dt * (r == 0 ? d0 : r == 1 ? d1 : r == 2 ? d2 : 0.f);
-            xn += (amax >= 0.9999995f) ? dth : 0.f;
-        }
-        OS_TS(3)                                        // covariance predict + this lane's component of next_state
-        // ---- optional outputs: the lane's own row of f / dp / imu came straight from the stage; its row of the rotated foot
-        // positions (leg rr / 3, component rr % 3) = row rr % 3 of R, picked by one-hot weights, times that leg's p ----
-        float pv = 0.f;
-        if (PROT) {
-            const float q0 = fmaf(rw2, R0[6], fmaf(rw1, R0[3], rw0 * R0[0])), q1 = fmaf(rw2, R0[7], fmaf(rw1, R0[4], rw0 * R0[1])),
-                        q2 = fmaf(rw2, R0[8], fmaf(rw1, R0[5], rw0 * R0[2]));
-            pv = fmaf(q2, in.qz, fmaf(q1, in.qxy[1], q0 * in.qxy[0]));
-        }
-        if (PROT && a.p_rot_out && live && r < 12) a.p_rot_out[((size_t)t * 12 + r) * B + b] = pv;
-        if (FEAT && live && r < 12) {
-            float *fo = a.feat_out + (size_t)t * a.feat_I * B + b;
-            const float *mm = a.minmax;
-            auto put = [&](int j, float v) { __builtin_nontemporal_store((v - mm[j]) / (mm[60 + j] - mm[j]), fo + (size_t)j * B); };
-            put(18 + r, in.fr); put(30 + r, pv); put(42 + r, in.dr);
-            if (r < 6) {
-                put(54 + r, in.ir);
-                put(12 + r, a.accel[((size_t)t * 6 + r) * B + b]);
-            }
-        }
-        OS_TS(4)                                        // component selects, optional outputs
-        // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
-        asm volatile("s_nop 4");
-        // The column the NEXT measurement reads (SN) is updated first, so that its scalar chain (row broadcast -> add -> class
-        // test -> v_rcp_f32 -> gain) starts while this measurement's other eleven multiply-adds are still issuing.
-#define OS_ROW_FMAC(S, J, SN) if (J != SN) fmac_bcast<S>(Prow[J], Prow[J], nkc);
-#define OS_ROW_SADD(AN, SN)                                                                           \
-        asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" \
-                     : "=v"(sv) : "v"(Prow[SN]), "v"(Rd[AN]), "n"(SN));
-        // The innovation of measurement A sits in lane S (= the lane's state component minus the lane's measurement, taken when
-        // the previous update of xn is done and twelve instructions before its DPP read: in assembly so that it stays there).
-        // S = P[s][s] + R[a][a] of the NEXT measurement (column SN, row SN) by one DPP add, two instructions behind the
-        // multiply-add that finishes P[.][SN], so that its chain (class test, v_rcp_f32, gain) runs under this measurement's
-        // other multiply-adds.
-#define OS_ROW_UPDATE2(A, S, SN, AN)                                                                  \
-        {                                                                                             \
-            float dz;                                                                                 \
-            bad |= !__builtin_amdgcn_classf(sv, 0x180);                                               \
-            const float nkc = -Prow[S] * __builtin_amdgcn_rcpf(sv);                                   \
-            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(xn), "v"(zr));                       \
-            fmac_bcast<S>(Prow[SN], Prow[SN], nkc);                                                   \
-            OS_ROW_FMAC(S, 0, SN) OS_ROW_FMAC(S, 1, SN) OS_ROW_FMAC(S, 2, SN)                         \
-            if (AN < NM) { OS_ROW_SADD(AN, SN) }                                                      \
-            OS_ROW_FMAC(S, 3, SN)                                                                     \
-            OS_ROW_FMAC(S, 4, SN) OS_ROW_FMAC(S, 5, SN) OS_ROW_FMAC(S, 6, SN) OS_ROW_FMAC(S, 7, SN)   \
-            OS_ROW_FMAC(S, 8, SN) OS_ROW_FMAC(S, 9, SN) OS_ROW_FMAC(S, 10, SN) OS_ROW_FMAC(S, 11, SN) \
-            fmac_bcast<S>(xn, dz, nkc);                                                               \
-        }
-        float sv;
-        OS_ROW_SADD(0, 0)
-        OS_ROW_UPDATE2(0, 0, 1, 1) OS_ROW_UPDATE2(1, 1, 2, 2) OS_ROW_UPDATE2(2, 2, 5, 3) OS_ROW_UPDATE2(3, 5, 6, 4)
-        OS_ROW_UPDATE2(4, 6, 7, 5) OS_ROW_UPDATE2(5, 7, 8, 6) OS_ROW_UPDATE2(6, 8, 9, 7) OS_ROW_UPDATE2(7, 9, 10, 8)
-        OS_ROW_UPDATE2(8, 10, 11, 9) OS_ROW_UPDATE2(9, 11, 0, 10)
-#undef OS_ROW_SADD
-#undef OS_ROW_FMAC
-#undef OS_ROW_UPDATE2
-        xr = xn;
-        OS_TS(5)                                        // ten measurement updates
-        if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
-        if (FEAT && live && r < 12)
-            __builtin_nontemporal_store((xr - a.minmax[r]) / (a.minmax[60 + r] - a.minmax[r]), a.feat_out + ((size_t)t * a.feat_I + r) * B + b);
-        if (AUX && a.ptrace_out) {
-            float dg = Prow[0];
-#pragma unroll
-            for (int i = 1; i < NS; i++) dg = (r == i) ? Prow[i] : dg;
-            dg = r < 12 ? dg : 0.f;
-            dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
-            if (live && r == 0) a.ptrace_out[(size_t)t * B + b] = dg;
-        }
-    }
-#ifdef OS_ROWS_TS
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.kgain_out) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.kgain_out);
-        for (int i = 0; i < 8; i++) o[i] = ts_sum[i];
-    }
-#endif
-    // ---- final state: lane r writes x[r] and row r of P; the status word is OR-reduced over the 16 lanes ----
-    int status = (bad ? 1 : 0) | ((xr * 0.f == 0.f) ? 0 : 2);
-    status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
-    status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
-    if (live && r < 12) {
-        a.x[(size_t)r * B + b] = xr;
-#pragma unroll
-        for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = Prow[j];
-        if (r == 0) a.status[b] = status;
-    }
-}
 
 // ---- single pieces for the drop-in Kalman_Filter class (B is tiny there; latency-bound by design) ----
 
@@ -894,11 +619,8 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
             if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
             else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
             else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        } else if (feat) hipLaunchKernelGGL((kf_run_rows2_kernel<false, true, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else if (aux) hipLaunchKernelGGL((kf_run_rows2_kernel<true, false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else if (a.p_rot_out) hipLaunchKernelGGL((kf_run_rows2_kernel<false, false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        else hipLaunchKernelGGL((kf_run_rows2_kernel<false, false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-        e = hipGetLastError();
+            e = hipGetLastError();
+        } else e = launch_kf_rows2(a, (const float *)ctx->kf_qr, feat, aux, s);
     } else if (use_sym) {
         dim3 grid((a.B + 63) / 64), block(64);
         const bool qd = ctx->q_is_diagonal;
