@@ -69,8 +69,8 @@ __device__ __forceinline__ void lds_dma16(rsrc_t r, float *l, uint32_t voff, uin
 }
 __device__ __forceinline__ void load_step_dma(const KfRunArgs &a, int t, uint32_t vo4, uint32_t rowB, float *lds /* [48][64] */)
 {
-    // The range check of a raw buffer access covers the VGPR offset only (not the SGPR offset), so every access here carries
-    // its whole offset in the VGPR and each descriptor spans exactly the rows it may touch: a lane whose trajectories lie past
+    // Every access here carries its whole offset in the VGPR and each descriptor spans exactly the rows it may touch, so the
+    // range check sees the complete offset whatever the hardware does with an SGPR part: a lane whose trajectories lie past
     // the end of the batch reads the next row (harmless) or, in the last row, nothing (zeros) -- never past the allocation.
     const size_t B = (size_t)a.B;
     const uint32_t vo[3] = {vo4, vo4 + 4u * rowB, vo4 + 8u * rowB};
