@@ -40,7 +40,9 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
     for (int i = 0; i < 10; i++) c->k.R[i * 10 + i] = 0.01f;
     c->r_is_diagonal = true;
     c->q_is_diagonal = true;
-    c->rows_kernel_below = 10240;   // measured crossover with the lane-per-trajectory kernels: ~10 k trajectories
+    // measured (tools/rows_crossover.py, round 3): the rows kernel holds 2,048 waves = 8,192 trajectories at two waves per SIMD
+    // (4.35e9 steps/s there; lane kernel 3.67e9) and needs a second, half-empty round beyond that (10,240: 3.3e9 against 4.6e9)
+    c->rows_kernel_below = 8193;
     {
         const char *e = getenv("OS_KF_ROWS_BELOW");      // tuning knobs (development): read once, here
         if (e) c->rows_kernel_below = atoi(e);

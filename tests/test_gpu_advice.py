@@ -147,7 +147,7 @@ def test_kernel_name_reports_the_variant_that_ran():
     P = torch.as_tensor(np.tile(Q_DEFAULT.astype(np.float32).reshape(144, 1), (1, 256))).cuda()
     eng.profile(True)
     eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone())
-    assert eng.kernel_name("kf") == "kf_run_rows2_kernel"               # B = 256 < 10,240: 16 lanes per trajectory
+    assert eng.kernel_name("kf") == "kf_run_rows2_kernel"               # B = 256 <= 8,192: 16 lanes per trajectory
     eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone(), sequential=False)
     assert eng.kernel_name("kf") == "kf_run_kernel<BATCH>"
     pr = eng.profile_read()

@@ -172,7 +172,7 @@ def test_config2_kf_4096x1000_oracle_sample_and_slice_independence():
     torch.cuda.synchronize()
     assert eng.kernel_name("kf") == "kf_run_rows2_kernel"
     assert int((full["status"] != 0).sum()) == 0 and torch.isfinite(full["x_out"]).all()
-    # a contiguous slice alone reproduces the full run bit for bit (same kernel: B < 10,240)
+    # a contiguous slice alone reproduces the full run bit for bit (same kernel: B <= 8,192)
     idx = torch.arange(1024, 1024 + 512, device="cuda")
     sl = lambda k: d[k][:, :, idx].contiguous()
     xs, Ps = d["x0"][:, idx].contiguous(), d["P0"][:, idx].contiguous()
@@ -192,6 +192,27 @@ def test_config2_kf_4096x1000_oracle_sample_and_slice_independence():
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[3]: the gru_train.py step at 8192 windows x 10, RNN(188,128,4,24), forward + backward
 # ------------------------------------------------------------------------------------------------------------------
+def test_small_batch_kernel_steps_aside_when_the_streams_outgrow_its_32_bit_offsets():
+    """kf_run_rows2_kernel carries a step's position in a 32-bit buffer offset (T * 48 B bytes): beyond that the dispatcher must
+    take the lane-per-trajectory kernel (per-step descriptors), and a causal filter's first steps must not depend on which."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    eng = Engine(0); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    Bs, Tl, Ts = 8000, 11200, 200                      # 8000 <= the rows/lane switch; 11200 * 48 * 8000 = 4.30e9 >= 2^32
+    assert Tl * 48 * Bs >= 2 ** 32 and Ts * 48 * Bs < 2 ** 32
+    d = synth_torch(Bs, Tl, "cuda", seed=41)
+    cp = eng.contact_soa_to_packed(d["contact"])
+    x, P = d["x0"].clone(), d["P0"].clone()
+    r = eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], cp, x, P)
+    assert eng.kernel_name("kf") == "kf_run_sym_kernel"
+    assert int(r["status"].abs().sum()) == 0 and bool(torch.isfinite(r["x_out"][-1]).all())
+    x2, P2 = d["x0"].clone(), d["P0"].clone()
+    r2 = eng.kf_run(d["p"][:Ts].contiguous(), d["f"][:Ts].contiguous(), d["dp"][:Ts].contiguous(), d["imu"][:Ts].contiguous(),
+                    cp[:Ts].contiguous(), x2, P2)
+    assert eng.kernel_name("kf") == "kf_run_rows2_kernel"
+    assert float((r["x_out"][:Ts] - r2["x_out"]).abs().max()) < 5e-5          # two kernels, same filter (cross-kernel bar)
+
+
 def test_config4_train_step_8192_windows_vs_float64_autograd():
     from optistate_amd import RNN
     from test_gpu_train import torch_reference_grads
