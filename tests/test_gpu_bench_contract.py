@@ -60,7 +60,7 @@ def _has_roofline_and_baseline(d):
 def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
     k = _run(["--mode", "kf", "--batch", "4096", "--seq", "50", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
     _has_roofline_and_baseline(k)
-    assert k["roofline"]["kernel"] == "kf_run_rows2_kernel" and "latency" in k["roofline"]["limiter"]     # the kernel that RAN
+    assert k["roofline"]["kernel"] == "kf_run_rows2_kernel" and "instruction issue" in k["roofline"]["limiter"]     # the kernel that RAN
     assert k["parity"]["state_linf"] < 1e-4 and "gru_linf" not in k["parity"]
     d = _run(["--mode", "train", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"])
     _has_roofline_and_baseline(d)
