@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         for (int j = 0; j < NS; j++) M[j] = j < 6 ? Prow[j] + qrow[j] : Prow[j];
         // this lane's component of next_state (misc/force_controller.py:269-291): the PRIOR state everywhere on the right
         float xn = fmaf(wa0, aw0, fmaf(wa1, aw1, fmaf(wa2, aw2, fmaf(wf0, fs0, fmaf(wf1, fs1, fmaf(wf2, fs2, xr + wg))))));
-        asm volatile("s_nop 1");
+        asm volatile("s_nop 1" : "+v"(xr), "+v"(Prow[0]), "+v"(Prow[1]), "+v"(Prow[2]), "+v"(Prow[3]), "+v"(Prow[4]), "+v"(Prow[5]), "+v"(Prow[6]),
+                                 "+v"(Prow[7]), "+v"(Prow[8]), "+v"(Prow[9]), "+v"(Prow[10]), "+v"(Prow[11]));
         // four multiply-adds per column, issued column-interleaved: consecutive instructions never touch the same accumulator
 #pragma unroll
         for (int j = 0; j < NS; j++) fmac_bcast<6>(M[j], Prow[j], cg0);
@@ -242,7 +243,9 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         OS_TS(4)                                        // component selects, optional outputs
         // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
         float en = xn - zr;
-        asm volatile("s_nop 4" : "+v"(en));
+        // (the operands pin every producer of the chains' DPP sources in FRONT of the nop)
+        asm volatile("s_nop 4" : "+v"(en), "+v"(Prow[0]), "+v"(Prow[1]), "+v"(Prow[2]), "+v"(Prow[3]), "+v"(Prow[4]), "+v"(Prow[5]), "+v"(Prow[6]),
+                                 "+v"(Prow[7]), "+v"(Prow[8]), "+v"(Prow[9]), "+v"(Prow[10]), "+v"(Prow[11]));
         // The column the NEXT measurement reads (SN) is updated first, so that its scalar chain (row broadcast -> add -> class
         // test -> v_rcp_f32 -> gain) starts while this measurement's other eleven multiply-adds are still issuing.
 #define OS_ROW_FMAC(S, J, SN) if (J != SN) fmac_bcast<S>(Prow[J], Prow[J], nkc);

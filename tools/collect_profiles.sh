@@ -43,4 +43,7 @@ python3 bench.py --mode mpc --batch 8 --seq 4000 --steps 3 --cpu-seconds 0 > $O/
 bash tools/pmc_pass.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY" > $O/pmc_sq.txt 2>&1
 bash tools/pmc_pass.sh ${TAG}_grbm "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES" > $O/pmc_grbm.txt 2>&1
 python3 tools/ab_fused.py 6 > $O/ab_fused.txt 2>&1
+
+bash tools/rows_ts.sh > $O/rows2_timestamps_raw.txt 2>&1
+python3 tools/rows_crossover.py 2>/dev/null | grep -v "^RCCL" > $O/rows_crossover.txt
 ls $O
