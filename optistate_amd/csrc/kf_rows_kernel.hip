@@ -185,32 +185,31 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         const float cg0 = fmaf(e2, R0[2], fmaf(e1, R0[1], e0 * R0[0]));
         const float cg1 = fmaf(e2, R0[5], fmaf(e1, R0[4], e0 * R0[3]));
         const float cg2 = fmaf(e2, R0[8], fmaf(e1, R0[7], e0 * R0[6]));
-        float M[NS];
-        // (columns 0..5 of M are not multiplied again: Q goes in with the copy the multiply-adds need anyway)
-#pragma unroll
-        for (int j = 0; j < NS; j++) M[j] = j < 6 ? Prow[j] + qrow[j] : Prow[j];
         // this lane's component of next_state (misc/force_controller.py:269-291): the PRIOR state everywhere on the right
         float xn = fmaf(wa0, aw0, fmaf(wa1, aw1, fmaf(wa2, aw2, fmaf(wf0, fs0, fmaf(wf1, fs1, fmaf(wf2, fs2, xr + wg))))));
         asm volatile("s_nop 1" : "+v"(xr), "+v"(Prow[0]), "+v"(Prow[1]), "+v"(Prow[2]), "+v"(Prow[3]), "+v"(Prow[4]), "+v"(Prow[5]), "+v"(Prow[6]),
                                  "+v"(Prow[7]), "+v"(Prow[8]), "+v"(Prow[9]), "+v"(Prow[10]), "+v"(Prow[11]));
-        // four multiply-adds per column, issued column-interleaved: consecutive instructions never touch the same accumulator
+        // IN PLACE: the rows the DPP operands come from (6..11) carry zero coefficients (cg, cd are zero there), so they stay what
+        // they were while rows 0..5 accumulate -- no copy of the row.  Four multiply-adds per column, issued column-interleaved:
+        // consecutive instructions never touch the same accumulator.
 #pragma unroll
-        for (int j = 0; j < NS; j++) fmac_bcast<6>(M[j], Prow[j], cg0);
+        for (int j = 0; j < NS; j++) fmac_bcast<6>(Prow[j], Prow[j], cg0);
 #pragma unroll
-        for (int j = 0; j < NS; j++) fmac_bcast<7>(M[j], Prow[j], cg1);
+        for (int j = 0; j < NS; j++) fmac_bcast<7>(Prow[j], Prow[j], cg1);
 #pragma unroll
-        for (int j = 0; j < NS; j++) fmac_bcast<8>(M[j], Prow[j], cg2);
+        for (int j = 0; j < NS; j++) fmac_bcast<8>(Prow[j], Prow[j], cg2);
 #pragma unroll
-        for (int j = 0; j < NS; j++) fmac_shl<6>(M[j], Prow[j], cd);       // row r + 6 (rows 9..11 for lanes 3..5)
+        for (int j = 0; j < NS; j++) fmac_shl<6>(Prow[j], Prow[j], cd);    // row r + 6 (rows 9..11 for lanes 3..5)
         fmac_shl<6>(xn, xr, cd);                                           // position += dt * the prior velocity
-        const float md0 = k.dt * M[6], md1 = k.dt * M[7], md2 = k.dt * M[8];
+        // columns: P' = (F_d P) F_d^T + Q with this lane's row of F_d P now in Prow
+        const float md0 = k.dt * Prow[6], md1 = k.dt * Prow[7], md2 = k.dt * Prow[8];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            Prow[j] = fmaf(R0[6 + j], md2, fmaf(R0[3 + j], md1, fmaf(R0[j], md0, M[j])));       // += dt (M[:, 6:9] R)[j]
-            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j];
+            Prow[j] = fmaf(R0[6 + j], md2, fmaf(R0[3 + j], md1, fmaf(R0[j], md0, Prow[j] + qrow[j])));     // += dt (M[:, 6:9] R)[j]
+            Prow[3 + j] = fmaf(k.dt, Prow[9 + j], Prow[3 + j] + qrow[3 + j]);
         }
 #pragma unroll
-        for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
+        for (int j = 6; j < NS; j++) Prow[j] += qrow[j];
         // theta += dt trunc(R^T) omega: zero unless an entry of R reaches +-1 in float64 (see trunc_block_f64)
         if (__builtin_amdgcn_ballot_w64(amax >= 0.9999995f) != 0ull) {
             float A[9];
@@ -243,41 +242,18 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         OS_TS(4)                                        // component selects, optional outputs
         // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
         float en = xn - zr;
-        // (the operands pin every producer of the chains' DPP sources in FRONT of the nop)
-        asm volatile("s_nop 4" : "+v"(en), "+v"(Prow[0]), "+v"(Prow[1]), "+v"(Prow[2]), "+v"(Prow[3]), "+v"(Prow[4]), "+v"(Prow[5]), "+v"(Prow[6]),
-                                 "+v"(Prow[7]), "+v"(Prow[8]), "+v"(Prow[9]), "+v"(Prow[10]), "+v"(Prow[11]));
-        // The column the NEXT measurement reads (SN) is updated first, so that its scalar chain (row broadcast -> add -> class
-        // test -> v_rcp_f32 -> gain) starts while this measurement's other eleven multiply-adds are still issuing.
-#define OS_ROW_FMAC(S, J, SN) if (J != SN) fmac_bcast<S>(Prow[J], Prow[J], nkc);
-#define OS_ROW_SADD(AN, SN)                                                                           \
-        asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" \
-                     : "=v"(sv) : "v"(Prow[SN]), "v"(Rd[AN]), "n"(SN));
         // The filter runs on e = x - z_lane (the lane's state component minus the lane's measurement, z constant within the
         // step): the innovation of measurement A is e of lane S, and the state update is one more multiply-add of the chain,
         // e += e[S] * (-K) -- the last one, so that its DPP operand is thirteen instructions old.  x = e + z afterwards.
-        // S = P[s][s] + R[a][a] of the NEXT measurement (column SN, row SN) by one DPP add, two instructions behind the
-        // multiply-add that finishes P[.][SN], so that its chain (v_rcp_f32, gain) runs under this measurement's other
-        // multiply-adds.  The smallest S of the whole run is tested once at the end (status bit 0).
-#define OS_ROW_UPDATE2(A, S, SN, AN)                                                                  \
-        {                                                                                             \
-            svmin = fminf(svmin, sv);                                                                 \
-            const float nkc = -Prow[S] * __builtin_amdgcn_rcpf(sv);                                   \
-            fmac_bcast<S>(Prow[SN], Prow[SN], nkc);                                                   \
-            OS_ROW_FMAC(S, 0, SN) OS_ROW_FMAC(S, 1, SN) OS_ROW_FMAC(S, 2, SN)                         \
-            if (AN < NM) { OS_ROW_SADD(AN, SN) }                                                      \
-            OS_ROW_FMAC(S, 3, SN)                                                                     \
-            OS_ROW_FMAC(S, 4, SN) OS_ROW_FMAC(S, 5, SN) OS_ROW_FMAC(S, 6, SN) OS_ROW_FMAC(S, 7, SN)   \
-            OS_ROW_FMAC(S, 8, SN) OS_ROW_FMAC(S, 9, SN) OS_ROW_FMAC(S, 10, SN) OS_ROW_FMAC(S, 11, SN) \
-            fmac_bcast<S>(en, en, nkc);                                                               \
-        }
-        float sv;
-        OS_ROW_SADD(0, 0)
-        OS_ROW_UPDATE2(0, 0, 1, 1) OS_ROW_UPDATE2(1, 1, 2, 2) OS_ROW_UPDATE2(2, 2, 5, 3) OS_ROW_UPDATE2(3, 5, 6, 4)
-        OS_ROW_UPDATE2(4, 6, 7, 5) OS_ROW_UPDATE2(5, 7, 8, 6) OS_ROW_UPDATE2(6, 8, 9, 7) OS_ROW_UPDATE2(7, 9, 10, 8)
-        OS_ROW_UPDATE2(8, 10, 11, 9) OS_ROW_UPDATE2(9, 11, 0, 10)
-#undef OS_ROW_SADD
-#undef OS_ROW_FMAC
-#undef OS_ROW_UPDATE2
+        // Ten inline-assembly blocks, generated (tools/gen_rows_chain.py -> kf_rows_chain.inc) so that the ORDER is ours: the
+        // column the NEXT measurement reads (SN) is updated first; two instructions later one DPP add forms its
+        // S = P[sn][sn] + R[a'][a'], v_rcp_f32 follows under the other multiply-adds, and the block ends with the next gain
+        // factor -P[.][sn] / S -- no instruction waits for its operand and hipcc has nothing to pad (it put an s_nop in front
+        // of each of its own instructions that read an assembly result: three per measurement).  The smallest S of the whole
+        // run is tested once at the end (status bit 0).  Hazards: a DPP source is at least two instructions old (P[.][sn]:
+        // written first, read by the add three later; everything else was written by the previous block), v_rcp_f32's
+        // result is read six or more instructions later, the prologue's s_nop 4 covers whatever hipcc scheduled in front.
+#include "kf_rows_chain.inc"
         xr = en + zr;
         OS_TS(5)                                        // ten measurement updates
         if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
