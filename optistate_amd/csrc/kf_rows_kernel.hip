@@ -112,9 +112,9 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     asm volatile("" : "+v"(sh8), "+v"(rw0), "+v"(rw1), "+v"(rw2));
     const RowsDma dma = rows_dma_setup(lane, first, a.B);
     const RowsSrc src = rows_src(a, rowB);
-    // the plain variant issues exactly one store per step (x_out), so the wait below can leave step t + 1's five DMA loads and
-    // the last two stores in flight (loads and stores retire in issue order): vmcnt(7).  With optional outputs the store
-    // count is not a compile-time constant: wait for everything (one step of latency hiding instead of two).
+    // the plain variant issues exactly one store per step (x_out), so its waits can be counted (loads and stores retire in
+    // issue order).  With optional outputs the store count is not a compile-time constant: wait for everything at the top of a
+    // step (one step of latency hiding instead of two).
     constexpr bool plain = !AUX && !FEAT && !PROT;
     OS_TS_DECL
     // (the prologue's loads retire here: otherwise hipcc re-checks them with a dozen s_waitcnt in every iteration)
@@ -123,21 +123,32 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     for (int j = 0; j < NS; j++) asm volatile("" : "+v"(qrow[j]), "+v"(Prow[j]));
     rows_dma_request(src, 0, dma, rowB, st_cur);
     rows_dma_request(src, a.T > 1 ? 1 : 0, dma, rowB, st_nxt);
+    // Plain runs pick step t + 1's inputs up in the MIDDLE of step t (the reads complete underneath the measurement updates,
+    // the top of a step only takes the registers over): `nx` travels across the loop edge.
+    RowsRaw nx;
+    if (plain) {
+        __builtin_amdgcn_s_waitcnt(0x0f75);                                 // vmcnt(5): step 0 has landed, step 1's five loads may be in flight
+        __builtin_amdgcn_wave_barrier();
+        rows_issue<FEAT, PROT>(st_cur, rd, nx);
+    }
     for (int t = 0; t < a.T; t++) {
         OS_TS(0)
-        // issued after DMA(t): t = 0: DMA(1); t = 1: DMA(2), store(0); t >= 2: store(t-2), DMA(t+1), store(t-1)
-        if (plain && t > 1) __builtin_amdgcn_s_waitcnt(0x0f77);            // vmcnt(7), nothing else waited for
-        else if (plain) __builtin_amdgcn_s_waitcnt(0x0f75);                 // vmcnt(5)
-        else __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
-        __builtin_amdgcn_wave_barrier();
         RowsRaw in;
         {
-            rows_issue<FEAT, PROT>(st_cur, rd, in);
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
-            rows_dma_request(src, (uint32_t)tn, dma, rowB, st_nn);
-            rows_fence<FEAT, PROT>(in);
-            const uint32_t st_old = st_cur;
-            st_cur = st_nxt; st_nxt = st_nn; st_nn = st_old;
+            if (plain) {
+                rows_fence<FEAT, PROT>(nx);
+                in = nx;
+                rows_dma_request(src, (uint32_t)tn, dma, rowB, st_nn);
+            } else {
+                // optional outputs: the number of stores per step is not a compile-time constant -- wait for everything at the
+                // top (one step of latency hiding) and read here
+                __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+                rows_issue<FEAT, PROT>(st_cur, rd, in);
+                rows_dma_request(src, (uint32_t)tn, dma, rowB, st_nn);
+                rows_fence<FEAT, PROT>(in);
+            }
         }
         OS_TS(1)                                        // wait + LDS reads + next request
         // ---- both rotations (every lane), then ONE LEG per lane (leg = lane & 3) and quad sums over the legs ----
@@ -253,6 +264,17 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         // run is tested once at the end (status bit 0).  Hazards: a DPP source is at least two instructions old (P[.][sn]:
         // written first, read by the add three later; everything else was written by the previous block), v_rcp_f32's
         // result is read six or more instructions later, the prologue's s_nop 4 covers whatever hipcc scheduled in front.
+        if (plain) {
+            // step t + 1 (requested at the top of step t - 1): younger than it are x_out(t - 1) and step t + 2's five loads;
+            // vmcnt(5) also waits for that store, issued most of a step ago
+            __builtin_amdgcn_s_waitcnt(0x0f75);
+            __builtin_amdgcn_wave_barrier();
+            rows_issue<FEAT, PROT>(st_nxt, rd, nx);
+        }
+        {
+            const uint32_t st_old = st_cur;
+            st_cur = st_nxt; st_nxt = st_nn; st_nn = st_old;
+        }
 #include "kf_rows_chain.inc"
         xr = en + zr;
         OS_TS(5)                                        // ten measurement updates
