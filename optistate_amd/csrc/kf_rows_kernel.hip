@@ -164,11 +164,13 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         const uint32_t cb = __builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, in.c), sh8, 8u);
         const bool st = cb == 1u, sw = cb == 0u;
         float sum_c = (float)cb, vx = st ? in.dxy[0] : 0.f, vy = st ? in.dxy[1] : 0.f, vz = sw ? in.dz : 0.f, hz = st ? in.pz : 0.f;
-        // next_state's input half (misc/force_controller.py:269-291): world-frame foot position, torque of the lane's leg
-        const float pw0 = fmaf(R0[2], in.pz, fmaf(R0[1], in.pxy[1], R0[0] * in.pxy[0]));
-        const float pw1 = fmaf(R0[5], in.pz, fmaf(R0[4], in.pxy[1], R0[3] * in.pxy[0]));
-        const float pw2 = fmaf(R0[8], in.pz, fmaf(R0[7], in.pxy[1], R0[6] * in.pxy[0]));
-        float tau0 = fmaf(-pw2, in.fxy[1], pw1 * in.fz), tau1 = fmaf(-pw0, in.fz, pw2 * in.fxy[0]), tau2 = fmaf(-pw1, in.fxy[0], pw0 * in.fxy[1]);
+        // next_state's input half (misc/force_controller.py:269-291).  The reference forms sum(R p x f) in the world frame and
+        // applies I_hat^-1 = R diag(1/I) R^T; R^T (R p x f) = p x (R^T f) exactly (a rotation preserves the cross product), so the
+        // lane rotates its leg's FORCE into the body frame and takes the torque there: 9 + 6 multiply-adds instead of 9 + 6 + 9.
+        const float fb0 = fmaf(R0[6], in.fz, fmaf(R0[3], in.fxy[1], R0[0] * in.fxy[0]));
+        const float fb1 = fmaf(R0[7], in.fz, fmaf(R0[4], in.fxy[1], R0[1] * in.fxy[0]));
+        const float fb2 = fmaf(R0[8], in.fz, fmaf(R0[5], in.fxy[1], R0[2] * in.fxy[0]));
+        float tau0 = fmaf(-in.pz, fb1, in.pxy[1] * fb2), tau1 = fmaf(-in.pxy[0], fb2, in.pz * fb0), tau2 = fmaf(-in.pxy[1], fb0, in.pxy[0] * fb1);
         float fs0 = in.fxy[0], fs1 = in.fxy[1], fs2 = in.fz;
         quad_sum5(sum_c, vx, vy, vz, hz);
         quad_sum6(tau0, tau1, tau2, fs0, fs1, fs2);
@@ -180,10 +182,8 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         const float zv1 = Rp[3][1] * bx + Rp[4][1] * by + Rp[5][1] * bz;
         const float zv2 = Rp[6][1] * bx + Rp[7][1] * by + Rp[8][1] * bz;
         const float zr = fmaf(z11, zv2, fmaf(z10, zv1, fmaf(z9, zv0, fmaf(z5, zh, zi * in.il))));
-        // body-frame torque, scaled by 1/I, back to world: I_hat^-1 = R diag(1/I) R^T (R orthogonal)
-        const float tb0 = (R0[0] * tau0 + R0[3] * tau1 + R0[6] * tau2) * k.inv_inertia[0];
-        const float tb1 = (R0[1] * tau0 + R0[4] * tau1 + R0[7] * tau2) * k.inv_inertia[1];
-        const float tb2 = (R0[2] * tau0 + R0[5] * tau1 + R0[8] * tau2) * k.inv_inertia[2];
+        // body-frame torque (summed over the legs above), scaled by 1/I, back to world
+        const float tb0 = tau0 * k.inv_inertia[0], tb1 = tau1 * k.inv_inertia[1], tb2 = tau2 * k.inv_inertia[2];
         const float aw0 = R0[0] * tb0 + R0[1] * tb1 + R0[2] * tb2;
         const float aw1 = R0[3] * tb0 + R0[4] * tb1 + R0[5] * tb2;
         const float aw2 = R0[6] * tb0 + R0[7] * tb1 + R0[8] * tb2;
