@@ -2,7 +2,7 @@
 # Development build with in-kernel timestamps in kf_run_sym_kernel (-DOS_SYM_TS); the kernel prints cycles per step and phase.
 R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/sts; mkdir -p $D
 cd $R/optistate_amd/csrc
-for f in capi kf_kernels kf_step gru_kernels fused_kernels gru_train_kernels vit_kernels mpc_kernels; do
+for f in capi kf_kernels kf_rows_kernel kf_step gru_kernels fused_kernels gru_train_kernels vit_kernels mpc_kernels; do
   [ $f = kf_kernels ] && X=-DOS_SYM_TS || X=
   [ -f $D/$f.o -a $f != kf_kernels ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $X -DOS_BUILD_ID='"ts-build"' -c $f.hip -o $D/$f.o &
 done; wait
