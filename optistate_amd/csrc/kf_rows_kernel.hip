@@ -34,20 +34,29 @@ __device__ __forceinline__ float row_bcast(float v)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// kf_run_rows2_kernel -- the same 16-lanes-per-trajectory layout with half the instructions (round 3).
-// The first version (above, kept behind OS_KF_ROWS_V1=1 for A/B runs) issues ~800 VALU instructions per dependent step at
-// exactly one wave per SIMD (B = 4096 trajectories = 1024 waves), i.e. its 1.97 us per step are instruction issue.  Here:
+// kf_run_rows2_kernel -- 16 lanes per trajectory (four trajectories per wave): lane r holds row r of P and x[r] (round 3; the
+// round-2 kernel with the same layout, kf_run_rows_kernel in kf_kernels.hip, stays behind OS_KF_ROWS_V1=1 for A/B runs).
+// At B = 4096 there is exactly one wave per SIMD and each wave is a chain of T dependent steps, so a step costs what the wave
+// issues: ~445 VALU instructions and ~2.1 k cycles (round 2: ~930 and 4.7 k; profiles/r03_rows2_timestamps.md has the
+// build-by-build table).  What is where:
 //   * every row broadcast is FUSED into the multiply-add that consumes it: `v_fmac_f32_dpp acc, src row_newbcast:S, m` reads
-//     src from lane S of the 16-lane row inside the instruction, so a rank-1 update of a row is 12 instructions, not 12 moves +
-//     12 FMAs (hipcc keeps the DPP move separate and then pairs the FMAs: 18), and the covariance predict needs no
-//     ds_bpermute (row r + 6 arrives by `row_shl:6`);
-//   * the part every lane computes redundantly (rotations, odometry, next_state: ~350 instructions) is the hand-packed
-//     form of kf_device.hpp (legs in pairs, both rotations side by side: ~190);
-//   * class test instead of two compares and a select per measurement, no Newton step after v_rcp_f32 (as the lane kernels).
+//     src from lane S of the 16-lane row inside the instruction (a rank-1 update of a row is 12 instructions); the predict
+//     needs no ds_bpermute (row r + 6 arrives by `row_shl:6`) and runs IN PLACE (its source rows carry zero coefficients);
+//   * the lanes share the input-dependent work instead of repeating it: one LEG per lane (leg = lane & 3; contact decode,
+//     stance / swing selects, force rotation, torque), the sums over the legs by two quad-permute DPP adds; both rotations
+//     (prior attitude | IMU attitude) side by side in register pairs;
+//   * each lane integrates ITS component of next_state and holds ITS measurement through weights that are one-hot in the
+//     lane's row (no select chains: a chain costs an SGPR mask pair per comparison, and hipcc spilled SGPRs into VGPR lanes);
+//   * the filter runs on e = x - z: the state update is the thirteenth DPP multiply-add of a measurement's chain; the ten
+//     chains are ONE generated inline-assembly statement (kf_rows_chain.inc) -- hipcc pads every hand-over between its own
+//     instructions and an assembly statement with an s_nop, and its order is not ours;
+//   * inputs by five LDS-DMA instructions per wave two steps ahead (constant descriptors, the step offset in the VGPR, stage
+//     addresses rotating in SGPRs), picked up by inline-assembly LDS reads half a step early: an LDS read hipcc can see is
+//     ordered behind EVERY outstanding LDS-DMA (s_waitcnt vmcnt(0)).
 // DPP hazards (inline asm is invisible to hipcc's hazard recogniser): a VALU result must be two instructions old before a
-// DPP operand reads it, an EXEC write five.  Within a chain every source was written at least twelve instructions
-// earlier; the blocks start behind hipcc's own (hazard-checked) DPP moves, and one s_nop 4 separates the update from
-// whatever branchy code precedes it.
+// DPP operand reads it, an EXEC write five.  Every DPP source of the assembly here was written by the previous chain (twelve or
+// more instructions earlier), or is guarded by an s_nop whose operands pin the producers in front of it.  All 64 lanes stay
+// active through the loop (quad_perm and row reads must not meet a disabled lane); lanes past the batch shadow the last trajectory.
 // ---------------------------------------------------------------------------------------------------------------
 template <int SRC>
 __device__ __forceinline__ void fmac_bcast(float &acc, float src, float m)     // acc += (src of lane SRC of this 16-lane row) * m
