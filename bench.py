@@ -747,7 +747,7 @@ def bench_hot_path(a, rk):
             per = 4
             waves = (B + per - 1) // per
             roof["limiter"] = (f"instruction issue of a serial chain: {waves} wavefronts on 1024 SIMDs, four trajectories (16 lanes each) "
-                               f"per wavefront, T = {T} dependent steps of ~445 VALU instructions at ~5 cycles each "
+                               f"per wavefront, T = {T} dependent steps of ~410 VALU instructions at ~5 cycles each "
                                f"({avg_ms * 1e3 / T:.2f} us per step: profiles/r03_rows2_timestamps.md); HBM is not the bound at this batch")
         else:
             roof["limiter"] = "VALU issue at one wavefront per SIMD (~5 cycles per instruction)"
