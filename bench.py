@@ -751,7 +751,8 @@ def bench_hot_path(a, rk):
                                f"({avg_ms * 1e3 / T:.2f} us per step: profiles/r03_rows2_timestamps.md); HBM is not the bound at this batch")
         else:
             roof["limiter"] = "VALU issue at one wavefront per SIMD (~5 cycles per instruction)"
-    roof["traffic"] = load_traffic(dk["kernel"], default_shape and not a.split_bf16)
+    rows_shape = a.mode == "kf" and B == 4096 and T == 1000 and dk["kernel"].startswith("kf_run_rows2")      # the shape traffic.json holds for it
+    roof["traffic"] = load_traffic(dk["kernel"], (default_shape or rows_shape) and not a.split_bf16)
     if roof["traffic"] is not None:
         roof["traffic_unit"] = "bytes/launch"
     for k in kernels:

@@ -207,7 +207,9 @@ __device__ __forceinline__ RowsSrc rows_src(const KfRunArgs &a, uint32_t rowB)
 }
 __device__ __forceinline__ void lds_dma4_at(rsrc_t r, uint32_t lds_byte, uint32_t voff)      // lds_byte: wave-uniform
 {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(uintptr_t)lds_byte, 4, voff, 0, 0, 2);
+    // default cache policy, not the non-temporal hint of the lane kernels' streams: a 128-byte line of a row serves two
+    // workgroups here (32 trajectories), and the second one should find it in the L2
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(uintptr_t)lds_byte, 4, voff, 0, 0, 0);
 }
 __device__ __forceinline__ void rows_dma_request(const RowsSrc &src, uint32_t t, const RowsDma &d, uint32_t rowB, uint32_t stage)
 {

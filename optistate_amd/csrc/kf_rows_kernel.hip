@@ -73,7 +73,12 @@ template <bool AUX, bool FEAT, bool PROT>
 __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a, const float *__restrict__ qmat)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
-    const int first = (blockIdx.x * (blockDim.x >> 6) + wv) * 4;        // this wave's first trajectory
+    // XCD-aware order: consecutive workgroup ids go round-robin to the eight XCDs, each with its own L2, and two workgroups
+    // (32 trajectories) share every 128-byte line of an input row -- so XCD x takes a CONTIGUOUS range of trajectory blocks
+    // (measured: 2.46x the algorithmic read traffic with the plain order, every line fetched by two L2s)
+    const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lblk = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int first = (lblk * (blockDim.x >> 6) + wv) * 4;              // this wave's first trajectory
     const int b_raw = first + grp;
     const bool live = b_raw < a.B;
     const int b = live ? b_raw : a.B - 1;

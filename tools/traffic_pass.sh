@@ -9,11 +9,12 @@ cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -- $R/tools/micro/traffic_cal > $OUT/cal_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $OUT/run_$c -- python3 $R/tools/run_fused_once.py 2 > $OUT/run_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/rows_$c -- python3 $R/tools/run_rows_once.py 2 > $OUT/rows_$c.log 2>&1      # configs[1]: B = 4096, T = 1000
 done
 python3 - <<PY
 import csv, glob, collections, json
 res = collections.defaultdict(dict)
-for tag in ("cal", "run"):
+for tag in ("cal", "run", "rows"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = glob.glob("$OUT/%s_%s/**/*counter_collection.csv" % (tag, c), recursive=True)
         if not f: continue
@@ -23,7 +24,7 @@ for tag in ("cal", "run"):
         for k, v in acc.items():
             res[k][c] = sum(v) / len(v)
 for k, d in res.items():
-    if any(s in k for s in ("rd_dword", "wr_dword", "fused_kf_gru", "kf_run_sym")):
+    if any(s in k for s in ("rd_dword", "wr_dword", "fused_kf_gru", "kf_run_sym", "kf_run_rows2")):
         print(k, {c: "%.4g" % v for c, v in d.items()})
 json.dump(res, open("$OUT/traffic_raw.json", "w"), indent=1)
 PY
