@@ -405,7 +405,7 @@ def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only
     order = torch.randperm(B, generator=torch.Generator().manual_seed(3))[:max(1, min(want, B))]
     w = None if kf_only else orc.flatten_state_dict(model.state_dict(), L)
     CH = 8192
-    done, secs, s_linf, g_linf, bad = 0, 0.0, 0.0, 0.0, 0
+    done, secs, s_linf, g_linf, bad, nonfinite = 0, 0.0, 0.0, 0.0, 0, 0
     worst = None
     for c0 in range(0, int(order.numel()), CH):
         idx = order[c0:c0 + CH].sort().values.to(d["p"].device)
@@ -420,6 +420,9 @@ def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only
         secs += time.perf_counter() - t0
         bad += int((ref["status"] != 0).sum())
         err = np.abs(x_out[:, :, idx].permute(2, 0, 1).cpu().numpy() - ref["x"])
+        nf = ~np.isfinite(err)                       # a NaN anywhere must fail the gate: Python's max(a, nan) is a
+        nonfinite += int(nf.sum())
+        err[nf] = np.inf
         if err.max() > s_linf or worst is None:
             bi, ti, ci = np.unravel_index(int(err.argmax()), err.shape)
             worst = {"trajectory": int(idx[bi].item()), "timestep": int(ti), "component": int(ci)}
@@ -432,7 +435,10 @@ def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only
             t0 = time.perf_counter()
             ro, _, _ = orc.gru_forward(rows, w, rows.shape[2], H, L, 24)
             secs += time.perf_counter() - t0
-            g_linf = max(g_linf, float(np.abs(out[idx].cpu().numpy() - ro).max()))
+            gerr = np.abs(out[idx].cpu().numpy() - ro)
+            nonfinite += int((~np.isfinite(gerr)).sum())
+            gerr[~np.isfinite(gerr)] = np.inf
+            g_linf = max(g_linf, float(gerr.max()))
         done += n
         del a, ref, err
         if secs > cap_seconds:
@@ -440,6 +446,7 @@ def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only
     orc.set_threads(1)
     res = {"trajectories": done, "timesteps_each": T, "of_batch": B, "whole_tensor": bool(done == B),
            "state_linf": s_linf, "state_linf_at": worst, "state_bar": 1e-4, "oracle_status_nonzero": bad,
+           "nonfinite": nonfinite,
            "reference": "oracle/kf_oracle.c + gru_oracle.c (float64; pinned to reference-generated goldens)"}
     if done < min(want, B):
         res["note"] = f"stopped after {secs:.0f} s of oracle time on {cores} cores (cap {cap_seconds:.0f} s): seeded random sample"
@@ -447,7 +454,10 @@ def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only
         res["gru_linf"] = g_linf
         res["gru_bar"] = 1e-5
         res["fused_chain_bar"] = 1e-4
-    res["ok"] = bool(s_linf < 1e-4 and g_linf < 1e-4)
+    res["ok"] = bool(nonfinite == 0 and s_linf < 1e-4 and g_linf < 1e-4)
+    for k in ("state_linf", "gru_linf"):            # strict JSON has no Infinity: null + the non-finite count says it
+        if k in res and not np.isfinite(res[k]):
+            res[k] = None
     return res, {"trajectories": done, "timesteps_each": T, "seconds": secs, "cores": cores}
 
 
