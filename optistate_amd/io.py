@@ -11,9 +11,10 @@
 
 * raw `.mat` logs (data_collection/data_conversion_raw_to_Kalman.py:43-57): `load_mat_trajectory` restates that script's ETL
   (mocap alignment, finite differences, list windows with their off-by-one) for everything that does not need the absent
-  `scaler_kin` leg Jacobian; foot velocities come from a caller-supplied Jacobian or array.  PARITY UNPINNED: the script is
-  top-level code importing cv2 / scaler_kin / matplotlib and cannot run in the build image; the test checks every
-  indexing rule on a synthetic `.mat`.
+  `scaler_kin` leg Jacobian; foot velocities come from a caller-supplied Jacobian or array.  Pinned by golden G13
+  (tests/golden/etl_g13.npz, tools/gen_golden_etl.py): the script itself executed unmodified in the build container on
+  seeded synthetic logs (cv2.imwrite recorded, scaler_kin's Jacobian a stand-in callable); tests/test_io_formats.py
+  requires every list to agree to 1e-12, at reduced and at the shipped cutoffs.
 
 The reference's recorded forces are never used by its pipeline (the MPC's forces are: SURVEY.md appendix 9); a trajectory
 dict may therefore carry an extra 'f_list' (externally supplied ground-reaction forces); without it `f` is the quasi-static

@@ -292,3 +292,74 @@ def test_persistent_kernel_agrees_with_the_launch_sequence(monkeypatch):
     assert float((rp["f"] - rs["f"]).abs().max()) < 5e-3
     assert float((xp - xs_).abs().max()) < 1e-4
     assert float((rp["ptrace"] - rs["ptrace"]).abs().max()) < 1e-3 * float(rs["ptrace"].abs().max())
+
+
+# ---- G12: the QP as the REFERENCE assembles it (tools/gen_golden_mpc.py: misc/force_controller.py:47-225 and
+# kalman_filter.py:140-182 run unmodified over the evaluating casadi stand-in).  formulation = reference, solver = certified
+# stand-in; tests/test_oracle_mpc_g12.py pins the oracle to the same file on the CPU.
+def _g12():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "mpc_g12_qp.npz"))
+
+
+def test_mpc_solve_matches_reference_formulation_g12(eng):
+    """os_mpc_solve on the 32 reference-assembled problems (all 16 contact patterns, twice): all 60 controls <= 2e-4 N of the
+    minimiser of the reference's own H, g, A; sol.value(controls)[:, 0] is what predict_mpc applies (kalman_filter.py:152,161)."""
+    g = _g12()
+    X, R, P = (np.asarray(g[k], np.float32) for k in ("x", "body_ref", "p"))
+    assert np.array_equal(X.astype(np.float64), g["x"])          # the fixture's inputs are float32-representable
+    r = _solve_gpu(eng, X, R, P, np.asarray(g["contact"], np.uint8))
+    assert int(r["status"].abs().max()) == 0
+    u = r["u"].cpu().numpy().T.astype(np.float64)                # stage-major [12 k + 3 leg + i]
+    ref = g["forces"].transpose(0, 2, 1).reshape(-1, 60)         # (12, N) matrix -> stage-major
+    assert np.abs(u - ref).max() < 2e-4, np.abs(u - ref).max()
+    assert np.abs(r["f"].cpu().numpy().T - g["forces"][:, :, 0]).max() < 2e-4
+    # and the GPU's answer is feasible for the reference's own rows, in Opti's variable order
+    m = g["opti_to_stage"]
+    for k in range(X.shape[0]):
+        uo = np.zeros(60); uo[m] = u[k]
+        s = g["A"][k] @ uo + g["b"][k]
+        assert np.all(np.abs(s[g["is_eq"][k]]) < 1e-4) and np.all(s[~g["is_eq"][k]] > -1e-4)
+        cost = lambda v: v @ g["H"][k] @ v + g["g"][k] @ v
+        assert cost(uo) <= cost(g["u"][k]) + 1e-6 * max(1.0, abs(cost(g["u"][k])))
+
+
+def test_kf_mpc_run_matches_reference_trajectory_g12(eng):
+    """os_kf_mpc_run against estimate_state_mpc run by the reference with the QP in the loop (T = 60, fitted Q/R)."""
+    g = _g12()
+    B, T = g["t_x"].shape[:2]
+    eng.set_noise(g["Q"], g["R"])
+    s = {k: eng.pack(torch.as_tensor(g["t_" + k])) for k in ("p", "dp", "imu", "body_ref")}
+    c = eng.pack_contact(torch.as_tensor(g["t_contact"]))
+    for kw in (dict(), dict(sequential=True)):
+        x = torch.as_tensor(g["t_x0"].T.copy()).cuda()
+        P = torch.as_tensor(np.tile(g["Q"].astype(np.float32).reshape(144, 1), (1, B))).cuda()
+        r = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x, P, want_p_rot=True, want_trace=True, **kw)
+        assert int(r["status"].abs().max()) == 0
+        x_gpu = eng.unpack(r["x_out"]).cpu().numpy(); f_gpu = eng.unpack(r["f"]).cpu().numpy()
+        assert np.abs(x_gpu - g["t_x"]).max() < 1e-4, np.abs(x_gpu - g["t_x"]).max()
+        # forces: the QP is a near dead-beat controller (R = 1e-6), ~3.5e3 N per metre of state error, fed back from a float32 state
+        assert np.abs(f_gpu - g["t_f"]).max() < 5e-3, np.abs(f_gpu - g["t_f"]).max()
+        assert np.abs(eng.unpack(r["p_rot"]).cpu().numpy() - g["t_p_rot"]).max() < 1e-5
+        pt = r["ptrace"].cpu().numpy().T
+        assert np.abs(pt / g["t_P_trace"] - 1).max() < 1e-3
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+
+
+def test_dropin_estimate_state_mpc_matches_reference_trajectory_g12():
+    """The drop-in class called exactly as the reference's loop calls it (data_conversion_Kalman_to_Training.py:136-203)."""
+    from optistate_amd import Kalman_Filter
+    g = _g12()
+    T = g["t_x"].shape[1]
+    kf = Kalman_Filter()
+    kf.x = g["t_x0"][0].astype(np.float64).reshape(12, 1).copy()
+    kf.P = g["Q"].copy(); kf.Q = g["Q"].copy(); kf.R = g["R"].copy()
+    for t in range(T):
+        p = g["t_p"][0, t].astype(np.float64).reshape(12, 1)
+        x = kf.estimate_state_mpc(g["t_imu"][0, t].reshape(6, 1).astype(np.float64), p, g["t_dp"][0, t].reshape(12, 1).astype(np.float64),
+                                  g["t_body_ref"][0, t].reshape(12, 1).astype(np.float64), g["t_contact"][0, t].reshape(4, 1).astype(np.float64))
+        assert np.abs(x.ravel() - g["t_x"][0, t]).max() < 1e-4, t
+        assert np.abs(kf.f[:, 0] - g["t_f"][0, t]).max() < 5e-3, t
+        assert np.abs(p.ravel() - g["t_p_rot"][0, t]).max() < 1e-5          # p is rotated in place, as next_state does
+        assert abs(kf.P_trace / g["t_P_trace"][0, t] - 1) < 1e-3

@@ -105,3 +105,49 @@ def test_empty_and_oversize_batches_are_refused_cleanly():
     rc = eng.lib.os_kf_run(eng._h, 8_000_000, 1, p, p, p, p, p, None, p, p, p, None, None, None, p, 1 | 4, None)
     assert rc == -2 and b"too large" in eng.lib.os_last_error(eng._h)
     torch.cuda.synchronize()
+
+
+# ---- G13: what the reference's second script writes (data_conversion_Kalman_to_Training.py executed unmodified by
+# tools/gen_golden_etl.py; QP formulation = reference, solver = certified stand-in).  tests/test_oracle_etl_g13.py pins the
+# oracles to the same file on the CPU.
+def test_noise_fit_matches_the_scripts_q_r_pkl_g13():
+    """pipeline.fit_noise_covariances against Q_R.pkl (:31-109): one batch of independent one-step predictions from the
+    ground truth; float32 device arithmetic, float64 variance."""
+    from optistate_amd import Engine
+    from optistate_amd import pipeline as pl
+    g = load_golden("etl_g13.npz")
+    eng = Engine(0)
+    k = 2                                                             # the script fits on the LAST trajectory only
+    n = g[f"k{k}_p_list_est"].shape[0]                                # traj_length = len(p_list_ref): the shorter lists
+    Q, R = pl.fit_noise_covariances(eng, g[f"k{k}_p_list_est"], g[f"k{k}_dp_list"], g[f"k{k}_imu_list"][:n], g[f"k{k}_contact_list"],
+                                    g[f"k{k}_mocap_list"][:n], alias_measurements=True)
+    assert np.count_nonzero(Q - np.diag(np.diag(Q))) == 0 and np.count_nonzero(R - np.diag(np.diag(R))) == 0
+    eq, er = np.abs(np.diag(Q) / np.diag(g["fit_Q"]) - 1).max(), np.abs(np.diag(R) / np.diag(g["fit_R"]) - 1).max()
+    assert eq < 2e-3 and er < 2e-3, (eq, er)
+
+
+def test_mpc_feature_rows_match_rnn_data_pkl_g13():
+    """pipeline.kalman_feature_rows_mpc (os_kf_mpc_run) against rnn_data.pkl's state_INPUT (:136-254), both trajectories as one
+    batch of two, with the script's fitted Q and R[0:3] = 1e-4."""
+    from optistate_amd import Engine
+    from optistate_amd import pipeline as pl
+    g = load_golden("etl_g13.npz")
+    eng = Engine(0)
+    n = g["k1_p_list_est"].shape[0]
+    st = lambda name, lo, hi: np.stack([g[f"k{k}_{name}"][:n, lo:hi] for k in (1, 2)])
+    traj = dict(p=st("p_list_est", 0, 12), dp=st("dp_list", 0, 12), imu=st("imu_list", 0, 6), accel=st("imu_list", 6, 12),
+                ref=st("ref_list", 0, 12), contact=st("contact_list", 0, 4).astype(np.uint8))
+    x0 = np.stack([g[f"k{k}_mocap_list"][0] for k in (1, 2)])         # KF2.x[:] = mocap_list[0] (:137-138)
+    rows, x_hist, forces, status = pl.kalman_feature_rows_mpc(eng, traj, g["fit_Q"], g["run_R"], x0)
+    assert int(status.abs().max()) == 0
+    rows = rows.cpu().numpy().astype(np.float64)
+    want = np.stack([g[f"k{k}_state_INPUT"] for k in (1, 2)])
+    e = np.abs(rows - want)
+    assert e[:, :, 0:12].max() < 1e-4, e[:, :, 0:12].max()                       # the state bar
+    assert e[:, :, 30:42].max() < 1e-5                                          # p rotated in place by next_state
+    assert e[:, :, 12:18].max() < 1e-6 * max(1.0, np.abs(want[:, :, 12:18]).max()) and e[:, :, 42:60].max() < 1e-6 * max(1.0, np.abs(want[:, :, 42:60]).max())
+    # forces: a near dead-beat controller (R = 1e-6) fed back from a float32 state, saturating at 150 N
+    assert e[:, :, 18:30].max() < 2e-2, e[:, :, 18:30].max()
+    assert np.median(e[:, :, 18:30]) < 1e-4
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)

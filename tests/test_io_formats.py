@@ -1,4 +1,5 @@
-"""CPU: the reference's on-disk formats (synthetic pickles with the schema of data_conversion_raw_to_Kalman.py:443-447)."""
+"""CPU: the reference's on-disk formats (synthetic pickles with the schema of data_conversion_raw_to_Kalman.py:443-447) and the raw
+`.mat` ETL pinned to the reference script's own output (G13)."""
 import pickle
 
 import numpy as np
@@ -55,84 +56,75 @@ def test_rnn_data_and_scaling_roundtrip(tmp_path):
     assert set(sp) == {"min_vals_KF", "max_vals_KF", "min_vals_VIC", "max_vals_VIC"} and np.allclose(sp["max_vals_KF"], mx)
 
 
-def _synthetic_mat(path, N=64, seed=0):
-    """A raw log with the schema of data_collection/data_conversion_raw_to_Kalman.py:43-57 (shapes (N,4,3), (N,3), (1,N), ...)."""
+def _write_g13_log(path, seed, N, drop_rows):
+    """The raw log the G13 fixture was generated from (tests/golden_recipes.g13_raw: arithmetic-only, rebuilt bit for bit)."""
     import scipy.io
-    from scipy.spatial.transform import Rotation as Rot
-    rng = np.random.default_rng(seed)
-    t = np.cumsum(rng.uniform(0.009, 0.011, N)).reshape(1, N)
-    quat = Rot.from_euler("xyz", rng.normal(0, 0.2, (N, 3))).as_quat()
-    mocap = np.concatenate([rng.normal(0, 300, (N, 3)) + np.array([1000.0, -500.0, 280.0]), quat], axis=1)
-    mocap[20] = 0.0                                                      # a dropped mocap frame (:133-137)
-    d = dict(foot_state_history=rng.normal(0, 0.1, (N, 4, 3)), footSteps_ref=rng.normal(0, 0.1, (N, 4, 3)),
-             bodyCM_ref=rng.normal(0, 0.1, (N, 3)), bodyR_ref=rng.normal(0, 0.1, (N, 3)), control_history=rng.normal(0, 1, (N, 12)),
-             liftLeg_ref=(rng.random((N, 4)) < 0.5).astype(np.float64), body_state_history=rng.normal(0, 0.1, (N, 12)),
-             time_history=t, imu=rng.normal(0, 1, (N, 6)), encoder_history=rng.normal(0, 0.5, (N, 4, 3)),
-             depth4=rng.random((N, 8, 8)), mocap_history=mocap)
-    scipy.io.savemat(path, d)
-    return d
+    from golden_recipes import g13_raw
+    raw = g13_raw(seed, N, drop_rows=drop_rows)
+    scipy.io.savemat(path, raw)
+    return raw
 
 
-def test_mat_loader_reproduces_the_scripts_indexing_rules(tmp_path):
-    from scipy.spatial.transform import Rotation as Rot
+LISTS = ("p_list_est", "p_list_ref", "dp_list", "imu_list", "contact_list", "t265_list", "mocap_list", "ref_list")
+
+
+def _g13():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "etl_g13.npz"))
+
+
+def test_mat_loader_reproduces_the_reference_etl_script_g13(tmp_path):
+    """G13 (tools/gen_golden_etl.py): data_collection/data_conversion_raw_to_Kalman.py executed UNMODIFIED on these logs
+    (cv2.imwrite recorded, scaler_kin's leg Jacobian = golden_recipes.g13_leg_jacobian, cutoffs 430 / 640).  Every list of
+    saved_trajectories.pkl -- the off-by-one windows (:176,233 vs :328,388,412), the in-place mocap re-expression with its
+    dropped-frame quirk (:133-137, trajectory 1 row 450), T265 finite differences (:158-173), the imu row order (:269),
+    contact = (liftLeg == 0) (:409-418), dp through the Jacobian / 1000 (:388-404) and the 8-bit depth frames (:427-433)."""
+    from golden_recipes import g13_leg_jacobian, G13_SEED, G13_ROWS, G13_CUTOFF, G13_END
     from optistate_amd.io import load_mat_trajectory, trajectories_to_batch
-    raw = _synthetic_mat(str(tmp_path / "traj.mat"))
-    cutoff, end = 5, 50
-    jac = lambda theta, leg: np.eye(3) * (100.0 + leg)                   # stand-in for scaler_kin's leg Jacobian (mm)
-    d = load_mat_trajectory(str(tmp_path / "traj.mat"), cutoff=cutoff, end_cutoff=end, leg_jacobian=jac, want_depth=True)
-    # list lengths: imu/mocap/t265/ref/time cover range(cutoff-1, end-1); p/dp/contact range(cutoff, end-1) (:176,233 vs :328,388,412)
-    for k in ("imu_list", "mocap_list", "t265_list", "ref_list", "time_list"):
-        assert len(d[k]) == end - cutoff, k
-    for k in ("p_list_est", "p_list_ref", "dp_list", "contact_list"):
-        assert len(d[k]) == end - cutoff - 1, k
-    t = raw["time_history"].reshape(-1)
-    t265 = raw["body_state_history"].copy()
-    for i in range(cutoff - 1, 63):                                      # finite differences written into row i+1 (:158-173)
-        dt = t[i + 1] - t[i]
-        t265[i + 1, 6:9] = (t265[i + 1, 0:3] - t265[i, 0:3]) / dt
-        t265[i + 1, 9:12] = (t265[i + 1, 3:6] - t265[i, 3:6]) / dt
-    for k in (0, 7, end - cutoff - 1):
-        i = cutoff - 1 + k
-        want = np.concatenate([t265[i, 0:3], t265[i, 6:9], raw["imu"][i, 3:6], raw["imu"][i, 0:3]])        # :269
-        assert np.allclose(d["imu_list"][k].ravel(), want, atol=1e-12)
-        assert d["time_list"][k] == t[i]
-        assert np.allclose(d["t265_list"][k].ravel(), t265[i], atol=1e-12)
-        assert np.allclose(d["ref_list"][k].ravel()[:6], np.concatenate([raw["bodyR_ref"][i], raw["bodyCM_ref"][i]]))
-        assert d["ref_list"][k][6:9].sum() == 0.0 and d["ref_list"][k][11, 0] == 0.0
-    for k in (0, 11, end - cutoff - 2):
-        i = cutoff + k                                                   # p is one log row ahead of imu at the same list index
-        assert np.array_equal(d["p_list_est"][k].ravel(), raw["foot_state_history"][i].reshape(12))
-        assert np.array_equal(d["p_list_ref"][k].ravel(), raw["footSteps_ref"][i].reshape(12))
-        assert np.array_equal(d["contact_list"][k].ravel(), (raw["liftLeg_ref"][i] == 0).astype(int))
-        dth = (raw["encoder_history"][i + 1] - raw["encoder_history"][i]) / (t[i + 1] - t[i])
-        want = np.concatenate([(100.0 + j) * dth[j] / 1000.0 for j in range(4)])                              # :388-399
-        assert np.allclose(d["dp_list"][k].ravel(), want, atol=1e-12)
-    assert d["dp_available"] and d["depth_u8"].shape == (end - cutoff - 1, 8, 8) and d["depth_u8"].dtype == np.uint8
-    assert np.array_equal(d["depth_u8"][3], (raw["depth4"][cutoff + 3] * 255).astype(np.uint8))
-    # mocap alignment: row 0's pose is the origin (z + 0.28), later rows relative to it (:101-156)
-    m = raw["mocap_history"]
-    rot0 = Rot.from_quat(m[0, 3:])
-    i = cutoff - 1 + 3 + 1                                               # mocap_list[3] describes row i (= loop index + 1)
-    pos = rot0.inv().apply(m[i, 0:3] / 1000.0 - m[0, 0:3] / 1000.0) + np.array([0, 0, 0.28])
-    eul = (rot0.inv() * Rot.from_quat(m[i, 3:])).as_euler("xyz")
-    assert np.allclose(d["mocap_list"][3].ravel()[3:6], pos, atol=1e-9)
-    assert np.allclose(d["mocap_list"][3].ravel()[0:3], eul, atol=1e-9)
-    # the dropped frame (row 20) borrowed row 19 AS ALREADY TRANSFORMED, divided by 1000 again (:135): reproduce that
-    k20 = 20 - cutoff                                                    # mocap_list[k] = row cutoff + k
-    pos19 = rot0.inv().apply(m[19, 0:3] / 1000.0 - m[0, 0:3] / 1000.0) + np.array([0, 0, 0.28])
-    want20 = rot0.inv().apply(pos19 / 1000.0 - m[0, 0:3] / 1000.0) + np.array([0, 0, 0.28])
-    assert np.allclose(d["mocap_list"][k20].ravel()[3:6], want20, atol=1e-9)
-    # the dict feeds trajectories_to_batch like a pickle entry; n = the shorter lists
+    g = _g13()
+    for k, (seed, drops) in enumerate(((G13_SEED, (450,)), (G13_SEED + 1, ())), start=1):
+        path = str(tmp_path / f"traj_{k}.mat")
+        _write_g13_log(path, seed, G13_ROWS, drops)
+        d = load_mat_trajectory(path, cutoff=G13_CUTOFF, end_cutoff=G13_END, leg_jacobian=g13_leg_jacobian, want_depth=True)
+        for name in LISTS:
+            want = g[f"k{k}_{name}"]
+            got = np.stack([np.asarray(v, dtype=np.float64).reshape(-1) for v in d[name]])
+            assert got.shape == want.shape, (k, name, got.shape, want.shape)
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (k, name, np.abs(got - want).max())
+        assert np.array_equal(np.asarray(d["time_list"], dtype=np.float64), g[f"k{k}_time_list"])
+        assert np.array_equal(d["depth_u8"], g[f"k{k}_depth_u8"])
+        assert len(d["imu_list"]) == G13_END - G13_CUTOFF and len(d["p_list_est"]) == G13_END - G13_CUTOFF - 1
+        assert d["dp_available"]
+    # the dict feeds trajectories_to_batch like a pickle entry; n = the shorter lists; x0 = mocap_list[0] (Kalman_to_Training.py:137-138)
     b = trajectories_to_batch({1: d})
-    assert b["p"].shape == (1, end - cutoff - 1, 12) and b["imu"].shape == (1, end - cutoff - 1, 6)
-    assert np.allclose(b["imu"][0, 0], d["imu_list"][0].ravel()[:6].astype(np.float32))
-    assert np.allclose(b["accel"][0, 0], d["imu_list"][0].ravel()[6:].astype(np.float32))
-    assert np.allclose(b["x0"][0], d["mocap_list"][0].ravel().astype(np.float32))
+    n = G13_END - G13_CUTOFF - 1
+    assert b["p"].shape == (1, n, 12) and b["imu"].shape == (1, n, 6)
+    assert np.array_equal(b["imu"][0], g["k2_imu_list"][:n, 0:6].astype(np.float32))
+    assert np.array_equal(b["accel"][0], g["k2_imu_list"][:n, 6:12].astype(np.float32))
+    assert np.array_equal(b["x0"][0], g["k2_mocap_list"][0].astype(np.float32))
+    assert np.array_equal(b["body_ref"][0], g["k2_ref_list"][:n].astype(np.float32))
+    assert np.array_equal(b["contact"][0], g["k2_contact_list"].astype(np.uint8))
+
+
+def test_mat_loader_at_the_shipped_cutoffs_g13(tmp_path):
+    """The same script at settings.py:15-16's own 430 / 4494 on a 4,500-row log with two dropped frames: list lengths, column
+    sums and sampled entries (first two, middle, last two)."""
+    from golden_recipes import g13_leg_jacobian, G13_SEED
+    from optistate_amd.io import load_mat_trajectory
+    g = _g13()
+    path = str(tmp_path / "full.mat")
+    _write_g13_log(path, G13_SEED + 2, 4500, (450, 3000))
+    d = load_mat_trajectory(path, leg_jacobian=g13_leg_jacobian)              # defaults = the shipped cutoffs
+    for name in LISTS:
+        got = np.stack([np.asarray(v, dtype=np.float64).reshape(-1) for v in d[name]])
+        assert got.shape[0] == int(g[f"full_len_{name}"][0]), name
+        assert np.abs(got[[0, 1, 2031, -2, -1]] - g[f"full_pick_{name}"]).max() <= 1e-12 * max(1.0, np.abs(g[f"full_pick_{name}"]).max()), name
+        assert np.abs(got.sum(0) - g[f"full_sum_{name}"]).max() <= 1e-9 * max(1.0, np.abs(g[f"full_sum_{name}"]).max()), name
 
 
 def test_mat_loader_without_a_jacobian_says_so(tmp_path):
     from optistate_amd.io import load_mat_trajectory
-    _synthetic_mat(str(tmp_path / "t.mat"), seed=1)
+    _write_g13_log(str(tmp_path / "t.mat"), 1, 64, ())
     d = load_mat_trajectory(str(tmp_path / "t.mat"), cutoff=5, end_cutoff=30)
     assert d["dp_available"] is False and all(float(np.abs(v).sum()) == 0.0 for v in d["dp_list"])
     import pytest
