@@ -19,7 +19,12 @@
  *     propagates NaN: kalman_filter/kalman_filter.py:168), bit2 = QP iteration cap (os_kf_mpc_run),
  *     bit3 = OS_KF_SYMMETRIC_P was requested but the caller's P0 is not symmetric (the kernel used its
  *     upper triangle; the reference never symmetrises P, kalman_filter/kalman_filter.py:172, so re-run
- *     that trajectory without the flag).
+ *     that trajectory without the flag), bit4 (16, informational) = at some step an entry of the float64
+ *     rotation matrix was within 2^-40 of +-1 at an attitude other than the exact start theta = 0: the
+ *     reference stores R^T into an int64 array (misc/force_controller.py:248-251,271), so whether that
+ *     entry integrates dt*omega into theta is decided by the last bits of the reference's own float64 state
+ *     (gimbal lock: pitch = pi/2 with roll = yaw); on such a trajectory the 1e-4 state bar is not promised,
+ *     the deviation is one dt*omega step per flagged decision (tests/test_gpu_fullsize.py).
  *   - Stream layout (structure of arrays, trajectory index fastest, float32):
  *       p, f, dp, body_ref : [T][12][B]      imu, accel : [T][6][B]
  *       contact            : [T][B] of 4 packed bytes (byte k = leg k, 0 swing / 1 stance)

@@ -3,12 +3,15 @@
     python -m optistate_amd.build [--force]
 
 The library carries a build id (`os_build_id()`): "<hash of every source / header + the compile flags>-<hash of `hipcc
---version`>".  build() recompiles what is stale by content, not only by mtime: a changed flag or a ROCm upgrade rebuilds
-everything; _capi.load() recomputes the source half from the files on disk and refuses a library built from other sources
-(the .so is git-ignored and travels to the GPU box as a file: nothing else ties it to the tree it sits in).
+--version`>".  build() recompiles what is stale BY CONTENT, never by mtime: every object has a key file next to it holding
+the hash of its source, of the headers it includes (scanned transitively from the `#include "..."` lines), of its flags and
+of the toolchain; an object is rebuilt when that key differs (a pushed / restored tree with arbitrary mtimes cannot link an old
+object under a new build id).  _capi.load() recomputes the source half from the files on disk and refuses a library built
+from other sources (the .so is git-ignored and travels to the GPU box as a file: nothing else ties it to the tree it sits in).
 """
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -49,11 +52,36 @@ def toolchain_id():
     return hashlib.sha256(v.encode()).hexdigest()[:8]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _includes(path, seen=None):
+    """Files reached from `path` through #include "..." (quoted includes only: the project's own headers)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, "r", errors="replace") as fh:
+        for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), re.M):
+            _includes(os.path.join(os.path.dirname(path), m.group(1)), seen)
+    return seen
+
+
+def object_key(src, tool_id):
+    """What an object file is a function of: its source, the headers it includes, its flags, the toolchain."""
+    h = hashlib.sha256()
+    for f in sorted(_includes(os.path.join(CSRC, src))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
+    h.update(tool_id.encode())
+    return h.hexdigest()[:24]
+
+
+def _key_of(obj):
+    try:
+        return open(obj + ".key").read().strip()
+    except OSError:
+        return ""
 
 
 def build(force=False, verbose=False):
@@ -63,46 +91,44 @@ def build(force=False, verbose=False):
     bid = source_id() + "-" + toolchain_id()
     stamp = os.path.join(objdir, "build_id.txt")
     old = open(stamp).read().strip() if os.path.exists(stamp) else ""
-    # another toolchain or other flags: every object is stale whatever its mtime says
-    if old.split("-")[-1] != bid.split("-")[-1] or _flags_changed(objdir):
-        force = True
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    tool = bid.split("-")[-1]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
+        key = object_key(src, tool)
         # capi.hip carries the id string: recompiled whenever the id moves (seconds)
-        if force or _stale(o, [s] + hdrs) or (src == "capi.hip" and old != bid):
-            jobs.append((s, o))
+        if force or not os.path.exists(o) or _key_of(o) != key or (src == "capi.hip" and old != bid):
+            jobs.append((s, o, key))
 
     def cc(job):
-        s, o = job
+        s, o, key = job
+        if os.path.exists(o + ".key"):
+            os.remove(o + ".key")
         cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + [f'-DOS_BUILD_ID="{bid}"', "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
+        with open(o + ".key", "w") as fh:
+            fh.write(key)
         return o
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
+    link_key = hashlib.sha256("".join(_key_of(o) for o in objs).encode() + bid.encode()).hexdigest()[:24]
+    if force or jobs or not os.path.exists(LIB) or _key_of(LIB) != link_key:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
-    with open(os.path.join(objdir, "flags.txt"), "w") as fh:
-        fh.write(_all_flags())
+        with open(LIB + ".key", "w") as fh:
+            fh.write(link_key)
     with open(stamp, "w") as fh:
         fh.write(bid)
     return LIB
-
-
-def _flags_changed(objdir):
-    f = os.path.join(objdir, "flags.txt")
-    return not os.path.exists(f) or open(f).read() != _all_flags()
 
 
 if __name__ == "__main__":

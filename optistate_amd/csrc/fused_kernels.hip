@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
     for (int t = 0; t < k.T; t++) {
         // ================= Kalman step (lane = trajectory) =================
         float z[NM], pw[12], F[KX];
-        kf_step_front_tri<QDIAG>(x, U, in, k.k, z, pw);
+        status |= kf_step_front_tri<QDIAG>(x, U, in, k.k, z, pw);
         status |= kf_step_back_tri(x, U, z, k.k);
         if (live) {
             rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         float z[NM], FA[KX];
         f2 PW[2][3];
         float g9[9];
-        kf_step_inputs_sym(X, in, k.k, z, PW, g9);
+        status |= kf_step_inputs_sym(X, in, k.k, z, PW, g9);
         __builtin_amdgcn_sched_barrier(0);
         OSF_TS(1)                                        // wait for the prefetched inputs + rotations, odometry, next_state
         // Features [x_post | accel | f | p_world | dp | imu] minus their minimum (the 1/(max-min) scale sits in the packed
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         float z[NM], FA[2][KBX][8];        // FA[rb][kb][j]: feature 16 kb + 8 (lane half) + j of trajectory block rb (AGPRs)
         f2 PW[2][3];
         float g9[9];
-        kf_step_inputs_sym(X, in, k.k, z, PW, g9);
+        status |= kf_step_inputs_sym(X, in, k.k, z, PW, g9);
         __builtin_amdgcn_sched_barrier(0);
         // k-block kb = features 16 kb .. 16 kb + 15; v_permlane32_swap pairs feature j with feature j + 8 of the block, so that
         // the first register serves trajectories 0-31 (lanes 0-31: feature j, lanes 32-63: feature j + 8), the second 32-63

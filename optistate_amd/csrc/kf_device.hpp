@@ -153,7 +153,12 @@ __device__ __forceinline__ void sincos_f64(double x, double *s, double *c)
 // The decision is made in float64 from the float32 angles promoted to double: cosf() rounds to
 // 1.0f for |th| up to ~3e-4 where the float64 cosine is still < 1, and that would integrate omega into theta
 // where the reference adds 0.  The float64 path only runs for lanes whose float32 entry is within a few ulp of 1.
-__device__ __forceinline__ void trunc_block_f64(float thx, float thy, float thz, float *A /* 9, A[i][j] = trunc(R[j][i]) */)
+// Returns status bit 4 (OS_STATUS_TRUNC_EDGE = 16) when the decision sits on a knife edge: some |R entry| >= 1 - 2^-40 in
+// float64 at an attitude other than the reference's own exact start theta = 0 (settings.py:25).  There the reference's
+// int64 store picks 0 or +-1 from the last bits of ITS float64 state (1 - cos(d) < 2^-40 for |d| < 1.3e-6, the size of a
+// float32 filter's state error), so a float32 filter may integrate dt*omega where the reference adds 0 or the reverse
+// (gimbal lock, pitch = pi/2 with roll = yaw: R[1][1] = cos(yaw - roll) stays within one rounding of 1 for several steps).
+__device__ __forceinline__ int trunc_block_f64(float thx, float thy, float thz, float *A /* 9, A[i][j] = trunc(R[j][i]) */)
 {
     double sx, cx, sy, cy, sz, cz;
     sincos_f64((double)thx, &sx, &cx);
@@ -171,6 +176,11 @@ __device__ __forceinline__ void trunc_block_f64(float thx, float thy, float thz,
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) A[3 * i + j] = (float)trunc(r[3 * j + i]);
+    double rmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) rmax = fmax(rmax, fabs(r[i]));
+    const bool exact_start = thx == 0.f && thy == 0.f && thz == 0.f;
+    return (rmax >= 1.0 - 0x1p-40 && !exact_start) ? 16 : 0;
 }
 
 struct StepIn {
@@ -216,9 +226,10 @@ __device__ __forceinline__ void measurement(const StepIn &in, float *z /*10*/)
 // next_state (misc/force_controller.py:269-291): x <- (I + A dt) x + B dt f + dt g, foot positions rotated
 // to the world frame (returned in pw: the reference mutates the caller's p, :274-277).
 // I_hat^-1 = R diag(1/I) R^T (R orthogonal), tau = sum_j pw_j x f_j.
-__device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p, const float *f, float *pw,
-                                         const KfConst &k)
+__device__ __forceinline__ int dynamics(float *x, const Rot &r, const float *p, const float *f, float *pw,
+                                        const KfConst &k)
 {
+    int edge = 0;
     float tau[3] = {0.f, 0.f, 0.f}, fs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int l = 0; l < 4; l++) {
@@ -248,7 +259,7 @@ __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p,
     float w0 = x[6], w1 = x[7], w2 = x[8];
     if (amax >= 0.9999995f) {
         float A[9];
-        trunc_block_f64(x[0], x[1], x[2], A);
+        edge = trunc_block_f64(x[0], x[1], x[2], A);
         x[0] += k.dt * (A[0] * w0 + A[1] * w1 + A[2] * w2);
         x[1] += k.dt * (A[3] * w0 + A[4] * w1 + A[5] * w2);
         x[2] += k.dt * (A[6] * w0 + A[7] * w1 + A[8] * w2);
@@ -259,6 +270,7 @@ __device__ __forceinline__ void dynamics(float *x, const Rot &r, const float *p,
     x[9] += k.dt * (fs[0] * k.inv_mass);
     x[10] += k.dt * (fs[1] * k.inv_mass);
     x[11] += k.dt * (fs[2] * k.inv_mass) + k.dt * k.gz;
+    return edge;
 }
 
 // P <- F_d P F_d^T + Q with F_d = I + dt F, F[0:3,6:9] = R^T, F[3:6,9:12] = I
@@ -828,8 +840,9 @@ __device__ __forceinline__ void dynamics_rates_p(const f2 *Rp, const StepInP &in
 }
 
 // next_state on the replicated state: X in/out.
-__device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &in, f2 (*PW)[3], const KfConst &k)
+__device__ __forceinline__ int dynamics_p(f2 *X, const f2 *Rp, const StepInP &in, f2 (*PW)[3], const KfConst &k)
 {
+    int edge = 0;
     float aw[3], fs[3], amax;
     dynamics_rates_p(Rp, in, PW, k, aw, fs, amax);
     const float aw0 = aw[0], aw1 = aw[1], aw2 = aw[2];
@@ -840,7 +853,7 @@ __device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &i
     // theta: A[0:3,6:9] = trunc(R^T) -- zero unless an entry of R reaches +-1 in float64 (see trunc_block_f64)
     if (amax >= 0.9999995f) {
         float A[9];
-        trunc_block_f64(x[0], x[1], x[2], A);
+        edge = trunc_block_f64(x[0], x[1], x[2], A);
         x[0] += k.dt * (A[0] * w0 + A[1] * w1 + A[2] * w2);
         x[1] += k.dt * (A[3] * w0 + A[4] * w1 + A[5] * w2);
         x[2] += k.dt * (A[6] * w0 + A[7] * w1 + A[8] * w2);
@@ -852,12 +865,14 @@ __device__ __forceinline__ void dynamics_p(f2 *X, const f2 *Rp, const StepInP &i
     x[11] += k.dt * (fs[2] * k.inv_mass) + k.dt * k.gz;
 #pragma unroll
     for (int i = 0; i < 6; i++) X[i] = (f2){x[2 * i], x[2 * i + 1]};
+    return edge;
 }
 
 // Everything of a step that reads its inputs: measurement vector, next_state, and g = dt R^T of the PRIOR attitude for the
 // covariance predict (kalman_filter.py:124: F_d and next_state both use the prior state).  The callers run the predict
 // (cov_predict_sym_blk(U, g, k)) afterwards, when the input registers are free again.
-__device__ __forceinline__ void kf_step_inputs_sym(f2 *X, const StepInP &in, const KfConst &k, float *z, f2 (*PW)[3], float *g /*9*/)
+// Returns status bit 4 (the int64-truncation knife edge, see trunc_block_f64) or 0.
+__device__ __forceinline__ int kf_step_inputs_sym(f2 *X, const StepInP &in, const KfConst &k, float *z, f2 (*PW)[3], float *g /*9*/)
 {
     f2 Rp[9];
     const float xs[3] = {X[0][0], X[0][1], X[1][0]};
@@ -867,15 +882,16 @@ __device__ __forceinline__ void kf_step_inputs_sym(f2 *X, const StepInP &in, con
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * Rp[3 * kk + i][0];     // g[3 i + kk] = dt R[kk][i]
-    dynamics_p(X, Rp, in, PW, k);
+    return dynamics_p(X, Rp, in, PW, k);
 }
 
 template <bool QDIAG>
-__device__ __forceinline__ void kf_step_front_sym(f2 *X, f2 *U, const StepInP &in, const KfConst &k, float *z, f2 (*PW)[3])
+__device__ __forceinline__ int kf_step_front_sym(f2 *X, f2 *U, const StepInP &in, const KfConst &k, float *z, f2 (*PW)[3])
 {
     float g[9];
-    kf_step_inputs_sym(X, in, k, z, PW, g);
+    const int edge = kf_step_inputs_sym(X, in, k, z, PW, g);
     cov_predict_sym_blk<QDIAG>(U, g, k);
+    return edge;
 }
 
 __device__ __forceinline__ int finite_status_p(const f2 *X)
@@ -940,8 +956,8 @@ __device__ __forceinline__ int finite_status(const float *x)
 //   kf_step_front: everything that consumes the step's inputs (measurement, covariance predict, dynamics)
 //   kf_step_back : the measurement update (the long part; needs only z)
 template <bool DENSE, bool QDIAG, typename PT>
-__device__ __forceinline__ void kf_step_front(float *x, PT *P, const StepIn &in, const float *body_ref /*3 angles*/,
-                                              const KfConst &k, float *z, float *pw)
+__device__ __forceinline__ int kf_step_front(float *x, PT *P, const StepIn &in, const float *body_ref /*3 angles*/,
+                                             const KfConst &k, float *z, float *pw)
 {
     measurement(in, z);
     Rot r = rotation(x[0], x[1], x[2]);     // prior attitude drives both F_d and next_state
@@ -951,17 +967,17 @@ __device__ __forceinline__ void kf_step_front(float *x, PT *P, const StepIn &in,
     } else {
         if constexpr (sizeof(PT) == 4) cov_predict<QDIAG>(P, r, k);
     }
-    dynamics(x, r, in.p, in.f, pw, k);
+    return dynamics(x, r, in.p, in.f, pw, k);      // status bit 4 or 0
 }
 
 // the same halves on the scalar triangle (fused kernel)
 template <bool QDIAG>
-__device__ __forceinline__ void kf_step_front_tri(float *x, float *U, const StepIn &in, const KfConst &k, float *z, float *pw)
+__device__ __forceinline__ int kf_step_front_tri(float *x, float *U, const StepIn &in, const KfConst &k, float *z, float *pw)
 {
     measurement(in, z);
     Rot r = rotation(x[0], x[1], x[2]);
     cov_predict_tri<QDIAG>(U, r, k);
-    dynamics(x, r, in.p, in.f, pw, k);
+    return dynamics(x, r, in.p, in.f, pw, k);
 }
 
 __device__ __forceinline__ int kf_step_back_tri(float *x, float *U, const float *z, const KfConst &k)

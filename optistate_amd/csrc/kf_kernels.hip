@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
     }
     for (int t = 0; t < a.T; t++) {
         float z[NM], pw[12], ptrace = 0.f, kgain = 0.f;
-        kf_step_front<DENSE, QDIAG, PT>(x, P, in, bref, a.k, z, pw);
+        status |= kf_step_front<DENSE, QDIAG, PT>(x, P, in, bref, a.k, z, pw);      // bit 4: int64-truncation knife edge
         rsrc_t rfeat;
         if (FEAT) {
             rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
@@ -189,7 +189,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         float z[NM];
         f2 PW[2][3];
         float g9[9];
-        kf_step_inputs_sym(X, in, kc, z, PW, g9);
+        status |= kf_step_inputs_sym(X, in, kc, z, PW, g9);
         OS_STS(2)                                       // rotations, odometry, next_state
         cov_predict_sym_blk<QDIAG>(U, g9, kc);
         OS_STS(3)                                       // covariance predict
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, 
 #pragma unroll
         for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
         // ---- dynamics (replicated), keep this lane's component ----
-        dynamics(x, rot, in.p, in.f, pw, k);
+        status |= dynamics(x, rot, in.p, in.f, pw, k);
         float xn = x[0];
 #pragma unroll
         for (int i = 1; i < NS; i++) xn = (rr == i) ? x[i] : xn;

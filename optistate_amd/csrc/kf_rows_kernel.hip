@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     // step (one step of latency hiding instead of two).
     constexpr bool plain = !AUX && !FEAT && !PROT;
     OS_TS_DECL
+    int edge = 0;                                      // status bit 4: int64-truncation knife edge (trunc_block_f64), rare path only
     // (the prologue's loads retire here: otherwise hipcc re-checks them with a dozen s_waitcnt in every iteration)
     __builtin_amdgcn_s_waitcnt(0x0070);
 #pragma unroll
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
         // theta += dt trunc(R^T) omega: zero unless an entry of R reaches +-1 in float64 (see trunc_block_f64)
         if (__builtin_amdgcn_ballot_w64(amax >= 0.9999995f) != 0ull) {
             float A[9];
-            trunc_block_f64(th[0], th[1], th[2], A);
+            const int e = trunc_block_f64(th[0], th[1], th[2], A);
+            edge |= (amax >= 0.9999995f) ? e : 0;                              // status bit 4
             const float w0 = row_bcast<6>(xr), w1 = row_bcast<7>(xr), w2 = row_bcast<8>(xr);
             const float d0 = A[0] * w0 + A[1] * w1 + A[2] * w2, d1 = A[3] * w0 + A[4] * w1 + A[5] * w2, d2 = A[6] * w0 + A[7] * w1 + A[8] * w2;
             const float dth = k.dt * (r == 0 ? d0 : r == 1 ? d1 : r == 2 ? d2 : 0.f);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
     }
 #endif
     // ---- final state: lane r writes x[r] and row r of P; the status word is OR-reduced over the 16 lanes ----
-    int status = (__builtin_amdgcn_classf(svmin, 0x180) ? 0 : 1) | ((xr * 0.f == 0.f) ? 0 : 2);
+    int status = (__builtin_amdgcn_classf(svmin, 0x180) ? 0 : 1) | ((xr * 0.f == 0.f) ? 0 : 2) | edge;
     status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
     status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
     if (live && r < 12) {

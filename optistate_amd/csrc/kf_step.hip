@@ -209,6 +209,12 @@ __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
                      aw2 = R[6] * tb0 + R[7] * tb1 + R[8] * tb2;
         const double w0 = x[6], w1 = x[7], w2 = x[8];
         // A[0:3,6:9] = R^T stored into an int64 array: truncated toward zero
+        {   // status bit 4 (see trunc_block_f64, kf_device.hpp): an entry within 2^-40 of +-1 away from the exact start theta = 0
+            double rmax = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) rmax = fmax(rmax, fabs(R[i]));
+            if (rmax >= 1.0 - 0x1p-40 && !(x[0] == 0.0 && x[1] == 0.0 && x[2] == 0.0)) status |= 16;
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++) x[i] += dt * (trunc(R[i]) * w0 + trunc(R[3 + i]) * w1 + trunc(R[6 + i]) * w2);
         x[3] += dt * x[9]; x[4] += dt * x[10]; x[5] += dt * x[11];

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
         const Rot r = rotation(x[0], x[1], x[2]);
         const Rot rb = rotation(bref[0], bref[1], bref[2]);
         cov_predict_dense_wave(W, rb, a.kf.k.dt, lane);
-        dynamics(x, r, in.p, in.f, pw, a.kf.k);
+        status |= dynamics(x, r, in.p, in.f, pw, a.kf.k);
         status |= update_batch_wave(x, W, z, lane, &kgain, &ptrace, &xl);
         status |= finite_status(x);
         if (lane < 12) a.kf.x_out[((size_t)t * 12 + lane) * B + b] = xl;

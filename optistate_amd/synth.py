@@ -33,19 +33,21 @@ NOISE_SETS = {"default": (Q_DEFAULT, R_DEFAULT), "fitted": (Q_FITTED, R_FITTED)}
 # to 8 rad/s (passes +-pi and keeps going: the Cody-Waite branch of the kernels' sincos, every quadrant), roll / pitch
 # sinusoids up to 1 rad; the first 5/16 of the batch start at exact attitudes (0, and theta_z / theta_y = float32(pi/2), +-pi)
 # with the IMU agreeing at t = 0, so the int64-truncation predicate (misc/force_controller.py:248-251,271) sees entries of R
-# at or next to +-1.  The pitch = pi/2 block starts with roll 0.3 and yaw -0.4: with roll = yaw = 0 there (gimbal lock: R depends on
-# yaw - roll only) the float64 R[1][1] = cz cx + sz sy sx lands within one rounding of 1.0 for several steps, and whether the
-# reference's int64 A picks up a 1 then depends on the last bit of its own float64 state -- a coin toss no float32 filter can
-# reproduce (measured: one trajectory in 65,536 x 100 steps flipped, theta_y off by 5e-3).
+# at or next to +-1.  The pitch = pi/2 block starts with roll 0.3 and yaw -0.4 by default: with roll = yaw = 0 there (gimbal lock:
+# R depends on yaw - roll only) the float64 R[1][1] = cz cx + sz sy sx lands within one rounding of 1.0 for several steps, and
+# whether the reference's int64 A picks up a 1 then depends on the last bit of its own float64 state -- a coin toss no float32
+# filter can reproduce (measured: one trajectory in 65,536 x 100 steps flipped, theta_y off by 5e-3).  gimbal_lock=True puts the
+# block AT roll = yaw = 0: the kernels report those decisions in status bit 4 (include/optistate_hip.h), and
+# tests/test_gpu_fullsize.py::test_gimbal_lock_knife_edge_is_flagged checks that nothing else exceeds the state bar.
 HOSTILE_SEG = 16
 
 
-def _hostile_exact_starts(B):
+def _hostile_exact_starts(B, gimbal_lock=False):
     """[(first, last, (thx, thy, thz))]: index ranges of the batch that start at exact attitudes."""
     n = max(1, B // 16)
     pi2, pi = float(np.float32(np.pi / 2)), float(np.float32(np.pi))
     return [(0, n, (0.0, 0.0, 0.0)), (n, 2 * n, (0.0, 0.0, pi2)), (2 * n, 3 * n, (0.0, 0.0, pi)),
-            (3 * n, 4 * n, (0.0, 0.0, -pi)), (4 * n, 5 * n, (0.3, pi2, -0.4))]
+            (3 * n, 4 * n, (0.0, 0.0, -pi)), (4 * n, 5 * n, (0.0, pi2, 0.0) if gimbal_lock else (0.3, pi2, -0.4))]
 
 
 def synth_numpy(B, T, seed=0, theta0_noise=True, dtype=np.float32, hostile=False):
@@ -85,7 +87,7 @@ def synth_numpy(B, T, seed=0, theta0_noise=True, dtype=np.float32, hostile=False
     return out
 
 
-def synth_torch(B, T, device, seed=0, soa=True, hostile=False):
+def synth_torch(B, T, device, seed=0, soa=True, hostile=False, gimbal_lock=False):
     """Same distributions generated on `device` with torch, directly in the kernel's SoA layout
     [T][field][B] (float32) when soa=True.  Used by bench.py at BASELINE sizes.  hostile=True: see HOSTILE_SEG above."""
     import torch
@@ -131,7 +133,7 @@ def synth_torch(B, T, device, seed=0, soa=True, hostile=False):
         imu = torch.cat([rp, yaw, imu[:, 3:6] + torch.cat([torch.zeros(1, 2, B, device=device), rate], dim=1)], dim=1) \
             + torch.cat([rn(T, 3, B, std=0.005), torch.zeros(T, 3, B, device=device)], dim=1)
         x0[0:3] = imu[0, 0:3]                                                        # the filter starts on the first IMU attitude
-        for lo, hi, th in _hostile_exact_starts(B):
+        for lo, hi, th in _hostile_exact_starts(B, gimbal_lock):
             for c in range(3):
                 x0[c, lo:hi] = th[c]
                 imu[0, c, lo:hi] = th[c]

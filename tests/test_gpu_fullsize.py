@@ -123,11 +123,16 @@ def test_hostile_contacts_and_unwrapped_yaw_through_every_kernel_family(noise):
     rw = eng.kf_run(g4("p"), g4("f"), g4("dp"), g4("imu"), cp[:, sl].contiguous(), xs, Ps)
     assert eng.kernel_name("kf") == "kf_run_rows2_kernel"
     torch.cuda.synchronize()
+    n_exact = _hostile_exact_starts(B)[-1][1]
     for r in (fz, sy, rw):
-        assert int((r["status"] != 0).sum()) == 0 and torch.isfinite(r["x_out"]).all()
+        assert int(((r["status"] & ~16) != 0).sum()) == 0 and torch.isfinite(r["x_out"]).all()
+    # status bit 4 (int64-truncation knife edge, include/optistate_hip.h): only the exact k pi/2 starts may carry it (an entry
+    # of R within 2^-40 of +-1 at t = 0; both filters hold the identical exact attitude there, so the decisions agree)
+    for r, off in ((fz, 0), (sy, 0), (rw, 2048)):
+        flagged = torch.nonzero(r["status"] & 16).flatten() + off
+        assert flagged.numel() == 0 or (int(flagged.min()) >= n_exact // 5 and int(flagged.max()) < n_exact), flagged[:8]
     # the two lane kernels run the same arithmetic on the filter state (omega_z reaches +-55 under the fitted set: 1 ulp = 4e-6)
     assert (fz["x_out"] - sy["x_out"]).abs().max().item() < 5e-5
-    n_exact = _hostile_exact_starts(B)[-1][1]
     pick = torch.cat([torch.arange(n_exact), n_exact + torch.randperm(B - n_exact, generator=torch.Generator().manual_seed(9))[:16384 - 4096],
                       ]).unique().cuda()
     orc.set_threads(orc.max_threads())
@@ -153,6 +158,75 @@ def test_hostile_contacts_and_unwrapped_yaw_through_every_kernel_family(noise):
     ro, _, _ = orc.gru_forward((rows + 60.0) / 120.0, orc.flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
     orc.set_threads(1)
     assert np.abs(fz["out"][pick].cpu().numpy() - ro).max() < 1e-4
+
+
+def test_gimbal_lock_knife_edge_is_flagged():
+    """The block the generator used to steer around: pitch = float32(pi/2) with roll = yaw = 0.  There
+    R[1][1] = cos(yaw - roll) sits within one rounding of 1 in float64, so whether the reference's int64 A[0:3,6:9]
+    (misc/force_controller.py:248-251,271) picks up a 1 is decided by the last bits of ITS float64 state.  Property:
+    every trajectory whose state error exceeds the 1e-4 bar carries status bit 4, through every kernel family; where a
+    decision did flip, the error at its first appearance is one dt * omega integration step (times |I - K H| <= 2)."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT, _hostile_exact_starts
+    from oracle import c_oracle as orc
+    Bg, Tg = 32768, 100
+    eng = Engine(0)
+    eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    d = synth_torch(Bg, Tg, "cuda", seed=78, hostile=True, gimbal_lock=True)
+    blocks = _hostile_exact_starts(Bg, gimbal_lock=True)
+    lo, hi = blocks[-1][0], blocks[-1][1]
+    assert blocks[-1][2][0] == 0.0 and blocks[-1][2][2] == 0.0
+    cp = eng.contact_soa_to_packed(d["contact"])
+    P0 = torch.tensor(np.asarray(Q_DEFAULT, dtype=np.float32).reshape(144, 1), device="cuda").repeat(1, Bg).contiguous()
+    torch.manual_seed(0)
+    from optistate_amd import RNN, flatten_state_dict
+    m = RNN(60, 64, 1, 24, torch.device("cpu"))
+    eng.load_gru(flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    mm = torch.stack([torch.full((60,), -60.0), torch.full((60,), 60.0)]).cuda()
+    x, P = d["x0"].clone(), P0.clone()
+    fz = eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], cp, d["accel"], mm, x, P, two_kernel=False)
+    x, P = d["x0"].clone(), P0.clone()
+    sy = eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], cp, x, P)
+    assert eng.kernel_name("kf") == "kf_run_sym_kernel"
+    sl = torch.arange(lo - 1024, hi + 1024, device="cuda")                            # the gimbal block + neighbours: rows kernel
+    g4 = lambda k: d[k][:, :, sl].contiguous()
+    xs, Ps = d["x0"][:, sl].contiguous(), P0[:, sl].contiguous()
+    rw = eng.kf_run(g4("p"), g4("f"), g4("dp"), g4("imu"), cp[:, sl].contiguous(), xs, Ps)
+    assert eng.kernel_name("kf") == "kf_run_rows2_kernel"
+    torch.cuda.synchronize()
+    pick = torch.cat([torch.arange(0, hi), hi + torch.randperm(Bg - hi, generator=torch.Generator().manual_seed(10))[:4096]]).cuda()
+    orc.set_threads(orc.max_threads())
+    g = lambda k: d[k][:, :, pick].permute(2, 0, 1).double().cpu().numpy()
+    n = int(pick.numel())
+    ref = orc.kf_run_batch(g("p"), g("f"), g("dp"), g("imu"), d["contact"][:, :, pick].permute(2, 0, 1).contiguous().cpu().numpy(),
+                           d["x0"][:, pick].t().double().cpu().numpy(), np.tile(Q_DEFAULT, (n, 1, 1)), Q_DEFAULT, R_DEFAULT)
+    orc.set_threads(1)
+    pk = pick.cpu().numpy()
+    report = {}
+    for name, r, off in (("fused_v2", fz, 0), ("sym", sy, 0), ("rows2", rw, lo - 1024)):
+        st = r["status"].cpu().numpy()
+        assert int(((st & ~16) != 0).sum()) == 0
+        sel = np.nonzero((pk >= off) & (pk < off + st.shape[0]))[0]
+        xg = r["x_out"][:, :, torch.as_tensor(pk[sel] - off, device="cuda")].permute(2, 0, 1).cpu().numpy()
+        err = np.abs(xg - ref["x"][sel])
+        worst = err.reshape(len(sel), -1).max(1)
+        flagged = (st[pk[sel] - off] & 16) != 0
+        # (a) the property: above the bar => flagged
+        assert np.all(flagged[worst >= 1e-4]), (name, np.nonzero((worst >= 1e-4) & ~flagged)[0][:8])
+        assert worst[~flagged].max() < 1e-4
+        # (b) the gimbal block is where the flags are (plus the exact k pi/2 starts, flagged at t = 0 only)
+        in_block = (pk[sel] >= lo) & (pk[sel] < hi)
+        assert flagged[in_block].all() and not flagged[pk[sel] >= hi].any()
+        # (c) a flipped decision costs one integration step: dt * sum |omega_prior|, through |I - K H| <= 2
+        bad = np.nonzero(worst >= 1e-4)[0]
+        for i in bad:
+            tstar = int(np.argmax(err[i].max(1) >= 1e-4))
+            w = np.abs(ref["x_prior"][sel[i], tstar, 6:9]).sum() if tstar > 0 else np.abs(ref["x_prior"][sel[i], 0, 6:9]).sum()
+            assert err[i, tstar].max() <= 2 * 0.01 * max(w, np.abs(ref["x"][sel[i], max(tstar - 1, 0), 6:9]).sum()) + 1e-4, (name, int(pk[sel[i]]), tstar)
+        report[name] = (int(flagged.sum()), int(len(bad)), float(worst.max()))
+    print("gimbal block: (flagged, above the bar, worst linf) per kernel:", report)
+    # the block is not vacuous: the reference really does integrate through the knife edge on some of these trajectories
+    # (theta_y moves away from pi/2 by dt * omega steps in the oracle's prior) -- whether the GPU agrees is what (a) covers
 
 
 # ------------------------------------------------------------------------------------------------------------------
