@@ -93,7 +93,28 @@ def self_launch(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    env.update(rccl_env_from_argv(argv))                    # --rccl-proto / --rccl-algo: in place before any rank creates a communicator
     return subprocess.run(launch_command(n, argv, _free_port()), env=env).returncode
+
+
+def rccl_env_from_argv(argv):
+    """NCCL_PROTO / NCCL_ALGO for the ranks (RCCL reads them at communicator creation).  Parsed by hand: this runs in the
+    launcher, before argparse and before anything imports torch."""
+    env = {}
+    argv = list(argv)
+    for flag, name, allowed in (("--rccl-proto", "NCCL_PROTO", ("default", "LL", "LL128", "Simple")),
+                                ("--rccl-algo", "NCCL_ALGO", ("default", "Ring", "Tree"))):
+        val = None
+        for i, t in enumerate(argv):
+            if t == flag and i + 1 < len(argv):
+                val = argv[i + 1]
+            elif t.startswith(flag + "="):
+                val = t.split("=", 1)[1]
+        if val is not None and val != "default":
+            if val not in allowed:
+                raise SystemExit(f"{flag}: one of {allowed}")
+            env[name] = val
+    return env
 
 
 class Ranks:
@@ -117,6 +138,8 @@ class Ranks:
             import torch.distributed as dist
             self.dist = dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            # launched directly under torch.distributed.run (the driver's form): the knob still lands before the communicator exists
+            os.environ.update(rccl_env_from_argv(["--rccl-proto", getattr(a, "rccl_proto", "default"), "--rccl-algo", getattr(a, "rccl_algo", "default")]))
             if self.cpu_only:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
@@ -137,7 +160,8 @@ class Ranks:
     def report(self):
         """What the process group itself says about the job: world size as RCCL sees it and every rank's device."""
         import torch
-        me = {"rank": self.rank, "local_rank": self.local_rank, "pid": os.getpid()}
+        me = {"rank": self.rank, "local_rank": self.local_rank, "pid": os.getpid(),
+              "rccl_env": {k: os.environ[k] for k in ("NCCL_PROTO", "NCCL_ALGO") if k in os.environ}}
         if not self.cpu_only:
             pr = torch.cuda.get_device_properties(self.dev)
             me.update(device=torch.cuda.current_device(), name=pr.name, gcn_arch=getattr(pr, "gcnArchName", ""),
@@ -225,17 +249,38 @@ def base_line(a, rk, metric, unit, value, el, dtype, config):
     return out
 
 
+TRAFFIC_SOURCE_OF = {"fused_kf_gru_kernel_v2": "fused_kernels.hip", "fused_kf_gru_bf16_kernel": "fused_kernels.hip",
+                     "fused_kf_gru_kernel": "fused_kernels.hip", "kf_run_sym_kernel": "kf_kernels.hip",
+                     "kf_run_rows2_kernel": "kf_rows_kernel.hip"}
+
+
 def load_traffic(kernel_name, shape_ok):
     """HBM bytes per launch from the PMC passes (tools/traffic_pass.sh -> profiles/traffic.json; FETCH_SIZE corrected x2
-    per the gfx950 calibration).  Valid for the shape it was collected on only; entries carry the kernel name they were
-    measured for, so a renamed or re-dispatched kernel simply finds nothing (null) instead of a stale figure."""
+    per the gfx950 calibration), WITH PROVENANCE: every entry carries the content key of the object file its kernel was
+    compiled into when the counters were collected (optistate_amd/build.py object_key: source + the headers it includes +
+    flags + toolchain) and the collection date.  The figure is returned only when that key equals the key of the sources
+    the loaded library was built from and the shape is the one it was collected on; anything else -- a changed kernel under
+    the same name, another shape, a renamed kernel -- reports null and says why.  Returns (bytes or None, source string)."""
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if not shape_ok or not os.path.exists(tj):
-        return None
+    name = kernel_name.split("<")[0].split(" ")[0]
+    if not shape_ok:
+        return None, "not collected for this shape / mode"
+    if not os.path.exists(tj):
+        return None, "profiles/traffic.json absent"
     try:
-        return json.load(open(tj)).get(kernel_name.split("<")[0].split(" ")[0])
-    except Exception:
-        return None
+        tab = json.load(open(tj))
+        if name not in tab:
+            return None, f"profiles/traffic.json has no entry for {name}"
+        det = tab.get(name + "_detail", {})
+        from optistate_amd import build as _b
+        src = TRAFFIC_SOURCE_OF.get(name)
+        now = _b.object_key(src, _b.toolchain_id()) if src else None
+        if not det.get("source_key") or det.get("source_key") != now:
+            return None, (f"profiles/traffic.json entry for {name} is stale: collected for object key {det.get('source_key')}, "
+                          f"the library's {src} has key {now}")
+        return tab[name], f"profiles/traffic.json@{det['source_key']} ({src}, collected {det.get('collected', '?')})"
+    except Exception as e:                               # a reporting aid must never take the bench line down
+        return None, f"profiles/traffic.json unreadable: {e!r}"
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -474,7 +519,8 @@ def bench_train(a, rk):
     B, T, I, H, L, C = 8192, 10, 188, 128, 4, 24
     torch.manual_seed(0)
     model = RNN(I, H, L, C, dev).to(dev)
-    tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=not a.no_split_allreduce, force_distributed=a.force_dist)
+    tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=not a.no_split_allreduce, force_distributed=a.force_dist,
+                             proto=a.rccl_proto if rk.dist else None, algo=a.rccl_algo if rk.dist else None)
     g = torch.Generator(device=dev); g.manual_seed(100 + rk.rank)
     x = torch.rand(B, T, I, device=dev, generator=g); y = torch.rand(B, C // 2, device=dev, generator=g)
     el, loss, _ = timed_region(rk, a.warmup, a.steps, lambda: tr.step(x, y))
@@ -489,6 +535,9 @@ def bench_train(a, rk):
             rk.dist.all_reduce(tr.bucket.g)
         e1.record(); torch.cuda.synchronize()
         ar_us = e0.elapsed_time(e1) / 20 * 1e3
+    # replica equality (every rank calls it: one broadcast + one MAX all-reduce): identical replicas + one averaged gradient +
+    # the same fused Adam must leave bit-identical weights on every rank after the timed steps
+    divergence = tr.replica_divergence()
     info = rk.report()
     if rk.rank == 0:
         rows = B * T
@@ -514,6 +563,10 @@ def bench_train(a, rk):
                                           "frac": tot / (el / a.steps) / 1e12 / MFMA_F32_PEAK_TF}}
         out["kernels"] = kernels
         out["kernel_events"] = "HIP events in a second, untimed pass of the same step"
+        out["parity"] = {"replica_max_abs_diff": divergence, "ranks": rk.world, "ok": bool(divergence == 0.0),
+                         "what": "max_r |w_r - w_0| over the flat parameter vector after the timed steps (0 = replicas identical); "
+                                 "single-step numerics vs the reference's loop body: tests/test_gpu_train.py (golden G6)"}
+        out["rccl"] = dict(tr.rccl)
         out.update(allreduce_us=ar_us, grad_bucket_bytes=int(tr.bucket.g.numel() * 4), final_loss=float(loss.item()),
                    allreduce="two halves: layers L/2..L-1 + head on a side stream behind their dW kernel, the rest on the main stream"
                    if tr.split is not None else "one bucket behind the backward", **info)
@@ -762,7 +815,7 @@ def bench_hot_path(a, rk):
         else:
             roof["limiter"] = "VALU issue at one wavefront per SIMD (~5 cycles per instruction)"
     rows_shape = a.mode == "kf" and B == 4096 and T == 1000 and dk["kernel"].startswith("kf_run_rows2")      # the shape traffic.json holds for it
-    roof["traffic"] = load_traffic(dk["kernel"], (default_shape or rows_shape) and not a.split_bf16)
+    roof["traffic"], roof["traffic_source"] = load_traffic(dk["kernel"], (default_shape or rows_shape) and not a.split_bf16)
     if roof["traffic"] is not None:
         roof["traffic_unit"] = "bytes/launch"
     for k in kernels:
@@ -850,6 +903,9 @@ def main(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="--mode train on ONE GPU with a one-rank RCCL process group: exercises (and prices) the split all-reduce path")
     ap.add_argument("--no-split-allreduce", action="store_true", help="--mode train: one all-reduce behind the whole backward")
+    ap.add_argument("--rccl-proto", default="default", choices=["default", "LL", "LL128", "Simple"],
+                    help="NCCL_PROTO for the ranks (set before any communicator exists); the 1.69 MB gradient bucket is latency-bound")
+    ap.add_argument("--rccl-algo", default="default", choices=["default", "Ring", "Tree"], help="NCCL_ALGO for the ranks")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")
     ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc", "windows"],
                     help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")

@@ -9,8 +9,51 @@
   there is no bucketing/overlap machinery.  The target of gru_train.py:237-244 is built on the
   device (no host round trip, no per-sample Python loop).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# RCCL reads these when a communicator is created: the 1.69 MB gradient bucket of BASELINE config 4 is latency-bound on
+# xGMI (SURVEY.md section 8e), so the protocol (LL: 8-byte flagged stores, lowest latency; LL128: 128-byte lines over
+# xGMI; Simple: bandwidth) and the algorithm (Ring / Tree) are a run-time choice, priced per node by tools/scale_sweep.sh.
+RCCL_PROTOS = ("default", "LL", "LL128", "Simple")
+RCCL_ALGOS = ("default", "Ring", "Tree")
+
+
+def rccl_env(proto="default", algo="default"):
+    """Environment entries that select RCCL's protocol / algorithm ({} for the library's own size-based tuning)."""
+    if proto not in RCCL_PROTOS or algo not in RCCL_ALGOS:
+        raise ValueError(f"rccl_env: proto in {RCCL_PROTOS}, algo in {RCCL_ALGOS}")
+    env = {}
+    if proto != "default":
+        env["NCCL_PROTO"] = proto
+    if algo != "default":
+        env["NCCL_ALGO"] = algo
+    return env
+
+
+def configure_rccl(proto="default", algo="default"):
+    """Apply rccl_env() to THIS process.  Must run before the process group exists: RCCL reads the variables when the
+    communicator is created, a later change is silently ignored -- hence the error instead."""
+    env = rccl_env(proto, algo)
+    if env and dist.is_available() and dist.is_initialized():
+        raise RuntimeError("configure_rccl: the process group already exists; set the protocol before init_process_group "
+                           "(bench.py --rccl-proto does it in the ranks' environment)")
+    os.environ.update(env)
+    return env
+
+
+def replica_divergence(flat_w, group=None):
+    """max_r |w_r - w_0| over the ranks of a data-parallel job (identical replicas must stay bit-identical: same averaged
+    gradient, same fused Adam).  One broadcast + one MAX all-reduce; 0.0 without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0.0
+    ref = flat_w.detach().clone()
+    dist.broadcast(ref, src=0, group=group)
+    d = (flat_w.detach() - ref).abs().max().reshape(1)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+    return float(d.item())
 
 
 def _flat_order_params(module):
@@ -112,8 +155,16 @@ class FlatBucket:
 class DataParallelTrainer:
     """One optimisation step = forward, device-side target + MSE, backward, bucket all-reduce, fused Adam."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, split_allreduce=True, force_distributed=False):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, split_allreduce=True, force_distributed=False,
+                 proto=None, algo=None):
         from .engine import default_engine
+        # proto / algo: the RCCL protocol / algorithm this trainer is meant to run under (rccl_env).  They take effect only
+        # when set before the process group was created, so a mismatch with the environment is an error, not a silent no-op.
+        for name, want in (("NCCL_PROTO", proto), ("NCCL_ALGO", algo)):
+            if want not in (None, "default") and os.environ.get(name) != want:
+                raise RuntimeError(f"DataParallelTrainer: {name}={want} requested but the process runs with "
+                                   f"{os.environ.get(name)!r}; call configure_rccl() before init_process_group")
+        self.rccl = {k: os.environ.get(k, "default") for k in ("NCCL_PROTO", "NCCL_ALGO")}
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("DataParallelTrainer needs the model on the MI355X (no CPU fallback)")
@@ -177,3 +228,7 @@ class DataParallelTrainer:
         # counters did not move -- make the next model(x) (evaluation between steps, gru_train.py:253-261) load again
         e.invalidate_gru()
         return loss
+
+    def replica_divergence(self):
+        """max over ranks of |w_r - w_0| (0.0 = the replicas are still identical)."""
+        return replica_divergence(self.bucket.w, self.group)

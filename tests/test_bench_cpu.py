@@ -45,13 +45,16 @@ def test_gpus_2_starts_its_own_ranks_and_reports_the_process_group():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
-                       text=True, timeout=300, env=env)
+    env = {k: v for k, v in env.items() if k not in ("NCCL_PROTO", "NCCL_ALGO")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--rccl-proto", "LL128"],
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["launch_check"] is True and d["rccl_world_size"] == 2 and d["sum_of_ones"] == 2.0
+    # --rccl-proto reaches every rank's environment before its communicator exists (gloo ignores it; RCCL reads it there)
+    assert all(x["rccl_env"] == {"NCCL_PROTO": "LL128"} for x in d["rank_devices"])
     assert sorted(x["rank"] for x in d["rank_devices"]) == [0, 1]
     assert len({x["pid"] for x in d["rank_devices"]}) == 2            # two separate rank processes
 
@@ -63,3 +66,30 @@ def test_a_rank_with_the_wrong_world_size_refuses():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
                        text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_traffic_figure_is_served_only_with_matching_provenance(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/traffic.json (PMC passes of an earlier GPU visit): bench.load_traffic returns it only
+    when the entry's recorded object key equals the key of the sources on disk -- a kernel changed under the same name reports
+    null plus the reason in roofline.traffic_source."""
+    import json
+    import bench
+    from optistate_amd import build as b
+    key = b.object_key("fused_kernels.hip", b.toolchain_id())
+    (tmp_path / "profiles").mkdir()
+    tj = tmp_path / "profiles" / "traffic.json"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    entry = {"fused_kf_gru_kernel_v2": 1.7e9,
+             "fused_kf_gru_kernel_v2_detail": {"source_key": key, "source": "fused_kernels.hip", "collected": "2026-10-03"}}
+    tj.write_text(json.dumps(entry))
+    v, src = bench.load_traffic("fused_kf_gru_kernel_v2<true, false>", True)
+    assert v == 1.7e9 and key in src and "2026-10-03" in src
+    assert bench.load_traffic("fused_kf_gru_kernel_v2", False) == (None, "not collected for this shape / mode")
+    entry["fused_kf_gru_kernel_v2_detail"]["source_key"] = "0" * 24
+    tj.write_text(json.dumps(entry))
+    v, src = bench.load_traffic("fused_kf_gru_kernel_v2", True)
+    assert v is None and "stale" in src
+    del entry["fused_kf_gru_kernel_v2_detail"]["source_key"]          # an entry from before provenance was recorded
+    tj.write_text(json.dumps(entry))
+    assert bench.load_traffic("fused_kf_gru_kernel_v2", True)[0] is None
+    assert bench.load_traffic("kf_run_sym_kernel", True)[0] is None   # no entry at all

@@ -132,3 +132,49 @@ def test_shard_range_covers_every_unit_once():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_replica(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from optistate_amd.train import replica_divergence, configure_rccl
+        w = torch.arange(1000, dtype=torch.float32) * 1e-3
+        same = replica_divergence(w)
+        if rank == 1:
+            w[617] += 2.5e-4                                   # one replica drifts in one parameter
+        drift = replica_divergence(w)
+        try:
+            configure_rccl("LL")                               # too late: the group exists
+            late = "accepted"
+        except RuntimeError:
+            late = "refused"
+        ret[rank] = (same, drift, late)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replica_divergence_world_2():
+    """bench.py --mode train reports max_r |w_r - w_0| after the timed steps: every rank sees the same
+    figure, 0.0 for identical replicas, the drift otherwise; the RCCL protocol cannot be changed once the group exists."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_replica, args=(world, 29700 + os.getpid() % 1000, ret), nprocs=world, join=True)
+    for r in range(world):
+        same, drift, late = ret[r]
+        assert same == 0.0 and abs(drift - 2.5e-4) < 1e-7 and late == "refused"
+
+
+def test_rccl_env_knob():
+    from optistate_amd.train import rccl_env, configure_rccl, replica_divergence
+    assert rccl_env() == {} and rccl_env("LL128", "Tree") == {"NCCL_PROTO": "LL128", "NCCL_ALGO": "Tree"}
+    with pytest.raises(ValueError):
+        rccl_env("fast")
+    assert replica_divergence(torch.zeros(4)) == 0.0          # no process group: a single replica
+    old = {k: os.environ.get(k) for k in ("NCCL_PROTO", "NCCL_ALGO")}
+    try:
+        assert configure_rccl("LL") == {"NCCL_PROTO": "LL"} and os.environ["NCCL_PROTO"] == "LL"
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)

@@ -29,7 +29,7 @@ def test_default_mode_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     ro = d["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and "traffic" in ro
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and "traffic" in ro and "traffic_source" in ro
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["single_thread_value"] > 0 and cb["gru_half_torch_cpu"]["value"] > 0
@@ -52,7 +52,7 @@ def test_default_mode_contract():
 
 def _has_roofline_and_baseline(d):
     ro, cb = d["roofline"], d["cpu_baseline"]
-    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and "traffic" in ro
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and "traffic" in ro and "traffic_source" in ro
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["achieved"] > 0
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and "unit" in cb
 

@@ -17,6 +17,12 @@ for mode in fused train; do
         > $O/${mode}_n$n.json 2> $O/${mode}_n$n.err || echo "bench $mode n=$n failed (rc $?)" >&2
   done
 done
+# the latency-bound 1.69 MB gradient bucket under each RCCL protocol, at the largest world size
+for proto in LL LL128 Simple; do
+  n=$MAXG; [ $n -ge 2 ] || continue
+  timeout 900 python3 bench.py --gpus $n --mode train --rccl-proto $proto --steps 10 --warmup 3 --cpu-seconds 0 \
+      > $O/train_n${n}_$proto.json 2> $O/train_n${n}_$proto.err || echo "bench train n=$n proto=$proto failed (rc $?)" >&2
+done
 python3 - "$O" <<'PY'
 import glob, json, os, sys
 o = sys.argv[1]
@@ -34,4 +40,14 @@ for mode in ("fused", "train"):
         ar = d.get("allreduce_us")
         print(f"| {mode} | {d['n_gpus']} | {d['value']:.4g} | {d['unit']} | {d['ms_per_step']:.3f} | {eff:.3f} | "
               f"{'-' if ar is None else '%.1f' % ar} | {d.get('rccl_world_size')} |")
+print()
+print("| train, RCCL protocol | GPUs | ms/step | all-reduce us | replicas identical |")
+print("|---|---|---|---|---|")
+for f in sorted(glob.glob(os.path.join(o, "train_n*_*.json"))):
+    if os.path.getsize(f) == 0:
+        continue
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    ar = d.get("allreduce_us")
+    print(f"| {d.get('rccl', {}).get('NCCL_PROTO')} | {d['n_gpus']} | {d['ms_per_step']:.3f} | {'-' if ar is None else '%.1f' % ar} | "
+          f"{d.get('parity', {}).get('ok')} |")
 PY

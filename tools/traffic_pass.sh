@@ -26,5 +26,12 @@ for tag in ("cal", "run", "rows"):
 for k, d in res.items():
     if any(s in k for s in ("rd_dword", "wr_dword", "fused_kf_gru", "kf_run_sym", "kf_run_rows2")):
         print(k, {c: "%.4g" % v for c, v in d.items()})
+# provenance, recorded where and when the counters were read: the content keys of the objects the measured kernels live in
+import sys, datetime
+sys.path.insert(0, "$R")
+from optistate_amd import build as b, _capi
+tool = b.toolchain_id()
+res["_provenance"] = {"keys": {s: b.object_key(s, tool) for s in ("fused_kernels.hip", "kf_kernels.hip", "kf_rows_kernel.hip")},
+                      "build_id": _capi.load().os_build_id().decode(), "collected": datetime.date.today().isoformat()}
 json.dump(res, open("$OUT/traffic_raw.json", "w"), indent=1)
 PY

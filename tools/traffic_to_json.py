@@ -21,16 +21,23 @@ fr = raw["rd_dword"]["FETCH_SIZE"] / GiB_KiB
 wr = raw["wr_dword"]["WRITE_SIZE"] / GiB_KiB
 out = {"_calibration": {"fetch_reported_over_actual": fr, "write_reported_over_actual": wr,
                         "correction": "bytes = (FETCH_SIZE / fetch_ratio + WRITE_SIZE / write_ratio) * 1024"}}
+prov = raw.get("_provenance", {})
+SRC = {"fused_kf_gru_kernel_v2": "fused_kernels.hip", "fused_kf_gru_bf16_kernel": "fused_kernels.hip", "fused_kf_gru_kernel": "fused_kernels.hip",
+       "kf_run_sym_kernel": "kf_kernels.hip", "kf_run_rows2_kernel": "kf_rows_kernel.hip"}
 SHAPES = {"kf_run_rows2_kernel": "B=4096, T=1000 (BASELINE configs[1]), per launch"}
 for key, name in (("fused_kf_gru_kernel_v2", "fused_kf_gru_kernel_v2"), ("fused_kf_gru_bf16_kernel", "fused_kf_gru_bf16_kernel"),
                   ("kf_run_sym_kernel", "kf_run_sym_kernel"), ("fused_kf_gru_kernel<", "fused_kf_gru_kernel"),
                   ("kf_run_rows2_kernel", "kf_run_rows2_kernel")):
-    hit = [k for k in raw if key in k]
+    hit = [k for k in raw if key in k and not k.startswith("_")]
     if not hit:
         continue
     d = raw[hit[0]]
     rb, wb = d.get("FETCH_SIZE", 0.0) / fr * 1024, d.get("WRITE_SIZE", 0.0) / wr * 1024
     out[name] = rb + wb
-    out[name + "_detail"] = {"read_bytes": rb, "write_bytes": wb, "shape": SHAPES.get(name, "B=65536, T=100 (bench shape), per launch")}
+    out[name + "_detail"] = {"read_bytes": rb, "write_bytes": wb, "shape": SHAPES.get(name, "B=65536, T=100 (bench shape), per launch"),
+                             # provenance (bench.py load_traffic): the content key of the object this kernel was compiled into, as
+                             # recorded ON THE GPU BOX by tools/traffic_pass.sh when the counters were read, and the date
+                             "source_key": prov.get("keys", {}).get(SRC.get(name)), "source": SRC.get(name),
+                             "build_id": prov.get("build_id"), "collected": prov.get("collected")}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
