@@ -163,6 +163,12 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
         __builtin_amdgcn_s_waitcnt(0x0f7c);                            // vmcnt(12): step 0 has landed, step 1's twelve loads may be in flight
         __builtin_amdgcn_wave_barrier();
         lds_issue_step(stage[0], lane, raw);
+    } else {
+        // step 0's twelve DMA loads are the only VMEM operations in flight here, so the loop's vmcnt(12) would return before any
+        // of them has landed: wait for them explicitly once (until round 4 only hipcc's own vmcnt(0) in front of the visible
+        // ds_reads of read_step_lds_p ordered the first pick-up)
+        __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
+        __builtin_amdgcn_wave_barrier();
     }
 #ifdef OS_SYM_TS
     OS_TS_DECL
@@ -177,9 +183,9 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             const int tn = t + 2 < a.T ? t + 2 : a.T - 1;
             load_step_dma(a, tn, vo4, rowB, stage[(t + 2) % 3]);
         } else {
-            // vmcnt(12): step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in issue
-            // order with the loads, and the twelve x_out stores of step t - 1 were issued a few instructions ago -- everything
-            // older than the last twelve operations includes every DMA load.
+            // vmcnt(12), t >= 1: step t has landed (requested a whole step ago).  Not vmcnt(0): stores count too and complete in
+            // issue order with the loads, and the twelve x_out stores of step t - 1 were issued a few instructions ago --
+            // everything older than the last twelve operations includes every DMA load.  (t = 0: see the wait before the loop.)
             __builtin_amdgcn_s_waitcnt(0x0f7c);
             __builtin_amdgcn_wave_barrier();
             read_step_lds_p(stage[t & 1], lane, in);

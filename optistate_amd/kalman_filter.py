@@ -13,9 +13,18 @@ Differences from the reference, all deliberate (SURVEY.md section 5 "race detect
     settings.INITIAL_PARAMS, kalman_filter/kalman_filter.py:10,27-29);
   * get_odom is defined for 0 and 4 stance legs (the reference raises ValueError there);
   * the convex-MPC QP inside predict_mpc (misc/force_controller.py:70-162, casadi/qpOASES in the reference) is solved
-    by the library's own exact active-set kernel (os_mpc_solve); pass f= to replay logged forces instead.
+    by the library's own exact active-set kernel (os_mpc_solve); pass f= to replay logged forces instead;
+  * update() raises numpy.linalg.LinAlgError when S = H P H^T + R is not POSITIVE DEFINITE (status bit 0 of os_kf_step: a
+    Cholesky pivot <= 0 or non-finite).  The reference's np.linalg.inv (kalman_filter.py:168) raises only for an exactly
+    singular S and would carry an indefinite, invertible S through (reachable only after predict_mpc's element-wise
+    exp(dt F) has destroyed P's definiteness): there this class raises where the reference continues with a meaningless
+    gain.  A positive definite S -- every case a covariance filter is defined for -- takes the same path in both;
+  * threads: the reference is single-threaded.  Here every instance stages its step through the engine context's one
+    pinned block, so os_kf_step calls on one engine are serialised by a per-engine lock (different engines / GPUs run
+    concurrently).
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -84,11 +93,13 @@ class Kalman_Filter:
                 b[key][:] = np.asarray(v, dtype=np.float64).reshape(-1)[:n]
         if contact is not None:
             b["c"][:] = np.asarray(contact).reshape(-1)[:4]
-        rc = e.lib.os_kf_step(e._h, what, q["model"], q["p"] if p is not None else None, q["f"] if f is not None else None,
-                              q["dp"] if dp is not None else None, q["imu"] if imu is not None else None,
-                              q["c"] if contact is not None else None, q["br"] if body_ref is not None else None, q["Q"], q["R"],
-                              q["x"], q["P"], q["z"], q["prot"], q["xm"], q["K"] if want_K else None, q["pt"], q["kg"], q["st"],
-                              e._stream())
+        lock = e.__dict__.setdefault("_kf_step_lock", threading.Lock())     # the context's staging block is shared by every instance
+        with lock:                                     # os_kf_step returns after its stream synchronise: results are in b[...] here
+            rc = e.lib.os_kf_step(e._h, what, q["model"], q["p"] if p is not None else None, q["f"] if f is not None else None,
+                                  q["dp"] if dp is not None else None, q["imu"] if imu is not None else None,
+                                  q["c"] if contact is not None else None, q["br"] if body_ref is not None else None, q["Q"], q["R"],
+                                  q["x"], q["P"], q["z"], q["prot"], q["xm"], q["K"] if want_K else None, q["pt"], q["kg"], q["st"],
+                                  e._stream())
         if rc:
             e._check(rc, "os_kf_step")
         if what & OS_STEP_ODOM:
