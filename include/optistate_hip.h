@@ -127,7 +127,9 @@ int os_kf_set_noise(os_ctx *ctx, const float *Q_host, const float *R_host);
  * (kalman_filter/kalman_filter.py:79-138,164-174; caller loop
  * data_collection/data_conversion_Kalman_to_Training.py:193-199) for B trajectories x T steps.
  * x, P are in/out.  p_rot_out (world-rotated p, the in-place side effect of next_state,
- * misc/force_controller.py:274-277), ptrace_out (P_trace), kgain_out (K_gain; batch form only),
+ * misc/force_controller.py:274-277), ptrace_out (P_trace), kgain_out (K_gain = np.trace(K), kalman_filter.py:174: the batch
+ * form sums the diagonal of the K it built; the sequential / symmetric / 16-lane forms, which never form K, evaluate
+ * trace(P+ H^T R^-1) = sum_a P+[a][sel a] / R[a][a] on their posterior covariance -- the same number for the optimal gain),
  * body_ref may be NULL. */
 int os_kf_run(os_ctx *ctx, int32_t B, int32_t T,
               const float *p, const float *f, const float *dp, const float *imu, const uint32_t *contact,
@@ -148,7 +150,8 @@ int os_kf_run_noise(os_ctx *ctx, int32_t B, int32_t T,
 /* Single-instance pieces for the drop-in Kalman_Filter class (B = 1 views over the same kernels).
  * os_kf_odom   : get_odom + set_measurements (kalman_filter/kalman_filter.py:79-117) -> z [10][B]
  * os_kf_predict: predict(p, f) (kalman_filter/kalman_filter.py:119-138); p [12][B] is rotated in place.
- * os_kf_update : update() (kalman_filter/kalman_filter.py:164-174); K_out [120][B] (12x10 row-major) optional. */
+ * os_kf_update : update() (kalman_filter/kalman_filter.py:164-174); K_out [120][B] (12x10 row-major) optional; with
+ *                OS_KF_SEQUENTIAL_UPDATE (diagonal R) K_out / kgain_out are formed from the posterior: K = P+ H^T R^-1. */
 int os_kf_odom(os_ctx *ctx, int32_t B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
                float *z, void *stream);
 int os_kf_predict(os_ctx *ctx, int32_t B, float *p, const float *f, const float *body_ref, float *x, float *P,

@@ -935,6 +935,26 @@ __device__ __forceinline__ void sym_load(f2 *U, LoadF ld)
         for (int jp = i / 2; jp < 6; jp++) U[pidx(i, jp)] = (f2){ld(i * NS + 2 * jp), ld(i * NS + 2 * jp + 1)};
 }
 
+// K_gain = np.trace(K) (kalman_filter.py:174: the ten main-diagonal entries of the 12 x 10 gain) WITHOUT forming K: for the
+// optimal gain K = P- H^T S^-1 = P+ H^T R^-1, so with the diagonal R the sequential update requires K[i][a] = P+[i][sel a] / R[a][a]
+// and trace(K) = sum_a P+[a][sel a] / R[a][a] -- ten divisions on the posterior covariance the sequential forms end with.
+template <typename PT>
+__device__ __forceinline__ float kgain_from_posterior(const PT *P, const KfConst &k)
+{
+    PT t = 0;
+#pragma unroll
+    for (int a = 0; a < NM; a++) t += P[a * NS + SEL[a]] / (PT)k.R[a * NM + a];
+    return (float)t;
+}
+
+__device__ __forceinline__ float kgain_from_posterior_sym(const f2 *U, const KfConst &k)
+{
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < NM; a++) t += OSK_SYM(U, a, SEL[a]) / k.R[a * NM + a];
+    return t;
+}
+
 template <typename PT>
 __device__ __forceinline__ float trace12(const PT *P)
 {
@@ -990,8 +1010,10 @@ __device__ __forceinline__ int kf_step_back(float *x, PT *P, const float *z, con
                                             float *kgain)
 {
     int st;
-    if (SEQ) st = update_sequential(x, P, z, k);
-    else st = update_batch<AUX, PT>(x, P, z, k, nullptr, kgain);
+    if (SEQ) {
+        st = update_sequential(x, P, z, k);
+        if (AUX) *kgain = kgain_from_posterior(P, k);
+    } else st = update_batch<AUX, PT>(x, P, z, k, nullptr, kgain);
     if (AUX) *ptrace = trace12(P);
     return st | finite_status(x);
 }

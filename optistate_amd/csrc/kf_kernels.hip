@@ -242,6 +242,7 @@ __device__ __forceinline__ void kf_run_sym_body(const KfRunArgs &a, const KfCons
             for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, vst, rowB, i, X[i / 2][i & 1]);
         }
         if (OUT == 1 && a.ptrace_out && live) a.ptrace_out[(size_t)t * B + b] = trace_sym(U);
+        if (OUT == 1 && a.kgain_out && live) a.kgain_out[(size_t)t * B + b] = kgain_from_posterior_sym(U, kc);
     }
     {
         rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
@@ -512,6 +513,13 @@ __global__ __launch_bounds__(64, 1) void kf_update_kernel(int B, const float *z,
     float kg = 0.f;
     if (SEQ) {
         st = update_sequential(xx, PP, zz, k);
+        kg = kgain_from_posterior(PP, k);
+        if (K_out) {                                   // K = P+ H^T R^-1 (diagonal R): the batch gain from the posterior
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+#pragma unroll
+                for (int a = 0; a < NM; a++) K_out[(size_t)(i * NM + a) * B + b] = PP[i * NS + SEL[a]] / (PT)k.R[a * NM + a];
+        }
     } else {
         PT K[NS * NM];
         st = update_batch<true, PT>(xx, PP, zz, k, K, &kg);
@@ -581,9 +589,6 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE, dense = flags & OS_KF_DENSE_FD;
     if (dense && !a.body_ref) return os_fail(ctx, -2, "os_kf_run: OS_KF_DENSE_FD needs body_ref");
     if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_run: sequential update needs a diagonal R");
-#ifndef OS_ROWS_TS
-    if (seq && a.kgain_out) return os_fail(ctx, -3, "os_kf_run: K_gain is only defined by the batch update");
-#endif
     if ((size_t)a.B * 144 * 4 >= 0xffffffffull) return os_fail(ctx, -2, "os_kf_run: B too large for 32-bit buffer offsets");
     a.k = ctx->k;
 #ifdef OS_ROWS_TS
@@ -594,17 +599,17 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     if (feat && aux) return os_fail(ctx, -3, "os_kf_run: feature emission and P_trace/K_gain outputs are exclusive");
     hipError_t e;
     const bool noise = a.q_diag != nullptr;
-    if (noise && (!seq || dense || a.kgain_out || !a.r_diag))
-        return os_fail(ctx, -3, "os_kf_run_noise: per-trajectory noise needs the sequential update, predict(p,f) covariance, no K_gain");
+    if (noise && (!seq || dense || !a.r_diag))
+        return os_fail(ctx, -3, "os_kf_run_noise: per-trajectory noise needs the sequential update and the predict(p,f) covariance");
 #ifdef OS_ROWS_TS
     const bool no_gain = true;                 // development build: kgain_out carries the timestamp sums
 #else
-    const bool no_gain = !a.kgain_out;
+    const bool no_gain = ctx->tune_rows_v1 ? !a.kgain_out : true;      // rows2 forms K_gain from the posterior; the v1 rows kernel does not
 #endif
     // (the rows kernel carries a step's position in a 32-bit SGPR offset: T * 48 B bytes must fit)
     const bool use_rows = !noise && seq && !dense && no_gain && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
                           a.B < ctx->rows_kernel_below && ctx->kf_qr && (uint64_t)a.T * 48ull * (uint64_t)a.B < 0xffffffffull;
-    const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise) && !a.kgain_out;
+    const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise);
     const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
                         : dense ? (seq ? "kf_run_kernel<SEQ,DENSE_F64>" : "kf_run_kernel<BATCH,DENSE_F64>")
                                 : (seq ? "kf_run_kernel<SEQ>" : "kf_run_kernel<BATCH>");
@@ -733,7 +738,7 @@ int os_kf_update(os_ctx *ctx, int32_t B, const float *z, float *x, float *P, flo
     if (B <= 0 || !z || !x || !P) return os_fail(ctx, -2, "os_kf_update: bad argument");
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE;
     if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_update: sequential update needs a diagonal R");
-    if (seq && (K_out || kgain_out)) return os_fail(ctx, -3, "os_kf_update: K is only formed by the batch update");
+    if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_update: sequential update needs a diagonal R");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid((B + 63) / 64), block(64);
     hipStream_t s = (hipStream_t)stream;

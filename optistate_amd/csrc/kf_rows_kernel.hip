@@ -305,6 +305,17 @@ __global__ __launch_bounds__(256, 2) void kf_run_rows2_kernel(const KfRunArgs a,
             dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
             if (live && r == 0) a.ptrace_out[(size_t)t * B + b] = dg;
         }
+#ifndef OS_ROWS_TS
+        if (AUX && a.kgain_out) {
+            // K_gain = trace(P+ H^T R^-1) (kgain_from_posterior, kf_device.hpp): lane r < 10 holds row r, its term is P+[r][SEL[r]] / R[r][r]
+            float kg = Prow[0] / Rd[0];
+#pragma unroll
+            for (int i = 1; i < NM; i++) kg = (r == i) ? Prow[SEL[i]] / Rd[i] : kg;
+            kg = r < NM ? kg : 0.f;
+            kg += __shfl_xor(kg, 1, 64); kg += __shfl_xor(kg, 2, 64); kg += __shfl_xor(kg, 4, 64); kg += __shfl_xor(kg, 8, 64);
+            if (live && r == 0) a.kgain_out[(size_t)t * B + b] = kg;
+        }
+#endif
     }
 #ifdef OS_ROWS_TS
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.kgain_out) {

@@ -145,7 +145,7 @@ class Engine:
         full P like the reference (kalman_filter.py:172 never symmetrises)."""
         T, _, B = p.shape
         if sequential is None:
-            sequential = self._diag_R and not want_gain
+            sequential = self._diag_R           # K_gain no longer forces the batch form: trace(P+ H^T R^-1) on the posterior
         if symmetric is None:
             symmetric = sequential and not dense_fd and self._sym_Q
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
@@ -350,6 +350,19 @@ class Engine:
         B = p.shape[1]
         self._check(self.lib.os_kf_predict(self._h, B, _ptr(p), _ptr(f), _ptr(body_ref), _ptr(x), _ptr(P), None,
                                            OS_KF_DENSE_FD if body_ref is not None else 0, self._stream()), "os_kf_predict")
+
+    def kf_update(self, z, x, P, sequential=False, want_K=False):
+        """update() (kalman_filter.py:164-174) for B trajectories: z [10][B]; x [12][B], P [144][B] in place.
+        Returns dict(status [B], P_trace [B], K_gain [B], K [120][B] (12 x 10 row-major) if want_K).  sequential=True (diagonal R)
+        never forms K during the update; K and K_gain then come from the posterior, K = P+ H^T R^-1."""
+        B = x.shape[1]
+        mk = lambda n: torch.empty((n, B) if n > 1 else (B,), dtype=torch.float32, device=self.device)
+        K = mk(120) if want_K else None
+        ptr, kg = mk(1), mk(1)
+        status = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.os_kf_update(self._h, B, _ptr(z), _ptr(x), _ptr(P), _ptr(K), _ptr(ptr), _ptr(kg), _ptr(status),
+                                          OS_KF_SEQUENTIAL_UPDATE if sequential else 0, self._stream()), "os_kf_update")
+        return dict(status=status, P_trace=ptr, K_gain=kg, K=K)
 
     # ---- convex-MPC ground-reaction forces (misc/force_controller.py:70-162, kalman_filter.py:141-152) ----
     def mpc_set_weights(self, q_weights, r_weight=1e-6, mu=0.6, fz_max=150.0):

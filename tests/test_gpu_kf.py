@@ -44,7 +44,7 @@ VIDS = ["batch", "seq-lanes", "sym-lanes", "rows"]
 def test_g3_trajectory_matches_reference(eng, s, v):
     g = load_golden("kf_g3_traj.npz")
     sequential = v["sequential"]
-    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], 2, want_p_rot=True, want_trace=True, want_gain=not sequential, **v)
+    r = run(eng, g, g[f"Q{s}"], g[f"R{s}"], 2, want_p_rot=True, want_trace=True, want_gain=True, **v)
     xo = eng.unpack(r["x_out"]).cpu().numpy()
     pr = eng.unpack(r["p_rot"]).cpu().numpy()
     for b in range(2):
@@ -52,9 +52,10 @@ def test_g3_trajectory_matches_reference(eng, s, v):
         assert np.abs(pr[b] - g[f"s{s}_b{b}_p_rot"]).max() < 1e-5
         ptr = r["P_trace"].cpu().numpy()[:, b]
         assert np.abs(ptr / g[f"s{s}_b{b}_P_trace"] - 1).max() < 1e-3
-        if not sequential:
-            kg = r["K_gain"].cpu().numpy()[:, b]
-            assert np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max() < 1e-3
+        # K_gain = np.trace(K) (kalman_filter.py:174) from every family: the batch form sums the K it built, the sequential /
+        # symmetric / 16-lane forms evaluate trace(P+ H^T R^-1) on their posterior (they never form K)
+        kg = r["K_gain"].cpu().numpy()[:, b]
+        assert np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max() < 1e-3 * max(1.0, np.abs(g[f"s{s}_b{b}_K_gain"]).max()), (np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max())
         Pf = r["P_final"].cpu().numpy()[:, b].reshape(12, 12)
         ref = g[f"s{s}_b{b}_P_final"]
         assert np.abs(Pf - ref).max() < 1e-3 * np.abs(ref).max()
@@ -325,3 +326,31 @@ def test_sym_lane_kernel_short_and_ragged(eng, B, T):
     Pf = r["P_final"].cpu().numpy().T.reshape(B, 12, 12)
     assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
     assert int(r["status"].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("s", [0, 1])
+@pytest.mark.parametrize("sequential", [False, True], ids=["batch", "sequential"])
+def test_update_entry_point_gain_matches_reference(eng, s, sequential):
+    """os_kf_odom -> os_kf_predict -> os_kf_update through the C-ABI on step 0 of G3: K (12 x 10), K_gain = np.trace(K) and the
+    posterior against the reference's (kalman_filter.py:164-174).  The sequential form never builds K during the update: K and
+    K_gain come from the posterior, K = P+ H^T R^-1 -- the same matrix for the optimal gain."""
+    g = load_golden("kf_g3_traj.npz")
+    Q, R = g[f"Q{s}"], g[f"R{s}"]
+    eng.set_noise(Q, R)
+    col = lambda k, n: torch.as_tensor(np.ascontiguousarray(np.asarray(g[k][:, 0, :n], dtype=np.float32).T)).cuda()
+    p, f, dp, imu = col("p", 12), col("f", 12), col("dp", 12), col("imu", 6)
+    c = torch.as_tensor(np.asarray(g["contact"][:, 0])).cuda().contiguous().view(torch.int32).reshape(-1)
+    x = torch.as_tensor(np.asarray(g["x0"], dtype=np.float32).T.copy()).cuda()
+    P = torch.as_tensor(np.tile(np.asarray(Q, dtype=np.float32).reshape(144, 1), (1, 2))).cuda()
+    z = eng.kf_odom(p, dp, c, imu)
+    eng.kf_predict(p, f, x, P)
+    r = eng.kf_update(z, x, P, sequential=sequential, want_K=True)
+    torch.cuda.synchronize()
+    assert int(r["status"].abs().sum()) == 0
+    for b in range(2):
+        K = r["K"].cpu().numpy()[:, b].reshape(12, 10)
+        Kref = g[f"s{s}_b{b}_K0"]
+        assert np.abs(K - Kref).max() < 2e-5 * max(1.0, np.abs(Kref).max()), np.abs(K - Kref).max()
+        assert abs(float(r["K_gain"][b]) - g[f"s{s}_b{b}_K_gain"][0]) < 1e-4 * max(1.0, abs(g[f"s{s}_b{b}_K_gain"][0]))
+        assert abs(float(r["P_trace"][b]) / g[f"s{s}_b{b}_P_trace"][0] - 1) < 1e-4
+        assert np.abs(x.cpu().numpy()[:, b] - g[f"s{s}_b{b}_x"][0]).max() < STATE_TOL
