@@ -557,7 +557,7 @@ def bench_train(a, rk):
                                     "parallelism": f"dp{rk.world}, one flat fp32 bucket all-reduce", "baseline_config": "BASELINE.json configs[3]"})
         tot = fl_fwd + fl_sweep + fl_dw
         out["roofline"] = {"kernel": dk["kernel"] + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": dk["ms_per_launch"],
+                           "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": dk["ms_per_launch"],
                            "algorithmic_flops_per_launch": fl_launch,
                            "whole_step": {"algorithmic_TFLOP": tot / 1e12, "achieved_TFLOPs": tot / (el / a.steps) / 1e12,
                                           "frac": tot / (el / a.steps) / 1e12 / MFMA_F32_PEAK_TF}}
@@ -619,7 +619,7 @@ def bench_full(a, rk):
             ach = fl_launch / (dk["ms_per_launch"] * 1e-3) / 1e12
             kname = dk["kernel"] if dom != "vit_gemm" else "ViT projections: vit_gemm_kernel<...> (patch, first qkv) + vit_mlp_kernel[_bm64] (proj + LN + fc1 + GELU + fc2 + next LN + next qkv)"
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": dk["ms_per_launch"],
+                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": dk["ms_per_launch"],
                                "algorithmic_flops_per_launch": fl_launch, "phase": dom,
                                "note": "average over the launches of the phase (the projections differ in shape)"}
         out["kernels"] = kernels
@@ -662,7 +662,7 @@ def bench_mpc(a, rk):
         bps = 268
         ach = bps * B * T / (el / a.steps) / 1e9
         out["roofline"] = {"kernel": kernels.get("mpc", {}).get("kernel", "mpc_solve_kernel"), "bound": "hbm", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": "not collected for this mode",
                            "algorithmic_bytes_per_step": bps,
                            "limiter": "latency: a dependent float64 elimination per active-set iteration, one QP per wavefront (not a roofline kernel)"}
         out.update(qp_iterations_mean=float(it.mean()), qp_iterations_max=int(it.max()),
@@ -697,7 +697,7 @@ def bench_windows(a, rk):
             fl = gru_flops_per_step(I, H, L) * N * T / dk["launches_per_step"]
             ach = fl / (dk["ms_per_launch"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": dk["kernel"] + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
-                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "traffic_source": "not collected for this mode",
                                "avg_launch_ms": dk["ms_per_launch"]}
         out["kernels"] = kernels
         out.update(info)
@@ -788,7 +788,7 @@ def bench_hot_path(a, rk):
         insn = ("v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if a.split_bf16 == 3 else "v_mfma_f32_32x32x16_bf16 x3 (hi/lo split)") \
             if (a.split_bf16 and dom == "fused") else "v_mfma_f32_32x32x2_f32"
         roof = {"kernel": f"{dk['kernel']} ({insn})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": fl}
+                "frac": ach / peak, "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": fl}
         if a.split_bf16 and dom == "fused":
             roof["note"] = ("algorithmic (fp32-equivalent) GRU flops against the bf16 dense peak; the kernel is VALU-bound "
                             "(Kalman step + operand splitting), not matrix-bound")
@@ -800,7 +800,7 @@ def bench_hot_path(a, rk):
     else:
         ach = BYTES_PER_STEP_KF * steps_per_pass / (avg_ms * 1e-3) / 1e9
         roof = {"kernel": dk["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": avg_ms,
                 "algorithmic_bytes": BYTES_PER_STEP_KF * steps_per_pass}
         # the filter is ~35 flop/byte in its structured form: beside the HBM figure report the fp32 vector-pipe figure
         tf = KF_FLOPS_STRUCTURED * steps_per_pass / (avg_ms * 1e-3) / 1e12
