@@ -50,6 +50,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_KF_ROWS_V1"); c->tune_rows_v1 = e ? atoi(e) : 0;
         e = getenv("OS_GRU_SPLIT"); c->tune_gru_split = e ? (atoi(e) != 0 ? -1 : 0) : -1;
         e = getenv("OS_GRU_AHEAD"); c->tune_gru_ahead = e ? atoi(e) : 1;
+        e = getenv("OS_GRU_STAGE"); c->tune_gru_stage = e ? atoi(e) : 1;
         e = getenv("OS_MPC_PERSISTENT"); c->tune_mpc_persistent = e ? atoi(e) : 1;
         e = getenv("OS_VIT_MLP_FUSED"); c->tune_vit_mlp_fused = e ? atoi(e) : 3;
         e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 512;      // 2 x 240 workgroups at the training batch: two per CU

@@ -26,6 +26,23 @@ using osk::buf_load;
 using osk::make_rsrc;
 using osk::rsrc_t;
 
+// Development build only (-DOS_LAYER_TS, tools/layer_ts.sh): shader-clock stamps at the phase boundaries of a step, summed over
+// the steps by thread 0 of workgroup 0 and printed (gru_layer_kernel and gru_layer_stage_kernel).
+#ifdef OS_LAYER_TS
+#define OSL_TS_DECL unsigned long long ts_prev = 0, ts_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define OSL_TS(i)                                                                  \
+    {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        const unsigned long long now = __builtin_readcyclecounter();               \
+        if ((i) > 0) ts_sum[i] += now - ts_prev;                                   \
+        ts_prev = now;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    }
+#else
+#define OSL_TS_DECL
+#define OSL_TS(i)
+#endif
+
 // One half of the gate GEMM (input part: XPART, accumulates gi_n into acc[.][2]; recurrent part: gh_n into acc[.][3]).
 // Software pipeline, DEPTH k-pairs deep: the B fragments (coalesced dword loads of the fragment-ordered weights,
 // L2-resident) and the A fragments (x part: one 128-B segment per k straight from the SoA stream; h part: LDS) of
@@ -38,16 +55,56 @@ __device__ __forceinline__ void mfma_part(f32x16 (*acc)[4], const float *wbase, 
     // weights: wave-uniform descriptor + SGPR offset (k-pair, gate) + constant per-lane offset -> no address VALU
     const rsrc_t w = make_rsrc(wbase, (uint32_t)KP * 3 * 256);
     const uint32_t wl = (uint32_t)lane * 4u;
+    int q0 = 0;
+    // Steady state: every k-pair of the block and every re-request is in range, so neither the prologue nor the body has a
+    // conditional, and the loop is entered from that prologue ONLY.  (Round 4: hipcc's wait-count pass keeps one state per basic
+    // block.  With the requests behind `if (q + DEPTH < KP)`, or with a guarded prologue merging into the loop header, the number
+    // of loads younger than the fragment it needs differs per path, the merge keeps the smallest, and the pass drained the whole
+    // queue -- s_waitcnt vmcnt(2) / (1) / (0) at the top of every block -- in every GRU layer kernel: the prefetch distance was
+    // one k-pair, not DEPTH.  Like this it emits the exact counts, e.g. vmcnt(15) for DEPTH = 4, RBW = 2.)
+    if (KP >= 2 * DEPTH) {
 #pragma unroll
-    for (int j = 0; j < DEPTH; j++) {
-        if (j < KP) {
+        for (int j = 0; j < DEPTH; j++) {
 #pragma unroll
             for (int g = 0; g < 3; g++) wb[j][g] = buf_load(w, wl, (uint32_t)(j * 3 + g) * 256u);
 #pragma unroll
             for (int rb = 0; rb < RBW; rb++) ab[j][rb] = afrag(j, rb);
+            // in request order: left alone, the scheduler issues slot 0's first fragment LAST, and the wait for the youngest
+            // load at the loop header is vmcnt(0) on every iteration
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; q0 + 2 * DEPTH <= KP; q0 += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
+                const int q = q0 + j;
+#pragma unroll
+                for (int rb = 0; rb < RBW; rb++) {
+                    const float av = ab[j][rb];
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[j][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[j][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][XPART ? 2 : 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[j][2], acc[rb][XPART ? 2 : 3], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+                    wb[j][g] = buf_load(w, wl, __builtin_amdgcn_readfirstlane((uint32_t)((q + DEPTH) * 3 + g) * 256u));
+#pragma unroll
+                for (int rb = 0; rb < RBW; rb++) ab[j][rb] = afrag(q + DEPTH, rb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            if (j < KP) {
+#pragma unroll
+                for (int g = 0; g < 3; g++) wb[j][g] = buf_load(w, wl, (uint32_t)(j * 3 + g) * 256u);
+#pragma unroll
+                for (int rb = 0; rb < RBW; rb++) ab[j][rb] = afrag(j, rb);
+            }
         }
     }
-    for (int q0 = 0; q0 < KP; q0 += DEPTH) {
+    // tail: the last DEPTH .. 2 DEPTH - 1 k-pairs, requests guarded
+    for (; q0 < KP; q0 += DEPTH) {
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
             const int q = q0 + j;
@@ -126,10 +183,13 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
         }
     };
 
+    OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
+        OSL_TS(0)
         const float *hl = hl2 + (t & 1) * BM * HS;          // h_{t-1}
         float *hn_buf = hl2 + ((t + 1) & 1) * BM * HS;       // h_t
         if (t > 0 && a.seq_out) write_back(hl, a.seq_out + (size_t)(t - 1) * H * B);
+        OSL_TS(1)                                            // write-back of h_{t-1} (LDS -> SoA)
 
         f32x16 acc[RBW][4];
 #pragma unroll
@@ -157,9 +217,11 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
                 acc[rb][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w_n, acc[rb][2], 0, 0, 0);
             }
         }
+        OSL_TS(2)                                            // x half of the gate GEMM
         mfma_part<RBW, false>(acc, wh, a.KPh, lane, [&](int q, int rb) {
             return hl[((row_blk0 + rb) * 32 + li) * HS + 2 * q + lh];
         });
+        OSL_TS(3)                                            // h half
 
         // ---- cell update on the accumulator layout: col = lane&31 (hidden unit), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
@@ -188,11 +250,248 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
                 }
             }
         }
+        OSL_TS(4)                                            // cell update
         lds_barrier();   // h_t complete; every wave is also done with h_{t-1}, which the NEXT epilogue overwrites
+        OSL_TS(5)
     }
+#ifdef OS_LAYER_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("gru_layer_kernel<%d,%d> K=%d cycles per step: write-back %llu | x half %llu | h half %llu | cell update %llu | barrier %llu | sum %llu\n",
+               RBW, OCC, a.K, ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T,
+               (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5]) / a.T);
+#endif
     const float *hT = hl2 + (a.T & 1) * BM * HS;
     if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
     if (a.h_last) write_back(hT, a.h_last);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gru_layer_stage_kernel -- large batches, H = 128, inference: the x tile of a step goes global -> LDS by LDS-DMA one step
+// ahead, so the MFMA loop reads BOTH halves of its A operand from LDS and the only vector loads it waits for are the
+// L2-resident weight fragments.
+//
+// Why (round 4; in-kernel timestamps: profiles/r04_layer_timestamps.md): gru_layer_kernel fetches the x fragments straight
+// from the SoA stream inside the pipelined k loop.  At B = 65,536 that stream (3.3 GB per layer and pass) comes from HBM,
+// a wave's vector loads return in order, and so every HBM-latency x fragment holds up the weight fragments queued behind
+// it -- and all four waves of a workgroup (one per 32-column chunk) fetch the same x tile again (5.8x the algorithmic
+// bytes).  gru_layer_split_kernel cured the same disease at small batches by staging through registers; here
+// the tile is 64 rows x K <= 188 inputs = 48 KB, too much for registers, so it travels by `buffer_load ... lds`
+// (16 bytes per lane: one instruction moves 4 inputs x 64 rows), fetched ONCE per workgroup.
+//
+// LDS (80,896 B at K = 188: two workgroups per CU): hS [64][129] (odd stride: conflict-free A fragments) | xS [K4][64]
+// (input-major, K4 = K rounded up to 4: exactly what the DMA writes, and lane li of an A fragment reads bank li).
+// Single-buffered, two barriers per step:
+//   MFMAs of step t (x part from xS, h part from hS)  | barrier 1: every wave is done reading xS and hS
+//   DMA x_{t+1} -> xS (asynchronous), cell update of step t (h_{t-1} of the wave's own 2 x 16 elements lives in registers:
+//   no LDS read), h_t -> hS and, as four 16-byte stores per row block, straight to seq_out in SoA (an accumulator's
+//   elements e = 4j .. 4j+3 are four consecutive trajectories of one hidden unit) | vmcnt: the DMA has landed | barrier 2
+// Every LDS access inside the T loop is inline assembly: hipcc treats an LDS-DMA as aliasing every later LDS access and
+// puts s_waitcnt vmcnt(0) in front of each (which would serialise the DMA with the cell update and wait for the write-once
+// seq_out stores as well).  An A fragment's register is re-requested behind the FIRST MFMA of the following k-pair: the
+// matrix pipe reads an MFMA's A/B registers when the instruction starts, not when it issues.
+// Bit-identical to gru_layer_kernel: same products, same accumulation order.
+// ---------------------------------------------------------------------------------------------------------------
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// (non-template helpers: inside a kernel template hipcc's host pass drops the launch stub when it meets these builtins)
+__device__ __forceinline__ void stage_dma16(rsrc_t r, float *l, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void buf_store4_nt(rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 2);
+}
+template <int OFF>
+__device__ __forceinline__ float lds_read_asm(uint32_t addr)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_asm(uint32_t addr, float v)
+{
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+constexpr int STAGE_HS = 129, STAGE_BM = 64, STAGE_DEPTH = 4;
+
+// One half of the gate GEMM with the A fragments in LDS.  ap: byte address of this lane's fragment element of k-pair 0, row
+// block 0; QS / RS: byte strides of a k-pair / of the second row block (immediates).  XPART: gate n accumulates into acc[.][2]
+// (gi_n), else acc[.][3] (gh_n).  Software pipeline STAGE_DEPTH k-pairs deep; slot j - 1 is re-requested behind the first
+// MFMA of slot j.
+template <bool XPART, int QS, int RS>
+__device__ __forceinline__ void mfma_part_lds(f32x16 (*acc)[4], const float *wbase, int KP, int lane, uint32_t ap)
+{
+    constexpr int D = STAGE_DEPTH;
+    constexpr int G = XPART ? 2 : 3;
+    float wb[D][3], ab[D][2];
+    const rsrc_t w = make_rsrc(wbase, (uint32_t)KP * 3 * 256);
+    const uint32_t wl = (uint32_t)lane * 4u;
+    uint32_t wo = 0;                                     // byte offset of k-pair q0's fragments (SGPR)
+    // request k-pair (q0 + off_kp)'s fragments into slot j: two A elements from LDS (ap points at k-pair q0), three B fragments
+#define OSL_REQ(j, off_kp)                                                                                             \
+    {                                                                                                                   \
+        ab[j][0] = lds_read_asm<(off_kp) * QS>(ap);                                                                     \
+        ab[j][1] = lds_read_asm<(off_kp) * QS + RS>(ap);                                                                \
+        wb[j][0] = buf_load(w, wl, wo + (uint32_t)((off_kp) * 3 + 0) * 256u);                                           \
+        wb[j][1] = buf_load(w, wl, wo + (uint32_t)((off_kp) * 3 + 1) * 256u);                                           \
+        wb[j][2] = buf_load(w, wl, wo + (uint32_t)((off_kp) * 3 + 2) * 256u);                                           \
+    }
+    // k-pair in slot j: wait for its A elements (the asm operands tie the wait to the registers: the MFMAs cannot move above it),
+    // first MFMA, then -- behind a started MFMA of this k-pair, so that every MFMA of the previous one has read its operands --
+    // re-request the previous k-pair's slot, then the other five MFMAs
+#define OSL_STEP(j, jm, off_next, REQ)                                                                                 \
+    {                                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ab[j][0]), "+v"(ab[j][1])::"memory");                                \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[j][0], wb[j][0], acc[0][0], 0, 0, 0);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (REQ) OSL_REQ(jm, off_next)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[j][0], wb[j][1], acc[0][1], 0, 0, 0);                       \
+        acc[0][G] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[j][0], wb[j][2], acc[0][G], 0, 0, 0);                       \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[j][1], wb[j][0], acc[1][0], 0, 0, 0);                       \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[j][1], wb[j][1], acc[1][1], 0, 0, 0);                       \
+        acc[1][G] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[j][1], wb[j][2], acc[1][G], 0, 0, 0);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+    // KP >= 4 and KP even (H = 128: KPh = 64; K even): prologue fills the four slots
+    OSL_REQ(0, 0) OSL_REQ(1, 1) OSL_REQ(2, 2) OSL_REQ(3, 3)
+    // steady state: NO conditional inside -- with the requests behind `if (q + D < KP)` hipcc's wait-count pass cannot tell how
+    // many loads are younger than the one it needs (the count differs per path) and drains the queue (vmcnt(0)) at the top of
+    // every block of four k-pairs: the prefetch distance collapses from four k-pairs to one (gru_layer_kernel's loop does that)
+    int q0 = 0;
+    for (; q0 + 2 * D <= KP; q0 += D) {
+        // offsets relative to ap / wo (k-pair q0): slot j - 1 takes k-pair q0 + j - 1 + D
+        OSL_STEP(0, 3, D - 1, q0 > 0)
+        OSL_STEP(1, 0, D, true)
+        OSL_STEP(2, 1, D + 1, true)
+        OSL_STEP(3, 2, D + 2, true)
+        ap += D * QS;
+        wo += D * 3 * 256;
+    }
+    // tail: fewer than 2 D k-pairs left, every one of them already requested except those the guarded requests below add
+    for (; q0 < KP; q0 += D) {
+#define OSL_TAIL(j, jm, off_next)                                                                                      \
+        if (q0 + (j) < KP) OSL_STEP(j, jm, off_next, (q0 + (j) >= 1 && q0 + (j) - 1 + D < KP))
+        OSL_TAIL(0, 3, D - 1)
+        OSL_TAIL(1, 0, D)
+        OSL_TAIL(2, 1, D + 1)
+        OSL_TAIL(3, 2, D + 2)
+#undef OSL_TAIL
+        ap += D * QS;
+        wo += D * 3 * 256;
+    }
+#undef OSL_STEP
+#undef OSL_REQ
+}
+
+__global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // hS [64][129] | xS [K4][64]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int H = 128, HS = STAGE_HS, BM = STAGE_BM;
+    const int chunk = wave;
+    const int tile_row0 = blockIdx.x * BM;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K4 = (a.K + 3) & ~3;
+    float *hS = sm, *xS = sm + BM * HS;                           // 64 * 129 floats = 33,024 B: xS stays 16-byte aligned
+    for (int i = threadIdx.x; i < BM * HS; i += 256) hS[i] = 0.f;          // h0 = 0 (gru/gru_model.py:27)
+
+    const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
+    const float *wh = wx + (size_t)a.KPx * 3 * 64;
+    const float *bias = wh + (size_t)a.KPh * 3 * 64;
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float nb_r = -LOG2E * bias[li], nb_z = -LOG2E * bias[32 + li], nb_n = 2.0f * LOG2E * bias[64 + li], b_hn = bias[96 + li];
+    const uint32_t rowB = (uint32_t)a.B * 4u;
+
+    // x tile DMA: instruction j moves inputs 4j .. 4j+3 of the 64 rows (lane l: input 4j + l / 16, rows 4 (l % 16) .. + 3)
+    const uint32_t dvoff = (uint32_t)(lane >> 4) * rowB + (uint32_t)(tile_row0 + 4 * (lane & 15)) * 4u;
+    auto stage_x = [&](int t) {
+        const rsrc_t rx = make_rsrc(a.xs + (size_t)t * a.K * a.B, (uint32_t)a.K * rowB);      // inputs past K read as zero (range check)
+        for (int j = wave; j < K4 / 4; j += 4)
+            stage_dma16(rx, xS + j * 256, dvoff, __builtin_amdgcn_readfirstlane((uint32_t)(4 * j) * rowB));
+    };
+    // LDS byte addresses of this lane's A-fragment elements (k-pair 0, row block 0) and of its 2 x 16 cell elements
+    const uint32_t xS_b = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)xS;
+    const uint32_t hS_b = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)hS;
+    const uint32_t ax0 = xS_b + (uint32_t)(lh * 64 + li) * 4u;
+    const uint32_t ah0 = hS_b + (uint32_t)(li * HS + lh) * 4u;
+    const uint32_t hw0 = hS_b + (uint32_t)((4 * lh) * HS + chunk * 32 + li) * 4u;     // row (e & 3) + 8 (e >> 2) + 4 lh, col chunk * 32 + li
+
+    stage_x(0);
+    float hv[2][16];                                                  // h_{t-1} of the wave's own elements
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) hv[rb][e] = 0.f;
+    // seq_out / h_last stores: byte offset of (hidden unit chunk * 32 + li, trajectory tile_row0 + 4 lh) inside one [H][B] block;
+    // rows past B aim past the descriptor's range (dropped)
+    uint32_t so[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const int row0 = tile_row0 + rb * 32 + 4 * lh;
+        so[rb] = (uint32_t)(chunk * 32 + li) * rowB + (uint32_t)row0 * 4u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    OSL_TS_DECL
+
+    for (int t = 0; t < a.T; t++) {
+        OSL_TS(0)
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
+        mfma_part_lds<true, 512, 128>(acc, wx, a.KPx, lane, ax0);
+        OSL_TS(1)                                        // x half of the gate GEMM
+        mfma_part_lds<false, 8, 32 * STAGE_HS * 4>(acc, wh, a.KPh, lane, ah0);
+        OSL_TS(2)                                        // h half
+        lds_barrier();                                   // barrier 1: xS and hS are free
+        OSL_TS(3)
+        if (t + 1 < a.T) stage_x(t + 1);
+        // ---- cell update on the accumulator layout: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+        const rsrc_t rs = make_rsrc(a.seq_out ? a.seq_out + (size_t)t * H * a.B : nullptr, a.seq_out ? (uint32_t)H * rowB : 0u);
+        const rsrc_t rl = make_rsrc((t == a.T - 1 && a.h_last) ? a.h_last : nullptr, (t == a.T - 1 && a.h_last) ? (uint32_t)H * rowB : 0u);
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
+                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
+                const float ghn = acc[rb][3][e] + b_hn;
+                const float u = fmaf(r, ghn, acc[rb][2][e]);
+                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
+                const float hn = fmaf(z, hv[rb][e] - n, n);          // (1 - z) n + z h
+                hv[rb][e] = hn;
+                lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e & 3) + 8 * (e >> 2)) * HS) * 4u, hn);   // (constant: folds into the offset field)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x4 v = {hv[rb][4 * j], hv[rb][4 * j + 1], hv[rb][4 * j + 2], hv[rb][4 * j + 3]};
+                const uint32_t off = (tile_row0 + rb * 32 + 8 * j + 4 * lh < a.B) ? so[rb] + (uint32_t)(8 * j) * 4u : 0x80000000u;
+                buf_store4_nt(rs, off, 0, v);
+                buf_store4_nt(rl, off, 0, v);
+            }
+        }
+        OSL_TS(4)                                        // DMA issue + cell update + stores
+        // the DMA (older than this step's 16 store instructions) has landed; the stores themselves may still be in flight
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        lds_barrier();                                   // barrier 2: h_t and x_{t+1} are in LDS
+        OSL_TS(5)
+    }
+#ifdef OS_LAYER_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("gru_layer_stage_kernel K=%d cycles per step: x half %llu | h half %llu | barrier 1 %llu | DMA issue + cell + stores %llu | DMA wait + barrier 2 %llu | sum %llu\n",
+               a.K, ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T,
+               (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5]) / a.T);
+#endif
 }
 
 // Small-batch variant: EIGHT waves per workgroup on one 32-row tile.  The concatenated k-pair range [x part | h part] of
@@ -273,10 +572,13 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
         }
     };
 
+    OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
+        OSL_TS(0)
         const float *hl = hl2 + (t & 1) * BM * HS;          // h_{t-1}
         float *hn_buf = hl2 + ((t + 1) & 1) * BM * HS;       // h_t
         if (t > 0 && a.seq_out) write_back(hl, a.seq_out + (size_t)(t - 1) * H * B);
+        OSL_TS(1)                                            // write-back of h_{t-1} (LDS -> SoA)
 
         f32x16 acc[1][4];
 #pragma unroll
@@ -739,9 +1041,20 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     if (ctx->tune_gru_split == 0) split = false;
     const bool ahead = ahead_eligible(ctx, a.B, a.T, a.K, H);
     if (a.xs_btf && !ahead) return os_fail(ctx, -4, "os_gru_launch_layer: a batch_first input needs the ahead kernel's shape");
+    // large batches, H = 128, inference: the x tile travels global -> LDS by DMA one step ahead (gru_layer_stage_kernel)
+    const size_t lds_st = ((size_t)STAGE_BM * STAGE_HS + (size_t)((a.K + 3) & ~3) * STAGE_BM) * sizeof(float);
+    const bool stage = !ahead && !split && RBW == 2 && H == 128 && !a.sv_r && !a.xs_btf && a.B % 4 == 0 && lds_st <= 80 * 1024 &&
+                       (size_t)a.K * a.B * 4 < ((size_t)1 << 31) && ctx->tune_gru_stage != 0;
     const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s,
-                                   ahead ? "gru_layer_ahead_kernel" : split ? "gru_layer_split_kernel" : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
-    if (ahead) {
+                                   ahead ? "gru_layer_ahead_kernel" : split ? "gru_layer_split_kernel" : stage ? "gru_layer_stage_kernel"
+                                   : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
+    if (stage) {
+        if (!ctx->stage_attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            ctx->stage_attr_set = true;
+        }
+        hipLaunchKernelGGL(gru_layer_stage_kernel, dim3((a.B + STAGE_BM - 1) / STAGE_BM), dim3(256), lds_st, s, a);
+    } else if (ahead) {
         const size_t lds_a = ((size_t)2 * 32 * (H + 1) + (size_t)32 * (2 * a.KPx + 1) + (size_t)4 * 48 * 64) * sizeof(float);
         if (!ctx->ahead_attr_set) {
             OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_ahead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
