@@ -54,6 +54,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_MPC_PERSISTENT"); c->tune_mpc_persistent = e ? atoi(e) : 1;
         e = getenv("OS_VIT_MLP_FUSED"); c->tune_vit_mlp_fused = e ? atoi(e) : 3;
         e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 512;      // 2 x 240 workgroups at the training batch: two per CU
+        e = getenv("OS_DW_DBG"); c->tune_dw_dbg = e ? atoi(e) : 0;
         e = getenv("OS_DW_FUSED"); c->tune_dw_fused = e ? atoi(e) : 1;
         e = getenv("OS_VIT_TAIL_SPLIT"); c->tune_vit_tail_split = e ? atoi(e) : 1;
         e = getenv("OS_VIT_ATT_DMA"); c->tune_vit_att_dma = e ? atoi(e) : 1;

@@ -505,6 +505,9 @@ template <int NCH>
 __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
 {
     constexpr int PARTS = 8 / NCH;
+#ifdef OS_LAYER_TS
+    const unsigned long long ts_start = __builtin_readcyclecounter();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][32][HS] h double buffer | [2][32][XS] x tiles | [NCH][PARTS-1][64][64] exchange
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, HS = H + 1;
@@ -572,6 +575,9 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
         }
     };
 
+#ifdef OS_LAYER_TS
+    const unsigned long long ts_pro = __builtin_readcyclecounter() - ts_start;
+#endif
     OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
         OSL_TS(0)
@@ -591,6 +597,7 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
             mfma_part<1, true, 8>(acc, wx + (size_t)xb * 3 * 64, xe - xb, lane, [&](int q, int) { return xl[li * XS + 2 * (q + xb) + lh]; });
         if (he > hb)
             mfma_part<1, false, 8>(acc, wh + (size_t)hb * 3 * 64, he - hb, lane, [&](int q, int) { return hl[li * HS + 2 * (q + hb) + lh]; });
+        OSL_TS(2)                                            // this wave's slice of the gate GEMM
         // x_{t+1}: requested behind the last weight fragment, lands underneath the exchange and the cell update
         if (t + 1 < a.T) xfetch(t + 1);
         if (part > 0) {
@@ -601,6 +608,7 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
                 for (int e = 0; e < 16; e++) dst[(g * 16 + e) * 64 + lane] = acc[0][g][e];
         }
         lds_barrier();   // partial sums in place; every wave is done reading h_{t-1}'s A fragments
+        OSL_TS(3)                                            // x request, partial sums -> LDS, barrier
         if (part == 0) {
 #pragma unroll
             for (int p = 0; p < PARTS - 1; p++) {
@@ -632,9 +640,17 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
                 }
             }
         }
+        OSL_TS(4)                                            // part 0: sum of the partials, cell update, saved activations
         if (t + 1 < a.T) xstage(xl2 + ((t + 1) & 1) * BM * XS);
         lds_barrier();   // h_t and x_{t+1} complete (and the exchange buffers free again)
+        OSL_TS(5)                                            // x tile staged, barrier
     }
+#ifdef OS_LAYER_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("gru_layer_split_kernel<%d> K=%d T=%d cycles per step (wave 0 = chunk 0, part 0): write-back %llu | GEMM slice %llu | exchange + barrier %llu | cell update %llu | x stage + barrier %llu | sum %llu; prologue %llu\n",
+               NCH, a.K, a.T, ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T,
+               (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5]) / a.T, ts_pro);
+#endif
     const float *hT = hl2 + (a.T & 1) * BM * HS;
     if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
     if (a.h_last) write_back(hT, a.h_last);

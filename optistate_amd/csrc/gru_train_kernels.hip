@@ -810,6 +810,7 @@ struct Dw3Args {
     int x_btf, B, T;
     const float *Hp;             // [rows][H]: row r - B pairs with dG row r
     float *dWih, *dWhh, *dbih, *dbhh;
+    int dbg;                     // development (OS_DW_DBG): 1 = skip the atomics (timing only), 2 = rotate the epilogue's element order per slice, 4 = stagger odd slices
 };
 
 // TR = rows per tile: 32, or 16 for the ten-accumulator form of the 188-wide first layer (160 accumulator registers leave
@@ -909,6 +910,9 @@ __global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    if ((a.dbg & 4) && (by & 1)) {                              // development: odd slices start half a tile late
+        for (int i = 0; i < 32; i++) __builtin_amdgcn_s_sleep(127);
+    }
     dma(0, 0);
     dg_load(0, 0);
     for (int tile = 0; tile < ntiles; tile += 2) {
@@ -921,24 +925,41 @@ __global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
             tile_mfma(1, hzero(tile + 1));
         }
     }
-    if (jok) {
+    if (jok && !(a.dbg & 1)) {
         const osk::rsrc_t rwx = osk::make_rsrc(a.dWih, (uint32_t)a.H3 * (uint32_t)a.Kx * 4u);
         const osk::rsrc_t rwh = osk::make_rsrc(a.dWhh, (uint32_t)a.H3 * (uint32_t)a.H * 4u);
+        // The 160 row slices of a column group add into the SAME 48 K addresses, and workgroups that start together reach their
+        // epilogues together: the element order is rotated per slice (four orders), so that at any moment the slices in flight
+        // hit different cache lines of the gradient instead of queueing on one
+        auto epilogue = [&](auto rot) {
+            constexpr int R = decltype(rot)::value;
 #pragma unroll
-        for (int c = 0; c < NCX; c++) {
-            const int k = c * 32 + li;
-            if (k < a.Kx) {
-                const uint32_t vo = (uint32_t)((4 * kk) * a.Kx + k) * 4u;
+            for (int c = 0; c < NCX; c++) {
+                const int k = c * 32 + li;
+                if (k < a.Kx) {
+                    const uint32_t vo = (uint32_t)((4 * kk) * a.Kx + k) * 4u;
 #pragma unroll
-                for (int e = 0; e < 16; e++) buf_atomic_add(accx[c][e], rwx, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.Kx) * 4u);
+                    for (int i = 0; i < 16; i++) {
+                        const int e = (i + R) & 15;
+                        buf_atomic_add(accx[c][e], rwx, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.Kx) * 4u);
+                    }
+                }
             }
-        }
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const uint32_t vo = (uint32_t)((4 * kk) * a.H + c * 32 + li) * 4u;
+            for (int c = 0; c < NCH; c++) {
+                const uint32_t vo = (uint32_t)((4 * kk) * a.H + c * 32 + li) * 4u;
 #pragma unroll
-            for (int e = 0; e < 16; e++) buf_atomic_add(acch[c][e], rwh, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.H) * 4u);
-        }
+                for (int i = 0; i < 16; i++) {
+                    const int e = (i + R) & 15;
+                    buf_atomic_add(acch[c][e], rwh, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.H) * 4u);
+                }
+            }
+        };
+        const int rsel = (a.dbg & 2) ? (by & 3) : 0;
+        if (rsel == 0) epilogue(std::integral_constant<int, 0>{});
+        else if (rsel == 1) epilogue(std::integral_constant<int, 4>{});
+        else if (rsel == 2) epilogue(std::integral_constant<int, 8>{});
+        else epilogue(std::integral_constant<int, 12>{});
         bsi += __shfl_xor(bsi, 32, 64);              // the two row parities of the same gate unit
         bsh += __shfl_xor(bsh, 32, 64);
         if (kk == 0) {
@@ -1312,6 +1333,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             else { d.X = act + ((size_t)(l - 1) * 5 + 4) * tbh; d.x_btf = 0; }
             d.dWih = gWih; d.dWhh = gWhh; d.dbih = gbih; d.dbhh = gbhh;
             d.ngroups = (H3 / 32 + 3) / 4;
+            d.dbg = ctx->tune_dw_dbg;
             const unsigned nslices = (unsigned)((rows + rps - 1) / rps);
             const dim3 grid(8u * ((nslices + 7) / 8) * (unsigned)d.ngroups);       // see the XCD-aware order in the kernel
             const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, "dw3_kernel");

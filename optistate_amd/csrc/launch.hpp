@@ -21,6 +21,7 @@ struct os_ctx {
     int tune_rows_v1;                    // OS_KF_ROWS_V1=1: the first 16-lanes-per-trajectory kernel instead of kf_run_rows2_kernel (A/B runs)
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
+    int tune_dw_dbg;                     // development: Dw3Args.dbg (OS_DW_DBG)
     int tune_gru_stage;                  // 1: large-batch H = 128 inference layers use gru_layer_stage_kernel (x tile by LDS-DMA), 0: gru_layer_kernel<2,2>
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
     int tune_mpc_persistent;             // os_kf_mpc_run: 1 = one persistent kernel up to 24 trajectories per CU (default), 2 = always, 0 = the per-step launch sequence

@@ -12,3 +12,4 @@ done; wait
 cd $R
 echo "== gru_layer_stage_kernel"; OPTISTATE_HIP_LIB=$D/liboptistate_lts.so python3 tools/run_ref_shape_once.py 1
 echo "== gru_layer_kernel<2,2> (OS_GRU_STAGE=0)"; OS_GRU_STAGE=0 OPTISTATE_HIP_LIB=$D/liboptistate_lts.so python3 tools/run_ref_shape_once.py 1
+echo "== training forward, 8192 x 10 (OS_GRU_AHEAD=0: gru_layer_split_kernel)"; OS_GRU_AHEAD=0 OPTISTATE_HIP_LIB=$D/liboptistate_lts.so python3 tools/train_fwd_ts.py 2>&1 | grep "cycles per step" | tail -4
