@@ -763,12 +763,15 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
     }
 
+    OSF_TS_DECL
     for (int t = 0; t < k.T; t++) {
+        OSF_TS(0)
         float z[NM], FA[2][KBX][8];        // FA[rb][kb][j]: feature 16 kb + 8 (lane half) + j of trajectory block rb (AGPRs)
         f2 PW[2][3];
         float g9[9];
         status |= kf_step_inputs_sym(X, in, k.k, z, PW, g9);
         __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(1)                                        // wait for the prefetched inputs + rotations, odometry, next_state
         // k-block kb = features 16 kb .. 16 kb + 15; v_permlane32_swap pairs feature j with feature j + 8 of the block, so that
         // the first register serves trajectories 0-31 (lanes 0-31: feature j, lanes 32-63: feature j + 8), the second 32-63
         auto feat8 = [&](int kb, float l0, float l1, float l2, float l3, float l4, float l5, float l6, float l7, float h0, float h1,
@@ -796,8 +799,10 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         feat8(3, OSF_LEG(in.dp, 6), OSF_LEG(in.dp, 7), OSF_LEG(in.dp, 8), OSF_LEG(in.dp, 9), OSF_LEG(in.dp, 10), OSF_LEG(in.dp, 11), in.imu[0], in.imu[1], in.imu[2], in.imu[3], in.imu[4],
               in.imu[5], 0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_sched_barrier(0);          // the inputs are in AGPRs now: the covariance work below starts with their registers free
+        OSF_TS(2)                                        // 48 raw features: subtract, swap, AGPR
         cov_predict_sym_blk<QDIAG>(U, g9, k.k);
         __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(3)                                        // covariance predict
         smin = fminf(smin, update_sequential_sym(X, U, z, k.k));
         {
             // shadow lanes: an offset no descriptor covers (the range check drops the store) instead of a branch around the stores
@@ -808,6 +813,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
         }
         feat8(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11), acl[0], acl[1], acl[2], acl[3]);
 
+        OSF_TS(4)                                        // ten measurement updates, x_out stores, 12 state features
         // ================= GRU cell: one 32-trajectory block at a time, both unit chunks together =================
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
@@ -872,6 +878,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]),
                          "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+            OSF_TS(5)                                    // bias init + activation split + MFMAs + drain (x 2 blocks)
             if (rb == 1) {
                 const int tn = (t + 1 < k.T) ? t + 1 : t;
                 load_step_p(k, tn, voff, rowB, in);
@@ -908,8 +915,15 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_bf16_kernel(const FusedAr
 #pragma unroll
                 for (int e = 0; e < 16; e++) hreg[rb][c][e] = agpr_put(acc[c][3][e]);
             }
+            OSF_TS(6)                                    // next step's input request (block 1) + cell update (x 2 blocks)
         }
     }
+#ifdef OS_FUSED_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("fused_bf16<SPL=%d> cycles per step: inputs %llu | features %llu | predict %llu | update %llu | split + mfma (2 blocks) %llu | cell (2 blocks) %llu | sum %llu\n",
+               SPL, ts_sum[1] / k.T, ts_sum[2] / k.T, ts_sum[3] / k.T, ts_sum[4] / k.T, ts_sum[5] / k.T, ts_sum[6] / k.T,
+               (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5] + ts_sum[6]) / k.T);
+#endif
 
     status |= singular_status(smin) | finite_status_p(X);
     if (live) {

@@ -10,3 +10,5 @@ done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboptistate_fts.so $D/*.o -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib
 cd $R
 OPTISTATE_HIP_LIB=$D/liboptistate_fts.so python3 tools/run_fused_once.py 2
+OPTISTATE_HIP_LIB=$D/liboptistate_fts.so python3 tools/run_fused_once.py 1 3     # fused_kf_gru_bf16_kernel<., 3>
+OPTISTATE_HIP_LIB=$D/liboptistate_fts.so python3 tools/run_fused_once.py 1 2     # <., 2>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs the fused path a few times at the bench shape (for rocprofv3 counter passes)."""
+"""Runs the fused path a few times at the bench shape (for rocprofv3 counter passes).  argv: n [split_bf16: 0 | 3 | 2]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +7,7 @@ from optistate_amd import Engine, RNN, flatten_state_dict
 from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
 B, T = 65536, 100
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+split = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = Engine(0); eng.set_noise(Q_DEFAULT, R_DEFAULT)
 d = synth_torch(B, T, "cuda", seed=1)
 c = eng.contact_soa_to_packed(d["contact"])
@@ -16,7 +17,9 @@ eng.load_gru(flatten_state_dict(m.state_dict(), 1, "cuda"), 60, 64, 1, 24)
 mm = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).cuda()
 for _ in range(n):
     x = d["x0"].clone(); P = d["P0"].clone()
-    eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], c, d["accel"], mm, x, P)
+    eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], c, d["accel"], mm, x, P, split_bf16=split)
+    if split:
+        continue
     x = d["x0"].clone(); P = d["P0"].clone()
     eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], c, x, P)
 torch.cuda.synchronize()
