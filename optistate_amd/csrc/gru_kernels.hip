@@ -317,7 +317,7 @@ __device__ __forceinline__ void lds_write_asm(uint32_t addr, float v)
     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
-constexpr int STAGE_HS = 129, STAGE_BM = 64, STAGE_DEPTH = 4;
+constexpr int STAGE_BM = 64, STAGE_DEPTH = 4;       // rows per wave pair of row blocks; k-pairs in flight
 
 // One half of the gate GEMM with the A fragments in LDS.  ap: byte address of this lane's fragment element of k-pair 0, row
 // block 0; QS / RS: byte strides of a k-pair / of the second row block (immediates).  XPART: gate n accumulates into acc[.][2]
@@ -389,16 +389,21 @@ __device__ __forceinline__ void mfma_part_lds(f32x16 (*acc)[4], const float *wba
 #undef OSL_REQ
 }
 
+// NCH = H / 32 column chunks: 4 (H = 128: a wave per chunk, 64-row tile) or 2 (H = 64: two waves per chunk on different
+// halves of a 128-row tile, as in gru_layer_kernel).
+template <int NCH>
 __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // hS [64][129] | xS [K4][64]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // hS [BM][H + 1] | xS [K4][BM]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int H = 128, HS = STAGE_HS, BM = STAGE_BM;
-    const int chunk = wave;
+    constexpr int H = 32 * NCH, HS = H + 1, BM = STAGE_BM * (4 / NCH);
+    constexpr int LPK = BM / 4, KPI = 64 / LPK;                   // DMA: lanes per input row of the tile, inputs per instruction
+    const int chunk = wave % NCH, rgrp = wave / NCH;              // rgrp: which 64 rows of the tile
     const int tile_row0 = blockIdx.x * BM;
     const int li = lane & 31, lh = lane >> 5;
     const int K4 = (a.K + 3) & ~3;
-    float *hS = sm, *xS = sm + BM * HS;                           // 64 * 129 floats = 33,024 B: xS stays 16-byte aligned
+    float *hS = sm, *xS = sm + BM * HS;                           // BM * HS floats: a multiple of 16 bytes in both shapes
+    static_assert((BM * HS * 4) % 16 == 0, "xS must stay 16-byte aligned");
     for (int i = threadIdx.x; i < BM * HS; i += 256) hS[i] = 0.f;          // h0 = 0 (gru/gru_model.py:27)
 
     const float *wx = a.w + (size_t)chunk * chunk_floats(a.KPx, a.KPh);
@@ -408,19 +413,20 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
     const float nb_r = -LOG2E * bias[li], nb_z = -LOG2E * bias[32 + li], nb_n = 2.0f * LOG2E * bias[64 + li], b_hn = bias[96 + li];
     const uint32_t rowB = (uint32_t)a.B * 4u;
 
-    // x tile DMA: instruction j moves inputs 4j .. 4j+3 of the 64 rows (lane l: input 4j + l / 16, rows 4 (l % 16) .. + 3)
-    const uint32_t dvoff = (uint32_t)(lane >> 4) * rowB + (uint32_t)(tile_row0 + 4 * (lane & 15)) * 4u;
+    // x tile DMA: instruction j moves inputs KPI j .. KPI j + KPI - 1 of the BM rows (lane l: input KPI j + l / LPK, rows
+    // 4 (l % LPK) .. + 3) = 256 consecutive floats of the input-major tile
+    const uint32_t dvoff = (uint32_t)(lane / LPK) * rowB + (uint32_t)(tile_row0 + 4 * (lane % LPK)) * 4u;
     auto stage_x = [&](int t) {
         const rsrc_t rx = make_rsrc(a.xs + (size_t)t * a.K * a.B, (uint32_t)a.K * rowB);      // inputs past K read as zero (range check)
-        for (int j = wave; j < K4 / 4; j += 4)
-            stage_dma16(rx, xS + j * 256, dvoff, __builtin_amdgcn_readfirstlane((uint32_t)(4 * j) * rowB));
+        for (int j = wave; j < K4 / KPI; j += 4)
+            stage_dma16(rx, xS + j * 256, dvoff, __builtin_amdgcn_readfirstlane((uint32_t)(KPI * j) * rowB));
     };
     // LDS byte addresses of this lane's A-fragment elements (k-pair 0, row block 0) and of its 2 x 16 cell elements
     const uint32_t xS_b = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)xS;
     const uint32_t hS_b = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)hS;
-    const uint32_t ax0 = xS_b + (uint32_t)(lh * 64 + li) * 4u;
-    const uint32_t ah0 = hS_b + (uint32_t)(li * HS + lh) * 4u;
-    const uint32_t hw0 = hS_b + (uint32_t)((4 * lh) * HS + chunk * 32 + li) * 4u;     // row (e & 3) + 8 (e >> 2) + 4 lh, col chunk * 32 + li
+    const uint32_t ax0 = xS_b + (uint32_t)(lh * BM + rgrp * 64 + li) * 4u;
+    const uint32_t ah0 = hS_b + (uint32_t)((rgrp * 64 + li) * HS + lh) * 4u;
+    const uint32_t hw0 = hS_b + (uint32_t)((rgrp * 64 + 4 * lh) * HS + chunk * 32 + li) * 4u;   // row (e & 3) + 8 (e >> 2) + 4 lh, col chunk * 32 + li
 
     stage_x(0);
     float hv[2][16];                                                  // h_{t-1} of the wave's own elements
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
     uint32_t so[2];
 #pragma unroll
     for (int rb = 0; rb < 2; rb++) {
-        const int row0 = tile_row0 + rb * 32 + 4 * lh;
+        const int row0 = tile_row0 + rgrp * 64 + rb * 32 + 4 * lh;
         so[rb] = (uint32_t)(chunk * 32 + li) * rowB + (uint32_t)row0 * 4u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -449,9 +455,9 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
             for (int g = 0; g < 4; g++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
-        mfma_part_lds<true, 512, 128>(acc, wx, a.KPx, lane, ax0);
+        mfma_part_lds<true, 2 * BM * 4, 128>(acc, wx, a.KPx, lane, ax0);
         OSL_TS(1)                                        // x half of the gate GEMM
-        mfma_part_lds<false, 8, 32 * STAGE_HS * 4>(acc, wh, a.KPh, lane, ah0);
+        mfma_part_lds<false, 8, 32 * HS * 4>(acc, wh, a.KPh, lane, ah0);
         OSL_TS(2)                                        // h half
         lds_barrier();                                   // barrier 1: xS and hS are free
         OSL_TS(3)
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const f32x4 v = {hv[rb][4 * j], hv[rb][4 * j + 1], hv[rb][4 * j + 2], hv[rb][4 * j + 3]};
-                const uint32_t off = (tile_row0 + rb * 32 + 8 * j + 4 * lh < a.B) ? so[rb] + (uint32_t)(8 * j) * 4u : 0x80000000u;
+                const uint32_t off = (tile_row0 + rgrp * 64 + rb * 32 + 8 * j + 4 * lh < a.B) ? so[rb] + (uint32_t)(8 * j) * 4u : 0x80000000u;
                 buf_store4_nt(rs, off, 0, v);
                 buf_store4_nt(rl, off, 0, v);
             }
@@ -488,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
     }
 #ifdef OS_LAYER_TS
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("gru_layer_stage_kernel K=%d cycles per step: x half %llu | h half %llu | barrier 1 %llu | DMA issue + cell + stores %llu | DMA wait + barrier 2 %llu | sum %llu\n",
-               a.K, ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T,
+        printf("gru_layer_stage_kernel<%d> K=%d cycles per step: x half %llu | h half %llu | barrier 1 %llu | DMA issue + cell + stores %llu | DMA wait + barrier 2 %llu | sum %llu\n",
+               NCH, a.K, ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, ts_sum[5] / a.T,
                (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5]) / a.T);
 #endif
 }
@@ -1057,19 +1063,22 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     if (ctx->tune_gru_split == 0) split = false;
     const bool ahead = ahead_eligible(ctx, a.B, a.T, a.K, H);
     if (a.xs_btf && !ahead) return os_fail(ctx, -4, "os_gru_launch_layer: a batch_first input needs the ahead kernel's shape");
-    // large batches, H = 128, inference: the x tile travels global -> LDS by DMA one step ahead (gru_layer_stage_kernel)
-    const size_t lds_st = ((size_t)STAGE_BM * STAGE_HS + (size_t)((a.K + 3) & ~3) * STAGE_BM) * sizeof(float);
-    const bool stage = !ahead && !split && RBW == 2 && H == 128 && !a.sv_r && !a.xs_btf && a.B % 4 == 0 && lds_st <= 80 * 1024 &&
-                       (size_t)a.K * a.B * 4 < ((size_t)1 << 31) && ctx->tune_gru_stage != 0;
+    // large batches, H = 128 / 64, inference: the x tile travels global -> LDS by DMA one step ahead (gru_layer_stage_kernel)
+    const int bm_st = STAGE_BM * (NCH >= 4 ? 1 : 2);
+    const size_t lds_st = ((size_t)bm_st * (H + 1) + (size_t)((a.K + 3) & ~3) * bm_st) * sizeof(float);
+    const bool stage = !ahead && !split && RBW == 2 && (H == 128 || H == 64) && a.KPx >= 2 * STAGE_DEPTH && !a.sv_r && !a.xs_btf && a.B % 4 == 0 &&
+                       lds_st <= 80 * 1024 && (size_t)a.K * a.B * 4 < ((size_t)1 << 31) && ctx->tune_gru_stage != 0;
     const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s,
                                    ahead ? "gru_layer_ahead_kernel" : split ? "gru_layer_split_kernel" : stage ? "gru_layer_stage_kernel"
                                    : (RBW == 2 ? "gru_layer_kernel<2,2>" : "gru_layer_kernel<1,3>"));
     if (stage) {
         if (!ctx->stage_attr_set) {
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_stage_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_stage_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             ctx->stage_attr_set = true;
         }
-        hipLaunchKernelGGL(gru_layer_stage_kernel, dim3((a.B + STAGE_BM - 1) / STAGE_BM), dim3(256), lds_st, s, a);
+        if (H == 128) hipLaunchKernelGGL(gru_layer_stage_kernel<4>, dim3((a.B + bm_st - 1) / bm_st), dim3(256), lds_st, s, a);
+        else hipLaunchKernelGGL(gru_layer_stage_kernel<2>, dim3((a.B + bm_st - 1) / bm_st), dim3(256), lds_st, s, a);
     } else if (ahead) {
         const size_t lds_a = ((size_t)2 * 32 * (H + 1) + (size_t)32 * (2 * a.KPx + 1) + (size_t)4 * 48 * 64) * sizeof(float);
         if (!ctx->ahead_attr_set) {
