@@ -756,6 +756,8 @@ def bench_hot_path(a, rk):
             if fused:
                 return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, gru_input=gru_in,
                                      split_bf16=a.split_bf16)
+            if a.wave_per_trajectory:       # the north_star's literal layout, measured beside the default kernels (never the default)
+                return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P, sequential=False, symmetric=False, wave_per_trajectory=True)
             return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
         # one to three launches per pass here: the per-kernel HIP events stay on over the timed region itself (two event
         # records per launch against milliseconds of kernel; the modes with dozens of short launches per step use a second
@@ -900,6 +902,8 @@ def main(argv=None):
                     help="inputs that leave the fast branches: 0-4 stance legs per step, yaw unwrapping past +-pi, wide roll / pitch")
     ap.add_argument("--split-bf16", type=int, nargs="?", const=3, default=0, choices=[0, 2, 3],
                     help="opt-in gate GEMM on the bf16 MFMA with 3 (default) or 2 bf16 terms per fp32 operand (second line; never the headline)")
+    ap.add_argument("--wave-per-trajectory", action="store_true",
+                    help="--mode kf: one wavefront per trajectory with x and P in LDS (the north_star's literal layout; measurement only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="--mode train on ONE GPU with a one-rank RCCL process group: exercises (and prices) the split all-reduce path")
     ap.add_argument("--no-split-allreduce", action="store_true", help="--mode train: one all-reduce behind the whole backward")

@@ -82,6 +82,10 @@ enum {
                                      terms = all 24 mantissa bits, six MFMAs per product block, fp32 accumulate); NOT the
                                      exact-fp32 default.  Measured GRU head l-inf vs the float64 oracle: 8e-8. */
     OS_FUSED_SPLIT_BF16_2   = 1024, /* the same with TWO bf16 terms (16 mantissa bits, three MFMAs per block): 5e-7. */
+    OS_KF_WAVE_PER_TRAJECTORY = 4096, /* os_kf_run: ONE TRAJECTORY PER WAVEFRONT with x and P in LDS for all T steps (the layout
+                                     BASELINE.json's north_star names), float64 batch update across the lanes.  Never chosen by default:
+                                     it exists so that the layout is measured, not argued (20-50x slower than the
+                                     lane-per-trajectory / 16-lanes-per-trajectory kernels). */
     OS_FUSED_LATENT_IN_PLACE = 2048 /* os_fused_run with n_latent > 0: `latent` is the caller's WHOLE GRU input buffer [T][60 + NL][B]
                                      with rows 60.. already holding the latent stream (os_pack_stream_rows writes them there);
                                      the Kalman kernel fills rows 0..59 in place and the GRU reads the buffer directly -- no

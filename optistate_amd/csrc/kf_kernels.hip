@@ -583,10 +583,18 @@ static hipError_t launch_kf_run(const KfRunArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+int os_kf_run_wave(os_ctx *ctx, const KfRunArgs &a, hipStream_t s);      // kf_step.hip: one trajectory per wavefront, P in LDS
+
 // Shared by os_kf_run and os_fused_run (v0: Kalman kernel emits normalised feature rows for the GRU kernels).
 int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
 {
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE, dense = flags & OS_KF_DENSE_FD;
+    if (flags & OS_KF_WAVE_PER_TRAJECTORY) {
+        // the north_star's literal layout, kept for measurement: float64 batch (Cholesky) update on one wavefront per trajectory
+        if (dense || a.q_diag || a.feat_out) return os_fail(ctx, -3, "os_kf_run: OS_KF_WAVE_PER_TRAJECTORY runs predict(p, f) + update with the context-wide noise only");
+        a.k = ctx->k;
+        return os_kf_run_wave(ctx, a, s);
+    }
     if (dense && !a.body_ref) return os_fail(ctx, -2, "os_kf_run: OS_KF_DENSE_FD needs body_ref");
     if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_run: sequential update needs a diagonal R");
     if ((size_t)a.B * 144 * 4 >= 0xffffffffull) return os_fail(ctx, -2, "os_kf_run: B too large for 32-bit buffer offsets");

@@ -19,6 +19,7 @@
 //   next_state                     misc/force_controller.py:269-291        (int64 truncation of A[0:3,6:9], :248-251,:271)
 //   update                         kalman_filter/kalman_filter.py:164-174   (K returned; P <- (I - K H) P, unsymmetrised)
 #include "launch.hpp"
+#include "kf_args.hpp"
 
 #include <stddef.h>
 
@@ -62,6 +63,9 @@ __device__ __forceinline__ double rsqrt_nr(double a)
     return r;
 }
 
+// One filter step on the LDS-resident block M (one wavefront; the caller has filled M.io and synchronised).  Returns the status bits.
+__device__ __forceinline__ int step_body(StepMem &M, const int lane);
+
 __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
 {
     __shared__ StepMem M;
@@ -81,6 +85,22 @@ __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
             if (lane + 64 * i < IO_IN_DOUBLES) dst[lane + 64 * i] = v[i];
     }
     __syncthreads();
+    const int status = step_body(M, lane);
+    __syncthreads();
+    if (lane == 0) io.status = status;
+    __syncthreads();
+    {
+        // write back the in/out head of the block (x, P, z, p) and the outputs behind the constant inputs
+        double *dst = reinterpret_cast<double *>(g);
+        const double *src = reinterpret_cast<const double *>(&io);
+        for (int i = lane; i < IO_INOUT_DOUBLES; i += 64) dst[i] = src[i];
+        for (int i = IO_IN_DOUBLES + lane; i < IO_DOUBLES; i += 64) dst[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ int step_body(StepMem &M, const int lane)
+{
+    StepIO &io = M.io;
     const uint32_t what = io.what;
     const double dt = io.dt;
     int status = 0;
@@ -324,19 +344,85 @@ __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
             if (!(fin == 0.0)) status |= 2;
         }
     }
-    __syncthreads();
-    if (lane == 0) io.status = status;
-    __syncthreads();
-    {
-        // write back the in/out head of the block (x, P, z, p) and the outputs behind the constant inputs
-        double *dst = reinterpret_cast<double *>(g);
-        const double *src = reinterpret_cast<const double *>(&io);
-        for (int i = lane; i < IO_INOUT_DOUBLES; i += 64) dst[i] = src[i];
-        for (int i = IO_IN_DOUBLES + lane; i < IO_DOUBLES; i += 64) dst[i] = src[i];
+    return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kf_run_wave_kernel -- the layout BASELINE.json's north_star names literally: ONE TRAJECTORY PER WAVEFRONT, state and
+// covariance tile in LDS, the whole T loop in one launch (OS_KF_WAVE_PER_TRAJECTORY; never chosen by default).
+// It is step_body above (float64 on one wavefront: covariance three entries per lane, Cholesky / gain / update across the
+// lanes) run over the SoA streams: x, P, Q, R stay in the workgroup's LDS block for all T steps; per step 43 lanes fetch
+// the trajectory's 43 input dwords (one 4-byte element out of each stream row: with the trajectory index fastest in memory,
+// a wavefront that owns ONE trajectory cannot coalesce -- every dword costs a 64-byte sector) and twelve lanes store x_out.
+// Built to MEASURE the layout against the lane-per-trajectory and 16-lanes-per-trajectory kernels (profiles/
+// r04_wave_per_trajectory.md), not to be fast: a step is ~35 barrier-separated cross-lane phases on one wavefront.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kf_run_wave_kernel(const osk::KfRunArgs a)
+{
+    __shared__ StepMem M;
+    const int lane = threadIdx.x;
+    // neighbouring trajectories share the 64-byte sectors of every input row: keep them on one XCD's L2 (consecutive workgroup
+    // ids go round-robin to the eight XCDs)
+    const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    if (b >= a.B) return;
+    const size_t B = (size_t)a.B;
+    StepIO &io = M.io;
+    for (int i = lane; i < 144; i += 64) {
+        io.P[i] = (double)a.P[(size_t)i * B + b];
+        io.Q[i] = (double)a.k.Q[i];
+        if (i < 100) io.R[i] = (double)a.k.R[i];
     }
+    if (lane < 12) io.x[lane] = (double)a.x[(size_t)lane * B + b];
+    if (lane == 0) {
+        io.dt = (double)a.k.dt; io.inv_mass = (double)a.k.inv_mass; io.gz = (double)a.k.gz;
+        for (int i = 0; i < 3; i++) io.inv_inertia[i] = (double)a.k.inv_inertia[i];
+        io.what = OS_STEP_ODOM | OS_STEP_PREDICT | OS_STEP_UPDATE;
+    }
+    int status = 0;
+    for (int t = 0; t < a.T; t++) {
+        // lanes 0-11: p, 12-23: f, 24-35: dp, 36-41: imu, 42: the contact word
+        float v = 0.f;
+        uint32_t cw = 0u;
+        if (lane < 12) v = __builtin_nontemporal_load(a.p + ((size_t)t * 12 + lane) * B + b);
+        else if (lane < 24) v = __builtin_nontemporal_load(a.f + ((size_t)t * 12 + lane - 12) * B + b);
+        else if (lane < 36) v = __builtin_nontemporal_load(a.dp + ((size_t)t * 12 + lane - 24) * B + b);
+        else if (lane < 42) v = __builtin_nontemporal_load(a.imu + ((size_t)t * 6 + lane - 36) * B + b);
+        else if (lane == 42) cw = __builtin_nontemporal_load(a.contact + (size_t)t * B + b);
+        __syncthreads();                                     // the previous step's readers of io are done
+        if (lane < 12) io.p[lane] = (double)v;
+        else if (lane < 24) io.f[lane - 12] = (double)v;
+        else if (lane < 36) io.dp[lane - 24] = (double)v;
+        else if (lane < 42) io.imu[lane - 36] = (double)v;
+        else if (lane == 42) io.contact = cw;
+        __syncthreads();
+        status |= step_body(M, lane);
+        __syncthreads();
+        if (lane < 12) {
+            __builtin_nontemporal_store((float)io.x[lane], a.x_out + ((size_t)t * 12 + lane) * B + b);
+            if (a.p_rot_out) __builtin_nontemporal_store((float)io.p[lane], a.p_rot_out + ((size_t)t * 12 + lane) * B + b);
+        }
+        if (lane == 0) {
+            if (a.ptrace_out) a.ptrace_out[(size_t)t * B + b] = (float)io.ptrace;
+            if (a.kgain_out) a.kgain_out[(size_t)t * B + b] = (float)io.kgain;
+        }
+    }
+    for (int i = lane; i < 144; i += 64) a.P[(size_t)i * B + b] = (float)io.P[i];
+    if (lane < 12) a.x[(size_t)lane * B + b] = (float)io.x[lane];
+    if (lane == 0) a.status[b] = status;
 }
 
 }  // namespace oss
+
+// os_kf_run with OS_KF_WAVE_PER_TRAJECTORY (called from os_kf_run_impl)
+int os_kf_run_wave(os_ctx *ctx, const osk::KfRunArgs &a, hipStream_t s)
+{
+    const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, "kf_run_wave_kernel");
+    hipLaunchKernelGGL(oss::kf_run_wave_kernel, dim3((unsigned)a.B), dim3(64), 0, s, a);
+    os_prof_end(ctx, slot, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
 
 struct os_step_state {
     oss::StepIO *host, *dev;

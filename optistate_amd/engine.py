@@ -15,7 +15,7 @@ import torch
 from . import _capi
 from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
                     OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16, OS_FUSED_SPLIT_BF16_2,
-                    OS_FUSED_LATENT_IN_PLACE)
+                    OS_FUSED_LATENT_IN_PLACE, OS_KF_WAVE_PER_TRAJECTORY)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -136,7 +136,8 @@ class Engine:
         return c_t4b.permute(0, 2, 1).reshape(T * B, 4).contiguous().view(torch.int32).reshape(T, B)
 
     def kf_run(self, p, f, dp, imu, contact, x, P, body_ref=None, sequential=None, dense_fd=False,
-               want_p_rot=False, want_trace=False, want_gain=False, symmetric=None, lane_per_trajectory=False):
+               want_p_rot=False, want_trace=False, want_gain=False, symmetric=None, lane_per_trajectory=False,
+               wave_per_trajectory=False):
         """Runs T filter steps for B trajectories.  All stream arguments are SoA device tensors; x [12][B] and
         P [144][B] are updated in place.  Returns dict(x_out [T][12][B], status [B], p_rot?, P_trace?, K_gain?).
         symmetric=None picks the symmetric-storage kernels (upper triangle of P in registers) when R is diagonal and Q is
@@ -149,7 +150,8 @@ class Engine:
         if symmetric is None:
             symmetric = sequential and not dense_fd and self._sym_Q
         flags = (OS_KF_SEQUENTIAL_UPDATE if sequential else 0) | (OS_KF_DENSE_FD if dense_fd else 0) | \
-                (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_KF_LANE_PER_TRAJECTORY if lane_per_trajectory else 0)
+                (OS_KF_SYMMETRIC_P if symmetric else 0) | (OS_KF_LANE_PER_TRAJECTORY if lane_per_trajectory else 0) | \
+                (OS_KF_WAVE_PER_TRAJECTORY if wave_per_trajectory else 0)   # one wavefront per trajectory, P in LDS: measurement only
         dev = self.device
         x_out = torch.empty((T, 12, B), dtype=torch.float32, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)

@@ -34,9 +34,11 @@ def run(eng, g, Q, R, B, **kw):
 
 
 # kernel families: batch (Cholesky), sequential full-P lanes, sequential symmetric lanes, 16-lanes-per-trajectory rows
+# + the north_star's literal layout (one wavefront per trajectory, P in LDS, float64): built to be measured, never the default
 VARIANTS = [dict(sequential=False, symmetric=False), dict(sequential=True, symmetric=False, lane_per_trajectory=True),
-            dict(sequential=True, symmetric=True, lane_per_trajectory=True), dict(sequential=True, symmetric=True)]
-VIDS = ["batch", "seq-lanes", "sym-lanes", "rows"]
+            dict(sequential=True, symmetric=True, lane_per_trajectory=True), dict(sequential=True, symmetric=True),
+            dict(sequential=False, symmetric=False, wave_per_trajectory=True)]
+VIDS = ["batch", "seq-lanes", "sym-lanes", "rows", "wave-per-trajectory"]
 
 
 @pytest.mark.parametrize("s", [0, 1])
