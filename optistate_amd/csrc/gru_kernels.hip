@@ -43,6 +43,32 @@ using osk::rsrc_t;
 #define OSL_TS(i)
 #endif
 
+// The GRU cell (gru/gru_model.py:16; gate order r | z | n) for TWO elements held in adjacent accumulator registers: the eleven
+// non-transcendental operations of an element are v_pk_* instructions on the pair, the six transcendentals stay scalar.
+// a_r, a_z: W_i. x + W_h. h pre-activations without bias; a_n = W_in x; a_h = W_hn h; nb_*: biases pre-scaled for exp2
+// (-log2 e (b_ir + b_hr), -log2 e (b_iz + b_hz), 2 log2 e b_in), b_hn as it is.  Same IEEE operations as the scalar form.
+struct CellPair { osk::f2 r, z, n, ghn, hn; };
+__device__ __forceinline__ CellPair gru_cell_pair(osk::f2 a_r, osk::f2 a_z, osk::f2 a_n, osk::f2 a_h, osk::f2 hprev, float nb_r, float nb_z,
+                                                  float nb_n, float b_hn)
+{
+    using osk::f2; using osk::fma2; using osk::splat2;
+    constexpr float LOG2E = 1.44269504088896341f;
+    CellPair c;
+    const f2 tr = fma2(a_r, splat2(-LOG2E), splat2(nb_r));
+    const f2 tz = fma2(a_z, splat2(-LOG2E), splat2(nb_z));
+    const f2 dr = (f2){__builtin_amdgcn_exp2f(tr[0]), __builtin_amdgcn_exp2f(tr[1])} + splat2(1.0f);
+    const f2 dz = (f2){__builtin_amdgcn_exp2f(tz[0]), __builtin_amdgcn_exp2f(tz[1])} + splat2(1.0f);
+    c.r = (f2){__builtin_amdgcn_rcpf(dr[0]), __builtin_amdgcn_rcpf(dr[1])};
+    c.z = (f2){__builtin_amdgcn_rcpf(dz[0]), __builtin_amdgcn_rcpf(dz[1])};
+    c.ghn = a_h + splat2(b_hn);
+    const f2 u = fma2(c.r, c.ghn, a_n);
+    const f2 tn = fma2(u, splat2(2.0f * LOG2E), splat2(nb_n));
+    const f2 dn = (f2){__builtin_amdgcn_exp2f(tn[0]), __builtin_amdgcn_exp2f(tn[1])} + splat2(1.0f);
+    c.n = fma2(splat2(-2.0f), (f2){__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])}, splat2(1.0f));
+    c.hn = fma2(c.z, hprev - c.n, c.n);                 // (1 - z) n + z h
+    return c;
+}
+
 // One half of the gate GEMM (input part: XPART, accumulates gi_n into acc[.][2]; recurrent part: gh_n into acc[.][3]).
 // Software pipeline, DEPTH k-pairs deep: the B fragments (coalesced dword loads of the fragment-ordered weights,
 // L2-resident) and the A fragments (x part: one 128-B segment per k straight from the SoA stream; h part: LDS) of
@@ -224,19 +250,22 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
         OSL_TS(3)                                            // h half
 
         // ---- cell update on the accumulator layout: col = lane&31 (hidden unit), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        CellPair cp;
 #pragma unroll
         for (int rb = 0; rb < RBW; rb++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = (row_blk0 + rb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int hidx = row * HS + chunk * 32 + li;
-                // biases folded into the exp2 arguments: one FMA per gate instead of add + mul
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
-                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
-                const float ghn = acc[rb][3][e] + b_hn;
-                const float u = fmaf(r, ghn, acc[rb][2][e]);
-                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
-                const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
+                // biases folded into the exp2 arguments: one FMA per gate instead of add + mul; the arithmetic runs on element
+                // pairs (gru_cell_pair): computed at the even element, picked up at the odd one
+                if ((e & 1) == 0) {
+                    const int hidx1 = hidx + HS;                        // element e + 1: the next row
+                    cp = gru_cell_pair((osk::f2){acc[rb][0][e], acc[rb][0][e + 1]}, (osk::f2){acc[rb][1][e], acc[rb][1][e + 1]},
+                                       (osk::f2){acc[rb][2][e], acc[rb][2][e + 1]}, (osk::f2){acc[rb][3][e], acc[rb][3][e + 1]},
+                                       (osk::f2){hl[hidx], hl[hidx1]}, nb_r, nb_z, nb_n, b_hn);
+                }
+                const float r = cp.r[e & 1], z = cp.z[e & 1], n = cp.n[e & 1], ghn = cp.ghn[e & 1], hn = cp.hn[e & 1];
                 hn_buf[hidx] = hn;
                 if (a.sv_r) {
                     const int g = tile_row0 + row;
@@ -467,16 +496,19 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
         const rsrc_t rl = make_rsrc((t == a.T - 1 && a.h_last) ? a.h_last : nullptr, (t == a.T - 1 && a.h_last) ? (uint32_t)H * rowB : 0u);
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
+            // element pairs (2 p, 2 p + 1) sit in adjacent accumulator registers (gru_cell_pair: packed arithmetic, bit-identical
+            // to the scalar form)
+            using osk::f2;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
-                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
-                const float ghn = acc[rb][3][e] + b_hn;
-                const float u = fmaf(r, ghn, acc[rb][2][e]);
-                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
-                const float hn = fmaf(z, hv[rb][e] - n, n);          // (1 - z) n + z h
-                hv[rb][e] = hn;
-                lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e & 3) + 8 * (e >> 2)) * HS) * 4u, hn);   // (constant: folds into the offset field)
+            for (int pr = 0; pr < 8; pr++) {
+                const int e0 = 2 * pr, e1 = e0 + 1;
+                const CellPair cp = gru_cell_pair((f2){acc[rb][0][e0], acc[rb][0][e1]}, (f2){acc[rb][1][e0], acc[rb][1][e1]},
+                                                  (f2){acc[rb][2][e0], acc[rb][2][e1]}, (f2){acc[rb][3][e0], acc[rb][3][e1]},
+                                                  (f2){hv[rb][e0], hv[rb][e1]}, nb_r, nb_z, nb_n, b_hn);
+                const f2 hn = cp.hn;
+                hv[rb][e0] = hn[0]; hv[rb][e1] = hn[1];
+                lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e0 & 3) + 8 * (e0 >> 2)) * HS) * 4u, hn[0]);   // (constant: folds into the offset field)
+                lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e1 & 3) + 8 * (e1 >> 2)) * HS) * 4u, hn[1]);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -624,16 +656,16 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
 #pragma unroll
                     for (int e = 0; e < 16; e++) acc[0][g][e] += src[(g * 16 + e) * 64 + lane];
             }
+            CellPair cp;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int hidx = row * HS + chunk * 32 + li;
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][0][e], -LOG2E, nb_r)));
-                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][1][e], -LOG2E, nb_z)));
-                const float ghn = acc[0][3][e] + b_hn;
-                const float u = fmaf(r, ghn, acc[0][2][e]);
-                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
-                const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
+                if ((e & 1) == 0)                                    // element pairs (gru_cell_pair): e + 1 is the next row
+                    cp = gru_cell_pair((osk::f2){acc[0][0][e], acc[0][0][e + 1]}, (osk::f2){acc[0][1][e], acc[0][1][e + 1]},
+                                       (osk::f2){acc[0][2][e], acc[0][2][e + 1]}, (osk::f2){acc[0][3][e], acc[0][3][e + 1]},
+                                       (osk::f2){hl[hidx], hl[hidx + HS]}, nb_r, nb_z, nb_n, b_hn);
+                const float r = cp.r[e & 1], z = cp.z[e & 1], n = cp.n[e & 1], ghn = cp.ghn[e & 1], hn = cp.hn[e & 1];
                 hn_buf[hidx] = hn;
                 if (a.sv_r) {
                     const int g = tile_row0 + row;
@@ -823,16 +855,16 @@ __global__ __launch_bounds__(512, 1) void gru_layer_ahead_kernel(const LayerArgs
             const rsrc_t rs_r = make_rsrc(a.sv_r, svbytes), rs_z = make_rsrc(a.sv_z, svbytes), rs_n = make_rsrc(a.sv_n, svbytes),
                          rs_g = make_rsrc(a.sv_g, svbytes), rs_h = make_rsrc(a.sv_h, svbytes);
             const uint32_t svoff = (uint32_t)(((size_t)(tile_row0 + 4 * lh) * H + chunk * 32 + li) * 4);
+            CellPair cp;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int hidx = row * HS + chunk * 32 + li;
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][0][e], -LOG2E, nb_r)));
-                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][1][e], -LOG2E, nb_z)));
-                const float ghn = acc[0][3][e] + b_hn;
-                const float u = fmaf(r, ghn, acc[0][2][e]);
-                const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
-                const float hn = fmaf(z, hl[hidx] - n, n);          // (1 - z) n + z h
+                if ((e & 1) == 0)                                    // element pairs (gru_cell_pair): e + 1 is the next row
+                    cp = gru_cell_pair((osk::f2){acc[0][0][e], acc[0][0][e + 1]}, (osk::f2){acc[0][1][e], acc[0][1][e + 1]},
+                                       (osk::f2){acc[0][2][e], acc[0][2][e + 1]}, (osk::f2){acc[0][3][e], acc[0][3][e + 1]},
+                                       (osk::f2){hl[hidx], hl[hidx + HS]}, nb_r, nb_z, nb_n, b_hn);
+                const float r = cp.r[e & 1], z = cp.z[e & 1], n = cp.n[e & 1], ghn = cp.ghn[e & 1], hn = cp.hn[e & 1];
                 hn_buf[hidx] = hn;
                 if (a.sv_r && tile_row0 + row < a.B) {
                     // one per-lane offset register for the 80 stores of a step (flat addresses: two registers per store in flight)

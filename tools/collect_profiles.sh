@@ -44,6 +44,33 @@ bash tools/pmc_pass.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_
 bash tools/pmc_pass.sh ${TAG}_grbm "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES" > $O/pmc_grbm.txt 2>&1
 python3 tools/ab_fused.py 6 > $O/ab_fused.txt 2>&1
 
+# round 4: the reference's model shapes with the repaired k-pair pipeline and gru_layer_stage_kernel (and with it switched off), PMC
+# traffic and SQ counters of the layer kernels, in-kernel timestamps of the layer and fused kernels, the wave-per-trajectory layout
+REF="--hidden 128 --layers 4 --latent 128 --steps 3 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise"
+stats ref_shape $REF
+python3 bench.py $REF > $O/bench_hidden128layers4latent128.json 2>> $O/bench.err
+OS_GRU_STAGE=0 python3 bench.py $REF > $O/bench_hidden128layers4latent128_nostage.json 2>> $O/bench.err
+python3 bench.py --hidden 128 --layers 4 --steps 3 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_hidden128layers4.json 2>> $O/bench.err
+python3 bench.py --hidden 64 --layers 4 --steps 5 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_hidden64layers4.json 2>> $O/bench.err
+bash tools/traffic_ref_shape.sh > $O/traffic_ref_shape.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_ref -- python3 $R/tools/run_ref_shape_once.py 1 > $O/pmc_ref.log 2>&1)
+python3 - <<PY > $O/pmc_ref_shape.txt
+import csv, glob, collections
+f = glob.glob("$O/pmc_ref/**/*counter_collection.csv", recursive=True)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+if f:
+    for r in csv.DictReader(open(f[0])):
+        if "gru_layer" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:32s} n={len(v)} mean={sum(v)/len(v):.5g}")
+PY
+bash tools/layer_ts.sh 2>&1 | grep -v "^$" | grep "==\|cycles per step" > $O/layer_timestamps_raw.txt
+bash tools/fused_ts.sh 2>&1 | grep "cycles per step" > $O/fused_timestamps_raw.txt
+python3 bench.py --mode kf --batch 4096 --seq 1000 --steps 3 --warmup 1 --cpu-seconds 0 --wave-per-trajectory > $O/bench_kf_wave_B4096_T1000.json 2>> $O/bench.err
+python3 bench.py --mode kf --steps 3 --warmup 1 --cpu-seconds 0 --wave-per-trajectory > $O/bench_kf_wave_B65536.json 2>> $O/bench.err
 bash tools/rows_ts.sh > $O/rows2_timestamps_raw.txt 2>&1
 python3 tools/rows_crossover.py 2>/dev/null | grep -v "^RCCL" > $O/rows_crossover.txt
 ls $O
