@@ -329,9 +329,13 @@ __device__ __forceinline__ void stage_dma16(rsrc_t r, float *l, uint32_t voff, u
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, 0);
 }
-__device__ __forceinline__ void buf_store4_nt(rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v)
+// seq_out stores of the stage kernel: DEFAULT cache policy, not non-temporal.  A 64-byte line of the SoA sequence (16 trajectories of
+// one hidden unit) is completed by four 16-byte stores of two lane halves within a few instructions; streamed (nt) they reached HBM as
+// partial sectors -- 4.88 GB written per launch against 2.52 GB algorithmic -- while the write-back L2 merges them: 2.525 GB, the
+// kernel's traffic 958 B per (trajectory, step) = 1.00x algorithmic, and 10.2 -> 9.9 ms per layer (profiles/r04_traffic_ref_shape.txt).
+__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 template <int OFF>
 __device__ __forceinline__ float lds_read_asm(uint32_t addr)
@@ -514,8 +518,8 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
             for (int j = 0; j < 4; j++) {
                 const f32x4 v = {hv[rb][4 * j], hv[rb][4 * j + 1], hv[rb][4 * j + 2], hv[rb][4 * j + 3]};
                 const uint32_t off = (tile_row0 + rgrp * 64 + rb * 32 + 8 * j + 4 * lh < a.B) ? so[rb] + (uint32_t)(8 * j) * 4u : 0x80000000u;
-                buf_store4_nt(rs, off, 0, v);
-                buf_store4_nt(rl, off, 0, v);
+                buf_store4(rs, off, 0, v);
+                buf_store4(rl, off, 0, v);
             }
         }
         OSL_TS(4)                                        // DMA issue + cell update + stores
