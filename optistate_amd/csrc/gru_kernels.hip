@@ -543,8 +543,31 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
 // recurrence cannot be split across workgroups), so a second wave per SIMD is the only thing that can hide a wave's L2 /
 // LDS stalls -- the same lever as the eight-wave backward sweep.  Numerically identical to gru_layer_kernel up to the order
 // of PARTS - 1 additions per gate.
-template <int NCH>
-__global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
+// STACK (gru_stack_kernel below): the layers of a small batch run as ONE launch, blockIdx.y = layer, and layer l consumes
+// layer l - 1's sequence step by step through per-(layer, tile) progress flags in global memory instead of waiting for the
+// whole kernel: `prev` = the producer's flag (null for the first layer of the launch), `mine` = this workgroup's.
+struct StackSync {
+    const uint32_t *prev;
+    uint32_t *mine;
+};
+// sequence elements that cross workgroups inside one launch: sc0 | sc1 accesses (coherent across the XCDs' L2s)
+__device__ __forceinline__ float buf_load_coh(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 17));
+}
+// wait until the producer has published step `need - 1`; false after ~4 M polls (seconds): the caller then poisons its input with
+// NaN, so a lost producer ends in NaN outputs -- never in a hung GPU and never in plausible wrong numbers
+__device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need)
+{
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+
+template <int NCH, bool STACK>
+__device__ __forceinline__ void split_layer_body(const LayerArgs &a, const StackSync sy)
 {
     constexpr int PARTS = 8 / NCH;
 #ifdef OS_LAYER_TS
@@ -589,12 +612,17 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
     const int xk0 = threadIdx.x >> 5;
     const uint32_t xsoff = (uint32_t)growc * 4u + (uint32_t)xk0 * rowB;
     float xr[XE];
+    const bool consume = STACK && sy.prev != nullptr;               // x comes from a producer inside this launch
     auto xfetch = [&](int t) {
+        bool lost = false;
+        if (consume) lost = !stack_wait(sy.prev, (uint32_t)t + 1u);  // every lane polls (one request per wave): step t is published
         const rsrc_t rx = make_rsrc(a.xs + (size_t)t * a.K * B, (uint32_t)a.K * rowB);
 #pragma unroll
         for (int e = 0; e < XE; e++) {
             if (e * 16 >= a.K) break;
-            xr[e] = buf_load(rx, xsoff, __builtin_amdgcn_readfirstlane((uint32_t)(e * 16) * rowB));
+            const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(e * 16) * rowB);
+            xr[e] = consume ? buf_load_coh(rx, xsoff, so) : buf_load(rx, xsoff, so);
+            if (STACK && lost) xr[e] = __builtin_nanf("");
         }
     };
     auto xstage = [&](float *xl) {
@@ -616,6 +644,20 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
             if (g < a.B) dst[(size_t)k * B + g] = hsrc[row * HS + k];
         }
     };
+    // STACK: h_t -> seq_out[t] with write-through (sc0 sc1) stores right after the step, then the progress flag as an agent-scope
+    // release once every wave's stores are acknowledged
+    auto publish = [&](const float *hsrc, int t) {
+        const rsrc_t rq = make_rsrc(a.seq_out + (size_t)t * H * B, (uint32_t)H * rowB);
+        for (int i = threadIdx.x; i < BM * H; i += 512) {
+            const int row = i % BM, k = i / BM;
+            const int g = tile_row0 + row;
+            if (g < a.B)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hsrc[row * HS + k]), rq, (uint32_t)g * 4u, (uint32_t)k * rowB, 17);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged (a workgroup-scope barrier does not wait for them)
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(sy.mine, (uint32_t)t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
 
 #ifdef OS_LAYER_TS
     const unsigned long long ts_pro = __builtin_readcyclecounter() - ts_start;
@@ -625,7 +667,7 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
         OSL_TS(0)
         const float *hl = hl2 + (t & 1) * BM * HS;          // h_{t-1}
         float *hn_buf = hl2 + ((t + 1) & 1) * BM * HS;       // h_t
-        if (t > 0 && a.seq_out) write_back(hl, a.seq_out + (size_t)(t - 1) * H * B);
+        if (!STACK && t > 0 && a.seq_out) write_back(hl, a.seq_out + (size_t)(t - 1) * H * B);
         OSL_TS(1)                                            // write-back of h_{t-1} (LDS -> SoA)
 
         f32x16 acc[1][4];
@@ -686,6 +728,7 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
         if (t + 1 < a.T) xstage(xl2 + ((t + 1) & 1) * BM * XS);
         lds_barrier();   // h_t and x_{t+1} complete (and the exchange buffers free again)
         OSL_TS(5)                                            // x tile staged, barrier
+        if (STACK && a.seq_out) publish(hn_buf, t);          // the next layer's workgroup of this tile may take step t now
     }
 #ifdef OS_LAYER_TS
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -694,8 +737,34 @@ __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs
                (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5]) / a.T, ts_pro);
 #endif
     const float *hT = hl2 + (a.T & 1) * BM * HS;
-    if (a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
+    if (!STACK && a.seq_out) write_back(hT, a.seq_out + (size_t)(a.T - 1) * H * B);
     if (a.h_last) write_back(hT, a.h_last);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
+{
+    split_layer_body<NCH, false>(a, StackSync{nullptr, nullptr});
+}
+
+// Small batches, several layers: ONE launch, blockIdx.y = layer, the layers of a tile pipelined against each other (round 4).
+// At B <= 32 x (CUs / layers) every (layer, tile) workgroup is resident at once, so layer l can run step t while layer l - 1 runs
+// step t + 2: a stack of L layers takes about T + 2 (L - 1) step times instead of L T (VERDICT r3 next 3 proposed this
+// layer-diagonal order for the 8,192-window training batch, where every CU already holds a tile and nothing is idle: section
+// 4.4; it pays where CUs ARE idle -- config 5's 128 trajectories, the reference's own batches of 64 and 1).  Workgroups are
+// dispatched in linear order (layer-major), a consumer only ever waits for a workgroup with a smaller id, and every wait is
+// bounded, so a producer that never shows up costs wrong numbers, not a hung device.
+struct StackArgs {
+    int n, tiles;
+    uint32_t *flags;             // [n][tiles] progress counters, zeroed before the launch
+    LayerArgs layer[8];
+};
+template <int NCH>
+__global__ __launch_bounds__(512, 1) void gru_stack_kernel(const StackArgs sa)
+{
+    const int l = blockIdx.y;
+    uint32_t *mine = sa.flags + (size_t)l * sa.tiles + blockIdx.x;
+    split_layer_body<NCH, true>(sa.layer[l], StackSync{l > 0 ? mine - sa.tiles : nullptr, mine});
 }
 
 // H = 128 small-batch variant with the INPUT half of the gate GEMM running ahead of the recurrence.
@@ -1072,6 +1141,13 @@ static bool ahead_eligible(os_ctx *ctx, int B, int T, int K, int H)
     return split && H == 128 && (size_t)T * B * H * 4 < ((size_t)1 << 32) && (size_t)T * B * K * 4 < ((size_t)1 << 32) &&
            ctx->tune_gru_ahead != 0;
 }
+// true when gru_layers will run layers first..L-1 as ONE pipelined launch (gru_stack_kernel: the eight-wave split body)
+static bool stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers)
+{
+    const int NCH = H / 32, tiles = (B + 31) / 32;
+    return ctx->tune_gru_stack != 0 && nlayers >= 2 && nlayers <= 8 && (NCH == 4 || NCH == 2 || NCH == 1) && Kfirst <= 192 && H <= 192 &&
+           tiles * nlayers <= ctx->cu_count && (size_t)T * B * (Kfirst > H ? Kfirst : H) * 4 < ((size_t)1 << 31);
+}
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H) { return ahead_eligible(ctx, B, T, K, H); }
 
 // Launches gru_layer_kernel for one layer (shared by inference and the training forward).
@@ -1166,6 +1242,52 @@ static int gru_layers(os_ctx *ctx, int B, int T, const float *in, int in_btf, in
     const size_t hf = (size_t)H * B;
     size_t woff = 0;
     for (int l = 0; l < first_layer; l++) woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
+    if (!in_btf && stack_eligible(ctx, B, T, first_layer == 0 ? d.input_size : H, H, L - first_layer)) {
+        // ---- small batch: the whole stack as one launch, layers pipelined through progress flags (gru_stack_kernel) ----
+        StackArgs sa;
+        sa.n = L - first_layer; sa.tiles = (B + 31) / 32;
+        const size_t nfl = (size_t)sa.n * sa.tiles;
+        if (ctx->stack_flags_n < nfl) {
+            if (ctx->stack_flags) OS_HIP(ctx, hipFree(ctx->stack_flags));
+            ctx->stack_flags = nullptr; ctx->stack_flags_n = 0;
+            OS_HIP(ctx, hipMalloc((void **)&ctx->stack_flags, nfl * sizeof(uint32_t)));
+            ctx->stack_flags_n = nfl;
+        }
+        sa.flags = ctx->stack_flags;
+        OS_HIP(ctx, hipMemsetAsync(sa.flags, 0, nfl * sizeof(uint32_t), s));
+        size_t lds_max = 0;
+        const float *lin = in;
+        for (int l = first_layer; l < L; l++) {
+            const int K = l == 0 ? d.input_size : H;
+            LayerArgs &a = sa.layer[l - first_layer];
+            a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
+            a.xs = lin; a.xs_btf = 0; a.w = ctx->gru_packed + woff;
+            a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
+            a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
+            a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
+            const int parts = 8 / NCH;
+            const size_t lds_l = ((size_t)2 * 32 * (H + 1) + (size_t)2 * 32 * (2 * a.KPx + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
+            lds_max = lds_l > lds_max ? lds_l : lds_max;
+            lin = a.seq_out;
+            woff += os_layer_packed_floats(K, H);
+        }
+        if (!ctx->stack_attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->stack_attr_set = true;
+        }
+        const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_stack_kernel");
+        const dim3 grid(sa.tiles, sa.n), block(512);
+        if (NCH == 4) hipLaunchKernelGGL(gru_stack_kernel<4>, grid, block, lds_max, s, sa);
+        else if (NCH == 2) hipLaunchKernelGGL(gru_stack_kernel<2>, grid, block, lds_max, s, sa);
+        else hipLaunchKernelGGL(gru_stack_kernel<1>, grid, block, lds_max, s, sa);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+        const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
+        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
+        return os_gru_head_launch(ctx, B, top, fcw, out, s);
+    }
     for (int l = first_layer; l < L; l++) {
         const int K = l == 0 ? d.input_size : H;
         LayerArgs a;
@@ -1210,7 +1332,8 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
     // reads that layout itself (small batches at H = 128)
     const int I = ctx->gru.input_size;
     const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
-    const bool x_direct = os_gru_layer_takes_btf(ctx, B, T, I, H);
+    // (the stack kernel reads an SoA first layer: packing costs a few microseconds at its sizes)
+    const bool x_direct = !stack_eligible(ctx, B, T, I, H, L) && os_gru_layer_takes_btf(ctx, B, T, I, H);
     int rc = 0;
     if (!x_direct) {
         if (os_ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;

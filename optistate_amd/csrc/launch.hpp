@@ -21,6 +21,9 @@ struct os_ctx {
     int tune_rows_v1;                    // OS_KF_ROWS_V1=1: the first 16-lanes-per-trajectory kernel instead of kf_run_rows2_kernel (A/B runs)
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
+    int tune_gru_stack;                  // 1: small batches run their layer stack as one pipelined launch (gru_stack_kernel), 0: a launch per layer
+    uint32_t *stack_flags;               // gru_stack_kernel's progress counters [layers][tiles]
+    size_t stack_flags_n;
     int tune_dw_dbg;                     // development: Dw3Args.dbg (OS_DW_DBG)
     int tune_gru_stage;                  // 1: large-batch H = 128 inference layers use gru_layer_stage_kernel (x tile by LDS-DMA), 0: gru_layer_kernel<2,2>
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
@@ -60,7 +63,7 @@ struct os_ctx {
     double mpc_w[12], mpc_rw, mpc_mu, mpc_fzmax;
     double mass64, inertia64[3], gz64;
     float *mpc_scratch; size_t mpc_scratch_floats;
-    bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set, ahead_attr_set, stage_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
+    bool fused_attr_set, sweep_attr_set, layer_attr_set, split_attr_set, ahead_attr_set, stage_attr_set, stack_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this device
     void *vit;                           // os_vit_state (vit_kernels.hip), created by os_vit_load
     void *train;                         // os_train_state (gru_train_kernels.hip), created on first use
     int bwd_mark_layer; void *bwd_mark_event;   // os_gru_backward_mark: event recorded behind this layer's weight-gradient kernel

@@ -60,8 +60,8 @@ def test_ragged_batch_vs_oracle(dims):
 
 
 @pytest.mark.parametrize("I,B,T", [(61, 1, 1), (60, 33, 2), (188, 40, 3), (128, 257, 5)])
-def test_run_ahead_layer_kernel_edges(I, B, T):
-    """H = 128 at small batch takes gru_layer_ahead_kernel (input half one to two steps ahead, (B, T, I) read directly): its
+def test_run_ahead_layer_kernel_edges(monkeypatch, I, B, T):
+    """H = 128 at small batch, a launch per layer (OS_GRU_STACK=0), takes gru_layer_ahead_kernel (input half one to two steps ahead, (B, T, I) read directly): its
     prologue / epilogue at T = 1, 2, 3, odd and 188-wide inputs, partial tiles; float64 oracle as truth, and the eight-wave
     split kernel (OS_GRU_AHEAD=0) must give the same numbers up to summation order."""
     import os
@@ -69,13 +69,16 @@ def test_run_ahead_layer_kernel_edges(I, B, T):
     from optistate_amd import engine as eng_mod
     from oracle import c_oracle as orc
     H, L, C = 128, 2, 24
+    monkeypatch.setenv("OS_GRU_STACK", "0")                  # tuning knobs are read when an Engine is created
     torch.manual_seed(11)
-    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda").eval()
+    m = RNN(I, H, L, C, torch.device("cpu"))
     x = torch.rand(B, T, I)
-    with torch.no_grad():
-        out = m(x.cuda()).cpu().numpy()
-    assert m._engine.kernel_name("gru_layer") == "gru_layer_ahead_kernel"
     w = orc.flatten_state_dict(m.state_dict(), L)
+    e1 = Engine(0)
+    e1.load_gru(torch.as_tensor(w, dtype=torch.float32).cuda(), I, H, L, C)
+    out = e1.gru_forward(x.cuda())
+    out = (out[0] if isinstance(out, (tuple, list)) else out).cpu().numpy()
+    assert e1.kernel_name("gru_layer") == "gru_layer_ahead_kernel"
     ref, _, _ = orc.gru_forward(x.numpy(), w, I, H, L, C)
     assert np.abs(out - ref).max() < GRU_TOL
     os.environ["OS_GRU_AHEAD"] = "0"
@@ -217,3 +220,67 @@ def test_stage_kernel_large_batch_bit_identical_to_plain_kernel_and_close_to_ora
     ref, _, _ = orc.gru_forward(x, orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
     err = np.abs(outs["1"][pick.cuda()].cpu().numpy() - ref).max()
     assert err < GRU_TOL, err
+
+
+@pytest.mark.parametrize("I,H,L,B,T", [(188, 128, 4, 128, 10), (188, 128, 4, 1, 10), (60, 64, 4, 64, 100), (61, 32, 2, 33, 7),
+                                       (60, 128, 8, 900, 25), (188, 128, 4, 2048, 3), (60, 64, 2, 5, 1)])
+def test_layer_pipelined_stack_kernel_bit_identical_to_per_layer_launches(monkeypatch, I, H, L, B, T):
+    """Small batches run their layer stack as ONE launch (gru_stack_kernel: blockIdx.y = layer, layer l takes step t of layer
+    l - 1 through a progress flag as soon as it is published).  The workgroups run gru_layer_split_kernel's body, so against a
+    launch per layer of THAT kernel (OS_GRU_STACK=0 OS_GRU_AHEAD=0) the outputs and every layer's h_T must be identical -- any
+    consumer that read a step before it was complete would show here -- on every one of 20 repeats; float64 oracle as truth.
+    Shapes: the reference's model at config 5's 128 trajectories and at its own batch of 1, 4 x 64 over 100 steps, odd input
+    width with a partial tile, eight layers x 29 tiles (232 of 256 CUs), the largest eligible batch (64 tiles x 4), T = 1."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from oracle import c_oracle as orc
+    C = 24
+    torch.manual_seed(23)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    x = (torch.rand(B, T, I) * 2 - 1).cuda()
+    monkeypatch.setenv("OS_GRU_STACK", "0"); monkeypatch.setenv("OS_GRU_AHEAD", "0")
+    e0 = Engine(0)
+    e0.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    out0, hl0 = e0.gru_forward(x, want_h_last=True)
+    torch.cuda.synchronize()
+    assert e0.kernel_name("gru_layer").startswith("gru_layer_split_kernel") or H == 32, e0.kernel_name("gru_layer")
+    monkeypatch.setenv("OS_GRU_STACK", "1"); monkeypatch.delenv("OS_GRU_AHEAD")
+    e1 = Engine(0)
+    e1.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    for rep in range(20):
+        out1, hl1 = e1.gru_forward(x, want_h_last=True)
+        torch.cuda.synchronize()
+        assert e1.kernel_name("gru_layer") == "gru_stack_kernel"
+        if H == 32:        # a launch per layer runs H = 32 through gru_layer_kernel<1,3>: same sums in another order
+            assert (out1 - out0).abs().max().item() < 2e-6 and (hl1 - hl0).abs().max().item() < 2e-6, rep
+        else:
+            assert torch.equal(out1, out0), (rep, (out1 - out0).abs().max().item())
+            assert torch.equal(hl1, hl0), rep
+    ref, _, _ = orc.gru_forward(x.cpu().numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+    assert np.abs(out1.cpu().numpy() - ref).max() < GRU_TOL
+
+
+def test_layer_pipelined_stack_kernel_behind_the_fused_first_layer(monkeypatch):
+    """os_fused_run shape: the fused Kalman + GRU layer-0 kernel writes the sequence, layers 1..3 follow as one stack launch
+    (first_layer = 1); identical numbers to a launch per layer of the split kernel."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    I, H, L, C, B, T = 60, 64, 4, 24, 96, 40
+    d = synth_numpy(B, T, seed=31)
+    torch.manual_seed(29)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    outs = {}
+    for stack in ("0", "1"):
+        monkeypatch.setenv("OS_GRU_STACK", stack)
+        eng = Engine(0)
+        eng.set_noise(Q_FITTED, R_FITTED)
+        eng.load_gru(flatten_state_dict(m.state_dict(), L), I, H, L, C)
+        s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
+        c = eng.pack_contact(torch.as_tensor(d["contact"]))
+        x = torch.as_tensor(d["x0"].T.copy()).cuda()
+        P = torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+        mm = torch.stack([torch.full((60,), -3.0), torch.full((60,), 3.0)]).cuda()
+        outs[stack] = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], c, s["accel"], mm, x, P)["out"]
+        torch.cuda.synchronize()
+        assert (eng.kernel_name("gru_layer") == "gru_stack_kernel") == (stack == "1"), eng.kernel_name("gru_layer")
+    assert torch.isfinite(outs["1"]).all()
+    assert (outs["1"] - outs["0"]).abs().max().item() < 2e-6
