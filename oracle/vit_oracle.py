@@ -31,8 +31,9 @@ def layer_norm(x, w, b, eps=1e-5):
     return (x - mu) / np.sqrt(var + eps) * w + b
 
 
-def encode(images, sd, patch=16, heads=4):
-    """images [N][H][W] float; sd: dict of numpy arrays with the reference's state_dict keys -> latent [N][D]."""
+def encode(images, sd, patch=16, heads=4, block_outputs=None):
+    """images [N][H][W] float; sd: dict of numpy arrays with the reference's state_dict keys -> latent [N][D].
+    block_outputs: optional list that receives the token tensor [N][1 + G*G][D] after every block."""
     g = lambda k: np.asarray(sd[k], dtype=np.float64)
     x = np.asarray(images, dtype=np.float64)
     N, Hh, Ww = x.shape
@@ -61,5 +62,7 @@ def encode(images, sd, patch=16, heads=4):
         h = y @ g(p + "mlp.fc1.weight").T + g(p + "mlp.fc1.bias")
         h = 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
         x = x + h @ g(p + "mlp.fc2.weight").T + g(p + "mlp.fc2.bias")
+        if block_outputs is not None:
+            block_outputs.append(x.copy())
     x = layer_norm(x, g("norm.weight"), g("norm.bias"))
     return 1.0 / (1.0 + np.exp(-x[:, 0, :]))

@@ -43,6 +43,10 @@ def test_hip_encoder_matches_the_reference_glue_fixture_g11():
     lat = m.forward_encoder(torch.from_numpy(g11_frames()).unsqueeze(1).cuda())[:, 0].cpu().numpy()
     assert np.abs(lat - g["latent_f64"]).max() < 2e-5, np.abs(lat - g["latent_f64"]).max()
     assert np.abs(lat - g["latent_f32"]).max() < 2e-5
+    # G14: the same frames and weights through the reference's glue with Hugging Face transformers' ViTLayer / ViTPatchEmbeddings as
+    # the blocks (tools/hf_vit_blocks.py): nothing of ours between the reference's code and these latents
+    h = load_golden("vit_g14_hf_blocks.npz")
+    assert np.abs(lat - h["latent_f64"]).max() < 2e-5 and np.abs(lat - h["latent_f32"]).max() < 2e-5
 
 
 def test_pos_embed_table_and_state_dict_keys():
