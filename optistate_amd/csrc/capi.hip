@@ -52,6 +52,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_GRU_AHEAD"); c->tune_gru_ahead = e ? atoi(e) : 1;
         e = getenv("OS_GRU_STAGE"); c->tune_gru_stage = e ? atoi(e) : 1;
         e = getenv("OS_GRU_STACK"); c->tune_gru_stack = e ? atoi(e) : 1;
+        e = getenv("OS_GRU_VEC"); c->tune_gru_vec = e ? atoi(e) : 1;
         e = getenv("OS_MPC_PERSISTENT"); c->tune_mpc_persistent = e ? atoi(e) : 1;
         e = getenv("OS_VIT_MLP_FUSED"); c->tune_vit_mlp_fused = e ? atoi(e) : 3;
         e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 512;      // 2 x 240 workgroups at the training batch: two per CU
@@ -92,7 +93,10 @@ void os_destroy(os_ctx *ctx)
     os_step_destroy(ctx);
     os_vit_destroy(ctx);
     for (auto &sl : ctx->gru_slots)
+    {
         if (sl.packed) (void)hipFree(sl.packed);
+        if (sl.vec) (void)hipFree(sl.vec);
+    }
     if (ctx->stack_flags) (void)hipFree(ctx->stack_flags);
     float *bufs[] = {ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)

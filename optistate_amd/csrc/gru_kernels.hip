@@ -1034,6 +1034,166 @@ __global__ __launch_bounds__(256) void gru_head_kernel(int B, int H, int C, cons
     }
 }
 
+
+// ---- B <= 4: the whole model in ONE single-workgroup launch on the vector pipe (round 4) --------------------------------------
+// The reference's own evaluation loop calls the model on ONE window at a time and reports the time of that call
+// (gru/gru_test.py:157, :171-177: DataLoader(batch_size=1), `computation_time`).  A 32-row MFMA tile is 31/32 padding there and a
+// step costs the full 12.6 us of tile MFMAs; as matrix-vector products the same step is 49 k multiply-adds.  One workgroup of 768
+// threads runs layer after layer: thread = (gate row r of 3H, column split s of CS = 768 / 3H).
+//   phase A  gi[n][r] = b + W_ih[r][:] x_n for ALL N = B T columns at once (x does not depend on this layer's h): each weight is read
+//            once (transposed image: coalesced over r), the x values are LDS broadcasts, N accumulators per thread;
+//   phase B  per step: the thread's H / CS recurrent weights stay in REGISTERS for the whole layer (H = 128: 64 VGPRs, 196 KB of the
+//            CU's 512 KB register file), h_{t-1} is an LDS broadcast; partial sums -> LDS, barrier, B H threads do the cell update and
+//            write h_t (and the next layer's input column), barrier.
+// No cross-workgroup traffic, no MFMA; the head (fc + sigmoid) and h_T of every layer in torch layout come out of the same launch.
+struct VecArgs {
+    int B, T, K0, L, C, use_sigmoid;
+    const float *x;              // (B, T, K0) as the caller passes it
+    const float *wvec;           // per layer: W_ih^T [K][3H] | W_hh^T [H][3H] | b_gi [3H] (b_ih + b_hh for r, z; b_in) | b_hn [H]
+    const float *fcw, *fcb;
+    float *out;                  // [B][C]
+    float *h_last;               // [L][B][H] or null
+};
+__host__ __device__ inline size_t vec_layer_floats(int K, int H) { return (size_t)K * 3 * H + (size_t)H * 3 * H + 3 * H + H; }
+
+struct PackVec { int n, H; int K[16]; const float *Wih[16], *Whh[16], *bih[16], *bhh[16]; float *dst[16]; };
+__global__ __launch_bounds__(256) void gru_pack_vec_kernel(const PackVec p)
+{
+    const int l = blockIdx.y, H = p.H, R = 3 * H, K = p.K[l];
+    float *d = p.dst[l];
+    const int nih = K * R, nhh = H * R;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nih + nhh + R + H; i += gridDim.x * 256) {
+        float v;
+        if (i < nih) v = p.Wih[l][(size_t)(i % R) * K + i / R];
+        else if (i < nih + nhh) { const int j = i - nih; v = p.Whh[l][(size_t)(j % R) * H + j / R]; }
+        else if (i < nih + nhh + R) { const int r = i - nih - nhh; v = p.bih[l][r] + (r < 2 * H ? p.bhh[l][r] : 0.f); }
+        else v = p.bhh[l][2 * H + (i - nih - nhh - R)];
+        d[i] = v;
+    }
+}
+
+constexpr int VEC_NMAX = 48, VEC_NPASS = 24, VEC_BMAX = 4, VEC_THREADS = 768;
+template <int H>
+__global__ __launch_bounds__(VEC_THREADS) void gru_vec_kernel(const VecArgs a)
+{
+    constexpr int R = 3 * H, CS = VEC_THREADS / R, HC = H / CS;
+    static_assert(CS * R == VEC_THREADS && HC % 4 == 0, "768 threads = 3H rows x CS column splits");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int B = a.B, T = a.T, N = B * T, NP = (N + 3) & ~3;
+    const int KA = a.K0 > H ? a.K0 : H;
+    float *xbuf[2] = {smem, smem + (size_t)KA * NP};                 // layer input [k][NP] (column n = b T + t), ping-pong
+    float *gi = xbuf[1] + (size_t)H * NP;                              // [NP][R]
+    float *gh = gi + (size_t)NP * R;                                   // [CS][B][R]
+    float *hcur = gh + (size_t)CS * VEC_BMAX * R;                      // [B][H]
+    const int tid = threadIdx.x;
+    const int row = tid % R, s = tid / R;                             // s is wave-uniform (R is a multiple of 64)
+
+    for (int i = tid; i < KA * NP; i += VEC_THREADS) xbuf[0][i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < N * a.K0; i += VEC_THREADS) xbuf[0][(i % a.K0) * NP + i / a.K0] = a.x[i];
+    __syncthreads();
+
+    const float *w = a.wvec;
+    for (int l = 0; l < a.L; l++) {
+        const int K = l == 0 ? a.K0 : H;
+        const float *wih = w, *whh = w + (size_t)K * R, *bgi = whh + (size_t)H * R, *bhn = bgi + R;
+        const float *xin = xbuf[l & 1];
+        float *xout = xbuf[(l + 1) & 1];
+        const bool last = l == a.L - 1;
+        // ---- phase A ----
+        const float b0 = s == 0 ? bgi[row] : 0.f;
+        const int KS = (K + CS - 1) / CS, k0 = s * KS, k1 = (k0 + KS < K) ? k0 + KS : K;
+        const rsrc_t ri = make_rsrc(wih, (uint32_t)K * R * 4u);        // rows past K read zero through the range check
+        for (int nb = 0; nb < NP; nb += VEC_NPASS) {                   // VEC_NPASS columns per pass over the weights (one pass at B = 1, 2)
+            float acc[VEC_NPASS];
+#pragma unroll
+            for (int n = 0; n < VEC_NPASS; n++) acc[n] = b0;
+            for (int kb = k0; kb < k1; kb += 4) {
+                float wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    wv[j] = kb + j < k1 ? buf_load(ri, (uint32_t)row * 4u, __builtin_amdgcn_readfirstlane((uint32_t)((kb + j) * R) * 4u)) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k = kb + j < k1 ? kb + j : k1 - 1;    // weight 0 beyond the range
+#pragma unroll
+                    for (int n4 = 0; n4 < VEC_NPASS; n4 += 4)
+                        if (nb + n4 < NP) {
+                            const float4 xv = *reinterpret_cast<const float4 *>(&xin[k * NP + nb + n4]);
+                            acc[n4] = fmaf(wv[j], xv.x, acc[n4]); acc[n4 + 1] = fmaf(wv[j], xv.y, acc[n4 + 1]);
+                            acc[n4 + 2] = fmaf(wv[j], xv.z, acc[n4 + 2]); acc[n4 + 3] = fmaf(wv[j], xv.w, acc[n4 + 3]);
+                        }
+                }
+            }
+            for (int ss = 0; ss < CS; ss++) {                         // the splits add up in a fixed order
+                if (s == ss) {
+#pragma unroll
+                    for (int n = 0; n < VEC_NPASS; n++)
+                        if (nb + n < N) gi[(nb + n) * R + row] = ss == 0 ? acc[n] : gi[(nb + n) * R + row] + acc[n];
+                }
+                __syncthreads();
+            }
+        }
+        // this thread's recurrent weights (requested behind phase A: held across it they would not fit beside its accumulators)
+        float wr[HC];
+        {   // one per-lane offset, the column in the scalar offset (flat addresses: a 64-bit address pair per weight, spilled)
+            const rsrc_t rw = make_rsrc(whh + (size_t)s * HC * R, (uint32_t)HC * R * 4u);
+#pragma unroll
+            for (int i = 0; i < HC; i++) wr[i] = buf_load(rw, (uint32_t)row * 4u, (uint32_t)(i * R) * 4u);
+        }
+        for (int i = tid; i < B * H; i += VEC_THREADS) hcur[i] = 0.f;  // h0 = 0 (gru/gru_model.py:27)
+        __syncthreads();
+        // ---- phase B ----
+        const int cb = tid / H, cu = tid % H;                          // cell update: thread = (trajectory, hidden unit)
+        const float my_bhn = tid < B * H ? bhn[cu] : 0.f;
+        for (int t = 0; t < T; t++) {
+            if (t > 0) {
+                for (int b = 0; b < B; b++) {
+                    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < HC; i += 4) {
+                        const float4 hv = *reinterpret_cast<const float4 *>(&hcur[b * H + s * HC + i]);
+                        p0 = fmaf(wr[i], hv.x, p0); p1 = fmaf(wr[i + 1], hv.y, p1);
+                        p0 = fmaf(wr[i + 2], hv.z, p0); p1 = fmaf(wr[i + 3], hv.w, p1);
+                    }
+                    gh[(s * VEC_BMAX + b) * R + row] = p0 + p1;
+                }
+                __syncthreads();
+            }
+            if (tid < B * H) {
+                const int n = cb * T + t;
+                float gr = 0.f, gz = 0.f, gn = 0.f;
+                if (t > 0) {
+#pragma unroll
+                    for (int ss = 0; ss < CS; ss++) {
+                        const float *g = gh + (ss * VEC_BMAX + cb) * R;
+                        gr += g[cu]; gz += g[H + cu]; gn += g[2 * H + cu];
+                    }
+                }
+                const float r = sigmoidf_(gi[n * R + cu] + gr), z = sigmoidf_(gi[n * R + H + cu] + gz);
+                const float nn = tanhf_(fmaf(r, gn + my_bhn, gi[n * R + 2 * H + cu]));
+                const float hn = fmaf(z, hcur[cb * H + cu] - nn, nn);                 // (1 - z) n + z h
+                hcur[cb * H + cu] = hn;
+                if (!last) xout[cu * NP + n] = hn;
+            }
+            __syncthreads();
+        }
+        if (a.h_last && tid < B * H) a.h_last[((size_t)l * B + cb) * H + cu] = hcur[cb * H + cu];
+        w += vec_layer_floats(K, H);
+    }
+    // ---- head: fc (+ sigmoid) on the top layer's h_T ----
+    for (int i = tid; i < B * a.C; i += VEC_THREADS) {
+        const int b = i / a.C, c = i % a.C;
+        float v0 = 0.f, v1 = 0.f;
+        for (int u = 0; u < H; u += 2) {
+            v0 = fmaf(a.fcw[(size_t)c * H + u], hcur[b * H + u], v0);
+            v1 = fmaf(a.fcw[(size_t)c * H + u + 1], hcur[b * H + u + 1], v1);
+        }
+        const float v = (v0 + v1) + a.fcb[c];
+        a.out[(size_t)b * a.C + c] = a.use_sigmoid ? sigmoidf_(v) : v;
+    }
+}
+
 }  // namespace osg
 
 using namespace osg;
@@ -1102,9 +1262,11 @@ int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, ui
         hipLaunchKernelGGL(gru_pack_all_kernel, dim3(H / 32, 16, d->num_layers), dim3(256), 0, (hipStream_t)stream, pa);
         OS_HIP(ctx, hipGetLastError());
         slot->key = key; slot->d = *d; slot->flat = w_flat;
+        slot->vec_valid = false;
         ctx->gru_generation++;                                  // counts packs (os_gru_generation): a cache hit does not bump it
     }
     slot->stamp = ++ctx->gru_clock;
+    ctx->gru_slot = slot;
     ctx->gru_packed = slot->packed;
     ctx->gru = *d;
     ctx->gru_flat = w_flat;
@@ -1133,6 +1295,13 @@ int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, f
     return 0;
 }
 
+// LDS bytes of the eight-wave split body: h double buffer | x double buffer | exchange buffers.  H = 64 with K = 189..192 does not
+// fit the 160 KB (round 4: found by a stack-kernel test; such a layer takes the plain kernel)
+static size_t split_lds_bytes(int K, int H)
+{
+    const int NCH = H / 32, parts = 8 / NCH, KPx = (K + 1) / 2;
+    return ((size_t)2 * 32 * (H + 1) + (size_t)2 * 32 * (2 * KPx + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
+}
 // true when os_gru_launch_layer will pick gru_layer_ahead_kernel for this shape (the one kernel that can read a (B, T, K)
 // batch_first input directly: LayerArgs.xs_btf)
 static bool ahead_eligible(os_ctx *ctx, int B, int T, int K, int H)
@@ -1146,7 +1315,7 @@ static bool stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nla
 {
     const int NCH = H / 32, tiles = (B + 31) / 32;
     return ctx->tune_gru_stack != 0 && nlayers >= 2 && nlayers <= 8 && (NCH == 4 || NCH == 2 || NCH == 1) && Kfirst <= 192 && H <= 192 &&
-           tiles * nlayers <= ctx->cu_count && (size_t)T * B * (Kfirst > H ? Kfirst : H) * 4 < ((size_t)1 << 31);
+           split_lds_bytes(Kfirst, H) <= 160 * 1024 && tiles * nlayers <= ctx->cu_count && (size_t)T * B * (Kfirst > H ? Kfirst : H) * 4 < ((size_t)1 << 31);
 }
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H) { return ahead_eligible(ctx, B, T, K, H); }
 
@@ -1171,7 +1340,7 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
     // at most one 32-row tile per CU: eight waves on one tile (slices of the gate GEMM's reduction);
     // measured (60,128,4), T = 100: B = 4096 35 -> 48, B = 8192 70 -> 92 TFLOP/s; from two tiles per CU on the plain kernel wins
     bool split = NCH >= 2 && (a.B + 31) / 32 <= ctx->cu_count;       // H = 32 (eight slices per chunk) loses: plain kernel
-    if (a.K > 192) split = false;                                    // its x tile staging covers 12 x 16 inputs
+    if (a.K > 192 || split_lds_bytes(a.K, H) > 160 * 1024) split = false;   // its x tile staging covers 12 x 16 inputs
     if (ctx->tune_gru_split == 0) split = false;
     const bool ahead = ahead_eligible(ctx, a.B, a.T, a.K, H);
     if (a.xs_btf && !ahead) return os_fail(ctx, -4, "os_gru_launch_layer: a batch_first input needs the ahead kernel's shape");
@@ -1322,6 +1491,57 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
     return os_gru_layers_impl(ctx, B, T, xs, 0, out, h_last_all, (hipStream_t)stream);
 }
 
+// B <= 4 windows of at most 48 / B steps at the reference's widths: the single-workgroup vector kernel
+static bool vec_eligible(os_ctx *ctx, int B, int T)
+{
+    const os_gru_dims &d = ctx->gru;
+    return ctx->tune_gru_vec != 0 && B <= VEC_BMAX && B * T <= VEC_NMAX && (d.hidden_size == 128 || d.hidden_size == 64) && d.input_size <= 192;
+}
+static int gru_vec_launch(os_ctx *ctx, int B, int T, const float *x, float *out, float *h_last, hipStream_t s)
+{
+    const os_gru_dims &d = ctx->gru;
+    const int H = d.hidden_size, L = d.num_layers, R = 3 * H;
+    os_ctx::GruSlot *slot = ctx->gru_slot;
+    if (!slot->vec_valid) {                                  // transposed image of the current weights, once per os_gru_load
+        size_t total = 0;
+        for (int l = 0; l < L; l++) total += vec_layer_floats(l == 0 ? d.input_size : H, H);
+        if (os_ensure_scratch(ctx, &slot->vec, &slot->vec_cap, total)) return -10;
+        PackVec pv;
+        pv.n = L; pv.H = H;
+        size_t src = 0, dst = 0;
+        for (int l = 0; l < L; l++) {
+            const int K = l == 0 ? d.input_size : H;
+            pv.K[l] = K;
+            pv.Wih[l] = ctx->gru_flat + src; pv.Whh[l] = pv.Wih[l] + (size_t)R * K; pv.bih[l] = pv.Whh[l] + (size_t)R * H; pv.bhh[l] = pv.bih[l] + R;
+            pv.dst[l] = slot->vec + dst;
+            src += (size_t)R * K + (size_t)R * H + 2 * (size_t)R;
+            dst += vec_layer_floats(K, H);
+        }
+        hipLaunchKernelGGL(gru_pack_vec_kernel, dim3(64, L), dim3(256), 0, s, pv);
+        OS_HIP(ctx, hipGetLastError());
+        slot->vec_valid = true;
+    }
+    VecArgs a;
+    a.B = B; a.T = T; a.K0 = d.input_size; a.L = L; a.C = d.num_classes; a.use_sigmoid = d.use_sigmoid;
+    a.x = x; a.wvec = slot->vec;
+    a.fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
+    a.fcb = a.fcw + (size_t)d.num_classes * H;
+    a.out = out; a.h_last = h_last;
+    const int NP = (B * T + 3) & ~3, KA = d.input_size > H ? d.input_size : H, CS = VEC_THREADS / R;
+    const size_t lds = ((size_t)KA * NP + (size_t)H * NP + (size_t)NP * R + (size_t)CS * VEC_BMAX * R + (size_t)VEC_BMAX * H) * sizeof(float);
+    if (!ctx->vec_attr_set) {
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_vec_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_vec_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->vec_attr_set = true;
+    }
+    const int slot_p = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_vec_kernel");
+    if (H == 128) hipLaunchKernelGGL(gru_vec_kernel<128>, dim3(1), dim3(VEC_THREADS), lds, s, a);
+    else hipLaunchKernelGGL(gru_vec_kernel<64>, dim3(1), dim3(VEC_THREADS), lds, s, a);
+    os_prof_end(ctx, slot_p, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *h_last, void *stream)
 {
     OS_CHECK_CTX(ctx);
@@ -1332,6 +1552,7 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
     // reads that layout itself (small batches at H = 128)
     const int I = ctx->gru.input_size;
     const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
+    if (vec_eligible(ctx, B, T)) return gru_vec_launch(ctx, B, T, x, out, h_last, (hipStream_t)stream);
     // (the stack kernel reads an SoA first layer: packing costs a few microseconds at its sizes)
     const bool x_direct = !stack_eligible(ctx, B, T, I, H, L) && os_gru_layer_takes_btf(ctx, B, T, I, H);
     int rc = 0;

@@ -46,7 +46,13 @@ struct os_ctx {
     float *gru_packed;        // device: weights re-packed into MFMA fragment order (the active slot of gru_slots)
     // LRU of packed images (os_gru_load_keyed): an ensemble of models alternating on one context (gru_train.py:205-217
     // `num_models`) re-selects its image instead of re-packing it on every forward
-    struct GruSlot { uint64_t key; os_gru_dims d; const float *flat; float *packed; size_t cap; uint64_t stamp; } gru_slots[4];
+    struct GruSlot {
+        uint64_t key; os_gru_dims d; const float *flat; float *packed; size_t cap; uint64_t stamp;
+        float *vec; size_t vec_cap; bool vec_valid;       // transposed image for gru_vec_kernel, packed on first use
+    } gru_slots[4];
+    GruSlot *gru_slot;                   // the slot os_gru_load selected last
+    int tune_gru_vec;                    // 1: B <= 4 inference runs the whole model in one single-workgroup launch (gru_vec_kernel)
+    bool vec_attr_set;
     uint64_t gru_clock;
     const float *gru_flat;    // caller-owned flat weights (kept for the head / biases)
     float *gru_seq;  size_t gru_seq_floats;   // inter-layer sequences [T][H][B] x2 + h_last

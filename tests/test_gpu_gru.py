@@ -70,6 +70,7 @@ def test_run_ahead_layer_kernel_edges(monkeypatch, I, B, T):
     from oracle import c_oracle as orc
     H, L, C = 128, 2, 24
     monkeypatch.setenv("OS_GRU_STACK", "0")                  # tuning knobs are read when an Engine is created
+    monkeypatch.setenv("OS_GRU_VEC", "0")
     torch.manual_seed(11)
     m = RNN(I, H, L, C, torch.device("cpu"))
     x = torch.rand(B, T, I)
@@ -237,6 +238,7 @@ def test_layer_pipelined_stack_kernel_bit_identical_to_per_layer_launches(monkey
     torch.manual_seed(23)
     m = RNN(I, H, L, C, torch.device("cpu"))
     x = (torch.rand(B, T, I) * 2 - 1).cuda()
+    monkeypatch.setenv("OS_GRU_VEC", "0")                      # (B <= 4 would otherwise take gru_vec_kernel)
     monkeypatch.setenv("OS_GRU_STACK", "0"); monkeypatch.setenv("OS_GRU_AHEAD", "0")
     e0 = Engine(0)
     e0.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
@@ -284,3 +286,69 @@ def test_layer_pipelined_stack_kernel_behind_the_fused_first_layer(monkeypatch):
         assert (eng.kernel_name("gru_layer") == "gru_stack_kernel") == (stack == "1"), eng.kernel_name("gru_layer")
     assert torch.isfinite(outs["1"]).all()
     assert (outs["1"] - outs["0"]).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("I,H,L,B,T", [(188, 128, 4, 1, 10), (188, 128, 4, 4, 10), (60, 64, 4, 1, 10), (60, 64, 2, 3, 16), (61, 128, 1, 2, 1),
+                                       (128, 128, 3, 1, 48), (188, 128, 4, 4, 12), (60, 128, 2, 2, 13), (192, 64, 5, 4, 7)])
+def test_single_window_vector_kernel_matches_oracle_and_mfma_path(monkeypatch, I, H, L, B, T):
+    """B <= 4 (the reference's own evaluation loop: one window per call, gru/gru_test.py:157-177) runs the whole model -- every
+    layer, the head, h_T of every layer -- in ONE single-workgroup launch on the vector pipe (gru_vec_kernel).  Float64 oracle as
+    truth (1e-5), the MFMA path (OS_GRU_VEC=0) within summation-order distance; shapes cover one and two passes of phase A
+    (B T <= 24 / <= 48, a ragged second pass at 26), odd and maximal input widths, T = 1, both hidden sizes."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from oracle import c_oracle as orc
+    C = 24
+    torch.manual_seed(37)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    x = (torch.rand(B, T, I) * 2 - 1).cuda()
+    res = {}
+    for vec in ("1", "0"):
+        monkeypatch.setenv("OS_GRU_VEC", vec)
+        e = Engine(0)
+        e.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+        for rep in range(3):
+            out, hl = e.gru_forward(x, want_h_last=True)
+        torch.cuda.synchronize()
+        assert (e.kernel_name("gru_layer") == "gru_vec_kernel") == (vec == "1"), e.kernel_name("gru_layer")
+        res[vec] = (out.clone(), hl.clone())
+    assert (res["1"][0] - res["0"][0]).abs().max().item() < 2e-6
+    assert (res["1"][1] - res["0"][1]).abs().max().item() < 2e-6
+    ref, hl_ref, _ = orc.gru_forward(x.cpu().numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+    assert np.abs(res["1"][0].cpu().numpy() - ref).max() < GRU_TOL
+    assert np.abs(res["1"][1].cpu().numpy() - hl_ref).max() < GRU_TOL
+
+
+def test_vector_kernel_follows_weight_updates(monkeypatch):
+    """The transposed weight image gru_vec_kernel reads is rebuilt when os_gru_load packs new weights (and only then)."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from oracle import c_oracle as orc
+    I, H, L, C = 60, 64, 2, 24
+    e = Engine(0)
+    x = torch.rand(1, 10, I).cuda()
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        m = RNN(I, H, L, C, torch.device("cpu"))
+        e.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+        out = e.gru_forward(x)
+        out = (out[0] if isinstance(out, (tuple, list)) else out).cpu().numpy()
+        ref, _, _ = orc.gru_forward(x.cpu().numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+        assert e.kernel_name("gru_layer") == "gru_vec_kernel" and np.abs(out - ref).max() < GRU_TOL, seed
+
+
+@pytest.mark.parametrize("stack", ["0", "1"])
+def test_h64_with_192_inputs_falls_back_where_the_split_body_does_not_fit_lds(monkeypatch, stack):
+    """H = 64 with K = 189..192 needs 164 KB for the eight-wave split body (h + x double buffers + three exchange buffers per
+    chunk): such a first layer takes the plain kernel, with or without the stack launch (was: launch failure, round 4)."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from oracle import c_oracle as orc
+    I, H, L, C, B, T = 192, 64, 3, 24, 40, 6
+    monkeypatch.setenv("OS_GRU_STACK", stack)
+    torch.manual_seed(41)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    e = Engine(0)
+    e.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    x = torch.rand(B, T, I)
+    out = e.gru_forward(x.cuda())
+    out = (out[0] if isinstance(out, (tuple, list)) else out).cpu().numpy()
+    ref, _, _ = orc.gru_forward(x.numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+    assert np.abs(out - ref).max() < GRU_TOL
