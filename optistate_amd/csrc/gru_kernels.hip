@@ -1445,6 +1445,46 @@ static bool stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nla
 }
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H) { return ahead_eligible(ctx, B, T, K, H); }
 
+bool os_gru_stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers) { return stack_eligible(ctx, B, T, Kfirst, H, nlayers); }
+
+// One gru_stack_kernel launch over n <= 8 consecutive layers (layer i + 1 reads layer i's seq_out); shared by inference and the
+// training forward (saved activations and every layer's sequence come out as from the per-layer kernels).
+int os_gru_launch_stack(os_ctx *ctx, const LayerArgs *layers, int n, hipStream_t s)
+{
+    const int B = layers[0].B, H = layers[0].H, NCH = H / 32;
+    StackArgs sa;
+    sa.n = n; sa.tiles = (B + 31) / 32;
+    const size_t nfl = (size_t)sa.n * sa.tiles;
+    if (ctx->stack_flags_n < nfl) {
+        if (ctx->stack_flags) OS_HIP(ctx, hipFree(ctx->stack_flags));
+        ctx->stack_flags = nullptr; ctx->stack_flags_n = 0;
+        OS_HIP(ctx, hipMalloc((void **)&ctx->stack_flags, nfl * sizeof(uint32_t)));
+        ctx->stack_flags_n = nfl;
+    }
+    sa.flags = ctx->stack_flags;
+    OS_HIP(ctx, hipMemsetAsync(sa.flags, 0, nfl * sizeof(uint32_t), s));
+    size_t lds_max = 0;
+    for (int l = 0; l < n; l++) {
+        sa.layer[l] = layers[l];
+        const size_t lds_l = split_lds_bytes(layers[l].K, H);
+        lds_max = lds_l > lds_max ? lds_l : lds_max;
+    }
+    if (!ctx->stack_attr_set) {
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->stack_attr_set = true;
+    }
+    const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_stack_kernel");
+    const dim3 grid(sa.tiles, sa.n), block(512);
+    if (NCH == 4) hipLaunchKernelGGL(gru_stack_kernel<4>, grid, block, lds_max, s, sa);
+    else if (NCH == 2) hipLaunchKernelGGL(gru_stack_kernel<2>, grid, block, lds_max, s, sa);
+    else hipLaunchKernelGGL(gru_stack_kernel<1>, grid, block, lds_max, s, sa);
+    os_prof_end(ctx, slot, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // Launches gru_layer_kernel for one layer (shared by inference and the training forward).
 int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
 {
@@ -1539,46 +1579,21 @@ static int gru_layers(os_ctx *ctx, int B, int T, const float *in, int in_btf, in
     for (int l = 0; l < first_layer; l++) woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
     if (!in_btf && stack_eligible(ctx, B, T, first_layer == 0 ? d.input_size : H, H, L - first_layer)) {
         // ---- small batch: the whole stack as one launch, layers pipelined through progress flags (gru_stack_kernel) ----
-        StackArgs sa;
-        sa.n = L - first_layer; sa.tiles = (B + 31) / 32;
-        const size_t nfl = (size_t)sa.n * sa.tiles;
-        if (ctx->stack_flags_n < nfl) {
-            if (ctx->stack_flags) OS_HIP(ctx, hipFree(ctx->stack_flags));
-            ctx->stack_flags = nullptr; ctx->stack_flags_n = 0;
-            OS_HIP(ctx, hipMalloc((void **)&ctx->stack_flags, nfl * sizeof(uint32_t)));
-            ctx->stack_flags_n = nfl;
-        }
-        sa.flags = ctx->stack_flags;
-        OS_HIP(ctx, hipMemsetAsync(sa.flags, 0, nfl * sizeof(uint32_t), s));
-        size_t lds_max = 0;
+        LayerArgs la[8];
         const float *lin = in;
         for (int l = first_layer; l < L; l++) {
             const int K = l == 0 ? d.input_size : H;
-            LayerArgs &a = sa.layer[l - first_layer];
+            LayerArgs &a = la[l - first_layer];
             a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
             a.xs = lin; a.xs_btf = 0; a.w = ctx->gru_packed + woff;
             a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
             a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
             a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
-            const int parts = 8 / NCH;
-            const size_t lds_l = ((size_t)2 * 32 * (H + 1) + (size_t)2 * 32 * (2 * a.KPx + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
-            lds_max = lds_l > lds_max ? lds_l : lds_max;
             lin = a.seq_out;
             woff += os_layer_packed_floats(K, H);
         }
-        if (!ctx->stack_attr_set) {
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            ctx->stack_attr_set = true;
-        }
-        const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_stack_kernel");
-        const dim3 grid(sa.tiles, sa.n), block(512);
-        if (NCH == 4) hipLaunchKernelGGL(gru_stack_kernel<4>, grid, block, lds_max, s, sa);
-        else if (NCH == 2) hipLaunchKernelGGL(gru_stack_kernel<2>, grid, block, lds_max, s, sa);
-        else hipLaunchKernelGGL(gru_stack_kernel<1>, grid, block, lds_max, s, sa);
-        os_prof_end(ctx, slot, s);
-        OS_HIP(ctx, hipGetLastError());
+        const int rc = os_gru_launch_stack(ctx, la, L - first_layer, s);
+        if (rc) return rc;
         const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
         const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
         return os_gru_head_launch(ctx, B, top, fcw, out, s);

@@ -1123,8 +1123,10 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
         ts->B = B; ts->T = T;
     }
     if (os_ensure_scratch(ctx, &ts->seq, &ts->seq_floats, (size_t)L * tbh)) return -10;
+    // small batches (the reference trains at 64, gru/gru_train.py:36): the whole forward as ONE layer-pipelined launch (gru_stack_kernel)
+    const bool stack = os_gru_stack_eligible(ctx, B, T, I, H, L);
     // layer 0 reads the caller's (B, T, I) tensor itself where its kernel can (no SoA copy of the input)
-    const bool x_direct = os_gru_layer_takes_btf(ctx, B, T, I, H);
+    const bool x_direct = !stack && os_gru_layer_takes_btf(ctx, B, T, I, H);
     if (!x_direct) {
         if (os_ensure_scratch(ctx, &ts->xs, &ts->xs_floats, (size_t)T * I * B)) return -10;
         int rc = os_pack_stream(ctx, B, T, I, x, ts->xs, stream);
@@ -1132,18 +1134,23 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
     }
     size_t woff = 0;
     const float *in = x_direct ? x : ts->xs;
+    osg::LayerArgs la[16];
     for (int l = 0; l < L; l++) {
         const int K = l == 0 ? I : H;
-        osg::LayerArgs a;
+        osg::LayerArgs &a = la[l];
         a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
         a.xs = in; a.xs_btf = (l == 0 && x_direct) ? 1 : 0; a.w = ctx->gru_packed + woff;
         a.seq_out = ts->seq + (size_t)l * tbh;
         a.h_last = nullptr;
         float *base = act + (size_t)l * 5 * tbh;
         a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
-        if (os_gru_launch_layer(ctx, a, s)) return -10;
+        if (!stack && os_gru_launch_layer(ctx, a, s)) return -10;
         in = a.seq_out;
         woff += os_layer_packed_floats(K, H);
+    }
+    if (stack) {
+        const int rc = os_gru_launch_stack(ctx, la, L, s);
+        if (rc) return rc;
     }
     // head on h_T of the top layer: the SoA sequence's last step is [H][B]
     const float *top = ts->seq + (size_t)(L - 1) * tbh + (size_t)(T - 1) * H * B;

@@ -149,6 +149,8 @@ namespace osg { struct LayerArgs; }
 size_t os_layer_packed_floats(int K, int H);
 int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats);
 int os_gru_launch_layer(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s);
+bool os_gru_stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers);   // gru_kernels.hip: small batch, all (layer, tile) workgroups resident
+int os_gru_launch_stack(os_ctx *ctx, const osg::LayerArgs *layers, int n, hipStream_t s);   // n <= 8 consecutive layers as one pipelined launch
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H);   // gru_kernels.hip: the layer kernel for this shape reads (B, T, K) inputs itself
 int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s);
 void os_train_destroy(os_ctx *ctx);

@@ -28,6 +28,8 @@ def torch_reference_grads(sd, dims, x, y):
 
 
 @pytest.mark.parametrize("dims,B,T", [((60, 64, 1, 24), 50, 10), ((60, 64, 2, 24), 130, 7), ((188, 128, 4, 24), 70, 10),
+                                      # the reference's own training batch (gru/gru_train.py:32-36): forward = one gru_stack_kernel launch
+                                      ((188, 128, 4, 24), 64, 10),
                                       ((61, 32, 2, 6), 33, 5),
                                       # whole 32-row tiles: the fused W_ih / W_hh gradient kernel (dw3_kernel<2,4>, <4,4>, <2,2>),
                                       # its batch_first layer-0 input, and T = 1 (falls back to the two-launch form)
@@ -48,6 +50,8 @@ def test_backward_matches_torch_autograd(dims, B, T):
     xg = x.cuda().requires_grad_(True)
     out = m(xg)                                           # HIP forward (training path: grad enabled)
     assert np.abs(out.detach().cpu().numpy() - ref_out.numpy()).max() < 1e-5
+    if 2 <= L <= 8 and ((B + 31) // 32) * L <= 256:       # small batch: the layers of the training forward run as one pipelined launch
+        assert m._engine.kernel_name("gru_layer") == "gru_stack_kernel", m._engine.kernel_name("gru_layer")
     tgt = torch.cat([y.cuda(), (out[:, :C // 2].detach() - y.cuda()).abs()], dim=1)
     loss = torch.nn.functional.mse_loss(out, tgt)         # the reference's criterion; torch only does bookkeeping
     loss.backward()                                       # HIP backward
