@@ -73,4 +73,11 @@ python3 bench.py --mode kf --batch 4096 --seq 1000 --steps 3 --warmup 1 --cpu-se
 python3 bench.py --mode kf --steps 3 --warmup 1 --cpu-seconds 0 --wave-per-trajectory > $O/bench_kf_wave_B65536.json 2>> $O/bench.err
 bash tools/rows_ts.sh > $O/rows2_timestamps_raw.txt 2>&1
 python3 tools/rows_crossover.py 2>/dev/null | grep -v "^RCCL" > $O/rows_crossover.txt
+# round 4, small batches: the layer-pipelined stack launch, the single-workgroup vector kernel (the reference's own evaluation call
+# and training batch), config 5 without the stack launch
+python3 tools/stack_timing.py 200 > $O/stack_timing_raw.md 2>> $O/bench.err
+python3 tools/dropin_rnn_latency.py 2000 > $O/dropin_rnn_latency.json 2>> $O/bench.err
+python3 tools/train_small_batch.py 200 > $O/train_small_batch.json 2>> $O/bench.err
+OS_GRU_STACK=0 python3 bench.py --mode full > $O/bench_full_nostack.json 2>> $O/bench.err
+bash tools/vec_ts.sh 2>&1 | grep "gru_vec_kernel" | sort -u > $O/vec_timestamps_raw.txt
 ls $O

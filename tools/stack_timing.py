@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from optistate_amd import Engine, RNN, flatten_state_dict   # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+os.environ["OS_GRU_VEC"] = "0"          # B <= 4 would take gru_vec_kernel in both columns (tools/dropin_rnn_latency.py times that one)
 SHAPES = [(188, 128, 4, 1, 10), (188, 128, 4, 64, 10), (188, 128, 4, 128, 8), (188, 128, 4, 128, 100), (188, 128, 4, 1024, 10),
           (188, 128, 4, 2048, 10), (60, 64, 4, 64, 100), (60, 64, 4, 1024, 100), (60, 128, 4, 512, 100)]
 print("| I | H | L | B | T | per-layer launches, us | stack launch, us | ratio |")
