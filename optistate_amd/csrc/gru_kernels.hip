@@ -1038,21 +1038,24 @@ __global__ __launch_bounds__(256) void gru_head_kernel(int B, int H, int C, cons
 // ---- B <= 4: the whole model in ONE single-workgroup launch on the vector pipe (round 4) --------------------------------------
 // The reference's own evaluation loop calls the model on ONE window at a time and reports the time of that call
 // (gru/gru_test.py:157, :171-177: DataLoader(batch_size=1), `computation_time`).  A 32-row MFMA tile is 31/32 padding there and a
-// step costs the full 12.6 us of tile MFMAs; as matrix-vector products the same step is 49 k multiply-adds.  One workgroup of 768
-// threads runs layer after layer: thread = (gate row r of 3H, column split s of CS = 768 / 3H).
+// step costs the full 12.6 us of tile MFMAs; as matrix-vector products the same step is 49 k multiply-adds.  One workgroup of 512
+// threads (eight waves, 256 registers each) runs layer after layer:
 //   phase A  gi[n][r] = b + W_ih[r][:] x_n for ALL N = B T columns at once (x does not depend on this layer's h) on
-//            v_mfma_f32_16x16x4_f32: wave = two (H = 64: one) blocks of 16 gate rows x up to three blocks of 16 columns over the whole
+//            v_mfma_f32_16x16x4_f32: wave = three (H = 64: two) blocks of 16 gate rows x up to three blocks of 16 columns over the whole
 //            K; each weight is read once (16-byte loads of a fragment-ordered image), the x fragments are ds_read_b32.  (First
 //            version on the vector pipe with the x broadcast inside v_fmac_f32_dpp: 22 k cycles per layer against 7-9 k, DPP
 //            multiply-adds issue at ~5 cycles per wave whatever the occupancy);
-//   phase B  per step: the thread's H / CS recurrent weights stay in REGISTERS for the whole layer (H = 128: 64 VGPRs, 196 KB of the
-//            CU's 512 KB register file), h_{t-1} is an LDS broadcast; partial sums -> LDS, barrier, B H threads do the cell update and
-//            write h_t (and the next layer's input column), barrier.
-// No cross-workgroup traffic, no MFMA; the head (fc + sigmoid) and h_T of every layer in torch layout come out of the same launch.
+//   phase B  per step: thread = (hidden unit u, column quarter c) of 4 H threads; its 3 gates x H / 4 recurrent weights stay in
+//            REGISTER PAIRS for the whole layer (H = 128: 96 VGPRs, 196 KB of the CU's 512 KB register file), h_{t-1} arrives as
+//            16-byte LDS reads, the products are v_pk_fma_f32 on six independent sums; the four quarters of a unit sit in one DPP
+//            quad, so two quad_perm adds finish the three gate sums and the same lanes do the cell update: ONE barrier per step
+//            (first version: thread = (gate row, column half), partial sums through LDS, a 128-thread cell update between two
+//            barriers: 1.6 k cycles per step);
+// No cross-workgroup traffic; the head (fc + sigmoid) and h_T of every layer in torch layout come out of the same launch.
 struct VecArgs {
     int B, T, K0, L, C, use_sigmoid;
     const float *x;              // (B, T, K0) as the caller passes it
-    const float *wvec;           // per layer: W_ih as [ceil(K / 16)][3H][4 kk][4 i], k = 16 Q + 4 i + kk (zero padded) | W_hh as [H / 4][3H][4] | b_gi [3H] (b_ih + b_hh for r, z; b_in) | b_hn [H]
+    const float *wvec;           // per layer: W_ih as [ceil(K / 16)][3H][4 kk][4 i], k = 16 Q + 4 i + kk (zero padded) | W_hh as [H / 16][3 gates][H units][4 column quarters][4] | b_gi [3H] (b_ih + b_hh for r, z; b_in) | b_hn [H]
     const float *fcw, *fcb;
     float *out;                  // [B][C]
     float *h_last;               // [L][B][H] or null
@@ -1068,14 +1071,17 @@ __global__ __launch_bounds__(256) void gru_pack_vec_kernel(const PackVec p)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nih + nhh + R + H; i += gridDim.x * 256) {
         float v;
         if (i < nih) { const int k = (i / (16 * R)) * 16 + 4 * (i & 3) + ((i >> 2) & 3), r = (i >> 4) % R; v = k < K ? p.Wih[l][(size_t)r * K + k] : 0.f; }
-        else if (i < nih + nhh) { const int j = i - nih, k = (j / (4 * R)) * 4 + (j & 3), r = (j >> 2) % R; v = p.Whh[l][(size_t)r * H + k]; }
+        else if (i < nih + nhh) {     // [quad i4][gate g][unit u][column quarter c][4]: W_hh[g H + u][c H/4 + 4 i4 + e]
+            const int j = i - nih, e = j & 3, c = (j >> 2) & 3, u = (j >> 4) % H, g = (j / (16 * H)) % 3, i4 = j / (48 * H);
+            v = p.Whh[l][(size_t)(g * H + u) * H + c * (H / 4) + 4 * i4 + e];
+        }
         else if (i < nih + nhh + R) { const int r = i - nih - nhh; v = p.bih[l][r] + (r < 2 * H ? p.bhh[l][r] : 0.f); }
         else v = p.bhh[l][2 * H + (i - nih - nhh - R)];
         d[i] = v;
     }
 }
 
-constexpr int VEC_NMAX = 48, VEC_BMAX = 4, VEC_THREADS = 768;
+constexpr int VEC_NMAX = 48, VEC_BMAX = 4, VEC_THREADS = 512;     // eight waves, two per SIMD: 256 registers each (twelve waves: 168, spills)
 __device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff, uint32_t soff)
 {
     // (cast the whole vector: __builtin_bit_cast of ONE element of a vector-typed value reads element 0 whatever the index, hipcc 7.0)
@@ -1091,10 +1097,14 @@ __device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff, uint32_t so
 template <int H, int NB, int KQ, class Mid>
 __device__ __forceinline__ void vec_phase_a(const float *xin, float *gi, const float *wih, const float *bgi, int K, int N, int NP, int tid, Mid &&mid)
 {
-    constexpr int R = 3 * H, MB = R / 16 / 12;                       // blocks of 16 gate rows per wave (12 waves)
+    constexpr int R = 3 * H, NWV = VEC_THREADS / 64, MB = (R / 16 + NWV - 1) / NWV;   // blocks of 16 gate rows per wave (H = 128: 3 on eight waves; 64: 2 on six)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, kk = lane >> 4;
     const int K16 = (K + 15) >> 4;
+    if (wave * MB >= R / 16) {                                       // (H = 64: waves 6, 7 have no rows; their phase-B registers are still requested)
+        mid();
+        return;
+    }
     const rsrc_t ri = make_rsrc(wih, (uint32_t)K16 * R * 64u);
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -1139,7 +1149,11 @@ __device__ __forceinline__ void vec_phase_a(const float *xin, float *gi, const f
             if (Q + 1 < KQ) load_x(Q + 1, xa[(Q + 1) & 1]);
             // the caller's requests for phase B (the recurrent weights) go out once enough fragment registers are free again: they land
             // underneath the remaining MFMAs
-            if (Q == KQ - (KQ + 2) / 3) mid();
+            if (Q == KQ - (KQ >= 8 ? 3 : 2)) {
+                __builtin_amdgcn_sched_barrier(0);                   // not earlier: the fragment registers it reuses are still live
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             mfmas(wall[Q], xa[Q & 1]);
         }
     } else {
@@ -1180,7 +1194,7 @@ template <int H, int NB, class Mid>
 __device__ __forceinline__ void vec_phase_a_k(const float *xin, float *gi, const float *wih, const float *bgi, int K, int N, int NP, int tid, Mid &&mid)
 {
     const int K16 = (K + 15) >> 4;
-    if (K16 == 12 && NB == 1) vec_phase_a<H, NB, (NB == 1 ? 12 : 0)>(xin, gi, wih, bgi, K, N, NP, tid, mid);   // (96 weight registers: one column block only)
+    if (K16 == 12 && NB == 1) vec_phase_a<H, NB, (NB == 1 ? 12 : 0)>(xin, gi, wih, bgi, K, N, NP, tid, mid);   // (144 weight registers at H = 128: one column block only)
     else if (K16 == 8) vec_phase_a<H, NB, 8>(xin, gi, wih, bgi, K, N, NP, tid, mid);
     else if (K16 == 4) vec_phase_a<H, NB, 4>(xin, gi, wih, bgi, K, N, NP, tid, mid);
     else vec_phase_a<H, NB, 0>(xin, gi, wih, bgi, K, N, NP, tid, mid);
@@ -1189,17 +1203,17 @@ __device__ __forceinline__ void vec_phase_a_k(const float *xin, float *gi, const
 template <int H>
 __global__ __launch_bounds__(VEC_THREADS) void gru_vec_kernel(const VecArgs a)
 {
-    constexpr int R = 3 * H, CS = VEC_THREADS / R, HC = H / CS;
-    static_assert(CS * R == VEC_THREADS && HC % 4 == 0, "768 threads = 3H rows x CS column splits");
+    constexpr int R = 3 * H, HQ = H / 4, NTB = 4 * H;                  // phase B: NTB threads = (unit, column quarter), HQ columns each
+    static_assert(NTB <= VEC_THREADS && HQ % 4 == 0 && R % 192 == 0, "H = 64 or 128");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int B = a.B, T = a.T, N = B * T, NP = (N + 3) & ~3;
     const int KA = a.K0 > H ? a.K0 : H;
     float *xbuf0 = smem, *xbuf1 = smem + KA * NP;                      // layer input [k][NP] (column n = b T + t), ping-pong
     float *gi = xbuf1 + H * NP;                                        // [NP][R]
-    float *gh = gi + NP * R;                                           // [CS][B][R]
-    float *hcur = gh + CS * VEC_BMAX * R;                              // [B][H]
+    float *hbuf = gi + NP * R;                                         // [2][B][H] h double buffer
     const int tid = threadIdx.x;
-    const int row = tid % R, s = __builtin_amdgcn_readfirstlane(tid / R);   // s is wave-uniform (R is a multiple of 64)
+    const int pu = tid >> 2, pc = tid & 3;                            // phase B: hidden unit, column quarter (lanes 4 u .. 4 u + 3 = one DPP quad)
+    const bool pb_active = tid < NTB;                                  // wave-uniform
 
 #ifdef OS_LAYER_TS
     unsigned long long vts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vprev = __builtin_readcyclecounter();
@@ -1220,17 +1234,21 @@ __global__ __launch_bounds__(VEC_THREADS) void gru_vec_kernel(const VecArgs a)
         const float *xin = (l & 1) ? xbuf1 : xbuf0;
         float *xout = (l & 1) ? xbuf0 : xbuf1;
         const bool last = l == a.L - 1;
-        // this thread's recurrent weights -> register pairs for the whole layer (the products are v_pk_fma_f32); one per-lane offset, the
-        // column quad in the scalar offset (with flat addresses hipcc kept a 64-bit address pair per weight and spilled them).
-        // Requested from inside phase A (its `mid` hook): before it, 64 more live registers spill; after it, the round trip is exposed
-        osk::f2 wr[HC / 2];
-        auto load_wr = [&]() {
-            const rsrc_t rw = make_rsrc(whh + (size_t)s * HC * R, (uint32_t)HC * R * 4u);
+        // this thread's recurrent weights -> register pairs for the whole layer: 16-byte loads, 1 KB contiguous per wave and load, one
+        // per-lane offset with the (quad, gate) in the scalar offset (flat addresses: hipcc kept a 64-bit address pair per weight and
+        // spilled them).  Requested from inside phase A (its `mid` hook): before it, the extra live registers spill; after it, the
+        // round trip is exposed
+        osk::f2 wr[3][HQ / 2];
+        auto load_wr = [&]() {           // (every thread, also the idle ones of phase B: a conditional definition keeps the array live --
+                                         // and spilled -- across all of phase A; their offsets stay inside the image or read zero)
+            const rsrc_t rw = make_rsrc(whh, (uint32_t)H * R * 4u);
 #pragma unroll
-            for (int i = 0; i < HC; i += 4) {
-                const float4 v = buf_load4(rw, (uint32_t)row * 16u, (uint32_t)((i / 4) * R) * 16u);
-                wr[i / 2] = (osk::f2){v.x, v.y}; wr[i / 2 + 1] = (osk::f2){v.z, v.w};
-            }
+            for (int i4 = 0; i4 < HQ / 4; i4++)
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    const float4 v = buf_load4(rw, (uint32_t)tid * 16u, (uint32_t)((i4 * 3 + g) * H) * 64u);
+                    wr[g][2 * i4] = (osk::f2){v.x, v.y}; wr[g][2 * i4 + 1] = (osk::f2){v.z, v.w};
+                }
         };
         // ---- phase A ----
         {
@@ -1240,68 +1258,78 @@ __global__ __launch_bounds__(VEC_THREADS) void gru_vec_kernel(const VecArgs a)
             else vec_phase_a_k<H, 3>(xin, gi, wih, bgi, K, N, NP, tid, load_wr);
         }
         VTS(1)                                                         // phase A
-        VTS(2)                                                         // phase A: gi -> LDS
-        for (int i = tid; i < B * H; i += VEC_THREADS) hcur[i] = 0.f;  // h0 = 0 (gru/gru_model.py:27)
-        __syncthreads();
-        VTS(3)                                                         // recurrent weights -> registers
+        VTS(2)
+        __syncthreads();                                               // gi complete
+        VTS(3)                                                         // barrier behind phase A
         // ---- phase B ----
-        const int cb = tid / H, cu = tid % H;                          // cell update: thread = (trajectory, hidden unit)
-        const float my_bhn = tid < B * H ? bhn[cu] : 0.f;
+        float hprev[VEC_BMAX] = {0.f, 0.f, 0.f, 0.f};                  // h_{t-1}[b][pu]; h0 = 0 (gru/gru_model.py:27)
+        const float my_bhn = pb_active ? bhn[pu] : 0.f;
         for (int t = 0; t < T; t++) {
-            if (t > 0) {
-                for (int b = 0; b < B; b++) {
-                    // h_{t-1} in batches of eight 16-byte broadcasts, four independent sums (hipcc made ONE chain of packed multiply-adds
-                    // with an LDS round trip in front of every pair: 1.1 k cycles per step at three waves per SIMD)
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-                    osk::f2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f}, pd = {0.f, 0.f};
-                    const f4 *hb = reinterpret_cast<const f4 *>(hcur + b * H + s * HC);
+            const float *hc = hbuf + (t & 1) * VEC_BMAX * H;           // h_{t-1}
+            float *hn_buf = hbuf + ((t + 1) & 1) * VEC_BMAX * H;       // h_t
+            if (pb_active) {
 #pragma unroll
-                    for (int i0 = 0; i0 < HC / 4; i0 += 8) {
-                        f4 hv[8];
+                for (int b = 0; b < VEC_BMAX; b++) {
+                    if (b < B) {
+                        const int n = b * T + t;
+                        const float gir = gi[n * R + pu], giz = gi[n * R + H + pu], gin = gi[n * R + 2 * H + pu];   // in flight under the products
+                        float sr = 0.f, sz = 0.f, sn = 0.f;
+                        if (t > 0) {
+                            typedef float f4 __attribute__((ext_vector_type(4)));
+                            osk::f2 ar[2] = {{0.f, 0.f}, {0.f, 0.f}}, az[2] = {{0.f, 0.f}, {0.f, 0.f}}, an[2] = {{0.f, 0.f}, {0.f, 0.f}};
+                            const f4 *hb = reinterpret_cast<const f4 *>(hc + b * H + pc * HQ);
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (i0 + j < HC / 4) hv[j] = hb[i0 + j];
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int j0 = 0; j0 < HQ / 4; j0 += 4) {           // four 16-byte reads in flight (all eight: spills)
+                                f4 hv[4];
 #pragma unroll
-                        for (int j = 0; j < 8; j += 2)
-                            if (i0 + j < HC / 4) {
-                                pa = osk::fma2(wr[2 * (i0 + j)], (osk::f2){hv[j][0], hv[j][1]}, pa);
-                                pb = osk::fma2(wr[2 * (i0 + j) + 1], (osk::f2){hv[j][2], hv[j][3]}, pb);
-                                pc = osk::fma2(wr[2 * (i0 + j) + 2], (osk::f2){hv[j + 1][0], hv[j + 1][1]}, pc);
-                                pd = osk::fma2(wr[2 * (i0 + j) + 3], (osk::f2){hv[j + 1][2], hv[j + 1][3]}, pd);
+                                for (int j = 0; j < 4; j++) hv[j] = hb[j0 + j];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const osk::f2 lo = {hv[j][0], hv[j][1]}, hi = {hv[j][2], hv[j][3]};
+                                    const int jj = 2 * (j0 + j);
+                                    ar[0] = osk::fma2(wr[0][jj], lo, ar[0]); ar[1] = osk::fma2(wr[0][jj + 1], hi, ar[1]);
+                                    az[0] = osk::fma2(wr[1][jj], lo, az[0]); az[1] = osk::fma2(wr[1][jj + 1], hi, az[1]);
+                                    an[0] = osk::fma2(wr[2][jj], lo, an[0]); an[1] = osk::fma2(wr[2][jj + 1], hi, an[1]);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
                             }
+                            const osk::f2 qr = ar[0] + ar[1], qz = az[0] + az[1], qn = an[0] + an[1];
+                            sr = qr[0] + qr[1]; sz = qz[0] + qz[1]; sn = qn[0] + qn[1];
+                            // the four column quarters of a unit are one DPP quad: quad_perm [1,0,3,2], then [2,3,0,1]
+                            sr += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sr), 0xB1, 0xf, 0xf, true));
+                            sz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sz), 0xB1, 0xf, 0xf, true));
+                            sn += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sn), 0xB1, 0xf, 0xf, true));
+                            sr += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sr), 0x4E, 0xf, 0xf, true));
+                            sz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sz), 0x4E, 0xf, 0xf, true));
+                            sn += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sn), 0x4E, 0xf, 0xf, true));
+                        }
+                        // cell update, the same on the four lanes of the quad; lane 0 of it writes
+                        const float r = sigmoidf_(gir + sr), z = sigmoidf_(giz + sz);
+                        const float nn = tanhf_(fmaf(r, sn + my_bhn, gin));
+                        const float hn = fmaf(z, hprev[b] - nn, nn);                  // (1 - z) n + z h
+                        hprev[b] = hn;
+                        if (pc == 0) {
+                            hn_buf[b * H + pu] = hn;
+                            if (!last) xout[pu * NP + n] = hn;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);           // one trajectory at a time (interleaved, their registers spill)
                     }
-                    const osk::f2 ps = (pa + pb) + (pc + pd);
-                    gh[(s * VEC_BMAX + b) * R + row] = ps[0] + ps[1];
                 }
-                VTS(4)                                                 // phase B: matrix-vector products
-                __syncthreads();
-                VTS(5)
             }
-            if (tid < B * H) {
-                const int n = cb * T + t;
-                float gr = 0.f, gz = 0.f, gn = 0.f;
-                if (t > 0) {
-#pragma unroll
-                    for (int ss = 0; ss < CS; ss++) {
-                        const float *g = gh + (ss * VEC_BMAX + cb) * R;
-                        gr += g[cu]; gz += g[H + cu]; gn += g[2 * H + cu];
-                    }
-                }
-                const float r = sigmoidf_(gi[n * R + cu] + gr), z = sigmoidf_(gi[n * R + H + cu] + gz);
-                const float nn = tanhf_(fmaf(r, gn + my_bhn, gi[n * R + 2 * H + cu]));
-                const float hn = fmaf(z, hcur[cb * H + cu] - nn, nn);                 // (1 - z) n + z h
-                hcur[cb * H + cu] = hn;
-                if (!last) xout[cu * NP + n] = hn;
-            }
-            VTS(6)                                                     // phase B: cell update
+            VTS(4)                                                     // phase B: products, quad sums, cell update
             __syncthreads();
             VTS(5)
         }
-        if (a.h_last && tid < B * H) a.h_last[((size_t)l * B + cb) * H + cu] = hcur[cb * H + cu];
+        if (a.h_last && pb_active && pc == 0) {
+#pragma unroll
+            for (int b = 0; b < VEC_BMAX; b++)
+                if (b < B) a.h_last[((size_t)l * B + b) * H + pu] = hprev[b];
+        }
         w += vec_layer_floats(K, H);
     }
     // ---- head: fc (+ sigmoid) on the top layer's h_T ----
+    const float *hcur = hbuf + (T & 1) * VEC_BMAX * H;
     for (int i = tid; i < B * a.C; i += VEC_THREADS) {
         const int b = i / a.C, c = i % a.C;
         float v0 = 0.f, v1 = 0.f;
@@ -1315,7 +1343,7 @@ __global__ __launch_bounds__(VEC_THREADS) void gru_vec_kernel(const VecArgs a)
     VTS(7)                                                             // head
 #ifdef OS_LAYER_TS
     if (tid == 0)
-        printf("gru_vec_kernel<%d> B=%d T=%d L=%d cycles (thread 0): x stage %llu | phase A fma %llu | phase A reduce %llu | w_hh load %llu | matvec %llu | barriers %llu | cell %llu | head %llu | sum %llu\n",
+        printf("gru_vec_kernel<%d> B=%d T=%d L=%d cycles (thread 0): x stage %llu | phase A %llu | - %llu | barrier behind phase A %llu | phase B products + cell %llu | phase B barriers %llu | - %llu | head %llu | sum %llu\n",
                H, B, T, a.L, vts[0], vts[1], vts[2], vts[3], vts[4], vts[5], vts[6], vts[7], vts[0] + vts[1] + vts[2] + vts[3] + vts[4] + vts[5] + vts[6] + vts[7]);
 #endif
 }
@@ -1668,8 +1696,8 @@ static int gru_vec_launch(os_ctx *ctx, int B, int T, const float *x, float *out,
     a.fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
     a.fcb = a.fcw + (size_t)d.num_classes * H;
     a.out = out; a.h_last = h_last;
-    const int NP = (B * T + 3) & ~3, KA = d.input_size > H ? d.input_size : H, CS = VEC_THREADS / R;
-    const size_t lds = ((size_t)KA * NP + (size_t)H * NP + (size_t)NP * R + (size_t)CS * VEC_BMAX * R + (size_t)VEC_BMAX * H) * sizeof(float);
+    const int NP = (B * T + 3) & ~3, KA = d.input_size > H ? d.input_size : H;
+    const size_t lds = ((size_t)KA * NP + (size_t)H * NP + (size_t)NP * R + (size_t)2 * VEC_BMAX * H) * sizeof(float);
     if (!ctx->vec_attr_set) {
         OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_vec_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_vec_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
