@@ -352,3 +352,23 @@ def test_h64_with_192_inputs_falls_back_where_the_split_body_does_not_fit_lds(mo
     out = (out[0] if isinstance(out, (tuple, list)) else out).cpu().numpy()
     ref, _, _ = orc.gru_forward(x.numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
     assert np.abs(out - ref).max() < GRU_TOL
+
+
+@pytest.mark.parametrize("B,T,expect", [(4, 12, "gru_vec_kernel"), (4, 13, "gru_stack_kernel"), (5, 9, "gru_stack_kernel"), (1, 48, "gru_vec_kernel"),
+                                        (1, 49, "gru_stack_kernel"), (3, 16, "gru_vec_kernel"), (3, 17, "gru_stack_kernel"),
+                                        (2048, 2, "gru_stack_kernel"), (2049, 2, "gru_layer")])
+def test_small_batch_dispatch_boundaries(B, T, expect):
+    """Either side of every dispatch boundary of os_gru_forward (B <= 4 and B T <= 48: gru_vec_kernel; (layer, tile) workgroups <= 256:
+    gru_stack_kernel; beyond: a launch per layer) gives the float64 oracle's numbers, through the drop-in class."""
+    from optistate_amd import RNN
+    from oracle import c_oracle as orc
+    I, H, L, C = 188, 128, 4, 24
+    torch.manual_seed(43)
+    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda").eval()
+    x = torch.rand(B, T, I)
+    with torch.no_grad():
+        out = m(x.cuda()).cpu().numpy()
+    assert m._engine.kernel_name("gru_layer").startswith(expect), m._engine.kernel_name("gru_layer")
+    pick = np.unique(np.r_[0:min(B, 40), max(B - 40, 0):B])
+    ref, _, _ = orc.gru_forward(x.numpy()[pick], orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+    assert np.abs(out[pick] - ref).max() < GRU_TOL
