@@ -55,7 +55,8 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_GRU_VEC"); c->tune_gru_vec = e ? atoi(e) : 1;
         e = getenv("OS_MPC_PERSISTENT"); c->tune_mpc_persistent = e ? atoi(e) : 1;
         e = getenv("OS_VIT_MLP_FUSED"); c->tune_vit_mlp_fused = e ? atoi(e) : 3;
-        e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 512;      // 2 x 240 workgroups at the training batch: two per CU
+        // rows per weight-gradient slice; unset (0) = about 32 slices, between one 32-row tile and 512 rows (gru_train_kernels.hip)
+        e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 0;
         e = getenv("OS_DW_DBG"); c->tune_dw_dbg = e ? atoi(e) : 0;
         e = getenv("OS_DW_FUSED"); c->tune_dw_fused = e ? atoi(e) : 1;
         e = getenv("OS_VIT_TAIL_SPLIT"); c->tune_vit_tail_split = e ? atoi(e) : 1;
@@ -64,7 +65,9 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_SWEEP_WR"); c->tune_sweep_wr = e ? atoi(e) : 32;
         e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
         e = getenv("OS_FUSED_V1"); c->tune_fused_v1 = e ? atoi(e) : 0;
-        e = getenv("OS_TRAIN_OVERLAP"); c->tune_train_overlap = e ? atoi(e) : 0;   // measured: no gain (both kernels are bound by the shared fp32 pipe)
+        // weight-gradient kernels on a side stream underneath the next layer's sweep: unset = where CUs are idle and the launches are long
+        // (gru_train_kernels.hip); 8,192 windows: measured, no gain (both kernels are bound by the shared fp32 pipe); 0 / 1 force it off / on
+        e = getenv("OS_TRAIN_OVERLAP"); c->tune_train_overlap = e ? atoi(e) : -1;
     }
     if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc((void **)&c->kf_qr, 244 * sizeof(float)) != hipSuccess ||
         hipMemcpy(c->kf_qr, c->k.Q, 144 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||

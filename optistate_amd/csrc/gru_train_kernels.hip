@@ -1212,7 +1212,10 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     if ((size_t)T * B * 4 * H * sizeof(float) >= ((size_t)1 << 32) || (size_t)T * B * Kmax * sizeof(float) >= ((size_t)1 << 32))
         return os_fail(ctx, -2, "os_gru_backward: T*B*4*hidden_size (or T*B*input_size) floats reach 4 GiB, beyond the backward "
                                 "sweep's 32-bit buffer offsets; split the batch");
-    const bool overlap = ctx->tune_train_overlap != 0 && L > 1;
+    // weight gradients on a side stream underneath the next layer's sweep: where CUs are idle (at most half a chip of 32-row tiles) and a
+    // dW launch is long enough to be worth two event hand-overs (measured: 512 windows 1.01 -> 0.96 ms per step, 64 windows 0.90 -> 0.92)
+    const bool overlap = L > 1 && (ctx->tune_train_overlap > 0 ||
+                                   (ctx->tune_train_overlap < 0 && 2 * ((B + 31) / 32) <= ctx->cu_count && (size_t)T * B >= 2048));
     if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (overlap ? 2 : 1) * (size_t)T * B * 4 * H)) return -10;
     if (overlap && train_side_stream(ctx, ts)) return -10;
     if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, 2 * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
@@ -1329,10 +1332,18 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         // the two separate products -- two MFMAs per gate-derivative load leave the second launch waiting on memory.)
         const bool wide = K > 128 && K <= 192 && H == 128;
         const int ncx = wide ? 6 : (K + 31) / 32 <= 2 ? 2 : 4, nchh = H / 32;
+        // rows per slice: OS_DW_RPS, or about 32 slices, between one 32-row tile and 512 rows.  512 is the training batch's tuned value
+        // (2 x 240 workgroups: two per CU); small batches want short slices (the reference's batch of 64: 640 rows = 20 tiles, one per
+        // workgroup instead of sixteen in a row: 90 -> 25 us per launch) but not one tile each at 512 windows: every slice adds a whole
+        // dW with atomics
+        int rps = ctx->tune_dw_rps;
+        if (rps <= 0) {
+            rps = (int)(((rows + 31) / 32 + DW_TR - 1) / DW_TR) * DW_TR;
+            rps = rps < DW_TR ? DW_TR : rps > 512 ? 512 : rps;
+        }
         const bool fuse_dw = ctx->tune_dw_fused != 0 && (K <= 128 || (wide && ctx->tune_dw_fused != 2)) && (K & 3) == 0 && (nchh == 4 || (nchh == 2 && ncx == 2)) && B % DW_TR == 0 &&
-                             ctx->tune_dw_rps % DW_TR == 0 && T > 1 && (size_t)T * B * (K > H ? K : H) * 4 < ((size_t)1 << 31);
+                             rps % DW_TR == 0 && T > 1 && (size_t)T * B * (K > H ? K : H) * 4 < ((size_t)1 << 31);
         if (fuse_dw) {
-            const int rps = ctx->tune_dw_rps;
             Dw3Args d;
             d.H3 = H3; d.Kx = K; d.H = H; d.rows = rows; d.rows_per_slice = rps; d.dG = dg4; d.ldg = 4 * H;
             d.B = B; d.T = T; d.Hp = base + 4 * tbh;
@@ -1352,7 +1363,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             OS_HIP(ctx, hipGetLastError());
             if (overlap) OS_HIP(ctx, hipEventRecord(ts->ev_dw[l], sw));
         } else {
-            const int rps = ctx->tune_dw_rps;          // rows per slice: T*B / rps slices x 3H/32 gate chunks of waves
+            // rows per slice (above): T*B / rps slices x 3H/32 gate chunks of waves
             DwArgs d1;
             d1.H3 = H3; d1.K = K; d1.r_begin = 0; d1.r_end = rows; d1.x_row_shift = 0; d1.x_valid_from = 0; d1.rows_per_slice = rps;
             d1.dG = dg4; d1.ldg = 4 * H; d1.nshift = 0; d1.dW = gWih; d1.db = gbih; d1.B = B; d1.T = T;
