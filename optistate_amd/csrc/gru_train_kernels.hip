@@ -203,6 +203,10 @@ struct SweepArgs {
     const float *wihT, *whhT;    // transposed-packed weights
     float *dg4;                  // [T][B][4H]: da_r | da_z | da_n | da_n * r  (W_ih's products read sections 0-2, W_hh's 0, 1, 3)
     float *dx;                   // [T][B][K]
+    // bwd_sweep_stack_kernel only (null otherwise): progress counters of the layer above (its dx is this layer's dy) and of this
+    // workgroup; a counter holds the number of steps published, T - t after step t
+    const uint32_t *flag_prev;
+    uint32_t *flag_mine;
 };
 
 // RB = 32-row blocks per workgroup (BM = 32*RB).  LDS: dh [BM][H+1] | dG [BM][4H+1] (sections da_r, da_z, da_n, da_n*r).
@@ -213,8 +217,12 @@ struct SweepArgs {
 // Vector-memory loads return in order per wave, so the first weight fragments of a step's MFMA phase used to queue behind
 // the 48 activation prefetches issued just before them and the phase started one HBM latency late (1.75 us of every step);
 // with 32 resident k-pairs the first 32 MFMAs need nothing from memory and that latency is covered.
-template <int RB, int NW, int WR = 0>
-__global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a)
+// STACK (bwd_sweep_stack_kernel below): all layers of a small batch in ONE launch, blockIdx.y = 0 for the top layer; layer l takes
+// dy[t] = dx_{l+1}[t] as soon as the layer above has published step t (both run t = T-1 .. 0).  Same protocol as gru_stack_kernel
+// (gru_kernels.hip): write-through stores, every wave drains its stores, workgroup barrier, agent-scope release of the counter;
+// the consumer polls with agent-scope acquires (bounded: a lost producer poisons dy with NaN) and reads with sc0 sc1 loads.
+template <int RB, int NW, int WR, bool STACK>
+__device__ __forceinline__ void sweep_body(const SweepArgs &a)
 {
     static_assert(WR == 0 || (RB == 1 && WR % 16 == 0), "resident weights: one row block, whole 16-k-pair blocks");
     constexpr int NT = NW * 64;
@@ -262,7 +270,21 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             pf_r[e] = osk::buf_load_nt(rr_, pf_off[e], step); pf_z[e] = osk::buf_load_nt(rz_, pf_off[e], step);
             pf_n[e] = osk::buf_load_nt(rn_, pf_off[e], step); pf_g[e] = osk::buf_load_nt(rg_, pf_off[e], step);
             pf_h[e] = osk::buf_load_nt(rh_, pf_off[e], hstep);
-            pf_d[e] = osk::buf_load_nt(rd_, pf_off[e], step);
+            if (!(STACK && a.flag_prev)) pf_d[e] = osk::buf_load_nt(rd_, pf_off[e], step);
+        }
+        if constexpr (STACK) {
+            if (a.flag_prev) {                                 // dy[t] comes from the layer above inside this launch
+                bool lost = true;
+                for (int spin = 0; spin < (1 << 22); spin++) {
+                    if (__hip_atomic_load(a.flag_prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)(a.T - t)) { lost = false; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+#pragma unroll
+                for (int e = 0; e < ELP; e++) {
+                    pf_d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd_, pf_off[e], step, 17));
+                    if (lost) pf_d[e] = __builtin_nanf("");
+                }
+            }
         }
     };
     if (PF) prefetch(a.T - 1);
@@ -478,7 +500,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
                         const int rr = rb * 32 + (e & 3) + 8 * (e >> 2);
                         if (cok && row0 + rr + 4 * lh < a.B) {
                             const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(((size_t)t * B + row0 + rr) * K * 4));
-                            osk::buf_store(rdx, dxl, so, acc[rb][e]);
+                            const float v = acc[rb][e];        // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0, hipcc 7.0)
+                            if (STACK) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdx, dxl, so, 17);
+                            else osk::buf_store(rdx, dxl, so, v);
                         }
                     }
             }
@@ -487,8 +511,33 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
             osg::lds_barrier();
             if (deferred_oc >= 0) dh_add(deferred_oc, deferred);
         }
+        if (STACK && a.flag_mine && a.need_dx) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's dx stores are acknowledged
         osg::lds_barrier();
+        if constexpr (STACK) {
+            if (a.flag_mine && a.need_dx && threadIdx.x == 0)
+                __hip_atomic_store(a.flag_mine, (uint32_t)(a.T - t), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+}
+
+template <int RB, int NW, int WR = 0>
+__global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a)
+{
+    sweep_body<RB, NW, WR, false>(a);
+}
+
+struct SweepStackArgs {
+    int n, tiles, y0;            // y0: first layer index of this launch (0; the debug sequence OS_SWEEP_STACK_DBG=1 launches one layer at a time)
+    uint32_t *flags;             // [n][tiles], zeroed before the launch
+    SweepArgs layer[8];          // layer[0] = the top layer
+};
+__global__ __launch_bounds__(512, 1) void bwd_sweep_stack_kernel(const SweepStackArgs sa)
+{
+    const int y = blockIdx.y + sa.y0;
+    SweepArgs a = sa.layer[y];
+    a.flag_mine = sa.flags + (size_t)y * sa.tiles + blockIdx.x;
+    a.flag_prev = y > 0 ? a.flag_mine - sa.tiles : nullptr;
+    sweep_body<1, 8, 32, true>(a);
 }
 
 // ---- weight gradients: dW[3H][K] += dG^T X over a slice of the T*B rows, db[3H] += column sums of dG ----
@@ -1052,6 +1101,7 @@ struct os_train_state {
     // depend on layer l's gate derivatives): non-blocking stream + events, created on first use
     hipStream_t side;
     hipEvent_t ev_fork, ev_sweep[17], ev_dw[17];
+    bool sweep_stack_attr_set;           // hipFuncSetAttribute done for bwd_sweep_stack_kernel on this context's device
     bool side_ready;
 };
 
@@ -1212,13 +1262,19 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     if ((size_t)T * B * 4 * H * sizeof(float) >= ((size_t)1 << 32) || (size_t)T * B * Kmax * sizeof(float) >= ((size_t)1 << 32))
         return os_fail(ctx, -2, "os_gru_backward: T*B*4*hidden_size (or T*B*input_size) floats reach 4 GiB, beyond the backward "
                                 "sweep's 32-bit buffer offsets; split the batch");
-    // weight gradients on a side stream underneath the next layer's sweep: where CUs are idle (at most half a chip of 32-row tiles) and a
+    // small batches at H = 128: every layer's sweep in ONE launch, layers pipelined through progress counters (bwd_sweep_stack_kernel);
+    // each layer then keeps its own gate-derivative and dx buffers
+    const bool stacked = ctx->tune_gru_stack != 0 && L >= 2 && L <= 8 && H == 128 && I <= 192 && ((B + 31) / 32) * L <= ctx->cu_count &&
+                         ctx->tune_sweep_wr == 32 && (ctx->tune_sweep_nw == 0 || ctx->tune_sweep_nw == 8) && !dx_out;
+    // weight gradients on a side stream underneath the next layer's sweep: where CUs are idle (at most half a chip of 32-row tiles), a
     // dW launch is long enough to be worth two event hand-overs (measured: 512 windows 1.01 -> 0.96 ms per step, 64 windows 0.90 -> 0.92)
+    // and the sweeps are separate launches (behind the stacked sweep there is nothing left to hide under: 0.81 against 0.74 ms)
     const bool overlap = L > 1 && (ctx->tune_train_overlap > 0 ||
-                                   (ctx->tune_train_overlap < 0 && 2 * ((B + 31) / 32) <= ctx->cu_count && (size_t)T * B >= 2048));
-    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (overlap ? 2 : 1) * (size_t)T * B * 4 * H)) return -10;
+                                   (ctx->tune_train_overlap < 0 && !stacked && 2 * ((B + 31) / 32) <= ctx->cu_count && (size_t)T * B >= 2048));
+    if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (stacked ? L : overlap ? 2 : 1) * (size_t)T * B * 4 * H)) return -10;
     if (overlap && train_side_stream(ctx, ts)) return -10;
-    if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, 2 * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
+    const int ndx = stacked ? L : 2;
+    if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, ndx * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
     // transposed-packed weights (re-done every call: parameters change every optimiser step)
     size_t wT_total = 0;
     for (int l = 0; l < L; l++) {
@@ -1257,7 +1313,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
     // ---- head ----
     const size_t fc_off = nparam - ((size_t)C * H + C);
     const float *fcw = w_flat + fc_off;
-    float *dhT = ts->dxy + 2 * (size_t)T * B * Kmax;
+    float *dhT = ts->dxy + ndx * (size_t)T * B * Kmax;
     const float *hT = act + ((size_t)(L - 1) * 5 + 4) * tbh + (size_t)(T - 1) * B * H;   // sv_h of the top layer, t = T-1
     {
         const size_t lds = (size_t)(64 * ((C + 31) / 32 * 32) + 64 * (H + 1)) * sizeof(float);
@@ -1268,8 +1324,22 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         OS_HIP(ctx, hipGetLastError());
     }
     // ---- layers, top to bottom ----
-    float *dxbuf[2] = {ts->dxy, ts->dxy + (size_t)T * B * Kmax};
-    const float *dy = nullptr;
+    auto dx_of = [&](int l) { return ts->dxy + (size_t)(stacked ? l : (l & 1)) * T * B * Kmax; };
+    auto dg_of = [&](int l) { return ts->dg + (stacked ? (size_t)l : overlap ? (size_t)(l & 1) : 0) * (size_t)T * B * 4 * H; };
+    auto sweep_args = [&](int l) {
+        const int K = l == 0 ? I : H;
+        float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
+        const float *base = act + (size_t)l * 5 * tbh;
+        SweepArgs a;
+        a.B = B; a.T = T; a.K = K; a.H = H;
+        a.need_dx = (l > 0 || dx_out) ? 1 : 0;
+        a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
+        a.dy = l == L - 1 ? nullptr : dx_of(l + 1); a.dy_last = (l == L - 1) ? dhT : nullptr;
+        a.wihT = wihT; a.whhT = whhT; a.dg4 = dg_of(l);
+        a.dx = dx_of(l);
+        a.flag_prev = nullptr; a.flag_mine = nullptr;
+        return a;
+    };
     hipStream_t sw = overlap ? ts->side : s;             // stream of the weight-gradient kernels
     if (overlap) {
         OS_HIP(ctx, hipEventRecord(ts->ev_fork, s));     // the side stream starts behind the gradient clear / head backward
@@ -1279,18 +1349,10 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         const int K = l == 0 ? I : H;
         // gate derivatives: two buffer sets by layer parity when overlapping, so that the sweep of layer l-1 does not
         // overwrite what the reductions of layer l are still reading; layer l reuses the set of layer l+2
-        float *dg4 = ts->dg + (overlap ? (size_t)(l & 1) * T * B * 4 * H : 0);
-        if (overlap && l + 2 < L) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[l + 2], 0));
-        const float *Wih = w_flat + poff[l], *Whh = Wih + (size_t)H3 * K;
-        float *wihT = ts->wT + wToff[l], *whhT = wihT + (size_t)((K + 31) / 32) * (H3 / 2) * 64;
+        float *dg4 = dg_of(l);
+        if (overlap && !stacked && l + 2 < L) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[l + 2], 0));
         const float *base = act + (size_t)l * 5 * tbh;
-        SweepArgs a;
-        a.B = B; a.T = T; a.K = K; a.H = H;
-        a.need_dx = (l > 0 || dx_out) ? 1 : 0;
-        a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
-        a.dy = dy; a.dy_last = (l == L - 1) ? dhT : nullptr;
-        a.wihT = wihT; a.whhT = whhT; a.dg4 = dg4;
-        a.dx = dxbuf[l & 1];
+        const SweepArgs a = sweep_args(l);
         const int RB = H <= 64 ? 2 : 1;
         const int BM = 32 * RB;
         const size_t lds = (size_t)(BM * (H + 1) + BM * (4 * H + 1)) * sizeof(float);
@@ -1305,7 +1367,33 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         dim3 grid((B + BM - 1) / BM);
         int nw = (RB == 1 && ((a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8 || (!a.need_dx && H / 32 >= 4))) ? 8 : 4;   // enough work items for eight waves
         if (ctx->tune_sweep_nw) nw = ctx->tune_sweep_nw == 8 && RB == 1 ? 8 : 4;
-        {
+        if (stacked) {
+            if (l == L - 1) {                                  // every layer's sweep in this one launch; the iterations below only reduce
+                SweepStackArgs sa;
+                sa.n = L; sa.tiles = (B + 31) / 32;
+                const size_t nfl = (size_t)sa.n * sa.tiles;
+                if (ctx->stack_flags_n < nfl) {
+                    if (ctx->stack_flags) OS_HIP(ctx, hipFree(ctx->stack_flags));
+                    ctx->stack_flags = nullptr; ctx->stack_flags_n = 0;
+                    OS_HIP(ctx, hipMalloc((void **)&ctx->stack_flags, nfl * sizeof(uint32_t)));
+                    ctx->stack_flags_n = nfl;
+                }
+                sa.flags = ctx->stack_flags;
+                OS_HIP(ctx, hipMemsetAsync(sa.flags, 0, nfl * sizeof(uint32_t), s));
+                for (int y = 0; y < L; y++) sa.layer[y] = sweep_args(L - 1 - y);
+                if (!ts->sweep_stack_attr_set) {
+                    OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    ts->sweep_stack_attr_set = true;
+                }
+                const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_SWEEP, s, "bwd_sweep_stack_kernel");
+                sa.y0 = 0;
+                if (getenv("OS_SWEEP_STACK_DBG")) {
+                    for (int y = 0; y < L; y++) { sa.y0 = y; hipLaunchKernelGGL(bwd_sweep_stack_kernel, dim3(sa.tiles, 1), dim3(512), lds, s, sa); }
+                } else
+                hipLaunchKernelGGL(bwd_sweep_stack_kernel, dim3(sa.tiles, L), dim3(512), lds, s, sa);
+                os_prof_end(ctx, slot, s);
+            }
+        } else {
             // resident leading k-pairs: one work item per wave
             const int nitems = ((a.need_dx ? (K + 31) / 32 : 0) + H / 32) * ((!a.need_dx && 8 > H / 32) ? 2 : 1);
             const int wr = (nw == 8 && H == 128 && nitems <= 8) ? ctx->tune_sweep_wr : 0;
@@ -1396,13 +1484,12 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         }
         // os_gru_backward_mark: layers l .. L-1 (and the head, done first) have their gradients in the flat vector from here on
         if (ctx->bwd_mark_event && l == ctx->bwd_mark_layer) OS_HIP(ctx, hipEventRecord((hipEvent_t)ctx->bwd_mark_event, sw));
-        dy = a.dx;
     }
     if (overlap) OS_HIP(ctx, hipStreamWaitEvent(s, ts->ev_dw[0], 0));      // join: the side stream is in order
     if (dx_out) {
         // dx of layer 0 is [T][B][I]; the caller's layout is (B, T, I)
         const size_t n = (size_t)B * T * I;
-        hipLaunchKernelGGL(permute_tb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, T, I, dxbuf[0], dx_out);
+        hipLaunchKernelGGL(permute_tb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, T, I, dx_of(0), dx_out);
         OS_HIP(ctx, hipGetLastError());
     }
     return 0;

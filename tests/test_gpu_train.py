@@ -174,3 +174,47 @@ def test_split_allreduce_on_a_side_stream_gives_the_same_step():
     scale = g0.abs().max().item()
     assert (g1 - g0).abs().max().item() < 1e-5 * scale and (g2 - g0).abs().max().item() < 1e-5 * scale
     assert g0.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("dims,B,T", [((188, 128, 4, 24), 64, 10), ((188, 128, 4, 24), 70, 10), ((60, 128, 2, 24), 1024, 6), ((128, 128, 8, 24), 33, 3),
+                                      ((188, 128, 4, 24), 2048, 2), ((60, 128, 3, 24), 5, 1)])
+def test_stacked_backward_sweep_matches_per_layer_sweeps(monkeypatch, dims, B, T):
+    """Small batches at H = 128 run every layer's backward sweep in ONE launch (bwd_sweep_stack_kernel: blockIdx.y = 0 is the top layer,
+    layer l takes dx_{l+1}[t] through a progress counter as soon as it is published).  The workgroups run bwd_sweep_kernel<1,8,32>'s
+    body, so the gate derivatives are the same numbers and the flat gradient may differ from a launch per layer only by the order of
+    the dW kernels' atomic additions -- on every one of 10 repeats (a consumer that read a step early would show here); torch
+    autograd (float64) as truth.  Shapes: the reference's training batch, a partial tile, 32 tiles x 2 layers, eight layers, the largest
+    eligible batch (64 tiles x 4), T = 1."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    I, H, L, C = dims
+    torch.manual_seed(47)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    x = torch.rand(B, T, I); y = torch.rand(B, C // 2)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    _, _, _, ref_g, _ = torch_reference_grads(sd, dims, x, y)
+    flat = flatten_state_dict(m.state_dict(), L, "cuda")
+    grads = {}
+    for stack in ("0", "1"):
+        monkeypatch.setenv("OS_GRU_STACK", stack)
+        e = Engine(0)
+        e.load_gru(flat, I, H, L, C)
+        for rep in range(10 if stack == "1" else 1):
+            out = e.gru_forward_train(x.cuda())
+            _, dout, _ = e.gru_loss(out, y.cuda())
+            g = e.gru_backward(x.cuda(), out, dout).clone()
+            torch.cuda.synchronize()
+            assert (e.kernel_name("train_sweep") == "bwd_sweep_stack_kernel") == (stack == "1"), e.kernel_name("train_sweep")
+            if stack == "1":
+                scale = grads["0"].abs().max().item()
+                assert torch.isfinite(g).all() and (g - grads["0"]).abs().max().item() < 2e-6 * scale + 1e-9, (rep, (g - grads["0"]).abs().max().item(), scale)
+        grads[stack] = g
+    # against autograd, parameter by parameter in the flat order
+    order = [f"gru.{k}_l{l}" for l in range(L) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] + ["fc.weight", "fc.bias"]
+    off = 0
+    gflat = grads["1"].cpu().double()
+    for k in order:
+        r = ref_g[k].reshape(-1)
+        gk = gflat[off:off + r.numel()]
+        scale = max(r.abs().max().item(), 1e-8)
+        assert (gk - r).abs().max().item() < 2e-4 * scale + 1e-9, k
+        off += r.numel()
