@@ -1387,7 +1387,8 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
                 }
                 const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_SWEEP, s, "bwd_sweep_stack_kernel");
                 sa.y0 = 0;
-                if (getenv("OS_SWEEP_STACK_DBG")) {
+                static const bool one_by_one = getenv("OS_SWEEP_STACK_DBG") != nullptr;   // debugging: the same kernel, one layer per launch
+                if (one_by_one) {
                     for (int y = 0; y < L; y++) { sa.y0 = y; hipLaunchKernelGGL(bwd_sweep_stack_kernel, dim3(sa.tiles, 1), dim3(512), lds, s, sa); }
                 } else
                 hipLaunchKernelGGL(bwd_sweep_stack_kernel, dim3(sa.tiles, L), dim3(512), lds, s, sa);
