@@ -183,15 +183,13 @@ def test_stacked_backward_sweep_matches_per_layer_sweeps(monkeypatch, dims, B, T
     layer l takes dx_{l+1}[t] through a progress counter as soon as it is published).  The workgroups run bwd_sweep_kernel<1,8,32>'s
     body, so the gate derivatives are the same numbers and the flat gradient may differ from a launch per layer only by the order of
     the dW kernels' atomic additions -- on every one of 10 repeats (a consumer that read a step early would show here); torch
-    autograd (float64) as truth.  Shapes: the reference's training batch, a partial tile, 32 tiles x 2 layers, eight layers, the largest
+    autograd (float64) as truth on the small shapes.  Shapes: the reference's training batch, a partial tile, 32 tiles x 2 layers, eight layers, the largest
     eligible batch (64 tiles x 4), T = 1."""
     from optistate_amd import Engine, RNN, flatten_state_dict
     I, H, L, C = dims
     torch.manual_seed(47)
     m = RNN(I, H, L, C, torch.device("cpu"))
     x = torch.rand(B, T, I); y = torch.rand(B, C // 2)
-    sd = {k: v.detach() for k, v in m.state_dict().items()}
-    _, _, _, ref_g, _ = torch_reference_grads(sd, dims, x, y)
     flat = flatten_state_dict(m.state_dict(), L, "cuda")
     grads = {}
     for stack in ("0", "1"):
@@ -208,7 +206,12 @@ def test_stacked_backward_sweep_matches_per_layer_sweeps(monkeypatch, dims, B, T
                 scale = grads["0"].abs().max().item()
                 assert torch.isfinite(g).all() and (g - grads["0"]).abs().max().item() < 2e-6 * scale + 1e-9, (rep, (g - grads["0"]).abs().max().item(), scale)
         grads[stack] = g
-    # against autograd, parameter by parameter in the flat order
+    # against autograd, parameter by parameter in the flat order (the smallest shapes only: the float64 CPU reference takes most of a
+    # minute per case on the GPU box's host, and the per-layer launches are held to it in test_backward_matches_torch_autograd)
+    if B * T > 128:
+        return
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    _, _, _, ref_g, _ = torch_reference_grads(sd, dims, x, y)
     order = [f"gru.{k}_l{l}" for l in range(L) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] + ["fc.weight", "fc.bias"]
     off = 0
     gflat = grads["1"].cpu().double()
