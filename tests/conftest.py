@@ -12,6 +12,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU-side checkers (torch float64 autograd, numpy) are small problems: on the GPU box's 256 hardware threads torch's
+    # default pool (128) and the C oracle's OpenMP pool fight over the cores once both exist, and a 0.03 s reference took 48 s
+    # (the training tests were 12 of the GPU suite's 14 minutes).  Eight threads are the fastest setting there and here.
+    try:
+        import torch
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+    except Exception:
+        pass
 
 
 def load_golden(name):

@@ -297,8 +297,14 @@ def test_config4_train_step_8192_windows_vs_float64_autograd():
     m = RNN(*dims, torch.device("cuda")).to("cuda")
     x, y = torch.rand(Bt, Tt, dims[0]), torch.rand(Bt, 12)
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
-    ref_out, _, ref_loss, ref_g, _ = torch_reference_grads(sd, dims, x, y)
+    # the float64 CPU reference of the whole batch: a few tens of threads, and the setting is RESTORED -- left at every hardware
+    # thread of the GPU box's host (256) it made each later small torch reference ~100x slower (a third of the GPU suite's time)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    try:
+        ref_out, _, ref_loss, ref_g, _ = torch_reference_grads(sd, dims, x, y)
+    finally:
+        torch.set_num_threads(prev_threads)
     out = m(x.cuda())
     assert np.abs(out.detach().cpu().numpy() - ref_out.numpy()).max() < 1e-5
     tgt = torch.cat([y.cuda(), (out[:, :12].detach() - y.cuda()).abs()], dim=1)
