@@ -516,7 +516,7 @@ def bench_train(a, rk):
     from optistate_amd import RNN
     from optistate_amd.train import DataParallelTrainer
     dev = rk.dev
-    B, T, I, H, L, C = 8192, 10, 188, 128, 4, 24
+    B, T, I, H, L, C = (a.batch or 8192), 10, 188, 128, 4, 24      # --batch 64: the reference's own batch size (gru/gru_train.py:36)
     torch.manual_seed(0)
     model = RNN(I, H, L, C, dev).to(dev)
     tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=not a.no_split_allreduce, force_distributed=a.force_dist,

@@ -78,6 +78,7 @@ python3 tools/rows_crossover.py 2>/dev/null | grep -v "^RCCL" > $O/rows_crossove
 python3 tools/stack_timing.py 200 > $O/stack_timing_raw.md 2>> $O/bench.err
 python3 tools/dropin_rnn_latency.py 2000 > $O/dropin_rnn_latency.json 2>> $O/bench.err
 python3 tools/train_small_batch.py 200 > $O/train_small_batch.json 2>> $O/bench.err
+python3 bench.py --mode train --batch 64 --steps 50 --cpu-seconds 0 > $O/bench_train_B64.json 2>> $O/bench.err
 OS_GRU_STACK=0 python3 bench.py --mode full > $O/bench_full_nostack.json 2>> $O/bench.err
 bash tools/vec_ts.sh 2>&1 | grep "gru_vec_kernel" | sort -u > $O/vec_timestamps_raw.txt
 ls $O
