@@ -32,6 +32,24 @@ def test_g5_forward_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["small", "ref"])
+def test_g5_one_window_per_call_matches_reference(name):
+    """The reference's evaluation loop feeds ONE window per call (gru/gru_test.py:157-177): the golden batch's windows one at a time
+    (and four at a time) through the drop-in class -- gru_vec_kernel where the model's widths allow it -- against the reference's
+    own outputs for them."""
+    m, g = load_module(name)
+    x = torch.as_tensor(g["x"]).cuda()
+    n = min(6, x.shape[0])
+    with torch.no_grad():
+        for i in range(n):
+            out = m(x[i:i + 1])
+            assert np.abs(out.cpu().numpy() - g["out"][i:i + 1]).max() < GRU_TOL, i
+        if x.shape[1] * 4 <= 48 and m.hidden_size in (64, 128) and m.input_size <= 192:
+            assert m._engine.kernel_name("gru_layer") == "gru_vec_kernel", m._engine.kernel_name("gru_layer")
+        out4 = m(x[:4])
+    assert np.abs(out4.cpu().numpy() - g["out"][:4]).max() < GRU_TOL
+
+
+@pytest.mark.parametrize("name", ["small", "ref"])
 def test_h_last_matches_reference(name):
     m, g = load_module(name)
     x = torch.as_tensor(g["x"]).cuda()
