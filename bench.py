@@ -516,7 +516,7 @@ def bench_train(a, rk):
     from optistate_amd import RNN
     from optistate_amd.train import DataParallelTrainer
     dev = rk.dev
-    B, T, I, H, L, C = (a.batch or 8192), 10, 188, 128, 4, 24      # --batch 64: the reference's own batch size (gru/gru_train.py:36)
+    B, T, I, H, L, C = a.batch, 10, 188, 128, 4, 24                # default 8192 (main); --batch 64: the reference's own batch size (gru/gru_train.py:36)
     torch.manual_seed(0)
     model = RNN(I, H, L, C, dev).to(dev)
     tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=not a.no_split_allreduce, force_distributed=a.force_dist,
@@ -886,7 +886,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="trajectories (windows) per GPU; default 65536 (windows: 8192)")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories (windows) per GPU; default 65536 (windows, train: 8192)")
     ap.add_argument("--seq", type=int, default=100)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=1)
@@ -915,7 +915,7 @@ def main(argv=None):
                     help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")
     a = ap.parse_args(argv)
     if a.batch is None:
-        a.batch = 8192 if a.mode == "windows" else 65536
+        a.batch = 8192 if a.mode in ("windows", "train") else 65536
 
     # N > 1 and not yet a rank: start the ranks as a child process BEFORE anything here touches the GPU
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
