@@ -1464,12 +1464,24 @@ static bool ahead_eligible(os_ctx *ctx, int B, int T, int K, int H)
     return split && H == 128 && (size_t)T * B * H * 4 < ((size_t)1 << 32) && (size_t)T * B * K * 4 < ((size_t)1 << 32) &&
            ctx->tune_gru_ahead != 0;
 }
-// true when gru_layers will run layers first..L-1 as ONE pipelined launch (gru_stack_kernel: the eight-wave split body)
-static bool stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers)
+// Layers per pipelined launch (gru_stack_kernel: the eight-wave split body) for a stack of nlayers on this batch: as many as leave every
+// (layer, tile) workgroup of a launch resident at once, at most eight; 0 = a launch per layer.  All of them up to 2,048 trajectories at
+// four layers; two at a time up to 4,096 (the reference's own data set: ~4,050 windows, gru/gru_test.py:138-140).
+static int stack_group(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers)
 {
     const int NCH = H / 32, tiles = (B + 31) / 32;
-    return ctx->tune_gru_stack != 0 && nlayers >= 2 && nlayers <= 8 && (NCH == 4 || NCH == 2 || NCH == 1) && Kfirst <= 192 && H <= 192 &&
-           split_lds_bytes(Kfirst, H) <= 160 * 1024 && tiles * nlayers <= ctx->cu_count && (size_t)T * B * (Kfirst > H ? Kfirst : H) * 4 < ((size_t)1 << 31);
+    if (!(ctx->tune_gru_stack != 0 && nlayers >= 2 && (NCH == 4 || NCH == 2 || NCH == 1) && Kfirst <= 192 && H <= 192 &&
+          split_lds_bytes(Kfirst, H) <= 160 * 1024 && (size_t)T * B * (Kfirst > H ? Kfirst : H) * 4 < ((size_t)1 << 31)))
+        return 0;
+    int g = ctx->cu_count / tiles;
+    g = g > 8 ? 8 : g;
+    g = g > nlayers ? nlayers : g;
+    return g >= 2 ? g : 0;
+}
+// true when the WHOLE stack is one launch
+static bool stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers)
+{
+    return nlayers <= 8 && stack_group(ctx, B, T, Kfirst, H, nlayers) == nlayers;
 }
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H) { return ahead_eligible(ctx, B, T, K, H); }
 
@@ -1605,23 +1617,27 @@ static int gru_layers(os_ctx *ctx, int B, int T, const float *in, int in_btf, in
     const size_t hf = (size_t)H * B;
     size_t woff = 0;
     for (int l = 0; l < first_layer; l++) woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
-    if (!in_btf && stack_eligible(ctx, B, T, first_layer == 0 ? d.input_size : H, H, L - first_layer)) {
-        // ---- small batch: the whole stack as one launch, layers pipelined through progress flags (gru_stack_kernel) ----
-        LayerArgs la[8];
+    const int grp = in_btf ? 0 : stack_group(ctx, B, T, first_layer == 0 ? d.input_size : H, H, L - first_layer);
+    if (grp >= 2) {
+        // ---- small batch: grp layers per launch, pipelined through progress flags (gru_stack_kernel); a single left-over layer on its own ----
         const float *lin = in;
-        for (int l = first_layer; l < L; l++) {
-            const int K = l == 0 ? d.input_size : H;
-            LayerArgs &a = la[l - first_layer];
-            a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
-            a.xs = lin; a.xs_btf = 0; a.w = ctx->gru_packed + woff;
-            a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
-            a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
-            a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
-            lin = a.seq_out;
-            woff += os_layer_packed_floats(K, H);
+        for (int l0 = first_layer; l0 < L; l0 += grp) {
+            const int n = L - l0 < grp ? L - l0 : grp;
+            LayerArgs la[8];
+            for (int l = l0; l < l0 + n; l++) {
+                const int K = l == 0 ? d.input_size : H;
+                LayerArgs &a = la[l - l0];
+                a.B = B; a.T = T; a.K = K; a.H = H; a.KPx = (K + 1) / 2; a.KPh = H / 2;
+                a.xs = lin; a.xs_btf = 0; a.w = ctx->gru_packed + woff;
+                a.seq_out = (l < L - 1) ? seqbuf[l & 1] : nullptr;
+                a.h_last = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
+                a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
+                lin = a.seq_out;
+                woff += os_layer_packed_floats(K, H);
+            }
+            const int rc = n >= 2 ? os_gru_launch_stack(ctx, la, n, s) : os_gru_launch_layer(ctx, la[0], s);
+            if (rc) return rc;
         }
-        const int rc = os_gru_launch_stack(ctx, la, L - first_layer, s);
-        if (rc) return rc;
         const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
         const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
         return os_gru_head_launch(ctx, B, top, fcw, out, s);
@@ -1723,7 +1739,7 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
     const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
     if (vec_eligible(ctx, B, T)) return gru_vec_launch(ctx, B, T, x, out, h_last, (hipStream_t)stream);
     // (the stack kernel reads an SoA first layer: packing costs a few microseconds at its sizes)
-    const bool x_direct = !stack_eligible(ctx, B, T, I, H, L) && os_gru_layer_takes_btf(ctx, B, T, I, H);
+    const bool x_direct = stack_group(ctx, B, T, I, H, L) < 2 && os_gru_layer_takes_btf(ctx, B, T, I, H);
     int rc = 0;
     if (!x_direct) {
         if (os_ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;

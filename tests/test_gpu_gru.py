@@ -242,14 +242,15 @@ def test_stage_kernel_large_batch_bit_identical_to_plain_kernel_and_close_to_ora
 
 
 @pytest.mark.parametrize("I,H,L,B,T", [(188, 128, 4, 128, 10), (188, 128, 4, 1, 10), (60, 64, 4, 64, 100), (61, 32, 2, 33, 7),
-                                       (60, 128, 8, 900, 25), (188, 128, 4, 2048, 3), (60, 64, 2, 5, 1)])
+                                       (60, 128, 8, 900, 25), (188, 128, 4, 2048, 3), (60, 64, 2, 5, 1), (188, 128, 4, 4000, 3), (60, 64, 5, 2500, 4)])
 def test_layer_pipelined_stack_kernel_bit_identical_to_per_layer_launches(monkeypatch, I, H, L, B, T):
     """Small batches run their layer stack as ONE launch (gru_stack_kernel: blockIdx.y = layer, layer l takes step t of layer
     l - 1 through a progress flag as soon as it is published).  The workgroups run gru_layer_split_kernel's body, so against a
     launch per layer of THAT kernel (OS_GRU_STACK=0 OS_GRU_AHEAD=0) the outputs and every layer's h_T must be identical -- any
     consumer that read a step before it was complete would show here -- on every one of 20 repeats; float64 oracle as truth.
     Shapes: the reference's model at config 5's 128 trajectories and at its own batch of 1, 4 x 64 over 100 steps, odd input
-    width with a partial tile, eight layers x 29 tiles (232 of 256 CUs), the largest eligible batch (64 tiles x 4), T = 1."""
+    width with a partial tile, eight layers x 29 tiles (232 of 256 CUs), the largest batch that is one launch (64 tiles x 4), T = 1, and
+    two batches that take several launches (4,000: two layers at a time; 2,500 x five layers: three + two)."""
     from optistate_amd import Engine, RNN, flatten_state_dict
     from oracle import c_oracle as orc
     C = 24
@@ -374,10 +375,11 @@ def test_h64_with_192_inputs_falls_back_where_the_split_body_does_not_fit_lds(mo
 
 @pytest.mark.parametrize("B,T,expect", [(4, 12, "gru_vec_kernel"), (4, 13, "gru_stack_kernel"), (5, 9, "gru_stack_kernel"), (1, 48, "gru_vec_kernel"),
                                         (1, 49, "gru_stack_kernel"), (3, 16, "gru_vec_kernel"), (3, 17, "gru_stack_kernel"),
-                                        (2048, 2, "gru_stack_kernel"), (2049, 2, "gru_layer")])
+                                        (2048, 2, "gru_stack_kernel"), (2049, 2, "gru_layer"), (4096, 2, "gru_stack_kernel"), (4097, 2, "gru_layer")])
 def test_small_batch_dispatch_boundaries(B, T, expect):
     """Either side of every dispatch boundary of os_gru_forward (B <= 4 and B T <= 48: gru_vec_kernel; (layer, tile) workgroups <= 256:
-    gru_stack_kernel; beyond: a launch per layer) gives the float64 oracle's numbers, through the drop-in class."""
+    one gru_stack_kernel launch; up to 128 tiles: as many layers per launch as fit -- 2,049: three + the fourth on its own, 4,096: two
+    + two; beyond: a launch per layer) gives the float64 oracle's numbers, through the drop-in class."""
     from optistate_amd import RNN
     from oracle import c_oracle as orc
     I, H, L, C = 188, 128, 4, 24
