@@ -129,10 +129,16 @@ class Ranks:
             raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch `python bench.py --gpus N` and let it start its ranks")
         self.dist = None
         self.cpu_only = a.launch_check and torch.cuda.device_count() == 0
+        # --share-gpu (development only): rank r uses device r % device_count and the process group runs over gloo with the
+        # collectives staged through the host -- RCCL refuses two ranks on one device.  It exists so that the world > 1 code
+        # paths run with real device tensors on a one-GPU box; its timings say nothing about xGMI and the line says so.
+        self.share = bool(getattr(a, "share_gpu", False)) and not self.cpu_only
         if not self.cpu_only:
-            torch.cuda.set_device(self.local_rank)
-            self.dev = torch.device("cuda", self.local_rank)
+            self.device_index = self.local_rank % torch.cuda.device_count() if self.share else self.local_rank
+            torch.cuda.set_device(self.device_index)
+            self.dev = torch.device("cuda", self.device_index)
         else:
+            self.device_index = 0
             self.dev = torch.device("cpu")
         if self.world > 1 or getattr(a, "force_dist", False):
             import torch.distributed as dist
@@ -140,7 +146,7 @@ class Ranks:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
             # launched directly under torch.distributed.run (the driver's form): the knob still lands before the communicator exists
             os.environ.update(rccl_env_from_argv(["--rccl-proto", getattr(a, "rccl_proto", "default"), "--rccl-algo", getattr(a, "rccl_algo", "default")]))
-            if self.cpu_only:
+            if self.cpu_only or self.share:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # nccl == RCCL on ROCm
@@ -153,7 +159,7 @@ class Ranks:
         if not self.dist:
             return seconds
         import torch
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if self.share else self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -170,7 +176,12 @@ class Ranks:
             return {"rccl_world_size": 1, "backend": None, "rank_devices": [me]}
         allr = [None] * self.world
         self.dist.all_gather_object(allr, me)
-        return {"rccl_world_size": self.dist.get_world_size(), "backend": self.dist.get_backend(), "rank_devices": allr}
+        out = {"rccl_world_size": self.dist.get_world_size(), "backend": self.dist.get_backend(), "rank_devices": allr}
+        if self.share:
+            out["share_gpu"] = True
+            out["share_gpu_note"] = ("development run: every rank on the same device, process group over gloo with host-staged "
+                                     "collectives; exercises the world > 1 code paths, its timings are not a scaling point")
+        return out
 
     def close(self):
         if self.dist:
@@ -527,12 +538,13 @@ def bench_train(a, rk):
     kernels = events_pass(tr.eng, max(2, min(a.steps, 5)), lambda: tr.step(x, y))
     ar_us = None
     if rk.dist:
+        from optistate_amd.train import all_reduce_
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        rk.dist.all_reduce(tr.bucket.g)
+        all_reduce_(tr.bucket.g)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(20):
-            rk.dist.all_reduce(tr.bucket.g)
+            all_reduce_(tr.bucket.g)
         e1.record(); torch.cuda.synchronize()
         ar_us = e0.elapsed_time(e1) / 20 * 1e3
     # replica equality (every rank calls it: one broadcast + one MAX all-reduce): identical replicas + one averaged gradient +
@@ -583,7 +595,7 @@ def bench_full(a, rk):
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
     dev = rk.dev
     B, T = 128, 8
-    eng = default_engine(rk.local_rank); eng.set_noise(Q_DEFAULT, R_DEFAULT)     # the context the ViT module uses too
+    eng = default_engine(rk.device_index); eng.set_noise(Q_DEFAULT, R_DEFAULT)     # the context the ViT module uses too
     torch.manual_seed(0)
     vit = Transformer_Autoencoder().to(dev)
     model = RNN(188, 128, 4, 24, dev)
@@ -638,7 +650,7 @@ def bench_mpc(a, rk):
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
     dev = rk.dev
     B, T = a.batch, a.seq
-    eng = Engine(rk.local_rank); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    eng = Engine(rk.device_index); eng.set_noise(Q_DEFAULT, R_DEFAULT)
     d = synth_torch(B, T, dev, seed=11 + rk.rank)
     contact = eng.contact_soa_to_packed(d["contact"])
     ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
@@ -666,7 +678,8 @@ def bench_mpc(a, rk):
                            "algorithmic_bytes_per_step": bps,
                            "limiter": "latency: a dependent float64 elimination per active-set iteration, one QP per wavefront (not a roofline kernel)"}
         out.update(qp_iterations_mean=float(it.mean()), qp_iterations_max=int(it.max()),
-                   status_nonzero_trajectories=int((last["status"] != 0).sum()), kernels=kernels, **info)
+                   status_nonzero_trajectories=int(eng.failed(last["status"]).sum()),
+                   trunc_edge_trajectories=int(eng.trunc_edge(last["status"]).sum()), kernels=kernels, **info)
         out["cpu_baseline"] = cpu_baseline_mpc(min(a.cpu_seconds, 20.0)) if (a.cpu_seconds > 0 and rk.world == 1) else None
         emit(json.dumps(out))
 
@@ -724,7 +737,7 @@ def bench_hot_path(a, rk):
     from optistate_amd.synth import synth_torch, NOISE_SETS
     B, T, H, L, I = a.batch, a.seq, a.hidden, a.layers, 60 + a.latent
     fused = a.mode == "fused"
-    eng = Engine(rk.local_rank)
+    eng = Engine(rk.device_index)
     dev = eng.device
     d = synth_torch(B, T, dev, seed=1000 + rk.rank, hostile=a.hostile)
     contact = eng.contact_soa_to_packed(d["contact"])
@@ -766,7 +779,8 @@ def bench_hot_path(a, rk):
         return el, r, kernels, Q, R
 
     el, r, kernels, Q, R = run_set(a.noise, a.warmup, a.steps)
-    bad = int((r["status"] != 0).sum().item())
+    bad = int(eng.failed(r["status"]).sum().item())           # bits 0-3; bit 4 is informational and counted on its own
+    edge = int(eng.trunc_edge(r["status"]).sum().item())
     info = rk.report()
     if rk.rank != 0:
         return
@@ -836,6 +850,9 @@ def bench_hot_path(a, rk):
     out["kernels"] = kernels
     out["kernel_events"] = "HIP events on the launch stream, recorded over the timed region (the wall time includes them)"
     out["status_nonzero_trajectories"] = bad
+    out["trunc_edge_trajectories"] = edge
+    out["status_note"] = ("status_nonzero_trajectories counts FAILURES (status bits 0-3); trunc_edge_trajectories counts the "
+                          "informational bit 4 (int64-truncation knife edge, include/optistate_hip.h)")
     out.update(info)
     # parity of the timed batch itself (rank 0's shard) over ALL of its (trajectory, timestep) pairs, outside the timed
     # region; the oracle's seconds double as the all-cores cpu_baseline (one run serves both)
@@ -855,7 +872,8 @@ def bench_hot_path(a, rk):
         # "second run with Q_R.pkl values" -- the reference's fitted Q / R (cond(S) ~ 1e6) on the same inputs
         el2, r2, k2, Q2, R2 = run_set("fitted", 1, 3)
         sec = {"noise": NOISE_NOTE["fitted"], "steps": 3, "ms_per_step": el2 / 3 * 1e3, "value": steps_per_pass * rk.world * 3 / el2,
-               "status_nonzero_trajectories": int((r2["status"] != 0).sum().item())}
+               "status_nonzero_trajectories": int(eng.failed(r2["status"]).sum().item()),
+               "trunc_edge_trajectories": int(eng.trunc_edge(r2["status"]).sum().item())}
         if a.parity_samples != 0:
             want2 = B if a.parity_samples < 0 else min(a.parity_samples, B)
             sec["parity"], _ = oracle_pass(d, r2["x_out"], r2.get("out"), model, H, L, Q2, R2, Q2, want2, cap, kf_only=not fused, latent=latent)
@@ -910,6 +928,9 @@ def main(argv=None):
     ap.add_argument("--rccl-proto", default="default", choices=["default", "LL", "LL128", "Simple"],
                     help="NCCL_PROTO for the ranks (set before any communicator exists); the 1.69 MB gradient bucket is latency-bound")
     ap.add_argument("--rccl-algo", default="default", choices=["default", "Ring", "Tree"], help="NCCL_ALGO for the ranks")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="development: with --gpus N on a box with fewer devices, rank r runs on device r %% device_count over gloo "
+                         "(host-staged collectives); runs the world > 1 code paths, not a scaling measurement")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")
     ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc", "windows"],
                     help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")

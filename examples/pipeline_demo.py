@@ -45,7 +45,7 @@ def main(argv=None):
         print(f"MPC forces: |f| max {float(forces.abs().max()):.1f} N")
     else:
         rows, x_hist, status = pl.kalman_feature_rows(eng, d, Q_FITTED, R_FITTED, d["x0"])
-    assert int(status.abs().sum()) == 0
+    assert int(eng.failed(status).sum()) == 0          # bits 0-3; bit 4 (truncation knife edge) is informational
     mocap = x_hist + 0.01 * torch.randn_like(x_hist)          # stand-in labels with the same 12-state layout
 
     # 2. scaling + windows (every trajectory contributes its own windows), training with the reference's loop

@@ -25,6 +25,8 @@
  *     entry integrates dt*omega into theta is decided by the last bits of the reference's own float64 state
  *     (gimbal lock: pitch = pi/2 with roll = yaw); on such a trajectory the 1e-4 state bar is not promised,
  *     the deviation is one dt*omega step per flagged decision (tests/test_gpu_fullsize.py).
+ *     FAILURE = (status & OS_STATUS_FAIL_MASK) != 0.  Bit 4 is NOT a failure: a consumer that treats any non-zero
+ *     word as "failed" must mask it (the Python engine does: Engine.failed(status) / Engine.trunc_edge(status)).
  *   - Stream layout (structure of arrays, trajectory index fastest, float32):
  *       p, f, dp, body_ref : [T][12][B]      imu, accel : [T][6][B]
  *       contact            : [T][B] of 4 packed bytes (byte k = leg k, 0 swing / 1 stance)
@@ -53,6 +55,16 @@ typedef struct os_kf_config {
     float inertia[3];      /* settings.py:20-23  body-frame diag(Ixx,Iyy,Izz) */
     float gz;              /* kalman_filter/kalman_filter.py:56  -9.81 (added to vz) */
 } os_kf_config;
+
+/* Bits of the per-trajectory status word (see "Conventions"). */
+enum {
+    OS_STATUS_S_NOT_PD   = 1,   /* bit0: innovation covariance not positive definite / non-finite */
+    OS_STATUS_NONFINITE  = 2,   /* bit1: non-finite state */
+    OS_STATUS_QP_ITER    = 4,   /* bit2: QP iteration cap (os_kf_mpc_run) */
+    OS_STATUS_P0_ASYM    = 8,   /* bit3: OS_KF_SYMMETRIC_P with a non-symmetric P0 */
+    OS_STATUS_TRUNC_EDGE = 16,  /* bit4: INFORMATIONAL, int64-truncation knife edge (not a failure) */
+    OS_STATUS_FAIL_MASK  = 15   /* failure = (status & OS_STATUS_FAIL_MASK) != 0 */
+};
 
 /* Flags for os_kf_run / os_fused_run. */
 enum {

@@ -18,6 +18,9 @@ OS_FUSED_SPLIT_BF16 = 512
 OS_FUSED_SPLIT_BF16_2 = 1024
 OS_FUSED_LATENT_IN_PLACE = 2048
 OS_KF_WAVE_PER_TRAJECTORY = 4096
+# status word (include/optistate_hip.h): bits 0-3 are failures, bit 4 is informational
+OS_STATUS_S_NOT_PD, OS_STATUS_NONFINITE, OS_STATUS_QP_ITER, OS_STATUS_P0_ASYM, OS_STATUS_TRUNC_EDGE = 1, 2, 4, 8, 16
+OS_STATUS_FAIL_MASK = 15
 OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD = 1, 2, 4, 8
 OS_PROF_PHASES = 12         # include/optistate_hip.h
 PHASE_NAMES = ("kf", "gru_layer", "gru_head", "fused", "mpc", "train_sweep", "train_dw", "train_misc", "vit_gemm",

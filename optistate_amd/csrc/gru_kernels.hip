@@ -955,17 +955,40 @@ __global__ __launch_bounds__(512, 1) void gru_layer_ahead_kernel(const LayerArgs
 }
 
 // Re-pack the torch-layout weights (W_ih [3H][K], W_hh [3H][H], b_ih [3H], b_hh [3H]) into fragment order;
-// all layers in one launch (blockIdx.z = layer): the training step re-packs every optimisation step
+// all layers in one launch (blockIdx.z = layer): the training step re-packs every optimisation step.
+// blockIdx.z in [n, 2n) (launched only when vdst is set): the same layers' image for gru_vec_kernel (layout in VecArgs) -- both
+// images come from ONE snapshot of the caller's flat weights, taken by ONE launch of os_gru_load.
+__host__ __device__ inline size_t vec_layer_floats(int K, int H) { return (size_t)((K + 15) & ~15) * 3 * H + (size_t)H * 3 * H + 3 * H + H; }
 struct PackAll {
     int n, H;
     int K[16];
     const float *Wih[16], *Whh[16], *bih[16], *bhh[16];
     float *dst[16];
+    float *vdst[16];
 };
 __global__ void gru_pack_all_kernel(const PackAll a)
 {
+    if ((int)blockIdx.z >= a.n) {
+        const int l = blockIdx.z - a.n, H = a.H, R = 3 * H, K = a.K[l];
+        if (l >= a.n) return;
+        float *d = a.vdst[l];
+        const float *Wih = a.Wih[l], *Whh = a.Whh[l], *bih = a.bih[l], *bhh = a.bhh[l];
+        const int nih = ((K + 15) & ~15) * R, nhh = H * R;
+        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+        for (int i = blk * blockDim.x + threadIdx.x; i < nih + nhh + R + H; i += nblk * blockDim.x) {
+            float v;
+            if (i < nih) { const int k = (i / (16 * R)) * 16 + 4 * (i & 3) + ((i >> 2) & 3), r = (i >> 4) % R; v = k < K ? Wih[(size_t)r * K + k] : 0.f; }
+            else if (i < nih + nhh) {     // [quad i4][gate g][unit u][column quarter c][4]: W_hh[g H + u][c H/4 + 4 i4 + e]
+                const int j = i - nih, e = j & 3, c = (j >> 2) & 3, u = (j >> 4) % H, g = (j / (16 * H)) % 3, i4 = j / (48 * H);
+                v = Whh[(size_t)(g * H + u) * H + c * (H / 4) + 4 * i4 + e];
+            }
+            else if (i < nih + nhh + R) { const int r = i - nih - nhh; v = bih[r] + (r < 2 * H ? bhh[r] : 0.f); }
+            else v = bhh[2 * H + (i - nih - nhh - R)];
+            d[i] = v;
+        }
+        return;
+    }
     const int l = blockIdx.z;
-    if (l >= a.n) return;
     const int K = a.K[l], H = a.H, KPx = (K + 1) / 2, KPh = H / 2, chunk = blockIdx.x;
     const float *Wih = a.Wih[l], *Whh = a.Whh[l], *bih = a.bih[l], *bhh = a.bhh[l];
     float *d = a.dst[l] + (size_t)chunk * chunk_floats(KPx, KPh);
@@ -1060,27 +1083,6 @@ struct VecArgs {
     float *out;                  // [B][C]
     float *h_last;               // [L][B][H] or null
 };
-__host__ __device__ inline size_t vec_layer_floats(int K, int H) { return (size_t)((K + 15) & ~15) * 3 * H + (size_t)H * 3 * H + 3 * H + H; }
-
-struct PackVec { int n, H; int K[16]; const float *Wih[16], *Whh[16], *bih[16], *bhh[16]; float *dst[16]; };
-__global__ __launch_bounds__(256) void gru_pack_vec_kernel(const PackVec p)
-{
-    const int l = blockIdx.y, H = p.H, R = 3 * H, K = p.K[l];
-    float *d = p.dst[l];
-    const int nih = ((K + 15) & ~15) * R, nhh = H * R;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nih + nhh + R + H; i += gridDim.x * 256) {
-        float v;
-        if (i < nih) { const int k = (i / (16 * R)) * 16 + 4 * (i & 3) + ((i >> 2) & 3), r = (i >> 4) % R; v = k < K ? p.Wih[l][(size_t)r * K + k] : 0.f; }
-        else if (i < nih + nhh) {     // [quad i4][gate g][unit u][column quarter c][4]: W_hh[g H + u][c H/4 + 4 i4 + e]
-            const int j = i - nih, e = j & 3, c = (j >> 2) & 3, u = (j >> 4) % H, g = (j / (16 * H)) % 3, i4 = j / (48 * H);
-            v = p.Whh[l][(size_t)(g * H + u) * H + c * (H / 4) + 4 * i4 + e];
-        }
-        else if (i < nih + nhh + R) { const int r = i - nih - nhh; v = p.bih[l][r] + (r < 2 * H ? p.bhh[l][r] : 0.f); }
-        else v = p.bhh[l][2 * H + (i - nih - nhh - R)];
-        d[i] = v;
-    }
-}
-
 constexpr int VEC_NMAX = 48, VEC_BMAX = 4, VEC_THREADS = 512;     // eight waves, two per SIMD: 256 registers each (twelve waves: 168, spills)
 __device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff, uint32_t soff)
 {
@@ -1379,6 +1381,8 @@ size_t os_gru_param_count(const os_gru_dims *d)
     return n + (size_t)d->num_classes * d->hidden_size + d->num_classes;
 }
 
+static bool vec_dims_eligible(const os_gru_dims &d);
+
 // key != 0: the caller's name for (these weights, in this state).  A slot holding the same key, dimensions and flat pointer is
 // re-selected without packing; otherwise the least recently used of the four slots is (re)packed.  key == 0: always pack.
 int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, uint64_t key, void *stream)
@@ -1402,7 +1406,16 @@ int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, ui
         size_t total = 0;
         for (int l = 0; l < d->num_layers; l++) total += os_layer_packed_floats(l == 0 ? d->input_size : H, H);
         if (os_ensure_scratch(ctx, &slot->packed, &slot->cap, total)) return -10;
-        size_t src = 0, dst = 0;
+        // the B <= 4 kernel's transposed image is packed HERE too, by the same launch and so from the same snapshot of w_flat as
+        // the MFMA image: a caller that edits w_flat in place without reloading keeps ONE consistent set of packed matrices on
+        // every batch size (the head's fc weights are read from w_flat live on every path: documented in the header)
+        const bool vec = vec_dims_eligible(*d);
+        if (vec) {
+            size_t vtotal = 0;
+            for (int l = 0; l < d->num_layers; l++) vtotal += vec_layer_floats(l == 0 ? d->input_size : H, H);
+            if (os_ensure_scratch(ctx, &slot->vec, &slot->vec_cap, vtotal)) return -10;
+        }
+        size_t src = 0, dst = 0, vdst = 0;
         PackAll pa;
         pa.n = d->num_layers; pa.H = H;
         for (int l = 0; l < d->num_layers; l++) {
@@ -1410,13 +1423,15 @@ int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, ui
             pa.K[l] = K;
             pa.Wih[l] = w_flat + src; pa.Whh[l] = pa.Wih[l] + (size_t)3 * H * K; pa.bih[l] = pa.Whh[l] + (size_t)3 * H * H; pa.bhh[l] = pa.bih[l] + 3 * H;
             pa.dst[l] = slot->packed + dst;
+            pa.vdst[l] = vec ? slot->vec + vdst : nullptr;
             src += (size_t)3 * H * K + (size_t)3 * H * H + 6 * (size_t)H;
             dst += os_layer_packed_floats(K, H);
+            vdst += vec_layer_floats(K, H);
         }
-        hipLaunchKernelGGL(gru_pack_all_kernel, dim3(H / 32, 16, d->num_layers), dim3(256), 0, (hipStream_t)stream, pa);
+        hipLaunchKernelGGL(gru_pack_all_kernel, dim3(H / 32, 16, (vec ? 2 : 1) * d->num_layers), dim3(256), 0, (hipStream_t)stream, pa);
         OS_HIP(ctx, hipGetLastError());
         slot->key = key; slot->d = *d; slot->flat = w_flat;
-        slot->vec_valid = false;
+        slot->vec_valid = vec;
         ctx->gru_generation++;                                  // counts packs (os_gru_generation): a cache hit does not bump it
     }
     slot->stamp = ++ctx->gru_clock;
@@ -1677,43 +1692,36 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
 }
 
 // B <= 4 windows of at most 48 / B steps at the reference's widths: the single-workgroup vector kernel
+// LDS the single-workgroup kernel needs for B windows of T steps (x tile | h sequence | gi | h double buffer)
+static size_t vec_lds_bytes(const os_gru_dims &d, int B, int T)
+{
+    const int H = d.hidden_size, R = 3 * H;
+    const int NP = (B * T + 3) & ~3, KA = d.input_size > H ? d.input_size : H;
+    return ((size_t)KA * NP + (size_t)H * NP + (size_t)NP * R + (size_t)2 * VEC_BMAX * H) * sizeof(float);
+}
+static bool vec_dims_eligible(const os_gru_dims &d)
+{
+    return (d.hidden_size == 128 || d.hidden_size == 64) && d.input_size <= 192;
+}
 static bool vec_eligible(os_ctx *ctx, int B, int T)
 {
     const os_gru_dims &d = ctx->gru;
-    return ctx->tune_gru_vec != 0 && B <= VEC_BMAX && B * T <= VEC_NMAX && (d.hidden_size == 128 || d.hidden_size == 64) && d.input_size <= 192;
+    return ctx->tune_gru_vec != 0 && B <= VEC_BMAX && B * T <= VEC_NMAX && vec_dims_eligible(d) &&
+           vec_lds_bytes(d, B, T) <= (size_t)160 * 1024;          // computed, not implied by the N / K caps
 }
 static int gru_vec_launch(os_ctx *ctx, int B, int T, const float *x, float *out, float *h_last, hipStream_t s)
 {
     const os_gru_dims &d = ctx->gru;
-    const int H = d.hidden_size, L = d.num_layers, R = 3 * H;
+    const int H = d.hidden_size, L = d.num_layers;
     os_ctx::GruSlot *slot = ctx->gru_slot;
-    if (!slot->vec_valid) {                                  // transposed image of the current weights, once per os_gru_load
-        size_t total = 0;
-        for (int l = 0; l < L; l++) total += vec_layer_floats(l == 0 ? d.input_size : H, H);
-        if (os_ensure_scratch(ctx, &slot->vec, &slot->vec_cap, total)) return -10;
-        PackVec pv;
-        pv.n = L; pv.H = H;
-        size_t src = 0, dst = 0;
-        for (int l = 0; l < L; l++) {
-            const int K = l == 0 ? d.input_size : H;
-            pv.K[l] = K;
-            pv.Wih[l] = ctx->gru_flat + src; pv.Whh[l] = pv.Wih[l] + (size_t)R * K; pv.bih[l] = pv.Whh[l] + (size_t)R * H; pv.bhh[l] = pv.bih[l] + R;
-            pv.dst[l] = slot->vec + dst;
-            src += (size_t)R * K + (size_t)R * H + 2 * (size_t)R;
-            dst += vec_layer_floats(K, H);
-        }
-        hipLaunchKernelGGL(gru_pack_vec_kernel, dim3(64, L), dim3(256), 0, s, pv);
-        OS_HIP(ctx, hipGetLastError());
-        slot->vec_valid = true;
-    }
+    if (!slot->vec_valid) return os_fail(ctx, -5, "gru_vec_launch: no packed image (os_gru_load packs it for eligible dimensions)");
     VecArgs a;
     a.B = B; a.T = T; a.K0 = d.input_size; a.L = L; a.C = d.num_classes; a.use_sigmoid = d.use_sigmoid;
     a.x = x; a.wvec = slot->vec;
     a.fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
     a.fcb = a.fcw + (size_t)d.num_classes * H;
     a.out = out; a.h_last = h_last;
-    const int NP = (B * T + 3) & ~3, KA = d.input_size > H ? d.input_size : H;
-    const size_t lds = ((size_t)KA * NP + (size_t)H * NP + (size_t)NP * R + (size_t)2 * VEC_BMAX * H) * sizeof(float);
+    const size_t lds = vec_lds_bytes(d, B, T);
     if (!ctx->vec_attr_set) {
         OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_vec_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_vec_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -746,7 +746,6 @@ int os_kf_update(os_ctx *ctx, int32_t B, const float *z, float *x, float *P, flo
     if (B <= 0 || !z || !x || !P) return os_fail(ctx, -2, "os_kf_update: bad argument");
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE;
     if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_update: sequential update needs a diagonal R");
-    if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_update: sequential update needs a diagonal R");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid((B + 63) / 64), block(64);
     hipStream_t s = (hipStream_t)stream;

@@ -15,7 +15,7 @@ import torch
 from . import _capi
 from ._capi import (OS_KF_DENSE_FD, OS_KF_SEQUENTIAL_UPDATE, OS_KF_SYMMETRIC_P, OS_FUSED_TWO_KERNEL,  # noqa: F401
                     OS_KF_LANE_PER_TRAJECTORY, OS_MPC_COLD_START, OS_FUSED_ONE_KERNEL, OS_KF_P_FLOAT64, OS_FUSED_SPLIT_BF16, OS_FUSED_SPLIT_BF16_2,
-                    OS_FUSED_LATENT_IN_PLACE, OS_KF_WAVE_PER_TRAJECTORY)
+                    OS_FUSED_LATENT_IN_PLACE, OS_KF_WAVE_PER_TRAJECTORY, OS_STATUS_FAIL_MASK, OS_STATUS_TRUNC_EDGE)
 
 # settings.py:5-23 and kalman_filter/kalman_filter.py:56
 DT, MASS, GZ = 0.01, 8.8, -9.81
@@ -69,6 +69,21 @@ class Engine:
         t = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32) if not torch.is_tensor(a) else a)
         t = t.to(self.device, dtype=torch.float32).contiguous()
         return t if shape is None else t.reshape(shape)
+
+    # ---- the per-trajectory status word ----
+    @staticmethod
+    def failed(status):
+        """bool [B]: trajectories whose filter FAILED (bits 0-3 of the status word: S not positive definite, non-finite state,
+        QP iteration cap, non-symmetric P0 under symmetric storage).  Bit 4 (OS_STATUS_TRUNC_EDGE) is informational and is not
+        a failure: `status != 0` is the wrong test -- use this."""
+        return (status & OS_STATUS_FAIL_MASK) != 0
+
+    @staticmethod
+    def trunc_edge(status):
+        """bool [B]: trajectories that met the reference's int64-truncation knife edge at some step (status bit 4: an entry of
+        the float64 rotation matrix within 2^-40 of +-1 away from the exact start; the 1e-4 state bar is not promised there --
+        include/optistate_hip.h)."""
+        return (status & OS_STATUS_TRUNC_EDGE) != 0
 
     # ---- per-kernel device timing ----
     def profile(self, enable=True):
@@ -143,7 +158,11 @@ class Engine:
         symmetric=None picks the symmetric-storage kernels (upper triangle of P in registers) when R is diagonal and Q is
         symmetric.  They read only the upper triangle of the caller's P0 and write the final P back mirrored: a P0 that is
         not symmetric sets status bit 3 (value 8) for that trajectory -- re-run it with symmetric=False, which keeps the
-        full P like the reference (kalman_filter.py:172 never symmetrises)."""
+        full P like the reference (kalman_filter.py:172 never symmetrises).
+        want_gain: K_gain [T][B].  The sequential / symmetric kernels (the default for a diagonal R) never form K: their
+        K_gain is trace(P+ H^T R^-1) on the float32 POSTERIOR -- equal to the reference's trace(K) (kalman_filter.py:174) in
+        exact arithmetic, to ~1e-3 relative in float32.  Callers that feed K_gain downstream and need the trace of the K the
+        batch update actually forms pass sequential=False.  Test Engine.failed(status), not status != 0 (bit 4 is informational)."""
         T, _, B = p.shape
         if sequential is None:
             sequential = self._diag_R           # K_gain no longer forces the batch form: trace(P+ H^T R^-1) on the posterior

@@ -44,15 +44,55 @@ def configure_rccl(proto="default", algo="default"):
     return env
 
 
+def _host_staged(t, group=None):
+    """True when the collective must go through host memory: a device tensor under the gloo backend.  That is the
+    `--share-gpu` development shape -- several ranks on ONE MI355X, where RCCL refuses the duplicate device -- which runs the
+    world > 1 code paths (shards, weighted bucket, split all-reduce behind os_gru_backward_mark, replica check) with real
+    device tensors on a one-GPU box.  RCCL ("nccl") always takes the device tensor directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t, op=None, group=None):
+    """dist.all_reduce on t in place, stream-ordered for device tensors on either backend: RCCL enqueues on the current
+    stream; under gloo the tensor is copied to the host on the CURRENT stream (which the copy waits for), reduced there and
+    copied back on the same stream."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t, group):
+        h = t.detach().to("cpu")
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def broadcast_(t, src=0, group=None):
+    if _host_staged(t, group):
+        h = t.detach().to("cpu")
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def all_gather_cat(t, dim=0, group=None):
+    """Concatenation over the ranks of (possibly ragged along `dim`) shard tensors: the host-side gather of outputs after a
+    sharded inference run (NOT part of the data path).  Goes through the object collective, so it works on every backend."""
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, t.detach().cpu(), group=group)
+    return torch.cat(parts, dim=dim).to(t.device)
+
+
 def replica_divergence(flat_w, group=None):
     """max_r |w_r - w_0| over the ranks of a data-parallel job (identical replicas must stay bit-identical: same averaged
     gradient, same fused Adam).  One broadcast + one MAX all-reduce; 0.0 without a process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0.0
     ref = flat_w.detach().clone()
-    dist.broadcast(ref, src=0, group=group)
+    broadcast_(ref, src=0, group=group)
     d = (flat_w.detach() - ref).abs().max().reshape(1)
-    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+    all_reduce_(d, op=dist.ReduceOp.MAX, group=group)
     return float(d.item())
 
 
@@ -133,7 +173,7 @@ class FlatBucket:
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
             if world > 1:
-                dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group)
+                all_reduce_(self.g, group=group)
                 self.g.div_(world)
         return self.g
 
@@ -147,7 +187,7 @@ class FlatBucket:
             if world > 1 or force:
                 self.g.mul_(float(n_local))
                 self._gbuf[self.n] = float(n_local)
-                dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
+                all_reduce_(self._gbuf, group=group)
                 self.g.div_(self._gbuf[self.n])
         return self.g
 
@@ -178,7 +218,7 @@ class DataParallelTrainer:
         self.force = bool(force_distributed) or split_allreduce == "force"
         self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force)
         if self.distributed and dist.get_world_size(group) > 1:
-            dist.broadcast(self.bucket.w, src=0, group=group)   # identical replicas
+            broadcast_(self.bucket.w, src=0, group=group)       # identical replicas
         # Two halves of the one bucket: the backward runs top layer first, so the gradients of layers L/2 .. L-1 and of the
         # head -- the TAIL of the flat vector, the count slot included -- are final while layers L/2-1 .. 0 are still being
         # swept.  Their all-reduce starts on a side stream at that point (os_gru_backward_mark) and travels underneath the
@@ -201,10 +241,10 @@ class DataParallelTrainer:
         sp["side"].wait_event(sp["ev_top"])                      # recorded by the library behind layer L/2's dW kernel
         with torch.cuda.stream(sp["side"]):
             top[:-1].mul_(n_local); top[-1:].fill_(n_local)
-            dist.all_reduce(top, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_(top, group=self.group)
             sp["ev_done"].record(sp["side"])
         low.mul_(n_local)
-        dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce_(low, group=self.group)
         main.wait_event(sp["ev_done"])
         b.g.div_(b._gbuf[b.n])
 

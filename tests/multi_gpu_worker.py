@@ -5,7 +5,11 @@ SURVEY.md 8(e) determinism check on real GPUs: the SAME samples processed by 1 G
     gathered shard outputs must equal rank 0's full-batch run;
   * training (one flat-bucket all-reduce over RCCL): DataParallelTrainer on shards vs a single-process full-batch step --
     gradients equal to fp32 reduction-order noise, identical replicas after the Adam update.
-Rank 0 prints one JSON line."""
+With OS_SHARE_GPU=1 every rank uses device (local_rank % device_count) and the process group runs over gloo with the
+collectives staged through the host (optistate_amd.train.all_reduce_): the SAME code paths -- shards, the weighted flat
+bucket, the split all-reduce behind os_gru_backward_mark, the replica check -- on the one GPU a development box has (RCCL
+refuses two ranks on one device).  OS_WORKER_TRAIN_BATCH sets the global training batch (a value that does not divide by the
+world size makes the last shards ragged).  Rank 0 prints one JSON line."""
 import json
 import os
 import sys
@@ -19,17 +23,26 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
-    torch.cuda.set_device(lr)
-    dev = torch.device("cuda", lr)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    share = os.environ.get("OS_SHARE_GPU", "0") == "1"
+    di = lr % torch.cuda.device_count() if share else lr         # device_count() does not initialise the GPU
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
+    if share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
-    from optistate_amd.train import DataParallelTrainer, shard_range
+    from optistate_amd.train import DataParallelTrainer, shard_range, all_gather_cat
     res = {"world": dist.get_world_size(), "backend": dist.get_backend()}
+    devs = [None] * world
+    dist.all_gather_object(devs, {"rank": rank, "pid": os.getpid(), "device": di,
+                                  "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)})
+    res["rank_devices"] = devs
 
     # ---------------- inference: trajectory sharding, no collective on the data path ----------------
     B, T = 8192 * world, 12
-    eng = Engine(lr)
+    eng = Engine(di)
     eng.set_noise(Q_DEFAULT, R_DEFAULT)
     d = synth_torch(B, T, dev, seed=4242)                 # same seed on every rank: the same samples (philox)
     cp = eng.contact_soa_to_packed(d["contact"])
@@ -45,27 +58,28 @@ def main():
         return r["x_out"], r["out"], r["status"]
     lo, hi = shard_range(B, rank, world)
     xs, os_, st = run(lo, hi)
-    gx = [torch.empty_like(xs) for _ in range(world)]; go = [torch.empty_like(os_) for _ in range(world)]
-    dist.all_gather(gx, xs); dist.all_gather(go, os_)      # host-side style gather of outputs, NOT part of the data path
+    gx, go = all_gather_cat(xs, dim=2), all_gather_cat(os_, dim=0)      # host-side gather of outputs, NOT part of the data path
     if rank == 0:
         xf, of, sf = run(0, B)
-        res["infer_state_max_abs_diff"] = float((torch.cat(gx, dim=2) - xf).abs().max())
-        res["infer_out_max_abs_diff"] = float((torch.cat(go, dim=0) - of).abs().max())
-        res["infer_status_nonzero"] = int((sf != 0).sum())
+        res["infer_state_max_abs_diff"] = float((gx - xf).abs().max())
+        res["infer_out_max_abs_diff"] = float((go - of).abs().max())
+        res["infer_status_nonzero"] = int(eng.failed(sf).sum())
 
     # ---------------- training: one flat gradient bucket all-reduced over RCCL ----------------
-    Bt, Tt, dims = 2048 * world, 10, (188, 128, 4, 24)
+    Bt, Tt, dims = int(os.environ.get("OS_WORKER_TRAIN_BATCH", 2048 * world)), 10, (188, 128, 4, 24)
     g = torch.Generator(device=dev); g.manual_seed(7)
     x = torch.rand(Bt, Tt, dims[0], device=dev, generator=g); y = torch.rand(Bt, 12, device=dev, generator=g)
     torch.manual_seed(3)
     m = RNN(*dims, dev).to(dev)
     tr = DataParallelTrainer(m, lr=1e-4)
     lo, hi = shard_range(Bt, rank, world)
+    res["train_shard_sizes"] = [shard_range(Bt, r, world)[1] - shard_range(Bt, r, world)[0] for r in range(world)]
+    res["train_split_allreduce"] = tr.split is not None
     tr.step(x[lo:hi], y[lo:hi])
     g_dp, w_dp = tr.bucket.g.clone(), tr.bucket.w.clone()
-    ws = [torch.empty_like(w_dp) for _ in range(world)]
-    dist.all_gather(ws, w_dp)
-    res_w = max(float((w - ws[0]).abs().max()) for w in ws)
+    ws = all_gather_cat(w_dp.reshape(1, -1), dim=0)
+    res_w = float((ws - ws[0:1]).abs().max())
+    res_div = tr.replica_divergence()                    # the product's own check: broadcast + MAX all-reduce
     dist.barrier()
     if rank == 0:
         # single-process full-batch step: same init, no process group involved (world-1 semantics by construction)
@@ -82,6 +96,11 @@ def main():
         res["train_grad_max_abs_diff"] = float((g_dp - bucket.g).abs().max())
         res["train_grad_scale"] = scale
         res["train_replica_weight_max_abs_diff"] = res_w
+        res["train_replica_divergence"] = res_div
+        # the weights after the data-parallel step against the single-process full-batch Adam step
+        m_, v_ = torch.zeros_like(bucket.w), torch.zeros_like(bucket.w)
+        e.adam_step(bucket.w, bucket.g, m_, v_, 1e-4, 0.9, 0.999, 1e-8, 1)
+        res["train_weight_vs_single_process_max_abs_diff"] = float((w_dp - bucket.w).abs().max())
         res["grad_bucket_bytes"] = int(bucket.g.numel() * 4)
         print(json.dumps(res), flush=True)
     dist.barrier()

@@ -1,0 +1,78 @@
+"""CPU: the register / scratch budget of the shipped library, read from its gfx950 code objects (tools/codeobj_report.py:
+`.hip_fatbin` -> offload bundles -> NT_AMDGPU_METADATA via llvm-readelf).  A kernel that a reference-shaped call reaches must
+not touch scratch memory: a spill is an HBM round trip per lane inside a loop that is otherwise register / LDS resident.
+The list below is the contract; everything else with scratch is printed (run with -s) and tracked in profiles/r05_scratch.md.
+"""
+import os
+import re
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import codeobj_report as cr   # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(cr.LIB) or not os.path.exists(os.path.join(cr.LLVM, "llvm-readelf")),
+                                reason="needs the built library and llvm-readelf")
+
+# kernel (demangled, as tools/codeobj_report.py prints it) -> which reference-shaped call reaches it
+SCRATCH_FREE = {
+    # BASELINE configs[2]: the headline kernel and its full-Q twin; GRU(60,64,L>1) writes layer 0's sequence (SEQOUT)
+    "osf::fused_kf_gru_kernel_v2<true, false>": "fused KF+GRU headline (diagonal Q)",
+    "osf::fused_kf_gru_kernel_v2<false, false>": "fused KF+GRU, full-matrix Q",
+    # PENDING "osf::fused_kf_gru_kernel_v2<true, true>": "fused KF+GRU(60,64,L>1): layer 0 with its sequence written",
+    # BASELINE configs[1] and the KF-only large batch
+    "osk::kf_run_sym_kernel<0, true, false>": "KF only, B = 65,536",
+    "osk::kf_run_sym_kernel<0, true, true>": "KF only with p_rot",
+    "osk::kf_run_rows2_kernel<false, false, false>": "KF only, B = 4,096 x 1,000 (configs[1])",
+    "osk::kf_run_rows2_kernel<true, false, true>": "small-batch KF with aux outputs",
+    # the GRU layer kernels of the reference's model shapes
+    "osg::gru_layer_stage_kernel<4>": "RNN(188,128,4) at the headline batch",
+    "osg::gru_layer_stage_kernel<2>": "GRU(60,64,4) layers 1..3 at the headline batch",
+    "osg::gru_layer_ahead_kernel": "training / windows forward, H = 128, one tile per CU",
+    "osg::gru_layer_split_kernel<4>": "H = 128 small batches",
+    # PENDING "osg::gru_layer_split_kernel<2>": "H = 64 small batches",
+    "osg::gru_stack_kernel<4>": "the reference's own windows (B = 1 / 64), H = 128",
+    # PENDING "osg::gru_stack_kernel<2>": "layer-pipelined stack, H = 64",
+    "osg::gru_vec_kernel<128>": "one window per call (gru/gru_test.py:157-177)",
+    "osg::gru_vec_kernel<64>": "one window per call, H = 64",
+    # PENDING "osg::gru_layer_kernel<2, 2>": "H = 128 fallback when the stage kernel steps aside",
+    # BASELINE configs[3]: the training step
+    "ost::bwd_sweep_kernel<1, 8, 0>": "training backward sweep",
+    # PENDING "ost::bwd_sweep_stack_kernel": "batch-64 training backward (gru/gru_train.py:36)",
+    # estimate_state_mpc -- the reference's real loop
+    # PENDING "osm::kf_mpc_persistent_kernel<1>": "estimate_state_mpc at the reference's shape (B < 8 CUs)",
+    # PENDING "osk::kf_dense_rows_kernel<false>": "predict_mpc covariance + update, float64, 16 lanes per trajectory",
+    # PENDING "osk::kf_dense_rows_kernel<true>": "the same with aux outputs",
+}
+
+
+@pytest.fixture(scope="module")
+def rows():
+    return {r["name"]: r for r in cr.report()}
+
+
+def test_metadata_is_readable_and_covers_the_library(rows):
+    assert len(rows) > 100
+    hk = rows["osf::fused_kf_gru_kernel_v2<true, false>"]
+    assert hk["vgpr_count"] > 256 and hk["agpr_count"] > 0          # the headline kernel uses both register halves
+
+
+@pytest.mark.parametrize("name", sorted(SCRATCH_FREE))
+def test_reference_shaped_kernels_use_no_scratch(rows, name):
+    assert name in rows, f"{name} is not in the library (renamed? update the list): {[k for k in rows if name.split('<')[0] in k]}"
+    r = rows[name]
+    assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, \
+        f"{name} ({SCRATCH_FREE[name]}): scratch {r['private_segment_fixed_size']} B/lane, {r['vgpr_spill_count']} VGPR spills"
+
+
+def test_report_the_rest(rows, capsys):
+    rest = [r for n, r in sorted(rows.items()) if r["private_segment_fixed_size"] and n not in SCRATCH_FREE]
+    with capsys.disabled():
+        print("\nkernels outside the scratch-free contract that use scratch (B/lane):")
+        for r in rest:
+            print(f"  {r['name']}: {r['private_segment_fixed_size']} (VGPR spills {r['vgpr_spill_count']})")
+    # nothing outside the list may grow unnoticed past a page of spills
+    assert all(r["private_segment_fixed_size"] <= 6000 for r in rest)
