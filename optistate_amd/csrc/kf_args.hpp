@@ -299,5 +299,7 @@ __device__ __forceinline__ void quad_sum6(float &a, float &b, float &c, float &d
 
 // kf_rows_kernel.hip (its own translation unit: compile flags): picks kf_run_rows2_kernel's instantiation and launches it
 hipError_t launch_kf_rows2(const KfRunArgs &a, const float *qmat, bool feat, bool aux, hipStream_t s);
+// kf_dense_rows.hip: the predict_mpc (dense F_d) filter in float64, 16 lanes per trajectory; qr = Q (144) | R (100) on the device
+hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s);
 
 }  // namespace osk

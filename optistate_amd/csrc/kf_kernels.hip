@@ -619,13 +619,16 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
                           a.B < ctx->rows_kernel_below && ctx->kf_qr && (uint64_t)a.T * 48ull * (uint64_t)a.B < 0xffffffffull;
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise);
     const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
-                        : dense ? (seq ? "kf_run_kernel<SEQ,DENSE_F64>" : "kf_run_kernel<BATCH,DENSE_F64>")
+                        : dense ? (seq ? "kf_dense_rows_kernel<SEQ>" : "kf_dense_rows_kernel<BATCH>")
                                 : (seq ? "kf_run_kernel<SEQ>" : "kf_run_kernel<BATCH>");
     const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, kname);
-#define OS_DISPATCH(SEQ, DENSE)                                                        \
-    (feat ? launch_kf_run<SEQ, DENSE, false, true>(a, s)                               \
-          : (aux ? launch_kf_run<SEQ, DENSE, true, false>(a, s) : launch_kf_run<SEQ, DENSE, false, false>(a, s)))
-    if (noise) {
+#define OS_DISPATCH(SEQ)                                                               \
+    (feat ? launch_kf_run<SEQ, false, false, true>(a, s)                               \
+          : (aux ? launch_kf_run<SEQ, false, true, false>(a, s) : launch_kf_run<SEQ, false, false, false>(a, s)))
+    if (dense) {
+        // predict_mpc covariance (element-wise exp(dt F)): float64, 16 lanes per trajectory, every batch size (kf_dense_rows.hip)
+        e = launch_kf_dense_rows(a, (const float *)ctx->kf_qr, seq, feat, aux, s);
+    } else if (noise) {
         dim3 grid((a.B + 63) / 64), block(64);
         if (feat) hipLaunchKernelGGL((kf_run_sym_noise_kernel<2>), grid, block, 0, s, a);
         else if (aux) hipLaunchKernelGGL((kf_run_sym_noise_kernel<1>), grid, block, 0, s, a);
@@ -659,8 +662,8 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
         e = feat ? launch_kf_run<true, false, false, true, true>(a, s)
                  : (aux ? launch_kf_run<true, false, true, false, true>(a, s)
                         : launch_kf_run<true, false, false, false, true>(a, s));
-    else if (seq) e = dense ? OS_DISPATCH(true, true) : OS_DISPATCH(true, false);
-    else e = dense ? OS_DISPATCH(false, true) : OS_DISPATCH(false, false);
+    else if (seq) e = OS_DISPATCH(true);
+    else e = OS_DISPATCH(false);
 #undef OS_DISPATCH
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, e);

@@ -44,8 +44,11 @@ SCRATCH_FREE = {
     # PENDING "ost::bwd_sweep_stack_kernel": "batch-64 training backward (gru/gru_train.py:36)",
     # estimate_state_mpc -- the reference's real loop
     # PENDING "osm::kf_mpc_persistent_kernel<1>": "estimate_state_mpc at the reference's shape (B < 8 CUs)",
-    # PENDING "osk::kf_dense_rows_kernel<false>": "predict_mpc covariance + update, float64, 16 lanes per trajectory",
-    # PENDING "osk::kf_dense_rows_kernel<true>": "the same with aux outputs",
+    "osk::kf_dense_rows_kernel<false, false, false>": "predict_mpc covariance + batch update, float64, 16 lanes per trajectory",
+    "osk::kf_dense_rows_kernel<true, false, false>": "the same with the sequential update (diagonal R)",
+    "osk::kf_dense_rows_kernel<false, true, false>": "batch update with P_trace / K_gain outputs",
+    "osk::kf_dense_rows_kernel<true, true, false>": "sequential update with P_trace / K_gain outputs",
+    "osk::kf_dense_rows_kernel<false, false, true>": "feature rows for the two-kernel fused path (dense F_d)",
 }
 
 

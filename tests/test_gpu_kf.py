@@ -356,3 +356,59 @@ def test_update_entry_point_gain_matches_reference(eng, s, sequential):
         assert abs(float(r["K_gain"][b]) - g[f"s{s}_b{b}_K_gain"][0]) < 1e-4 * max(1.0, abs(g[f"s{s}_b{b}_K_gain"][0]))
         assert abs(float(r["P_trace"][b]) / g[f"s{s}_b{b}_P_trace"][0] - 1) < 1e-4
         assert np.abs(x.cpu().numpy()[:, b] - g[f"s{s}_b{b}_x"][0]).max() < STATE_TOL
+
+
+@pytest.mark.parametrize("B", [1, 5, 37, 4100])
+@pytest.mark.parametrize("sequential", [False, True], ids=["batch", "seq"])
+def test_dense_rows_kernel_matches_oracle_predict_mpc(eng, B, sequential):
+    """kf_dense_rows_kernel (float64, 16 lanes per trajectory) against the C oracle's predict_mpc path (kalman_filter.py:
+    153-174 with supplied forces) for both update forms, ragged batch sizes (partial waves / workgroups), P_trace, K_gain, the
+    rotated foot positions and the final state; the reference-generated G8 pins the same path above."""
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    T = 40
+    d = synth_numpy(B, T, seed=100 + B)
+    rng = np.random.default_rng(B)
+    d["body_ref"] = np.zeros((B, T, 12), dtype=np.float32)
+    d["body_ref"][..., 0:3] = d["imu"][..., 0:3] + rng.normal(0, 0.01, (B, T, 3)).astype(np.float32)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)), Q_FITTED, R_FITTED,
+                           body_ref=d["body_ref"], mode=1)
+    s = soa(eng, d)
+    br = eng.pack(torch.as_tensor(d["body_ref"]))
+    eng.set_noise(Q_FITTED, R_FITTED)
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    r = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], s["contact"], x, P, body_ref=br, dense_fd=True, sequential=sequential,
+                   want_p_rot=True, want_trace=True, want_gain=True)
+    assert eng.kernel_name("kf").startswith("kf_dense_rows_kernel")
+    xo = eng.unpack(r["x_out"]).cpu().numpy()
+    assert np.abs(xo - ref["x"]).max() < STATE_TOL
+    assert np.abs(eng.unpack(r["p_rot"]).cpu().numpy() - ref["p_rot"]).max() < 1e-5
+    assert np.abs(r["P_trace"].cpu().numpy().T / ref["P_trace"] - 1).max() < 1e-3
+    kg = r["K_gain"].cpu().numpy().T
+    assert np.abs(kg - ref["K_gain"]).max() < 1e-3 * max(1.0, np.abs(ref["K_gain"]).max())
+    assert np.abs(x.cpu().numpy().T - ref["x_final"]).max() < STATE_TOL
+    Pf = P.cpu().numpy().T.reshape(B, 12, 12)
+    assert np.abs(Pf - ref["P_final"]).max() < 1e-3 * np.abs(ref["P_final"]).max()
+    assert int(eng.failed(r["status"]).sum()) == 0
+
+
+def test_dense_rows_kernel_full_matrix_noise_and_feature_rows(eng):
+    """Non-diagonal Q and R (batch update only) and the FEAT instantiation (two-kernel fused path with dense_fd)."""
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import synth_numpy, Q_DEFAULT, R_DEFAULT
+    B, T = 19, 25
+    rng = np.random.default_rng(5)
+    A = rng.normal(0, 1, (12, 12)); Q = Q_DEFAULT + 1e-4 * (A @ A.T)
+    A = rng.normal(0, 1, (10, 10)); R = R_DEFAULT + 1e-3 * (A @ A.T)
+    d = synth_numpy(B, T, seed=8)
+    d["body_ref"] = np.zeros((B, T, 12), dtype=np.float32); d["body_ref"][..., 0:3] = d["imu"][..., 0:3]
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q, (B, 1, 1)), Q, R, body_ref=d["body_ref"], mode=1)
+    s = soa(eng, d)
+    br = eng.pack(torch.as_tensor(d["body_ref"]))
+    eng.set_noise(Q, R)
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    r = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], s["contact"], x, P, body_ref=br, dense_fd=True, sequential=False)
+    assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < STATE_TOL
+    assert int(eng.failed(r["status"]).sum()) == 0

@@ -1,0 +1,59 @@
+"""Development probe: the timings the round's work items are judged on, in one process (device time via torch events).
+  dense-F_d float64 filter at B = 65,536 (T = 20), the estimate_state_mpc loop at the reference's shape (B = 8, T = 4000),
+  GRU(60,64,4) fused layer 0, the sliding-window inference mode and the training step."""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from optistate_amd import Engine, RNN, flatten_state_dict  # noqa: E402
+from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT  # noqa: E402
+
+dev = torch.device("cuda:0")
+eng = Engine(0); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+res = {}
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+# dense-F_d filter, large batch
+for B, T in ((65536, 20), (4096, 100)):
+    d = synth_torch(B, T, dev, seed=3)
+    contact = eng.contact_soa_to_packed(d["contact"])
+    f = torch.zeros((T, 12, B), device=dev); f[:, 2::3] = 30.0
+    ref = torch.zeros((T, 12, B), device=dev)
+    for seq in (False, True):
+        def run():
+            x, P = d["x0"].clone(), d["P0"].clone()
+            return eng.kf_run(d["p"], f, d["dp"], d["imu"], contact, x, P, body_ref=ref, dense_fd=True, sequential=seq)
+        ms = timeit(run, n=3, warm=1)
+        res[f"dense_kf_B{B}_T{T}_{'seq' if seq else 'batch'}"] = {"ms_per_launch": ms, "ms_per_step": ms / T, "kernel": eng.kernel_name("kf")}
+    del d, f, ref
+
+# estimate_state_mpc at the reference's shape
+for B, T in ((8, 4000), (65536, 20)):
+    d = synth_torch(B, T, dev, seed=11)
+    contact = eng.contact_soa_to_packed(d["contact"])
+    ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
+    tt = torch.arange(T, device=dev)[:, None] * 0.01
+    ref[:, 0] = 0.02 * torch.sin(3 * tt); ref[:, 1] = 0.02 * torch.cos(2 * tt)
+    def run():
+        x, P = d["x0"].clone(), d["P0"].clone()
+        return eng.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P)
+    ms = timeit(run, n=2, warm=1)
+    res[f"mpc_run_B{B}_T{T}"] = {"ms": ms, "us_per_step": ms * 1e3 / T, "steps_per_s": B * T / ms * 1e3}
+    del d, ref
+
+print(json.dumps(res, indent=1))
