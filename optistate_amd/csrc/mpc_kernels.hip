@@ -28,6 +28,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "kf_dense_rows.hpp"
 #include "kf_args.hpp"
 
 namespace osm {
@@ -612,12 +613,37 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
 // filter state around them (the persistent kernel at small batch: 1,100 SGPR and 50-370 VGPR spills inlined; B = 8:
 // 109 -> 92 us per step as a call.  At large batch the call's stack costs occupancy: 7.9e6 -> 5.8e6 steps/s, so the
 // two-waves-per-SIMD instantiation keeps the inlined form).
+// Round 5: nothing crosses the call through the stack.  References to the caller's kernel argument (`a.prm`) and to its local
+// arrays (x, ref, p, legs, the outputs) made hipcc copy the whole 1.3 KB argument block and the arrays into scratch: 1,748 B
+// per lane.  The problem data now sits in an LDS block the caller fills (QpCall; the callee copies it into registers), the
+// per-lane solver state goes in and out by value (QpRet comes back in six VGPRs).
+struct QpCall {
+    MpcParams prm;
+    double x[12], ref[12], p[12];
+    int legs[4];
+};
+struct QpRet { double u; int face; float val; int iters; int conv; };
+typedef const __attribute__((address_space(3))) QpCall *QpCallLds;
 template <int NST>
-__device__ __attribute__((noinline)) void mpc_solve_wave_call(const MpcParams &P, uint32_t cbits, const int (&legs)[4], const double (&x)[12],
-                                                             const double (&ref)[12], const double (&p)[12], int max_iter, bool warm,
-                                                             WaveMemT<15 * NST> &M, QpLane &io, float &val, int &iters_out, bool &converged_out)
+static __device__ __attribute__((noinline)) QpRet mpc_solve_wave_call(QpCallLds qc, uint32_t cbits, int max_iter, bool warm,
+                                                               WaveMemT<15 * NST> &M, double u_in, int face_in)
 {
-    mpc_solve_wave<NST>(P, cbits, legs, x, ref, p, max_iter, warm, M, io, val, iters_out, converged_out);
+    MpcParams P;
+    double x[12], ref[12], p[12];
+    int legs[4];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { P.w[j] = qc->prm.w[j]; x[j] = qc->x[j]; ref[j] = qc->ref[j]; p[j] = qc->p[j]; }
+    P.rw = qc->prm.rw; P.mu = qc->prm.mu; P.fzmax = qc->prm.fzmax; P.dt = qc->prm.dt; P.inv_mass = qc->prm.inv_mass; P.gz = qc->prm.gz;
+#pragma unroll
+    for (int j = 0; j < 3; j++) P.inv_inertia[j] = qc->prm.inv_inertia[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) legs[j] = qc->legs[j];
+    QpLane io = {u_in, face_in};
+    QpRet r;
+    bool conv;
+    mpc_solve_wave<NST>(P, cbits, legs, x, ref, p, max_iter, warm, M, io, r.val, r.iters, conv);
+    r.u = io.u; r.face = io.face; r.conv = conv ? 1 : 0;
+    return r;
 }
 
 // NST = number of legs that carry force variables (contact byte != 0).  Swing legs are eliminated up front: a trot
@@ -686,13 +712,9 @@ __global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const M
 // reference (the launch sequence rounded it to float32 at every step boundary).
 // =====================================================================================================================
 struct KfWave {
-    double P[144], Mt[144];      // covariance, scratch (F_d P)
-    double L[10][10];            // S, then its Cholesky factor (lower triangle)
-    double K[12][10];
-    double Q[144], R[100];       // symmetrised R
-    double cs[12], rs[12], dinv[10];
-    double e[10];                // exp(dt R^T_ij) - 1 of the body_ref rotation (9) and e^dt - 1
-    float xs[12];
+    double Q[144];               // float64 copies for the row layout: a lane reads ITS row of Q ...
+    double R[12][10];            // ... and the row of R of the measurement its state row owns (rows 10, 11: zeros, lanes without one)
+    QpCall qc;                   // the QP's problem data for mpc_solve_wave_call
 };
 
 struct MpcRunArgs {
@@ -702,153 +724,6 @@ struct MpcRunArgs {
     int max_iter, cold;
     MpcParams prm;
 };
-
-// P <- F_d P F_d^T + Q with F_d = 1 1^T + E (cov_predict_dense in kf_device.hpp, same operation order per entry)
-__device__ __forceinline__ void cov_predict_dense_wave(KfWave &W, const osk::Rot &rb, float dt, int lane)
-{
-    if (lane < 9) W.e[lane] = expm1((double)dt * (double)rb.m[3 * (lane % 3) + lane / 3]);      // e[3 i + kk] = expm1(dt R[kk][i])
-    if (lane == 9) W.e[9] = expm1((double)dt);
-    if (lane < 12) {
-        double c = 0.0;
-#pragma unroll
-        for (int i = 0; i < 12; i++) c += W.P[i * 12 + lane];
-        W.cs[lane] = c;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double ed = W.e[9];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int el = lane + 64 * r;
-        if (el < 144) {
-            const int i = el / 12, j = el % 12;
-            double m = W.cs[j];
-            if (i < 3) m += W.e[3 * i] * W.P[6 * 12 + j] + W.e[3 * i + 1] * W.P[7 * 12 + j] + W.e[3 * i + 2] * W.P[8 * 12 + j];
-            else if (i < 6) m += ed * W.P[(i + 6) * 12 + j];
-            W.Mt[el] = m;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 12) {
-        double c = 0.0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) c += W.Mt[lane * 12 + j];
-        W.rs[lane] = c;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int el = lane + 64 * r;
-        if (el < 144) {
-            const int i = el / 12, j = el % 12;
-            double v = W.rs[i] + W.Q[el];
-            if (j < 3) v += W.e[3 * j] * W.Mt[i * 12 + 6] + W.e[3 * j + 1] * W.Mt[i * 12 + 7] + W.e[3 * j + 2] * W.Mt[i * 12 + 8];
-            else if (j < 6) v += ed * W.Mt[i * 12 + j + 6];
-            W.P[el] = v;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Batch update (update_batch in kf_device.hpp: y = z - x[sel]; S = P[sel,sel] + R; K = P[:,sel] S^-1; x += K y;
-// P <- P - K P[sel,:]) on the LDS-resident covariance.  x: the state, replicated on every lane.  Returns status bit 0
-// (S not positive definite) wave-uniformly; *kgain = sum of the ten main-diagonal entries of K, *ptrace = trace(P).
-__device__ __forceinline__ int update_batch_wave(float *x, KfWave &W, const float *z, int lane, float *kgain, float *ptrace,
-                                                 float *xnew_lane)
-{
-    using osk::SEL;
-    int status = 0;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int el = lane + 64 * r;
-        if (el < 100) {
-            const int a = el / 10, b = el % 10;
-            if (b <= a) W.L[a][b] = 0.5 * (W.P[SEL[a] * 12 + SEL[b]] + W.P[SEL[b] * 12 + SEL[a]]) + W.R[el];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // Cholesky, column by column: the pivot is recomputed by every lane (wave-uniform LDS reads), lane i > j updates L[i][j]
-    for (int j = 0; j < 10; j++) {
-        double d = W.L[j][j];
-        for (int q = 0; q < j; q++) d -= W.L[j][q] * W.L[j][q];
-        if (!(d > 0.0) || !(d < 3.0e38)) { status |= 1; d = 1.0; }
-        const double di = rsqrt64(d);
-        if (lane > j && lane < 10) {
-            double sacc = W.L[lane][j];
-            for (int q = 0; q < j; q++) sacc -= W.L[lane][q] * W.L[j][q];
-            W.L[lane][j] = sacc * di;
-        }
-        if (lane == 0) { W.dinv[j] = di; }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) W.L[j][j] = d * di;
-        __builtin_amdgcn_wave_barrier();
-    }
-    // K[i,:] = solve(S, P[i,sel]): lane i < 12 does row i (forward and back substitution against wave-uniform L entries)
-    double Krow[10];
-    {
-        const int i = lane < 12 ? lane : 0;
-        double y[10];
-#pragma unroll
-        for (int a = 0; a < 10; a++) {
-            double sacc = W.P[i * 12 + SEL[a]];
-#pragma unroll
-            for (int q = 0; q < a; q++) sacc -= W.L[a][q] * y[q];
-            y[a] = sacc * W.dinv[a];
-        }
-#pragma unroll
-        for (int a = 9; a >= 0; a--) {
-            double sacc = y[a];
-#pragma unroll
-            for (int q = a + 1; q < 10; q++) sacc -= W.L[q][a] * Krow[q];
-            Krow[a] = sacc * W.dinv[a];
-        }
-        if (lane < 12) {
-#pragma unroll
-            for (int a = 0; a < 10; a++) W.K[lane][a] = Krow[a];
-        }
-        double sx = 0.0;
-#pragma unroll
-        for (int a = 0; a < 10; a++) sx += Krow[a] * ((double)z[a] - (double)x[SEL[a]]);
-        // x[i] of this lane's row (replicated array: pick it through LDS)
-        if (lane < 12) W.xs[lane] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 12; k++)
-            if (lane == k) W.xs[k] = (float)((double)x[k] + sx);
-        __builtin_amdgcn_wave_barrier();
-        *xnew_lane = W.xs[i];
-#pragma unroll
-        for (int k = 0; k < 12; k++) x[k] = W.xs[k];
-    }
-    // P <- P - K P[sel,:]: every entry reads only OLD rows; all three values of a lane are formed before any is written
-    double pn[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int el = lane + 64 * r;
-        pn[r] = 0.0;
-        if (el < 144) {
-            const int i = el / 12, j = el % 12;
-            double sacc = 0.0;
-#pragma unroll
-            for (int a = 0; a < 10; a++) sacc += W.K[i][a] * W.P[SEL[a] * 12 + j];
-            pn[r] = W.P[el] - sacc;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int el = lane + 64 * r;
-        if (el < 144) W.P[el] = pn[r];
-    }
-    __builtin_amdgcn_wave_barrier();
-    double tk = 0.0, tp = 0.0;
-#pragma unroll
-    for (int a = 0; a < 10; a++) tk += W.K[a][a];
-#pragma unroll
-    for (int i = 0; i < 12; i++) tp += W.P[i * 13];
-    *kgain = (float)tk;
-    *ptrace = (float)tp;
-    return status;
-}
 
 union QpMem {
     WaveMemT<15> m1;
@@ -866,21 +741,34 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
     __shared__ QpMem QM;
     __shared__ KfWave W;
     using namespace osk;
+    namespace rw = osk::rows64;
     const int b = blockIdx.x, lane = threadIdx.x;
+    // Filter state on the 16-lanes-per-trajectory layout of kf_dense_rows.hpp, the SAME trajectory in all four DPP rows of the
+    // wavefront: lane (lane & 15) = r holds row r of P in float64 (24 registers) and x[r]; rows 12-15 of every group shadow row 11.
+    const int r = lane & 15, rr = r < 12 ? r : 11, am = rw::row_measurement(r);
     const size_t B = (size_t)a.kf.B;
     const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.kf.B * 4u;
-    float x[12];
+    float xr = a.kf.x[(size_t)rr * B + b];
+    double P[NS];
 #pragma unroll
-    for (int i = 0; i < 12; i++) x[i] = a.kf.x[(size_t)i * B + b];
-    for (int el = lane; el < 144; el += 64) {
-        W.P[el] = (double)a.kf.P[(size_t)el * B + b];
-        W.Q[el] = (double)a.kf.k.Q[el];
-    }
-    for (int el = lane; el < 100; el += 64) {
-        const int r = el / 10, c = el % 10;
-        W.R[el] = (double)(0.5f * (a.kf.k.R[r * 10 + c] + a.kf.k.R[c * 10 + r]));
+    for (int j = 0; j < NS; j++) P[j] = (double)a.kf.P[(size_t)(rr * NS + j) * B + b];
+    for (int el = lane; el < 144; el += 64) W.Q[el] = (double)a.kf.k.Q[el];
+    for (int el = lane; el < 120; el += 64)             // symmetrised, as update_batch forms S (kf_device.hpp)
+        (&W.R[0][0])[el] = el < 100 ? (double)(0.5f * (a.kf.k.R[el] + a.kf.k.R[(el % 10) * 10 + el / 10])) : 0.0;
+    if (lane == 0) {
+        // MpcParams, field by field: a reference to a.prm would make hipcc copy the whole argument block to scratch
+#pragma unroll
+        for (int j = 0; j < 12; j++) W.qc.prm.w[j] = a.prm.w[j];
+        W.qc.prm.rw = a.prm.rw; W.qc.prm.mu = a.prm.mu; W.qc.prm.fzmax = a.prm.fzmax; W.qc.prm.dt = a.prm.dt;
+        W.qc.prm.inv_mass = a.prm.inv_mass; W.qc.prm.gz = a.prm.gz;
+#pragma unroll
+        for (int j = 0; j < 3; j++) W.qc.prm.inv_inertia[j] = a.prm.inv_inertia[j];
     }
     __builtin_amdgcn_wave_barrier();
+    const double *qrow = W.Q + rr * NS, *rrow_l = &W.R[am >= 0 ? am : NM][0];
+    double one = 1.0;
+    asm volatile("" : "+v"(one));
+    const double ed = expm1((double)a.kf.k.dt);
     QpLane qio = {0.0, 0};
     uint32_t prev_c = 0xffffffffu;
     int status = 0;
@@ -901,6 +789,8 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
 #pragma unroll
         for (int i = 0; i < 12; i++) bref[i] = bref_n[i];
         fetch(t + 1 < a.kf.T ? t + 1 : t);
+        float x[NS];
+        rw::gather_state(xr, x);                       // the replicated prior state
         // ---- forces from the state BEFORE this step's predict (kalman_filter.py:141-152) ----
         const uint32_t cbits = __builtin_amdgcn_readfirstlane(in.contact);
         int legs[4] = {0, 0, 0, 0}, nst = 0;
@@ -914,17 +804,27 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
         float fval = 0.f;
         int iters = 0;
         if (nst > 0) {
-            double xd[12], rd[12], pd[12];
-#pragma unroll
-            for (int j = 0; j < 12; j++) { xd[j] = (double)x[j]; rd[j] = (double)bref[j]; pd[j] = (double)in.p[j]; }
             const bool warm = !a.cold && prev_c != 0xffffffffu && contact_ranks(cbits) == contact_ranks(prev_c);
             bool conv = true;
             if constexpr (OCC == 1) {
-                if (nst == 1) mpc_solve_wave_call<1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
-                else if (nst == 2) mpc_solve_wave_call<2>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
-                else if (nst == 3) mpc_solve_wave_call<3>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
-                else mpc_solve_wave_call<4>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m4, qio, fval, iters, conv);
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < 12; j++) { W.qc.x[j] = (double)x[j]; W.qc.ref[j] = (double)bref[j]; W.qc.p[j] = (double)in.p[j]; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) W.qc.legs[j] = legs[j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const QpCallLds qc = (QpCallLds)&W.qc;
+                QpRet q;
+                if (nst == 1) q = mpc_solve_wave_call<1>(qc, cbits, a.max_iter, warm, QM.m1, qio.u, qio.face);
+                else if (nst == 2) q = mpc_solve_wave_call<2>(qc, cbits, a.max_iter, warm, QM.m2, qio.u, qio.face);
+                else if (nst == 3) q = mpc_solve_wave_call<3>(qc, cbits, a.max_iter, warm, QM.m3, qio.u, qio.face);
+                else q = mpc_solve_wave_call<4>(qc, cbits, a.max_iter, warm, QM.m4, qio.u, qio.face);
+                qio.u = q.u; qio.face = q.face; fval = q.val; iters = q.iters; conv = q.conv != 0;
             } else {
+                double xd[12], rd[12], pd[12];
+#pragma unroll
+                for (int j = 0; j < 12; j++) { xd[j] = (double)x[j]; rd[j] = (double)bref[j]; pd[j] = (double)in.p[j]; }
                 if (nst == 1) mpc_solve_wave<1, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m1, qio, fval, iters, conv);
                 else if (nst == 2) mpc_solve_wave<2, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m2, qio, fval, iters, conv);
                 else if (nst == 3) mpc_solve_wave<3, 1>(a.prm, cbits, legs, xd, rd, pd, a.max_iter, warm, QM.m3, qio, fval, iters, conv);
@@ -937,31 +837,41 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
         if (a.iters && lane == 0) a.iters[(size_t)t * B + b] = iters;
 #pragma unroll
         for (int j = 0; j < 12; j++) in.f[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fval), j));
-        // ---- get_odom + set_measurements + predict_mpc + next_state + update (kalman_filter.py:176-182) ----
-        float z[NM], pw[12], kgain = 0.f, ptrace = 0.f, xl = 0.f;
-        measurement(in, z);
-        const Rot r = rotation(x[0], x[1], x[2]);
-        const Rot rb = rotation(bref[0], bref[1], bref[2]);
-        cov_predict_dense_wave(W, rb, a.kf.k.dt, lane);
-        status |= dynamics(x, r, in.p, in.f, pw, a.kf.k);
-        status |= update_batch_wave(x, W, z, lane, &kgain, &ptrace, &xl);
-        status |= finite_status(x);
-        if (lane < 12) a.kf.x_out[((size_t)t * 12 + lane) * B + b] = xl;
-        if (lane == 0) {
-            if (a.kf.p_rot_out) {
+        // ---- get_odom + set_measurements + predict_mpc + next_state + update (kalman_filter.py:176-182), float64 covariance on
+        // the row layout: every cross-lane term is a broadcast fused into a v_fmac_f64_dpp (kf_dense_rows.hpp) ----
+        float z[NM], pw[12];
+        status |= rw::front_row(x, xr, P, in, bref, a.kf.k, ed, qrow, one, r, z, pw);
+        float xn = x[0];
 #pragma unroll
-                for (int i = 0; i < 12; i++) a.kf.p_rot_out[((size_t)t * 12 + i) * B + b] = pw[i];
-            }
-            if (a.kf.ptrace_out) a.kf.ptrace_out[(size_t)t * B + b] = ptrace;
-            if (a.kf.kgain_out) a.kf.kgain_out[(size_t)t * B + b] = kgain;
+        for (int i = 1; i < NS; i++) xn = (rr == i) ? x[i] : xn;
+        double xd = (double)xn, K[NM], rrow[NM];
+#pragma unroll
+        for (int q = 0; q < NM; q++) rrow[q] = rrow_l[q];
+        status |= rw::update_batch_row(xd, P, z, rrow, K);
+        xr = (float)xd;
+        if (!(xr * 0.f == 0.f)) status |= 2;
+        if (lane < 12) a.kf.x_out[((size_t)t * 12 + lane) * B + b] = xr;
+        if (a.kf.p_rot_out && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) a.kf.p_rot_out[((size_t)t * 12 + i) * B + b] = pw[i];
+        }
+        if (a.kf.ptrace_out) {                         // (wave-uniform branches: every lane takes part in the DPP sums)
+            const float tr = rw::ptrace_rows(P, one);
+            if (lane == 0) a.kf.ptrace_out[(size_t)t * B + b] = tr;
+        }
+        if (a.kf.kgain_out) {
+            const float kg = rw::kgain_rows(K, one);
+            if (lane == 0) a.kf.kgain_out[(size_t)t * B + b] = kg;
         }
     }
-    if (lane == 0) {
+    // the status word is OR-reduced over the wavefront (bit 1 is per state component)
+    for (int m = 1; m < 64; m <<= 1) status |= __shfl_xor(status, m, 64);
+    if (lane < 12) {
+        a.kf.x[(size_t)lane * B + b] = xr;
 #pragma unroll
-        for (int i = 0; i < 12; i++) a.kf.x[(size_t)i * B + b] = x[i];
-        a.kf.status[b] = status;
+        for (int j = 0; j < NS; j++) a.kf.P[(size_t)(lane * NS + j) * B + b] = (float)P[j];
     }
-    for (int el = lane; el < 144; el += 64) a.kf.P[(size_t)el * B + b] = (float)W.P[el];
+    if (lane == 0) a.kf.status[b] = status;
 }
 
 // which leg counts occur at each step of a [T][B] contact stream: flags[t] bit n set <=> some trajectory has n legs on the ground
