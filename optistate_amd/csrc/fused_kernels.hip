@@ -277,6 +277,23 @@ __device__ __forceinline__ float agpr_put(float v)
     asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
     return a;
 }
+// buffer_store straight from an AGPR (gfx90a+: one register file, VMEM data operands may be accumulator registers): the
+// layer-0 sequence of the SEQOUT variants leaves without a v_accvgpr_read per element.  vo: per-lane byte offset, so: wave-uniform.
+// Two stores per statement behind ONE `s_nop 4`: an SGPR written by a VALU instruction (v_readfirstlane, and the v_readlane that
+// reloads a spilled SGPR -- this kernel has ~160 of those) needs five wait states before a VMEM instruction reads it, and hipcc's
+// hazard recogniser does not look inside inline assembly (without the nop: random wrong addresses, GRU l-inf 1.5e-2).
+__device__ __forceinline__ void buf_store_agpr2(osk::rsrc_t r, uint32_t vo, uint32_t so0, float a0, uint32_t so1, float a1)
+{
+    asm volatile("s_nop 4\n\tbuffer_store_dword %0, %2, %3, %4 offen\n\tbuffer_store_dword %1, %2, %3, %5 offen"
+                 : : "a"(a0), "a"(a1), "v"(vo), "s"(r), "s"(so0), "s"(so1) : "memory");
+}
+// a descriptor hipcc knows to be wave-uniform (an "s" operand of inline assembly must be: nothing legalises it afterwards)
+__device__ __forceinline__ osk::rsrc_t make_rsrc_uniform(const void *base, uint32_t bytes)
+{
+    const uint64_t p = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 __device__ __forceinline__ float agpr_get(float a)
 {
     float v;
@@ -409,9 +426,15 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
     }
 
+    // SEQOUT: lanes 0-31 / 32-63 write two 128-byte row segments of seq_out[t][unit][trajectory]; trajectories past the batch get
+    // an offset no descriptor covers
+    const uint32_t vo_seq0 = (wbase + li) < k.B ? (uint32_t)(wbase + li) * 4u + (uint32_t)(4 * lh) * rowB : 0x7ffffff0u;
+    const uint32_t vo_seq1 = (wbase + 32 + li) < k.B ? (uint32_t)(wbase + 32 + li) * 4u + (uint32_t)(4 * lh) * rowB : 0x7ffffff0u;
     OSF_TS_DECL
     for (int t = 0; t < k.T; t++) {
         OSF_TS(0)
+        const osk::rsrc_t rs_prev = make_rsrc_uniform(SEQOUT ? a.seq_out + (size_t)(t > 0 ? t - 1 : 0) * H * B : nullptr,
+                                                      (SEQOUT && t > 0) ? (uint32_t)H * rowB : 0u);
         // ================= Kalman step (lane = trajectory) =================
         // Order chosen for register pressure: everything that reads the step's 55 input registers runs first (measurement,
         // dynamics, the 48 raw-input features, which go straight to AGPRs); the covariance predict and the update then work
@@ -494,6 +517,14 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
                         for (int i = 0; i < NS; i++) buf_store_nt(ro, vst, i * rowB, OSF_X(i));
                     }
+                    if (SEQOUT && rb == 0 && c == 0 && q >= 12 && q < 12 + 32) {
+                        // layer 0's h_{t-1} -> seq_out[t-1] (deeper stacks), two stores per k-pair of this pass, straight from the
+                        // AGPRs: every hreg keeps step t-1's value until the cell update of pass (0, 1).  At t = 0 the descriptor
+                        // covers nothing; lanes past the batch use an offset no descriptor covers (no branch in the loop).
+                        const int i0 = 2 * (q - 12), srb = i0 >> 5, sc = (i0 >> 4) & 1, se = i0 & 15;      // elements i0, i0 + 1: se even
+                        buf_store_agpr2(rs_prev, srb ? vo_seq1 : vo_seq0, (uint32_t)(32 * sc + (se & 3) + 8 * (se >> 2)) * rowB, hreg[srb][sc][se],
+                                        (uint32_t)(32 * sc + ((se + 1) & 3) + 8 * ((se + 1) >> 2)) * rowB, hreg[srb][sc][se + 1]);
+                    }
                     if (rb == 1 && c == 1 && q == KPX) {
                         // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
                         const int tn = (t + 1 < k.T) ? t + 1 : t;
@@ -560,21 +591,15 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
             for (int e = 0; e < 16; e++) hreg[rb][0][e] = agpr_mov(park[e]);
         }
         OSF_TS(7)
-        if (SEQOUT) {
-            // layer-0 output sequence [T][64][B] for deeper stacks: lanes 0-31 / 32-63 write two 128-byte row segments
+    }
+    if (SEQOUT) {
+        // the last step's h
+        const osk::rsrc_t rs = make_rsrc_uniform(a.seq_out + (size_t)(k.T - 1) * H * B, (uint32_t)H * rowB);
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) {
-                const int tr = wbase + 32 * rb + li;
-                if (tr < k.B) {
-                    rsrc_t rs = make_rsrc(a.seq_out + (size_t)t * H * B, (uint32_t)H * rowB);
-                    const uint32_t vo = (uint32_t)tr * 4u + (uint32_t)(4 * lh) * rowB;
-#pragma unroll
-                    for (int c = 0; c < 2; c++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++)
-                            buf_store(rs, vo, (uint32_t)(32 * c + (e & 3) + 8 * (e >> 2)) * rowB, agpr_get(hreg[rb][c][e]));
-                }
-            }
+        for (int i = 0; i < 64; i += 2) {
+            const int srb = i >> 5, sc = (i >> 4) & 1, se = i & 15;
+            buf_store_agpr2(rs, srb ? vo_seq1 : vo_seq0, (uint32_t)(32 * sc + (se & 3) + 8 * (se >> 2)) * rowB, hreg[srb][sc][se],
+                            (uint32_t)(32 * sc + ((se + 1) & 3) + 8 * ((se + 1) >> 2)) * rowB, hreg[srb][sc][se + 1]);
         }
     }
 

@@ -250,6 +250,13 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
         OSL_TS(3)                                            // h half
 
         // ---- cell update on the accumulator layout: col = lane&31 (hidden unit), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        rsrc_t rs_r, rs_z, rs_n, rs_g, rs_h;
+        if (a.sv_r) {
+            const size_t so_t = (size_t)t * B * H;
+            const uint32_t sbytes = (uint32_t)a.B * (uint32_t)H * 4u;
+            rs_r = make_rsrc(a.sv_r + so_t, sbytes); rs_z = make_rsrc(a.sv_z + so_t, sbytes); rs_n = make_rsrc(a.sv_n + so_t, sbytes);
+            rs_g = make_rsrc(a.sv_g + so_t, sbytes); rs_h = make_rsrc(a.sv_h + so_t, sbytes);
+        }
         CellPair cp;
 #pragma unroll
         for (int rb = 0; rb < RBW; rb++) {
@@ -268,14 +275,13 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
                 const float r = cp.r[e & 1], z = cp.z[e & 1], n = cp.n[e & 1], ghn = cp.ghn[e & 1], hn = cp.hn[e & 1];
                 hn_buf[hidx] = hn;
                 if (a.sv_r) {
-                    const int g = tile_row0 + row;
-                    if (g < a.B) {
-                        const size_t o = ((size_t)t * B + g) * H + chunk * 32 + li;   // lanes 0-31: 128 contiguous bytes
-                        // write-once streams: non-temporal, so they do not evict the L2-resident weights
-                        __builtin_nontemporal_store(r, a.sv_r + o); __builtin_nontemporal_store(z, a.sv_z + o);
-                        __builtin_nontemporal_store(n, a.sv_n + o); __builtin_nontemporal_store(ghn, a.sv_g + o);
-                        __builtin_nontemporal_store(hn, a.sv_h + o);
-                    }
+                    // write-once streams (non-temporal: they must not evict the L2-resident weights) through the step's [B][H]
+                    // descriptors: one per-lane offset per row block, the element's row in a wave-uniform offset, rows past the batch
+                    // dropped by the range check (flat addresses cost two registers per store in flight: 21 spilled VGPRs)
+                    const uint32_t svo = (uint32_t)(((size_t)(tile_row0 + (row_blk0 + rb) * 32 + 4 * lh) * H + chunk * 32 + li) * 4);
+                    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)((e & 3) + 8 * (e >> 2)) * (uint32_t)H * 4u);
+                    osk::buf_store_nt(rs_r, svo, so, r); osk::buf_store_nt(rs_z, svo, so, z); osk::buf_store_nt(rs_n, svo, so, n);
+                    osk::buf_store_nt(rs_g, svo, so, ghn); osk::buf_store_nt(rs_h, svo, so, hn);
                 }
             }
         }
@@ -566,7 +572,9 @@ __device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need)
     return false;
 }
 
-template <int NCH, bool STACK>
+// SAVE: the training forward (r, z, n, gh_n, h_t saved row-major).  A template parameter since round 5: with the five output
+// streams' address arithmetic compiled in, the H = 64 inference instantiations spilled 82 VGPRs.
+template <int NCH, bool STACK, bool SAVE>
 __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const StackSync sy)
 {
     constexpr int PARTS = 8 / NCH;
@@ -662,6 +670,7 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
 #ifdef OS_LAYER_TS
     const unsigned long long ts_pro = __builtin_readcyclecounter() - ts_start;
 #endif
+    const uint32_t svoff = (uint32_t)(((size_t)(tile_row0 + 4 * lh) * H + chunk * 32 + li) * 4);      // saved activations: row 4 lh of the tile, this lane's unit
     OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
         OSL_TS(0)
@@ -702,6 +711,13 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
 #pragma unroll
                     for (int e = 0; e < 16; e++) acc[0][g][e] += src[(g * 16 + e) * 64 + lane];
             }
+            rsrc_t rs_r, rs_z, rs_n, rs_g, rs_h;
+            if (SAVE) {
+                const size_t so_t = (size_t)t * B * H;
+                const uint32_t sbytes = (uint32_t)a.B * (uint32_t)H * 4u;
+                rs_r = make_rsrc(a.sv_r + so_t, sbytes); rs_z = make_rsrc(a.sv_z + so_t, sbytes); rs_n = make_rsrc(a.sv_n + so_t, sbytes);
+                rs_g = make_rsrc(a.sv_g + so_t, sbytes); rs_h = make_rsrc(a.sv_h + so_t, sbytes);
+            }
             CellPair cp;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -713,14 +729,13 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
                                        (osk::f2){hl[hidx], hl[hidx + HS]}, nb_r, nb_z, nb_n, b_hn);
                 const float r = cp.r[e & 1], z = cp.z[e & 1], n = cp.n[e & 1], ghn = cp.ghn[e & 1], hn = cp.hn[e & 1];
                 hn_buf[hidx] = hn;
-                if (a.sv_r) {
-                    const int g = tile_row0 + row;
-                    if (g < a.B) {
-                        const size_t o = ((size_t)t * B + g) * H + chunk * 32 + li;
-                        __builtin_nontemporal_store(r, a.sv_r + o); __builtin_nontemporal_store(z, a.sv_z + o);
-                        __builtin_nontemporal_store(n, a.sv_n + o); __builtin_nontemporal_store(ghn, a.sv_g + o);
-                        __builtin_nontemporal_store(hn, a.sv_h + o);
-                    }
+                if (SAVE) {
+                    // one per-lane offset register for the 80 stores of a step, the element's row in a wave-uniform offset; rows
+                    // past the batch fall outside the step's [B][H] descriptor and are dropped by the range check (flat
+                    // addresses: two registers per store in flight -- the H = 64 instantiation spilled 82 VGPRs)
+                    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)((e & 3) + 8 * (e >> 2)) * (uint32_t)H * 4u);
+                    osk::buf_store_nt(rs_r, svoff, so, r); osk::buf_store_nt(rs_z, svoff, so, z); osk::buf_store_nt(rs_n, svoff, so, n);
+                    osk::buf_store_nt(rs_g, svoff, so, ghn); osk::buf_store_nt(rs_h, svoff, so, hn);
                 }
             }
         }
@@ -741,10 +756,10 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
     if (a.h_last) write_back(hT, a.h_last);
 }
 
-template <int NCH>
+template <int NCH, bool SAVE>
 __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
 {
-    split_layer_body<NCH, false>(a, StackSync{nullptr, nullptr});
+    split_layer_body<NCH, false, SAVE>(a, StackSync{nullptr, nullptr});
 }
 
 // Small batches, several layers: ONE launch, blockIdx.y = layer, the layers of a tile pipelined against each other (round 4).
@@ -759,12 +774,12 @@ struct StackArgs {
     uint32_t *flags;             // [n][tiles] progress counters, zeroed before the launch
     LayerArgs layer[8];
 };
-template <int NCH>
+template <int NCH, bool SAVE>
 __global__ __launch_bounds__(512, 1) void gru_stack_kernel(const StackArgs sa)
 {
     const int l = blockIdx.y;
     uint32_t *mine = sa.flags + (size_t)l * sa.tiles + blockIdx.x;
-    split_layer_body<NCH, true>(sa.layer[l], StackSync{l > 0 ? mine - sa.tiles : nullptr, mine});
+    split_layer_body<NCH, true, SAVE>(sa.layer[l], StackSync{l > 0 ? mine - sa.tiles : nullptr, mine});
 }
 
 // H = 128 small-batch variant with the INPUT half of the gate GEMM running ahead of the recurrence.
@@ -1524,17 +1539,24 @@ int os_gru_launch_stack(os_ctx *ctx, const LayerArgs *layers, int n, hipStream_t
         const size_t lds_l = split_lds_bytes(layers[l].K, H);
         lds_max = lds_l > lds_max ? lds_l : lds_max;
     }
+    if (NCH != 4 && NCH != 2 && NCH != 1) return os_fail(ctx, -4, "os_gru_launch_stack: hidden_size must be 128, 64 or 32");
+    bool save = layers[0].sv_r != nullptr;
+    for (int l = 1; l < n; l++)
+        if ((layers[l].sv_r != nullptr) != save) return os_fail(ctx, -4, "os_gru_launch_stack: every layer of a launch saves its activations or none does");
     if (!ctx->stack_attr_set) {
-        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_stack_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->stack_attr_set = true;
     }
     const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_stack_kernel");
     const dim3 grid(sa.tiles, sa.n), block(512);
-    if (NCH == 4) hipLaunchKernelGGL(gru_stack_kernel<4>, grid, block, lds_max, s, sa);
-    else if (NCH == 2) hipLaunchKernelGGL(gru_stack_kernel<2>, grid, block, lds_max, s, sa);
-    else hipLaunchKernelGGL(gru_stack_kernel<1>, grid, block, lds_max, s, sa);
+    if (NCH == 4) { if (save) hipLaunchKernelGGL((gru_stack_kernel<4, true>), grid, block, lds_max, s, sa); else hipLaunchKernelGGL((gru_stack_kernel<4, false>), grid, block, lds_max, s, sa); }
+    else if (NCH == 2) { if (save) hipLaunchKernelGGL((gru_stack_kernel<2, true>), grid, block, lds_max, s, sa); else hipLaunchKernelGGL((gru_stack_kernel<2, false>), grid, block, lds_max, s, sa); }
+    else { if (save) hipLaunchKernelGGL((gru_stack_kernel<1, true>), grid, block, lds_max, s, sa); else hipLaunchKernelGGL((gru_stack_kernel<1, false>), grid, block, lds_max, s, sa); }      // (H = 32, eight slices per chunk: outside the scratch-free contract)
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
@@ -1592,15 +1614,16 @@ int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
         const int parts = 8 / NCH;
         const size_t lds_s = ((size_t)2 * 32 * (H + 1) + (size_t)2 * 32 * (2 * a.KPx + 1) + (size_t)NCH * (parts - 1) * 64 * 64) * sizeof(float);
         if (!ctx->split_attr_set) {
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             ctx->split_attr_set = true;
         }
         const dim3 g32((a.B + 31) / 32), b512(512);
-        if (NCH == 4) hipLaunchKernelGGL(gru_layer_split_kernel<4>, g32, b512, lds_s, s, a);
-        else if (NCH == 2) hipLaunchKernelGGL(gru_layer_split_kernel<2>, g32, b512, lds_s, s, a);
-        else hipLaunchKernelGGL(gru_layer_split_kernel<1>, g32, b512, lds_s, s, a);
+        const bool save = a.sv_r != nullptr;
+        if (NCH == 4) { if (save) hipLaunchKernelGGL((gru_layer_split_kernel<4, true>), g32, b512, lds_s, s, a); else hipLaunchKernelGGL((gru_layer_split_kernel<4, false>), g32, b512, lds_s, s, a); }
+        else { if (save) hipLaunchKernelGGL((gru_layer_split_kernel<2, true>), g32, b512, lds_s, s, a); else hipLaunchKernelGGL((gru_layer_split_kernel<2, false>), g32, b512, lds_s, s, a); }
     } else if (RBW == 2) hipLaunchKernelGGL((gru_layer_kernel<2, 2>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gru_layer_kernel<1, 3>), grid, block, lds, s, a);
     os_prof_end(ctx, slot, s);

@@ -22,7 +22,7 @@ SCRATCH_FREE = {
     # BASELINE configs[2]: the headline kernel and its full-Q twin; GRU(60,64,L>1) writes layer 0's sequence (SEQOUT)
     "osf::fused_kf_gru_kernel_v2<true, false>": "fused KF+GRU headline (diagonal Q)",
     "osf::fused_kf_gru_kernel_v2<false, false>": "fused KF+GRU, full-matrix Q",
-    # PENDING "osf::fused_kf_gru_kernel_v2<true, true>": "fused KF+GRU(60,64,L>1): layer 0 with its sequence written",
+    "osf::fused_kf_gru_kernel_v2<true, true>": "fused KF+GRU(60,64,L>1): layer 0 with its sequence written",
     # BASELINE configs[1] and the KF-only large batch
     "osk::kf_run_sym_kernel<0, true, false>": "KF only, B = 65,536",
     "osk::kf_run_sym_kernel<0, true, true>": "KF only with p_rot",
@@ -32,13 +32,18 @@ SCRATCH_FREE = {
     "osg::gru_layer_stage_kernel<4>": "RNN(188,128,4) at the headline batch",
     "osg::gru_layer_stage_kernel<2>": "GRU(60,64,4) layers 1..3 at the headline batch",
     "osg::gru_layer_ahead_kernel": "training / windows forward, H = 128, one tile per CU",
-    "osg::gru_layer_split_kernel<4>": "H = 128 small batches",
-    # PENDING "osg::gru_layer_split_kernel<2>": "H = 64 small batches",
-    "osg::gru_stack_kernel<4>": "the reference's own windows (B = 1 / 64), H = 128",
-    # PENDING "osg::gru_stack_kernel<2>": "layer-pipelined stack, H = 64",
+    "osf::fused_kf_gru_kernel_v2<false, true>": "the same with a full-matrix Q",
+    "osg::gru_layer_split_kernel<4, false>": "H = 128 small batches",
+    "osg::gru_layer_split_kernel<4, true>": "H = 128 small batches, training forward",
+    "osg::gru_layer_split_kernel<2, false>": "H = 64 small batches",
+    "osg::gru_layer_split_kernel<2, true>": "H = 64 small batches, training forward",
+    "osg::gru_stack_kernel<4, false>": "the reference's own windows (B = 1 / 64), H = 128",
+    "osg::gru_stack_kernel<4, true>": "batch-64 training forward (gru/gru_train.py:36)",
+    "osg::gru_stack_kernel<2, false>": "layer-pipelined stack, H = 64",
+    "osg::gru_stack_kernel<2, true>": "layer-pipelined stack, H = 64, training forward",
     "osg::gru_vec_kernel<128>": "one window per call (gru/gru_test.py:157-177)",
     "osg::gru_vec_kernel<64>": "one window per call, H = 64",
-    # PENDING "osg::gru_layer_kernel<2, 2>": "H = 128 fallback when the stage kernel steps aside",
+    "osg::gru_layer_kernel<2, 2>": "H = 128 fallback when the stage kernel steps aside",
     # BASELINE configs[3]: the training step
     "ost::bwd_sweep_kernel<1, 8, 0>": "training backward sweep",
     # PENDING "ost::bwd_sweep_stack_kernel": "batch-64 training backward (gru/gru_train.py:36)",
