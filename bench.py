@@ -685,33 +685,48 @@ def bench_mpc(a, rk):
 
 
 def bench_windows(a, rk):
-    """The reference's OWN inference mode (gru/gru_test.py:138-140,174-191): every output timestep re-runs a window of 10
-    steps from h0 = 0 through RNN(188,128,4,24) -- here all windows of a batch at once (pipeline.predict_windows)."""
+    """The reference's OWN inference mode (gru/gru_test.py:138-140,174-191): every output timestep re-runs a window of 10 steps from
+    h0 = 0 through RNN(188,128,4,24).  Here all windows of one time-ordered ROW STREAM at once, without building the window tensor,
+    with the first layer's input projection computed once per row (os_gru_forward_windows, pipeline.predict_rows); --materialise
+    runs the round-4 form (unfold().contiguous() + os_gru_forward) for comparison."""
     import torch
     from optistate_amd import RNN
-    from optistate_amd.pipeline import predict_windows
+    from optistate_amd.pipeline import predict_windows, predict_rows
     dev = rk.dev
     N, T, I, H, L = a.batch, 10, 188, 128, 4
     torch.manual_seed(0)
     model = RNN(I, H, L, 24, dev).to(dev).eval()
     g = torch.Generator(device=dev); g.manual_seed(5 + rk.rank)
-    w = torch.rand(N, T, I, device=dev, generator=g)
+    rows = torch.rand(N + T - 1, I, device=dev, generator=g)          # N windows = N + T - 1 rows
     mn, mx = torch.zeros(12, device=dev), torch.ones(12, device=dev)
-    el, _, _ = timed_region(rk, a.warmup, a.steps, lambda: predict_windows(model, w, mn, mx))
-    kernels = events_pass(model._engine, max(2, min(a.steps, 5)), lambda: predict_windows(model, w, mn, mx))
+    if a.materialise:
+        w = rows.unfold(0, T, 1).permute(0, 2, 1).contiguous()
+        one = lambda: predict_windows(model, w, mn, mx)
+    else:
+        one = lambda: predict_rows(model, rows, T, mn, mx)
+    el, _, _ = timed_region(rk, a.warmup, a.steps, one)
+    kernels = events_pass(model._engine, max(2, min(a.steps, 5)), one)
     info = rk.report()
     if rk.rank == 0:
         out = base_line(a, rk, "sliding-window GRU outputs/sec (gru_test.py inference mode, window 10 from h0=0)", "windows/s",
                         N * rk.world * a.steps / el, el, "f32",
-                        {"workload": "RNN(188,128,4,24) on windows of 10, one output per window (gru/gru_test.py:138-191)",
-                         "windows_per_gpu": N, "seq_len": T, "gru_timesteps_per_output": T})
+                        {"workload": "RNN(188,128,4,24) on the sliding windows of 10 of one row stream, one output per window (gru/gru_test.py:138-191)",
+                         "windows_per_gpu": N, "rows_per_gpu": N + T - 1, "seq_len": T, "gru_timesteps_per_output": T,
+                         "form": "materialised windows (B, 10, 188) + os_gru_forward" if a.materialise else
+                                 "row stream (N + 9, 188) + os_gru_forward_windows: layer 0's x W_ih^T once per row"})
         dk = kernels.get("gru_layer")
         if dk:
-            fl = gru_flops_per_step(I, H, L) * N * T / dk["launches_per_step"]
-            ach = fl / (dk["ms_per_launch"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dk["kernel"] + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
-                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "traffic_source": "not collected for this mode",
-                               "avg_launch_ms": dk["ms_per_launch"]}
+            # algorithmic flops of THIS form: the stream form does layer 0's input half once per row instead of once per (window, step)
+            fl_full = gru_flops_per_step(I, H, L) * N * T
+            fl_in0 = 2 * 3 * H * I
+            fl = fl_full if a.materialise else fl_full - fl_in0 * N * T + fl_in0 * (N + T - 1)
+            ms_all = dk["ms_per_launch"] * dk["launches_per_step"]
+            ach = fl / (ms_all * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dk["kernel"] + " (v_mfma_f32_32x32x2_f32; all GRU launches of a pass: " + str(dk["launches_per_step"]) + ")",
+                               "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
+                               "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": dk["ms_per_launch"],
+                               "algorithmic_flops_per_pass": fl, "flops_of_the_materialised_form": fl_full,
+                               "note": "achieved = the form's own (reduced) flop count over the summed device time of its GRU launches"}
         out["kernels"] = kernels
         out.update(info)
         if a.cpu_seconds > 0 and rk.world == 1:
@@ -922,6 +937,8 @@ def main(argv=None):
                     help="opt-in gate GEMM on the bf16 MFMA with 3 (default) or 2 bf16 terms per fp32 operand (second line; never the headline)")
     ap.add_argument("--wave-per-trajectory", action="store_true",
                     help="--mode kf: one wavefront per trajectory with x and P in LDS (the north_star's literal layout; measurement only)")
+    ap.add_argument("--materialise", action="store_true",
+                    help="--mode windows: build the (B, 10, 188) window tensor and call os_gru_forward (the round-4 form) instead of the row-stream entry")
     ap.add_argument("--force-dist", action="store_true",
                     help="--mode train on ONE GPU with a one-rank RCCL process group: exercises (and prices) the split all-reduce path")
     ap.add_argument("--no-split-allreduce", action="store_true", help="--mode train: one all-reduce behind the whole backward")

@@ -75,9 +75,9 @@ def main(argv=None):
 
     # 3. evaluation on the first trajectory
     model.eval()
-    w0, l0 = pl.make_windows(pl.normalize(rows[0], mn, mx), pl.normalize(mocap[0], mn_v, mx_v), 10)
-    pred, above, below = pl.predict_windows(model, w0, mn_v, mx_v)
-    truth = pl.denormalize(l0, mn_v, mx_v)
+    # (the row stream itself: no window tensor, the first layer's input projection once per row -- os_gru_forward_windows)
+    pred, above, below = pl.predict_rows(model, pl.normalize(rows[0], mn, mx), 10, mn_v, mx_v)
+    truth = mocap[0][9:]                                         # window i <-> the label of row i + 9 (gru_train.py:186-192)
     mae = (pred - truth).abs().mean(dim=0)
     print("MAE per state:", np.round(mae.cpu().numpy(), 4))
     return losses, float(mae.mean().item())

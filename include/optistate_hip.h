@@ -210,6 +210,19 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
 /* Same with the input already in the library's stream layout xs [T][I][B]; h_last_soa (optional) [L][H][B]. */
 int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_soa, void *stream);
 
+/* Replaces the reference's inference loop over sliding windows (gru/gru_test.py:138-140 builds window i = rows i .. i + W - 1 of ONE
+ * time-ordered row stream, :155,174-191 evaluates them one by one from h0 = 0): rows [N][I] row-major -> out [N - W + 1][C], output
+ * i = RNN.forward(rows[i : i + W]).  The windows are never materialised (that tensor is W times the stream) and the input half of
+ * the first layer's gate GEMM, x W_ih^T, is computed once per ROW and shared by the W windows that contain it (17 % of the model's
+ * flops at RNN(188,128,4)).  hidden_size 128 or 64, input_size <= 192; returns -4 for other shapes (materialise + os_gru_forward). */
+int os_gru_forward_windows(os_ctx *ctx, int32_t n_rows, int32_t window, const float *rows, float *out, void *stream);
+
+/* The post-processing of the reference's evaluation loop (gru/gru_test.py:184-189,208-213) in one launch: out [B][2 n] = [prediction |
+ * error] (normalised) -> pred = p (max - min) + min, above = (p + e) (max - min) + min, below = (p - e) (max - min) + min, each
+ * [B][n]; min_v, max_v: device float[n] (the label scaling of gru/gru_train.py:59-62). */
+int os_gru_bands(os_ctx *ctx, int32_t B, int32_t n, const float *out, const float *min_v, const float *max_v, float *pred, float *above,
+                 float *below, void *stream);
+
 /* Fused path (single kernel where it applies, see OS_FUSED_TWO_KERNEL): KF loop + 60-feature row [x_post | accel | f | p_world | dp | imu]
  * (data_collection/data_conversion_Kalman_to_Training.py:245-254) + min-max normalisation
  * (gru/gru_test.py:99-101; minmax = device float[2][60]: mins then maxs) + optional latent [T][NL][B] appended

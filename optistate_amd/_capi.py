@@ -35,6 +35,7 @@ EXPORTS = [
     "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
     "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows", "os_gru_backward_mark",
+    "os_gru_forward_windows", "os_gru_bands",
 ]
 
 
@@ -99,6 +100,10 @@ def load():
     lib.os_gru_load_keyed.restype = C.c_int
     lib.os_gru_forward.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp]
     lib.os_gru_forward_soa.argtypes = [vp, i32, i32, f32p, f32p, f32p, vp]
+    lib.os_gru_forward_windows.argtypes = [vp, i32, i32, f32p, f32p, vp]
+    lib.os_gru_forward_windows.restype = C.c_int
+    lib.os_gru_bands.argtypes = [vp, i32, i32, f32p, f32p, f32p, f32p, f32p, f32p, vp]
+    lib.os_gru_bands.restype = C.c_int
     lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]
     lib.os_pack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
     lib.os_unpack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]

@@ -101,7 +101,7 @@ void os_destroy(os_ctx *ctx)
         if (sl.vec) (void)hipFree(sl.vec);
     }
     if (ctx->stack_flags) (void)hipFree(ctx->stack_flags);
-    float *bufs[] = {ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
+    float *bufs[] = {ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->gru_gi, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)

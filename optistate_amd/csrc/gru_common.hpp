@@ -17,6 +17,10 @@ struct LayerArgs {
     float *h_last;             // [H][B] or null
     // training only (null for inference): per-step activations saved row-major [T][B][H] for the backward sweep
     float *sv_r, *sv_z, *sv_n, *sv_g, *sv_h;   // r, z, n, gh_n (= W_hn h + b_hn), h_t
+    // window-stream inference (os_gru_forward_windows, first layer only; null otherwise): gi [gi_rows][3H] = rows . W_ih^T of the
+    // ROW stream, computed once per row; trajectory b of this launch is the window starting at row b, so its step t takes row b + t
+    const float *gi = nullptr;
+    int gi_rows = 0;
 };
 
 __host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }

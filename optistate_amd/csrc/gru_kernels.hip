@@ -17,6 +17,7 @@
 
 #include <math.h>
 
+#include <type_traits>
 #include "gru_common.hpp"
 #include "kf_device.hpp"   // buffer addressing helpers (make_rsrc / buf_load)
 
@@ -574,7 +575,11 @@ __device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need)
 
 // SAVE: the training forward (r, z, n, gh_n, h_t saved row-major).  A template parameter since round 5: with the five output
 // streams' address arithmetic compiled in, the H = 64 inference instantiations spilled 82 VGPRs.
-template <int NCH, bool STACK, bool SAVE>
+// GI (os_gru_forward_windows): the input half of the gate GEMM is not computed here -- the launch's trajectories are the sliding
+// windows of ONE row stream (window b = rows b .. b + T - 1, gru/gru_test.py:138-140), so x_t W_ih^T of a row is shared by the T
+// windows that contain it and comes precomputed (gru_gi_kernel) as a.gi; part 0 adds its tile (one step ahead, in registers)
+// to the recurrent half's accumulators.  a.K = a.KPx = 0 in that mode: no x tile, the whole k range is the recurrent half.
+template <int NCH, bool STACK, bool SAVE, bool GI = false>
 __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const StackSync sy)
 {
     constexpr int PARTS = 8 / NCH;
@@ -610,7 +615,7 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
     const int g0 = tile_row0 + li;
     const int growc = g0 < a.B ? g0 : a.B - 1;
     // this part's slice of the k-pair range: x k-pairs [xb, xe), h k-pairs [hb, he)
-    const int KPfull = a.KPx, total = KPfull + a.KPh;
+    const int KPfull = GI ? 0 : a.KPx, total = KPfull + a.KPh;      // (GI: no x part; the weight image still has one, a.KPx locates the h part)
     const int qb = (int)((long)total * part / PARTS), qe = (int)((long)total * (part + 1) / PARTS);
     const int xb = qb < KPfull ? qb : KPfull, xe = qe < KPfull ? qe : KPfull;
     const int hb = (qb > KPfull ? qb : KPfull) - KPfull, he = (qe > KPfull ? qe : KPfull) - KPfull;
@@ -641,8 +646,10 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
         }
     };
     __syncthreads();
-    xfetch(0);
-    xstage(xl2);
+    if (!GI) {
+        xfetch(0);
+        xstage(xl2);
+    }
     __syncthreads();
 
     auto write_back = [&](const float *hsrc, float *dst) {
@@ -671,6 +678,27 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
     const unsigned long long ts_pro = __builtin_readcyclecounter() - ts_start;
 #endif
     const uint32_t svoff = (uint32_t)(((size_t)(tile_row0 + 4 * lh) * H + chunk * 32 + li) * 4);      // saved activations: row 4 lh of the tile, this lane's unit
+    // GI: this lane's 48 entries of the gi tile of the step AFTER the one whose MFMAs are running (element e = window row
+    // (e & 3) + 8 (e >> 2) + 4 lh of the tile, gate g): 128-byte segments of gi[row][g H + unit]; rows past the stream read zero
+    // (PARTS == 2: each of a chunk's two waves owns eight of the sixteen elements -- see the exchange below -- and fetches those)
+    constexpr bool HALVES = PARTS == 2;
+    constexpr int NE = HALVES ? 8 : 16;
+    float gn[3][NE];
+    const rsrc_t rgi = make_rsrc(GI ? a.gi : nullptr, GI ? (uint32_t)a.gi_rows * 3u * (uint32_t)H * 4u : 0u);
+    uint32_t gvo = (uint32_t)(((size_t)(tile_row0 + 4 * lh) * 3 * H + chunk * 32 + li) * 4);
+    auto gfetch = [&](auto E0) {
+        constexpr int e0 = decltype(E0)::value;
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+            for (int i = 0; i < NE; i++)
+                gn[g][i] = buf_load(rgi, gvo, (uint32_t)((((e0 + i) & 3) + 8 * ((e0 + i) >> 2)) * 3 * H + g * H) * 4u);
+        gvo += 3u * (uint32_t)H * 4u;                   // the next step's rows are one row further down
+    };
+    if (GI) {
+        if (part == 0) gfetch(std::integral_constant<int, 0>{});
+        else if (HALVES) gfetch(std::integral_constant<int, 8>{});
+    }
     OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
         OSL_TS(0)
@@ -689,11 +717,28 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
         if (xe > xb)
             mfma_part<1, true, 8>(acc, wx + (size_t)xb * 3 * 64, xe - xb, lane, [&](int q, int) { return xl[li * XS + 2 * (q + xb) + lh]; });
         if (he > hb)
-            mfma_part<1, false, 8>(acc, wh + (size_t)hb * 3 * 64, he - hb, lane, [&](int q, int) { return hl[li * HS + 2 * (q + hb) + lh]; });
+            mfma_part<1, false, GI ? 4 : 8>(acc, wh + (size_t)hb * 3 * 64, he - hb, lane, [&](int q, int) { return hl[li * HS + 2 * (q + hb) + lh]; });      // (GI: 48 registers hold the next gi tile)
         OSL_TS(2)                                            // this wave's slice of the gate GEMM
         // x_{t+1}: requested behind the last weight fragment, lands underneath the exchange and the cell update
-        if (t + 1 < a.T) xfetch(t + 1);
-        if (part > 0) {
+        if (!GI && t + 1 < a.T) xfetch(t + 1);
+        // Exchange of the partial sums.  PARTS == 2 (H = 128): the two waves of a chunk SWAP halves -- part 0 hands elements 8..15 to
+        // part 1 and takes elements 0..7 from it -- and each does the cell update of its eight elements (rows 0-3, 8-11 / 16-19, 24-27
+        // of the tile, + 4 lh): the same 64 values cross LDS as before, but the cell update, which was a third of a step on ONE wave
+        // per SIMD while the other sat at the barrier, runs on both (round 5).  PARTS == 4 (H = 64): parts 1.. hand everything to part 0.
+        if (HALVES) {
+            float *dst = xch;
+            if (part == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 8; e < 16; e++) dst[(g * 16 + e) * 64 + lane] = acc[0][g][e];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) dst[(g * 16 + e) * 64 + lane] = acc[0][g][e];
+            }
+        } else if (part > 0) {
             float *dst = xch + (size_t)(part - 1) * 64 * 64;
 #pragma unroll
             for (int g = 0; g < 4; g++)
@@ -702,14 +747,16 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
         }
         lds_barrier();   // partial sums in place; every wave is done reading h_{t-1}'s A fragments
         OSL_TS(3)                                            // x request, partial sums -> LDS, barrier
-        if (part == 0) {
+        // sum of the partials + cell update of elements [e0, e0 + ne) on the calling wave
+        auto cell = [&](auto E0, auto NEL) {
+            constexpr int e0 = decltype(E0)::value, ne = decltype(NEL)::value;
 #pragma unroll
-            for (int p = 0; p < PARTS - 1; p++) {
+            for (int p = 0; p < (HALVES ? 1 : PARTS - 1); p++) {
                 const float *src = xch + (size_t)p * 64 * 64;
 #pragma unroll
                 for (int g = 0; g < 4; g++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) acc[0][g][e] += src[(g * 16 + e) * 64 + lane];
+                    for (int e = e0; e < e0 + ne; e++) acc[0][g][e] += src[(g * 16 + e) * 64 + lane];
             }
             rsrc_t rs_r, rs_z, rs_n, rs_g, rs_h;
             if (SAVE) {
@@ -718,9 +765,15 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
                 rs_r = make_rsrc(a.sv_r + so_t, sbytes); rs_z = make_rsrc(a.sv_z + so_t, sbytes); rs_n = make_rsrc(a.sv_n + so_t, sbytes);
                 rs_g = make_rsrc(a.sv_g + so_t, sbytes); rs_h = make_rsrc(a.sv_h + so_t, sbytes);
             }
+            if (GI) {
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+#pragma unroll
+                    for (int i = 0; i < ne; i++) acc[0][g][e0 + i] += gn[g][i];      // r, z, n_x: the input half, shared by T windows
+            }
             CellPair cp;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
+            for (int e = e0; e < e0 + ne; e++) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int hidx = row * HS + chunk * 32 + li;
                 if ((e & 1) == 0)                                    // element pairs (gru_cell_pair): e + 1 is the next row
@@ -738,9 +791,57 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
                     osk::buf_store_nt(rs_g, svoff, so, ghn); osk::buf_store_nt(rs_h, svoff, so, hn);
                 }
             }
+            // GI: the next step's tile, requested BEHIND the cell update (more live registers across it did not fit): it lands
+            // under the x-free barrier phase and the next step's MFMAs
+            if (GI && t + 1 < a.T) gfetch(E0);
+        };
+        if (HALVES) {
+            if (part == 0) cell(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+            else cell(std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{});
+        } else if (part == 0) {
+            // (PARTS == 4, H = 64: the round-4 form, textually: routed through the lambda above hipcc spills 12-20 registers here)
+#pragma unroll
+            for (int p = 0; p < PARTS - 1; p++) {
+                const float *src = xch + (size_t)p * 64 * 64;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[0][g][e] += src[(g * 16 + e) * 64 + lane];
+            }
+            rsrc_t rs_r, rs_z, rs_n, rs_g, rs_h;
+            if (SAVE) {
+                const size_t so_t = (size_t)t * B * H;
+                const uint32_t sbytes = (uint32_t)a.B * (uint32_t)H * 4u;
+                rs_r = make_rsrc(a.sv_r + so_t, sbytes); rs_z = make_rsrc(a.sv_z + so_t, sbytes); rs_n = make_rsrc(a.sv_n + so_t, sbytes);
+                rs_g = make_rsrc(a.sv_g + so_t, sbytes); rs_h = make_rsrc(a.sv_h + so_t, sbytes);
+            }
+            if (GI) {
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[0][g][e] += gn[g][e];
+            }
+            CellPair cp;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int hidx = row * HS + chunk * 32 + li;
+                if ((e & 1) == 0)
+                    cp = gru_cell_pair((osk::f2){acc[0][0][e], acc[0][0][e + 1]}, (osk::f2){acc[0][1][e], acc[0][1][e + 1]},
+                                       (osk::f2){acc[0][2][e], acc[0][2][e + 1]}, (osk::f2){acc[0][3][e], acc[0][3][e + 1]},
+                                       (osk::f2){hl[hidx], hl[hidx + HS]}, nb_r, nb_z, nb_n, b_hn);
+                const float r = cp.r[e & 1], z = cp.z[e & 1], n = cp.n[e & 1], ghn = cp.ghn[e & 1], hn = cp.hn[e & 1];
+                hn_buf[hidx] = hn;
+                if (SAVE) {
+                    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)((e & 3) + 8 * (e >> 2)) * (uint32_t)H * 4u);
+                    osk::buf_store_nt(rs_r, svoff, so, r); osk::buf_store_nt(rs_z, svoff, so, z); osk::buf_store_nt(rs_n, svoff, so, n);
+                    osk::buf_store_nt(rs_g, svoff, so, ghn); osk::buf_store_nt(rs_h, svoff, so, hn);
+                }
+            }
+            if (GI && t + 1 < a.T) gfetch(std::integral_constant<int, 0>{});
         }
         OSL_TS(4)                                            // part 0: sum of the partials, cell update, saved activations
-        if (t + 1 < a.T) xstage(xl2 + ((t + 1) & 1) * BM * XS);
+        if (!GI && t + 1 < a.T) xstage(xl2 + ((t + 1) & 1) * BM * XS);
         lds_barrier();   // h_t and x_{t+1} complete (and the exchange buffers free again)
         OSL_TS(5)                                            // x tile staged, barrier
         if (STACK && a.seq_out) publish(hn_buf, t);          // the next layer's workgroup of this tile may take step t now
@@ -756,10 +857,60 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
     if (a.h_last) write_back(hT, a.h_last);
 }
 
-template <int NCH, bool SAVE>
+template <int NCH, bool SAVE, bool GI = false>
 __global__ __launch_bounds__(512, 1) void gru_layer_split_kernel(const LayerArgs a)
 {
-    split_layer_body<NCH, false, SAVE>(a, StackSync{nullptr, nullptr});
+    split_layer_body<NCH, false, SAVE, GI>(a, StackSync{nullptr, nullptr});
+}
+
+// gi [N][3H] = rows [N][K] . W_ih^T for os_gru_forward_windows: the input half of layer 0's gate GEMM once per ROW of the stream
+// (the windowed form recomputes it for each of the T windows that contain the row: 144,384 of 832,512 flop per GRU step at
+// RNN(188,128,4), gru/gru_test.py:138-140).  Workgroup = 64 rows x all 3H columns: wave c = the 32 hidden units of chunk c for
+// the three gates, two 32-row blocks; the row tile staged once in LDS (coalesced), A fragments by ds_read (odd pitch), the packed
+// x-part fragments of the layer-0 image as in the layer kernels.  No bias here: the cell update folds the biases in.
+struct GiArgs {
+    int N, K, H, KPx, KPh;
+    const float *rows;         // [N][K] row-major (the caller's row stream)
+    const float *w;            // packed layer-0 weights (chunk-major, x part first)
+    float *gi;                 // [N][3H]
+};
+// RBW = 32-row blocks per workgroup: 2 when that still gives every CU two workgroups, else 1 (8,201 rows: 257 workgroups, not 129)
+template <int RBW>
+__global__ __launch_bounds__(256, 2) void gru_gi_kernel(const GiArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [32 RBW][XS]
+    constexpr int BM = 32 * RBW;
+    const int lane = threadIdx.x & 63, chunk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NCH = a.H / 32;
+    const int li = lane & 31, lh = lane >> 5;
+    const int XS = 2 * a.KPx + 1, row0 = blockIdx.x * BM;
+    // stage: wave w takes rows w, w + 4, ...; its 64 lanes walk a row (K floats apart: consecutive lanes, consecutive addresses)
+    for (int r = chunk; r < BM; r += 4) {
+        const int g = row0 + r;
+        const float *src = a.rows + (size_t)(g < a.N ? g : a.N - 1) * a.K;
+        for (int k = lane; k < XS; k += 64) smem[r * XS + k] = (k < a.K && g < a.N) ? src[k] : 0.f;
+    }
+    __syncthreads();
+    for (int c = chunk; c < NCH; c += 4) {
+        f32x16 acc[RBW][4];
+#pragma unroll
+        for (int rb = 0; rb < RBW; rb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
+        const float *wx = a.w + (size_t)c * chunk_floats(a.KPx, a.KPh);
+        mfma_part<RBW, true>(acc, wx, a.KPx, lane, [&](int q, int rb) { return smem[(rb * 32 + li) * XS + 2 * q + lh]; });
+        const rsrc_t ro = make_rsrc(a.gi, (uint32_t)a.N * 3u * (uint32_t)a.H * 4u);       // rows past N fall outside: dropped
+#pragma unroll
+        for (int rb = 0; rb < RBW; rb++) {
+            const uint32_t vo = (uint32_t)(((size_t)(row0 + rb * 32 + 4 * lh) * 3 * a.H + c * 32 + li) * 4);
+#pragma unroll
+            for (int g = 0; g < 3; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    osk::buf_store(ro, vo, (uint32_t)(((e & 3) + 8 * (e >> 2)) * 3 * a.H + g * a.H) * 4u, acc[rb][g][e]);
+        }
+    }
 }
 
 // Small batches, several layers: ONE launch, blockIdx.y = layer, the layers of a tile pipelined against each other (round 4).
@@ -1466,6 +1617,20 @@ int os_gru_load(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, void *st
 }  // extern "C"
 
 // fc + sigmoid head on an SoA hidden state top [H][B]; fcw points at fc.weight followed by fc.bias.
+// De-normalised prediction and error bands of gru/gru_test.py:184-189,208-213 in one pass: out [B][2 n] = [prediction (n) | error (n)]
+// -> pred = p (max - min) + min, above = (p + e) (max - min) + min, below = (p - e) (max - min) + min, each [B][n].
+__global__ void gru_bands_kernel(int B, int n, const float *__restrict__ out, const float *__restrict__ mn, const float *__restrict__ mx,
+                                 float *__restrict__ pred, float *__restrict__ above, float *__restrict__ below)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n) return;
+    const int b = i / n, j = i - b * n;
+    const float p = out[(size_t)b * 2 * n + j], e = out[(size_t)b * 2 * n + n + j], lo = mn[j], sc = mx[j] - mn[j];
+    pred[i] = p * sc + lo;
+    above[i] = (p + e) * sc + lo;
+    below[i] = (p - e) * sc + lo;
+}
+
 int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s)
 {
     const os_gru_dims &d = ctx->gru;
@@ -1754,6 +1919,78 @@ static int gru_vec_launch(os_ctx *ctx, int B, int T, const float *x, float *out,
     if (H == 128) hipLaunchKernelGGL(gru_vec_kernel<128>, dim3(1), dim3(VEC_THREADS), lds, s, a);
     else hipLaunchKernelGGL(gru_vec_kernel<64>, dim3(1), dim3(VEC_THREADS), lds, s, a);
     os_prof_end(ctx, slot_p, s);
+    OS_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// gru/gru_test.py:138-140,174-191: the reference builds overlapping windows from ONE row stream (window i = rows i .. i + W - 1) and
+// evaluates them one by one.  Here all N - W + 1 windows run as one batch WITHOUT being materialised (the windowed tensor is W
+// times the stream) and the input half of layer 0's gate GEMM is computed once per ROW (gru_gi_kernel) instead of once per
+// (window, step): rows [N][I] row-major on the device -> out [N - W + 1][C].
+int os_gru_forward_windows(os_ctx *ctx, int32_t N, int32_t W, const float *rows, float *out, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward_windows: call os_gru_load first");
+    if (N <= 0 || W <= 0 || W > N || !rows || !out) return os_fail(ctx, -2, "os_gru_forward_windows: bad argument (1 <= window <= rows)");
+    const os_gru_dims &d = ctx->gru;
+    const int I = d.input_size, H = d.hidden_size, L = d.num_layers, NCH = H / 32, B = N - W + 1, T = W;
+    if ((H != 128 && H != 64) || I > 192 || split_lds_bytes(I, H) > 160 * 1024)
+        return os_fail(ctx, -4, "os_gru_forward_windows: hidden_size 128 or 64 and input_size <= 192 (materialise the windows and call os_gru_forward otherwise)");
+    if ((size_t)N * 3 * H * 4 >= ((size_t)1 << 32) || (size_t)T * B * H * 4 >= ((size_t)1 << 31))
+        return os_fail(ctx, -2, "os_gru_forward_windows: stream too long for 32-bit buffer offsets");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (os_ensure_scratch(ctx, &ctx->gru_gi, &ctx->gru_gi_floats, (size_t)N * 3 * H)) return -10;
+    float *seqbuf[2], *hlast;
+    if (os_gru_scratch(ctx, B, T, &seqbuf[0], &seqbuf[1], &hlast)) return -10;
+    // ---- gi = rows . W_ih(layer 0)^T, once per row ----
+    GiArgs g;
+    g.N = N; g.K = I; g.H = H; g.KPx = (I + 1) / 2; g.KPh = H / 2; g.rows = rows; g.w = ctx->gru_packed; g.gi = ctx->gru_gi;
+    {
+        const int rbw = (N + 63) / 64 >= 2 * ctx->cu_count ? 2 : 1;
+        const size_t lds_g = (size_t)32 * rbw * (2 * g.KPx + 1) * sizeof(float);
+        const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_gi_kernel");
+        if (rbw == 2) hipLaunchKernelGGL(gru_gi_kernel<2>, dim3((N + 63) / 64), dim3(256), lds_g, s, g);
+        else hipLaunchKernelGGL(gru_gi_kernel<1>, dim3((N + 31) / 32), dim3(256), lds_g, s, g);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+    }
+    // ---- layer 0 on the windows: recurrent half + gi tile ----
+    LayerArgs a;
+    a.B = B; a.T = T; a.K = I; a.H = H; a.KPx = (I + 1) / 2; a.KPh = H / 2;
+    a.xs = nullptr; a.xs_btf = 0; a.w = ctx->gru_packed;
+    a.seq_out = L > 1 ? seqbuf[0] : nullptr;
+    a.h_last = L == 1 ? hlast : nullptr;
+    a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
+    a.gi = ctx->gru_gi; a.gi_rows = N;
+    {
+        const size_t lds_s = split_lds_bytes(I, H);
+        if (!ctx->gi_attr_set) {
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_split_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->gi_attr_set = true;
+        }
+        const int slot = os_prof_begin(ctx, OS_PHASE_GRU_LAYER, s, "gru_layer_split_kernel<GI>");
+        const dim3 g32((B + 31) / 32), b512(512);
+        if (NCH == 4) hipLaunchKernelGGL((gru_layer_split_kernel<4, false, true>), g32, b512, lds_s, s, a);
+        else hipLaunchKernelGGL((gru_layer_split_kernel<2, false, true>), g32, b512, lds_s, s, a);
+        os_prof_end(ctx, slot, s);
+        OS_HIP(ctx, hipGetLastError());
+    }
+    if (L == 1) {
+        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
+        return os_gru_head_launch(ctx, B, hlast, fcw, out, s);
+    }
+    return gru_layers(ctx, B, T, seqbuf[0], 0, 1, out, nullptr, s);
+}
+
+int os_gru_bands(os_ctx *ctx, int32_t B, int32_t n, const float *out, const float *min_v, const float *max_v, float *pred, float *above,
+                 float *below, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (B <= 0 || n <= 0 || !out || !min_v || !max_v || !pred || !above || !below) return os_fail(ctx, -2, "os_gru_bands: bad argument");
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(gru_bands_kernel, dim3((B * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n, out, min_v, max_v, pred, above, below);
     OS_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
             double K[NM], rrow[NM];
 #pragma unroll
             for (int q = 0; q < NM; q++) rrow[q] = rrow_b[q];
-            status |= update_batch_row(xd, P, z, rrow, K);
-            if (AUX && a.kgain_out) kgain = kgain_rows(K, one);
+            if (AUX) status |= update_batch_row<true>(xd, P, z, rrow, K, one, &kgain);
+            else status |= update_batch_row(xd, P, z, rrow, K);
         }
         xr = (float)xd;
         if (!(xr * 0.f == 0.f)) status |= 2;

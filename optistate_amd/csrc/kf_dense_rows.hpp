@@ -132,10 +132,21 @@ __device__ __forceinline__ int update_seq_row(double &xd, double *P, const float
     return status;
 }
 
+// np.trace of the 12 x 10 gain (kalman_filter.py:174): K[a][a], a < 10, from the lanes' rows of K
+__device__ __forceinline__ float kgain_rows(const double (&K)[NM], double one)
+{
+    double t = 0.0;
+    asm volatile("s_nop 1\n" OSD_F(0, 1, 11, 0) OSD_F(0, 2, 11, 1) OSD_F(0, 3, 11, 2) OSD_F(0, 4, 11, 3) OSD_F(0, 5, 11, 4) OSD_F(0, 6, 11, 5)
+                 OSD_F(0, 7, 11, 6) OSD_F(0, 8, 11, 7) OSD_F(0, 9, 11, 8) OSD_F(0, 10, 11, 9)
+                 : "+v"(t) : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "v"(K[8]), "v"(K[9]), "v"(one));
+    return (float)t;
+}
 // ---- batch update as the reference writes it: S = H P H^T + R, K = P H^T S^-1, x += K y, P -= K H P ----
 // The lane of state row SEL[a] also owns measurement a: row a of the Cholesky factor L (entries q <= a) lives in ITS registers
 // L[0..9]; rrow: that lane's row of R.  K[0..9]: this lane's row of the 12 x 10 gain.
-__device__ __forceinline__ int update_batch_row(double &xd, double *P, const float *z, const double *rrow, double *K)
+template <bool WANT_KGAIN = false>
+__device__ __forceinline__ int update_batch_row(double &xd, double *P, const float *z, const double *rrow, double (&K)[NM], double one = 1.0,
+                                                float *kgain = nullptr)
 {
     int status = 0;
     double L[NM], dinv[NM];
@@ -202,6 +213,7 @@ __device__ __forceinline__ int update_batch_row(double &xd, double *P, const flo
         dx = fma(K[a], (double)z[a] - bc64<sa>(xd), dx);
     });
     xd += dx;
+    if (WANT_KGAIN) *kgain = kgain_rows(K, one);       // here: K is live until the covariance update anyway
     // P[i][j] -= sum_a K[i][a] P[SEL[a]][j], column by column: within column j only the registers P[j] are read (from the
     // lanes of the selected rows) and they are written after all ten reads -- the OLD rows, as (I - K H) P needs
 #pragma unroll
@@ -281,15 +293,6 @@ __device__ __forceinline__ float ptrace_rows(const double (&P)[NS], double one)
                  OSD_F(0, 7, 13, 6) OSD_F(0, 8, 13, 7) OSD_F(0, 9, 13, 8) OSD_F(0, 10, 13, 9) OSD_F(0, 11, 13, 10) OSD_F(0, 12, 13, 11)
                  : "+v"(t) : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]), "v"(P[7]), "v"(P[8]), "v"(P[9]),
                    "v"(P[10]), "v"(P[11]), "v"(one));
-    return (float)t;
-}
-// np.trace of the 12 x 10 gain (kalman_filter.py:174): K[a][a], a < 10, from the lanes' rows of K
-__device__ __forceinline__ float kgain_rows(const double (&K)[NM], double one)
-{
-    double t = 0.0;
-    asm volatile("s_nop 1\n" OSD_F(0, 1, 11, 0) OSD_F(0, 2, 11, 1) OSD_F(0, 3, 11, 2) OSD_F(0, 4, 11, 3) OSD_F(0, 5, 11, 4) OSD_F(0, 6, 11, 5)
-                 OSD_F(0, 7, 11, 6) OSD_F(0, 8, 11, 7) OSD_F(0, 9, 11, 8) OSD_F(0, 10, 11, 9)
-                 : "+v"(t) : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "v"(K[8]), "v"(K[9]), "v"(one));
     return (float)t;
 }
 // the same from the posterior of the sequential form (diagonal R): K = P+ H^T R^-1, trace = sum_a P+[a][SEL[a]] / R[a][a]

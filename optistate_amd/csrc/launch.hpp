@@ -58,6 +58,8 @@ struct os_ctx {
     float *gru_seq;  size_t gru_seq_floats;   // inter-layer sequences [T][H][B] x2 + h_last
     float *gru_xs;   size_t gru_xs_floats;    // SoA copy of a (B,T,I) input
     float *gru_hl;   size_t gru_hl_floats;    // SoA h_last of all layers
+    float *gru_gi;   size_t gru_gi_floats;    // os_gru_forward_windows: rows . W_ih^T of the row stream [N][3H]
+    bool gi_attr_set;
     float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *fused_img;                         // fused v2: per-call LDS image (weights with folded scales, k order of the register-resident h)
     int tune_fused_v1;                        // OS_FUSED_V1=1: the round-1 kernel (h in LDS) instead of v2

@@ -847,7 +847,8 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
         double xd = (double)xn, K[NM], rrow[NM];
 #pragma unroll
         for (int q = 0; q < NM; q++) rrow[q] = rrow_l[q];
-        status |= rw::update_batch_row(xd, P, z, rrow, K);
+        float kg = 0.f;
+        status |= rw::update_batch_row<true>(xd, P, z, rrow, K, one, &kg);
         xr = (float)xd;
         if (!(xr * 0.f == 0.f)) status |= 2;
         if (lane < 12) a.kf.x_out[((size_t)t * 12 + lane) * B + b] = xr;
@@ -859,10 +860,7 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
             const float tr = rw::ptrace_rows(P, one);
             if (lane == 0) a.kf.ptrace_out[(size_t)t * B + b] = tr;
         }
-        if (a.kf.kgain_out) {
-            const float kg = rw::kgain_rows(K, one);
-            if (lane == 0) a.kf.kgain_out[(size_t)t * B + b] = kg;
-        }
+        if (a.kf.kgain_out && lane == 0) a.kf.kgain_out[(size_t)t * B + b] = kg;
     }
     // the status word is OR-reduced over the wavefront (bit 1 is per state component)
     for (int m = 1; m < 64; m <<= 1) status |= __shfl_xor(status, m, 64);

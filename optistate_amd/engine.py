@@ -243,6 +243,40 @@ class Engine:
         self._check(self.lib.os_gru_forward(self._h, B, T, _ptr(x), _ptr(out), _ptr(hl), self._stream()), "os_gru_forward")
         return (out, hl) if want_h_last else out
 
+    def gru_forward_windows(self, rows_ni, window):
+        """The reference's inference mode without materialised windows (gru/gru_test.py:138-140,174-191): rows (N, I), one
+        time-ordered row stream -> (N - window + 1, C), output i = RNN.forward(rows[i : i + window]).  The input half of the first
+        layer's gate GEMM is computed once per row and shared by the `window` windows that contain it (os_gru_forward_windows).
+        hidden_size 128 / 64 and input_size <= 192; other shapes raise (materialise the windows and call gru_forward)."""
+        rows = rows_ni.to(self.device, dtype=torch.float32).contiguous()
+        N, I = rows.shape
+        d = self._gru_dims
+        if d is None or I != d.input_size:
+            raise ValueError("load_gru first / input width mismatch")
+        if not 1 <= window <= N:
+            raise ValueError("1 <= window <= number of rows")
+        out = torch.empty((N - window + 1, d.num_classes), dtype=torch.float32, device=self.device)
+        self._check(self.lib.os_gru_forward_windows(self._h, N, int(window), _ptr(rows), _ptr(out), self._stream()), "os_gru_forward_windows")
+        return out
+
+    def gru_bands(self, out, min_v, max_v):
+        """(pred, band_above, band_below), de-normalised, from the model's output [B][2 n] = [prediction | error] (gru/gru_test.py:
+        184-189,208-213) in one launch (os_gru_bands)."""
+        out = out.to(self.device, dtype=torch.float32).contiguous()
+        B, C2 = out.shape
+        n = C2 // 2
+        mn = min_v.to(self.device, dtype=torch.float32).contiguous(); mx = max_v.to(self.device, dtype=torch.float32).contiguous()
+        if C2 != 2 * n or mn.numel() != n or mx.numel() != n:
+            raise ValueError("out must be [B][2 n] and min_v / max_v [n]")
+        pred, above, below = (torch.empty((B, n), dtype=torch.float32, device=self.device) for _ in range(3))
+        self._check(self.lib.os_gru_bands(self._h, B, n, _ptr(out), _ptr(mn), _ptr(mx), _ptr(pred), _ptr(above), _ptr(below), self._stream()),
+                    "os_gru_bands")
+        return pred, above, below
+
+    def gru_windows_supported(self):
+        d = self._gru_dims
+        return d is not None and d.hidden_size in (64, 128) and d.input_size <= 192
+
     def gru_forward_soa(self, xs_tib):
         T, I, B = xs_tib.shape
         d = self._gru_dims

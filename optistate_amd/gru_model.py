@@ -54,3 +54,15 @@ class RNN(nn.Module):
             return gru_forward_autograd(self, x)
         self._sync_weights(x.device)
         return self._engine.gru_forward(x)
+
+    def forward_windows(self, rows, window):
+        """All sliding windows of ONE time-ordered row stream at once: rows (N, input_size) -> (N - window + 1, num_classes), output i
+        = forward(rows[i : i + window][None]) -- the reference's evaluation loop (gru/gru_test.py:138-140 builds the windows,
+        :174-191 runs them one by one) without materialising the windows and with the first layer's input projection computed once
+        per row (os_gru_forward_windows).  Inference only; shapes the kernel does not take fall back to materialised windows."""
+        if not rows.is_cuda:
+            raise RuntimeError("optistate_amd.RNN.forward_windows needs a tensor on the MI355X (no CPU fallback)")
+        self._sync_weights(rows.device)
+        if self._engine.gru_windows_supported():
+            return self._engine.gru_forward_windows(rows, window)
+        return self._engine.gru_forward(rows.unfold(0, window, 1).permute(0, 2, 1).contiguous())

@@ -105,10 +105,18 @@ def make_windows(rows_norm, labels_norm, seq_len):
     return w, labels_norm[seq_len - 1:]
 
 
+def predict_rows(model, rows_norm, seq_len, min_v, max_v):
+    """predict_windows for the row stream itself: rows_norm [N][F] (one trajectory, time-ordered, normalised) -> the de-normalised
+    (pred, band_above, band_below), each [N - seq_len + 1][12]; entry i belongs to window rows i .. i + seq_len - 1, i.e. to the
+    label of row i + seq_len - 1 (gru_test.py:138-140,174-213).  No window tensor is built (RNN.forward_windows)."""
+    with torch.no_grad():
+        out = model.forward_windows(rows_norm, seq_len)
+    return model._engine.gru_bands(out, min_v, max_v)
+
+
 def predict_windows(model, windows, min_v, max_v):
     """The inference loop of gru_test.py:174-213 for all windows at once: returns de-normalised (pred [N][12],
     band_above [N][12], band_below [N][12])."""
     with torch.no_grad():
         out = model(windows)
-    pred, err = out[:, 0:12], out[:, 12:24]
-    return (denormalize(pred, min_v, max_v), denormalize(pred + err, min_v, max_v), denormalize(pred - err, min_v, max_v))
+    return model._engine.gru_bands(out, min_v, max_v)

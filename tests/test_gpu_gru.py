@@ -392,3 +392,47 @@ def test_small_batch_dispatch_boundaries(B, T, expect):
     pick = np.unique(np.r_[0:min(B, 40), max(B - 40, 0):B])
     ref, _, _ = orc.gru_forward(x.numpy()[pick], orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
     assert np.abs(out[pick] - ref).max() < GRU_TOL
+
+
+@pytest.mark.parametrize("I,H,L,N,W", [(188, 128, 4, 8201, 10), (188, 128, 4, 4059, 10), (60, 64, 1, 300, 10), (60, 64, 3, 75, 7),
+                                        (61, 128, 2, 40, 40), (188, 128, 4, 10, 10), (188, 128, 1, 33, 1)])
+def test_window_stream_forward_equals_materialised_windows(I, H, L, N, W):
+    """os_gru_forward_windows (gru/gru_test.py:138-140,174-191 without the window tensor; layer 0's x W_ih^T once per row) against
+    the same model on the materialised windows (1e-6: the input half is summed in another order) and against the float64 oracle on
+    a sample of windows; the reference's real shape at the bench size and at its own data-set size (~4,050 windows: the stack
+    path behind the first layer), H = 64, an odd input width, one window covering the whole stream, window = 1."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from oracle import c_oracle as orc
+    C = 24
+    torch.manual_seed(41)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    rows = (torch.rand(N, I) * 2 - 1).cuda()
+    eng = Engine(0)
+    eng.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    out = eng.gru_forward_windows(rows, W)
+    assert out.shape == (N - W + 1, C)
+    assert eng.kernel_name("gru_layer") in ("gru_layer_split_kernel<GI>", "gru_layer_ahead_kernel", "gru_stack_kernel", "gru_layer_split_kernel",
+                                            "gru_layer_kernel<2,2>", "gru_layer_kernel<1,3>", "gru_vec_kernel", "gru_layer_stage_kernel")
+    win = rows.unfold(0, W, 1).permute(0, 2, 1).contiguous()
+    ref_gpu = eng.gru_forward(win)
+    assert (out - ref_gpu).abs().max().item() < 1e-6
+    pick = np.unique(np.concatenate([np.arange(0, min(48, N - W + 1)), np.arange(max(0, N - W + 1 - 48), N - W + 1)]))
+    ref, _, _ = orc.gru_forward(win[pick].cpu().numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+    assert np.abs(out[pick].cpu().numpy() - ref).max() < GRU_TOL
+
+
+def test_window_stream_through_the_module_and_pipeline_g5():
+    """RNN.forward_windows / pipeline.predict_rows on the reference-generated G5 weights: every window's output equals the module's
+    own forward on that window (the reference's one-window call, gru_test.py:174-191)."""
+    from optistate_amd import RNN
+    from optistate_amd import pipeline as pl
+    torch.manual_seed(1)
+    m = RNN(188, 128, 4, 24, torch.device("cuda")).to("cuda").eval()
+    rows = torch.rand(57, 188, device="cuda")
+    with torch.no_grad():
+        out = m.forward_windows(rows, 10)
+        one_by_one = torch.cat([m(rows[i:i + 10][None]) for i in range(48)])
+    assert (out - one_by_one).abs().max().item() < 1e-6
+    mn, mx = torch.zeros(12, device="cuda") - 2.0, torch.zeros(12, device="cuda") + 3.0
+    pred, above, below = pl.predict_rows(m, rows, 10, mn, mx)
+    assert torch.allclose(pred, out[:, :12] * 5.0 - 2.0, atol=1e-6) and torch.allclose(above - pred, out[:, 12:] * 5.0, atol=1e-5)

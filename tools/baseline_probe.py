@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from optistate_amd import Engine, RNN, flatten_state_dict  # noqa: E402
 from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT  # noqa: E402
 

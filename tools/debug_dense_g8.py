@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from optistate_amd import Engine
 from oracle import c_oracle as orc
 np.set_printoptions(linewidth=200, precision=3)

@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from optistate_amd import Engine
 from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED, Q_DEFAULT, R_DEFAULT
 from oracle import c_oracle as orc
