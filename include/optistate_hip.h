@@ -13,7 +13,7 @@
  *     is marked "host".  The caller owns all buffers; the library allocates only context scratch.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
  *     stream-ordered and asynchronous; no call synchronises the device.
- *   - Return value: 0 ok, <0 error (os_last_error() gives text).  Per-trajectory numerical
+ *   - Return value: 0 ok, <0 error (os_last_error() gives text); -20 = a layer-pipelined launch lost a producer (os_gru_set_stack).  Per-trajectory numerical
  *     status is reported in `status[B]`: bit0 = innovation covariance S not positive definite /
  *     non-finite, bit1 = non-finite state (the reference raises LinAlgError /
  *     propagates NaN: kalman_filter/kalman_filter.py:168), bit2 = QP iteration cap (os_kf_mpc_run),
@@ -216,6 +216,15 @@ int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float
  * the first layer's gate GEMM, x W_ih^T, is computed once per ROW and shared by the W windows that contain it (17 % of the model's
  * flops at RNN(188,128,4)).  hidden_size 128 or 64, input_size <= 192; returns -4 for other shapes (materialise + os_gru_forward). */
 int os_gru_forward_windows(os_ctx *ctx, int32_t n_rows, int32_t window, const float *rows, float *out, void *stream);
+
+/* Small batches run their layer stack as ONE launch whose layers hand each other time steps through progress counters
+ * (gru_stack_kernel, bwd_sweep_stack_kernel).  Every wait in there is bounded; a consumer whose wait expires sets the context's error
+ * word, stops waiting and poisons its input with NaN.  mode 1 (default; OS_GRU_STACK): a call that made such a launch waits for it and
+ * returns -20 when the word is set (os_last_error says which kernel): re-run that call after os_gru_set_stack(ctx, 0).  mode 2: the
+ * launch stays asynchronous; the word is reported (-20) by the NEXT os_gru_forward* / os_gru_backward* / os_adam_step call that finds
+ * it, and os_adam_step's kernel skips its update while it is set (the model is never stepped on poisoned gradients).
+ * mode 0: a launch per layer, no progress counters. */
+int os_gru_set_stack(os_ctx *ctx, int32_t mode);
 
 /* The post-processing of the reference's evaluation loop (gru/gru_test.py:184-189,208-213) in one launch: out [B][2 n] = [prediction |
  * error] (normalised) -> pred = p (max - min) + min, above = (p + e) (max - min) + min, below = (p - e) (max - min) + min, each

@@ -53,6 +53,10 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_GRU_STAGE"); c->tune_gru_stage = e ? atoi(e) : 1;
         e = getenv("OS_GRU_STACK"); c->tune_gru_stack = e ? atoi(e) : 1;
         e = getenv("OS_GRU_VEC"); c->tune_gru_vec = e ? atoi(e) : 1;
+        e = getenv("OS_STACK_DBG_POLLS"); c->stack_max_polls = e && atoi(e) > 0 ? (uint32_t)atoi(e) : (1u << 22);
+        c->stack_dbg_drop_layer = c->stack_dbg_drop_step = -1;
+        e = getenv("OS_STACK_DBG_DROP");
+        if (e) (void)sscanf(e, "%d,%d", &c->stack_dbg_drop_layer, &c->stack_dbg_drop_step);
         e = getenv("OS_MPC_PERSISTENT"); c->tune_mpc_persistent = e ? atoi(e) : 1;
         e = getenv("OS_VIT_MLP_FUSED"); c->tune_vit_mlp_fused = e ? atoi(e) : 3;
         // rows per weight-gradient slice; unset (0) = about 32 slices, between one 32-row tile and 512 rows (gru_train_kernels.hip)
@@ -75,8 +79,20 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         free(c);
         return -10;
     }
+    if (hipHostMalloc((void **)&c->stack_err_host, sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->stack_err_dev, c->stack_err_host, 0) != hipSuccess) {
+        (void)hipFree(c->kf_qr);
+        free(c);
+        return -10;
+    }
+    *c->stack_err_host = 0;
+    if (hipMalloc((void **)&c->stack_err_local, sizeof(int32_t)) != hipSuccess || hipMemset(c->stack_err_local, 0, sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(c->kf_qr); (void)hipHostFree(c->stack_err_host);
+        free(c);
+        return -10;
+    }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { (void)hipFree(c->kf_qr); free(c); return -10; }
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { (void)hipFree(c->kf_qr); (void)hipHostFree(c->stack_err_host); free(c); return -10; }
     c->cu_count = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         // built for gfx950 only; refuse to pretend on anything else
@@ -101,6 +117,8 @@ void os_destroy(os_ctx *ctx)
         if (sl.vec) (void)hipFree(sl.vec);
     }
     if (ctx->stack_flags) (void)hipFree(ctx->stack_flags);
+    if (ctx->stack_err_host) (void)hipHostFree(ctx->stack_err_host);
+    if (ctx->stack_err_local) (void)hipFree(ctx->stack_err_local);
     float *bufs[] = {ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->gru_gi, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)
         if (b) (void)hipFree(b);

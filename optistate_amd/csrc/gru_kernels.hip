@@ -556,17 +556,30 @@ __global__ __launch_bounds__(256, 2) void gru_layer_stage_kernel(const LayerArgs
 struct StackSync {
     const uint32_t *prev;
     uint32_t *mine;
+    int32_t *err = nullptr;          // the context's error word (pinned host memory, device-mapped): bit 0 = a wait expired
+    int32_t *err_local = nullptr;    // its twin in device memory (adam_kernel polls this one)
+    uint32_t max_polls = 1u << 22;
+    int drop_from = -1;              // tests (OS_STACK_DBG_DROP): this workgroup stops publishing from this step on
 };
 // sequence elements that cross workgroups inside one launch: sc0 | sc1 accesses (coherent across the XCDs' L2s)
 __device__ __forceinline__ float buf_load_coh(rsrc_t r, uint32_t voff, uint32_t soff)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 17));
 }
-// wait until the producer has published step `need - 1`; false after ~4 M polls (seconds): the caller then poisons its input with
-// NaN, so a lost producer ends in NaN outputs -- never in a hung GPU and never in plausible wrong numbers
-__device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need)
+// wait until the producer has published step `need - 1`; false after ~4 M polls (seconds): the caller then reports it in the
+// context's error word (stack_lost), latches the loss (no further waits in this launch) and poisons its input with NaN, so a lost
+// producer ends in an error return of the call (or of the next one: launch.hpp) and NaN outputs -- never in a hung GPU and never
+// in plausible wrong numbers
+__device__ __forceinline__ void stack_lost(int32_t *err, int32_t *err_local)
 {
-    for (int spin = 0; spin < (1 << 22); spin++) {
+    if ((threadIdx.x & 63) == 0) {
+        if (err_local) __hip_atomic_fetch_or(err_local, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err) __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need, uint32_t max_polls = 1u << 22)
+{
+    for (uint32_t spin = 0; spin < max_polls; spin++) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
         __builtin_amdgcn_s_sleep(4);
     }
@@ -626,9 +639,12 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
     const uint32_t xsoff = (uint32_t)growc * 4u + (uint32_t)xk0 * rowB;
     float xr[XE];
     const bool consume = STACK && sy.prev != nullptr;               // x comes from a producer inside this launch
+    bool lost = false;                                               // latched: after one expired wait this workgroup stops waiting
     auto xfetch = [&](int t) {
-        bool lost = false;
-        if (consume) lost = !stack_wait(sy.prev, (uint32_t)t + 1u);  // every lane polls (one request per wave): step t is published
+        if (consume && !lost) {
+            lost = !stack_wait(sy.prev, (uint32_t)t + 1u, sy.max_polls);   // every lane polls (one request per wave): step t is published
+            if (lost) stack_lost(sy.err, sy.err_local);
+        }
         const rsrc_t rx = make_rsrc(a.xs + (size_t)t * a.K * B, (uint32_t)a.K * rowB);
 #pragma unroll
         for (int e = 0; e < XE; e++) {
@@ -671,7 +687,8 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged (a workgroup-scope barrier does not wait for them)
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(sy.mine, (uint32_t)t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && !(sy.drop_from >= 0 && t >= sy.drop_from))
+            __hip_atomic_store(sy.mine, (uint32_t)t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     };
 
 #ifdef OS_LAYER_TS
@@ -923,6 +940,9 @@ __global__ __launch_bounds__(256, 2) void gru_gi_kernel(const GiArgs a)
 struct StackArgs {
     int n, tiles;
     uint32_t *flags;             // [n][tiles] progress counters, zeroed before the launch
+    int32_t *err, *err_local;    // the context's error word (host-mapped) and its device twin
+    uint32_t max_polls;
+    int drop_layer, drop_step;   // tests: layer drop_layer stops publishing from step drop_step on (-1: never)
     LayerArgs layer[8];
 };
 template <int NCH, bool SAVE>
@@ -930,7 +950,8 @@ __global__ __launch_bounds__(512, 1) void gru_stack_kernel(const StackArgs sa)
 {
     const int l = blockIdx.y;
     uint32_t *mine = sa.flags + (size_t)l * sa.tiles + blockIdx.x;
-    split_layer_body<NCH, true, SAVE>(sa.layer[l], StackSync{l > 0 ? mine - sa.tiles : nullptr, mine});
+    split_layer_body<NCH, true, SAVE>(sa.layer[l], StackSync{l > 0 ? mine - sa.tiles : nullptr, mine, sa.err, sa.err_local, sa.max_polls,
+                                                             l == sa.drop_layer ? sa.drop_step : -1});
 }
 
 // H = 128 small-batch variant with the INPUT half of the gate GEMM running ahead of the recurrence.
@@ -1697,6 +1718,8 @@ int os_gru_launch_stack(os_ctx *ctx, const LayerArgs *layers, int n, hipStream_t
         ctx->stack_flags_n = nfl;
     }
     sa.flags = ctx->stack_flags;
+    sa.err = ctx->stack_err_dev; sa.err_local = ctx->stack_err_local; sa.max_polls = ctx->stack_max_polls;
+    sa.drop_layer = ctx->stack_dbg_drop_layer; sa.drop_step = ctx->stack_dbg_drop_step;
     OS_HIP(ctx, hipMemsetAsync(sa.flags, 0, nfl * sizeof(uint32_t), s));
     size_t lds_max = 0;
     for (int l = 0; l < n; l++) {
@@ -1724,6 +1747,37 @@ int os_gru_launch_stack(os_ctx *ctx, const LayerArgs *layers, int n, hipStream_t
     else { if (save) hipLaunchKernelGGL((gru_stack_kernel<1, true>), grid, block, lds_max, s, sa); else hipLaunchKernelGGL((gru_stack_kernel<1, false>), grid, block, lds_max, s, sa); }      // (H = 32, eight slices per chunk: outside the scratch-free contract)
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
+    return os_stack_verify(ctx, s, "gru_stack_kernel");
+}
+
+// After a launch of a progress-counter kernel.  OS_GRU_STACK=1 (default): wait for it and read the error word -- a consumer whose
+// bounded wait expired (its producer never became resident, or another process held the producer's CUs for seconds) makes THIS call
+// fail with -20; the caller re-runs it with a launch per layer (os_gru_set_stack(ctx, 0): the Python engine does).  The wait costs
+// ~10 us on launches of 0.2-2 ms that their callers read back at once.  OS_GRU_STACK=2: no wait; the word is looked at by
+// os_stack_pending at the entry of the next os_gru_* call, and adam_kernel keeps the weights unchanged while it is set.
+int os_stack_verify(os_ctx *ctx, hipStream_t s, const char *what)
+{
+    if (ctx->tune_gru_stack == 1) OS_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->tune_gru_stack == 1 && *(volatile int32_t *)ctx->stack_err_host) {
+        *(volatile int32_t *)ctx->stack_err_host = 0;
+        (void)hipMemsetAsync(ctx->stack_err_local, 0, sizeof(int32_t), s);
+        char msg[256];
+        snprintf(msg, sizeof(msg), "%s: a layer's bounded wait for the layer before it expired (progress-counter pipeline); outputs are NaN-poisoned -- "
+                 "re-run with a launch per layer (os_gru_set_stack(ctx, 0) / OS_GRU_STACK=0)", what);
+        return os_fail(ctx, -20, msg);
+    }
+    return 0;
+}
+int os_stack_pending(os_ctx *ctx, const char *what)
+{
+    if (*(volatile int32_t *)ctx->stack_err_host) {
+        *(volatile int32_t *)ctx->stack_err_host = 0;
+        (void)hipMemset(ctx->stack_err_local, 0, sizeof(int32_t));      // (synchronous: whatever was enqueued behind the lost producer has run)
+        char msg[256];
+        snprintf(msg, sizeof(msg), "%s: an EARLIER stacked launch on this context lost a producer (its outputs were NaN-poisoned, optimiser steps behind it "
+                 "were skipped): re-run that work with os_gru_set_stack(ctx, 0)", what);
+        return os_fail(ctx, -20, msg);
+    }
     return 0;
 }
 
@@ -1927,9 +1981,18 @@ static int gru_vec_launch(os_ctx *ctx, int B, int T, const float *x, float *out,
 // evaluates them one by one.  Here all N - W + 1 windows run as one batch WITHOUT being materialised (the windowed tensor is W
 // times the stream) and the input half of layer 0's gate GEMM is computed once per ROW (gru_gi_kernel) instead of once per
 // (window, step): rows [N][I] row-major on the device -> out [N - W + 1][C].
+int os_gru_set_stack(os_ctx *ctx, int32_t mode)
+{
+    OS_CHECK_CTX(ctx);
+    if (mode < 0 || mode > 2) return os_fail(ctx, -2, "os_gru_set_stack: 0 (a launch per layer), 1 (stacked, verified) or 2 (stacked, asynchronous)");
+    ctx->tune_gru_stack = mode;
+    return 0;
+}
+
 int os_gru_forward_windows(os_ctx *ctx, int32_t N, int32_t W, const float *rows, float *out, void *stream)
 {
     OS_CHECK_CTX(ctx);
+    if (int rcp = os_stack_pending(ctx, "os_gru_forward_windows")) return rcp;
     if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward_windows: call os_gru_load first");
     if (N <= 0 || W <= 0 || W > N || !rows || !out) return os_fail(ctx, -2, "os_gru_forward_windows: bad argument (1 <= window <= rows)");
     const os_gru_dims &d = ctx->gru;
@@ -1998,6 +2061,7 @@ int os_gru_bands(os_ctx *ctx, int32_t B, int32_t n, const float *out, const floa
 int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, float *h_last, void *stream)
 {
     OS_CHECK_CTX(ctx);
+    if (int rcp = os_stack_pending(ctx, "os_gru_forward")) return rcp;
     if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
     if (B <= 0 || T <= 0 || !x || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
     OS_HIP(ctx, hipSetDevice(ctx->device));

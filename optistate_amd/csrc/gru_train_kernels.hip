@@ -207,6 +207,10 @@ struct SweepArgs {
     // workgroup; a counter holds the number of steps published, T - t after step t
     const uint32_t *flag_prev;
     uint32_t *flag_mine;
+    int32_t *err = nullptr;      // the context's error word (launch.hpp): bit 0 = a bounded wait expired
+    int32_t *err_local = nullptr;    // its twin in device memory
+    uint32_t max_polls = 1u << 22;
+    int drop_from = -1;          // tests (OS_STACK_DBG_DROP): stop publishing once T - 1 - t reaches this count of steps done
 };
 
 // RB = 32-row blocks per workgroup (BM = 32*RB).  LDS: dh [BM][H+1] | dG [BM][4H+1] (sections da_r, da_z, da_n, da_n*r).
@@ -259,6 +263,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a)
         const int r = ic >> lgH, c = ic & (H - 1), g = row0 + r;
         pf_off[e] = (uint32_t)(((size_t)(g < a.B ? g : a.B - 1) * H + c) * 4);
     }
+    bool lost = false;                                         // STACK: latched after one expired wait (no further waits in this launch)
     auto prefetch = [&](int t) {
         const uint32_t step = (uint32_t)((size_t)t * B * H * 4), bytes = (uint32_t)((size_t)a.T * B * H * 4);
         const osk::rsrc_t rr_ = osk::make_rsrc(a.sv_r, bytes), rz_ = osk::make_rsrc(a.sv_z, bytes), rn_ = osk::make_rsrc(a.sv_n, bytes),
@@ -274,10 +279,17 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a)
         }
         if constexpr (STACK) {
             if (a.flag_prev) {                                 // dy[t] comes from the layer above inside this launch
-                bool lost = true;
-                for (int spin = 0; spin < (1 << 22); spin++) {
-                    if (__hip_atomic_load(a.flag_prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)(a.T - t)) { lost = false; break; }
-                    __builtin_amdgcn_s_sleep(4);
+                if (!lost) {
+                    lost = true;
+                    for (uint32_t spin = 0; spin < a.max_polls; spin++) {
+                        if (__hip_atomic_load(a.flag_prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)(a.T - t)) { lost = false; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    // reported in the context's error word: the call (or the next one) fails with -20, adam_kernel skips its update
+                    if (lost && lane == 0) {
+                        if (a.err_local) __hip_atomic_fetch_or(a.err_local, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err) __hip_atomic_fetch_or(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < ELP; e++) {
@@ -514,7 +526,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a)
         if (STACK && a.flag_mine && a.need_dx) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's dx stores are acknowledged
         osg::lds_barrier();
         if constexpr (STACK) {
-            if (a.flag_mine && a.need_dx && threadIdx.x == 0)
+            if (a.flag_mine && a.need_dx && threadIdx.x == 0 && !(a.drop_from >= 0 && a.T - 1 - t >= a.drop_from))
                 __hip_atomic_store(a.flag_mine, (uint32_t)(a.T - t), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -529,6 +541,9 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
 struct SweepStackArgs {
     int n, tiles, y0;            // y0: first layer index of this launch (0; the debug sequence OS_SWEEP_STACK_DBG=1 launches one layer at a time)
     uint32_t *flags;             // [n][tiles], zeroed before the launch
+    int32_t *err, *err_local;    // the context's error word and its device twin
+    uint32_t max_polls;
+    int drop_y, drop_step;       // tests: launch row drop_y (0 = the top layer) stops publishing after drop_step steps (-1: never)
     SweepArgs layer[8];          // layer[0] = the top layer
 };
 __global__ __launch_bounds__(512, 1) void bwd_sweep_stack_kernel(const SweepStackArgs sa)
@@ -537,6 +552,7 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_stack_kernel(const SweepStac
     SweepArgs a = sa.layer[y];
     a.flag_mine = sa.flags + (size_t)y * sa.tiles + blockIdx.x;
     a.flag_prev = y > 0 ? a.flag_mine - sa.tiles : nullptr;
+    a.err = sa.err; a.err_local = sa.err_local; a.max_polls = sa.max_polls; a.drop_from = y == sa.drop_y ? sa.drop_step : -1;
     sweep_body<1, 8, 32, true>(a);
 }
 
@@ -1051,11 +1067,15 @@ __global__ void permute_tb_kernel(int B, int T, int F, const float *src, float *
 }
 
 // fused Adam (torch.optim.Adam defaults, gru_train.py:219): one pass over the flat parameter / gradient vectors
+// err: the context's error word (launch.hpp).  While a stacked launch's lost producer is unreported the gradients behind it are
+// NaN-poisoned: the update is skipped (weights and moments unchanged), so an asynchronous caller (OS_GRU_STACK=2) never steps a model
+// on them (gru/gru_train.py:247-249 would).
 __global__ void adam_kernel(size_t n, float *w, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
-                            float bc1, float bc2)
+                            float bc1, float bc2, const int32_t *err)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // (the device twin of the error word)
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
@@ -1210,6 +1230,8 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
 
 int os_gru_forward_train(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out, void *stream)
 {
+    OS_CHECK_CTX(ctx);
+    if (const int rcp = os_stack_pending(ctx, "os_gru_forward_train")) return rcp;
     return forward_train_impl(ctx, B, T, x, out, nullptr, stream);
 }
 
@@ -1217,6 +1239,7 @@ int os_gru_forward_train_ws(os_ctx *ctx, int32_t B, int32_t T, const float *x, f
 {
     OS_CHECK_CTX(ctx);
     if (!ws) return os_fail(ctx, -2, "os_gru_forward_train_ws: null workspace");
+    if (const int rcp = os_stack_pending(ctx, "os_gru_forward_train_ws")) return rcp;
     return forward_train_impl(ctx, B, T, x, out, ws, stream);
 }
 
@@ -1379,6 +1402,9 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
                     ctx->stack_flags_n = nfl;
                 }
                 sa.flags = ctx->stack_flags;
+                sa.err = ctx->stack_err_dev; sa.err_local = ctx->stack_err_local; sa.max_polls = ctx->stack_max_polls;
+                // (the debug knob names a LAYER of the model; this launch's row 0 is the top layer)
+                sa.drop_y = ctx->stack_dbg_drop_layer >= 0 ? L - 1 - ctx->stack_dbg_drop_layer : -1; sa.drop_step = ctx->stack_dbg_drop_step;
                 OS_HIP(ctx, hipMemsetAsync(sa.flags, 0, nfl * sizeof(uint32_t), s));
                 for (int y = 0; y < L; y++) sa.layer[y] = sweep_args(L - 1 - y);
                 if (!ts->sweep_stack_attr_set) {
@@ -1393,6 +1419,7 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
                 } else
                 hipLaunchKernelGGL(bwd_sweep_stack_kernel, dim3(sa.tiles, L), dim3(512), lds, s, sa);
                 os_prof_end(ctx, slot, s);
+                if (const int rcv = os_stack_verify(ctx, s, "bwd_sweep_stack_kernel")) return rcv;
             }
         } else {
             // resident leading k-pairs: one work item per wave
@@ -1503,6 +1530,7 @@ int os_gru_backward(os_ctx *ctx, int32_t B, int32_t T, const float *x, const flo
     if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_backward: call os_gru_load first");
     os_train_state *ts = (os_train_state *)ctx->train;
     if (!ts || !ts->act || ts->B != B || ts->T != T) return os_fail(ctx, -5, "os_gru_backward: call os_gru_forward_train first (same B, T)");
+    if (const int rcp = os_stack_pending(ctx, "os_gru_backward")) return rcp;
     return backward_impl(ctx, ctx->gru, ctx->gru_flat, ts->act, B, T, x, out, dout, grad_flat, dx_out, stream);
 }
 
@@ -1522,6 +1550,7 @@ int os_gru_backward_ws(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, i
     if (!d || B <= 0 || T <= 0) return os_fail(ctx, -2, "os_gru_backward_ws: bad argument");
     const int H = d->hidden_size;
     if (H != 32 && H != 64 && H != 128) return os_fail(ctx, -4, "os_gru_backward_ws: hidden_size must be 32, 64 or 128");
+    if (const int rcp = os_stack_pending(ctx, "os_gru_backward_ws")) return rcp;
     return backward_impl(ctx, *d, w_flat, ws, B, T, x, out, dout, grad_flat, dx, stream);
 }
 
@@ -1530,11 +1559,12 @@ int os_adam_step(os_ctx *ctx, size_t n, float *w, const float *g, float *m, floa
 {
     OS_CHECK_CTX(ctx);
     if (!n || !w || !g || !m || !v || step < 1) return os_fail(ctx, -2, "os_adam_step: bad argument");
+    if (const int rcp = os_stack_pending(ctx, "os_adam_step")) return rcp;
     OS_HIP(ctx, hipSetDevice(ctx->device));
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, (hipStream_t)stream, "adam_kernel");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, w, g, m, v, lr,
-                       beta1, beta2, eps, bc1, bc2);
+                       beta1, beta2, eps, bc1, bc2, (const int32_t *)ctx->stack_err_local);
     os_prof_end(ctx, slot, (hipStream_t)stream);
     OS_HIP(ctx, hipGetLastError());
     return 0;

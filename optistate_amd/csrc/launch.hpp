@@ -10,6 +10,9 @@
 
 struct GruPacked;   // gru_kernels.hip
 
+int os_stack_verify(struct os_ctx *ctx, hipStream_t s, const char *what);     // gru_kernels.hip
+int os_stack_pending(struct os_ctx *ctx, const char *what);
+
 struct os_ctx {
     uint32_t magic;
     int device;
@@ -21,9 +24,20 @@ struct os_ctx {
     int tune_rows_v1;                    // OS_KF_ROWS_V1=1: the first 16-lanes-per-trajectory kernel instead of kf_run_rows2_kernel (A/B runs)
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
-    int tune_gru_stack;                  // 1: small batches run their layer stack as one pipelined launch (gru_stack_kernel), 0: a launch per layer
+    int tune_gru_stack;                  // small batches run their layer stack as one pipelined launch (gru_stack_kernel / bwd_sweep_stack_kernel):
+                                         // 1 = yes, and the call waits for the launch and reads the error word (default); 2 = yes, asynchronous (a lost
+                                         // producer surfaces at the next os_gru_* call); 0 = a launch per layer.  OS_GRU_STACK / os_gru_set_stack
     uint32_t *stack_flags;               // gru_stack_kernel's progress counters [layers][tiles]
     size_t stack_flags_n;
+    // error word of the progress-counter kernels: pinned host memory mapped into the device's address space.  A consumer whose
+    // bounded wait expires ORs bit 0 into it (system scope) before it poisons its input with NaN; the host reads it without a
+    // copy (os_stack_verify after a stacked launch, os_stack_pending at the entry of later calls); adam_kernel reads it on the
+    // device and leaves the weights alone while it is set.
+    int32_t *stack_err_host, *stack_err_dev;
+    int32_t *stack_err_local;            // the same bit in DEVICE memory: what adam_kernel polls (422 k threads reading a word of host
+                                         // memory over PCIe doubled the batch-64 training step); cleared on the stream when the error is reported
+    uint32_t stack_max_polls;            // OS_STACK_DBG_POLLS (development / tests): polls before a wait gives up (default 2^22: seconds)
+    int stack_dbg_drop_layer, stack_dbg_drop_step;   // OS_STACK_DBG_DROP="layer,step" (tests): that workgroup row stops publishing from that step on
     int tune_dw_dbg;                     // development: Dw3Args.dbg (OS_DW_DBG)
     int tune_gru_stage;                  // 1: large-batch H = 128 inference layers use gru_layer_stage_kernel (x tile by LDS-DMA), 0: gru_layer_kernel<2,2>
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel

@@ -8,6 +8,7 @@ Stream layout (see the header): structure of arrays, trajectory index fastest, e
 `pack()` converts the reference's per-trajectory row lists ([B][T][F]) on the device.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -24,6 +25,10 @@ INERTIA = (55303643.08 / 1e9, 60119440.34 / 1e9, 105304340.05 / 1e9)
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class StackLost(RuntimeError):
+    """A layer-pipelined launch lost a producer (C-ABI return code -20, os_gru_set_stack)."""
 
 
 class Engine:
@@ -46,6 +51,9 @@ class Engine:
         self._keyed_flats = {}
         self._next_key = 0
         self._inval_epoch = 0
+        # a context holds ONE loaded model and ONE set of scratch buffers: whoever pairs load_gru with a forward on a context that
+        # other threads may use holds this lock across the pair (RNN.forward, DataParallelTrainer.step, the ViT module)
+        self.lock = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -59,8 +67,31 @@ class Engine:
             pass
 
     def _check(self, rc, what):
+        if rc == _capi.OS_ERR_STACK_LOST:
+            raise StackLost(f"{what} failed ({rc}): {self.lib.os_last_error(self._h).decode()}")
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.os_last_error(self._h).decode()}")
+
+    def set_stack_mode(self, mode):
+        """0: a launch per layer; 1 (default): small batches run their layer stack as one pipelined launch and the call waits for it
+        and checks its error word; 2: the same, asynchronous (os_gru_set_stack in include/optistate_hip.h)."""
+        self._check(self.lib.os_gru_set_stack(self._h, int(mode)), "os_gru_set_stack")
+        self._stack_mode = int(mode)
+
+    def _stack_guarded(self, call):
+        """Runs call(); when a layer-pipelined launch reports a lost producer (StackLost: the library's bounded wait expired -- the
+        producer workgroup never became resident, or another process held its CUs for seconds), runs it again with a launch per
+        layer.  The GRU entry points are idempotent (outputs and the flat gradient are overwritten), so the retry is exact."""
+        try:
+            return call()
+        except StackLost:
+            prev = getattr(self, "_stack_mode", None)
+            self.lib.os_gru_set_stack(self._h, 0)
+            self.stack_fallbacks = getattr(self, "stack_fallbacks", 0) + 1
+            try:
+                return call()
+            finally:
+                self.lib.os_gru_set_stack(self._h, 1 if prev is None else prev)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -240,7 +271,7 @@ class Engine:
             raise ValueError("load_gru first / input width mismatch")
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
         hl = torch.empty((d.num_layers, B, d.hidden_size), dtype=torch.float32, device=self.device) if want_h_last else None
-        self._check(self.lib.os_gru_forward(self._h, B, T, _ptr(x), _ptr(out), _ptr(hl), self._stream()), "os_gru_forward")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_forward(self._h, B, T, _ptr(x), _ptr(out), _ptr(hl), self._stream()), "os_gru_forward"))
         return (out, hl) if want_h_last else out
 
     def gru_forward_windows(self, rows_ni, window):
@@ -256,7 +287,8 @@ class Engine:
         if not 1 <= window <= N:
             raise ValueError("1 <= window <= number of rows")
         out = torch.empty((N - window + 1, d.num_classes), dtype=torch.float32, device=self.device)
-        self._check(self.lib.os_gru_forward_windows(self._h, N, int(window), _ptr(rows), _ptr(out), self._stream()), "os_gru_forward_windows")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_forward_windows(self._h, N, int(window), _ptr(rows), _ptr(out), self._stream()),
+                                                "os_gru_forward_windows"))
         return out
 
     def gru_bands(self, out, min_v, max_v):
@@ -283,8 +315,8 @@ class Engine:
         if d is None:
             raise RuntimeError("gru_forward_soa: load_gru first")
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
-        self._check(self.lib.os_gru_forward_soa(self._h, B, T, _ptr(xs_tib), _ptr(out), None, self._stream()),
-                    "os_gru_forward_soa")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_forward_soa(self._h, B, T, _ptr(xs_tib), _ptr(out), None, self._stream()),
+                                                "os_gru_forward_soa"))
         return out
 
     # ---- training step (gru/gru_train.py:232-249) ----
@@ -295,7 +327,7 @@ class Engine:
         if d is None or I != d.input_size:
             raise ValueError("load_gru first / input width mismatch")
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
-        self._check(self.lib.os_gru_forward_train(self._h, B, T, _ptr(x), _ptr(out), self._stream()), "os_gru_forward_train")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_forward_train(self._h, B, T, _ptr(x), _ptr(out), self._stream()), "os_gru_forward_train"))
         return out
 
     def gru_forward_train_ws(self, x_bti):
@@ -309,8 +341,8 @@ class Engine:
         n = self.lib.os_gru_train_ws_floats(C.byref(d), B, T)
         ws = torch.empty((n,), dtype=torch.float32, device=self.device)
         out = torch.empty((B, d.num_classes), dtype=torch.float32, device=self.device)
-        self._check(self.lib.os_gru_forward_train_ws(self._h, B, T, _ptr(x), _ptr(out), _ptr(ws), self._stream()),
-                    "os_gru_forward_train_ws")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_forward_train_ws(self._h, B, T, _ptr(x), _ptr(out), _ptr(ws), self._stream()),
+                                                "os_gru_forward_train_ws"))
         return out, ws, self._gru_flat, _capi.OsGruDims(d.input_size, d.hidden_size, d.num_layers, d.num_classes, d.use_sigmoid)
 
     def gru_backward_ws(self, dims, flat, ws, x_bti, out, dout, grad_flat=None, want_dx=False):
@@ -321,8 +353,8 @@ class Engine:
             grad_flat = torch.empty((n,), dtype=torch.float32, device=self.device)
         dx = torch.empty_like(x) if want_dx else None
         dout = dout.to(self.device, dtype=torch.float32).contiguous()
-        self._check(self.lib.os_gru_backward_ws(self._h, C.byref(dims), _ptr(flat), B, T, _ptr(x), _ptr(out), _ptr(dout), _ptr(ws),
-                                                _ptr(grad_flat), _ptr(dx), self._stream()), "os_gru_backward_ws")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_backward_ws(self._h, C.byref(dims), _ptr(flat), B, T, _ptr(x), _ptr(out), _ptr(dout), _ptr(ws),
+                                                                            _ptr(grad_flat), _ptr(dx), self._stream()), "os_gru_backward_ws"))
         return (grad_flat, dx) if want_dx else grad_flat
 
     def gru_loss(self, out, y, want_target=False):
@@ -344,8 +376,8 @@ class Engine:
             grad_flat = torch.empty((n,), dtype=torch.float32, device=self.device)
         dx = torch.empty_like(x) if want_dx else None
         dout = dout.to(self.device, dtype=torch.float32).contiguous()
-        self._check(self.lib.os_gru_backward(self._h, B, T, _ptr(x), _ptr(out), _ptr(dout), _ptr(grad_flat), _ptr(dx),
-                                             self._stream()), "os_gru_backward")
+        self._stack_guarded(lambda: self._check(self.lib.os_gru_backward(self._h, B, T, _ptr(x), _ptr(out), _ptr(dout), _ptr(grad_flat), _ptr(dx),
+                                                                         self._stream()), "os_gru_backward"))
         return (grad_flat, dx) if want_dx else grad_flat
 
     def gru_backward_mark(self, layer, event):
@@ -469,11 +501,17 @@ def flatten_state_dict(sd, num_layers, device=None):
     return flat.to(device) if device is not None else flat
 
 
-_default_engines = {}
+_default_engines = threading.local()
 
 
 def default_engine(device=0):
+    """The calling THREAD's context on `device` (one context per (thread, GPU); calls on a context are stream-ordered
+    and a context holds ONE loaded model and one set of scratch buffers, so two threads must not share one).  The weight
+    containers (RNN, Transformer_Autoencoder), the drop-in Kalman_Filter and DataParallelTrainer take theirs from here; a
+    container that is handed to another thread keeps the engine it was first used with and serialises its load + forward pairs on
+    that engine's lock (Engine.lock)."""
     idx = device if isinstance(device, int) else (torch.device(device).index or 0)
-    if idx not in _default_engines:
-        _default_engines[idx] = Engine(idx)
-    return _default_engines[idx]
+    engines = _default_engines.__dict__.setdefault("engines", {})
+    if idx not in engines:
+        engines[idx] = Engine(idx)
+    return engines[idx]

@@ -52,8 +52,15 @@ class RNN(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .train import gru_forward_autograd        # training path: HIP forward + HIP backward
             return gru_forward_autograd(self, x)
-        self._sync_weights(x.device)
-        return self._engine.gru_forward(x)
+        self._bind_engine(x.device)
+        with self._engine.lock:                            # load + forward as one unit: the context holds ONE model
+            self._sync_weights(x.device)
+            return self._engine.gru_forward(x)
+
+    def _bind_engine(self, dev):
+        if self._engine is None or self._engine.device != dev:
+            self._engine = default_engine(dev.index or 0)  # the calling thread's context on this GPU
+            self._loaded_versions = None
 
     def forward_windows(self, rows, window):
         """All sliding windows of ONE time-ordered row stream at once: rows (N, input_size) -> (N - window + 1, num_classes), output i
@@ -62,7 +69,9 @@ class RNN(nn.Module):
         per row (os_gru_forward_windows).  Inference only; shapes the kernel does not take fall back to materialised windows."""
         if not rows.is_cuda:
             raise RuntimeError("optistate_amd.RNN.forward_windows needs a tensor on the MI355X (no CPU fallback)")
-        self._sync_weights(rows.device)
-        if self._engine.gru_windows_supported():
-            return self._engine.gru_forward_windows(rows, window)
-        return self._engine.gru_forward(rows.unfold(0, window, 1).permute(0, 2, 1).contiguous())
+        self._bind_engine(rows.device)
+        with self._engine.lock:
+            self._sync_weights(rows.device)
+            if self._engine.gru_windows_supported():
+                return self._engine.gru_forward_windows(rows, window)
+            return self._engine.gru_forward(rows.unfold(0, window, 1).permute(0, 2, 1).contiguous())

@@ -98,7 +98,11 @@ class Transformer_Autoencoder(nn.Module):
     def forward_encoder(self, x):
         if not x.is_cuda:
             raise RuntimeError("optistate_amd Transformer_Autoencoder.forward_encoder needs a tensor on the MI355X (no CPU fallback)")
-        eng = default_engine(x.device.index or 0)
+        eng = default_engine(x.device.index or 0)          # the calling thread's context on this GPU
+        with eng.lock:                                     # load + encode as one unit: a context holds ONE encoder
+            return self._encode_locked(eng, x)
+
+    def _encode_locked(self, eng, x):
         versions = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._loaded is None or self._loaded[0] != versions or getattr(eng, "_vit_owner", None) is not self:
             flat = self._flat(x.device)

@@ -73,3 +73,130 @@ def test_mpc_rejects_bad_arguments(eng):
     w = (C.c_double * 12)(*([1.0] * 12))
     assert lib.os_mpc_set_weights(h, w, C.c_double(-1.0), C.c_double(0.6), C.c_double(150.0)) < 0
     assert lib.os_mpc_set_weights(h, None, C.c_double(1e-6), C.c_double(0.6), C.c_double(150.0)) < 0
+
+
+# ---- the progress-counter kernels' error path (include/optistate_hip.h: os_gru_set_stack) ----
+def _ref_forward(x, sd_flat, dims):
+    import os
+    from optistate_amd import Engine
+    old = os.environ.get("OS_GRU_STACK")
+    os.environ["OS_GRU_STACK"] = "0"
+    try:
+        e = Engine(0)
+        e.load_gru(sd_flat, *dims)
+        return e.gru_forward(x)
+    finally:
+        if old is None:
+            del os.environ["OS_GRU_STACK"]
+        else:
+            os.environ["OS_GRU_STACK"] = old
+
+
+def test_lost_producer_fails_the_call_and_the_engine_falls_back_to_a_launch_per_layer(monkeypatch):
+    """OS_STACK_DBG_DROP withholds layer 1's publishes from step 3 on, OS_STACK_DBG_POLLS shortens the bounded wait: layer 2's wait
+    expires, it sets the context's error word and poisons its input.  The raw C call returns -20 and names the kernel; the Python
+    engine re-runs the call with a launch per layer and returns the right numbers (VERDICT r4 missing 4: no silent NaN)."""
+    import ctypes as C
+    import torch
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.engine import _ptr
+    dims = (188, 128, 4, 24)
+    torch.manual_seed(2)
+    m = RNN(*dims, torch.device("cpu"))
+    flat = flatten_state_dict(m.state_dict(), 4, "cuda")
+    x = torch.rand(64, 10, 188, device="cuda")
+    ref = _ref_forward(x, flat, dims)
+    monkeypatch.setenv("OS_STACK_DBG_DROP", "1,3"); monkeypatch.setenv("OS_STACK_DBG_POLLS", "3000"); monkeypatch.setenv("OS_GRU_VEC", "0")
+    eng = Engine(0)
+    eng.load_gru(flat, *dims)
+    out = torch.empty((64, 24), device="cuda")
+    rc = eng.lib.os_gru_forward(eng._h, 64, 10, _ptr(x), _ptr(out), None, eng._stream())
+    assert rc == -20 and b"gru_stack_kernel" in eng.lib.os_last_error(eng._h) and b"os_gru_set_stack" in eng.lib.os_last_error(eng._h)
+    got = eng.gru_forward(x)                                   # the engine: same failure, then a launch per layer
+    assert eng.stack_fallbacks == 1 and torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 2e-6
+    # asynchronous mode: the call returns at once; the NEXT call on the context reports it
+    eng.set_stack_mode(2)
+    rc = eng.lib.os_gru_forward(eng._h, 64, 10, _ptr(x), _ptr(out), None, eng._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out).all()
+    rc = eng.lib.os_gru_forward(eng._h, 64, 10, _ptr(x), _ptr(out), None, eng._stream())
+    assert rc == -20 and b"EARLIER" in eng.lib.os_last_error(eng._h)
+    torch.cuda.synchronize()
+
+
+def test_adam_kernel_skips_its_update_behind_a_lost_producer(monkeypatch):
+    """Asynchronous mode (os_gru_set_stack 2): the optimiser step enqueued behind a stacked launch that lost a producer must leave
+    the weights and moments alone (gru/gru_train.py:247-249 would step Adam on NaN gradients)."""
+    import torch
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.engine import _ptr
+    dims = (188, 128, 4, 24)
+    torch.manual_seed(2)
+    m = RNN(*dims, torch.device("cpu"))
+    flat = flatten_state_dict(m.state_dict(), 4, "cuda")
+    x = torch.rand(64, 10, 188, device="cuda")
+    monkeypatch.setenv("OS_STACK_DBG_DROP", "1,3"); monkeypatch.setenv("OS_STACK_DBG_POLLS", "400000"); monkeypatch.setenv("OS_GRU_VEC", "0")
+    eng = Engine(0)
+    eng.load_gru(flat, *dims)
+    eng.set_stack_mode(2)
+    w = flat.clone(); w0 = w.clone()
+    g = torch.full_like(w, float("nan")); mo = torch.zeros_like(w); v = torch.zeros_like(w)
+    out = torch.empty((64, 24), device="cuda")
+    assert eng.lib.os_gru_forward(eng._h, 64, 10, _ptr(x), _ptr(out), None, eng._stream()) == 0          # in flight: its wait takes ~0.1 s
+    eng.adam_step(w, g, mo, v, 1e-4, 0.9, 0.999, 1e-8, 1)                                                # enqueued behind it
+    torch.cuda.synchronize()
+    assert torch.equal(w, w0) and float(mo.abs().sum()) == 0.0 and float(v.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="EARLIER"):
+        eng.adam_step(w, g, mo, v, 1e-4, 0.9, 0.999, 1e-8, 1)
+    g.fill_(0.5)
+    eng.adam_step(w, g, mo, v, 1e-4, 0.9, 0.999, 1e-8, 1)                                                # the word is cleared: updates run again
+    torch.cuda.synchronize()
+    assert not torch.equal(w, w0)
+
+
+def test_two_threads_two_contexts_equal_the_sequential_results():
+    """SURVEY 8(b) threading contract: different contexts from different threads, each on its own stream, concurrently -- the
+    Kalman run and the GRU forward of each thread equal what the same calls return one after the other; default_engine() is per
+    thread, so two RNN modules evaluated from two threads never share a context's loaded weights."""
+    import threading
+    import numpy as np
+    import torch
+    from optistate_amd import Engine, RNN, flatten_state_dict, default_engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT, Q_FITTED, R_FITTED
+    dev = torch.device("cuda", 0)
+    jobs = []
+    for i, (Q, R, dims) in enumerate(((Q_DEFAULT, R_DEFAULT, (60, 64, 1, 24)), (Q_FITTED, R_FITTED, (188, 128, 4, 24)))):
+        torch.manual_seed(10 + i)
+        m = RNN(*dims, torch.device("cpu"))
+        jobs.append(dict(Q=Q, R=R, dims=dims, flat=flatten_state_dict(m.state_dict(), dims[2], dev), d=synth_torch(4096, 50, dev, seed=50 + i),
+                         x=torch.rand(512, 10, dims[0], device=dev), model=RNN(*dims, dev).to(dev).eval()))
+
+    def work(j, res, reps):
+        torch.cuda.set_device(0)
+        eng = Engine(0)
+        eng.set_noise(j["Q"], j["R"])
+        eng.load_gru(j["flat"], *j["dims"])
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            for _ in range(reps):
+                d = j["d"]
+                c = eng.contact_soa_to_packed(d["contact"])
+                x, P = d["x0"].clone(), d["P0"].clone()
+                r = eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], c, x, P)
+                o = eng.gru_forward(j["x"])
+                with torch.no_grad():
+                    mo = j["model"](j["x"])                 # through the module: this thread's default engine
+            st.synchronize()
+        res.update(x_out=r["x_out"].clone(), out=o.clone(), mout=mo.clone(), engine=id(default_engine(0)))
+
+    seq = [dict(), dict()]
+    for j, r in zip(jobs, seq):
+        work(j, r, 1)
+    par = [dict(), dict()]
+    ths = [threading.Thread(target=work, args=(j, r, 20)) for j, r in zip(jobs, par)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    for s, p in zip(seq, par):
+        assert p and torch.equal(s["x_out"], p["x_out"]) and torch.equal(s["out"], p["out"]) and torch.equal(s["mout"], p["mout"])
+    assert par[0]["engine"] != par[1]["engine"]                 # one default context per thread
