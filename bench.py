@@ -294,6 +294,27 @@ def load_traffic(kernel_name, shape_ok):
         return None, f"profiles/traffic.json unreadable: {e!r}"
 
 
+def rocprof_avg_ms(kernel_name, tag="default"):
+    """Average launch duration of `kernel_name` in the newest TRACKED rocprofv3 --kernel-trace --stats summary of this mode
+    (profiles/rNN_<tag>_kernel_stats.md, written on the GPU box by tools/collect_profiles.sh from the same command): the figure the live
+    HIP-event measurement is calibrated against.  Returns (ms or None, source)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]*_{tag}_kernel_stats.md")))
+    if not files:
+        return None, f"no profiles/rNN_{tag}_kernel_stats.md"
+    name = kernel_name.split("<")[0].split(" ")[0]
+    f = files[-1]
+    try:
+        for line in open(f):
+            cells = [c.strip() for c in line.split("|")]
+            if len(cells) > 5 and name in cells[1] and re.fullmatch(r"[0-9.]+", cells[4] or "x"):
+                return float(cells[4]) / 1e3, f"{os.path.relpath(f, ROOT)} (rocprofv3 average over {cells[2]} calls, profiler on, warm-ups included)"
+    except Exception as e:
+        return None, f"{os.path.relpath(f, ROOT)} unreadable: {e!r}"
+    return None, f"{os.path.relpath(f, ROOT)} has no row for {name}"
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baselines and the parity block: the ONLY users of oracle/ in this file (checker / reported baseline, never the
 # thing measured as `value`)
@@ -370,9 +391,10 @@ def cpu_baseline(H, L, target_seconds, kf_only=False, all_cores=None):
     return out
 
 
-def cpu_baseline_train(target_seconds):
+def cpu_baseline_train(target_seconds, batch=8192):
     """gru/gru_train.py:232-249 as the reference runs it (torch.nn.GRU + Linear + sigmoid, the self-referential target,
-    MSELoss, Adam lr 1e-4) on the host cores, fp32, on a bounded number of windows of the same shape."""
+    MSELoss, Adam lr 1e-4) on the host cores, fp32, on a bounded number of windows of the same shape (at most the bench's own
+    batch: --batch 64 is the reference's, gru/gru_train.py:36)."""
     import torch
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -387,11 +409,11 @@ def cpu_baseline_train(target_seconds):
         loss = torch.nn.functional.mse_loss(out, tgt)
         opt.zero_grad(); loss.backward(); opt.step()
 
-    Bs = 256
+    Bs = min(256, batch)
     x, y = torch.rand(Bs, T, I), torch.rand(Bs, 12)
     step(x, y)
     t0 = time.perf_counter(); step(x, y); t1 = time.perf_counter() - t0
-    Bs = int(min(8192, max(256, Bs * 0.5 * target_seconds / max(t1, 1e-6))))
+    Bs = int(min(batch, max(Bs, Bs * 0.5 * target_seconds / max(t1, 1e-6))))
     x, y = torch.rand(Bs, T, I), torch.rand(Bs, 12)
     t0 = time.perf_counter(); step(x, y); el = time.perf_counter() - t0
     return {"value": Bs / el, "unit": "windows/s", "cores": cores, "kind": "port",
@@ -422,7 +444,7 @@ def cpu_baseline_full(target_seconds):
     el = time.perf_counter() - t0
     orc.set_threads(1)
     return {"value": Bt * T / el, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{Bt * T} frames (numpy float64 ViT restatement on BLAS threads + C oracle KF/GRU, {el:.1f} s); parity unpinned for the ViT"}
+            "sample": f"{Bt * T} frames (numpy float64 ViT restatement on BLAS threads + C oracle KF/GRU, {el:.1f} s); the ViT blocks are pinned to transformers' ViTLayer under the reference's glue (G14), not to timm 0.3.2 itself"}
 
 
 def cpu_baseline_mpc(target_seconds):
@@ -443,7 +465,8 @@ def cpu_baseline_mpc(target_seconds):
     el = time.perf_counter() - t0
     return {"value": n / el, "unit": "timesteps/s", "cores": 1, "kind": "port",
             "sample": f"{n} force QPs (numpy float64 active-set restatement, 1 thread, {el:.1f} s); the filter step adds <1 %; "
-                      "the reference solves them with qpOASES (absent here: parity unpinned)"}
+                      "the QP is the reference's own assembly (G12: H, g and every constraint row extracted from force_controller.py); "
+                      "qpOASES itself is absent, the minimiser of the strictly convex QP is KKT-certified"}
 
 
 def oracle_pass(d, x_out, out, model, H, L, Q, R, P0, want, cap_seconds, kf_only=False, latent=None):
@@ -582,7 +605,7 @@ def bench_train(a, rk):
         out.update(allreduce_us=ar_us, grad_bucket_bytes=int(tr.bucket.g.numel() * 4), final_loss=float(loss.item()),
                    allreduce="two halves: layers L/2..L-1 + head on a side stream behind their dW kernel, the rest on the main stream"
                    if tr.split is not None else "one bucket behind the backward", **info)
-        out["cpu_baseline"] = cpu_baseline_train(a.cpu_seconds) if (a.cpu_seconds > 0 and rk.world == 1) else None
+        out["cpu_baseline"] = cpu_baseline_train(a.cpu_seconds, B) if (a.cpu_seconds > 0 and rk.world == 1) else None
         emit(json.dumps(out))
 
 
@@ -623,7 +646,7 @@ def bench_full(a, rk):
         out = base_line(a, rk, "depth frames/sec through ViT latent + KF + GRU", "frames/s", N * rk.world * a.steps / el, el, "f32",
                         {"workload": "ViT encoder (3 blocks, dim 128) latent + Kalman + GRU(188,128,4,24)", "frames": N,
                          "trajectories": B, "seq_len": T, "baseline_config": "BASELINE.json configs[4]",
-                         "note": "ViT parity unpinned (timm/weights absent)"})
+                         "note": "ViT blocks checked against transformers' ViTLayer under the reference's glue (G11 / G14); timm 0.3.2 and the trained weights are absent"})
         if cand:
             dom = max(cand, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
             dk = kernels[dom]
@@ -669,7 +692,7 @@ def bench_mpc(a, rk):
                         B * T * rk.world * a.steps / el, el, "f64 (QP) / f32 (filter)",
                         {"workload": "estimate_state_mpc: 60-variable force QP + Kalman(12/10) predict_mpc/update",
                          "batch_per_gpu": B, "seq_len": T, "parallelism": f"trajectory-sharded x{rk.world}, no collective",
-                         "note": "QP parity unpinned (qpOASES absent): checked against the KKT-certified oracle"})
+                         "note": "QP formulation pinned to the reference's own assembly (G12); solver = KKT-certified minimiser (qpOASES absent)"})
         # bytes per step: p, dp, body_ref 48 each + imu 24 + contact 4 in; x 48 + f 48 out
         bps = 268
         ach = bps * B * T / (el / a.steps) / 1e9
@@ -845,6 +868,13 @@ def bench_hot_path(a, rk):
                                f"({avg_ms * 1e3 / T:.2f} us per step: profiles/r03_rows2_timestamps.md); HBM is not the bound at this batch")
         else:
             roof["limiter"] = "VALU issue at one wavefront per SIMD (~5 cycles per instruction)"
+    roof["frac_source"] = "HIP events on the launch stream over the timed region, this box"
+    if default_shape and a.mode == "fused" and not a.split_bf16:
+        # beside the live figure: the same fraction from the tracked rocprofv3 summary of the same command
+        rp_ms, rp_src = rocprof_avg_ms(dk["kernel"])
+        roof["frac_rocprof"] = (roof["achieved"] * avg_ms / rp_ms) / roof["peak"] if rp_ms else None
+        roof["rocprof_avg_launch_ms"] = rp_ms
+        roof["rocprof_source"] = rp_src
     rows_shape = a.mode == "kf" and B == 4096 and T == 1000 and dk["kernel"].startswith("kf_run_rows2")      # the shape traffic.json holds for it
     roof["traffic"], roof["traffic_source"] = load_traffic(dk["kernel"], (default_shape or rows_shape) and not a.split_bf16)
     if roof["traffic"] is not None:

@@ -5,7 +5,9 @@ cls_token, pos_embed, blocks.{i}.norm1/attn.qkv/attn.proj/norm2/mlp.fc1/mlp.fc2.
 `transformer/autoencoder_training.py:128-131` loads with `load_state_dict(..., strict=False)` (decoder keys are
 ignored: the decoder and its loss are training-only and out of scope).  `forward_encoder(x)` takes (N,1,224,224) in [0,1]
 (gru/gru_test.py:49-53) and returns (N,1,128) like the reference; it runs `os_vit_encode` (hand-written HIP kernels only: fp32-MFMA GEMM with fused epilogues, MFMA attention).
-PARITY UNPINNED (timm and the trained weights are absent): checked against oracle/vit_oracle.py only.
+Parity: the reference's own class (unmodified glue: patch + position table, cls token, block loop, final LayerNorm, token 0, sigmoid)
+around a plain-torch restatement of the timm-0.3.2 blocks (golden G11) and around Hugging Face transformers' ViTLayer (G14: identical
+float32 latents); timm 0.3.2 itself and the trained weights are absent from the image.
 """
 import ctypes as C
 
