@@ -10,7 +10,7 @@
 //   * H and q are never stored.  With a_v = I_hat^-1 (R p_leg x e_c) and b_v = e_c / m the generators of variable v,
 //       H[v][w] = a_v^T (al W_w + be R1 W_th R1^T) a_w + b_v^T (al W_v + be W_r) b_w + r delta_vw,
 //       al = dt^2 (5 - max(i,l)),  be = dt^4 sum_{k>max(i,l)} (k-1-i)(k-1-l)       (i, l = horizon steps of v, w)
-//     because x_k depends on the inputs only through the per-step wrench (derivation in DESIGN.md); a row is rebuilt
+//     because x_k depends on the inputs only through the per-step wrench (derivation in docs/DESIGN_history_r01-r04.md section 4.5); a row is rebuilt
 //     from the six-vectors in LDS whenever it is needed (one horizon-step block at a time: 3.5 - 13 KB of LDS per
 //     wavefront, two to three wavefronts per SIMD).
 //   * the feasible set is a product of truncated friction pyramids, so an active set is a FACE per (leg, step):
@@ -391,7 +391,7 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         }
     }
 
-    // linear term: q_v = a_v . cw_i + b_v . cv_i from the zero-input trajectory (see header / DESIGN.md).  The errors of the
+    // linear term: q_v = a_v . cw_i + b_v . cv_i from the zero-input trajectory (see header / docs/DESIGN_history_r01-r04.md section 4.5).  The errors of the
     // zero-input trajectory at horizon step k are polynomials in k (attitude and velocity linear, position quadratic through
     // gravity), so the sums over the steps k > i that variable v still influences are closed forms in the lane's step i:
     // with Mm = 4 - i and m = k - 1 - i = 0..Mm,
