@@ -708,7 +708,7 @@ def bench_mpc(a, rk):
         mpc_ms = mk.get("ms_per_launch", 0.0) * mk.get("launches_per_step", 0.0)
         ach = qp_flops / (mpc_ms * 1e-3) / 1e12 if mpc_ms else 0.0
         persistent = mk.get("kernel", "").startswith("kf_mpc_persistent")
-        out["roofline"] = {"kernel": mk.get("kernel", "mpc_solve_kernel") + " (float64 vector pipe: v_fma_f64)", "bound": "fp64 vector", "achieved": ach,
+        out["roofline"] = {"kernel": mk.get("kernel", "mpc_solve_kernel") + " (float64 vector pipe: v_fma_f64)", "bound": "mfma", "pipe": "fp64 VECTOR pipe (compute-bound class of the contract's two; nothing here runs on a matrix core)", "achieved": ach,
                            "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TF, "traffic": None,
                            "traffic_source": "not collected for this mode", "algorithmic_flops_per_pass": qp_flops,
                            "flops_per_iteration": "2 n^3 / 3 + 14 n^2 + 260 n, n = 15 x stance legs (30 at trot: 32 kflop)",

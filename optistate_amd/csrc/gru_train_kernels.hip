@@ -1214,6 +1214,12 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
         a.h_last = nullptr;
         float *base = act + (size_t)l * 5 * tbh;
         a.sv_r = base; a.sv_z = base + tbh; a.sv_n = base + 2 * tbh; a.sv_g = base + 3 * tbh; a.sv_h = base + 4 * tbh;
+        {
+            // development (timing ablation only, OS_TRAIN_DBG_NOSAVE=1): the forward without its saved-activation stores -- an upper bound
+            // on what ANY re-layout of those stores could gain (the backward then reads stale activations: wrong gradients)
+            static const bool nosave = getenv("OS_TRAIN_DBG_NOSAVE") != nullptr;
+            if (nosave) a.sv_r = a.sv_z = a.sv_n = a.sv_g = a.sv_h = nullptr;
+        }
         if (!stack && os_gru_launch_layer(ctx, a, s)) return -10;
         in = a.seq_out;
         woff += os_layer_packed_floats(K, H);

@@ -30,6 +30,8 @@ def test_default_mode_contract():
     ro = d["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and "traffic" in ro and "traffic_source" in ro
+    assert "HIP events" in ro["frac_source"]                   # (the default SHAPE also carries frac_rocprof from the tracked summary)
+    assert d["status_nonzero_trajectories"] == 0 and "trunc_edge_trajectories" in d      # failures (bits 0-3) and the informational bit apart
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["single_thread_value"] > 0 and cb["gru_half_torch_cpu"]["value"] > 0
@@ -70,9 +72,17 @@ def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
     _has_roofline_and_baseline(m)
     assert m["value"] > 0 and m["status_nonzero_trajectories"] == 0 and m["kernels"]["mpc"]["launches_per_step"] == 1
     assert m["kernels"]["mpc"]["kernel"] == "kf_mpc_persistent_kernel"        # one launch for all T steps, no per-step launches
+    # the QP line's bound: algorithmic fp64 flops of the iterations taken against the fp64 vector peak
+    assert m["roofline"]["unit"] == "TFLOP/s" and m["roofline"]["peak"] == 78.6 and "fp64" in m["roofline"]["pipe"] and m["roofline"]["algorithmic_flops_per_pass"] > 0
+    assert "trunc_edge_trajectories" in m
     f = _run(["--mode", "full", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
     _has_roofline_and_baseline(f)
     assert f["config"]["frames"] == 1024 and f["unit"] == "frames/s"
     w = _run(["--mode", "windows", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
     _has_roofline_and_baseline(w)
     assert w["unit"] == "windows/s" and w["config"]["gru_timesteps_per_output"] == 10
+    # the row-stream form: no window tensor, layer 0's input projection once per row; the roofline counts ITS flops
+    assert "os_gru_forward_windows" in w["config"]["form"] and w["config"]["rows_per_gpu"] == 2048 + 9
+    assert w["roofline"]["algorithmic_flops_per_pass"] < w["roofline"]["flops_of_the_materialised_form"]
+    wm = _run(["--mode", "windows", "--materialise", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])
+    assert "materialised" in wm["config"]["form"] and wm["roofline"]["algorithmic_flops_per_pass"] == wm["roofline"]["flops_of_the_materialised_form"]

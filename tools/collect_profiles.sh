@@ -81,4 +81,16 @@ python3 tools/train_small_batch.py 200 > $O/train_small_batch.json 2>> $O/bench.
 python3 bench.py --mode train --batch 64 --steps 50 --cpu-seconds 0 > $O/bench_train_B64.json 2>> $O/bench.err
 OS_GRU_STACK=0 python3 bench.py --mode full > $O/bench_full_nostack.json 2>> $O/bench.err
 bash tools/vec_ts.sh 2>&1 | grep "gru_vec_kernel" | sort -u > $O/vec_timestamps_raw.txt
+# round 5: the window-stream inference entry (and the materialised form beside it), its kernel table; the dense-F_d float64 filter on
+# the row layout; the QP line's fp64 roofline + SQ counters; the world > 1 paths on this one GPU (gloo, host-staged collectives);
+# the training step's ablations
+stats windows --mode windows --cpu-seconds 0
+python3 bench.py --mode windows --materialise > $O/bench_windows_materialised.json 2>> $O/bench.err
+python3 tools/windows_probe.py > $O/windows_probe.txt 2>> $O/bench.err
+python3 tools/baseline_probe.py > $O/dense_kf_and_mpc_probe.json 2>> $O/bench.err
+python3 bench.py --mode mpc --seq 100 --steps 2 --warmup 1 --cpu-seconds 0 > $O/bench_mpc_T100.json 2>> $O/bench.err
+bash tools/pmc_any.sh ${TAG}_mpc "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" $R/tools/mpc_run_bench.py 65536 10 > $O/pmc_mpc.txt 2>&1
+python3 bench.py --gpus 2 --share-gpu --steps 5 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_share_gpu2_fused.json 2>> $O/bench.err
+python3 bench.py --gpus 2 --share-gpu --mode train --steps 10 --warmup 2 --cpu-seconds 0 > $O/bench_share_gpu2_train.json 2>> $O/bench.err
+for e in "" "OS_TRAIN_DBG_NOSAVE=1" "OS_DW_DBG=1"; do env $e python3 bench.py --mode train --steps 20 --cpu-seconds 0 > $O/bench_train_ablation_${e%%=*}.json 2>> $O/bench.err; done
 ls $O
