@@ -33,10 +33,13 @@ SCRATCH_FREE = {
     "osg::gru_layer_stage_kernel<2>": "GRU(60,64,4) layers 1..3 at the headline batch",
     "osg::gru_layer_ahead_kernel": "training / windows forward, H = 128, one tile per CU",
     "osf::fused_kf_gru_kernel_v2<false, true>": "the same with a full-matrix Q",
-    "osg::gru_layer_split_kernel<4, false>": "H = 128 small batches",
-    "osg::gru_layer_split_kernel<4, true>": "H = 128 small batches, training forward",
-    "osg::gru_layer_split_kernel<2, false>": "H = 64 small batches",
-    "osg::gru_layer_split_kernel<2, true>": "H = 64 small batches, training forward",
+    "osg::gru_layer_split_kernel<4, false, false>": "H = 128 small batches",
+    "osg::gru_layer_split_kernel<4, true, false>": "H = 128 small batches, training forward",
+    "osg::gru_layer_split_kernel<2, false, false>": "H = 64 small batches",
+    "osg::gru_layer_split_kernel<2, true, false>": "H = 64 small batches, training forward",
+    "osg::gru_layer_split_kernel<4, false, true>": "window-stream inference, layer 0 of RNN(188,128,4) (os_gru_forward_windows)",
+    "osg::gru_gi_kernel<1>": "window-stream inference: rows . W_ih^T once per row",
+    "osg::gru_gi_kernel<2>": "the same, 64-row tiles",
     "osg::gru_stack_kernel<4, false>": "the reference's own windows (B = 1 / 64), H = 128",
     "osg::gru_stack_kernel<4, true>": "batch-64 training forward (gru/gru_train.py:36)",
     "osg::gru_stack_kernel<2, false>": "layer-pipelined stack, H = 64",
