@@ -343,7 +343,14 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
     L.i = L.v / NPS; L.c = L.v % 3; L.ls = L.v / 3;
     {
         const int rank = (L.v % NPS) / 3;
-        L.leg = rank == 0 ? legs[0] : (rank == 1 ? legs[1] : (rank == 2 ? legs[2] : legs[3]));
+        // (one select at a time, opaque in between: as a chain hipcc turns it into legs[rank] on a copy of legs in scratch)
+        int lg = legs[0];
+        if (rank == 1) lg = legs[1];
+        asm volatile("" : "+v"(lg));
+        if (rank == 2) lg = legs[2];
+        asm volatile("" : "+v"(lg));
+        if (rank >= 3) lg = legs[3];
+        L.leg = lg;
     }
 
     // ---- problem data (wave-uniform) ----
@@ -368,8 +375,12 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         (void)R;
         double px = p[0], py = p[1], pz = p[2];
 #pragma unroll
-        for (int l = 1; l < 4; l++)
+        for (int l = 1; l < 4; l++) {
             if (L.leg == l) { px = p[3 * l]; py = p[3 * l + 1]; pz = p[3 * l + 2]; }
+            // (opaque between the selects: hipcc otherwise turns the chain into p[3 * leg + c] on a 96-byte copy of p in SCRATCH --
+            // the 112 B per lane every solver instance carried, code-object metadata round 5)
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+        }
         const double wx = Rm[0] * px + Rm[1] * py + Rm[2] * pz, wy = Rm[3] * px + Rm[4] * py + Rm[5] * pz,
                      wz = Rm[6] * px + Rm[7] * py + Rm[8] * pz;
         double cr[3];                                  // pw x e_c

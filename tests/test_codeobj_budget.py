@@ -51,7 +51,14 @@ SCRATCH_FREE = {
     "ost::bwd_sweep_kernel<1, 8, 0>": "training backward sweep",
     # PENDING "ost::bwd_sweep_stack_kernel": "batch-64 training backward (gru/gru_train.py:36)",
     # estimate_state_mpc -- the reference's real loop
-    # PENDING "osm::kf_mpc_persistent_kernel<1>": "estimate_state_mpc at the reference's shape (B < 8 CUs)",
+    # NOT HELD: "osm::kf_mpc_persistent_kernel<1>" (estimate_state_mpc at the reference's shape): 172 B = the callee-saved VGPRs of the QP
+    # call's ABI, written at call entry and read back at its exit, nothing inside a loop body; the two ways around the call that were
+    # built and measured (all four solver instances inlined in a QP wave: 460 registers, 44 us per step against 33; one QP wave per
+    # leg count: 5 waves, 256-register cap, spills) are slower -- DESIGN.md section 4.5
+    "osm::mpc_solve_kernel<1>": "the force QP (os_mpc_solve, the launch sequence of os_kf_mpc_run), one leg on the ground",
+    "osm::mpc_solve_kernel<2>": "the same, trot (two legs)",
+    "osm::mpc_solve_kernel<3>": "three legs",
+    "osm::mpc_solve_kernel<4>": "four legs",
     "osk::kf_dense_rows_kernel<false, false, false>": "predict_mpc covariance + batch update, float64, 16 lanes per trajectory",
     "osk::kf_dense_rows_kernel<true, false, false>": "the same with the sequential update (diagonal R)",
     "osk::kf_dense_rows_kernel<false, true, false>": "batch update with P_trace / K_gain outputs",
