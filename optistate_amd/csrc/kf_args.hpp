@@ -301,5 +301,10 @@ __device__ __forceinline__ void quad_sum6(float &a, float &b, float &c, float &d
 hipError_t launch_kf_rows2(const KfRunArgs &a, const float *qmat, bool feat, bool aux, hipStream_t s);
 // kf_dense_rows.hip: the predict_mpc (dense F_d) filter in float64, 16 lanes per trajectory; qr = Q (144) | R (100) on the device
 hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s);
+// the batched single-step pieces on the same layout (P as float, or double with OS_KF_P_FLOAT64)
+hipError_t launch_kf_predict_rows(int B, float *p, const float *f, const float *body_ref, float *x, void *P, bool p64, float *ptrace_out,
+                                  const KfConst &k, const float *qr, bool dense, hipStream_t s);
+hipError_t launch_kf_update_rows(int B, const float *z, float *x, void *P, void *K_out, bool p64, float *ptrace_out, float *kgain_out,
+                                 int32_t *status, const KfConst &k, const float *qr, bool seq, hipStream_t s);
 
 }  // namespace osk

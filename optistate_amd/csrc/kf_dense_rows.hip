@@ -161,6 +161,169 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The batched single-step pieces of the C-ABI (os_kf_predict / os_kf_update: Engine.kf_predict / kf_update, the Q / R fitter of
+// pipeline.fit_noise_covariances) on the same row layout, float64 inside whatever the storage type of P (PT = float or, with
+// OS_KF_P_FLOAT64, double).  They replace the one-trajectory-per-lane kf_predict_kernel / kf_update_kernel (190-616 spilled VGPRs).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool DENSE, typename PT>
+__global__ __launch_bounds__(256, 2) void kf_predict_rows_kernel(int B_, float *p, const float *f, const float *body_ref, float *x, PT *Pm,
+                                                                float *ptrace_out, const KfConst k, const float *__restrict__ qr)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+    const int b_raw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + grp;
+    const bool live = b_raw < B_;
+    const int b = live ? b_raw : B_ - 1;
+    const int rr = r < 12 ? r : 11;
+    const size_t B = (size_t)B_;
+    float xr = x[(size_t)rr * B + b];
+    double P[NS], qrow[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) { P[j] = (double)Pm[(size_t)(rr * NS + j) * B + b]; qrow[j] = (double)qr[rr * NS + j]; }
+    StepIn in;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { in.p[i] = p[(size_t)i * B + b]; in.f[i] = f[(size_t)i * B + b]; in.dp[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.imu[i] = 0.f;
+    in.contact = 0u;
+    float bref[3] = {0.f, 0.f, 0.f};
+    if (DENSE) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) bref[i] = body_ref[(size_t)i * B + b];
+    }
+    double one = 1.0;
+    asm volatile("" : "+v"(one));
+    float xs[NS], pw[12];
+    gather_state(xr, xs);
+    // sincos shared over the lanes: prior attitude on lanes 0..2, body_ref attitude on lanes 6..8
+    float sv, cv;
+    sincos_f32(r < 3 ? xr : r == 6 ? bref[0] : r == 7 ? bref[1] : bref[2], &sv, &cv);
+    const Rot rot = rotation_sc(bc32<0>(sv), bc32<0>(cv), bc32<1>(sv), bc32<1>(cv), bc32<2>(sv), bc32<2>(cv));
+    double cf[6];
+    if (DENSE) {
+        const Rot rbr = rotation_sc(bc32<6>(sv), bc32<6>(cv), bc32<7>(sv), bc32<7>(cv), bc32<8>(sv), bc32<8>(cv));
+        float rbn = rbr.m[0];
+#pragma unroll
+        for (int n = 1; n < 9; n++) rbn = (r == n) ? rbr.m[3 * (n % 3) + n / 3] : rbn;
+        const double en = expm1((double)k.dt * (double)rbn), ed = expm1((double)k.dt);
+        double e[9];
+        e[0] = bc64<0>(en); e[1] = bc64<1>(en); e[2] = bc64<2>(en); e[3] = bc64<3>(en); e[4] = bc64<4>(en);
+        e[5] = bc64<5>(en); e[6] = bc64<6>(en); e[7] = bc64<7>(en); e[8] = bc64<8>(en);
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            cf[kk] = r == 0 ? e[kk] : r == 1 ? e[3 + kk] : r == 2 ? e[6 + kk] : 0.0;
+            cf[3 + kk] = (r == 3 + kk) ? ed : 0.0;
+        }
+        predict_dense_row(P, qrow, e, ed, cf, one);
+    } else {
+        double g[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = (double)k.dt * (double)rot.m[3 * kk + i];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            cf[kk] = r == 0 ? g[kk] : r == 1 ? g[3 + kk] : r == 2 ? g[6 + kk] : 0.0;
+            cf[3 + kk] = (r == 3 + kk) ? (double)k.dt : 0.0;
+        }
+        predict_struct_row(P, qrow, g, (double)k.dt, cf);
+    }
+    dynamics(xs, rot, in.p, in.f, pw, k);
+    float xn = xs[0], pv = pw[0];
+#pragma unroll
+    for (int i = 1; i < NS; i++) { xn = (rr == i) ? xs[i] : xn; pv = (rr == i) ? pw[i] : pv; }
+    const float tr = ptrace_out ? ptrace_rows(P, one) : 0.f;            // (wave-uniform branch: every lane takes part)
+    if (live && r < 12) {
+        x[(size_t)r * B + b] = xn;
+        p[(size_t)r * B + b] = pv;                                      // the foot positions rotated in place (force_controller.py:274-277)
+#pragma unroll
+        for (int j = 0; j < NS; j++) Pm[(size_t)(r * NS + j) * B + b] = (PT)P[j];
+        if (r == 0 && ptrace_out) ptrace_out[b] = tr;
+    }
+}
+
+template <bool SEQ, typename PT>
+__global__ __launch_bounds__(256, 2) void kf_update_rows_kernel(int B_, const float *z, float *x, PT *Pm, PT *K_out, float *ptrace_out,
+                                                               float *kgain_out, int32_t *status, const KfConst k, const float *__restrict__ qr)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+    const int b_raw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + grp;
+    const bool live = b_raw < B_;
+    const int b = live ? b_raw : B_ - 1;
+    const int rr = r < 12 ? r : 11, am = row_measurement(r);
+    const size_t B = (size_t)B_;
+    double P[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) P[j] = (double)Pm[(size_t)(rr * NS + j) * B + b];
+    float zz[NM];
+#pragma unroll
+    for (int i = 0; i < NM; i++) zz[i] = z[(size_t)i * B + b];
+    double xd = (double)x[(size_t)rr * B + b], one = 1.0;
+    asm volatile("" : "+v"(one));
+    double K[NM], rrow[NM];
+    int st;
+    float kg;
+    if (SEQ) {
+#pragma unroll
+        for (int q = 0; q < NM; q++) rrow[q] = (double)k.R[q * NM + q];
+        st = update_seq_row(xd, P, zz, rrow);
+        kg = kgain_posterior_rows(P, rrow);
+        // K = P+ H^T R^-1 (diagonal R): the batch gain from the posterior, this lane's row
+        for_sel([&](auto A, auto SA) { K[decltype(A)::v] = P[decltype(SA)::v] * rcp64(rrow[decltype(A)::v]); });
+    } else {
+#pragma unroll
+        for (int q = 0; q < NM; q++)                    // symmetrised, as update_batch forms S
+            rrow[q] = am >= 0 ? (double)(0.5f * (qr[144 + am * NM + q] + qr[144 + q * NM + am])) : 0.0;
+        st = update_batch_row<true>(xd, P, zz, rrow, K, one, &kg);
+    }
+    const float xo = (float)xd;
+    if (!(xo * 0.f == 0.f)) st |= 2;
+    st |= __shfl_xor(st, 1, 64); st |= __shfl_xor(st, 2, 64); st |= __shfl_xor(st, 4, 64); st |= __shfl_xor(st, 8, 64);
+    const float tr = ptrace_out ? ptrace_rows(P, one) : 0.f;
+    if (live && r < 12) {
+        x[(size_t)r * B + b] = xo;
+#pragma unroll
+        for (int j = 0; j < NS; j++) Pm[(size_t)(r * NS + j) * B + b] = (PT)P[j];
+        if (K_out) {
+#pragma unroll
+            for (int a = 0; a < NM; a++) K_out[(size_t)(r * NM + a) * B + b] = (PT)K[a];
+        }
+        if (r == 0) {
+            if (ptrace_out) ptrace_out[b] = tr;
+            if (kgain_out) kgain_out[b] = kg;
+            if (status) status[b] = st;
+        }
+    }
+}
+
+hipError_t launch_kf_predict_rows(int B, float *p, const float *f, const float *body_ref, float *x, void *P, bool p64, float *ptrace_out,
+                                  const KfConst &k, const float *qr, bool dense, hipStream_t s)
+{
+    dim3 grid((B + 15) / 16), block(256);
+    if (p64) {
+        if (dense) hipLaunchKernelGGL((kf_predict_rows_kernel<true, double>), grid, block, 0, s, B, p, f, body_ref, x, (double *)P, ptrace_out, k, qr);
+        else hipLaunchKernelGGL((kf_predict_rows_kernel<false, double>), grid, block, 0, s, B, p, f, body_ref, x, (double *)P, ptrace_out, k, qr);
+    } else {
+        if (dense) hipLaunchKernelGGL((kf_predict_rows_kernel<true, float>), grid, block, 0, s, B, p, f, body_ref, x, (float *)P, ptrace_out, k, qr);
+        else hipLaunchKernelGGL((kf_predict_rows_kernel<false, float>), grid, block, 0, s, B, p, f, body_ref, x, (float *)P, ptrace_out, k, qr);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_kf_update_rows(int B, const float *z, float *x, void *P, void *K_out, bool p64, float *ptrace_out, float *kgain_out,
+                                 int32_t *status, const KfConst &k, const float *qr, bool seq, hipStream_t s)
+{
+    dim3 grid((B + 15) / 16), block(256);
+    if (p64) {
+        if (seq) hipLaunchKernelGGL((kf_update_rows_kernel<true, double>), grid, block, 0, s, B, z, x, (double *)P, (double *)K_out, ptrace_out, kgain_out, status, k, qr);
+        else hipLaunchKernelGGL((kf_update_rows_kernel<false, double>), grid, block, 0, s, B, z, x, (double *)P, (double *)K_out, ptrace_out, kgain_out, status, k, qr);
+    } else {
+        if (seq) hipLaunchKernelGGL((kf_update_rows_kernel<true, float>), grid, block, 0, s, B, z, x, (float *)P, (float *)K_out, ptrace_out, kgain_out, status, k, qr);
+        else hipLaunchKernelGGL((kf_update_rows_kernel<false, float>), grid, block, 0, s, B, z, x, (float *)P, (float *)K_out, ptrace_out, kgain_out, status, k, qr);
+    }
+    return hipGetLastError();
+}
+
 // host side: picks the instantiation (kf_kernels.hip: os_kf_run_impl)
 hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s)
 {

@@ -25,22 +25,25 @@ __device__ __forceinline__ double bc64(double v)
 template <int SRC, bool NOP = true>
 __device__ __forceinline__ void fmacb(double &acc, double src, double m)
 {
-    if (NOP) asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(SRC));
-    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(SRC));
+    if (NOP) asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(SRC));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(SRC));
 }
+// (the accumulators of the multi-instruction statements are EARLY-CLOBBER operands: an accumulator initialised with the value of the
+// broadcast source -- M[j] = P[j] in predict_struct_row -- must not share its register, or a later member of the statement reads, in
+// other lanes, a register the earlier members have just written)
 #define OSD_F(acc, src, m, S) "v_fmac_f64_dpp %" #acc ", %" #src ", %" #m " row_newbcast:" #S " row_mask:0xf bank_mask:0xf\n"
 // acc += sum over lanes 0..11 of the row of src (m = 1.0 in a register: a DPP instruction takes no inline constant)
 __device__ __forceinline__ void rowsum12(double &acc, double src, double one)
 {
     asm volatile("s_nop 1\n" OSD_F(0, 1, 2, 0) OSD_F(0, 1, 2, 1) OSD_F(0, 1, 2, 2) OSD_F(0, 1, 2, 3) OSD_F(0, 1, 2, 4) OSD_F(0, 1, 2, 5)
                  OSD_F(0, 1, 2, 6) OSD_F(0, 1, 2, 7) OSD_F(0, 1, 2, 8) OSD_F(0, 1, 2, 9) OSD_F(0, 1, 2, 10) OSD_F(0, 1, 2, 11)
-                 : "+v"(acc) : "v"(src), "v"(one));
+                 : "+&v"(acc) : "v"(src), "v"(one));
 }
 // acc += sum_k cf[k] * (src of lane 6 + k): row i of E applied to a column held one entry per lane (rows 6..11)
 __device__ __forceinline__ void ecomb6(double &acc, double src, const double *cf)
 {
     asm volatile("s_nop 1\n" OSD_F(0, 1, 2, 6) OSD_F(0, 1, 3, 7) OSD_F(0, 1, 4, 8) OSD_F(0, 1, 5, 9) OSD_F(0, 1, 6, 10) OSD_F(0, 1, 7, 11)
-                 : "+v"(acc) : "v"(src), "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]));
+                 : "+&v"(acc) : "v"(src), "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]));
 }
 // P[j] += (P[j] of lane S) * m for the twelve entries of the lane's row: the rank-1 update of a sequential measurement
 template <int S>
@@ -58,7 +61,7 @@ __device__ __forceinline__ void kdot_sel(double &acc, double src, const double *
 {
     asm volatile("s_nop 1\n" OSD_F(0, 1, 2, 0) OSD_F(0, 1, 3, 1) OSD_F(0, 1, 4, 2) OSD_F(0, 1, 5, 5) OSD_F(0, 1, 6, 6) OSD_F(0, 1, 7, 7)
                  OSD_F(0, 1, 8, 8) OSD_F(0, 1, 9, 9) OSD_F(0, 1, 10, 10) OSD_F(0, 1, 11, 11)
-                 : "+v"(acc) : "v"(src), "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]),
+                 : "+&v"(acc) : "v"(src), "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]),
                    "v"(K[8]), "v"(K[9]));
 }
 
@@ -138,7 +141,7 @@ __device__ __forceinline__ float kgain_rows(const double (&K)[NM], double one)
     double t = 0.0;
     asm volatile("s_nop 1\n" OSD_F(0, 1, 11, 0) OSD_F(0, 2, 11, 1) OSD_F(0, 3, 11, 2) OSD_F(0, 4, 11, 3) OSD_F(0, 5, 11, 4) OSD_F(0, 6, 11, 5)
                  OSD_F(0, 7, 11, 6) OSD_F(0, 8, 11, 7) OSD_F(0, 9, 11, 8) OSD_F(0, 10, 11, 9)
-                 : "+v"(t) : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "v"(K[8]), "v"(K[9]), "v"(one));
+                 : "+&v"(t) : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "v"(K[8]), "v"(K[9]), "v"(one));
     return (float)t;
 }
 // ---- batch update as the reference writes it: S = H P H^T + R, K = P H^T S^-1, x += K y, P -= K H P ----
@@ -234,6 +237,26 @@ __device__ __forceinline__ double group_sum12(double v, double one)
 }
 
 
+// ---- covariance predict of predict(p, f) (kalman_filter.py:124-135) on the row layout: F_d = I + G with G[0:3,6:9] = dt R^T,
+// G[3:6,9:12] = dt I -- the sparsity of E above.  M = P + G P (the lane's row of G over the source rows 6..11 is cf), then
+// P' = M + M G^T + Q in-lane.  g[3 i + k] = dt R[k][i].
+__device__ __forceinline__ void predict_struct_row(double *P, const double *qrow, const double *g, double dt, const double *cf)
+{
+    double M[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        M[j] = P[j];
+        ecomb6(M[j], P[j], cf);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        P[j] = M[j] + qrow[j] + (g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8]);
+        P[3 + j] = M[3 + j] + qrow[3 + j] + dt * M[9 + j];
+    }
+#pragma unroll
+    for (int j = 6; j < NS; j++) P[j] = M[j] + qrow[j];
+}
+
 // The replicated prior state from the lanes' own components
 __device__ __forceinline__ void gather_state(float xr, float *x /*12*/)
 {
@@ -291,7 +314,7 @@ __device__ __forceinline__ float ptrace_rows(const double (&P)[NS], double one)
     double t = 0.0;
     asm volatile("s_nop 1\n" OSD_F(0, 1, 13, 0) OSD_F(0, 2, 13, 1) OSD_F(0, 3, 13, 2) OSD_F(0, 4, 13, 3) OSD_F(0, 5, 13, 4) OSD_F(0, 6, 13, 5)
                  OSD_F(0, 7, 13, 6) OSD_F(0, 8, 13, 7) OSD_F(0, 9, 13, 8) OSD_F(0, 10, 13, 9) OSD_F(0, 11, 13, 10) OSD_F(0, 12, 13, 11)
-                 : "+v"(t) : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]), "v"(P[7]), "v"(P[8]), "v"(P[9]),
+                 : "+&v"(t) : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]), "v"(P[7]), "v"(P[8]), "v"(P[9]),
                    "v"(P[10]), "v"(P[11]), "v"(one));
     return (float)t;
 }

@@ -463,80 +463,7 @@ __global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uin
     for (int i = 0; i < NM; i++) z[(size_t)i * B + b] = zz[i];
 }
 
-template <bool DENSE, typename PT>
-__global__ __launch_bounds__(64, 1) void kf_predict_kernel(int B, float *p, const float *f, const float *body_ref,
-                                                           float *x, PT *P, float *ptrace_out, const KfConst k)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float xx[NS], pp[12], ff[12], pw[12];
-    PT PP[NS * NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) xx[i] = x[(size_t)i * B + b];
-#pragma unroll
-    for (int i = 0; i < NS * NS; i++) PP[i] = P[(size_t)i * B + b];
-#pragma unroll
-    for (int i = 0; i < 12; i++) { pp[i] = p[(size_t)i * B + b]; ff[i] = f[(size_t)i * B + b]; }
-    Rot r = rotation(xx[0], xx[1], xx[2]);
-    if (DENSE) {
-        Rot rb = rotation(body_ref[b], body_ref[(size_t)B + b], body_ref[(size_t)2 * B + b]);
-        cov_predict_dense(PP, rb, k);
-    } else {
-        cov_predict<false, PT>(PP, r, k);
-    }
-    dynamics(xx, r, pp, ff, pw, k);
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[(size_t)i * B + b] = xx[i];
-#pragma unroll
-    for (int i = 0; i < NS * NS; i++) P[(size_t)i * B + b] = PP[i];
-#pragma unroll
-    for (int i = 0; i < 12; i++) p[(size_t)i * B + b] = pw[i];
-    if (ptrace_out) ptrace_out[b] = trace12(PP);
-}
-
-template <bool SEQ, typename PT>
-__global__ __launch_bounds__(64, 1) void kf_update_kernel(int B, const float *z, float *x, PT *P, PT *K_out,
-                                                          float *ptrace_out, float *kgain_out, int32_t *status,
-                                                          const KfConst k)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float xx[NS], zz[NM];
-    PT PP[NS * NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) xx[i] = x[(size_t)i * B + b];
-#pragma unroll
-    for (int i = 0; i < NS * NS; i++) PP[i] = P[(size_t)i * B + b];
-#pragma unroll
-    for (int i = 0; i < NM; i++) zz[i] = z[(size_t)i * B + b];
-    int st;
-    float kg = 0.f;
-    if (SEQ) {
-        st = update_sequential(xx, PP, zz, k);
-        kg = kgain_from_posterior(PP, k);
-        if (K_out) {                                   // K = P+ H^T R^-1 (diagonal R): the batch gain from the posterior
-#pragma unroll
-            for (int i = 0; i < NS; i++)
-#pragma unroll
-                for (int a = 0; a < NM; a++) K_out[(size_t)(i * NM + a) * B + b] = PP[i * NS + SEL[a]] / (PT)k.R[a * NM + a];
-        }
-    } else {
-        PT K[NS * NM];
-        st = update_batch<true, PT>(xx, PP, zz, k, K, &kg);
-        if (K_out) {
-#pragma unroll
-            for (int i = 0; i < NS * NM; i++) K_out[(size_t)i * B + b] = K[i];
-        }
-    }
-    st |= finite_status(xx);
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[(size_t)i * B + b] = xx[i];
-#pragma unroll
-    for (int i = 0; i < NS * NS; i++) P[(size_t)i * B + b] = PP[i];
-    if (ptrace_out) ptrace_out[b] = trace12(PP);
-    if (kgain_out) kgain_out[b] = kg;
-    if (status) status[b] = st;
-}
+// (kf_predict / kf_update: kf_dense_rows.hip, 16 lanes per trajectory, float64 inside)
 
 // ---- layout helpers: [B][T][F] <-> [T][F][B] through a 32x32 LDS tile (coalesced on both sides) ----
 __global__ void pack_btf_to_tfb(int B, int TF, const float *__restrict__ src, float *__restrict__ dst)
@@ -730,15 +657,8 @@ int os_kf_predict(os_ctx *ctx, int32_t B, float *p, const float *f, const float 
     const bool dense = flags & OS_KF_DENSE_FD;
     if (dense && !body_ref) return os_fail(ctx, -2, "os_kf_predict: OS_KF_DENSE_FD needs body_ref");
     OS_HIP(ctx, hipSetDevice(ctx->device));
-    dim3 grid((B + 63) / 64), block(64);
-    hipStream_t s = (hipStream_t)stream;
-    if (flags & OS_KF_P_FLOAT64) {
-        double *P64 = reinterpret_cast<double *>(P);
-        if (dense) hipLaunchKernelGGL((kf_predict_kernel<true, double>), grid, block, 0, s, B, p, f, body_ref, x, P64, ptrace_out, ctx->k);
-        else hipLaunchKernelGGL((kf_predict_kernel<false, double>), grid, block, 0, s, B, p, f, body_ref, x, P64, ptrace_out, ctx->k);
-    } else if (dense) hipLaunchKernelGGL((kf_predict_kernel<true, float>), grid, block, 0, s, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
-    else hipLaunchKernelGGL((kf_predict_kernel<false, float>), grid, block, 0, s, B, p, f, body_ref, x, P, ptrace_out, ctx->k);
-    OS_HIP(ctx, hipGetLastError());
+    OS_HIP(ctx, launch_kf_predict_rows(B, p, f, body_ref, x, P, (flags & OS_KF_P_FLOAT64) != 0, ptrace_out, ctx->k, (const float *)ctx->kf_qr, dense,
+                                        (hipStream_t)stream));
     return 0;
 }
 
@@ -750,15 +670,8 @@ int os_kf_update(os_ctx *ctx, int32_t B, const float *z, float *x, float *P, flo
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE;
     if (seq && !ctx->r_is_diagonal) return os_fail(ctx, -3, "os_kf_update: sequential update needs a diagonal R");
     OS_HIP(ctx, hipSetDevice(ctx->device));
-    dim3 grid((B + 63) / 64), block(64);
-    hipStream_t s = (hipStream_t)stream;
-    if (flags & OS_KF_P_FLOAT64) {
-        double *P64 = reinterpret_cast<double *>(P), *K64 = reinterpret_cast<double *>(K_out);
-        if (seq) hipLaunchKernelGGL((kf_update_kernel<true, double>), grid, block, 0, s, B, z, x, P64, K64, ptrace_out, kgain_out, status, ctx->k);
-        else hipLaunchKernelGGL((kf_update_kernel<false, double>), grid, block, 0, s, B, z, x, P64, K64, ptrace_out, kgain_out, status, ctx->k);
-    } else if (seq) hipLaunchKernelGGL((kf_update_kernel<true, float>), grid, block, 0, s, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
-    else hipLaunchKernelGGL((kf_update_kernel<false, float>), grid, block, 0, s, B, z, x, P, K_out, ptrace_out, kgain_out, status, ctx->k);
-    OS_HIP(ctx, hipGetLastError());
+    OS_HIP(ctx, launch_kf_update_rows(B, z, x, P, K_out, (flags & OS_KF_P_FLOAT64) != 0, ptrace_out, kgain_out, status, ctx->k, (const float *)ctx->kf_qr, seq,
+                                       (hipStream_t)stream));
     return 0;
 }
 

@@ -55,6 +55,14 @@ SCRATCH_FREE = {
     # call's ABI, written at call entry and read back at its exit, nothing inside a loop body; the two ways around the call that were
     # built and measured (all four solver instances inlined in a QP wave: 460 registers, 44 us per step against 33; one QP wave per
     # leg count: 5 waves, 256-register cap, spills) are slower -- DESIGN.md section 4.5
+    "osk::kf_predict_rows_kernel<true, float>": "Engine.kf_predict with body_ref: the Q / R fitter's predict_mpc batch (pipeline.fit_noise_covariances)",
+    "osk::kf_predict_rows_kernel<false, float>": "Engine.kf_predict (os_kf_predict)",
+    "osk::kf_predict_rows_kernel<true, double>": "the split predict_mpc -> update sequence with a float64 P (OS_KF_P_FLOAT64)",
+    "osk::kf_predict_rows_kernel<false, double>": "os_kf_predict, float64 P",
+    "osk::kf_update_rows_kernel<false, float>": "Engine.kf_update, batch form (os_kf_update)",
+    "osk::kf_update_rows_kernel<true, float>": "Engine.kf_update, sequential form",
+    "osk::kf_update_rows_kernel<false, double>": "os_kf_update, float64 P, batch form",
+    "osk::kf_update_rows_kernel<true, double>": "os_kf_update, float64 P, sequential form",
     "osm::mpc_solve_kernel<1>": "the force QP (os_mpc_solve, the launch sequence of os_kf_mpc_run), one leg on the ground",
     "osm::mpc_solve_kernel<2>": "the same, trot (two legs)",
     "osm::mpc_solve_kernel<3>": "three legs",
