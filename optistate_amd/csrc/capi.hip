@@ -68,7 +68,6 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_VIT_MLP_BM"); c->tune_vit_mlp_bm = e ? atoi(e) : 64;
         e = getenv("OS_SWEEP_WR"); c->tune_sweep_wr = e ? atoi(e) : 32;
         e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
-        e = getenv("OS_FUSED_V1"); c->tune_fused_v1 = e ? atoi(e) : 0;
         // weight-gradient kernels on a side stream underneath the next layer's sweep: unset = where CUs are idle and the launches are long
         // (gru_train_kernels.hip); 8,192 windows: measured, no gain (both kernels are bound by the shared fp32 pipe); 0 / 1 force it off / on
         e = getenv("OS_TRAIN_OVERLAP"); c->tune_train_overlap = e ? atoi(e) : -1;

@@ -37,213 +37,6 @@ struct FusedArgs {
     float *h_last;             // v2 only: h_T [64][B] for the trailing head launch (when seq_out == nullptr)
 };
 
-// (v - min) * (1 / (max - min)); norm_prep_kernel forms [min | 1/(max-min)] once per call (IEEE division), the fused
-// kernel reads them with scalar loads (uniform address), so each feature costs one v_sub and one v_mul
-__device__ __forceinline__ float norm_feat(const float *__restrict__ nrm, int j, float v) { return (v - nrm[j]) * nrm[60 + j]; }
-
-__global__ void norm_prep_kernel(const float *minmax, float *nrm)
-{
-    const int j = threadIdx.x;
-    if (j < 60) {
-        nrm[j] = minmax[j];
-        nrm[60 + j] = 1.0f / (minmax[60 + j] - minmax[j]);
-    }
-}
-
-template <bool QDIAG>
-__global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel(const FusedArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    float *W = lds;
-    float *hl = lds + 2 * CHF + wave * 64 * HS;
-    const KfRunArgs &k = a.kf;
-    const size_t B = (size_t)k.B;
-
-    // ---- one-time staging: weights -> LDS (coalesced float4), h0 = 0 ----
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.wpacked);
-        float4 *dst = reinterpret_cast<float4 *>(W);
-        for (int i = threadIdx.x; i < 2 * CHF / 4; i += 256) dst[i] = src[i];
-        for (int i = lane; i < 64 * HS; i += 64) hl[i] = 0.f;
-    }
-    __syncthreads();
-    const float *__restrict__ nrm = a.nrm;
-
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const bool live = b < k.B;
-    const int bb = live ? b : k.B - 1;                 // dead lanes shadow the last trajectory, stores masked
-    const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
-
-    float x[NS], U[NT];
-    int status;
-    {
-        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
-#pragma unroll
-        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
-        // status bit 3: P0 not symmetric (only the upper triangle is read; see include/optistate_hip.h)
-        status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i; j < NS; j++) U[uidx(i, j)] = buf_load(rP, voff, (i * NS + j) * rowB);
-    }
-    constexpr float LOG2E = 1.44269504088896341f;
-
-    StepIn in;
-    float acl[6];
-    load_step(k, 0, voff, rowB, in);
-    {
-        rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
-#pragma unroll
-        for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
-    }
-
-    for (int t = 0; t < k.T; t++) {
-        // ================= Kalman step (lane = trajectory) =================
-        float z[NM], pw[12], F[KX];
-        status |= kf_step_front_tri<QDIAG>(x, U, in, k.k, z, pw);
-        status |= kf_step_back_tri(x, U, z, k.k);
-        if (live) {
-            rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
-#pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
-        }
-        // feature row [x_post | accel | f | p_world | dp | imu], normalised; built only now so that the update above does
-        // not have to keep 48 extra registers alive (the inputs stay in `in` until the prefetch inside the GRU cell)
-#pragma unroll
-        for (int i = 0; i < NS; i++) F[i] = norm_feat(nrm, i, x[i]);
-#pragma unroll
-        for (int i = 0; i < 6; i++) F[12 + i] = norm_feat(nrm, 12 + i, acl[i]);
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            F[18 + i] = norm_feat(nrm, 18 + i, in.f[i]);
-            F[30 + i] = norm_feat(nrm, 30 + i, pw[i]);
-            F[42 + i] = norm_feat(nrm, 42 + i, in.dp[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++) F[54 + i] = norm_feat(nrm, 54 + i, in.imu[i]);
-
-        // ================= GRU cell on this wave's 64 rows =================
-        // feature registers -> A fragments: after the swap, F[2kp] holds rows 0-31 (k = 2kp | 2kp+1 by lane half),
-        // F[2kp+1] holds rows 32-63
-#pragma unroll
-        for (int kp = 0; kp < KPX; kp++) {
-            // v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second.  Written as inline
-            // asm because hipcc (ROCm 7.2) drops the second result of __builtin_amdgcn_permlane32_swap in this kernel
-            // (the rows 32-63 MFMAs were folded onto rows 0-31); s_nop 1 covers the VALU->permlane->VALU wait states.
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(F[2 * kp]), "+v"(F[2 * kp + 1]));
-        }
-        float hnew0[2][16];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const float *Wc = W + c * CHF;
-            f32x16 acc[2][4];
-#pragma unroll
-            for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
-            // Explicit two-deep software pipeline over the 62 k-pairs (30 input + 32 recurrent): the B fragments (and the
-            // recurrent A fragments) of k-pair q+1 are requested from LDS before the six MFMAs of k-pair q issue, and a
-            // sched_barrier per k-pair keeps hipcc from hoisting all 372 LDS reads to the top (which spills).
-            float wb[2][3], ab[2][2];
-#pragma unroll
-            for (int g = 0; g < 3; g++) wb[0][g] = Wc[g * 64 + lane];
-#pragma unroll
-            for (int q = 0; q < KPX + KPH; q++) {
-                const int cur = q & 1, nxt = cur ^ 1;
-                if (q + 1 < KPX + KPH) {
-#pragma unroll
-                    for (int g = 0; g < 3; g++) wb[nxt][g] = Wc[((q + 1) * 3 + g) * 64 + lane];
-                    if (q + 1 >= KPX) {
-#pragma unroll
-                        for (int rb = 0; rb < 2; rb++) ab[nxt][rb] = hl[(rb * 32 + li) * HS + 2 * (q + 1 - KPX) + lh];
-                    }
-                }
-                if (c == 1 && q == KPX) {
-                    // the feature registers are dead from here on: issue step t+1's 49 input loads into the space they
-                    // free, underneath the remaining ~200 MFMAs and the cell update (one wave per SIMD: nobody else
-                    // hides the HBM latency)
-                    const int tn = (t + 1 < k.T) ? t + 1 : t;
-                    load_step(k, tn, voff, rowB, in);
-                    rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
-                }
-#pragma unroll
-                for (int rb = 0; rb < 2; rb++) {
-                    const float av = q < KPX ? F[2 * (q < KPX ? q : 0) + rb] : ab[cur][rb];
-                    const int gn = q < KPX ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
-                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[cur][0], acc[rb][0], 0, 0, 0);
-                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[cur][1], acc[rb][1], 0, 0, 0);
-                    acc[rb][gn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[cur][2], acc[rb][gn], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // cell update on the accumulator layout: col = li (hidden unit c*32+li), row = (e&3) + 8*(e>>2) + 4*lh.
-            // The four biases of this lane's column come from the LDS weight image each time (cheaper than 14 live VGPRs);
-            // three of them are folded into the exp2 arguments (-log2e * b, 2 log2e * b_in): one FMA per gate.
-            const float *bc = Wc + (KPX + KPH) * 192 + li;
-            const float nb_r = -LOG2E * bc[0], nb_z = -LOG2E * bc[32], nb_n = 2.0f * LOG2E * bc[64], b_hn = bc[96];
-#pragma unroll
-            for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float hold = hl[row * HS + c * 32 + li];
-                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][0][e], -LOG2E, nb_r)));
-                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rb][1][e], -LOG2E, nb_z)));
-                    const float u = fmaf(r, acc[rb][3][e] + b_hn, acc[rb][2][e]);
-                    const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, 2.0f * LOG2E, nb_n))), 1.0f);
-                    const float hn = fmaf(zg, hold - n, n);          // (1 - z) n + z h
-                    if (c == 0) hnew0[rb][e] = hn;            // old h[:, 0:32] is still needed by chunk 1
-                    else hl[row * HS + 32 + li] = hn;
-                }
-        }
-#pragma unroll
-        for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                hl[row * HS + li] = hnew0[rb][e];
-            }
-        // LDS operations of one wave complete in order: the next step's reads see these writes without a barrier.
-        if (a.seq_out && live) {
-            rsrc_t rs = make_rsrc(a.seq_out + (size_t)t * H * B, (uint32_t)H * rowB);
-#pragma unroll 8
-            for (int kk = 0; kk < H; kk++) buf_store(rs, voff, kk * rowB, hl[lane * HS + kk]);
-        }
-    }
-
-    // ---- final state, status, head ----
-    if (live) {
-        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
-#pragma unroll
-        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_TRI(U, i, j));
-        k.status[b] = status;
-        if (!a.seq_out) {
-            // fc + sigmoid on h_T (gru/gru_model.py:43-48), lane = trajectory
-            float hrow[H];
-#pragma unroll
-            for (int kk = 0; kk < H; kk++) hrow[kk] = hl[lane * HS + kk];
-            for (int c = 0; c < a.C; c++) {
-                float s = a.fcb[c];
-#pragma unroll
-                for (int kk = 0; kk < H; kk++) s += a.fcw[c * H + kk] * hrow[kk];
-                a.out[(size_t)b * a.C + c] = a.use_sigmoid ? osg::sigmoidf_(s) : s;
-            }
-        }
-    }
-}
-
-
 // =====================================================================================================================
 // element i = 3 leg + component of a per-leg quantity stored as leg pairs (StepInP, kf_device.hpp); state element i of the pairs
 #define OSF_LEG(v, i) (v)[((i) / 3) >> 1][(i) % 3][((i) / 3) & 1]
@@ -1051,7 +844,7 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
         const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
         return os_gru_head_launch(ctx, B, hlast, fcw, out, s);
     }
-    if (single_kernel && !ctx->tune_fused_v1) {
+    if (single_kernel) {
         // v2: transposed GRU cell, h in registers, scales folded into a per-call LDS image, head as a trailing launch
         osf::FusedArgs fa;
         fa.kf = a; fa.kf.k = ctx->k;
@@ -1083,39 +876,6 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
         const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
         return os_gru_head_launch(ctx, B, hlast, fcw, out, s);
     }
-    if (single_kernel) {
-        // round-1 kernel (h tile in LDS), kept for A/B runs (OS_FUSED_V1=1)
-        osf::FusedArgs fa;
-        fa.kf = a; fa.kf.k = ctx->k;
-        fa.wpacked = ctx->gru_packed;
-        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));
-        fa.fcw = fcw; fa.fcb = fcw + (size_t)d.num_classes * 64;
-        fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out; fa.seq_out = nullptr; fa.h_last = nullptr;
-        float *seq0 = nullptr, *seq1 = nullptr, *hlast = nullptr;
-        if (d.num_layers > 1) {
-            if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
-            fa.seq_out = seq0;
-        }
-        if (!ctx->fused_attr_set) {            // per context (= per device), not process-global
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel<true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS_BYTES));
-            ctx->fused_attr_set = true;
-        }
-        if (!ctx->nrm) OS_HIP(ctx, hipMalloc((void **)&ctx->nrm, 120 * sizeof(float)));
-        hipLaunchKernelGGL(osf::norm_prep_kernel, dim3(1), dim3(64), 0, s, minmax, ctx->nrm);
-        fa.nrm = ctx->nrm;
-        dim3 grid((B + 255) / 256), block(256);
-        const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, "fused_kf_gru_kernel");
-        if (ctx->q_is_diagonal) hipLaunchKernelGGL(osf::fused_kf_gru_kernel<true>, grid, block, osf::LDS_BYTES, s, fa);
-        else hipLaunchKernelGGL(osf::fused_kf_gru_kernel<false>, grid, block, osf::LDS_BYTES, s, fa);
-        os_prof_end(ctx, slot, s);
-        OS_HIP(ctx, hipGetLastError());
-        if (d.num_layers > 1) return os_gru_layers_impl(ctx, B, T, seq0, 1, out, nullptr, s);
-        return 0;
-    }
-
     if (n_latent > 0 && (flags & OS_FUSED_LATENT_IN_PLACE)) {
         // the caller's buffer IS the GRU input [T][I][B] (rows 60.. = latent): features written in place, nothing copied
         float *buf = const_cast<float *>(latent);

@@ -76,7 +76,6 @@ struct os_ctx {
     bool gi_attr_set;
     float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *fused_img;                         // fused v2: per-call LDS image (weights with folded scales, k order of the register-resident h)
-    int tune_fused_v1;                        // OS_FUSED_V1=1: the round-1 kernel (h in LDS) instead of v2
     bool fused2_attr_set, fusedbf_attr_set;
     float *fused_img_bf;                      // LDS image of the opt-in split-bf16 kernel
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]

@@ -13,7 +13,7 @@ from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
 B, T = int(os.environ.get("AB_B", 65536)), int(os.environ.get("AB_T", 100))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 variants, kw = {}, {}
-for name, env, kws in (("v1", {"OS_FUSED_V1": "1"}, {}), ("v2", {}, {}), ("bf3", {}, {"split_bf16": True}),
+for name, env, kws in (("v2", {}, {}), ("bf3", {}, {"split_bf16": True}),
                        ("bf2", {}, {"split_bf16": 2})):
     for e in ("OS_FUSED_V1", "OS_BF16_TERMS"):
         os.environ.pop(e, None)
