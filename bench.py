@@ -966,8 +966,8 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed passes; default 10 (windows: 100 -- a pass is 0.6 ms, ten of them time the clock ramp)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed passes; default 2 (windows: 20)")
     ap.add_argument("--batch", type=int, default=None, help="trajectories (windows) per GPU; default 65536 (windows, train: 8192)")
     ap.add_argument("--seq", type=int, default=100)
     ap.add_argument("--hidden", type=int, default=64)
@@ -1003,6 +1003,10 @@ def main(argv=None):
     a = ap.parse_args(argv)
     if a.batch is None:
         a.batch = 8192 if a.mode in ("windows", "train") else 65536
+    if a.steps is None:
+        a.steps = 100 if a.mode == "windows" else 10
+    if a.warmup is None:
+        a.warmup = 20 if a.mode == "windows" else 2
 
     # N > 1 and not yet a rank: start the ranks as a child process BEFORE anything here touches the GPU
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

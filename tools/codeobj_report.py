@@ -136,9 +136,15 @@ def main():
         rows = [r for r in rows if r["private_segment_fixed_size"] or r["vgpr_spill_count"] or r["sgpr_spill_count"]]
     md = to_markdown(rows)
     if a.md:
+        # a hand-written preamble (everything up to the line "All kernels:") survives regeneration
+        head = (f"# Register / scratch budget of every kernel in liboptistate_hip.so\n\nGenerated by `tools/codeobj_report.py` from the "
+                f"gfx950 code objects inside the library ({len(rows)} kernels).\n\n")
+        if os.path.exists(a.md):
+            old = open(a.md).read()
+            if "\nAll kernels:\n" in old:
+                head = old[:old.index("\nAll kernels:\n")] + "\nAll kernels:\n\n"
         with open(a.md, "w") as fh:
-            fh.write(f"# Register / scratch budget of every kernel in liboptistate_hip.so\n\nGenerated by `tools/codeobj_report.py` from the "
-                     f"gfx950 code objects inside the library ({len(rows)} kernels).\n\n" + md + "\n")
+            fh.write(head + md + "\n")
     print(md)
 
 
