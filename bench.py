@@ -801,6 +801,13 @@ def bench_hot_path(a, rk):
     torch.manual_seed(0)
     model = RNN(I, H, L, 24, dev)                       # random-init weights of the named architecture
     eng.load_gru(flatten_state_dict(model.state_dict(), L, dev), I, H, L, 24)
+    # --split-bf16: the single-kernel shape (GRU(60,64,1)) has its own fused bf16 kernel (os_fused_run flag); the H = 128 model
+    # shapes run their layer launches on gru_layer_bf16_kernel (os_gru_set_split_bf16); other shapes have no bf16 path
+    fused_bf16 = a.split_bf16 if (H == 64 and L == 1 and not a.latent) else 0
+    if a.split_bf16 and not fused_bf16:
+        if H != 128:
+            raise SystemExit("--split-bf16: GRU(60,64,1) (fused kernel) or hidden 128 (layer kernels)")
+        eng.set_gru_split_bf16(a.split_bf16)
     # min-max constants for the synthetic distributions (every feature lands in (0,1) like the reference's scaling)
     minmax = torch.stack([torch.full((60,), -30.0), torch.full((60,), 30.0)]).to(dev)
     x0 = d["x0"]
@@ -825,7 +832,7 @@ def bench_hot_path(a, rk):
             x.copy_(x0); P.copy_(P0)                    # device-to-device reset of the 40 MB filter state
             if fused:
                 return eng.fused_run(d["p"], d["f"], d["dp"], d["imu"], contact, d["accel"], minmax, x, P, gru_input=gru_in,
-                                     split_bf16=a.split_bf16)
+                                     split_bf16=fused_bf16)
             if a.wave_per_trajectory:       # the north_star's literal layout, measured beside the default kernels (never the default)
                 return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P, sequential=False, symmetric=False, wave_per_trajectory=True)
             return eng.kf_run(d["p"], d["f"], d["dp"], d["imu"], contact, x, P)
@@ -857,14 +864,21 @@ def bench_hot_path(a, rk):
             # the single fused kernel ran layer 0 (H = 64 stacks): the layer launches are layers 1 .. L-1
             fl = (gru_flops_per_step(I, H, L) - gru_flops_per_step(I, H, 1)) * steps_per_pass / dk["launches_per_step"]
         ach = fl / (avg_ms * 1e-3) / 1e12
-        peak = MFMA_BF16_PEAK_TF if (a.split_bf16 and dom == "fused") else MFMA_F32_PEAK_TF
+        on_bf16 = bool(a.split_bf16) and "bf16" in dk["kernel"]
+        peak = MFMA_BF16_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF
         insn = ("v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if a.split_bf16 == 3 else "v_mfma_f32_32x32x16_bf16 x3 (hi/lo split)") \
-            if (a.split_bf16 and dom == "fused") else "v_mfma_f32_32x32x2_f32"
+            if on_bf16 else "v_mfma_f32_32x32x2_f32"
         roof = {"kernel": f"{dk['kernel']} ({insn})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": fl}
-        if a.split_bf16 and dom == "fused":
+        if on_bf16 and dom == "fused":
             roof["note"] = ("algorithmic (fp32-equivalent) GRU flops against the bf16 dense peak; the kernel is VALU-bound "
                             "(Kalman step + operand splitting), not matrix-bound")
+        elif on_bf16:
+            nprod = 6 if a.split_bf16 == 3 else 3
+            roof["note"] = (f"algorithmic (fp32-equivalent) GRU flops against the bf16 dense peak; the kernel issues {nprod} bf16 products per "
+                            f"fp32 product ({nprod} x these flops on the matrix pipe = {ach * nprod / peak:.2f} of the peak), one wave per SIMD: the "
+                            "exposed cell update and the issue slots of the operand splits are the rest (DESIGN 4.2f)")
+            roof["executed_bf16_TFLOPs"] = ach * nprod
         if dom == "fused":
             gbs = BYTES_PER_STEP_FUSED * steps_per_pass / (avg_ms * 1e-3) / 1e9
             roof["hbm_algorithmic_GBps"] = gbs

@@ -226,6 +226,16 @@ int os_gru_forward_windows(os_ctx *ctx, int32_t n_rows, int32_t window, const fl
  * mode 0: a launch per layer, no progress counters. */
 int os_gru_set_stack(os_ctx *ctx, int32_t mode);
 
+/* OPT-IN reduced precision for the GRU layer GEMMs at large batches (never the default; env OS_GRU_SPLIT_BF16 = 2 | 3 at os_create).
+ * mode 0: exact fp32 (v_mfma_f32_32x32x2_f32).  mode 3 / 2: every fp32 operand of the gate GEMM of an H = 128 inference layer is
+ * split into 3 / 2 bf16 terms and the products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (gru_layer_bf16_kernel:
+ * 6 / 3 products per operand pair; 3 terms keep every product term down to 2^-16, measured GRU l-inf vs float64 in
+ * tests/test_gpu_gru_bf16.py).  Applies to layers with input width <= 188 at batches of at least 128 x CUs trajectories (mode |
+ * OS_GRU_SPLIT_ANY_BATCH: any batch that is a multiple of 4 -- tests); every other shape and the training path stay on the fp32
+ * kernels.  The reference computes this GEMM in fp32 (torch.nn.GRU, gru/gru_model.py:12); returns -4 for another mode. */
+#define OS_GRU_SPLIT_ANY_BATCH 0x100
+int os_gru_set_split_bf16(os_ctx *ctx, int32_t mode);
+
 /* The post-processing of the reference's evaluation loop (gru/gru_test.py:184-189,208-213) in one launch: out [B][2 n] = [prediction |
  * error] (normalised) -> pred = p (max - min) + min, above = (p + e) (max - min) + min, below = (p - e) (max - min) + min, each
  * [B][n]; min_v, max_v: device float[n] (the label scaling of gru/gru_train.py:59-62). */

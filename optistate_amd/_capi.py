@@ -21,6 +21,7 @@ OS_KF_WAVE_PER_TRAJECTORY = 4096
 # status word (include/optistate_hip.h): bits 0-3 are failures, bit 4 is informational
 OS_STATUS_S_NOT_PD, OS_STATUS_NONFINITE, OS_STATUS_QP_ITER, OS_STATUS_P0_ASYM, OS_STATUS_TRUNC_EDGE = 1, 2, 4, 8, 16
 OS_STATUS_FAIL_MASK = 15
+OS_GRU_SPLIT_ANY_BATCH = 0x100
 OS_ERR_STACK_LOST = -20     # a layer-pipelined launch (gru_stack_kernel / bwd_sweep_stack_kernel) lost a producer: see os_gru_set_stack
 OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD = 1, 2, 4, 8
 OS_PROF_PHASES = 12         # include/optistate_hip.h
@@ -36,7 +37,7 @@ EXPORTS = [
     "os_vit_param_count", "os_vit_load", "os_vit_encode", "os_mpc_set_weights", "os_mpc_solve", "os_kf_mpc_run",
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
     "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows", "os_gru_backward_mark",
-    "os_gru_forward_windows", "os_gru_bands", "os_gru_set_stack",
+    "os_gru_forward_windows", "os_gru_bands", "os_gru_set_stack", "os_gru_set_split_bf16",
 ]
 
 
@@ -107,6 +108,8 @@ def load():
     lib.os_gru_bands.restype = C.c_int
     lib.os_gru_set_stack.argtypes = [vp, i32]
     lib.os_gru_set_stack.restype = C.c_int
+    lib.os_gru_set_split_bf16.argtypes = [vp, i32]
+    lib.os_gru_set_split_bf16.restype = C.c_int
     lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]
     lib.os_pack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
     lib.os_unpack_stream.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]

@@ -51,6 +51,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_GRU_SPLIT"); c->tune_gru_split = e ? (atoi(e) != 0 ? -1 : 0) : -1;
         e = getenv("OS_GRU_AHEAD"); c->tune_gru_ahead = e ? atoi(e) : 1;
         e = getenv("OS_GRU_STAGE"); c->tune_gru_stage = e ? atoi(e) : 1;
+        e = getenv("OS_GRU_SPLIT_BF16"); c->gru_split_bf16 = (e && (atoi(e) == 2 || atoi(e) == 3)) ? atoi(e) : 0;
         e = getenv("OS_GRU_STACK"); c->tune_gru_stack = e ? atoi(e) : 1;
         e = getenv("OS_GRU_VEC"); c->tune_gru_vec = e ? atoi(e) : 1;
         e = getenv("OS_STACK_DBG_POLLS"); c->stack_max_polls = e && atoi(e) > 0 ? (uint32_t)atoi(e) : (1u << 22);
@@ -114,6 +115,7 @@ void os_destroy(os_ctx *ctx)
     {
         if (sl.packed) (void)hipFree(sl.packed);
         if (sl.vec) (void)hipFree(sl.vec);
+        if (sl.bf) (void)hipFree(sl.bf);
     }
     if (ctx->stack_flags) (void)hipFree(ctx->stack_flags);
     if (ctx->stack_err_host) (void)hipHostFree(ctx->stack_err_host);

@@ -445,7 +445,6 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 //      = 148,736 B (SPL = 3) / 99,584 B (SPL = 2).
 // =====================================================================================================================
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 constexpr int KBX = 4, KBH = 4, KBT = KBX + KBH;
 template <int SPL> struct Bf16Img {
     static constexpr int CH = KBT * 3 * SPL * 256;                // dwords per chunk of weight fragments
@@ -455,26 +454,7 @@ template <int SPL> struct Bf16Img {
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b)       // (low half = a, high half = b), round to nearest even
-{
-    const bf16x2_t v = __builtin_convertvector((f2){a, b}, bf16x2_t);
-    return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ float bf16_lo_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// one pair of fp32 values -> SPL dwords of packed bf16 terms (hi [, mid], lo); the remainders are exact in fp32
-template <int SPL>
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t *t)
-{
-    t[0] = pack_bf16(a, b);
-    float ra = a - bf16_lo_f32(t[0]), rb = b - bf16_hi_f32(t[0]);
-    if (SPL == 3) {
-        t[1] = pack_bf16(ra, rb);
-        ra -= bf16_lo_f32(t[1]); rb -= bf16_hi_f32(t[1]);
-    }
-    t[SPL - 1] = pack_bf16(ra, rb);
-}
+using osg::bf16_hi_f32; using osg::bf16_lo_f32; using osg::pack_bf16; using osg::split_pair;   // gru_common.hpp
 
 template <int SPL>
 __global__ void fused_pack_bf16_kernel(const float *__restrict__ w0, const float *__restrict__ minmax, uint32_t *__restrict__ img)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -21,6 +22,10 @@ struct LayerArgs {
     // ROW stream, computed once per row; trajectory b of this launch is the window starting at row b, so its step t takes row b + t
     const float *gi = nullptr;
     int gi_rows = 0;
+    // opt-in split-bf16 gate GEMM (gru_layer_bf16_kernel; null otherwise): this layer's weights as bf16 terms in the fragment
+    // order of v_mfma_f32_32x32x16_bf16, KBx = 16-wide k-blocks of the x part (rounded up to even)
+    const uint32_t *wbf = nullptr;
+    int KBx = 0;
 };
 
 __host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }
@@ -45,6 +50,30 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// ---- split-bf16 operands (opt-in reduced-precision gate GEMMs: fused_kf_gru_bf16_kernel, gru_layer_bf16_kernel) ----
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)       // (low half = a, high half = b), round to nearest even
+{
+    const bf16x2_t v = __builtin_convertvector((f2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// one pair of fp32 values -> SPL dwords of packed bf16 terms (hi [, mid], lo); the remainders are exact in fp32
+template <int SPL>
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t *t)
+{
+    t[0] = pack_bf16(a, b);
+    float ra = a - bf16_lo_f32(t[0]), rb = b - bf16_hi_f32(t[0]);
+    if (SPL == 3) {
+        t[1] = pack_bf16(ra, rb);
+        ra -= bf16_lo_f32(t[1]); rb -= bf16_hi_f32(t[1]);
+    }
+    t[SPL - 1] = pack_bf16(ra, rb);
 }
 
 }  // namespace osg

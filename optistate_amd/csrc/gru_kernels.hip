@@ -20,55 +20,13 @@
 #include <type_traits>
 #include "gru_common.hpp"
 #include "kf_device.hpp"   // buffer addressing helpers (make_rsrc / buf_load)
+#include "gru_device.hpp"  // gru_cell_pair, LDS-DMA / inline-asm LDS helpers
 
 namespace osg {
 
 using osk::buf_load;
 using osk::make_rsrc;
 using osk::rsrc_t;
-
-// Development build only (-DOS_LAYER_TS, tools/layer_ts.sh): shader-clock stamps at the phase boundaries of a step, summed over
-// the steps by thread 0 of workgroup 0 and printed (gru_layer_kernel and gru_layer_stage_kernel).
-#ifdef OS_LAYER_TS
-#define OSL_TS_DECL unsigned long long ts_prev = 0, ts_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define OSL_TS(i)                                                                  \
-    {                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-        const unsigned long long now = __builtin_readcyclecounter();               \
-        if ((i) > 0) ts_sum[i] += now - ts_prev;                                   \
-        ts_prev = now;                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-    }
-#else
-#define OSL_TS_DECL
-#define OSL_TS(i)
-#endif
-
-// The GRU cell (gru/gru_model.py:16; gate order r | z | n) for TWO elements held in adjacent accumulator registers: the eleven
-// non-transcendental operations of an element are v_pk_* instructions on the pair, the six transcendentals stay scalar.
-// a_r, a_z: W_i. x + W_h. h pre-activations without bias; a_n = W_in x; a_h = W_hn h; nb_*: biases pre-scaled for exp2
-// (-log2 e (b_ir + b_hr), -log2 e (b_iz + b_hz), 2 log2 e b_in), b_hn as it is.  Same IEEE operations as the scalar form.
-struct CellPair { osk::f2 r, z, n, ghn, hn; };
-__device__ __forceinline__ CellPair gru_cell_pair(osk::f2 a_r, osk::f2 a_z, osk::f2 a_n, osk::f2 a_h, osk::f2 hprev, float nb_r, float nb_z,
-                                                  float nb_n, float b_hn)
-{
-    using osk::f2; using osk::fma2; using osk::splat2;
-    constexpr float LOG2E = 1.44269504088896341f;
-    CellPair c;
-    const f2 tr = fma2(a_r, splat2(-LOG2E), splat2(nb_r));
-    const f2 tz = fma2(a_z, splat2(-LOG2E), splat2(nb_z));
-    const f2 dr = (f2){__builtin_amdgcn_exp2f(tr[0]), __builtin_amdgcn_exp2f(tr[1])} + splat2(1.0f);
-    const f2 dz = (f2){__builtin_amdgcn_exp2f(tz[0]), __builtin_amdgcn_exp2f(tz[1])} + splat2(1.0f);
-    c.r = (f2){__builtin_amdgcn_rcpf(dr[0]), __builtin_amdgcn_rcpf(dr[1])};
-    c.z = (f2){__builtin_amdgcn_rcpf(dz[0]), __builtin_amdgcn_rcpf(dz[1])};
-    c.ghn = a_h + splat2(b_hn);
-    const f2 u = fma2(c.r, c.ghn, a_n);
-    const f2 tn = fma2(u, splat2(2.0f * LOG2E), splat2(nb_n));
-    const f2 dn = (f2){__builtin_amdgcn_exp2f(tn[0]), __builtin_amdgcn_exp2f(tn[1])} + splat2(1.0f);
-    c.n = fma2(splat2(-2.0f), (f2){__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])}, splat2(1.0f));
-    c.hn = fma2(c.z, hprev - c.n, c.n);                 // (1 - z) n + z h
-    return c;
-}
 
 // One half of the gate GEMM (input part: XPART, accumulates gi_n into acc[.][2]; recurrent part: gh_n into acc[.][3]).
 // Software pipeline, DEPTH k-pairs deep: the B fragments (coalesced dword loads of the fragment-ordered weights,
@@ -327,35 +285,6 @@ __global__ __launch_bounds__(256, OCC) void gru_layer_kernel(const LayerArgs a)
 // matrix pipe reads an MFMA's A/B registers when the instruction starts, not when it issues.
 // Bit-identical to gru_layer_kernel: same products, same accumulation order.
 // ---------------------------------------------------------------------------------------------------------------
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// (non-template helpers: inside a kernel template hipcc's host pass drops the launch stub when it meets these builtins)
-__device__ __forceinline__ void stage_dma16(rsrc_t r, float *l, uint32_t voff, uint32_t soff)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, 0);
-}
-// seq_out stores of the stage kernel: DEFAULT cache policy, not non-temporal.  A 64-byte line of the SoA sequence (16 trajectories of
-// one hidden unit) is completed by four 16-byte stores of two lane halves within a few instructions; streamed (nt) they reached HBM as
-// partial sectors -- 4.88 GB written per launch against 2.52 GB algorithmic -- while the write-back L2 merges them: 2.525 GB, the
-// kernel's traffic 958 B per (trajectory, step) = 1.00x algorithmic, and 10.2 -> 9.9 ms per layer (profiles/r04_traffic_ref_shape.txt).
-__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-template <int OFF>
-__device__ __forceinline__ float lds_read_asm(uint32_t addr)
-{
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ void lds_write_asm(uint32_t addr, float v)
-{
-    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
 
 constexpr int STAGE_BM = 64, STAGE_DEPTH = 4;       // rows per wave pair of row blocks; k-pairs in flight
 
@@ -1619,6 +1548,7 @@ int os_gru_load_keyed(os_ctx *ctx, const os_gru_dims *d, const float *w_flat, ui
         OS_HIP(ctx, hipGetLastError());
         slot->key = key; slot->d = *d; slot->flat = w_flat;
         slot->vec_valid = vec;
+        slot->bf_spl = 0;                                       // the bf16 term image (if any) is of the previous weights
         ctx->gru_generation++;                                  // counts packs (os_gru_generation): a cache hit does not bump it
     }
     slot->stamp = ++ctx->gru_clock;
@@ -1699,7 +1629,11 @@ static bool stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nla
 {
     return nlayers <= 8 && stack_group(ctx, B, T, Kfirst, H, nlayers) == nlayers;
 }
-bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H) { return ahead_eligible(ctx, B, T, K, H); }
+bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H)
+{
+    if (ctx->gru_split_bf16 && H == 128) return false;      // the opt-in bf16 layer kernel reads the SoA stream
+    return ahead_eligible(ctx, B, T, K, H);
+}
 
 bool os_gru_stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers) { return stack_eligible(ctx, B, T, Kfirst, H, nlayers); }
 
@@ -1784,6 +1718,11 @@ int os_stack_pending(os_ctx *ctx, const char *what)
 // Launches gru_layer_kernel for one layer (shared by inference and the training forward).
 int os_gru_launch_layer(os_ctx *ctx, const LayerArgs &a, hipStream_t s)
 {
+    if (ctx->gru_split_bf16) {               // opt-in reduced precision: H = 128 inference layers at large batches (gru_bf16_kernels.hip)
+        bool done = false;
+        const int rc = os_gru_try_layer_bf16(ctx, a, s, &done);
+        if (rc || done) return rc;
+    }
     const int H = a.H, NCH = H / 32;
     const int WPC = NCH >= 4 ? 1 : 4 / NCH;
     // rows per workgroup: H = 64: RBW 2 x 2 waves/chunk = 128; H = 128: RBW 2 = 64; H = 32: RBW 1 x 4 waves/chunk = 128

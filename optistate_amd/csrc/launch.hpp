@@ -63,8 +63,12 @@ struct os_ctx {
     struct GruSlot {
         uint64_t key; os_gru_dims d; const float *flat; float *packed; size_t cap; uint64_t stamp;
         float *vec; size_t vec_cap; bool vec_valid;       // transposed image for gru_vec_kernel, packed on first use
+        float *bf; size_t bf_cap; int bf_spl;             // bf16 term image of gru_layer_bf16_kernel (dwords), built on first use; bf_spl = 0: stale
     } gru_slots[4];
     GruSlot *gru_slot;                   // the slot os_gru_load selected last
+    int gru_split_bf16;                  // os_gru_set_split_bf16 / OS_GRU_SPLIT_BF16: 0 exact fp32 (default), 2 | 3 = bf16 terms per operand in the H = 128
+                                         // large-batch layer kernel (gru_layer_bf16_kernel), | OS_GRU_SPLIT_ANY_BATCH
+    bool bf16_layer_attr_set;
     int tune_gru_vec;                    // 1: B <= 4 inference runs the whole model in one single-workgroup launch (gru_vec_kernel)
     bool vec_attr_set;
     uint64_t gru_clock;
@@ -164,6 +168,7 @@ namespace osg { struct LayerArgs; }
 size_t os_layer_packed_floats(int K, int H);
 int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats);
 int os_gru_launch_layer(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s);
+int os_gru_try_layer_bf16(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s, bool *done);   // gru_bf16_kernels.hip: the opt-in split-bf16 layer kernel
 bool os_gru_stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nlayers);   // gru_kernels.hip: small batch, all (layer, tile) workgroups resident
 int os_gru_launch_stack(os_ctx *ctx, const osg::LayerArgs *layers, int n, hipStream_t s);   // n <= 8 consecutive layers as one pipelined launch
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H);   // gru_kernels.hip: the layer kernel for this shape reads (B, T, K) inputs itself

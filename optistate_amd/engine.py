@@ -78,6 +78,13 @@ class Engine:
         self._check(self.lib.os_gru_set_stack(self._h, int(mode)), "os_gru_set_stack")
         self._stack_mode = int(mode)
 
+    def set_gru_split_bf16(self, terms, any_batch=False):
+        """OPT-IN reduced precision for the GRU layer GEMMs (never the default; the reference computes them in fp32,
+        gru/gru_model.py:12): 0 = exact fp32; 3 / 2 = every operand of an H = 128 inference layer's gate GEMM split into that many bf16
+        terms, products on the bf16 matrix instruction with fp32 accumulation (os_gru_set_split_bf16 in include/optistate_hip.h:
+        batches of at least 128 x CUs trajectories; any_batch: every batch that is a multiple of 4)."""
+        self._check(self.lib.os_gru_set_split_bf16(self._h, int(terms) | (_capi.OS_GRU_SPLIT_ANY_BATCH if any_batch else 0)), "os_gru_set_split_bf16")
+
     def _stack_guarded(self, call):
         """Runs call(); when a layer-pipelined launch reports a lost producer (StackLost: the library's bounded wait expired -- the
         producer workgroup never became resident, or another process held its CUs for seconds), runs it again with a launch per

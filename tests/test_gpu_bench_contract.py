@@ -86,3 +86,14 @@ def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
     assert w["roofline"]["algorithmic_flops_per_pass"] < w["roofline"]["flops_of_the_materialised_form"]
     wm = _run(["--mode", "windows", "--materialise", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])
     assert "materialised" in wm["config"]["form"] and wm["roofline"]["algorithmic_flops_per_pass"] == wm["roofline"]["flops_of_the_materialised_form"]
+
+
+def test_split_bf16_line_on_the_h128_layer_kernel():
+    """--split-bf16 with hidden 128: the layer launches run on gru_layer_bf16_kernel (opt-in), the line says so (dtype, kernel, bf16
+    peak) and its parity block keeps the unchanged 1e-5 GRU bar."""
+    d = _run(["--split-bf16", "3", "--hidden", "128", "--layers", "2", "--batch", "32768", "--seq", "4", "--steps", "2", "--warmup", "1",
+              "--cpu-seconds", "1", "--parity-samples", "2048"])
+    assert d["dtype"].startswith("bf16x3") and d["kernels"]["gru_layer"]["kernel"] == "gru_layer_bf16_kernel<3>"
+    ro = d["roofline"]
+    assert ro["bound"] == "mfma" and "bf16" in ro["kernel"] and ro["peak"] > 2000 and ro["executed_bf16_TFLOPs"] > ro["achieved"]
+    assert d["parity"]["gru_bar"] == 1e-5 and d["parity"]["gru_linf"] < 1e-5 and d["parity"]["ok"] is True

@@ -1,0 +1,115 @@
+"""GPU: the OPT-IN split-bf16 layer kernel (gru_layer_bf16_kernel; os_gru_set_split_bf16 / Engine.set_gru_split_bf16) against the
+float64 oracle and against the default exact-fp32 path.  The reference computes these GEMMs in fp32 (torch.nn.GRU,
+gru/gru_model.py:12): the default path's bar is 1e-5; the opt-in's measured distances are asserted here with their own bars
+(3 terms: the same 1e-5; 2 terms: 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BAR = {3: 1e-5, 2: 1e-4}
+
+
+def _model(I, H, L, C, seed=5):
+    from optistate_amd import RNN
+    torch.manual_seed(seed)
+    return RNN(I, H, L, C, torch.device("cuda")).to("cuda").eval()
+
+
+def _oracle(m, x, I, H, L, C):
+    from oracle import c_oracle as orc
+    w = orc.flatten_state_dict(m.state_dict(), L)
+    ref, _, _ = orc.gru_forward(x.numpy(), w, I, H, L, C)
+    return ref
+
+
+@pytest.mark.parametrize("spl", [3, 2])
+@pytest.mark.parametrize("I,L,B,T", [(188, 4, 512, 6), (60, 2, 388, 5), (40, 1, 132, 3), (128, 1, 256, 4)])
+def test_split_bf16_layers_vs_oracle(spl, I, L, B, T):
+    """RNN(I,128,L,24) through the bf16 layer kernel (any-batch flag: the tiles of these batches do not fill the chip): the reference's
+    188-wide input, 60 features (four k-blocks), 40 (three, padded to four: the clamped tail block), a partial tile (388, 132)."""
+    H, C = 128, 24
+    m = _model(I, H, L, C)
+    x = torch.rand(B, T, I)
+    with torch.no_grad():
+        exact = m(x.cuda()).cpu().numpy()
+    eng = m._engine                                            # (bound by the first forward)
+    eng.set_gru_split_bf16(spl, any_batch=True)
+    eng.set_stack_mode(0)                                      # (a small batch would take the layer-pipelined stack launch: a launch per layer here)
+    try:
+        with torch.no_grad():
+            out = m(x.cuda()).cpu().numpy()
+        name = eng.kernel_name("gru_layer")
+    finally:
+        eng.set_gru_split_bf16(0)
+        eng.set_stack_mode(1)
+    assert name == f"gru_layer_bf16_kernel<{spl}>", name
+    ref = _oracle(m, x, I, H, L, C)
+    err, err_exact = np.abs(out - ref).max(), np.abs(exact - ref).max()
+    print(f"split-bf16 x{spl} RNN({I},128,{L}) B={B} T={T}: l-inf vs float64 {err:.2e} (exact fp32 path {err_exact:.2e})")
+    assert np.isfinite(out).all() and err < BAR[spl], (err, err_exact)
+    with torch.no_grad():
+        again = m(x.cuda()).cpu().numpy()                      # back on the fp32 kernels: bit-identical to before
+    assert np.array_equal(again, exact)
+
+
+def test_split_bf16_is_off_by_default_and_rejects_other_modes():
+    m = _model(188, 128, 2, 24)
+    x = torch.rand(256, 3, 188).cuda()
+    with torch.no_grad():
+        m(x)
+    eng = m._engine
+    assert "bf16" not in eng.kernel_name("gru_layer")
+    with pytest.raises(RuntimeError):
+        eng.set_gru_split_bf16(1)
+    with pytest.raises(RuntimeError):
+        eng.set_gru_split_bf16(7)
+    # without the any-batch flag a batch below 128 x CUs stays on the fp32 kernels
+    eng.set_gru_split_bf16(3)
+    try:
+        with torch.no_grad():
+            m(x)
+        assert "bf16" not in eng.kernel_name("gru_layer")
+    finally:
+        eng.set_gru_split_bf16(0)
+
+
+def test_a_nan_trajectory_stays_alone():
+    """The k-blocks past the input width re-read a trajectory's OWN last input (zero weights): a NaN in one trajectory must not
+    reach its tile neighbours (K = 40: three blocks padded to four, 8 of 16 values of the third block clamped)."""
+    I, H, L, C = 40, 128, 1, 24
+    m = _model(I, H, L, C)
+    x = torch.rand(256, 4, I)
+    with torch.no_grad():
+        m(x[:4].cuda())
+    eng = m._engine
+    eng.set_gru_split_bf16(3, any_batch=True)
+    try:
+        with torch.no_grad():
+            clean = m(x.cuda()).cpu().numpy()
+            x[17, 1, I - 1] = float("nan")
+            out = m(x.cuda()).cpu().numpy()
+    finally:
+        eng.set_gru_split_bf16(0)
+    assert np.isnan(out[17]).all()
+    keep = np.ones(256, bool); keep[17] = False
+    assert np.array_equal(out[keep], clean[keep])
+
+
+def test_weights_edited_and_reloaded_rebuild_the_bf16_image():
+    m = _model(188, 128, 1, 24)
+    x = torch.rand(256, 3, 188)
+    with torch.no_grad():
+        m(x[:4].cuda())
+    eng = m._engine
+    eng.set_gru_split_bf16(3, any_batch=True)
+    try:
+        with torch.no_grad():
+            a = m(x.cuda()).cpu().numpy()
+            m.gru.weight_hh_l0.mul_(0.5)
+            b = m(x.cuda()).cpu().numpy()
+        ref = _oracle(m, x, 188, 128, 1, 24)
+    finally:
+        eng.set_gru_split_bf16(0)
+    assert np.abs(a - b).max() > 1e-4 and np.abs(b - ref).max() < 1e-5

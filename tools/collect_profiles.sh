@@ -38,6 +38,9 @@ python3 bench.py --mode train > $O/bench_train.json 2>> $O/bench.err
 python3 bench.py --mode full > $O/bench_full.json 2>> $O/bench.err
 python3 bench.py --mode windows > $O/bench_windows.json 2>> $O/bench.err
 python3 bench.py --split-bf16 > $O/bench_split_bf16.json 2>> $O/bench.err
+# the reference's model shape on the opt-in split-bf16 layer kernel (gru_layer_bf16_kernel), 3 and 2 terms
+python3 bench.py --split-bf16 3 --hidden 128 --layers 4 --latent 128 > $O/bench_split_bf16_hidden128layers4latent128.json 2>> $O/bench.err
+python3 bench.py --split-bf16 2 --hidden 128 --layers 4 --latent 128 > $O/bench_split_bf16x2_hidden128layers4latent128.json 2>> $O/bench.err
 python3 bench.py --mode mpc --steps 3 --cpu-seconds 5 > $O/bench_mpc.json 2>> $O/bench.err
 python3 bench.py --mode mpc --batch 8 --seq 4000 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B8_T4000.json 2>> $O/bench.err
 bash tools/pmc_pass.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY" > $O/pmc_sq.txt 2>&1

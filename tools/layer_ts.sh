@@ -4,7 +4,7 @@
 # (OS_GRU_STAGE=0): each layer prints its cycles per step and phase.   usage (GPU box): bash tools/layer_ts.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/lts; mkdir -p $D
 cd $R/optistate_amd/csrc
-for f in capi kf_kernels kf_rows_kernel kf_step gru_kernels fused_kernels gru_train_kernels vit_kernels mpc_kernels; do
+for f in capi kf_kernels kf_rows_kernel kf_dense_rows kf_step gru_kernels gru_bf16_kernels fused_kernels gru_train_kernels vit_kernels mpc_kernels; do
   X=; [ $f = gru_kernels ] && X=-DOS_LAYER_TS; [ $f = kf_rows_kernel ] && X="-fno-slp-vectorize"
   [ -f $D/$f.o -a $f != gru_kernels ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $X -DOS_BUILD_ID='"ts-build"' -c $f.hip -o $D/$f.o &
 done; wait
