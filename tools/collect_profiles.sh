@@ -96,4 +96,10 @@ bash tools/pmc_any.sh ${TAG}_mpc "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES 
 python3 bench.py --gpus 2 --share-gpu --steps 5 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_share_gpu2_fused.json 2>> $O/bench.err
 python3 bench.py --gpus 2 --share-gpu --mode train --steps 10 --warmup 2 --cpu-seconds 0 > $O/bench_share_gpu2_train.json 2>> $O/bench.err
 for e in "" "OS_TRAIN_DBG_NOSAVE=1" "OS_DW_DBG=1"; do env $e python3 bench.py --mode train --steps 20 --cpu-seconds 0 > $O/bench_train_ablation_${e%%=*}.json 2>> $O/bench.err; done
+# the opt-in split-bf16 layer kernel: whole-model times against the fp32 stage kernel, phase timestamps, counters, the bare MFMA mix
+python3 tools/bf16_layer_probe.py > $O/bf16_layer_probe.txt 2>> $O/bench.err
+bash tools/bf16_layer_ts.sh > $O/bf16_layer_timestamps_raw.txt 2>&1
+bash tools/pmc_any.sh ${TAG}_bf16 "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE" $R/tools/bf16_layer_probe.py 65536 100 > $O/pmc_bf16_layer.txt 2>&1
+[ -x tools/micro/mfma_bf16_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/micro/mfma_bf16_rate tools/micro/mfma_bf16_rate.hip
+tools/micro/mfma_bf16_rate > $O/mfma_bf16_rate.txt 2>&1
 ls $O
