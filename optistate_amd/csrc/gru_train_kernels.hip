@@ -546,6 +546,9 @@ struct SweepStackArgs {
     int drop_y, drop_step;       // tests: launch row drop_y (0 = the top layer) stops publishing after drop_step steps (-1: never)
     SweepArgs layer[8];          // layer[0] = the top layer
 };
+#ifndef OS_SWEEP_STACK_WR
+#define OS_SWEEP_STACK_WR 16     // leading k-pairs of a wave's weight chunk kept in registers: 32 spills two VGPRs here (12 B of scratch)
+#endif
 __global__ __launch_bounds__(512, 1) void bwd_sweep_stack_kernel(const SweepStackArgs sa)
 {
     const int y = blockIdx.y + sa.y0;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_stack_kernel(const SweepStac
     a.flag_mine = sa.flags + (size_t)y * sa.tiles + blockIdx.x;
     a.flag_prev = y > 0 ? a.flag_mine - sa.tiles : nullptr;
     a.err = sa.err; a.err_local = sa.err_local; a.max_polls = sa.max_polls; a.drop_from = y == sa.drop_y ? sa.drop_step : -1;
-    sweep_body<1, 8, 32, true>(a);
+    sweep_body<1, 8, OS_SWEEP_STACK_WR, true>(a);
 }
 
 // ---- weight gradients: dW[3H][K] += dG^T X over a slice of the T*B rows, db[3H] += column sums of dG ----

@@ -49,7 +49,7 @@ SCRATCH_FREE = {
     "osg::gru_layer_kernel<2, 2>": "H = 128 fallback when the stage kernel steps aside",
     # BASELINE configs[3]: the training step
     "ost::bwd_sweep_kernel<1, 8, 0>": "training backward sweep",
-    # PENDING "ost::bwd_sweep_stack_kernel": "batch-64 training backward (gru/gru_train.py:36)",
+    "ost::bwd_sweep_stack_kernel": "batch-64 training backward, all layers in one launch (gru/gru_train.py:36)",
     # estimate_state_mpc -- the reference's real loop
     # NOT HELD: "osm::kf_mpc_persistent_kernel<1>" (estimate_state_mpc at the reference's shape): 172 B = the callee-saved VGPRs of the QP
     # call's ABI, written at call entry and read back at its exit, nothing inside a loop body; the two ways around the call that were
