@@ -25,10 +25,11 @@ def _oracle(m, x, I, H, L, C):
 
 
 @pytest.mark.parametrize("spl", [3, 2])
-@pytest.mark.parametrize("I,L,B,T", [(188, 4, 512, 6), (60, 2, 388, 5), (40, 1, 132, 3), (128, 1, 256, 4)])
+@pytest.mark.parametrize("I,L,B,T", [(188, 4, 512, 6), (60, 2, 388, 5), (40, 1, 132, 3), (128, 1, 256, 4), (188, 2, 260, 1)])
 def test_split_bf16_layers_vs_oracle(spl, I, L, B, T):
     """RNN(I,128,L,24) through the bf16 layer kernel (any-batch flag: the tiles of these batches do not fill the chip): the reference's
-    188-wide input, 60 features (four k-blocks), 40 (three, padded to four: the clamped tail block), a partial tile (388, 132)."""
+    188-wide input, 60 features (four k-blocks), 40 (three, padded to four: the clamped tail block), a partial tile (388, 132), a
+    single step (the late write-back has only its flush)."""
     H, C = 128, 24
     m = _model(I, H, L, C)
     x = torch.rand(B, T, I)
@@ -113,3 +114,22 @@ def test_weights_edited_and_reloaded_rebuild_the_bf16_image():
     finally:
         eng.set_gru_split_bf16(0)
     assert np.abs(a - b).max() > 1e-4 and np.abs(b - ref).max() < 1e-5
+
+
+def test_a_batch_that_is_not_a_multiple_of_four_stays_on_the_fp32_kernels():
+    """The bf16 kernel's 16-byte stores and x-tile DMA need B % 4 == 0: other batches keep the exact path, silently and correctly."""
+    m = _model(188, 128, 1, 24)
+    x = torch.rand(262, 3, 188)
+    with torch.no_grad():
+        exact = m(x.cuda()).cpu().numpy()
+    eng = m._engine
+    eng.set_gru_split_bf16(3, any_batch=True)
+    eng.set_stack_mode(0)
+    try:
+        with torch.no_grad():
+            out = m(x.cuda()).cpu().numpy()
+        assert "bf16" not in eng.kernel_name("gru_layer")
+    finally:
+        eng.set_gru_split_bf16(0)
+        eng.set_stack_mode(1)
+    assert np.array_equal(out, exact)
