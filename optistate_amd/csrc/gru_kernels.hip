@@ -641,9 +641,11 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
                 gn[g][i] = buf_load(rgi, gvo, (uint32_t)((((e0 + i) & 3) + 8 * ((e0 + i) >> 2)) * 3 * H + g * H) * 4u);
         gvo += 3u * (uint32_t)H * 4u;                   // the next step's rows are one row further down
     };
-    if (GI) {
+    // (PARTS == 4, H = 64: 48 more registers across the MFMA slice do not fit -- 9 spilled VGPRs -- so part 0 requests its tile BEHIND
+    // its slice instead, under the exchange)
+    if (GI && HALVES) {
         if (part == 0) gfetch(std::integral_constant<int, 0>{});
-        else if (HALVES) gfetch(std::integral_constant<int, 8>{});
+        else gfetch(std::integral_constant<int, 8>{});
     }
     OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
@@ -667,6 +669,7 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
         OSL_TS(2)                                            // this wave's slice of the gate GEMM
         // x_{t+1}: requested behind the last weight fragment, lands underneath the exchange and the cell update
         if (!GI && t + 1 < a.T) xfetch(t + 1);
+        if (GI && !HALVES && part == 0) gfetch(std::integral_constant<int, 0>{});
         // Exchange of the partial sums.  PARTS == 2 (H = 128): the two waves of a chunk SWAP halves -- part 0 hands elements 8..15 to
         // part 1 and takes elements 0..7 from it -- and each does the cell update of its eight elements (rows 0-3, 8-11 / 16-19, 24-27
         // of the tile, + 4 lh): the same 64 values cross LDS as before, but the cell update, which was a third of a step on ONE wave
@@ -746,6 +749,13 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
             else cell(std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{});
         } else if (part == 0) {
             // (PARTS == 4, H = 64: the round-4 form, textually: routed through the lambda above hipcc spills 12-20 registers here)
+            if (GI) {      // the gi tile first: its 48 registers are free before the 192 partial sums arrive
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[0][g][e] += gn[g][e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int p = 0; p < PARTS - 1; p++) {
                 const float *src = xch + (size_t)p * 64 * 64;
@@ -760,12 +770,6 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
                 const uint32_t sbytes = (uint32_t)a.B * (uint32_t)H * 4u;
                 rs_r = make_rsrc(a.sv_r + so_t, sbytes); rs_z = make_rsrc(a.sv_z + so_t, sbytes); rs_n = make_rsrc(a.sv_n + so_t, sbytes);
                 rs_g = make_rsrc(a.sv_g + so_t, sbytes); rs_h = make_rsrc(a.sv_h + so_t, sbytes);
-            }
-            if (GI) {
-#pragma unroll
-                for (int g = 0; g < 3; g++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) acc[0][g][e] += gn[g][e];
             }
             CellPair cp;
 #pragma unroll
@@ -784,7 +788,6 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
                     osk::buf_store_nt(rs_g, svoff, so, ghn); osk::buf_store_nt(rs_h, svoff, so, hn);
                 }
             }
-            if (GI && t + 1 < a.T) gfetch(std::integral_constant<int, 0>{});
         }
         OSL_TS(4)                                            // part 0: sum of the partials, cell update, saved activations
         if (!GI && t + 1 < a.T) xstage(xl2 + ((t + 1) & 1) * BM * XS);
