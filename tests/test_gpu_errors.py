@@ -63,6 +63,29 @@ def test_fused_and_gru_preconditions(eng):
         e2.load_gru(torch.zeros(10, device="cuda"), 60, 64, 1, 24)                  # wrong flat-parameter count
 
 
+def test_window_stream_and_split_bf16_preconditions():
+    """os_gru_forward_windows / os_gru_bands / os_gru_set_split_bf16: return codes for what they do not define."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from optistate_amd.engine import _ptr
+    e2 = Engine(0)
+    lib, h = e2.lib, e2._h
+    rows = torch.rand(20, 60, device="cuda"); out = torch.zeros(20, 24, device="cuda")
+    assert lib.os_gru_forward_windows(h, 20, 10, _ptr(rows), _ptr(out), None) < 0 and b"os_gru_load" in lib.os_last_error(h)     # no weights yet
+    m = RNN(60, 64, 1, 24, torch.device("cpu"))
+    e2.load_gru(flatten_state_dict(m.state_dict(), 1, "cuda"), 60, 64, 1, 24)
+    assert lib.os_gru_forward_windows(h, 20, 10, _ptr(rows), _ptr(out), None) == 0
+    assert lib.os_gru_forward_windows(h, 20, 21, _ptr(rows), _ptr(out), None) < 0 and b"window" in lib.os_last_error(h)          # window longer than the stream
+    assert lib.os_gru_forward_windows(h, 0, 1, _ptr(rows), _ptr(out), None) < 0                                                  # empty stream
+    assert lib.os_gru_forward_windows(h, 20, 10, None, _ptr(out), None) < 0                                                      # null rows
+    with pytest.raises(ValueError):
+        e2.gru_forward_windows(rows, 0)
+    m32 = RNN(60, 32, 1, 24, torch.device("cpu"))                                                                                  # hidden 32: not a window-stream shape
+    e2.load_gru(flatten_state_dict(m32.state_dict(), 1, "cuda"), 60, 32, 1, 24)
+    assert lib.os_gru_forward_windows(h, 20, 10, _ptr(rows), _ptr(out), None) == -4 and not e2.gru_windows_supported()
+    assert lib.os_gru_set_split_bf16(h, 1) == -4 and lib.os_gru_set_split_bf16(h, 4) == -4 and lib.os_gru_set_split_bf16(h, 3) == 0
+    assert lib.os_gru_set_split_bf16(h, 0) == 0 and lib.os_gru_set_split_bf16(None, 3) < 0
+
+
 def test_mpc_rejects_bad_arguments(eng):
     from optistate_amd.engine import _ptr
     lib, h = eng.lib, eng._h
