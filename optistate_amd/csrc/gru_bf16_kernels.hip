@@ -44,6 +44,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef OSB_PEEL
 #define OSB_PEEL 0
 #endif
+#ifndef OSB_SGB_VALU
+#define OSB_SGB_VALU 3           // VALU instructions of the next unit's split scheduled behind each MFMA (0: the scheduler's own order)
+#endif
 constexpr int BF_BM = 128, BF_H = 128, BF_HS = OSB_HS, BF_KBH = BF_H / 16;
 
 __host__ __device__ inline int bf_kbx(int K) { return (((K + 15) / 16) + 1) & ~1; }                        // even
@@ -318,9 +321,9 @@ __global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs 
                         acc[rb][G] = mfma_bf16(Af[rb & 1][PA[pi]], W[CUR][g][PW[pi]], (zero && pi == 0) ? (f32x16)(0.f) : acc[rb][G]);   \
                 }                                                                                                                \
             }                                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 12 * NP; i++) {                                                                 \
+            _Pragma("unroll") for (int i = 0; i < (OSB_SGB_VALU ? 12 * NP : 0); i++) {                                            \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                                            \
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      /* a few VALU of the next split */                        \
+                __builtin_amdgcn_sched_group_barrier(0x002, OSB_SGB_VALU, 0);      /* a few VALU of the next split */             \
             }                                                                                                                    \
         }
 #if OSB_PEEL
