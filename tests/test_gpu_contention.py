@@ -1,0 +1,69 @@
+"""GPU: the layer-pipelined launches (gru_stack_kernel: layer l takes layer l - 1's steps through progress counters) while ANOTHER
+process keeps every CU of the same GPU busy.  A consumer workgroup can then sit resident while its producer waits for a CU; the
+design's answer is a bounded wait + error word + a launch-per-layer re-run.  Whatever happens underneath -- the
+stacked launch goes through, or the engine falls back -- every call must return one of the two known-good results."""
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+HOG = r'''
+import sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from optistate_amd import Engine, RNN, flatten_state_dict
+eng = Engine(0)
+m = RNN(188, 128, 4, 24, torch.device("cpu"))
+eng.load_gru(flatten_state_dict(m.state_dict(), 4, "cuda"), 188, 128, 4, 24)
+xs = torch.rand(40, 188, 32768, device="cuda")            # 256 tiles of 128 / 512 of 64 rows: every CU busy, ~15 ms per call
+print("hog ready", flush=True)
+t0 = time.time()
+while time.time() - t0 < float(sys.argv[2]):
+    eng.gru_forward_soa(xs)
+    torch.cuda.synchronize()
+print("hog done", flush=True)
+'''
+
+
+def test_stacked_launches_beside_a_process_that_fills_the_gpu():
+    from optistate_amd import RNN
+    torch.manual_seed(9)
+    m = RNN(188, 128, 4, 24, torch.device("cuda")).to("cuda").eval()
+    x = torch.rand(64, 10, 188, device="cuda")             # the reference's own batch (gru/gru_train.py:36): one stacked launch
+    with torch.no_grad():
+        m(x)
+        eng = m._engine
+        assert eng.kernel_name("gru_layer") == "gru_stack_kernel"
+        ref_stack = m(x).clone()                            # the stacked launch on an idle GPU
+        eng.set_stack_mode(0)
+        ref = m(x).clone()                                  # a launch per layer (other kernels: another summation order, ~1e-7 apart)
+        eng.set_stack_mode(1)
+    assert (ref - ref_stack).abs().max().item() < 1e-6
+    hog = subprocess.Popen([sys.executable, "-c", HOG, ROOT, "12"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = hog.stdout.readline()
+        while line and "hog ready" not in line:
+            line = hog.stdout.readline()
+        assert "hog ready" in line, line
+        t0, n, worst = time.time(), 0, 0.0
+        with torch.no_grad():
+            while time.time() - t0 < 8.0:
+                t1 = time.time()
+                out = m(x)
+                torch.cuda.synchronize()
+                worst = max(worst, time.time() - t1)
+                # bit for bit the idle-GPU stacked result, or -- if the launch lost a producer and the engine re-ran it -- the per-layer one
+                assert torch.equal(out, ref_stack) or torch.equal(out, ref), n
+                n += 1
+        fb = getattr(eng, "stack_fallbacks", 0)
+        print(f"{n} stacked forwards beside the hog: all equal to a known-good result; {fb} fell back to a launch per layer; slowest call {worst * 1e3:.1f} ms")
+        assert n > 20
+    finally:
+        hog.wait(timeout=60)
+    assert eng.kernel_name("gru_layer") == "gru_stack_kernel"     # the mode is back on after any fallback
