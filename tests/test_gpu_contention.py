@@ -67,3 +67,42 @@ def test_stacked_launches_beside_a_process_that_fills_the_gpu():
     finally:
         hog.wait(timeout=60)
     assert eng.kernel_name("gru_layer") == "gru_stack_kernel"     # the mode is back on after any fallback
+
+
+def test_stacked_training_sweeps_beside_a_process_that_fills_the_gpu():
+    """The batch-64 training step's two stacked launches (forward with saved activations, bwd_sweep_stack_kernel) beside the same hog:
+    every gradient equals the idle-GPU one to the summation order of the dW atomics."""
+    from optistate_amd import RNN, default_engine, flatten_state_dict
+    torch.manual_seed(10)
+    I, H, L, C, B, T = 188, 128, 4, 24, 64, 10
+    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda")
+    eng = default_engine(0)
+    eng.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    x = torch.rand(B, T, I, device="cuda"); y = torch.rand(B, C // 2, device="cuda")
+
+    def grad():
+        out = eng.gru_forward_train(x)
+        _, dout, _ = eng.gru_loss(out, y, want_target=True)
+        return out, eng.gru_backward(x, out, dout).clone()
+
+    out0, g0 = grad()
+    assert eng.kernel_name("gru_layer") == "gru_stack_kernel" and eng.kernel_name("train_sweep") == "bwd_sweep_stack_kernel"
+    scale = g0.abs().max().item()
+    hog = subprocess.Popen([sys.executable, "-c", HOG, ROOT, "10"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = hog.stdout.readline()
+        while line and "hog ready" not in line:
+            line = hog.stdout.readline()
+        assert "hog ready" in line, line
+        t0, n = time.time(), 0
+        while time.time() - t0 < 6.0:
+            out, g = grad()
+            torch.cuda.synchronize()
+            assert torch.isfinite(g).all() and (out - out0).abs().max().item() < 1e-6, n
+            assert (g - g0).abs().max().item() < 1e-4 * scale, n
+            n += 1
+        print(f"{n} forward + backward passes at batch 64 beside the hog: gradients equal the idle-GPU ones; "
+              f"{getattr(eng, 'stack_fallbacks', 0)} fell back to a launch per layer")
+        assert n > 20
+    finally:
+        hog.wait(timeout=60)
