@@ -876,8 +876,8 @@ def bench_hot_path(a, rk):
         elif on_bf16:
             nprod = 6 if a.split_bf16 == 3 else 3
             roof["note"] = (f"algorithmic (fp32-equivalent) GRU flops against the bf16 dense peak; the kernel issues {nprod} bf16 products per "
-                            f"fp32 product ({nprod} x these flops on the matrix pipe = {ach * nprod / peak:.2f} of the peak), one wave per SIMD: the "
-                            "exposed cell update and the issue slots of the operand splits are the rest (DESIGN 4.2f)")
+                            f"fp32 product ({nprod} x these flops on the matrix pipe = {ach * nprod / peak:.2f} of the peak); power-bound: the chip "
+                            "drops to ~1.7 GHz under this kernel's 68 % matrix-pipe occupancy (DESIGN 4.2f, profiles/r05_pmc_bf16_layer.txt)")
             roof["executed_bf16_TFLOPs"] = ach * nprod
         if dom == "fused":
             gbs = BYTES_PER_STEP_FUSED * steps_per_pass / (avg_ms * 1e-3) / 1e9

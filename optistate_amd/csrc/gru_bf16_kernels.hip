@@ -6,22 +6,24 @@
 // operand of the gate GEMM is split into SPL bf16 terms (v = hi + mid + lo, 8 significant bits each; gru_common.hpp split_pair) and
 // the products are formed on the bf16 MFMA with fp32 accumulation: SPL = 3 issues hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid (every
 // term down to 2^-16 of a product, what is dropped is below fp32 rounding), SPL = 2 issues hi.hi, hi.lo, lo.hi (relative 2^-16 per
-// product).  Per (trajectory tile, step) 4 x 20 x 18 = 1,440 (720) instructions of 32 cycles instead of 4 x 158 x 6 of 64.
+// product).  Per (64-trajectory tile, chunk, step) 2 x 20 x 18 = 720 (360) instructions of 32 cycles instead of 2 x 158 x 6 of 64.
 //
 // Shape of the kernel (a sibling of gru_layer_stage_kernel, whose skeleton it keeps: x tile by LDS-DMA a step ahead, h in LDS,
-// two barriers per step, the fp32 cell update on the accumulator layout, h_t straight to seq_out in SoA):
-//   * ONE workgroup of four waves per CU, a wave = one 32-column chunk of r, z, n for 128 trajectories (four 32-row blocks):
-//     the weight fragments of a k-block are used by 4 row blocks, so the L2 -> register weight stream is 9.5 TB/s chip-wide at the
-//     MFMA-bound rate with SPL = 3 (the 64-row tile of the stage kernel would need 19 TB/s: the L2s deliver 17-19);
-//   * 256 fp32 accumulators per lane (r, z, gi_n, gh_n x 4 row blocks), the bf16 weight terms of a k-block (9 or 6 x 16 bytes
-//     per lane, straight from L2 in fragment order, requested one k-block ahead), the fp32 A values of the NEXT k-block read
-//     from LDS (x tile [K][128] / h tile [128][129], both fp32: exactly the stage kernel's images) and split into bf16 terms on
-//     the VALU in the shadow of the current unit's MFMAs (one wave per SIMD: an MFMA holds the issue port for 8 of its 32
-//     cycles);
+// two barriers per step, the fp32 cell update on the accumulator layout):
+//   * TWO independent four-wave workgroups per CU, each on a 64-trajectory tile (xS [K4][64] | hS [64][129], both fp32: exactly
+//     the stage kernel's images, 81,152 B at K = 188), a wave = one 32-column chunk of r, z, n x two 32-row blocks, 256 registers:
+//     128 fp32 accumulators, the bf16 weight terms of two k-blocks (9 or 6 x 16 bytes per lane each, straight from L2 in fragment
+//     order, requested one k-block ahead), ONE set of fp32 A values (read from LDS) and of the fragments they are split into on
+//     the VALU.  No software pipelining inside a wave: the SIMD's other wave belongs to the other workgroup, drifts out of phase
+//     with this one, and its MFMAs cover this wave's LDS reads, operand splits, waits and cell update;
 //   * k runs over 16-wide blocks: KBx of the x part (K rounded up to 16, and to an even block count: zero weights; the A values
 //     of k >= K are re-reads of the trajectory's own last input, so nothing foreign -- and no NaN of another row -- enters) and
-//     8 of the h part.
-// LDS: xS [K4][128] | hS [128][129] = 162,304 B at K = 188.
+//     8 of the h part;
+//   * h_t leaves for seq_out one step LATE, from hS, inside step t + 1's k loop (256-byte runs; per-lane 16-byte pieces out of
+//     the cell update cost 4.5 k exposed cycles per step in the first version).
+// What bounds it (profiles/r05_pmc_bf16_layer.txt): POWER.  Under this load the chip drops its clock: 1.9 GHz at 60 % matrix-pipe
+// occupancy (first version: one 4-wave workgroup per CU on a 128-row tile, software-pipelined splits), 1.7 GHz at 68 % (this one):
+// 11 % fewer cycles became 2 % less time with three terms, 8 % with two.  The fp32 kernel holds 2.3 GHz at 87 %.
 #include "launch.hpp"
 
 #include "gru_common.hpp"
@@ -35,19 +37,7 @@ using osk::rsrc_t;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// (development switches, both measured and left at the slower setting's opposite: OSB_HS 132 = 16-byte aligned h rows read by
-// ds_read_b128 -- fewer LDS instructions, but the write-back reads turn 8-way bank-conflicted: +7 k cycles per step; OSB_PEEL 1 = the
-// first block of each part peeled so that the accumulators start from the C operand: +2 k, code 25 -> 40 KB)
-#ifndef OSB_HS
-#define OSB_HS 129
-#endif
-#ifndef OSB_PEEL
-#define OSB_PEEL 0
-#endif
-#ifndef OSB_SGB_VALU
-#define OSB_SGB_VALU 3           // VALU instructions of the next unit's split scheduled behind each MFMA (0: the scheduler's own order)
-#endif
-constexpr int BF_BM = 128, BF_H = 128, BF_HS = OSB_HS, BF_KBH = BF_H / 16;
+constexpr int BF_BM = 64, BF_H = 128, BF_HS = 129, BF_KBH = BF_H / 16;
 
 __host__ __device__ inline int bf_kbx(int K) { return (((K + 15) / 16) + 1) & ~1; }                        // even
 __host__ __device__ inline size_t bf_layer_dwords(int K, int spl) { return (size_t)4 * (bf_kbx(K) + BF_KBH) * 3 * spl * 256; }
@@ -120,39 +110,12 @@ __device__ __forceinline__ void read8(uint32_t addr, Raw8 &r)
     r.q[0][3] = lds_read_asm<OFF + 3 * JS>(addr); r.q[1][0] = lds_read_asm<OFF + 4 * JS>(addr); r.q[1][1] = lds_read_asm<OFF + 5 * JS>(addr);
     r.q[1][2] = lds_read_asm<OFF + 6 * JS>(addr); r.q[1][3] = lds_read_asm<OFF + 7 * JS>(addr);
 }
-template <int RBS, int JS>
-__device__ __forceinline__ void read_block(uint32_t addr, Raw8 *raw)
-{
-    read8<0 * RBS, JS>(addr, raw[0]); read8<1 * RBS, JS>(addr, raw[1]); read8<2 * RBS, JS>(addr, raw[2]); read8<3 * RBS, JS>(addr, raw[3]);
-}
 // the same with one address per value (the x block that reaches past K: k clamped to K - 1)
 template <int OFF>
 __device__ __forceinline__ void read8_addr(const uint32_t *addr, Raw8 &r)
 {
     r.q[0][0] = lds_read_asm<OFF>(addr[0]); r.q[0][1] = lds_read_asm<OFF>(addr[1]); r.q[0][2] = lds_read_asm<OFF>(addr[2]); r.q[0][3] = lds_read_asm<OFF>(addr[3]);
     r.q[1][0] = lds_read_asm<OFF>(addr[4]); r.q[1][1] = lds_read_asm<OFF>(addr[5]); r.q[1][2] = lds_read_asm<OFF>(addr[6]); r.q[1][3] = lds_read_asm<OFF>(addr[7]);
-}
-template <int RBS>
-__device__ __forceinline__ void read_block_addr(const uint32_t *addr, Raw8 *raw)
-{
-    read8_addr<0 * RBS>(addr, raw[0]); read8_addr<1 * RBS>(addr, raw[1]); read8_addr<2 * RBS>(addr, raw[2]); read8_addr<3 * RBS>(addr, raw[3]);
-}
-// h part: hS [row][132]: the eight k of a lane are 32 contiguous, 16-byte aligned bytes -- two ds_read_b128 (row stride 132 floats:
-// sixteen lanes' quads cover the 64 banks exactly once)
-template <int OFF>
-__device__ __forceinline__ f32x4 lds_read4_asm(uint32_t addr)
-{
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ void read_block_h(uint32_t addr, Raw8 *raw)
-{
-    constexpr int RBS = 32 * BF_HS * 4;
-    raw[0].q[0] = lds_read4_asm<0 * RBS>(addr); raw[0].q[1] = lds_read4_asm<0 * RBS + 16>(addr);
-    raw[1].q[0] = lds_read4_asm<1 * RBS>(addr); raw[1].q[1] = lds_read4_asm<1 * RBS + 16>(addr);
-    raw[2].q[0] = lds_read4_asm<2 * RBS>(addr); raw[2].q[1] = lds_read4_asm<2 * RBS + 16>(addr);
-    raw[3].q[0] = lds_read4_asm<3 * RBS>(addr); raw[3].q[1] = lds_read4_asm<3 * RBS + 16>(addr);
 }
 // h_{t-1} of the wave's own 16 elements of row block RB: rows (e & 3) + 8 (e >> 2) of the block (+ 4 lh in the address)
 template <int RB>
@@ -165,33 +128,22 @@ __device__ __forceinline__ void read_own(uint32_t hw0, float *hv)
     hv[12] = lds_read_asm<B0 + 24 * S>(hw0); hv[13] = lds_read_asm<B0 + 25 * S>(hw0); hv[14] = lds_read_asm<B0 + 26 * S>(hw0); hv[15] = lds_read_asm<B0 + 27 * S>(hw0);
 }
 // every outstanding LDS read has landed; ties the wait to the value registers so that no use can be scheduled above it
-__device__ __forceinline__ void lds_landed(Raw8 *raw)
+__device__ __forceinline__ void lds_landed2_wb(Raw8 *raw, f32x4 &wv)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(raw[0].q[0]), "+v"(raw[0].q[1]), "+v"(raw[1].q[0]), "+v"(raw[1].q[1]), "+v"(raw[2].q[0]), "+v"(raw[2].q[1]), "+v"(raw[3].q[0]),
-                   "+v"(raw[3].q[1])::"memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0].q[0]), "+v"(raw[0].q[1]), "+v"(raw[1].q[0]), "+v"(raw[1].q[1]), "+v"(wv)::"memory");
 }
-__device__ __forceinline__ void lds_landed_wb(Raw8 *raw, f32x4 *wv)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(raw[0].q[0]), "+v"(raw[0].q[1]), "+v"(raw[1].q[0]), "+v"(raw[1].q[1]), "+v"(raw[2].q[0]), "+v"(raw[2].q[1]), "+v"(raw[3].q[0]),
-                   "+v"(raw[3].q[1]), "+v"(wv[0]), "+v"(wv[1])::"memory");
-}
-// write-back groups: four consecutive trajectories (rows 4 (lane & 31) .. + 3) of hidden units u and u + 2 of the h tile
-__device__ __forceinline__ void wb_read(uint32_t addr, f32x4 *wv)
+__device__ __forceinline__ void wb_read1(uint32_t addr, f32x4 &wv)
 {
     constexpr int S = BF_HS * 4;
-    wv[0][0] = lds_read_asm<0 * S>(addr); wv[0][1] = lds_read_asm<1 * S>(addr); wv[0][2] = lds_read_asm<2 * S>(addr); wv[0][3] = lds_read_asm<3 * S>(addr);
-    wv[1][0] = lds_read_asm<0 * S + 8>(addr); wv[1][1] = lds_read_asm<1 * S + 8>(addr); wv[1][2] = lds_read_asm<2 * S + 8>(addr); wv[1][3] = lds_read_asm<3 * S + 8>(addr);
+    wv[0] = lds_read_asm<0 * S>(addr); wv[1] = lds_read_asm<1 * S>(addr); wv[2] = lds_read_asm<2 * S>(addr); wv[3] = lds_read_asm<3 * S>(addr);
 }
 
 template <int SPL>
-__global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs a)
+__global__ __launch_bounds__(256, 2) void gru_layer_bf16_kernel(const LayerArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // xS [K4][128] | hS [128][129]
-    constexpr int H = BF_H, HS = BF_HS, BM = BF_BM, LPK = BM / 4, KPI = 64 / LPK;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // xS [K4][64] | hS [64][129]
+    constexpr int H = BF_H, HS = BF_HS, BM = BF_BM, LPK = BM / 4, KPI = 64 / LPK;      // DMA: 16 lanes per input, four inputs per instruction
     constexpr int NP = SPL == 3 ? 6 : 3;
-    // (weight term, activation term) of the products, largest first
     constexpr int PW[6] = {0, 0, 1, 0, 2, 1}, PA[6] = {0, 1, 0, 2, 0, 1};
     const int lane = threadIdx.x & 63, chunk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile_row0 = blockIdx.x * BM;
@@ -207,7 +159,6 @@ __global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs 
     const rsrc_t rw = make_rsrc(a.wbf + (size_t)chunk * KB * 3 * SPL * 256, (uint32_t)KB * 3 * SPL * 1024);
     const uint32_t wl = (uint32_t)lane * 16u;
 
-    // x tile DMA (as gru_layer_stage_kernel<2>: 128 rows, two inputs per instruction)
     const uint32_t dvoff = (uint32_t)(lane / LPK) * rowB + (uint32_t)(tile_row0 + 4 * (lane % LPK)) * 4u;
     auto stage_x = [&](int t) {
         const rsrc_t rx = make_rsrc(a.xs + (size_t)t * K * a.B, (uint32_t)K * rowB);      // inputs past K read as zero (range check)
@@ -218,19 +169,16 @@ __global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs 
     const uint32_t hS_b = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)hS;
     const uint32_t ax0 = xS_b + (uint32_t)(8 * lh * BM + li) * 4u;                 // k = 16 kb + 8 lh + j, row rb * 32 + li
     const uint32_t ah0 = hS_b + (uint32_t)(li * HS + 8 * lh) * 4u;
-    const uint32_t hw0 = hS_b + (uint32_t)(4 * lh * HS + chunk * 32 + li) * 4u;    // row (e & 3) + 8 (e >> 2) + 4 lh, col chunk * 32 + li
+    const uint32_t hw0 = hS_b + (uint32_t)(4 * lh * HS + chunk * 32 + li) * 4u;
 
     stage_x(0);
-    // h_t leaves for seq_out ([H][B]: 128 consecutive trajectories of a hidden unit are 512 contiguous bytes) one step LATE, from hS,
-    // inside step t + 1's k-block loop: group i of a wave = hidden units chunk * 32 + 2 i + lh, lane = four consecutive trajectories:
-    // a store instruction writes two 512-byte runs.  (First version: every lane stored its own accumulator elements in the cell
-    // update -- 64 pieces of 16 bytes per instruction, 4.5 k exposed cycles per step.)
-    const uint32_t wb_rd = hS_b + (uint32_t)(4 * (lane & 31) * HS + chunk * 32 + lh) * 4u;
-    const uint32_t wb_vo = (tile_row0 + 4 * (lane & 31) < a.B) ? (uint32_t)lh * rowB + (uint32_t)(tile_row0 + 4 * (lane & 31)) * 4u : 0x80000000u;
+    // h_t -> seq_out ([H][B]: consecutive trajectories of a hidden unit are contiguous) one step late: group i of a wave = hidden units chunk * 32 + 4 i + (lane >> 4), lane & 15 = four
+    // consecutive trajectories: a store instruction writes four 256-byte runs
+    const uint32_t wb_rd = hS_b + (uint32_t)(4 * (lane & 15) * HS + chunk * 32 + (lane >> 4)) * 4u;
+    const uint32_t wb_vo = (tile_row0 + 4 * (lane & 15) < a.B) ? (uint32_t)(lane >> 4) * rowB + (uint32_t)(tile_row0 + 4 * (lane & 15)) * 4u : 0x80000000u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // request the weight terms of k-block kb
     auto req_w = [&](int kb, u32x4 (*W)[SPL]) {
 #pragma unroll
         for (int g = 0; g < 3; g++)
@@ -238,11 +186,12 @@ __global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs 
             for (int sp = 0; sp < SPL; sp++)
                 W[g][sp] = buf_load4(rw, wl, __builtin_amdgcn_readfirstlane((uint32_t)((kb * 3 + g) * SPL + sp) * 1024u));
     };
-    // request the fp32 A values of k-block kb (x part: xS [k][128]; h part: hS [row][132])
     auto req_a = [&](int kb, Raw8 *raw) {
         if (kb < KBx) {
-            if (16 * kb + 16 <= K) read_block<128, BM * 4>(ax0 + (uint32_t)kb * (16 * BM * 4), raw);
-            else {
+            if (16 * kb + 16 <= K) {
+                const uint32_t ad = ax0 + (uint32_t)kb * (16 * BM * 4);
+                read8<0, BM * 4>(ad, raw[0]); read8<128, BM * 4>(ad, raw[1]);
+            } else {
                 uint32_t ad[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -250,129 +199,76 @@ __global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs 
                     k = k < K ? k : K - 1;
                     ad[j] = xS_b + (uint32_t)(k * BM + li) * 4u;
                 }
-                read_block_addr<128>(ad, raw);
+                read8_addr<0>(ad, raw[0]); read8_addr<128>(ad, raw[1]);
             }
-        } else if (BF_HS % 4 == 0) read_block_h(ah0 + (uint32_t)(kb - KBx) * 64u, raw);
-        else read_block<32 * BF_HS * 4, 4>(ah0 + (uint32_t)(kb - KBx) * 64u, raw);
+        } else {
+            const uint32_t ad = ah0 + (uint32_t)(kb - KBx) * 64u;
+            read8<0, 4>(ad, raw[0]); read8<32 * HS * 4, 4>(ad, raw[1]);
+        }
     };
 
-    u32x4 W[2][3][SPL], Af[2][SPL];
-    Raw8 raw[2][4];
+    u32x4 W[2][3][SPL];
     req_w(0, W[0]);
     OSL_TS_DECL
     for (int t = 0; t < a.T; t++) {
         OSL_TS(0)
-        // the accumulators start at zero through the first product's C operand (FIRST blocks below): r, z, gi_n in k-block 0,
-        // gh_n in the first h block -- no 256 register writes per step
-        f32x16 acc[4][4];
-        // seq_out block of step t - 1 (a descriptor of size 0 drops every store: t = 0, or a layer that keeps no sequence)
-        const bool wbk = t > 0 && a.seq_out;
-        const rsrc_t rp = make_rsrc(wbk ? a.seq_out + (size_t)(t - 1) * H * a.B : nullptr, wbk ? (uint32_t)H * rowB : 0u);
-        req_a(0, raw[0]);
-        lds_landed(raw[0]);
-        split8<SPL>(raw[0][0], Af[0]);
-
-        // one k-block: the next block's weights and A values are requested first; unit (kb, rb) = 3 gates x NP products on the bf16
-        // MFMA, with the split of the NEXT unit's A values issued between them.  The weight request is UNCONDITIONAL (the last
-        // block re-requests itself): behind `if (more)` hipcc's wait-count pass loses the number of loads younger than the
-        // fragment an MFMA needs at the merge and waits for vmcnt(0) -- the NEXT block's weights -- in front of every block's
-        // MFMAs (first build: 7.8 ms per layer; the same disease as gru_kernels.hip's mfma_part, round 4).
-        // (timing ablations of development builds: -DOSB_NO_W / -DOSB_NO_A / -DOSB_NO_SPLIT drop the weight requests, the A-value
-        // reads, the splits -- results are wrong, the phase timestamps say what each costs)
-#ifdef OSB_NO_W
-#define OSB_REQ_W(k, w)
-#else
-#define OSB_REQ_W(k, w) req_w(k, w)
-#endif
-#ifdef OSB_NO_A
-#define OSB_REQ_A(k, r)
-#else
-#define OSB_REQ_A(k, r) req_a(k, r)
-#endif
-#ifdef OSB_NO_SPLIT
-#define OSB_SPLIT(r, f)
-#else
-#define OSB_SPLIT(r, f) split8<SPL>(r, f)
-#endif
-#define OSB_BODY(XP, FIRST, CUR, kb)                                                                                             \
-        {                                                                                                                        \
-            const int kn = (kb) + 1 < KB ? (kb) + 1 : (kb);   /* the last block re-requests itself: nobody uses it */            \
-            const int kw = (kb) < 8 ? (kb) : 7;               /* write-back groups 2 kb, 2 kb + 1 of h_{t-1} (first eight blocks) */ \
-            f32x4 wv[2];                                                                                                         \
-            wb_read(wb_rd + (uint32_t)kw * 16u, wv);                                                                             \
-            OSB_REQ_W(kn, W[(CUR) ^ 1]);                                                                                         \
-            OSB_REQ_A(kn, raw[(CUR) ^ 1]);                                                                                       \
-            __builtin_amdgcn_sched_barrier(0);                /* the requests stay in FRONT of the block's MFMAs */               \
-            /* the four units of the block in ONE basic block, so that the scheduler can place a unit's MFMAs between the */      \
-            /* VALU instructions of the next unit's split (sched_group_barrier pattern below) */                                 \
-            _Pragma("unroll") for (int rb = 0; rb < 4; rb++) {                                                                    \
-                if (rb == 3) {                                                                                                   \
-                    lds_landed_wb(raw[(CUR) ^ 1], wv);                                                                           \
-                    const uint32_t vo = (kb) < 8 ? wb_vo : 0x80000000u;                                                          \
-                    const uint32_t sof = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * 32 + 4 * kw) * rowB);                 \
-                    buf_store4(rp, vo, sof, wv[0]);                                                                              \
-                    buf_store4(rp, vo, sof + 2u * rowB, wv[1]);                                                                  \
-                }                                                                                                                \
-                OSB_SPLIT(rb < 3 ? raw[CUR][rb < 3 ? rb + 1 : 0] : raw[(CUR) ^ 1][0], Af[(rb + 1) & 1]);                        \
-                _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                   \
-                    const int G = g < 2 ? g : ((XP) ? 2 : 3);                                                                    \
-                    const bool zero = (FIRST) && ((XP) || g == 2);                                                               \
-                    _Pragma("unroll") for (int pi = 0; pi < NP; pi++)                                                             \
-                        acc[rb][G] = mfma_bf16(Af[rb & 1][PA[pi]], W[CUR][g][PW[pi]], (zero && pi == 0) ? (f32x16)(0.f) : acc[rb][G]);   \
-                }                                                                                                                \
-            }                                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < (OSB_SGB_VALU ? 12 * NP : 0); i++) {                                            \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                                            \
-                __builtin_amdgcn_sched_group_barrier(0x002, OSB_SGB_VALU, 0);      /* a few VALU of the next split */             \
-            }                                                                                                                    \
-        }
-#if OSB_PEEL
-        // the first block of each part is peeled: its first products start the accumulators from zero
-        OSB_BODY(true, true, 0, 0)
-        OSB_BODY(true, false, 1, 1)
-        for (int kb = 2; kb < KBx; kb += 2) {
-            OSB_BODY(true, false, 0, kb)
-            OSB_BODY(true, false, 1, kb + 1)
-        }
-        OSB_BODY(false, true, 0, KBx)
-        OSB_BODY(false, false, 1, KBx + 1)
-        for (int kb = KBx + 2; kb < KB; kb += 2) {
-            OSB_BODY(false, false, 0, kb)
-            OSB_BODY(false, false, 1, kb + 1)
-        }
-#else
+        f32x16 acc[2][4];
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++)
+        for (int rb = 0; rb < 2; rb++)
 #pragma unroll
             for (int g = 0; g < 4; g++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[rb][g][e] = 0.f;
+        const bool wbk = t > 0 && a.seq_out;
+        const rsrc_t rp = make_rsrc(wbk ? a.seq_out + (size_t)(t - 1) * H * a.B : nullptr, wbk ? (uint32_t)H * rowB : 0u);
+
+        // one k-block.  The weight request of the NEXT block is UNCONDITIONAL (the last block re-requests itself): behind
+        // `if (more)` hipcc's wait-count pass loses the number of loads younger than the fragment an MFMA needs at the merge and
+        // waits for vmcnt(0) -- the NEXT block's weights -- in front of every block's MFMAs (the same disease as gru_kernels.hip's
+        // mfma_part, round 4).
+#define OSB2_BODY(XP, CUR, kb)                                                                                                   \
+        {                                                                                                                        \
+            const int kn = (kb) + 1 < KB ? (kb) + 1 : (kb);                                                                      \
+            const int kw = (kb) < 8 ? (kb) : 7;                                                                                  \
+            f32x4 wv;                                                                                                            \
+            Raw8 raw[2];                                                                                                         \
+            u32x4 Af[SPL];                                                                                                       \
+            wb_read1(wb_rd + (uint32_t)kw * 16u, wv);                                                                            \
+            req_w(kn, W[(CUR) ^ 1]);                          /* unconditional: see below */                                     \
+            req_a((kb), raw);                                                                                                    \
+            lds_landed2_wb(raw, wv);                                                                                             \
+            buf_store4(rp, (kb) < 8 ? wb_vo : 0x80000000u, __builtin_amdgcn_readfirstlane((uint32_t)(chunk * 32 + 4 * kw) * rowB), wv);   \
+            _Pragma("unroll") for (int rb = 0; rb < 2; rb++) {                                                                    \
+                split8<SPL>(raw[rb], Af);                                                                                        \
+                _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                   \
+                    const int G = g < 2 ? g : ((XP) ? 2 : 3);                                                                    \
+                    _Pragma("unroll") for (int pi = 0; pi < NP; pi++)                                                             \
+                        acc[rb][G] = mfma_bf16(Af[PA[pi]], W[CUR][g][PW[pi]], acc[rb][G]);                                       \
+                }                                                                                                                \
+            }                                                                                                                    \
+        }
         for (int kb = 0; kb < KBx; kb += 2) {
-            OSB_BODY(true, false, 0, kb)
-            OSB_BODY(true, false, 1, kb + 1)
+            OSB2_BODY(true, 0, kb)
+            OSB2_BODY(true, 1, kb + 1)
         }
         for (int kb = KBx; kb < KB; kb += 2) {
-            OSB_BODY(false, false, 0, kb)
-            OSB_BODY(false, false, 1, kb + 1)
+            OSB2_BODY(false, 0, kb)
+            OSB2_BODY(false, 1, kb + 1)
         }
-#endif
-#undef OSB_BODY
-        OSL_TS(1)                                        // both parts of the gate GEMM
-        // h_{t-1} of the wave's own elements back from hS (each element is read and later overwritten by the same lane): requested
-        // in front of barrier 1, whose wait covers them
-        float hv[4][16];
-        read_own<0>(hw0, hv[0]); read_own<1>(hw0, hv[1]); read_own<2>(hw0, hv[2]); read_own<3>(hw0, hv[3]);
+#undef OSB2_BODY
+        OSL_TS(1)                                        // gate GEMM (both parts)
+        float hv[2][16];
+        read_own<0>(hw0, hv[0]); read_own<1>(hw0, hv[1]);
         lds_barrier();                                   // barrier 1: xS and hS are free
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++)
+        for (int rb = 0; rb < 2; rb++)
             asm volatile("" : "+v"(hv[rb][0]), "+v"(hv[rb][1]), "+v"(hv[rb][2]), "+v"(hv[rb][3]), "+v"(hv[rb][4]), "+v"(hv[rb][5]), "+v"(hv[rb][6]),
                          "+v"(hv[rb][7]), "+v"(hv[rb][8]), "+v"(hv[rb][9]), "+v"(hv[rb][10]), "+v"(hv[rb][11]), "+v"(hv[rb][12]), "+v"(hv[rb][13]),
                          "+v"(hv[rb][14]), "+v"(hv[rb][15]));
-        OSL_TS(2)
+        OSL_TS(2)                                        // own-h reads + barrier 1
         if (t + 1 < a.T) stage_x(t + 1);
-        // ---- cell update on the accumulator layout: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
+        for (int rb = 0; rb < 2; rb++) {
             using osk::f2;
 #pragma unroll
             for (int pr = 0; pr < 8; pr++) {
@@ -381,35 +277,32 @@ __global__ __launch_bounds__(256, 1) void gru_layer_bf16_kernel(const LayerArgs 
                                                   (f2){acc[rb][2][e0], acc[rb][2][e1]}, (f2){acc[rb][3][e0], acc[rb][3][e1]},
                                                   (f2){hv[rb][e0], hv[rb][e1]}, nb_r, nb_z, nb_n, b_hn);
                 const f2 hn = cp.hn;
-                lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e0 & 3) + 8 * (e0 >> 2)) * HS) * 4u, hn[0]);   // (constant: folds into the offset field)
+                lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e0 & 3) + 8 * (e0 >> 2)) * HS) * 4u, hn[0]);
                 lds_write_asm<0>(hw0 + (uint32_t)((rb * 32 + (e1 & 3) + 8 * (e1 >> 2)) * HS) * 4u, hn[1]);
             }
         }
         OSL_TS(3)                                        // DMA issue + cell update
-        // the next step's first weight block: requested here (no register is busy), its L2 round trip under barrier 2 and the first
-        // A-value reads; the DMA is older than these 3 SPL loads
-        req_w(0, W[0]);
+        req_w(0, W[0]);                                  // the next step's first weight block: the DMA is older than these 3 SPL loads
         if (SPL == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         lds_barrier();                                   // barrier 2: h_t and x_{t+1} are in LDS
         OSL_TS(4)
     }
-    // the last step's h: seq_out[T - 1] and h_last, the same groups
     {
         const rsrc_t rs = make_rsrc(a.seq_out ? a.seq_out + (size_t)(a.T - 1) * H * a.B : nullptr, a.seq_out ? (uint32_t)H * rowB : 0u);
         const rsrc_t rl = make_rsrc(a.h_last, a.h_last ? (uint32_t)H * rowB : 0u);
         for (int i = 0; i < 8; i++) {
-            f32x4 wv[2];
-            wb_read(wb_rd + (uint32_t)i * 16u, wv);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1])::"memory");
+            f32x4 wv;
+            wb_read1(wb_rd + (uint32_t)i * 16u, wv);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv)::"memory");
             const uint32_t sof = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * 32 + 4 * i) * rowB);
-            buf_store4(rs, wb_vo, sof, wv[0]); buf_store4(rs, wb_vo, sof + 2u * rowB, wv[1]);
-            buf_store4(rl, wb_vo, sof, wv[0]); buf_store4(rl, wb_vo, sof + 2u * rowB, wv[1]);
+            buf_store4(rs, wb_vo, sof, wv);
+            buf_store4(rl, wb_vo, sof, wv);
         }
     }
 #ifdef OS_LAYER_TS
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("gru_layer_bf16_kernel<%d> K=%d cycles per step: gate GEMM %llu | own-h reads + barrier 1 %llu | DMA issue + cell %llu | DMA wait + barrier 2 %llu | sum %llu\n",
+        printf("gru_layer_bf16_kernel<%d> K=%d cycles per step (one wave; the SIMD's other wave belongs to the CU's second workgroup): gate GEMM %llu | own-h reads + barrier 1 %llu | DMA issue + cell %llu | DMA wait + barrier 2 %llu | sum %llu\n",
                SPL, a.K, ts_sum[1] / a.T, ts_sum[2] / a.T, ts_sum[3] / a.T, ts_sum[4] / a.T, (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4]) / a.T);
 #endif
 }
@@ -429,10 +322,10 @@ int os_gru_try_layer_bf16(os_ctx *ctx, const LayerArgs &a, hipStream_t s, bool *
     const bool any_batch = (mode & OS_GRU_SPLIT_ANY_BATCH) != 0;
     os_ctx::GruSlot *slot = ctx->gru_slot;
     const size_t lds = ((size_t)((a.K + 3) & ~3) * BF_BM + (size_t)BF_BM * BF_HS) * sizeof(float);
-    if (!slot || a.H != BF_H || a.sv_r || a.xs_btf || a.gi || a.B % 4 != 0 || lds > 160 * 1024 || (size_t)a.K * a.B * 4 >= ((size_t)1 << 31) ||
+    if (!slot || a.H != BF_H || a.sv_r || a.xs_btf || a.gi || a.B % 4 != 0 || lds > 80 * 1024 || (size_t)a.K * a.B * 4 >= ((size_t)1 << 31) ||
         (size_t)a.H * a.B * 4 >= ((size_t)1 << 31))
         return 0;
-    if (!any_batch && (a.B + BF_BM - 1) / BF_BM < ctx->cu_count) return 0;       // fewer tiles than CUs: the fp32 small-batch kernels
+    if (!any_batch && (a.B + BF_BM - 1) / BF_BM < 2 * ctx->cu_count) return 0;   // fewer than two tiles per CU: the fp32 small-batch kernels
     // which layer of the loaded model is this?
     const os_gru_dims &d = ctx->gru;
     size_t off = 0, boff = 0;
@@ -461,8 +354,8 @@ int os_gru_try_layer_bf16(os_ctx *ctx, const LayerArgs &a, hipStream_t s, bool *
         slot->bf_spl = spl;
     }
     if (!ctx->bf16_layer_attr_set) {
-        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        OS_HIP(ctx, hipFuncSetAttribute((const void *)gru_layer_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         ctx->bf16_layer_attr_set = true;
     }
     LayerArgs b = a;

@@ -39,6 +39,8 @@ SCRATCH_FREE = {
     "osg::gru_layer_split_kernel<2, true, false>": "H = 64 small batches, training forward",
     "osg::gru_layer_split_kernel<4, false, true>": "window-stream inference, layer 0 of RNN(188,128,4) (os_gru_forward_windows)",
     "osg::gru_layer_split_kernel<2, false, true>": "window-stream inference, layer 0 of an H = 64 model",
+    "osg::gru_layer_bf16_kernel<3>": "opt-in split-bf16 layer GEMMs (os_gru_set_split_bf16), three terms",
+    "osg::gru_layer_bf16_kernel<2>": "the same, two terms",
     "osg::gru_gi_kernel<1>": "window-stream inference: rows . W_ih^T once per row",
     "osg::gru_gi_kernel<2>": "the same, 64-row tiles",
     "osg::gru_stack_kernel<4, false>": "the reference's own windows (B = 1 / 64), H = 128",
