@@ -1336,6 +1336,8 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             pa.K[pa.n] = K; pa.chunks[pa.n] = (K + 31) / 32; pa.W[pa.n] = Wih; pa.dst[pa.n] = wihT; pa.n++;
             pa.K[pa.n] = H; pa.chunks[pa.n] = H / 32; pa.W[pa.n] = Whh; pa.dst[pa.n] = whhT; pa.n++;
             if ((K + 31) / 32 > maxch) maxch = (K + 31) / 32;
+            if (H / 32 > maxch) maxch = H / 32;      // (round 5, found by tools/fuzz_shapes.py: a one-layer model with fewer input chunks
+                                                     // than hidden chunks left W_hh^T's upper chunks unpacked: wrong gradients)
         }
         const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_MISC, s, "pack_T_all_kernel");
         hipLaunchKernelGGL(pack_T_all_kernel, dim3(maxch, 16, pa.n), dim3(256), 0, s, pa, H3, grad_flat, nparam);

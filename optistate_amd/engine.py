@@ -313,8 +313,10 @@ class Engine:
         return pred, above, below
 
     def gru_windows_supported(self):
+        """Shapes os_gru_forward_windows takes: hidden 128 with up to 192 inputs, hidden 64 with up to 190 (the eight-wave split body's
+        LDS: gru_kernels.hip split_lds_bytes)."""
         d = self._gru_dims
-        return d is not None and d.hidden_size in (64, 128) and d.input_size <= 192
+        return d is not None and ((d.hidden_size == 128 and d.input_size <= 192) or (d.hidden_size == 64 and d.input_size <= 190))
 
     def gru_forward_soa(self, xs_tib):
         T, I, B = xs_tib.shape

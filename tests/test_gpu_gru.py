@@ -436,3 +436,21 @@ def test_window_stream_through_the_module_and_pipeline_g5():
     mn, mx = torch.zeros(12, device="cuda") - 2.0, torch.zeros(12, device="cuda") + 3.0
     pred, above, below = pl.predict_rows(m, rows, 10, mn, mx)
     assert torch.allclose(pred, out[:, :12] * 5.0 - 2.0, atol=1e-6) and torch.allclose(above - pred, out[:, 12:] * 5.0, atol=1e-5)
+
+
+def test_window_stream_shape_the_entry_point_declines_falls_back_to_materialised_windows():
+    """hidden 64 with 191-192 inputs: the split body's LDS does not fit, os_gru_forward_windows returns -4 and RNN.forward_windows
+    materialises (round 5, found by tools/fuzz_shapes.py: Engine.gru_windows_supported said yes and the call raised)."""
+    from optistate_amd import RNN
+    torch.manual_seed(2)
+    m = RNN(192, 64, 1, 24, torch.device("cuda")).to("cuda").eval()
+    rows = torch.rand(300, 192, device="cuda")
+    with torch.no_grad():
+        out = m.forward_windows(rows, 10)
+        ref = m(rows.unfold(0, 10, 1).permute(0, 2, 1).contiguous())
+    assert not m._engine.gru_windows_supported() and torch.equal(out, ref)
+    m2 = RNN(190, 64, 1, 24, torch.device("cuda")).to("cuda").eval()
+    with torch.no_grad():
+        o2 = m2.forward_windows(rows[:, :190].contiguous(), 10)
+        r2 = m2(rows[:, :190].contiguous().unfold(0, 10, 1).permute(0, 2, 1).contiguous())
+    assert m2._engine.gru_windows_supported() and (o2 - r2).abs().max().item() < 1e-6

@@ -221,3 +221,35 @@ def test_stacked_backward_sweep_matches_per_layer_sweeps(monkeypatch, dims, B, T
         scale = max(r.abs().max().item(), 1e-8)
         assert (gk - r).abs().max().item() < 2e-4 * scale + 1e-9, k
         off += r.numel()
+
+
+@pytest.mark.parametrize("I,H,B,T", [(64, 128, 33, 25), (32, 128, 64, 3), (20, 64, 40, 5)])
+def test_one_layer_model_with_fewer_input_chunks_than_hidden_chunks(I, H, B, T):
+    """Round 5, found by tools/fuzz_shapes.py: the backward's transposed weight pack sized its grid by the INPUT chunks of the widest
+    layer; a one-layer model with input_size <= 96 at hidden 128 (<= 32 at hidden 64) left W_hh^T's upper chunks unpacked and every
+    GRU gradient was wrong by ~10 % (the reference's shapes -- four layers, or 60 inputs at hidden 64 -- were never affected).
+    Gradients against fp64 autograd."""
+    from optistate_amd import RNN
+    torch.manual_seed(25)
+    C = 24
+    m = RNN(I, H, 1, C, torch.device("cuda")).to("cuda").eval()
+    x = torch.rand(B, T, I) * 2 - 1
+    with torch.no_grad():
+        m(x[:1].cuda())
+    eng = m._engine
+    xg = x.cuda()
+    y = torch.rand(B, C // 2, device="cuda")
+    o = eng.gru_forward_train(xg)
+    _, dout, _ = eng.gru_loss(o, y, want_target=True)
+    g = eng.gru_backward(xg, o, dout).double().cpu()
+    md = torch.nn.GRU(I, H, 1, batch_first=True).double()
+    fc = torch.nn.Linear(H, C).double()
+    sd = {k: v.double().cpu() for k, v in m.state_dict().items()}
+    md.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("gru.")})
+    fc.load_state_dict({k[3:]: v for k, v in sd.items() if k.startswith("fc.")})
+    hseq, _ = md(x.double())
+    od = torch.sigmoid(fc(hseq[:, -1]))
+    od.backward(dout.double().cpu())
+    ref = torch.cat([p.grad.reshape(-1) for p in list(md.parameters()) + list(fc.parameters())])
+    assert (o.double().cpu() - od.detach()).abs().max().item() < 1e-5
+    assert (g - ref).abs().max().item() < 1e-4 * ref.abs().max().item()

@@ -1,0 +1,83 @@
+"""GPU: random-shape parity sweep of the GRU entry points (drop-in RNN forward, window-stream forward, training forward + backward)
+against the float64 C oracle / fp64 autograd.   python tools/fuzz_shapes.py [n_cases] [seed]
+Every case prints its shape and distances; the script exits non-zero at the first distance above the suite's bars (1e-5 forward,
+1e-4 relative gradients)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from optistate_amd import RNN  # noqa: E402
+from oracle import c_oracle as orc  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for case in range(n):
+        H = int(rng.choice([32, 64, 128, 128]))
+        L = int(rng.integers(1, 5))
+        I = int(rng.choice([1, 3, 17, 60, 61, 64, 100, 128, 188, 189, 192, 200]))
+        C = int(rng.choice([2, 24, 24, 30]))
+        B = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 64, 65, 100, 257, 640, 1000, 2049, 4100]))
+        T = int(rng.choice([1, 2, 3, 7, 10, 10, 25]))
+        torch.manual_seed(case)
+        m = RNN(I, H, L, C, torch.device("cuda")).to("cuda").eval()
+        x = torch.rand(B, T, I) * 2 - 1
+        with torch.no_grad():
+            out = m(x.cuda()).cpu().numpy()
+        name = m._engine.kernel_name("gru_layer")
+        w = orc.flatten_state_dict(m.state_dict(), L)
+        pick = np.unique(np.r_[0:min(B, 24), max(B - 24, 0):B])
+        ref, _, _ = orc.gru_forward(x.numpy()[pick], w, I, H, L, C)
+        e_fwd = float(np.abs(out[pick] - ref).max())
+        msg = f"case {case}: RNN({I},{H},{L},{C}) B={B} T={T} [{name}] fwd {e_fwd:.1e}"
+        ok = np.isfinite(out).all() and e_fwd < 1e-5
+        # window stream (shapes the entry point takes)
+        if H in (64, 128) and I <= 192 and B >= 2:
+            rows = (torch.rand(B + T - 1, I) * 2 - 1).cuda()
+            with torch.no_grad():
+                ow = m.forward_windows(rows, T)
+                om = m(rows.unfold(0, T, 1).permute(0, 2, 1).contiguous())
+            e_w = float((ow - om).abs().max())
+            msg += f" | windows {e_w:.1e}"
+            ok = ok and e_w < 1e-6
+        # training forward + backward against fp64 autograd on a small batch
+        if B <= 257:
+          try:
+            eng = m._engine
+            xg = x.cuda()
+            y = torch.rand(B, C // 2, device="cuda")
+            o = eng.gru_forward_train(xg)
+            _, dout, _ = eng.gru_loss(o, y, want_target=True)
+            g = eng.gru_backward(xg, o, dout).double().cpu()
+            md = torch.nn.GRU(I, H, L, batch_first=True).double()
+            fc = torch.nn.Linear(H, C).double()
+            sd = {k: v.double().cpu() for k, v in m.state_dict().items()}
+            md.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("gru.")})
+            fc.load_state_dict({k[3:]: v for k, v in sd.items() if k.startswith("fc.")})
+            hseq, _ = md(x.double())
+            od = torch.sigmoid(fc(hseq[:, -1]))
+            od.backward(dout.double().cpu())
+            ref_g = torch.cat([p.grad.reshape(-1) for p in list(md.parameters()) + list(fc.parameters())])
+            scale = float(ref_g.abs().max()) + 1e-30
+            e_g = float((g - ref_g).abs().max()) / scale
+            e_o = float((o.double().cpu() - od.detach()).abs().max())
+            msg += f" | train fwd {e_o:.1e} grad {e_g:.1e} [{eng.kernel_name('train_sweep')}]"
+            ok = ok and e_g < 1e-4 and e_o < 1e-5
+          except RuntimeError as e:
+            if "(-4)" not in str(e):
+                raise
+            msg += " | train: shape not taken (-4)"
+        print(msg + ("" if ok else "   <-- ABOVE THE BAR"), flush=True)
+        bad += 0 if ok else 1
+    print(f"{n} cases, {bad} above the bars")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
