@@ -300,7 +300,7 @@ __device__ __forceinline__ void quad_sum6(float &a, float &b, float &c, float &d
 // kf_rows_kernel.hip (its own translation unit: compile flags): picks kf_run_rows2_kernel's instantiation and launches it
 hipError_t launch_kf_rows2(const KfRunArgs &a, const float *qmat, bool feat, bool aux, hipStream_t s);
 // kf_dense_rows.hip: the predict_mpc (dense F_d) filter in float64, 16 lanes per trajectory; qr = Q (144) | R (100) on the device
-hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s);
+hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s, bool dense = true);
 // the batched single-step pieces on the same layout (P as float, or double with OS_KF_P_FLOAT64)
 hipError_t launch_kf_predict_rows(int B, float *p, const float *f, const float *body_ref, float *x, void *P, bool p64, float *ptrace_out,
                                   const KfConst &k, const float *qr, bool dense, hipStream_t s);

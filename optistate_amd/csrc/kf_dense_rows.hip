@@ -33,7 +33,7 @@ using namespace rows64;
 
 // AUX: P_trace / K_gain / p_rot outputs where the pointers are set; FEAT: the normalised 60-feature row of the two-kernel
 // fused path [x_post | accel | f | p_world | dp | imu] (lane r writes the r-th element of each block).
-template <bool SEQ, bool AUX, bool FEAT>
+template <bool SEQ, bool AUX, bool FEAT, bool DENSE = true>
 __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a, const float *__restrict__ qr /* Q 144 | R 100 */)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
     // every batch update (six / five 16-byte reads) instead of holding 24 + 20 registers across the whole step
     __shared__ __attribute__((aligned(16))) double qs[NS * NS], rs[(NM + 2) * NM];
     for (int i = threadIdx.x; i < NS * NS; i += blockDim.x) qs[i] = (double)qr[i];
-    for (int i = threadIdx.x; i < (NM + 2) * NM; i += blockDim.x) rs[i] = i < NM * NM ? (double)(0.5f * (qr[144 + i] + qr[144 + (i % NM) * NM + i / NM])) : 0.0;     // symmetrised as update_batch forms S; rows 10, 11: zeros for the lanes that own no measurement
+    for (int i = threadIdx.x; i < (NM + 2) * NM; i += blockDim.x) rs[i] = i < NM * NM ? (double)qr[144 + i] : 0.0;     // R as it is (the reference adds it to H P H^T as given); rows 10, 11: zeros for the lanes that own no measurement
     __syncthreads();
     const int qoff = rr * NS, roff = (am >= 0 ? am : NM) * NM;
 
@@ -70,11 +70,11 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
     StepIn in;
     float bref[3];
     load_step(a, 0, voff, rowB, in);
-    {
+    if (DENSE) {
         rsrc_t rb = make_rsrc(a.body_ref, 12 * rowB);
 #pragma unroll
         for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
-    }
+    } else bref[0] = bref[1] = bref[2] = 0.f;
     for (int t = 0; t < a.T; t++) {
         // (an offset the optimiser cannot see through: the LDS reads of Q / R stay inside the step instead of being hoisted
         // into 44 loop-invariant registers)
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
         // ---- the prior state, replicated per lane; z, covariance predict, next_state (kf_dense_rows.hpp) ----
         float x[NS], z[NM], pw[12];
         gather_state(xr, x);
-        status |= front_row(x, xr, P, in, bref, k, ed, qrow, one, r, z, pw);
+        status |= front_row<DENSE>(x, xr, P, in, bref, k, ed, qrow, one, r, z, pw);
         float xn = x[0];
 #pragma unroll
         for (int i = 1; i < NS; i++) xn = (rr == i) ? x[i] : xn;
@@ -115,9 +115,11 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
         const int tn = (t + 1 < a.T) ? t + 1 : t;
         auto prefetch = [&]() {
             load_step(a, tn, voff, rowB, in);
-            rsrc_t rb = make_rsrc(a.body_ref + (size_t)tn * 12 * B, 12 * rowB);
+            if (DENSE) {
+                rsrc_t rb = make_rsrc(a.body_ref + (size_t)tn * 12 * B, 12 * rowB);
 #pragma unroll
-            for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
+                for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
+            }
         };
         if (!AUX) prefetch();
         // ---- update (kalman_filter.py:164-174) ----
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
             double K[NM], rrow[NM];
 #pragma unroll
             for (int q = 0; q < NM; q++) rrow[q] = rrow_b[q];
-            if (AUX) status |= update_batch_row<true>(xd, P, z, rrow, K, one, &kgain);
-            else status |= update_batch_row(xd, P, z, rrow, K);
+            if (AUX) status |= update_batch_row<true>(xd, P, z, rrow, K, am, one, &kgain);
+            else status |= update_batch_row(xd, P, z, rrow, K, am);
         }
         xr = (float)xd;
         if (!(xr * 0.f == 0.f)) status |= 2;
@@ -154,10 +156,14 @@ __global__ __launch_bounds__(256, 2) void kf_dense_rows_kernel(const KfRunArgs a
     status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
     status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
     if (live && r < 12) {
-        a.x[(size_t)r * B + b] = xr;
+        // (opaque copies of the trajectory and row indices: the addresses of these stores are formed HERE, not hoisted above the T loop
+        // and kept -- or spilled: 12 B of scratch in the <batch, AUX, dense> instance -- across it)
+        int bb = b, rq = r;
+        asm volatile("" : "+v"(bb), "+v"(rq));
+        a.x[(size_t)rq * B + bb] = xr;
 #pragma unroll
-        for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = (float)P[j];
-        if (r == 0) a.status[b] = status;
+        for (int j = 0; j < NS; j++) a.P[(size_t)(rq * NS + j) * B + bb] = (float)P[j];
+        if (r == 0) a.status[bb] = status;
     }
 }
 
@@ -272,9 +278,9 @@ __global__ __launch_bounds__(256, 2) void kf_update_rows_kernel(int B_, const fl
         for_sel([&](auto A, auto SA) { K[decltype(A)::v] = P[decltype(SA)::v] * rcp64(rrow[decltype(A)::v]); });
     } else {
 #pragma unroll
-        for (int q = 0; q < NM; q++)                    // symmetrised, as update_batch forms S
-            rrow[q] = am >= 0 ? (double)(0.5f * (qr[144 + am * NM + q] + qr[144 + q * NM + am])) : 0.0;
-        st = update_batch_row<true>(xd, P, zz, rrow, K, one, &kg);
+        for (int q = 0; q < NM; q++)                    // the lane's row of R, as given
+            rrow[q] = am >= 0 ? (double)qr[144 + am * NM + q] : 0.0;
+        st = update_batch_row<true>(xd, P, zz, rrow, K, am, one, &kg);
     }
     const float xo = (float)xd;
     if (!(xo * 0.f == 0.f)) st |= 2;
@@ -325,18 +331,25 @@ hipError_t launch_kf_update_rows(int B, const float *z, float *x, void *P, void 
 }
 
 // host side: picks the instantiation (kf_kernels.hip: os_kf_run_impl)
-hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s)
+hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, bool feat, bool aux, hipStream_t s, bool dense)
 {
     dim3 grid((a.B + 15) / 16), block(256);
-#define OSD_GO(SEQ_, AUX_, FEAT_) hipLaunchKernelGGL((kf_dense_rows_kernel<SEQ_, AUX_, FEAT_>), grid, block, 0, s, a, qr)
-    if (seq) {
-        if (feat) OSD_GO(true, false, true);
-        else if (aux) OSD_GO(true, true, false);
-        else OSD_GO(true, false, false);
+#define OSD_GO(SEQ_, AUX_, FEAT_, DENSE_) hipLaunchKernelGGL((kf_dense_rows_kernel<SEQ_, AUX_, FEAT_, DENSE_>), grid, block, 0, s, a, qr)
+    if (!dense) {
+        // the predict(p, f) covariance with the BATCH update (a non-diagonal R, or the caller asked for the form that builds K):
+        // float64 here -- the float32 one-trajectory-per-lane kernel this replaces lost the filter on ill-conditioned S (fitted
+        // noise, cond ~1e6, plus flight phases: state errors of 1e-3 .. 1e+1 after 40-100 steps; found by tools/fuzz_kf.py, round 5)
+        if (feat) OSD_GO(false, false, true, false);
+        else if (aux) OSD_GO(false, true, false, false);
+        else OSD_GO(false, false, false, false);
+    } else if (seq) {
+        if (feat) OSD_GO(true, false, true, true);
+        else if (aux) OSD_GO(true, true, false, true);
+        else OSD_GO(true, false, false, true);
     } else {
-        if (feat) OSD_GO(false, false, true);
-        else if (aux) OSD_GO(false, true, false);
-        else OSD_GO(false, false, false);
+        if (feat) OSD_GO(false, false, true, true);
+        else if (aux) OSD_GO(false, true, false, true);
+        else OSD_GO(false, false, false, true);
     }
 #undef OSD_GO
     return hipGetLastError();

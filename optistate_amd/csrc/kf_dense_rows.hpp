@@ -145,69 +145,71 @@ __device__ __forceinline__ float kgain_rows(const double (&K)[NM], double one)
     return (float)t;
 }
 // ---- batch update as the reference writes it: S = H P H^T + R, K = P H^T S^-1, x += K y, P -= K H P ----
-// The lane of state row SEL[a] also owns measurement a: row a of the Cholesky factor L (entries q <= a) lives in ITS registers
-// L[0..9]; rrow: that lane's row of R.  K[0..9]: this lane's row of the 12 x 10 gain.
+// S is taken as it IS -- rounding leaves P, and with it S, not exactly symmetric, and the reference inverts that S
+// (np.linalg.inv, kalman_filter.py:169).  K from a SYMMETRISED S (rounds 1-5a: a Cholesky of the lower triangle) is unstable with
+// this covariance update: the antisymmetric part of P then grows step by step instead of staying at rounding level -- in float64
+// the filter was lost after 70-110 steps of ill-conditioned runs (fitted noise, flight phases; found by tools/fuzz_kf.py; numpy
+// reproduces it: the reference's form keeps |P - P^T| at 1e-15 over the same 160 steps).  So: LU of the full S, no pivoting (S is a
+// positive definite matrix plus rounding noise), one row per lane.
+// The lane of state row SEL[a] also owns measurement a (am = a; am < 0: none) and holds row a of S, then of the factors, in
+// M[0..9]: multipliers L[a][q] (q < a) | 1 / U[a][a] | U[a][q] (q > a).  rrow: that lane's row of R.  K[0..9]: this lane's row of the gain.
+template <int S>
+__device__ __forceinline__ void fmac_self(double &acc, double m)      // acc += (acc of lane S) * m
+{
+    asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(S));
+}
 template <bool WANT_KGAIN = false>
-__device__ __forceinline__ int update_batch_row(double &xd, double *P, const float *z, const double *rrow, double (&K)[NM], double one = 1.0,
+__device__ __forceinline__ int update_batch_row(double &xd, double *P, const float *z, const double *rrow, double (&K)[NM], int am, double one = 1.0,
                                                 float *kgain = nullptr)
 {
     int status = 0;
-    double L[NM], dinv[NM];
-    // S[a][q], q <= a, from the lower triangle (row SEL[a] of P is this lane's): what a Cholesky reads
-    for_sel([&](auto Q, auto SQ) { L[decltype(Q)::v] = P[decltype(SQ)::v] + rrow[decltype(Q)::v]; });
+    double M[NM];
+    for_sel([&](auto Q, auto SQ) { M[decltype(Q)::v] = P[decltype(SQ)::v] + rrow[decltype(Q)::v]; });      // row a of S (row SEL[a] of P is this lane's)
     for_sel([&](auto J, auto SJ) {
         constexpr int j = decltype(J)::v, sj = decltype(SJ)::v;
-        // s = S[a][j] - sum_{q<j} L[a][q] L[j][q]; in lane SEL[j] this is the pivot d
-        double t = 0.0;
-#pragma unroll
-        for (int q = 0; q < j; q++) {
-            if (q == 0) fmacb<sj, true>(t, L[q], L[q]);
-            else fmacb<sj, false>(t, L[q], L[q]);
-        }
-        const double s = L[j] - t;
-        double d = bc64<sj>(s);
+        double d = bc64<sj>(M[j]);                     // the pivot U[j][j]
         if (!(d > 0.0) || !(d < 1.0e300)) { status |= 1; d = 1.0; }
-        const double di = rsqrt64(d);
-        dinv[j] = di;
-        L[j] = s * di;                                 // lane SEL[j]: sqrt(d); lanes of later measurements: L[a][j]
-        // L[j] is the DPP source of later chain members that carry no s_nop of their own: pin its definition HERE (volatile
-        // assembly statements keep their order), or hipcc sinks the multiply to just in front of its first use -- inside the next
-        // column's chain, zero wait states ahead of the DPP read (found by tools/isa_dpp_hazard_scan.py after G8 failed by 9e-4)
-        asm volatile("" : "+v"(L[j]));
-    });
-    // K[i,:] = solve(S, P[i,sel]): forward then back substitution, L[a][q] broadcast from the lane of measurement a
-    double y[NM];
-    for_sel([&](auto A, auto SA) {
-        constexpr int a = decltype(A)::v, sa = decltype(SA)::v;
-        double t = 0.0;
+        const double di = rcp64(d);
+        const double m = am > j ? M[j] * di : 0.0;     // rows below the pivot: L[a][j]; every other lane: untouched
+        const double nm = -m;
 #pragma unroll
-        for (int q = 0; q < a; q++) {
-            if (q == 0) fmacb<sa, true>(t, L[q], y[q]);
-            else fmacb<sa, false>(t, L[q], y[q]);
-        }
-        y[a] = (P[sa] - t) * dinv[a];
+        for (int q = j + 1; q < NM; q++) fmac_self<sj>(M[q], nm);     // S[a][q] -= L[a][j] U[j][q]
+        M[j] = am > j ? m : (am == j ? di : M[j]);     // (the pivot lane keeps 1 / U[j][j]: all the substitution needs of it)
+        // M[j] is a DPP source of the substitutions below: pin its definition HERE (see tools/isa_dpp_hazard_scan.py)
+        asm volatile("" : "+v"(M[j]));
     });
-    // back: K[a] = (y[a] - sum_{q>a} L[q][a] K[q]) dinv[a];  L[q][a] = register a of the lane of measurement q
-#define OSD_BACK(a, ...)                                            \
+    // K[i,:] S = P[i,sel]:  w U = P[i,sel] (forward over the columns of U), then K L = w (backward, unit diagonal);
+    // U[b][c] / L[b][c] = register c of the lane of measurement b
+    // (w is built in K's registers and turned into K in place)
+    for_sel([&](auto C_, auto SC) {
+        constexpr int c = decltype(C_)::v, sc = decltype(SC)::v;
+        double t = 0.0;
+        for_sel([&](auto B_, auto SB) {
+            constexpr int b = decltype(B_)::v, sb = decltype(SB)::v;
+            if constexpr (b < c) fmacb<sb, true>(t, M[c], K[b]);
+        });
+        K[c] = (P[sc] - t) * bc64<sc>(M[c]);
+    });
+#define OSD_BACK(c, ...)                                            \
     {                                                               \
         double t = 0.0;                                             \
         __VA_ARGS__                                                 \
-        K[a] = (y[a] - t) * dinv[a];                                \
+        K[c] -= t;                                                  \
     }
     OSD_BACK(9, )
-    OSD_BACK(8, fmacb<11, true>(t, L[8], K[9]);)
-    OSD_BACK(7, fmacb<10, true>(t, L[7], K[8]); fmacb<11, false>(t, L[7], K[9]);)
-    OSD_BACK(6, fmacb<9, true>(t, L[6], K[7]); fmacb<10, false>(t, L[6], K[8]); fmacb<11, false>(t, L[6], K[9]);)
-    OSD_BACK(5, fmacb<8, true>(t, L[5], K[6]); fmacb<9, false>(t, L[5], K[7]); fmacb<10, false>(t, L[5], K[8]); fmacb<11, false>(t, L[5], K[9]);)
-    OSD_BACK(4, fmacb<7, true>(t, L[4], K[5]); fmacb<8, false>(t, L[4], K[6]); fmacb<9, false>(t, L[4], K[7]); fmacb<10, false>(t, L[4], K[8]); fmacb<11, false>(t, L[4], K[9]);)
-    OSD_BACK(3, fmacb<6, true>(t, L[3], K[4]); fmacb<7, false>(t, L[3], K[5]); fmacb<8, false>(t, L[3], K[6]); fmacb<9, false>(t, L[3], K[7]); fmacb<10, false>(t, L[3], K[8]);
-             fmacb<11, false>(t, L[3], K[9]);)
-    OSD_BACK(2, fmacb<5, true>(t, L[2], K[3]); fmacb<6, false>(t, L[2], K[4]); fmacb<7, false>(t, L[2], K[5]); fmacb<8, false>(t, L[2], K[6]); fmacb<9, false>(t, L[2], K[7]);
-             fmacb<10, false>(t, L[2], K[8]); fmacb<11, false>(t, L[2], K[9]);)
-    OSD_BACK(1, fmacb<2, true>(t, L[1], K[2]); fmacb<5, false>(t, L[1], K[3]); fmacb<6, false>(t, L[1], K[4]); fmacb<7, false>(t, L[1], K[5]); fmacb<8, false>(t, L[1], K[6]);
-             fmacb<9, false>(t, L[1], K[7]); fmacb<10, false>(t, L[1], K[8]); fmacb<11, false>(t, L[1], K[9]);)
-    OSD_BACK(0, fmacb<1, true>(t, L[0], K[1]); fmacb<2, false>(t, L[0], K[2]); fmacb<5, false>(t, L[0], K[3]); fmacb<6, false>(t, L[0], K[4]); fmacb<7, false>(t, L[0], K[5]);
-             fmacb<8, false>(t, L[0], K[6]); fmacb<9, false>(t, L[0], K[7]); fmacb<10, false>(t, L[0], K[8]); fmacb<11, false>(t, L[0], K[9]);)
+    OSD_BACK(8, fmacb<11, true>(t, M[8], K[9]);)
+    OSD_BACK(7, fmacb<10, true>(t, M[7], K[8]); fmacb<11, true>(t, M[7], K[9]);)
+    OSD_BACK(6, fmacb<9, true>(t, M[6], K[7]); fmacb<10, true>(t, M[6], K[8]); fmacb<11, true>(t, M[6], K[9]);)
+    OSD_BACK(5, fmacb<8, true>(t, M[5], K[6]); fmacb<9, true>(t, M[5], K[7]); fmacb<10, true>(t, M[5], K[8]); fmacb<11, true>(t, M[5], K[9]);)
+    OSD_BACK(4, fmacb<7, true>(t, M[4], K[5]); fmacb<8, true>(t, M[4], K[6]); fmacb<9, true>(t, M[4], K[7]); fmacb<10, true>(t, M[4], K[8]); fmacb<11, true>(t, M[4], K[9]);)
+    OSD_BACK(3, fmacb<6, true>(t, M[3], K[4]); fmacb<7, true>(t, M[3], K[5]); fmacb<8, true>(t, M[3], K[6]); fmacb<9, true>(t, M[3], K[7]); fmacb<10, true>(t, M[3], K[8]);
+             fmacb<11, true>(t, M[3], K[9]);)
+    OSD_BACK(2, fmacb<5, true>(t, M[2], K[3]); fmacb<6, true>(t, M[2], K[4]); fmacb<7, true>(t, M[2], K[5]); fmacb<8, true>(t, M[2], K[6]); fmacb<9, true>(t, M[2], K[7]);
+             fmacb<10, true>(t, M[2], K[8]); fmacb<11, true>(t, M[2], K[9]);)
+    OSD_BACK(1, fmacb<2, true>(t, M[1], K[2]); fmacb<5, true>(t, M[1], K[3]); fmacb<6, true>(t, M[1], K[4]); fmacb<7, true>(t, M[1], K[5]); fmacb<8, true>(t, M[1], K[6]);
+             fmacb<9, true>(t, M[1], K[7]); fmacb<10, true>(t, M[1], K[8]); fmacb<11, true>(t, M[1], K[9]);)
+    OSD_BACK(0, fmacb<1, true>(t, M[0], K[1]); fmacb<2, true>(t, M[0], K[2]); fmacb<5, true>(t, M[0], K[3]); fmacb<6, true>(t, M[0], K[4]); fmacb<7, true>(t, M[0], K[5]);
+             fmacb<8, true>(t, M[0], K[6]); fmacb<9, true>(t, M[0], K[7]); fmacb<10, true>(t, M[0], K[8]); fmacb<11, true>(t, M[0], K[9]);)
 #undef OSD_BACK
     // x += K (z - H x)
     double dx = 0.0;
@@ -268,6 +270,9 @@ __device__ __forceinline__ void gather_state(float xr, float *x /*12*/)
 // next_state (x is the replicated prior on entry and the replicated prediction on return; pw = the rotated foot positions).
 // r = lane & 15, xr = the lane's own prior component (angles for the sincos sharing), bref = body_ref's three angles,
 // ed = expm1(dt), qrow = the lane's row of Q (float64), one = 1.0 in a register.  Returns status bit 4 or 0.
+// DENSE = false: the covariance of predict(p, f) instead (kalman_filter.py:124-135: F_d = I + dt F from the PRIOR attitude;
+// bref, ed unused).
+template <bool DENSE = true>
 __device__ __forceinline__ int front_row(float *x, float xr, double *P, const StepIn &in, const float *bref, const KfConst &k, double ed,
                                          const double *qrow, double one, int r, float *z, float *pw)
 {
@@ -282,7 +287,19 @@ __device__ __forceinline__ int front_row(float *x, float xr, double *P, const St
     const Rot rbr = rotation_sc(bc32<6>(sv), bc32<6>(cv), bc32<7>(sv), bc32<7>(cv), bc32<8>(sv), bc32<8>(cv));
     measurement_r(in, rimu, z);
     // ---- covariance predict (kalman_filter.py:153-158) ----
-    {
+    if (!DENSE) {
+        double g[9], cf[6];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = (double)k.dt * (double)rot.m[3 * kk + i];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            cf[kk] = r == 0 ? g[kk] : r == 1 ? g[3 + kk] : r == 2 ? g[6 + kk] : 0.0;
+            cf[3 + kk] = (r == 3 + kk) ? (double)k.dt : 0.0;
+        }
+        predict_struct_row(P, qrow, g, (double)k.dt, cf);
+    } else {
         // e[3 i + kk] = expm1(dt Rb[kk][i]): lane n < 9 evaluates entry n
         float rbn = rbr.m[0];
 #pragma unroll

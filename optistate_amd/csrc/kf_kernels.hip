@@ -547,7 +547,7 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise);
     const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
                         : dense ? (seq ? "kf_dense_rows_kernel<SEQ>" : "kf_dense_rows_kernel<BATCH>")
-                                : (seq ? "kf_run_kernel<SEQ>" : "kf_run_kernel<BATCH>");
+                                : (seq ? "kf_run_kernel<SEQ>" : "kf_dense_rows_kernel<BATCH,predict(p,f)>");
     const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, kname);
 #define OS_DISPATCH(SEQ)                                                               \
     (feat ? launch_kf_run<SEQ, false, false, true>(a, s)                               \
@@ -590,7 +590,7 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
                  : (aux ? launch_kf_run<true, false, true, false, true>(a, s)
                         : launch_kf_run<true, false, false, false, true>(a, s));
     else if (seq) e = OS_DISPATCH(true);
-    else e = OS_DISPATCH(false);
+    else e = launch_kf_dense_rows(a, (const float *)ctx->kf_qr, false, feat, aux, s, false);      // batch update: float64 row layout
 #undef OS_DISPATCH
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, e);

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
     for (int j = 0; j < NS; j++) P[j] = (double)a.kf.P[(size_t)(rr * NS + j) * B + b];
     for (int el = lane; el < 144; el += 64) W.Q[el] = (double)a.kf.k.Q[el];
     for (int el = lane; el < 120; el += 64)             // symmetrised, as update_batch forms S (kf_device.hpp)
-        (&W.R[0][0])[el] = el < 100 ? (double)(0.5f * (a.kf.k.R[el] + a.kf.k.R[(el % 10) * 10 + el / 10])) : 0.0;
+        (&W.R[0][0])[el] = el < 100 ? (double)a.kf.k.R[el] : 0.0;
     if (lane == 0) {
         // MpcParams, field by field: a reference to a.prm would make hipcc copy the whole argument block to scratch
 #pragma unroll
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
 #pragma unroll
         for (int q = 0; q < NM; q++) rrow[q] = rrow_l[q];
         float kg = 0.f;
-        status |= rw::update_batch_row<true>(xd, P, z, rrow, K, one, &kg);
+        status |= rw::update_batch_row<true>(xd, P, z, rrow, K, am, one, &kg);
         xr = (float)xd;
         if (!(xr * 0.f == 0.f)) status |= 2;
         if (lane < 12) a.kf.x_out[((size_t)t * 12 + lane) * B + b] = xr;

@@ -70,11 +70,14 @@ SCRATCH_FREE = {
     "osm::mpc_solve_kernel<2>": "the same, trot (two legs)",
     "osm::mpc_solve_kernel<3>": "three legs",
     "osm::mpc_solve_kernel<4>": "four legs",
-    "osk::kf_dense_rows_kernel<false, false, false>": "predict_mpc covariance + batch update, float64, 16 lanes per trajectory",
-    "osk::kf_dense_rows_kernel<true, false, false>": "the same with the sequential update (diagonal R)",
-    "osk::kf_dense_rows_kernel<false, true, false>": "batch update with P_trace / K_gain outputs",
-    "osk::kf_dense_rows_kernel<true, true, false>": "sequential update with P_trace / K_gain outputs",
-    "osk::kf_dense_rows_kernel<false, false, true>": "feature rows for the two-kernel fused path (dense F_d)",
+    "osk::kf_dense_rows_kernel<false, false, false, true>": "predict_mpc covariance + batch update, float64, 16 lanes per trajectory",
+    "osk::kf_dense_rows_kernel<true, false, false, true>": "the same with the sequential update (diagonal R)",
+    "osk::kf_dense_rows_kernel<false, true, false, true>": "batch update with P_trace / K_gain outputs",
+    "osk::kf_dense_rows_kernel<true, true, false, true>": "sequential update with P_trace / K_gain outputs",
+    "osk::kf_dense_rows_kernel<false, false, false, false>": "predict(p,f) covariance + BATCH update (non-diagonal R / sequential=False), float64",
+    "osk::kf_dense_rows_kernel<false, true, false, false>": "the same with P_trace / K_gain outputs",
+    "osk::kf_dense_rows_kernel<false, false, true, false>": "the same as the first kernel of the two-kernel fused path",
+    "osk::kf_dense_rows_kernel<false, false, true, true>": "feature rows for the two-kernel fused path (dense F_d)",
 }
 
 

@@ -149,7 +149,7 @@ def test_kernel_name_reports_the_variant_that_ran():
     eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone())
     assert eng.kernel_name("kf") == "kf_run_rows2_kernel"               # B = 256 <= 8,192: 16 lanes per trajectory
     eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone(), sequential=False)
-    assert eng.kernel_name("kf") == "kf_run_kernel<BATCH>"
+    assert eng.kernel_name("kf") == "kf_dense_rows_kernel<BATCH,predict(p,f)>"      # the batch form: float64, 16 lanes per trajectory
     pr = eng.profile_read()
     assert pr["kf"][1] == 2 and pr["kf"][0] > 0 and set(pr) == set(__import__("optistate_amd._capi", fromlist=["x"]).PHASE_NAMES)
     eng.profile(False)

@@ -412,3 +412,33 @@ def test_dense_rows_kernel_full_matrix_noise_and_feature_rows(eng):
     r = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], s["contact"], x, P, body_ref=br, dense_fd=True, sequential=False)
     assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < STATE_TOL
     assert int(eng.failed(r["status"]).sum()) == 0
+
+
+@pytest.mark.parametrize("dense", [False, True], ids=["predict(p,f)", "predict_mpc"])
+def test_batch_update_stays_with_the_reference_over_long_ill_conditioned_runs(eng, dense):
+    """Round 5, found by tools/fuzz_kf.py: K from a SYMMETRISED S (a Cholesky of its lower triangle) lets the antisymmetric part of P
+    grow step by step under the reference's covariance update P -= K H P; with the fitted noise set (cond(S) ~ 1e6) and hostile
+    inputs (flight phases, fast yaw) the float64 filter was lost after 70-110 steps.  The reference inverts S as it is
+    (kalman_filter.py:169); so does update_batch_row now (LU of the full S).  160 steps, batch form, against the oracle."""
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    B, T = 600, 160
+    d = synth_numpy(B, T, seed=1055, hostile=True)
+    kw = {}
+    if dense:
+        d["body_ref"] = np.zeros((B, T, 12), dtype=np.float32); d["body_ref"][..., 0:3] = d["imu"][..., 0:3]
+        kw = dict(body_ref=eng.pack(torch.as_tensor(d["body_ref"])), dense_fd=True)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)), Q_FITTED, R_FITTED,
+                           body_ref=d.get("body_ref"), mode=1 if dense else 0)
+    s = soa(eng, d)
+    eng.set_noise(Q_FITTED, R_FITTED)
+    x = torch.as_tensor(d["x0"].T.copy()).cuda()
+    P = torch.as_tensor(np.tile(Q_FITTED.astype(np.float32).reshape(144, 1), (1, B))).cuda()
+    r = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], s["contact"], x, P, sequential=False, symmetric=False, want_trace=True, **kw)
+    assert eng.kernel_name("kf").startswith("kf_dense_rows_kernel<BATCH")
+    assert int(eng.failed(r["status"]).sum()) == 0 and int((ref["status"] != 0).sum()) == 0
+    xo = eng.unpack(r["x_out"]).cpu().numpy()
+    assert np.abs(xo - ref["x"]).max() < STATE_TOL
+    assert np.abs(r["P_trace"].cpu().numpy().T / ref["P_trace"] - 1).max() < 1e-3
+    Pf = P.cpu().numpy().T.reshape(B, 12, 12)
+    assert np.abs(Pf - np.swapaxes(Pf, 1, 2)).max() < 1e-5 * np.abs(Pf).max()           # P stays symmetric to rounding, as the reference's does
