@@ -361,104 +361,9 @@ __device__ __forceinline__ void cov_predict_dense(PT *P, const Rot &rb, const Kf
     }
 }
 
-// Batch update as the reference writes it (kalman_filter/kalman_filter.py:166-172):
-//   y = z - x[sel]; S = P[sel,sel] + R; K = P[:,sel] S^-1; x += K y; P <- P - K P[sel,:]
-// S^-1 is applied through the Cholesky factor S = L L^T (S is symmetric positive definite; unpivoted and
-// branch-free, which suits 64 lanes in lock-step).  Returns status bits.
-template <bool WANT_K, typename PT = float>
-__device__ __forceinline__ int update_batch(float *x, PT *P, const float *z, const KfConst &k, PT *Kout,
-                                            float *kgain)
-{
-    int status = 0;
-    PT L[NM * (NM + 1) / 2];   // packed lower triangle, L[a(a+1)/2 + b]
-    PT dinv[NM];
-#pragma unroll
-    for (int a = 0; a < NM; a++)
-#pragma unroll
-        for (int b = 0; b <= a; b++)
-            // symmetrised entry: the reference's S is symmetric up to rounding of P
-            L[a * (a + 1) / 2 + b] = (PT)0.5 * (P[SEL[a] * NS + SEL[b]] + P[SEL[b] * NS + SEL[a]]) +
-                                     (PT)(0.5f * (k.R[a * NM + b] + k.R[b * NM + a]));
-#pragma unroll
-    for (int j = 0; j < NM; j++) {
-        PT d = L[j * (j + 1) / 2 + j];
-#pragma unroll
-        for (int q = 0; q < j; q++) d -= L[j * (j + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
-        if (!(d > 0) || !(d < (PT)3.0e38)) { status |= 1; d = 1; }
-        PT di;
-        if (sizeof(PT) == 8) {
-            di = (PT)(1.0 / sqrt((double)d));
-        } else {
-            di = (PT)rsqrtf((float)d);
-            // one Newton step: rsqrtf is ~1 ulp on gfx950 but keep the factor tight for cond(S) ~ 1e6
-            di = di * ((PT)1.5 - (PT)0.5 * d * di * di);
-        }
-        dinv[j] = di;
-        L[j * (j + 1) / 2 + j] = d * di;
-#pragma unroll
-        for (int i = j + 1; i < NM; i++) {
-            PT s = L[i * (i + 1) / 2 + j];
-#pragma unroll
-            for (int q = 0; q < j; q++) s -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
-            L[i * (i + 1) / 2 + j] = s * di;
-        }
-    }
-    // K[i,:] = solve(S, P[i,sel]) for each of the 12 rows (S symmetric: K = P[:,sel] S^-1)
-    PT K[NS * NM];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        PT y[NM];
-#pragma unroll
-        for (int a = 0; a < NM; a++) {
-            PT s = P[i * NS + SEL[a]];
-#pragma unroll
-            for (int q = 0; q < a; q++) s -= L[a * (a + 1) / 2 + q] * y[q];
-            y[a] = s * dinv[a];
-        }
-#pragma unroll
-        for (int a = NM - 1; a >= 0; a--) {
-            PT s = y[a];
-#pragma unroll
-            for (int q = a + 1; q < NM; q++) s -= L[q * (q + 1) / 2 + a] * K[i * NM + q];
-            K[i * NM + a] = s * dinv[a];
-        }
-    }
-    PT innov[NM];
-#pragma unroll
-    for (int a = 0; a < NM; a++) innov[a] = (PT)z[a] - (PT)x[SEL[a]];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        PT s = 0;
-#pragma unroll
-        for (int a = 0; a < NM; a++) s += K[i * NM + a] * innov[a];
-        x[i] = (float)((PT)x[i] + s);
-    }
-    // P <- P - K P[sel,:], one column at a time (the selected rows of the OLD column are needed)
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-        PT c[NM];
-#pragma unroll
-        for (int a = 0; a < NM; a++) c[a] = P[SEL[a] * NS + j];
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            PT s = 0;
-#pragma unroll
-            for (int a = 0; a < NM; a++) s += K[i * NM + a] * c[a];
-            P[i * NS + j] -= s;
-        }
-    }
-    if (WANT_K) {
-        if (Kout) {
-#pragma unroll
-            for (int i = 0; i < NS * NM; i++) Kout[i] = K[i];
-        }
-        PT t = 0;   // np.trace of the 12x10 K sums its 10 main-diagonal entries (kalman_filter.py:174)
-#pragma unroll
-        for (int a = 0; a < NM; a++) t += K[a * NM + a];
-        *kgain = (float)t;
-    }
-    return status;
-}
+// (The one-trajectory-per-lane batch update lived here until round 5: a float32 Cholesky of the symmetrised S.  It lost the filter
+// on ill-conditioned runs -- kf_dense_rows.hpp update_batch_row has the account -- and the batch form now runs on the float64 row
+// layout for every covariance model.)
 
 // Sequential (one measurement at a time) form of the same update; exact-arithmetic identical to the batch
 // form when R is diagonal, which every Q/R set of the reference is (settings.py:30,
@@ -1013,7 +918,10 @@ __device__ __forceinline__ int kf_step_back(float *x, PT *P, const float *z, con
     if (SEQ) {
         st = update_sequential(x, P, z, k);
         if (AUX) *kgain = kgain_from_posterior(P, k);
-    } else st = update_batch<AUX, PT>(x, P, z, k, nullptr, kgain);
+    } else {
+        static_assert(SEQ, "the batch update runs on the float64 row layout (kf_dense_rows.hpp)");
+        st = 0;
+    }
     if (AUX) *ptrace = trace12(P);
     return st | finite_status(x);
 }

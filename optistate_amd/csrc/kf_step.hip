@@ -258,49 +258,46 @@ __device__ __forceinline__ int step_body(StepMem &M, const int lane)
     }
 
     if (what & OS_STEP_UPDATE) {
-        // S = P[sel,sel] + R (symmetrised: the reference's S is symmetric up to the rounding of P)
+        // S = P[sel,sel] + R AS IT IS: rounding leaves P (and S) not exactly symmetric and the reference inverts that S
+        // (np.linalg.inv, kalman_filter.py:169).  K from a symmetrised S is unstable with P -= K H P: P's antisymmetric part then
+        // grows step by step (kf_dense_rows.hpp update_batch_row; found by tools/fuzz_kf.py, round 5).  LU without pivoting.
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const int el = lane + 64 * r;
             if (el < 100) {
                 const int a = el / 10, b = el % 10;
-                if (b <= a) M.L[a][b] = 0.5 * (io.P[SEL[a] * 12 + SEL[b]] + io.P[SEL[b] * 12 + SEL[a]]) + 0.5 * (io.R[a * 10 + b] + io.R[b * 10 + a]);
+                M.L[a][b] = io.P[SEL[a] * 12 + SEL[b]] + io.R[a * 10 + b];
             }
         }
         __syncthreads();
-        // Cholesky, column by column: every lane recomputes the pivot (uniform LDS reads), lane i > j updates L[i][j]
+        // row a of the factors in M.L[a][:]: multipliers L[a][q] (q < a) | U[a][q] (q >= a); lane i > j eliminates its row
         for (int j = 0; j < 10; j++) {
             double d = M.L[j][j];
-            for (int q = 0; q < j; q++) d -= M.L[j][q] * M.L[j][q];
             if (!(d > 0.0) || !(d < 1.0e300)) { status |= 1; d = 1.0; }
-            const double di = rsqrt_nr(d);
+            const double di = 1.0 / d;
             if (lane > j && lane < 10) {
-                double s = M.L[lane][j];
-                for (int q = 0; q < j; q++) s -= M.L[lane][q] * M.L[j][q];
-                M.L[lane][j] = s * di;
+                const double m = M.L[lane][j] * di;
+                for (int q = j + 1; q < 10; q++) M.L[lane][q] -= m * M.L[j][q];
+                M.L[lane][j] = m;
             }
             if (lane == 0) M.dinv[j] = di;
             __syncthreads();
-            if (lane == 0) M.L[j][j] = d * di;
-            __syncthreads();
         }
-        // K[i,:] = solve(S, P[i,sel]) (S symmetric: K = P[:,sel] S^-1), one row per lane
+        // K[i,:] S = P[i,sel], one row per lane: w U = P[i,sel], then K L = w (unit diagonal)
         {
             const int i = lane < 12 ? lane : 0;
-            double y[10], Kr[10];
+            double Kr[10];
 #pragma unroll
-            for (int a = 0; a < 10; a++) {
-                double s = io.P[i * 12 + SEL[a]];
+            for (int c = 0; c < 10; c++) {
+                double s = io.P[i * 12 + SEL[c]];
 #pragma unroll
-                for (int q = 0; q < a; q++) s -= M.L[a][q] * y[q];
-                y[a] = s * M.dinv[a];
+                for (int b = 0; b < c; b++) s -= Kr[b] * M.L[b][c];
+                Kr[c] = s * M.dinv[c];
             }
 #pragma unroll
-            for (int a = 9; a >= 0; a--) {
-                double s = y[a];
+            for (int c = 8; c >= 0; c--) {
 #pragma unroll
-                for (int q = a + 1; q < 10; q++) s -= M.L[q][a] * Kr[q];
-                Kr[a] = s * M.dinv[a];
+                for (int b = c + 1; b < 10; b++) Kr[c] -= Kr[b] * M.L[b][c];
             }
             double sx = 0.0;
 #pragma unroll

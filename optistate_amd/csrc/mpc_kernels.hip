@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
 #pragma unroll
     for (int j = 0; j < NS; j++) P[j] = (double)a.kf.P[(size_t)(rr * NS + j) * B + b];
     for (int el = lane; el < 144; el += 64) W.Q[el] = (double)a.kf.k.Q[el];
-    for (int el = lane; el < 120; el += 64)             // symmetrised, as update_batch forms S (kf_device.hpp)
+    for (int el = lane; el < 120; el += 64)             // R as given (kf_dense_rows.hpp update_batch_row)
         (&W.R[0][0])[el] = el < 100 ? (double)a.kf.k.R[el] : 0.0;
     if (lane == 0) {
         // MpcParams, field by field: a reference to a.prm would make hipcc copy the whole argument block to scratch
