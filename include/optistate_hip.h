@@ -70,7 +70,7 @@ enum {
 enum {
     OS_KF_SEQUENTIAL_UPDATE = 1,  /* process the 10 measurements one at a time (requires diagonal R; same
                                      posterior as the batch form in exact arithmetic).  Without it the
-                                     batch form K = P H^T S^-1 (Cholesky of S) is used, as written in
+                                     batch form K = P H^T S^-1 (LU of S as it is, float64) is used, as written in
                                      kalman_filter/kalman_filter.py:166-172. */
     OS_KF_DENSE_FD          = 2,  /* predict_mpc covariance: F_d = element-wise exp(dt F), R from body_ref
                                      (kalman_filter/kalman_filter.py:153-158); needs body_ref. */
@@ -328,7 +328,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * filter launch per step, one trajectory per lane; the leg-count histogram is read back once at entry), which has the
  * higher throughput there.  OS_MPC_PERSISTENT=0 / 2 in the environment forces the sequence / the persistent kernel.
  * OS_KF_SEQUENTIAL_UPDATE in `flags` selects the scalar-update form in the launch sequence only; the persistent kernel always
- * uses the batch (Cholesky) form of kalman_filter.py:166-172 -- the same posterior for the diagonal R the flag requires. */
+ * uses the batch form of kalman_filter.py:166-172 (LU of S) -- the same posterior for the diagonal R the flag requires. */
 int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
                   const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *f_out,
                   float *p_rot_out, float *ptrace_out, float *kgain_out, int32_t *mpc_iters, int32_t *status,

@@ -14,7 +14,7 @@
 //     and E has rows 0..5 and columns 6..11 only (E[i][6+k] = expm1(dt Rb[k][i]), E[3+i][9+i] = expm1(dt)): six column
 //     sums, six row-sum broadcasts and a 6 x 6 block of E P instead of 2 x 12^3 multiply-adds;
 //   * both update forms of the lane kernels: sequential (diagonal R: ten rank-1 updates, 12 fused multiply-adds per lane
-//     each) and batch as the reference writes it (S = P[sel,sel] + R -> Cholesky, row a of L in the lane of measurement a ->
+//     each) and batch as the reference writes it (S = P[sel,sel] + R -> LU of S as it is, row a of the factors in the lane of measurement a ->
 //     K = P[:,sel] S^-1 by forward / back substitution, one ROW of K per lane -> P -= K P[sel,:] column by column);
 //   * the float32 front (odometry, z, next_state with the int64-truncation quirk) is kf_device.hpp's code, computed
 //     redundantly by a trajectory's 16 lanes; the nine sincos and the nine expm1 of a step are shared (one per lane).

@@ -517,7 +517,7 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
 {
     const bool seq = flags & OS_KF_SEQUENTIAL_UPDATE, dense = flags & OS_KF_DENSE_FD;
     if (flags & OS_KF_WAVE_PER_TRAJECTORY) {
-        // the north_star's literal layout, kept for measurement: float64 batch (Cholesky) update on one wavefront per trajectory
+        // the north_star's literal layout, kept for measurement: float64 batch update (LU of S) on one wavefront per trajectory
         if (dense || a.q_diag || a.feat_out) return os_fail(ctx, -3, "os_kf_run: OS_KF_WAVE_PER_TRAJECTORY runs predict(p, f) + update with the context-wide noise only");
         a.k = ctx->k;
         return os_kf_run_wave(ctx, a, s);

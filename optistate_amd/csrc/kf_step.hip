@@ -7,7 +7,7 @@
 //     outputs to it directly over PCIe (a few KB) -- no hipMemcpy, no device buffers, ONE launch and ONE stream
 //     synchronise per call, whatever combination of get_odom / predict / update the call asks for;
 //   * one wavefront works on the step: the 12 x 12 covariance sits in LDS in FLOAT64, three entries per lane, and the
-//     Cholesky / gain / covariance update run across the lanes (the dependent chain of a single lane would be ~20 k
+//     LU of S / gain / covariance update run across the lanes (the dependent chain of a single lane would be ~20 k
 //     instructions long); the short vector part (odometry, rotation, next_state) is computed redundantly on every lane.
 // Everything is float64 here: one wavefront issues an fp64 instruction as fast as an fp32 one (profiles/r01j_valu_rates.md),
 // so the drop-in class gets the reference's own precision (float64 NumPy) for free.
@@ -347,7 +347,7 @@ __device__ __forceinline__ int step_body(StepMem &M, const int lane)
 // ---------------------------------------------------------------------------------------------------------------
 // kf_run_wave_kernel -- the layout BASELINE.json's north_star names literally: ONE TRAJECTORY PER WAVEFRONT, state and
 // covariance tile in LDS, the whole T loop in one launch (OS_KF_WAVE_PER_TRAJECTORY; never chosen by default).
-// It is step_body above (float64 on one wavefront: covariance three entries per lane, Cholesky / gain / update across the
+// It is step_body above (float64 on one wavefront: covariance three entries per lane, LU / gain / update across the
 // lanes) run over the SoA streams: x, P, Q, R stay in the workgroup's LDS block for all T steps; per step 43 lanes fetch
 // the trajectory's 43 input dwords (one 4-byte element out of each stream row: with the trajectory index fastest in memory,
 // a wavefront that owns ONE trajectory cannot coalesce -- every dword costs a 64-byte sector) and twelve lanes store x_out.

@@ -15,7 +15,7 @@ Differences from the reference, all deliberate (SURVEY.md section 5 "race detect
   * the convex-MPC QP inside predict_mpc (misc/force_controller.py:70-162, casadi/qpOASES in the reference) is solved
     by the library's own exact active-set kernel (os_mpc_solve); pass f= to replay logged forces instead;
   * update() raises numpy.linalg.LinAlgError when S = H P H^T + R is not POSITIVE DEFINITE (status bit 0 of os_kf_step: a
-    Cholesky pivot <= 0 or non-finite).  The reference's np.linalg.inv (kalman_filter.py:168) raises only for an exactly
+    LU pivot <= 0 or non-finite).  The reference's np.linalg.inv (kalman_filter.py:168) raises only for an exactly
     singular S and would carry an indefinite, invertible S through (reachable only after predict_mpc's element-wise
     exp(dt F) has destroyed P's definiteness): there this class raises where the reference continues with a meaningless
     gain.  A positive definite S -- every case a covariance filter is defined for -- takes the same path in both;

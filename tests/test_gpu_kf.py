@@ -442,3 +442,24 @@ def test_batch_update_stays_with_the_reference_over_long_ill_conditioned_runs(en
     assert np.abs(r["P_trace"].cpu().numpy().T / ref["P_trace"] - 1).max() < 1e-3
     Pf = P.cpu().numpy().T.reshape(B, 12, 12)
     assert np.abs(Pf - np.swapaxes(Pf, 1, 2)).max() < 1e-5 * np.abs(Pf).max()           # P stays symmetric to rounding, as the reference's does
+
+
+def test_dropin_class_stays_with_the_reference_on_an_ill_conditioned_run(eng):
+    """The drop-in Kalman_Filter (one wavefront, float64) through 160 hostile steps with the fitted noise set -- the conditions under
+    which a gain from a symmetrised S loses P's symmetry (see the test above): against the oracle, and P symmetric to rounding."""
+    from optistate_amd import Kalman_Filter
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import synth_numpy, Q_FITTED, R_FITTED
+    B, T = 3, 160
+    d = synth_numpy(B, T, seed=1055, hostile=True)
+    ref = orc.kf_run_batch(d["p"], d["f"], d["dp"], d["imu"], d["contact"], d["x0"], np.tile(Q_FITTED, (B, 1, 1)), Q_FITTED, R_FITTED)
+    for b in range(B):
+        kf = Kalman_Filter()
+        kf.x[:] = d["x0"][b].astype(np.float64).reshape(12, 1)
+        kf.Q = Q_FITTED.copy(); kf.R = R_FITTED.copy(); kf.P = Q_FITTED.copy()
+        for t in range(T):
+            a = lambda key, n: d[key][b, t].astype(np.float64).reshape(n, 1)
+            x = kf.step(a("p", 12), a("f", 12), a("dp", 12), a("imu", 6), d["contact"][b, t].reshape(4, 1))
+            assert np.abs(x.ravel() - ref["x"][b, t]).max() < 1e-6, (b, t)
+        assert np.abs(kf.P - kf.P.T).max() < 1e-12 * np.abs(kf.P).max()
+        assert np.abs(kf.P - ref["P_final"][b]).max() < 1e-6 * np.abs(ref["P_final"][b]).max()
