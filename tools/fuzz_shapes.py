@@ -47,7 +47,7 @@ def main():
             msg += f" | windows {e_w:.1e}"
             ok = ok and e_w < 1e-6
         # training forward + backward against fp64 autograd on a small batch
-        if B <= 257:
+        if B <= 1100 and B * T <= 12000:
           try:
             eng = m._engine
             xg = x.cuda()
@@ -73,6 +73,22 @@ def main():
             if "(-4)" not in str(e):
                 raise
             msg += " | train: shape not taken (-4)"
+        # the opt-in split-bf16 layer kernel (any-batch flag) where it applies: H = 128, inputs <= 188, B a multiple of 4
+        if H == 128 and I <= 188 and B % 4 == 0 and B >= 8:           # (B <= 4 is the one-workgroup gru_vec_kernel whatever the mode)
+            eng = m._engine
+            terms = int(rng.choice([2, 3]))
+            eng.set_gru_split_bf16(terms, any_batch=True)
+            eng.set_stack_mode(0)
+            try:
+                with torch.no_grad():
+                    ob = m(x.cuda()).cpu().numpy()
+                nb = eng.kernel_name("gru_layer")
+            finally:
+                eng.set_gru_split_bf16(0)
+                eng.set_stack_mode(1)
+            e_b = float(np.abs(ob[pick] - ref).max())
+            msg += f" | bf16x{terms} {e_b:.1e} [{nb}]"
+            ok = ok and e_b < (1e-5 if terms == 3 else 1e-4) and "bf16" in nb
         print(msg + ("" if ok else "   <-- ABOVE THE BAR"), flush=True)
         bad += 0 if ok else 1
     print(f"{n} cases, {bad} above the bars")
