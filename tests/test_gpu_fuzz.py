@@ -1,5 +1,6 @@
 """GPU: a fixed-seed slice of the random-shape parity sweeps under tools/ (fuzz_shapes.py: GRU forward / window stream / training
-gradients; fuzz_kf.py: every Kalman kernel family; fuzz_fused.py: the fused chain; fuzz_mpc.py: the force QP; fuzz_pieces.py: one update() on random, not exactly symmetric covariances) -- each case against the float64 oracle or fp64
+gradients; fuzz_kf.py: every Kalman kernel family; fuzz_fused.py: the fused chain; fuzz_mpc.py: the force QP; fuzz_pieces.py: one update() on random, not exactly symmetric covariances; fuzz_mpc_run.py:
+estimate_state_mpc, persistent kernel against launch sequence against the oracles) -- each case against the float64 oracle or fp64
 autograd at the suite's bars.  The full sweeps (hundreds of cases, other seeds) are run by hand: round 5's first run found the
 backward's transposed-pack grid bug (a one-layer model with fewer input chunks than hidden chunks)."""
 import os
@@ -13,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("script, n, seed", [("fuzz_shapes.py", 24, 7), ("fuzz_kf.py", 24, 7), ("fuzz_fused.py", 14, 7), ("fuzz_mpc.py", 60, 7), ("fuzz_pieces.py", 30, 7)])
+@pytest.mark.parametrize("script, n, seed", [("fuzz_shapes.py", 24, 7), ("fuzz_kf.py", 24, 7), ("fuzz_fused.py", 14, 7), ("fuzz_mpc.py", 60, 7), ("fuzz_pieces.py", 30, 7), ("fuzz_mpc_run.py", 8, 7)])
 def test_fixed_seed_slice_of_the_shape_sweeps(script, n, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(n), str(seed)], capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.splitlines()[-6:])

@@ -1,0 +1,91 @@
+"""GPU: os_kf_mpc_run (estimate_state_mpc over B x T, kalman_filter.py:176-182) -- the persistent kernel against the per-step launch
+sequence on random batch sizes (around the forms' crossovers), horizons, nominal and hostile inputs (every contact pattern), both
+update forms; a few short trajectories of each case also against the two oracles (QP: mpc_oracle, filter step: the C oracle).
+    python tools/fuzz_mpc_run.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from optistate_amd import Engine  # noqa: E402
+from optistate_amd.synth import synth_numpy, NOISE_SETS  # noqa: E402
+from oracle import mpc_oracle as mo  # noqa: E402
+from oracle import c_oracle as co  # noqa: E402
+
+
+def oracle_run(d, Q, R, T, rows):
+    xs = np.zeros((len(rows), T, 12)); fs = np.zeros((len(rows), T, 12))
+    for i, b in enumerate(rows):
+        x = d["x0"][b].astype(np.float64).copy(); P = Q.copy()
+        for t in range(T):
+            x32 = x.astype(np.float32).astype(np.float64)
+            f, _, info = mo.mpc_forces(x32, d["body_ref"][b, t].astype(np.float64), d["p"][b, t].astype(np.float64), d["contact"][b, t],
+                                       dt=float(np.float32(0.01)))
+            f32 = f.astype(np.float32).astype(np.float64)
+            r = co.kf_run_batch(d["p"][b:b + 1, t:t + 1], f32.reshape(1, 1, 12), d["dp"][b:b + 1, t:t + 1], d["imu"][b:b + 1, t:t + 1],
+                                d["contact"][b:b + 1, t:t + 1], x.reshape(1, 12), P.reshape(1, 144), Q, R,
+                                body_ref=d["body_ref"][b:b + 1, t:t + 1], mode=1)
+            x = r["x_final"][0].copy(); P = r["P_final"][0].copy()
+            xs[i, t] = x; fs[i, t] = f
+    return xs, fs
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    mo.MASS = float(np.float32(8.8))
+    mo.INERTIA = np.asarray(np.float32([0.05530364, 0.06011944, 0.10530434]), np.float64)
+    engs = {}
+    for mode in ("2", "0"):
+        os.environ["OS_MPC_PERSISTENT"] = mode
+        engs[mode] = Engine(0)
+    bad = 0
+    for case in range(n):
+        B = int(rng.choice([1, 2, 7, 8, 63, 65, 256, 1000, 2047, 2049, 6144]))
+        T = int(rng.choice([1, 2, 7, 20, 40]))
+        if B > 1000:
+            T = min(T, 7)
+        hostile = bool(rng.integers(0, 2))
+        sequential = bool(rng.integers(0, 2))
+        noise = str(rng.choice(["default", "fitted"]))
+        Q, R = NOISE_SETS[noise]
+        d = synth_numpy(B, T, seed=3000 + case, hostile=hostile)
+        tt = np.arange(T) * 0.01
+        ref = np.zeros((B, T, 12), np.float32)
+        ref[:, :, 0] = 0.02 * np.sin(3 * tt); ref[:, :, 1] = 0.02 * np.cos(2 * tt); ref[:, :, 5] = 0.28; ref[:, :, 9] = 0.1
+        ref += rng.normal(0, 0.005, ref.shape).astype(np.float32)
+        d["body_ref"] = ref
+        out = {}
+        for mode, eng in engs.items():
+            eng.set_noise(Q, R)
+            s = {k: eng.pack(torch.as_tensor(np.asarray(d[k], dtype=np.float32))) for k in ("p", "dp", "imu", "body_ref")}
+            c = eng.pack_contact(torch.as_tensor(np.asarray(d["contact"])))
+            x = torch.as_tensor(d["x0"].T.copy()).cuda()
+            P = torch.as_tensor(np.tile(np.asarray(Q, dtype=np.float32).reshape(144, 1), (1, B))).cuda()
+            r = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x, P, sequential=sequential, want_trace=True)
+            torch.cuda.synchronize()
+            out[mode] = (eng.unpack(r["x_out"]).cpu().numpy(), eng.unpack(r["f"]).cpu().numpy(), eng.failed(r["status"]).cpu().numpy().astype(bool),
+                         eng.kernel_name("mpc"))
+        xp, fp, sp, kp = out["2"]; xs, fs, ss, ks = out["0"]
+        good = ~sp & ~ss
+        e_x = float(np.abs(xp[good] - xs[good]).max()) if good.any() else 0.0
+        e_f = float(np.abs(fp[good] - fs[good]).max()) if good.any() else 0.0
+        rows = [b for b in np.unique(np.r_[0, B // 2, B - 1]) if good[b]][:2]
+        To = min(T, 8)
+        xo, fo = oracle_run(d, Q, R, To, rows) if rows else (np.zeros((0, To, 12)), np.zeros((0, To, 12)))
+        e_xo = float(np.abs(xp[rows][:, :To] - xo).max()) if rows else 0.0
+        e_fo = float(np.abs(fp[rows][:, :To] - fo).max()) if rows else 0.0
+        ok = e_x < 1e-4 and e_f < 5e-3 and e_xo < 1e-4 and e_fo < 5e-3 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
+        print(f"case {case}: B={B} T={T} hostile={hostile} {'seq' if sequential else 'batch'} noise={noise} [{kp} | {ks}] persistent vs sequence: x {e_x:.1e} f {e_f:.1e} N | "
+              f"vs oracles ({len(rows)} trajectories x {To}): x {e_xo:.1e} f {e_fo:.1e} N | flagged {int(sp.sum())}/{int(ss.sum())}"
+              + ("" if ok else "   <-- ABOVE THE BAR"), flush=True)
+        bad += 0 if ok else 1
+    print(f"{n} cases, {bad} above the bars")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
