@@ -1,7 +1,7 @@
-"""GPU: ViT-encoder latent (optional row A10 / config 5).  The transformer BLOCKS are parity unpinned with respect to the
-reference (timm 0.3.2 and the trained weights are absent): the HIP path is compared with this repo's own float64
-restatement (oracle/vit_oracle.py).  The reference-owned GLUE around them (forward_encoder, initialize_weights) is pinned by
-G11: the reference's own class run with a timm stand-in (tests/test_vit_glue_golden.py explains the label)."""
+"""GPU: ViT-encoder latent (optional row A10 / config 5).  timm 0.3.2 and the trained weights are absent: the HIP path is compared
+with this repo's float64 restatement (oracle/vit_oracle.py), which is pinned to the reference-owned GLUE (forward_encoder,
+initialize_weights) by G11 -- the reference's own class run with a timm stand-in (tests/test_vit_glue_golden.py) -- and to an
+independent implementation of the transformer block by G14 (the reference class around Hugging Face's ViTLayer)."""
 import numpy as np
 import pytest
 import torch
