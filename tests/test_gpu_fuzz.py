@@ -14,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("script, n, seed", [("fuzz_shapes.py", 24, 7), ("fuzz_kf.py", 24, 7), ("fuzz_fused.py", 14, 7), ("fuzz_mpc.py", 60, 7), ("fuzz_pieces.py", 30, 7), ("fuzz_mpc_run.py", 8, 7), ("fuzz_vit.py", 6, 7)])
+@pytest.mark.parametrize("script, n, seed", [("fuzz_shapes.py", 24, 7), ("fuzz_kf.py", 24, 7), ("fuzz_fused.py", 14, 7), ("fuzz_mpc.py", 60, 7), ("fuzz_pieces.py", 30, 7), ("fuzz_mpc_run.py", 8, 7), ("fuzz_vit.py", 6, 7), ("fuzz_trainer.py", 8, 7)])
 def test_fixed_seed_slice_of_the_shape_sweeps(script, n, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(n), str(seed)], capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.splitlines()[-6:])
