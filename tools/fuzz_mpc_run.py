@@ -49,6 +49,11 @@ def main():
         if B > 1000:
             T = min(T, 7)
         hostile = bool(rng.integers(0, 2))
+        if hostile:
+            # the QP closes a loop around the filter: on hostile stretches (fast yaw, one or two stance legs) the closed loop is unstable
+            # and a 1e-7 rounding difference grows ~3x per step (seen: 1e-6 at step 12 -> 1e-2 at step 26, both GPU forms together,
+            # away from the float64 chain) -- keep hostile horizons short enough for a 1e-4 comparison to mean something
+            T = min(T, 12)
         sequential = bool(rng.integers(0, 2))
         noise = str(rng.choice(["default", "fitted"]))
         Q, R = NOISE_SETS[noise]
@@ -79,9 +84,20 @@ def main():
         e_xo = float(np.abs(xp[rows][:, :To] - xo).max()) if rows else 0.0
         e_fo = float(np.abs(fp[rows][:, :To] - fo).max()) if rows else 0.0
         ok = e_x < 1e-4 and e_f < 5e-3 and e_xo < 1e-4 and e_fo < 5e-3 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
+        diag = ""
+        if not ok and good.any():
+            # which form left the oracle chain?  the trajectory where the two forms are furthest apart, over the whole horizon
+            bw = int(np.argmax(np.where(good, np.abs(xp - xs).max(axis=(1, 2)), -1.0)))
+            xo2, fo2 = oracle_run(d, Q, R, T, [bw])
+            diag = (f"\n     trajectory {bw}: persistent vs oracle x {np.abs(xp[bw] - xo2[0]).max():.1e} f {np.abs(fp[bw] - fo2[0]).max():.1e} | "
+                    f"sequence vs oracle x {np.abs(xs[bw] - xo2[0]).max():.1e} f {np.abs(fs[bw] - fo2[0]).max():.1e} | first step the forms differ by > 1e-5: "
+                    f"{int(np.argmax(np.abs(xp[bw] - xs[bw]).max(axis=1) > 1e-5))}")
+            ex = np.abs(xp[bw] - xo2[0]).max(axis=1); ef = np.abs(fp[bw] - fo2[0]).max(axis=1)
+            diag += "\n     persistent vs oracle per step (x | f): " + " ".join(f"{t}:{ex[t]:.0e}|{ef[t]:.0e}" for t in range(T))
+            diag += "\n     stance legs per step: " + " ".join(str(int(d["contact"][bw, t].sum())) for t in range(T))
         print(f"case {case}: B={B} T={T} hostile={hostile} {'seq' if sequential else 'batch'} noise={noise} [{kp} | {ks}] persistent vs sequence: x {e_x:.1e} f {e_f:.1e} N | "
               f"vs oracles ({len(rows)} trajectories x {To}): x {e_xo:.1e} f {e_fo:.1e} N | flagged {int(sp.sum())}/{int(ss.sum())}"
-              + ("" if ok else "   <-- ABOVE THE BAR"), flush=True)
+              + ("" if ok else "   <-- ABOVE THE BAR") + diag, flush=True)
         bad += 0 if ok else 1
     print(f"{n} cases, {bad} above the bars")
     return 1 if bad else 0
