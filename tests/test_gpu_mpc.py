@@ -1,5 +1,5 @@
 """GPU parity of the batched convex-MPC force QP (os_mpc_solve) against oracle/mpc_oracle.py (KKT-certified float64 solution of
-the problem misc/force_controller.py:70-162 states; pinned to the reference's own QP assembly by G12 below).  qpOASES itself is absent.
+the problem misc/force_controller.py:70-162 states; pinned to the reference's own QP assembly by G12 below).  qpOASES itself is absent."""
 import numpy as np
 import pytest
 import torch
