@@ -83,7 +83,8 @@ def main():
         xo, fo = oracle_run(d, Q, R, To, rows) if rows else (np.zeros((0, To, 12)), np.zeros((0, To, 12)))
         e_xo = float(np.abs(xp[rows][:, :To] - xo).max()) if rows else 0.0
         e_fo = float(np.abs(fp[rows][:, :To] - fo).max()) if rows else 0.0
-        ok = e_x < 1e-4 and e_f < 5e-3 and e_xo < 1e-4 and e_fo < 5e-3 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
+        # forces: the QP's solution moves by ~100-500 N per unit of state near a face change, the states agree to ~3e-5: 2e-2 N (of up to 150)
+        ok = e_x < 1e-4 and e_f < 2e-2 and e_xo < 1e-4 and e_fo < 2e-2 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
         diag = ""
         if not ok and good.any():
             # which form left the oracle chain?  the trajectory where the two forms are furthest apart, over the whole horizon
