@@ -335,13 +335,18 @@ hipError_t launch_kf_dense_rows(const KfRunArgs &a, const float *qr, bool seq, b
 {
     dim3 grid((a.B + 15) / 16), block(256);
 #define OSD_GO(SEQ_, AUX_, FEAT_, DENSE_) hipLaunchKernelGGL((kf_dense_rows_kernel<SEQ_, AUX_, FEAT_, DENSE_>), grid, block, 0, s, a, qr)
-    if (!dense) {
+    if (!dense && !seq) {
         // the predict(p, f) covariance with the BATCH update (a non-diagonal R, or the caller asked for the form that builds K):
         // float64 here -- the float32 one-trajectory-per-lane kernel this replaces lost the filter on ill-conditioned S (fitted
         // noise, cond ~1e6, plus flight phases: state errors of 1e-3 .. 1e+1 after 40-100 steps; found by tools/fuzz_kf.py, round 5)
         if (feat) OSD_GO(false, false, true, false);
         else if (aux) OSD_GO(false, true, false, false);
         else OSD_GO(false, false, false, false);
+    } else if (!dense) {
+        // ... and with the sequential update where the full (not symmetrised) P is wanted: a Q that is not symmetric, or the caller's flag
+        if (feat) OSD_GO(true, false, true, false);
+        else if (aux) OSD_GO(true, true, false, false);
+        else OSD_GO(true, false, false, false);
     } else if (seq) {
         if (feat) OSD_GO(true, false, true, true);
         else if (aux) OSD_GO(true, true, false, true);

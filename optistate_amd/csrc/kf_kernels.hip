@@ -18,89 +18,10 @@ __device__ __forceinline__ void store_feat(rsrc_t rf, const float *mm, uint32_t 
     buf_store_nt(rf, voff, j * rowB, (v - mn) / (mx - mn));
 }
 
-template <bool SEQ, bool DENSE, bool AUX, bool FEAT, bool QDIAG>
-__global__ __launch_bounds__(64, 1) void kf_run_kernel(const KfRunArgs a)
-{
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.B) return;
-    const size_t B = (size_t)a.B;
-    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
-    // the predict_mpc covariance (DENSE) is carried in float64: see cov_predict_dense
-    using PT = typename std::conditional<DENSE, double, float>::type;
-    float x[NS];
-    PT P[NS * NS];
-    {
-        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
-#pragma unroll
-        for (int i = 0; i < NS; i++) x[i] = buf_load(rx, voff, i * rowB);
-#pragma unroll
-        for (int i = 0; i < NS * NS; i++) P[i] = (PT)buf_load(rP, voff, i * rowB);
-    }
-    int status = 0;
-    StepIn in;
-    float bref[3] = {0.f, 0.f, 0.f};
-    load_step(a, 0, voff, rowB, in);
-    if (DENSE) {
-        rsrc_t rb = make_rsrc(a.body_ref, 12 * rowB);
-#pragma unroll
-        for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
-    }
-    for (int t = 0; t < a.T; t++) {
-        float z[NM], pw[12], ptrace = 0.f, kgain = 0.f;
-        status |= kf_step_front<DENSE, QDIAG, PT>(x, P, in, bref, a.k, z, pw);      // bit 4: int64-truncation knife edge
-        rsrc_t rfeat;
-        if (FEAT) {
-            rfeat = make_rsrc(a.feat_out + (size_t)t * a.feat_I * B, (uint32_t)a.feat_I * rowB);
-            rsrc_t ra = make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB);
-#pragma unroll
-            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 12 + i, buf_load_nt(ra, voff, i * rowB));
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                store_feat(rfeat, a.minmax, voff, rowB, 18 + i, in.f[i]);
-                store_feat(rfeat, a.minmax, voff, rowB, 30 + i, pw[i]);
-                store_feat(rfeat, a.minmax, voff, rowB, 42 + i, in.dp[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 6; i++) store_feat(rfeat, a.minmax, voff, rowB, 54 + i, in.imu[i]);
-        }
-        if (a.p_rot_out) {
-            rsrc_t ro = make_rsrc(a.p_rot_out + (size_t)t * 12 * B, 12 * rowB);
-#pragma unroll
-            for (int i = 0; i < 12; i++) buf_store_nt(ro, voff, i * rowB, pw[i]);
-        }
-        // the inputs are dead now: reuse their registers to prefetch step t+1 underneath the update,
-        // which is the long part of the step (43 coalesced loads in flight, one wave per SIMD)
-        const int tn = (t + 1 < a.T) ? t + 1 : t;
-        load_step(a, tn, voff, rowB, in);
-        if (DENSE) {
-            rsrc_t rb = make_rsrc(a.body_ref + (size_t)tn * 12 * B, 12 * rowB);
-#pragma unroll
-            for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
-        }
-        status |= kf_step_back<SEQ, AUX, PT>(x, P, z, a.k, &ptrace, &kgain);
-        {
-            rsrc_t ro = make_rsrc(a.x_out + (size_t)t * 12 * B, 12 * rowB);
-#pragma unroll
-            for (int i = 0; i < NS; i++) buf_store_nt(ro, voff, i * rowB, x[i]);
-        }
-        if (FEAT) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) store_feat(rfeat, a.minmax, voff, rowB, i, x[i]);
-        }
-        if (AUX) {
-            if (a.ptrace_out) a.ptrace_out[(size_t)t * B + b] = ptrace;
-            if (a.kgain_out) a.kgain_out[(size_t)t * B + b] = kgain;
-        }
-    }
-    {
-        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
-#pragma unroll
-        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, x[i]);
-#pragma unroll
-        for (int i = 0; i < NS * NS; i++) buf_store(rP, voff, i * rowB, (float)P[i]);
-    }
-    a.status[b] = status;
-}
+// (kf_run_kernel -- one trajectory per lane with the full 12 x 12 P in 144 registers, the fallback for a non-symmetric Q, a
+// non-diagonal R or the predict_mpc covariance -- lived here until round 5: 0.1-1.5 k spilled VGPRs per instance, and its float32
+// batch update lost the filter on ill-conditioned runs.  Every one of its cases runs on the float64 row layout now:
+// kf_dense_rows.hip.)
 
 // Development builds only (-DOS_ROWS_TS: tools/rows_ts.sh, kf_run_rows2_kernel; -DOS_SYM_TS: kf_run_sym_kernel): shader-clock stamps at the
 // phase boundaries of a step, summed over the steps by lane 0 of workgroup 0 (written to kgain_out as 8 x uint64 / printed).
@@ -502,13 +423,6 @@ __global__ void pack_btf_rows(int B, int T, int F, int F_total, int row0, const 
 
 using namespace osk;
 
-template <bool SEQ, bool DENSE, bool AUX, bool FEAT, bool QDIAG = false>
-static hipError_t launch_kf_run(const KfRunArgs &a, hipStream_t s)
-{
-    dim3 grid((a.B + 63) / 64), block(64);
-    hipLaunchKernelGGL((kf_run_kernel<SEQ, DENSE, AUX, FEAT, QDIAG>), grid, block, 0, s, a);
-    return hipGetLastError();
-}
 
 int os_kf_run_wave(os_ctx *ctx, const KfRunArgs &a, hipStream_t s);      // kf_step.hip: one trajectory per wavefront, P in LDS
 
@@ -547,11 +461,8 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise);
     const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
                         : dense ? (seq ? "kf_dense_rows_kernel<SEQ>" : "kf_dense_rows_kernel<BATCH>")
-                                : (seq ? "kf_run_kernel<SEQ>" : "kf_dense_rows_kernel<BATCH,predict(p,f)>");
+                                : (seq ? "kf_dense_rows_kernel<SEQ,predict(p,f)>" : "kf_dense_rows_kernel<BATCH,predict(p,f)>");
     const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, kname);
-#define OS_DISPATCH(SEQ)                                                               \
-    (feat ? launch_kf_run<SEQ, false, false, true>(a, s)                               \
-          : (aux ? launch_kf_run<SEQ, false, true, false>(a, s) : launch_kf_run<SEQ, false, false, false>(a, s)))
     if (dense) {
         // predict_mpc covariance (element-wise exp(dt F)): float64, 16 lanes per trajectory, every batch size (kf_dense_rows.hip)
         e = launch_kf_dense_rows(a, (const float *)ctx->kf_qr, seq, feat, aux, s);
@@ -585,13 +496,8 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
         else hipLaunchKernelGGL((kf_run_sym_kernel<0, false, true>), grid, block, 0, s, a);
 #undef OS_SYM
         e = hipGetLastError();
-    } else if (seq && !dense && ctx->q_is_diagonal)   // sequential update, diagonal Q and R, full P
-        e = feat ? launch_kf_run<true, false, false, true, true>(a, s)
-                 : (aux ? launch_kf_run<true, false, true, false, true>(a, s)
-                        : launch_kf_run<true, false, false, false, true>(a, s));
-    else if (seq) e = OS_DISPATCH(true);
-    else e = launch_kf_dense_rows(a, (const float *)ctx->kf_qr, false, feat, aux, s, false);      // batch update: float64 row layout
-#undef OS_DISPATCH
+    } else   // full P wanted (a Q that is not symmetric, a non-diagonal R, OS_KF_LANE_PER_TRAJECTORY without the symmetric flag): float64 rows
+        e = launch_kf_dense_rows(a, (const float *)ctx->kf_qr, seq, feat, aux, s, false);
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, e);
     return 0;

@@ -77,6 +77,9 @@ SCRATCH_FREE = {
     "osk::kf_dense_rows_kernel<false, false, false, false>": "predict(p,f) covariance + BATCH update (non-diagonal R / sequential=False), float64",
     "osk::kf_dense_rows_kernel<false, true, false, false>": "the same with P_trace / K_gain outputs",
     "osk::kf_dense_rows_kernel<false, false, true, false>": "the same as the first kernel of the two-kernel fused path",
+    "osk::kf_dense_rows_kernel<true, false, false, false>": "predict(p,f) covariance + sequential update with the full P (non-symmetric Q / symmetric=False), float64",
+    "osk::kf_dense_rows_kernel<true, true, false, false>": "the same with P_trace / K_gain outputs",
+    "osk::kf_dense_rows_kernel<true, false, true, false>": "the same as the first kernel of the two-kernel fused path",
     "osk::kf_dense_rows_kernel<false, false, true, true>": "feature rows for the two-kernel fused path (dense F_d)",
 }
 

@@ -126,12 +126,12 @@ def test_asymmetric_p0_is_flagged_by_the_symmetric_storage_kernel():
     st = r["status"].cpu().numpy()
     assert st[100] & 8 and (np.delete(st, 100) == 0).all()
     r2 = eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone(), symmetric=False)     # the reference's full P
-    assert eng.kernel_name("kf") == "kf_run_kernel<SEQ>" and (r2["status"].cpu().numpy() == 0).all()
+    assert eng.kernel_name("kf") == "kf_dense_rows_kernel<SEQ,predict(p,f)>" and (r2["status"].cpu().numpy() == 0).all()
     # a non-symmetric Q switches the default to the full-P kernels
     Qa = Q_DEFAULT.copy(); Qa[0, 5] = 1e-3
     eng.set_noise(Qa, R_DEFAULT)
     eng.kf_run(s["p"], s["f"], s["dp"], s["imu"], c, x.clone(), P.clone())
-    assert eng.kernel_name("kf") == "kf_run_kernel<SEQ>"
+    assert eng.kernel_name("kf") == "kf_dense_rows_kernel<SEQ,predict(p,f)>"
     eng.set_noise(Q_DEFAULT, R_DEFAULT)
 
 
