@@ -85,7 +85,9 @@ enum {
                                      faster below ~20 k trajectories; OS_FUSED_TWO_KERNEL forces that path) */
     OS_MPC_COLD_START       = 64, /* os_kf_mpc_run: do not reuse the previous step's active set (development / tests) */
     OS_KF_LANE_PER_TRAJECTORY = 32, /* os_kf_run: never use the small-batch kernel (16 lanes per trajectory, row-parallel P),
-                                     which is otherwise chosen for sequential updates when B <= 8,192 (the measured crossover). */
+                                     which is otherwise chosen for sequential updates when B <= 8,192 (the measured crossover).
+                                     Without OS_KF_SYMMETRIC_P the full, never symmetrised P of the reference is carried -- in float64,
+                                     16 lanes per trajectory (kf_dense_rows_kernel). */
     OS_KF_P_FLOAT64         = 256, /* os_kf_predict / os_kf_update: P (and K_out) are DOUBLE arrays and the covariance
                                      arithmetic runs in float64.  predict_mpc's element-wise exp(dt F) (kalman_filter.py:157)
                                      leaves a P that float32 cannot carry to the following update within the 1e-4 bar; the
