@@ -989,8 +989,9 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
             m.prm = tmp.prm;
         }
         const int slot = os_prof_begin(ctx, 4, s, "kf_mpc_persistent_kernel");
-        if (B >= 8 * ctx->cu_count) hipLaunchKernelGGL(osm::kf_mpc_persistent_kernel<2>, dim3(B), dim3(64), 0, s, m);
-        else hipLaunchKernelGGL(osm::kf_mpc_persistent_kernel<1>, dim3(B), dim3(64), 0, s, m);
+        // (a two-waves-per-SIMD instance, 256 registers, served B >= 8 x CUs until round 5: 325 spilled VGPRs; since the filter half
+        // runs on the row layout the one-wave-per-SIMD instance is 15-34 % faster there too: B = 3,072 1.15e7 -> 1.54e7 steps/s)
+        hipLaunchKernelGGL(osm::kf_mpc_persistent_kernel<1>, dim3(B), dim3(64), 0, s, m);
         os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
         return 0;
