@@ -661,7 +661,12 @@ static __device__ __attribute__((noinline)) QpRet mpc_solve_wave_call(QpCallLds 
 // problem has 30 variables, not 60 (elimination work ~ n^3), and each instance gets the register budget its row needs.
 // Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
 template <int NST>
-__global__ __launch_bounds__(64, NST <= 2 ? 3 : 2) void mpc_solve_kernel(const MpcArgs a)
+#ifndef OS_MPC_SOLVE_OCC
+// waves per SIMD the register budget is sized for: 4 at one / two stance legs (108 / 127 registers, no spills; measured at trot,
+// B = 65,536: 1.758 -> 1.683 ms per launch against 3), 3 at three (160), 2 at four (185)
+#define OS_MPC_SOLVE_OCC (NST <= 2 ? 4 : NST == 3 ? 3 : 2)
+#endif
+__global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const MpcArgs a)
 {
     typedef WaveMemT<15 * NST> WaveMem;
     __shared__ WaveMem M;
