@@ -24,7 +24,18 @@ INERTIA = (55303643.08 / 1e9, 60119440.34 / 1e9, 105304340.05 / 1e9)
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device pointer of a tensor handed to the C-ABI (None -> NULL).  The library sees only the address: a host tensor would fault on
+    the device, a strided view or a float64 tensor would be read as contiguous float32 -- refuse them here (4-byte element types only:
+    float32 streams, int32 / uint32 contact and status words)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TypeError("optistate_amd: a device tensor is required (got a host tensor); the hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError("optistate_amd: a contiguous tensor is required (call .contiguous())")
+    if t.element_size() != 4:
+        raise TypeError(f"optistate_amd: float32 / int32 data expected, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
 
 
 class StackLost(RuntimeError):

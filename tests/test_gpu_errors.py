@@ -86,6 +86,19 @@ def test_window_stream_and_split_bf16_preconditions():
     assert lib.os_gru_set_split_bf16(h, 0) == 0 and lib.os_gru_set_split_bf16(None, 3) < 0
 
 
+def test_engine_refuses_host_strided_and_float64_tensors(eng):
+    """The C-ABI sees only addresses: the Python engine refuses what the library would misread (a host tensor, a strided view, float64)."""
+    b = _bufs(8, 3)
+    args = lambda **kw: [kw.get(k, b[k]) for k in ("p", "f", "dp", "imu", "c", "x", "P")]
+    assert eng.kf_run(*args())["x_out"].shape == (3, 12, 8)
+    with pytest.raises(TypeError, match="device tensor"):
+        eng.kf_run(*args(p=b["p"].cpu()))
+    with pytest.raises(ValueError, match="contiguous"):
+        eng.kf_run(*args(f=torch.zeros((3, 8, 12), device="cuda").permute(0, 2, 1)))
+    with pytest.raises(TypeError, match="float32"):
+        eng.kf_run(*args(imu=b["imu"].double()))
+
+
 def test_mpc_rejects_bad_arguments(eng):
     from optistate_amd.engine import _ptr
     lib, h = eng.lib, eng._h
