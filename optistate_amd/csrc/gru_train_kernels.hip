@@ -1093,21 +1093,23 @@ using namespace ost;
 
 
 // picks the accumulator count for the input width: the smallest NC in {2, 4, 6} that covers K in one pass, else 6 per pass
+// (dw2_kernel); the fallback dw_kernel stops at 4 per pass -- with 6 accumulators its register-staged X tile spilled (540 B of
+// scratch per lane), and it is what the LAST, partial batch of an epoch reaches (B % 32 != 0 with the batch_first input,
+// gru/gru_train.py:199-201 keeps that batch): two passes over the rows for a 188-wide layer there, no scratch
 static void launch_dw(const DwArgs &d, int K, dim3 grid, hipStream_t s)
 {
     const int nkc = (K + 31) / 32;
     // dw2_kernel: 16-byte pieces (K % 4), X within one 32-bit buffer, and for the batch_first input whole 32-window tiles
     const bool v4 = (K & 3) == 0 && (size_t)d.T * d.B * K * 4 < ((size_t)1 << 31) &&
                     (!d.x_btf || (d.B % DW_TR == 0 && d.rows_per_slice % DW_TR == 0 && (d.r_begin - d.x_row_shift) % DW_TR == 0));
-#define OS_DW(NC)                                                                          \
-    do {                                                                                   \
-        if (v4) hipLaunchKernelGGL((dw2_kernel<NC>), grid, dim3(256), 0, s, d);             \
-        else hipLaunchKernelGGL((dw_kernel<false, NC>), grid, dim3(256), 0, s, d);          \
-    } while (0)
-    if (nkc <= 2) OS_DW(2);
-    else if (nkc <= 4) OS_DW(4);
-    else OS_DW(6);
-#undef OS_DW
+    if (v4) {
+        if (nkc <= 2) hipLaunchKernelGGL((dw2_kernel<2>), grid, dim3(256), 0, s, d);
+        else if (nkc <= 4) hipLaunchKernelGGL((dw2_kernel<4>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((dw2_kernel<6>), grid, dim3(256), 0, s, d);
+    } else {
+        if (nkc <= 2) hipLaunchKernelGGL((dw_kernel<false, 2>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((dw_kernel<false, 4>), grid, dim3(256), 0, s, d);
+    }
 }
 
 

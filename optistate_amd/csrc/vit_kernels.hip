@@ -264,9 +264,13 @@ __device__ __forceinline__ void vit_lds_barrier()
 // K / V of one (image, head) -> dst by LDS-DMA (a real call: inlined, its address arithmetic shares the register allocation of
 // the attention body, which has none to spare)
 template <int NW, int KP>
-__device__ __attribute__((noinline)) void attention_stage_dma(const float *QKV, int L, int D, int heads, int item, float *dst)
+__device__ __attribute__((noinline)) void attention_stage_dma(const float *QKV, int L, int D, int heads, int item, float *dst, int wave_)
 {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (no threadIdx here: a callee that reads it makes the caller keep the packed work-item ids alive for v31 across its whole
+    // body -- one more spilled register there; the lane id is the exec-mask count, the wave comes as an argument)
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(wave_);
     const int npk = L * (KP / 4), npieces = npk + L * 8;
     const int n = item / heads, h = item % heads;
     const float *base = QKV + (size_t)n * L * 3 * D + h * ATT_HD;
@@ -289,36 +293,39 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_dma_kernel(int L, i
     constexpr int KP = 36;                                                // K row pitch in floats
     const int bufw = L * (KP + 32);                                       // floats per buffer
     int item = blockIdx.x;
-    if (item < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item, sm);
+    if (item < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item, sm, wave);
     bool stored = false;                                                  // this wave issued output stores in the previous item
     // This wave's Q tile (NT <= NW: one tile per wave and head), RAW: the fragments of the NEXT head are requested right after
     // the score MFMAs of the current one (their registers are dead from there on) and scaled when that head starts -- the
     // sixteen strided loads used to sit exposed at the top of every tile (2-5 k of its ~50 k cycles).
     static_assert(NT <= NW, "one query tile per wave");
     float qa[ATT_HD / 2];
-    auto loadq = [&](int it_) {
+    auto loadq = [&](int it_, int li__, int lh__) {
         const int n_ = it_ / heads, h_ = it_ % heads;
-        const int qrow = 32 * wave + li < L ? 32 * wave + li : L - 1;
-        const float *qp = QKV + (size_t)n_ * L * 3 * D + (size_t)qrow * 3 * D + h_ * ATT_HD + lh;
+        const int qrow = 32 * wave + li__ < L ? 32 * wave + li__ : L - 1;
+        const float *qp = QKV + (size_t)n_ * L * 3 * D + (size_t)qrow * 3 * D + h_ * ATT_HD + lh__;
 #pragma unroll
         for (int q = 0; q < ATT_HD / 2; q++) qa[q] = qp[2 * q];
     };
-    if (item < nitems && wave < NT) loadq(item);
+    if (item < nitems && wave < NT) loadq(item, li, lh);
     for (int it = 0; item < nitems; item += gridDim.x, it++) {
         // my DMA pieces of this item have landed: they are older than the (at most four) output stores of the previous item,
         // which need not be waited for (loads and stores retire in issue order)
         if (stored) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f70);
         vit_lds_barrier();
         float *Kb = sm + (it & 1) * bufw, *Vb = Kb + L * KP;
-        if (item + (int)gridDim.x < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item + gridDim.x, sm + ((it + 1) & 1) * bufw);
+        if (item + (int)gridDim.x < nitems) attention_stage_dma<NW, KP>(QKV, L, D, heads, item + gridDim.x, sm + ((it + 1) & 1) * bufw, wave);
         const int n = item / heads, h = item % heads;
         const float *base = QKV + (size_t)n * L * 3 * D;
         stored = false;
         // opaque per-iteration copies: everything below that depends only on (L, lane) -- 112 clamped V row addresses, the key
         // masks -- is invariant across the item loop, and hoisted out of it it stays live across the whole body (60 spills)
-        int L_ = L, li_ = li, lh_ = lh;
+        // (the lane id itself is re-derived per item from the exec mask count: copies of li / lh would keep those two registers and
+        // the row addresses built from them alive -- and spilled, 8 registers -- across the body)
+        int L_ = L, lane_;
         asm volatile("" : "+s"(L_));
-        asm volatile("" : "+v"(li_), "+v"(lh_));
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+        const int li_ = lane_ & 31, lh_ = lane_ >> 5;
         // 1/sqrt(d) and log2(e) folded into Q: the softmax numerators are exp2(S' - max'), one v_exp_f32 per score and no multiply
         const float scale = rsqrtf((float)ATT_HD) * 1.44269504088896341f;
         for (int qt = wave; qt < NT; qt += NW) {
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_mfma_dma_kernel(int L, i
             }
             // every score MFMA has delivered (the maximum consumed their results): the Q registers are free for the next head
             __builtin_amdgcn_sched_barrier(0);
-            if (item + (int)gridDim.x < nitems) loadq(item + gridDim.x);
+            if (item + (int)gridDim.x < nitems) loadq(item + gridDim.x, li_, lh_);
             __builtin_amdgcn_sched_barrier(0);
             float den = 0.f;
 #pragma unroll

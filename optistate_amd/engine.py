@@ -524,6 +524,12 @@ def flatten_state_dict(sd, num_layers, device=None):
 _default_engines = threading.local()
 
 
+def reset_default_engines():
+    """Forgets the calling thread's default contexts (the next default_engine() creates a fresh one, re-reading the OS_* tuning
+    variables): for tools that compare tuning knobs inside one process."""
+    _default_engines.__dict__.pop("engines", None)
+
+
 def default_engine(device=0):
     """The calling THREAD's context on `device` (one context per (thread, GPU); calls on a context are stream-ordered
     and a context holds ONE loaded model and one set of scratch buffers, so two threads must not share one).  The weight

@@ -53,6 +53,11 @@ SCRATCH_FREE = {
     # BASELINE configs[3]: the training step
     "ost::bwd_sweep_kernel<1, 8, 0>": "training backward sweep",
     "ost::bwd_sweep_stack_kernel": "batch-64 training backward, all layers in one launch (gru/gru_train.py:36)",
+    "ost::dw2_kernel<6>": "training weight gradients, the 188-wide first layer",
+    "ost::dw2_kernel<4>": "training weight gradients, the 128-wide layers",
+    "ost::dw2_kernel<2>": "training weight gradients, 60 / 64-wide layers",
+    "ost::dw_kernel<false, 4>": "weight gradients of an epoch's last, partial batch (B % 32 != 0 with the batch_first input): two passes for 188 columns",
+    "ost::dw_kernel<false, 2>": "the same, 60 / 64-wide layers",
     # estimate_state_mpc -- the reference's real loop
     # NOT HELD: "osm::kf_mpc_persistent_kernel<1>" (estimate_state_mpc at the reference's shape): 172 B = the callee-saved VGPRs of the QP
     # call's ABI, written at call entry and read back at its exit, nothing inside a loop body; the two ways around the call that were
@@ -66,6 +71,11 @@ SCRATCH_FREE = {
     "osk::kf_update_rows_kernel<true, float>": "Engine.kf_update, sequential form",
     "osk::kf_update_rows_kernel<false, double>": "os_kf_update, float64 P, batch form",
     "osk::kf_update_rows_kernel<true, double>": "os_kf_update, float64 P, sequential form",
+    # BASELINE configs[5]: the depth encoder at the reference's shape (197 tokens, 4 heads x 32)
+    "osv::attention_mfma_dma_kernel<7, 8>": "ViT attention, persistent workgroups with LDS-DMA K / V (transformer/transformer_model.py:113-135)",
+    "osv::attention_mfma_kernel<7, 8>": "the same, one workgroup per head (OS_VIT_ATT_DMA=0)",
+    "osv::vit_mlp_kernel": "ViT MLP block",
+    "osv::vit_gemm_kernel<1, 3>": "ViT patch embedding / qkv / projection GEMMs",
     "osm::mpc_solve_kernel<1>": "the force QP (os_mpc_solve, the launch sequence of os_kf_mpc_run), one leg on the ground",
     "osm::mpc_solve_kernel<2>": "the same, trot (two legs)",
     "osm::mpc_solve_kernel<3>": "three legs",

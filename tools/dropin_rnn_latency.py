@@ -20,7 +20,7 @@ for tag, env in (("vec", {}), ("stack", {"OS_GRU_VEC": "0"}), ("per_layer", {"OS
         os.environ.pop(k, None)
     os.environ.update(env)
     from optistate_amd import engine as eng_mod
-    eng_mod._default_engines.clear()            # tuning knobs are read when an Engine is created
+    eng_mod.reset_default_engines()            # tuning knobs are read when an Engine is created
     torch.manual_seed(0)
     m = RNN(188, 128, 4, 24, torch.device("cuda"), evaluate=True).to("cuda").eval()
     xs = torch.rand(n, 1, 10, 188)

@@ -2,13 +2,8 @@
 # Development build of the library with in-kernel timestamps in the GRU layer kernels (-DOS_LAYER_TS) and runs of the reference's
 # real model shape GRU(188,128,4) at B = 65,536, T = 100 with gru_layer_stage_kernel (default) and with gru_layer_kernel<2,2>
 # (OS_GRU_STAGE=0): each layer prints its cycles per step and phase.   usage (GPU box): bash tools/layer_ts.sh
-R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/lts; mkdir -p $D
-cd $R/optistate_amd/csrc
-for f in capi kf_kernels kf_rows_kernel kf_dense_rows kf_step gru_kernels gru_bf16_kernels fused_kernels gru_train_kernels vit_kernels mpc_kernels; do
-  X=; [ $f = gru_kernels ] && X=-DOS_LAYER_TS; [ $f = kf_rows_kernel ] && X="-fno-slp-vectorize"
-  [ -f $D/$f.o -a $f != gru_kernels ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $X -DOS_BUILD_ID='"ts-build"' -c $f.hip -o $D/$f.o &
-done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboptistate_lts.so $D/*.o -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib
+R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/lts
+bash $R/tools/ts_lib.sh lts liboptistate_lts.so gru_kernels -DOS_LAYER_TS > /dev/null || exit 1
 cd $R
 echo "== gru_layer_stage_kernel"; OPTISTATE_HIP_LIB=$D/liboptistate_lts.so python3 tools/run_ref_shape_once.py 1
 echo "== gru_layer_kernel<2,2> (OS_GRU_STAGE=0)"; OS_GRU_STAGE=0 OPTISTATE_HIP_LIB=$D/liboptistate_lts.so python3 tools/run_ref_shape_once.py 1

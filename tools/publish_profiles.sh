@@ -4,6 +4,8 @@
 TAG=${1:-r04}; R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/$TAG
 for f in $O/*.json $O/*_kernel_stats.md $O/*.txt $O/*_raw.md; do
   [ -f "$f" ] || continue
+  # an empty file or a Python traceback is a collection step that failed: say so, keep what profiles/ holds
+  if [ ! -s "$f" ] || grep -q "^Traceback (most recent call last)" "$f"; then echo "NOT PUBLISHED (empty or a traceback): $f" >&2; continue; fi
   b=$(basename $f)
   case $b in
     traffic.json) cp $f $R/profiles/${TAG}_traffic_raw.json;;

@@ -1,13 +1,8 @@
 #!/bin/bash
 # Development build of the library with in-kernel timestamps in kf_run_rows2_kernel (-DOS_ROWS_TS) and a run at BASELINE
 # configs[1] (B = 4096, T = 1000): prints cycles per step and phase.  usage (GPU box): bash tools/rows_ts.sh
-R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/ts; mkdir -p $D
-cd $R/optistate_amd/csrc
-for f in capi kf_kernels kf_rows_kernel kf_step gru_kernels fused_kernels gru_train_kernels vit_kernels mpc_kernels; do
-  X=; [ $f = kf_kernels ] && X=-DOS_ROWS_TS; [ $f = kf_rows_kernel ] && X="-DOS_ROWS_TS -fno-slp-vectorize"
-  [ -f $D/$f.o -a $f != kf_rows_kernel -a $f != kf_kernels ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $X -DOS_BUILD_ID='"ts-build"' -c $f.hip -o $D/$f.o &
-done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboptistate_ts.so $D/*.o -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib
+R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/ts
+bash $R/tools/ts_lib.sh ts liboptistate_ts.so kf_kernels,kf_rows_kernel -DOS_ROWS_TS > /dev/null || exit 1
 cd $R
 OPTISTATE_HIP_LIB=$D/liboptistate_ts.so python3 - <<'PY'
 import ctypes as C, numpy as np, torch, sys

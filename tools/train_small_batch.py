@@ -18,7 +18,7 @@ for tag, env in (("stack", {}), ("per_layer", {"OS_GRU_STACK": "0"})):
     os.environ.pop("OS_GRU_STACK", None)
     os.environ.update(env)
     from optistate_amd import engine as eng_mod, train
-    eng_mod._default_engines.clear()
+    eng_mod.reset_default_engines()
     for B in (64, 512):
         torch.manual_seed(0)
         from optistate_amd import RNN
