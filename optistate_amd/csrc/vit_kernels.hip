@@ -45,7 +45,7 @@ __global__ void layernorm_kernel(size_t M, int D, const float *X, const float *w
 // Attention for one (image, head): QKV rows [L][3D] (bias already added by the projection's epilogue), head h owns columns h*hd..; K and V of the head staged in LDS,
 // one query per lane with an online softmax; output O[row][h*hd + :].  hd <= 64.
 template <int HD>
-__global__ void attention_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
+__global__ __launch_bounds__(256) void attention_kernel(int L, int D, int heads, const float *QKV, const float *qkv_b, float *O)
 {
     extern __shared__ float sm[];            // K [L][HD+1], V [L][HD+1]
     float *Ks = sm, *Vs = sm + (size_t)L * (HD + 1);

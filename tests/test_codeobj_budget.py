@@ -74,6 +74,8 @@ SCRATCH_FREE = {
     # BASELINE configs[5]: the depth encoder at the reference's shape (197 tokens, 4 heads x 32)
     "osv::attention_mfma_dma_kernel<7, 8>": "ViT attention, persistent workgroups with LDS-DMA K / V (transformer/transformer_model.py:113-135)",
     "osv::attention_mfma_kernel<7, 8>": "the same, one workgroup per head (OS_VIT_ATT_DMA=0)",
+    "osv::attention_kernel<32>": "ViT attention for other token counts (non-default img_size)",
+    "osv::attention_kernel<64>": "ViT attention with a head dimension of 64 (non-default num_heads / embed_dim)",
     "osv::vit_mlp_kernel": "ViT MLP block",
     "osv::vit_gemm_kernel<1, 3>": "ViT patch embedding / qkv / projection GEMMs",
     "osm::mpc_solve_kernel<1>": "the force QP (os_mpc_solve, the launch sequence of os_kf_mpc_run), one leg on the ground",

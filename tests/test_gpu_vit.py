@@ -130,3 +130,27 @@ def test_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
     assert float((out["3"][0] - out["0"][0]).abs().max()) < 5e-6
     assert float((out["1"][0] - out["0"][0]).abs().max()) < 5e-6
     assert float((out["2"][0] - out["0"][0]).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("img,dim,depth,heads", [(64, 128, 2, 2), (96, 128, 1, 4), (64, 256, 2, 4), (224, 128, 1, 2)])
+def test_other_constructor_arguments_take_the_general_attention_kernels(img, dim, depth, heads):
+    """The reference's constructor takes img_size / embed_dim / depth / num_heads (transformer/transformer_model.py:11-29); only its
+    defaults (197 tokens, 4 heads x 32) reach the matrix-core attention kernel.  Other token counts and a head dimension of 64 run
+    the one-query-per-lane kernels (attention_kernel<32>, <64>): same float64 restatement, same bar."""
+    from optistate_amd.transformer_model import Transformer_Autoencoder
+    from oracle import vit_oracle
+    torch.manual_seed(3)
+    m = Transformer_Autoencoder(img_size=img, embed_dim=dim, depth=depth, num_heads=heads).to("cuda")
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    x = torch.rand(3, 1, img, img)
+    lat = m.forward_encoder(x.cuda())
+    assert lat.shape == (3, 1, dim)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ref = vit_oracle.encode(x[:, 0].numpy(), sd, heads=heads)
+    err = np.abs(lat.cpu().numpy()[:, 0] - ref).max()
+    assert err < 2e-5, err
+    from optistate_amd.engine import default_engine
+    assert default_engine(0).kernel_name("vit_attn") == "attention_kernel"
