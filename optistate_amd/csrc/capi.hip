@@ -47,7 +47,6 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         const char *e = getenv("OS_KF_ROWS_BELOW");      // tuning knobs (development): read once, here
         if (e) c->rows_kernel_below = atoi(e);
         e = getenv("OS_KF_SYM_PRE"); c->tune_sym_pre = e ? atoi(e) : 1;
-        e = getenv("OS_KF_ROWS_V1"); c->tune_rows_v1 = e ? atoi(e) : 0;
         e = getenv("OS_GRU_SPLIT"); c->tune_gru_split = e ? (atoi(e) != 0 ? -1 : 0) : -1;
         e = getenv("OS_GRU_AHEAD"); c->tune_gru_ahead = e ? atoi(e) : 1;
         e = getenv("OS_GRU_STAGE"); c->tune_gru_stage = e ? atoi(e) : 1;

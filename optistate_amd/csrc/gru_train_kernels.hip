@@ -1397,7 +1397,6 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_kernel<1, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             ctx->sweep_attr_set = true;
         }
         dim3 grid((B + BM - 1) / BM);
@@ -1437,13 +1436,12 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         } else {
             // resident leading k-pairs: one work item per wave
             const int nitems = ((a.need_dx ? (K + 31) / 32 : 0) + H / 32) * ((!a.need_dx && 8 > H / 32) ? 2 : 1);
-            const int wr = (nw == 8 && H == 128 && nitems <= 8) ? ctx->tune_sweep_wr : 0;
+            const int wr = (nw == 8 && H == 128 && nitems <= 8 && ctx->tune_sweep_wr != 0) ? 32 : 0;      // OS_SWEEP_WR=0: all of it streamed
             const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_SWEEP, s,
-                                           RB == 2 ? "bwd_sweep_kernel<2,4>" : wr == 32 ? "bwd_sweep_kernel<1,8,32>" : wr == 16 ? "bwd_sweep_kernel<1,8,16>" :
+                                           RB == 2 ? "bwd_sweep_kernel<2,4>" : wr == 32 ? "bwd_sweep_kernel<1,8,32>" :
                                            nw == 8 ? "bwd_sweep_kernel<1,8>" : "bwd_sweep_kernel<1,4>");
             if (RB == 2) hipLaunchKernelGGL((bwd_sweep_kernel<2, 4>), grid, dim3(256), lds, s, a);
             else if (wr == 32) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8, 32>), grid, dim3(512), lds, s, a);
-            else if (wr == 16) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8, 16>), grid, dim3(512), lds, s, a);
             else if (nw == 8) hipLaunchKernelGGL((bwd_sweep_kernel<1, 8>), grid, dim3(512), lds, s, a);
             else hipLaunchKernelGGL((bwd_sweep_kernel<1, 4>), grid, dim3(256), lds, s, a);
             os_prof_end(ctx, slot, s);

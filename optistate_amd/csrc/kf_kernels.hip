@@ -206,165 +206,6 @@ __global__ __launch_bounds__(64, 1) void kf_run_sym_noise_kernel(const KfRunArgs
     kf_run_sym_body<OUT, true>(a, kc, b_raw);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Small-batch variant: 16 lanes per trajectory (4 trajectories per wave), lane r of a group holds ROW r of P (12 VGPRs)
-// and x[r].  At B = 4096 the lane-per-trajectory kernels fill 64 of the 1024 SIMDs; this one fills all of them.  Row
-// broadcasts inside a 16-lane DPP row are single `row_share` moves, the rank-1 covariance updates are 12 FMAs per lane.
-// Scalars of a trajectory (inputs, rotation, dynamics, z) are computed redundantly by its 16 lanes.  Same arithmetic as
-// the sequential full-P form (update_sequential), so the same parity bars apply.
-// ---------------------------------------------------------------------------------------------------------------
-template <int SRC>
-__device__ __forceinline__ float row_bcast(float v)
-{
-    // value of lane SRC of this lane's 16-lane row (DPP row_share)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + SRC, 0xf, 0xf, true));
-}
-
-// FEAT: emit the normalised 60-feature row [x_post | accel | f | p_world | dp | imu] (two-kernel fused path at small batches);
-// lane r of a trajectory's group writes the r-th element of each block
-template <bool AUX, bool FEAT>
-__global__ __launch_bounds__(256, 2) void kf_run_rows_kernel(const KfRunArgs a, const float *__restrict__ qmat)
-{
-    const int lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
-    const int b_raw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + grp;
-    const bool live = b_raw < a.B;
-    const int b = live ? b_raw : a.B - 1;
-    const int rr = r < 12 ? r : 11;                    // idle lanes 12-15 shadow row 11 (never broadcast from, never stored)
-    const size_t B = (size_t)a.B;
-    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
-    const KfConst &k = a.k;
-
-    float Prow[NS], qrow[NS], xr;
-    {
-        // (the row is per lane: in the VGPR offset -- as an SGPR offset hipcc wraps every load in a waterfall loop)
-        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
-        xr = buf_load(rx, voff + (uint32_t)rr * rowB, 0);
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            Prow[j] = buf_load(rP, voff + (uint32_t)(rr * NS + j) * rowB, 0);
-            qrow[j] = qmat[rr * NS + j];
-        }
-    }
-    // per-lane row selectors for the structured F_d = I + dt F
-    const bool top = r < 3, mid = r >= 3 && r < 6;
-    int status = 0;
-    StepIn in;
-    load_step(a, 0, voff, rowB, in);
-    for (int t = 0; t < a.T; t++) {
-        // ---- gather the full prior state (replicated per lane) ----
-        float x[NS];
-        x[0] = row_bcast<0>(xr); x[1] = row_bcast<1>(xr); x[2] = row_bcast<2>(xr); x[3] = row_bcast<3>(xr);
-        x[4] = row_bcast<4>(xr); x[5] = row_bcast<5>(xr); x[6] = row_bcast<6>(xr); x[7] = row_bcast<7>(xr);
-        x[8] = row_bcast<8>(xr); x[9] = row_bcast<9>(xr); x[10] = row_bcast<10>(xr); x[11] = row_bcast<11>(xr);
-        float z[NM], pw[12];
-        // the six sincos of a step (prior attitude, IMU attitude) are shared: lane r < 6 evaluates one angle, twelve row
-        // broadcasts hand the values to the group (replicated, they were a sixth of this kernel's instructions)
-        float sv, cv;
-        {
-            const float ang = r < 3 ? xr : (r == 3 ? in.imu[0] : (r == 4 ? in.imu[1] : in.imu[2]));
-            sincos_f32(ang, &sv, &cv);
-        }
-        const Rot rot = rotation_sc(row_bcast<0>(sv), row_bcast<0>(cv), row_bcast<1>(sv), row_bcast<1>(cv), row_bcast<2>(sv), row_bcast<2>(cv));
-        const Rot rimu = rotation_sc(row_bcast<3>(sv), row_bcast<3>(cv), row_bcast<4>(sv), row_bcast<4>(cv), row_bcast<5>(sv), row_bcast<5>(cv));
-        measurement_r(in, rimu, z);
-        // ---- covariance predict, row-parallel: M = F_d P (rows), then P' = M F_d^T (columns, local) + Q ----
-        float g[9];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) g[3 * i + kk] = k.dt * rot.m[3 * kk + i];
-        const float cg0 = top ? (r == 0 ? g[0] : (r == 1 ? g[3] : g[6])) : 0.f;
-        const float cg1 = top ? (r == 0 ? g[1] : (r == 1 ? g[4] : g[7])) : 0.f;
-        const float cg2 = top ? (r == 0 ? g[2] : (r == 1 ? g[5] : g[8])) : 0.f;
-        const float cd = mid ? k.dt : 0.f;
-        const int src6 = (lane & ~15) | ((r + 6) & 15);
-        float M[NS];
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            const float b6 = row_bcast<6>(Prow[j]), b7 = row_bcast<7>(Prow[j]), b8 = row_bcast<8>(Prow[j]);
-            const float up = __shfl(Prow[j], src6, 64);                 // row r+6 (rows 9..11 for lanes 3..5)
-            M[j] = Prow[j] + cg0 * b6 + cg1 * b7 + cg2 * b8 + cd * up;
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            Prow[j] = M[j] + g[3 * j] * M[6] + g[3 * j + 1] * M[7] + g[3 * j + 2] * M[8] + qrow[j];
-            Prow[3 + j] = M[3 + j] + k.dt * M[9 + j] + qrow[3 + j];
-        }
-#pragma unroll
-        for (int j = 6; j < NS; j++) Prow[j] = M[j] + qrow[j];
-        // ---- dynamics (replicated), keep this lane's component ----
-        status |= dynamics(x, rot, in.p, in.f, pw, k);
-        float xn = x[0];
-#pragma unroll
-        for (int i = 1; i < NS; i++) xn = (rr == i) ? x[i] : xn;
-        xr = xn;
-        if (a.p_rot_out && live && r < 12) {
-            float pv = pw[0];
-#pragma unroll
-            for (int i = 1; i < 12; i++) pv = (r == i) ? pw[i] : pv;
-            a.p_rot_out[((size_t)t * 12 + r) * B + b] = pv;
-        }
-        if (FEAT && live && r < 12) {
-            float fv = in.f[0], pv = pw[0], dv = in.dp[0];
-#pragma unroll
-            for (int i = 1; i < 12; i++) { fv = (r == i) ? in.f[i] : fv; pv = (r == i) ? pw[i] : pv; dv = (r == i) ? in.dp[i] : dv; }
-            float *fo = a.feat_out + (size_t)t * a.feat_I * B + b;
-            const float *mm = a.minmax;
-            auto put = [&](int j, float v) { __builtin_nontemporal_store((v - mm[j]) / (mm[60 + j] - mm[j]), fo + (size_t)j * B); };
-            put(18 + r, fv); put(30 + r, pv); put(42 + r, dv);
-            if (r < 6) {
-                float iv = in.imu[0];
-#pragma unroll
-                for (int i = 1; i < 6; i++) iv = (r == i) ? in.imu[i] : iv;
-                put(54 + r, iv);
-                put(12 + r, a.accel[((size_t)t * 6 + r) * B + b]);
-            }
-        }
-        // prefetch the next step's inputs underneath the update
-        const int tn = (t + 1 < a.T) ? t + 1 : t;
-        load_step(a, tn, voff, rowB, in);
-        // ---- ten sequential scalar measurement updates (kalman_filter.py:164-172 for diagonal R) ----
-#define OS_ROW_UPDATE(A, S)                                                                  \
-        {                                                                                    \
-            float rowv[NS];                                                                  \
-            _Pragma("unroll") for (int j = 0; j < NS; j++) rowv[j] = row_bcast<S>(Prow[j]);   \
-            float sv = rowv[S] + k.R[A * NM + A];                                            \
-            if (!(sv > 0.f) || !(sv < 3.0e38f)) { status |= 1; sv = 1.0f; }                  \
-            float inv = __builtin_amdgcn_rcpf(sv);                                           \
-            inv = inv * (2.0f - sv * inv);      /* one Newton step, <= 1 ulp (as in the lane kernels) */ \
-            const float innov = z[A] - row_bcast<S>(xr);                                     \
-            const float kc = Prow[S] * inv;                                                  \
-            xr += kc * innov;                                                                \
-            _Pragma("unroll") for (int j = 0; j < NS; j++) Prow[j] -= kc * rowv[j];           \
-        }
-        OS_ROW_UPDATE(0, 0) OS_ROW_UPDATE(1, 1) OS_ROW_UPDATE(2, 2) OS_ROW_UPDATE(3, 5) OS_ROW_UPDATE(4, 6)
-        OS_ROW_UPDATE(5, 7) OS_ROW_UPDATE(6, 8) OS_ROW_UPDATE(7, 9) OS_ROW_UPDATE(8, 10) OS_ROW_UPDATE(9, 11)
-#undef OS_ROW_UPDATE
-        if (!(xr * 0.f == 0.f)) status |= 2;
-        if (live && r < 12) a.x_out[((size_t)t * 12 + r) * B + b] = xr;
-        if (FEAT && live && r < 12)
-            __builtin_nontemporal_store((xr - a.minmax[r]) / (a.minmax[60 + r] - a.minmax[r]), a.feat_out + ((size_t)t * a.feat_I + r) * B + b);
-        if (AUX && a.ptrace_out) {
-            float dg = Prow[0];
-#pragma unroll
-            for (int i = 1; i < NS; i++) dg = (r == i) ? Prow[i] : dg;
-            dg = r < 12 ? dg : 0.f;
-            dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
-            if (live && r == 0) a.ptrace_out[(size_t)t * B + b] = dg;
-        }
-    }
-    // ---- final state: lane r writes x[r] and row r of P; the status word is OR-reduced over the 16 lanes ----
-    status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
-    status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
-    if (live && r < 12) {
-        a.x[(size_t)r * B + b] = xr;
-#pragma unroll
-        for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = Prow[j];
-        if (r == 0) a.status[b] = status;
-    }
-}
-
-
 // ---- single pieces for the drop-in Kalman_Filter class (B is tiny there; latency-bound by design) ----
 
 __global__ void kf_odom_kernel(int B, const float *p, const float *dp, const uint32_t *contact, const float *imu,
@@ -450,16 +291,11 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
     const bool noise = a.q_diag != nullptr;
     if (noise && (!seq || dense || !a.r_diag))
         return os_fail(ctx, -3, "os_kf_run_noise: per-trajectory noise needs the sequential update and the predict(p,f) covariance");
-#ifdef OS_ROWS_TS
-    const bool no_gain = true;                 // development build: kgain_out carries the timestamp sums
-#else
-    const bool no_gain = ctx->tune_rows_v1 ? !a.kgain_out : true;      // rows2 forms K_gain from the posterior; the v1 rows kernel does not
-#endif
     // (the rows kernel carries a step's position in a 32-bit SGPR offset: T * 48 B bytes must fit)
-    const bool use_rows = !noise && seq && !dense && no_gain && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
+    const bool use_rows = !noise && seq && !dense && !(flags & OS_KF_LANE_PER_TRAJECTORY) &&
                           a.B < ctx->rows_kernel_below && ctx->kf_qr && (uint64_t)a.T * 48ull * (uint64_t)a.B < 0xffffffffull;
     const bool use_sym = !use_rows && seq && !dense && ((flags & OS_KF_SYMMETRIC_P) || noise);
-    const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? (ctx->tune_rows_v1 ? "kf_run_rows_kernel" : "kf_run_rows2_kernel") : use_sym ? "kf_run_sym_kernel"
+    const char *kname = noise ? "kf_run_sym_noise_kernel" : use_rows ? "kf_run_rows2_kernel" : use_sym ? "kf_run_sym_kernel"
                         : dense ? (seq ? "kf_dense_rows_kernel<SEQ>" : "kf_dense_rows_kernel<BATCH>")
                                 : (seq ? "kf_dense_rows_kernel<SEQ,predict(p,f)>" : "kf_dense_rows_kernel<BATCH,predict(p,f)>");
     const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, kname);
@@ -468,19 +304,13 @@ int os_kf_run_impl(os_ctx *ctx, KfRunArgs &a, uint32_t flags, hipStream_t s)
         e = launch_kf_dense_rows(a, (const float *)ctx->kf_qr, seq, feat, aux, s);
     } else if (noise) {
         dim3 grid((a.B + 63) / 64), block(64);
-        if (feat) hipLaunchKernelGGL((kf_run_sym_noise_kernel<2>), grid, block, 0, s, a);
-        else if (aux) hipLaunchKernelGGL((kf_run_sym_noise_kernel<1>), grid, block, 0, s, a);
+        if (aux) hipLaunchKernelGGL((kf_run_sym_noise_kernel<1>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((kf_run_sym_noise_kernel<0>), grid, block, 0, s, a);
         e = hipGetLastError();
     } else if (use_rows) {
         // small batch: 16 lanes per trajectory so that every SIMD gets a wave
         dim3 grid((a.B + 15) / 16), block(256);                       // 4 waves x 4 trajectories per workgroup
-        if (ctx->tune_rows_v1) {
-            if (feat) hipLaunchKernelGGL((kf_run_rows_kernel<false, true>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-            else if (aux) hipLaunchKernelGGL((kf_run_rows_kernel<true, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-            else hipLaunchKernelGGL((kf_run_rows_kernel<false, false>), grid, block, 0, s, a, (const float *)ctx->kf_qr);
-            e = hipGetLastError();
-        } else e = launch_kf_rows2(a, (const float *)ctx->kf_qr, feat, aux, s);
+        e = launch_kf_rows2(a, (const float *)ctx->kf_qr, feat, aux, s);
     } else if (use_sym) {
         dim3 grid((a.B + 63) / 64), block(64);
         const bool qd = ctx->q_is_diagonal;

@@ -35,7 +35,7 @@ __device__ __forceinline__ float row_bcast(float v)
 
 // ---------------------------------------------------------------------------------------------------------------
 // kf_run_rows2_kernel -- 16 lanes per trajectory (four trajectories per wave): lane r holds row r of P and x[r] (round 3; the
-// round-2 kernel with the same layout, kf_run_rows_kernel in kf_kernels.hip, stays behind OS_KF_ROWS_V1=1 for A/B runs).
+// round-2 kernel with the same layout was deleted in round 5: never launched outside A/B runs).
 // At B = 4096 there is exactly one wave per SIMD and each wave is a chain of T dependent steps, so a step costs what the wave
 // issues: 409 VALU instructions (PMC) and ~2.1 k cycles (round 2: ~930 and 4.7 k; profiles/r03_rows2_timestamps.md has the
 // build-by-build table).  What is where:

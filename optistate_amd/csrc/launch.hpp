@@ -21,7 +21,6 @@ struct os_ctx {
     float *kf_qr;                        // device copy of Q (144) and R (100) for per-lane indexing (small-batch kernel)
     int rows_kernel_below;               // use the 16-lanes-per-trajectory kernel when B is below this
     int tune_sym_pre;                    // OS_KF_SYM_PRE=0: kf_run_sym_kernel without the half-step-ahead LDS pick-up of the inputs (A/B runs)
-    int tune_rows_v1;                    // OS_KF_ROWS_V1=1: the first 16-lanes-per-trajectory kernel instead of kf_run_rows2_kernel (A/B runs)
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
     int tune_gru_stack;                  // small batches run their layer stack as one pipelined launch (gru_stack_kernel / bwd_sweep_stack_kernel):
@@ -50,7 +49,7 @@ struct os_ctx {
     int tune_vit_tail_split;             // 1: the last partial round of vit_mlp_kernel tiles runs as 32- / 64-row tiles (OS_VIT_TAIL_SPLIT=0: full tiles)
     int tune_dw_fused;                   // 1: W_ih and W_hh gradients of a layer in one launch (dw3_kernel) when eligible, 0: two launches,
                                          // 2: one launch only for inputs of at most 128 columns (the round-2d state)
-    int tune_sweep_wr;                   // backward sweep: leading k-pairs of a wave's weight chunk kept in registers (32, 16 or 0)
+    int tune_sweep_wr;                   // backward sweep: 32 leading k-pairs of a wave's weight chunk kept in registers (OS_SWEEP_WR=0: none)
     int tune_sweep_nw;                   // 0 automatic, 4 / 8 waves per backward-sweep workgroup
     int tune_train_overlap;              // OS_TRAIN_OVERLAP=0: weight-gradient kernels on the caller's stream (no side stream)
     char err[512];
