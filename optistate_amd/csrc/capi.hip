@@ -66,6 +66,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_VIT_TAIL_SPLIT"); c->tune_vit_tail_split = e ? atoi(e) : 1;
         e = getenv("OS_VIT_ATT_DMA"); c->tune_vit_att_dma = e ? atoi(e) : 1;
         e = getenv("OS_VIT_MLP_BM"); c->tune_vit_mlp_bm = e ? atoi(e) : 64;
+        e = getenv("OS_GRU_WIDE"); c->tune_gru_wide = e ? atoi(e) : 1; c->wide_attr_set = false;
         e = getenv("OS_SWEEP_WR"); c->tune_sweep_wr = e ? atoi(e) : 32;
         e = getenv("OS_SWEEP_NW"); c->tune_sweep_nw = e ? atoi(e) : 0;
         // weight-gradient kernels on a side stream underneath the next layer's sweep: unset = where CUs are idle and the launches are long
@@ -119,7 +120,7 @@ void os_destroy(os_ctx *ctx)
     if (ctx->stack_flags) (void)hipFree(ctx->stack_flags);
     if (ctx->stack_err_host) (void)hipHostFree(ctx->stack_err_host);
     if (ctx->stack_err_local) (void)hipFree(ctx->stack_err_local);
-    float *bufs[] = {ctx->gru_seq, ctx->gru_xs, ctx->gru_hl, ctx->gru_gi, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
+    float *bufs[] = {ctx->gru_seq, ctx->gru_wide_seq, ctx->gru_xs, ctx->gru_hl, ctx->gru_gi, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)

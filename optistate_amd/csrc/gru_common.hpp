@@ -28,6 +28,20 @@ struct LayerArgs {
     int KBx = 0;
 };
 
+// gru_wide_kernel (gru_wide_kernel.hip): the layer stack of a small batch on four CUs per (layer, tile)
+struct WideArgs {
+    int n, tiles, B, T, K0;               // layers in this launch, 32-row tiles, batch, steps, input width of layer 0
+    const float *xs0;                     // layer 0's input, SoA [T][K0][B]
+    const float *w[8];                    // packed weight image of each layer (os_gru_load)
+    float *hseq[8];                       // h stream of each layer, row-major [T][B][H]: the exchange buffer (training: the saved h stream)
+    float *sv_r[8], *sv_z[8], *sv_n[8], *sv_g[8];      // SAVE: the other saved activations, [T][B][H]
+    float *h_last[8];                     // optional h_T of a layer, SoA [H][B]
+    uint32_t *flags;                      // [n][tiles][4] progress counters: steps published
+    int32_t *err, *err_local;
+    uint32_t max_polls;
+    int drop_layer, drop_step;            // tests: that layer stops publishing from that step on
+};
+
 __host__ __device__ inline size_t chunk_floats(int KPx, int KPh) { return (size_t)(KPx + KPh) * 3 * 64 + 4 * 32; }
 
 // Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each):

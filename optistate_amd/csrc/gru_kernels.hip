@@ -1816,6 +1816,24 @@ static int gru_layers(os_ctx *ctx, int B, int T, const float *in, int in_btf, in
     const size_t hf = (size_t)H * B;
     size_t woff = 0;
     for (int l = 0; l < first_layer; l++) woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
+    // ---- small H = 128 batch: every layer in ONE launch on four CUs per (layer, tile) (gru_wide_kernel.hip) ----
+    if (!in_btf && first_layer == 0 && L >= 2 && os_gru_wide_eligible(ctx, B, T, d.input_size, H, L)) {
+        const size_t tbh = (size_t)T * B * H;
+        if (os_ensure_scratch(ctx, &ctx->gru_wide_seq, &ctx->gru_wide_seq_floats, (size_t)L * tbh)) return -10;
+        WideArgs wa;
+        wa.n = L; wa.tiles = (B + 31) / 32; wa.B = B; wa.T = T; wa.K0 = d.input_size; wa.xs0 = in;
+        for (int l = 0; l < L; l++) {
+            wa.w[l] = ctx->gru_packed + woff;
+            wa.hseq[l] = ctx->gru_wide_seq + (size_t)l * tbh;
+            wa.sv_r[l] = wa.sv_z[l] = wa.sv_n[l] = wa.sv_g[l] = nullptr;
+            wa.h_last[l] = h_last_all ? h_last_all + (size_t)l * hf : ((l == L - 1) ? hlast : nullptr);
+            woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
+        }
+        if (const int rc = os_gru_launch_wide(ctx, wa, false, s)) return rc;
+        const float *top = h_last_all ? h_last_all + (size_t)(L - 1) * hf : hlast;
+        const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * H + d.num_classes));
+        return os_gru_head_launch(ctx, B, top, fcw, out, s);
+    }
     const int grp = in_btf ? 0 : stack_group(ctx, B, T, first_layer == 0 ? d.input_size : H, H, L - first_layer);
     if (grp >= 2) {
         // ---- small batch: grp layers per launch, pipelined through progress flags (gru_stack_kernel); a single left-over layer on its own ----

@@ -1200,6 +1200,7 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
     if (os_ensure_scratch(ctx, &ts->seq, &ts->seq_floats, (size_t)L * tbh)) return -10;
     // small batches (the reference trains at 64, gru/gru_train.py:36): the whole forward as ONE layer-pipelined launch (gru_stack_kernel)
     const bool stack = os_gru_stack_eligible(ctx, B, T, I, H, L);
+    const bool wide = stack && L >= 2 && os_gru_wide_eligible(ctx, B, T, I, H, L);      // gru_wide_kernel.hip
     // layer 0 reads the caller's (B, T, I) tensor itself where its kernel can (no SoA copy of the input)
     const bool x_direct = !stack && os_gru_layer_takes_btf(ctx, B, T, I, H);
     if (!x_direct) {
@@ -1229,7 +1230,19 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
         in = a.seq_out;
         woff += os_layer_packed_floats(K, H);
     }
-    if (stack) {
+    if (stack && wide) {
+        // four CUs per (layer, tile): the saved h stream [T][B][H] is the exchange buffer; the head's [H][B] comes out as h_last
+        osg::WideArgs wa;
+        wa.n = L; wa.tiles = (B + 31) / 32; wa.B = B; wa.T = T; wa.K0 = I; wa.xs0 = ts->xs;
+        for (int l = 0; l < L; l++) {
+            wa.w[l] = la[l].w;
+            wa.hseq[l] = la[l].sv_h ? la[l].sv_h : ts->seq + (size_t)l * tbh;      // (OS_TRAIN_DBG_NOSAVE: the SoA buffer's memory, row-major)
+            wa.sv_r[l] = la[l].sv_r; wa.sv_z[l] = la[l].sv_z; wa.sv_n[l] = la[l].sv_n; wa.sv_g[l] = la[l].sv_g;
+            wa.h_last[l] = l == L - 1 ? ts->seq + (size_t)(L - 1) * tbh + (size_t)(T - 1) * H * B : nullptr;
+        }
+        const int rc = os_gru_launch_wide(ctx, wa, la[0].sv_r != nullptr, s);
+        if (rc) return rc;
+    } else if (stack) {
         const int rc = os_gru_launch_stack(ctx, la, L, s);
         if (rc) return rc;
     }

@@ -23,6 +23,8 @@ struct os_ctx {
     int tune_sym_pre;                    // OS_KF_SYM_PRE=0: kf_run_sym_kernel without the half-step-ahead LDS pick-up of the inputs (A/B runs)
     // development knobs, read from the environment ONCE in os_create (OS_KF_ROWS_BELOW, OS_GRU_SPLIT, OS_DW_RPS, OS_SWEEP_NW)
     int tune_gru_split;                  // -1 automatic, 0 never use the eight-wave split layer kernel
+    int tune_gru_wide;                   // OS_GRU_WIDE=0: small H = 128 batches stay on gru_stack_kernel (one CU per (layer, tile)) instead of gru_wide_kernel (four)
+    bool wide_attr_set;
     int tune_gru_stack;                  // small batches run their layer stack as one pipelined launch (gru_stack_kernel / bwd_sweep_stack_kernel):
                                          // 1 = yes, and the call waits for the launch and reads the error word (default); 2 = yes, asynchronous (a lost
                                          // producer surfaces at the next os_gru_* call); 0 = a launch per layer.  OS_GRU_STACK / os_gru_set_stack
@@ -72,6 +74,7 @@ struct os_ctx {
     bool vec_attr_set;
     uint64_t gru_clock;
     const float *gru_flat;    // caller-owned flat weights (kept for the head / biases)
+    float *gru_wide_seq; size_t gru_wide_seq_floats;   // gru_wide_kernel's exchange buffers: L x [T][B][H] (inference)
     float *gru_seq;  size_t gru_seq_floats;   // inter-layer sequences [T][H][B] x2 + h_last
     float *gru_xs;   size_t gru_xs_floats;    // SoA copy of a (B,T,I) input
     float *gru_hl;   size_t gru_hl_floats;    // SoA h_last of all layers
@@ -163,7 +166,7 @@ static inline int os_fail(os_ctx *ctx, int code, const char *msg)
     } while (0)
 
 // ---- internal cross-translation-unit helpers (not part of the C ABI) ----
-namespace osg { struct LayerArgs; }
+namespace osg { struct LayerArgs; struct WideArgs; }
 size_t os_layer_packed_floats(int K, int H);
 int os_ensure_scratch(os_ctx *ctx, float **buf, size_t *cap, size_t need_floats);
 int os_gru_launch_layer(os_ctx *ctx, const osg::LayerArgs &a, hipStream_t s);
@@ -172,6 +175,8 @@ bool os_gru_stack_eligible(os_ctx *ctx, int B, int T, int Kfirst, int H, int nla
 int os_gru_launch_stack(os_ctx *ctx, const osg::LayerArgs *layers, int n, hipStream_t s);   // n <= 8 consecutive layers as one pipelined launch
 bool os_gru_layer_takes_btf(os_ctx *ctx, int B, int T, int K, int H);   // gru_kernels.hip: the layer kernel for this shape reads (B, T, K) inputs itself
 int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, float *out, hipStream_t s);
+bool os_gru_wide_eligible(os_ctx *ctx, int B, int T, int K0, int H, int n);                 // gru_wide_kernel.hip
+int os_gru_launch_wide(os_ctx *ctx, osg::WideArgs &a, bool save, hipStream_t s);
 void os_train_destroy(os_ctx *ctx);
 void os_step_destroy(os_ctx *ctx);
 void os_vit_destroy(os_ctx *ctx);

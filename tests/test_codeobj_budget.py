@@ -43,7 +43,9 @@ SCRATCH_FREE = {
     "osg::gru_layer_bf16_kernel<2>": "the same, two terms",
     "osg::gru_gi_kernel<1>": "window-stream inference: rows . W_ih^T once per row",
     "osg::gru_gi_kernel<2>": "the same, 64-row tiles",
-    "osg::gru_stack_kernel<4, false>": "the reference's own windows (B = 1 / 64), H = 128",
+    "osg::gru_wide_kernel<false>": "the reference's own windows as a batch (2 <= layers, H = 128, up to 512 windows): four CUs per (layer, tile)",
+    "osg::gru_wide_kernel<true>": "batch-64 training forward (gru/gru_train.py:36)",
+    "osg::gru_stack_kernel<4, false>": "H = 128 batches of 513 .. 2,048 windows (and OS_GRU_WIDE=0)",
     "osg::gru_stack_kernel<4, true>": "batch-64 training forward (gru/gru_train.py:36)",
     "osg::gru_stack_kernel<2, false>": "layer-pipelined stack, H = 64",
     "osg::gru_stack_kernel<2, true>": "layer-pipelined stack, H = 64, training forward",

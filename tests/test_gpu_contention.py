@@ -39,7 +39,7 @@ def test_stacked_launches_beside_a_process_that_fills_the_gpu():
     with torch.no_grad():
         m(x)
         eng = m._engine
-        assert eng.kernel_name("gru_layer") == "gru_stack_kernel"
+        assert eng.kernel_name("gru_layer") in ("gru_stack_kernel", "gru_wide_kernel")      # one launch for the stack (H = 128 up to 512 windows: four CUs per (layer, tile))
         ref_stack = m(x).clone()                            # the stacked launch on an idle GPU
         eng.set_stack_mode(0)
         ref = m(x).clone()                                  # a launch per layer (other kernels: another summation order, ~1e-7 apart)
@@ -66,7 +66,7 @@ def test_stacked_launches_beside_a_process_that_fills_the_gpu():
         assert n > 20
     finally:
         hog.wait(timeout=60)
-    assert eng.kernel_name("gru_layer") == "gru_stack_kernel"     # the mode is back on after any fallback
+    assert eng.kernel_name("gru_layer") in ("gru_stack_kernel", "gru_wide_kernel")     # the mode is back on after any fallback
 
 
 def test_stacked_training_sweeps_beside_a_process_that_fills_the_gpu():
@@ -86,7 +86,7 @@ def test_stacked_training_sweeps_beside_a_process_that_fills_the_gpu():
         return out, eng.gru_backward(x, out, dout).clone()
 
     out0, g0 = grad()
-    assert eng.kernel_name("gru_layer") == "gru_stack_kernel" and eng.kernel_name("train_sweep") == "bwd_sweep_stack_kernel"
+    assert eng.kernel_name("gru_layer") in ("gru_stack_kernel", "gru_wide_kernel") and eng.kernel_name("train_sweep") == "bwd_sweep_stack_kernel"
     scale = g0.abs().max().item()
     hog = subprocess.Popen([sys.executable, "-c", HOG, ROOT, "10"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:

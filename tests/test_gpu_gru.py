@@ -258,6 +258,7 @@ def test_layer_pipelined_stack_kernel_bit_identical_to_per_layer_launches(monkey
     m = RNN(I, H, L, C, torch.device("cpu"))
     x = (torch.rand(B, T, I) * 2 - 1).cuda()
     monkeypatch.setenv("OS_GRU_VEC", "0")                      # (B <= 4 would otherwise take gru_vec_kernel)
+    monkeypatch.setenv("OS_GRU_WIDE", "0")                     # (H = 128 up to 512 windows would otherwise take gru_wide_kernel: its own test below)
     monkeypatch.setenv("OS_GRU_STACK", "0"); monkeypatch.setenv("OS_GRU_AHEAD", "0")
     e0 = Engine(0)
     e0.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
@@ -305,6 +306,44 @@ def test_layer_pipelined_stack_kernel_behind_the_fused_first_layer(monkeypatch):
         assert (eng.kernel_name("gru_layer") == "gru_stack_kernel") == (stack == "1"), eng.kernel_name("gru_layer")
     assert torch.isfinite(outs["1"]).all()
     assert (outs["1"] - outs["0"]).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("I,H,L,B,T", [(188, 128, 4, 64, 10), (188, 128, 4, 1, 10), (188, 128, 4, 512, 6), (61, 128, 2, 33, 7), (60, 128, 8, 250, 25),
+                                       (192, 128, 3, 100, 1), (128, 128, 2, 97, 2), (1, 128, 2, 40, 5), (188, 128, 4, 8, 120)])
+def test_wide_kernel_four_cus_per_layer_tile(monkeypatch, I, H, L, B, T):
+    """gru_wide_kernel: the stack of a small H = 128 batch as ONE launch with the 128 hidden units of a (layer, tile) split over four
+    workgroups that exchange their slices of h_t every step through progress counters.  Against the float64 oracle, against a launch
+    per layer (1e-6: another summation order) for the output and every layer's h_T, and bit for bit against ITSELF on 20 repeats (its
+    summation order is fixed: a consumer that read a slice before it was complete would show as a run-to-run difference).  Shapes: the
+    reference's model at its training batch, at one window, at the largest batch the kernel takes (16 tiles x 4 layers x 4 = 256
+    workgroups); odd input width with a partial tile; eight layers (tiles <= 8); the widest input at T = 1; T = 2; input width 1; 120 steps."""
+    from optistate_amd import Engine, RNN, flatten_state_dict
+    from oracle import c_oracle as orc
+    C = 24
+    torch.manual_seed(24)
+    m = RNN(I, H, L, C, torch.device("cpu"))
+    x = (torch.rand(B, T, I) * 2 - 1).cuda()
+    monkeypatch.setenv("OS_GRU_VEC", "0")
+    monkeypatch.setenv("OS_GRU_STACK", "0")
+    e0 = Engine(0)
+    e0.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    out0, hl0 = e0.gru_forward(x, want_h_last=True)
+    torch.cuda.synchronize()
+    assert "wide" not in e0.kernel_name("gru_layer") and "stack" not in e0.kernel_name("gru_layer")
+    monkeypatch.setenv("OS_GRU_STACK", "1")
+    e1 = Engine(0)
+    e1.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
+    first = None
+    for rep in range(20):
+        out1, hl1 = e1.gru_forward(x, want_h_last=True)
+        torch.cuda.synchronize()
+        assert e1.kernel_name("gru_layer") == "gru_wide_kernel"
+        if first is None:
+            first = (out1.clone(), hl1.clone())
+        assert torch.equal(out1, first[0]) and torch.equal(hl1, first[1]), rep
+    assert (out1 - out0).abs().max().item() < 1e-6 and (hl1 - hl0).abs().max().item() < 2e-6
+    ref, _, _ = orc.gru_forward(x.cpu().numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
+    assert np.abs(out1.cpu().numpy() - ref).max() < GRU_TOL
 
 
 @pytest.mark.parametrize("I,H,L,B,T", [(188, 128, 4, 1, 10), (188, 128, 4, 4, 10), (60, 64, 4, 1, 10), (60, 64, 2, 3, 16), (61, 128, 1, 2, 1),
@@ -373,12 +412,12 @@ def test_h64_with_192_inputs_falls_back_where_the_split_body_does_not_fit_lds(mo
     assert np.abs(out - ref).max() < GRU_TOL
 
 
-@pytest.mark.parametrize("B,T,expect", [(4, 12, "gru_vec_kernel"), (4, 13, "gru_stack_kernel"), (5, 9, "gru_stack_kernel"), (1, 48, "gru_vec_kernel"),
-                                        (1, 49, "gru_stack_kernel"), (3, 16, "gru_vec_kernel"), (3, 17, "gru_stack_kernel"),
-                                        (2048, 2, "gru_stack_kernel"), (2049, 2, "gru_layer"), (4096, 2, "gru_stack_kernel"), (4097, 2, "gru_layer")])
+@pytest.mark.parametrize("B,T,expect", [(4, 12, "gru_vec_kernel"), (4, 13, "gru_wide_kernel"), (5, 9, "gru_wide_kernel"), (1, 48, "gru_vec_kernel"),
+                                        (1, 49, "gru_wide_kernel"), (3, 16, "gru_vec_kernel"), (3, 17, "gru_wide_kernel"),
+                                        (512, 3, "gru_wide_kernel"), (513, 3, "gru_stack_kernel"), (2048, 2, "gru_stack_kernel"), (2049, 2, "gru_layer"), (4096, 2, "gru_stack_kernel"), (4097, 2, "gru_layer")])
 def test_small_batch_dispatch_boundaries(B, T, expect):
-    """Either side of every dispatch boundary of os_gru_forward (B <= 4 and B T <= 48: gru_vec_kernel; (layer, tile) workgroups <= 256:
-    one gru_stack_kernel launch; up to 128 tiles: as many layers per launch as fit -- 2,049: three + the fourth on its own, 4,096: two
+    """Either side of every dispatch boundary of os_gru_forward (B <= 4 and B T <= 48: gru_vec_kernel; up to 512 windows at four layers of 128: one
+    gru_wide_kernel launch, four CUs per (layer, tile); (layer, tile) workgroups <= 256: one gru_stack_kernel launch; up to 128 tiles: as many layers per launch as fit -- 2,049: three + the fourth on its own, 4,096: two
     + two; beyond: a launch per layer) gives the float64 oracle's numbers, through the drop-in class."""
     from optistate_amd import RNN
     from oracle import c_oracle as orc
@@ -411,7 +450,7 @@ def test_window_stream_forward_equals_materialised_windows(I, H, L, N, W):
     eng.load_gru(flatten_state_dict(m.state_dict(), L, "cuda"), I, H, L, C)
     out = eng.gru_forward_windows(rows, W)
     assert out.shape == (N - W + 1, C)
-    assert eng.kernel_name("gru_layer") in ("gru_layer_split_kernel<GI>", "gru_layer_ahead_kernel", "gru_stack_kernel", "gru_layer_split_kernel",
+    assert eng.kernel_name("gru_layer") in ("gru_layer_split_kernel<GI>", "gru_layer_ahead_kernel", "gru_stack_kernel", "gru_wide_kernel", "gru_layer_split_kernel",
                                             "gru_layer_kernel<2,2>", "gru_layer_kernel<1,3>", "gru_vec_kernel", "gru_layer_stage_kernel")
     win = rows.unfold(0, W, 1).permute(0, 2, 1).contiguous()
     ref_gpu = eng.gru_forward(win)

@@ -51,7 +51,7 @@ def test_backward_matches_torch_autograd(dims, B, T):
     out = m(xg)                                           # HIP forward (training path: grad enabled)
     assert np.abs(out.detach().cpu().numpy() - ref_out.numpy()).max() < 1e-5
     if 2 <= L <= 8 and ((B + 31) // 32) * L <= 256:       # small batch: the layers of the training forward run as one pipelined launch
-        assert m._engine.kernel_name("gru_layer") == "gru_stack_kernel", m._engine.kernel_name("gru_layer")
+        assert m._engine.kernel_name("gru_layer") in ("gru_stack_kernel", "gru_wide_kernel"), m._engine.kernel_name("gru_layer")
     tgt = torch.cat([y.cuda(), (out[:, :C // 2].detach() - y.cuda()).abs()], dim=1)
     loss = torch.nn.functional.mse_loss(out, tgt)         # the reference's criterion; torch only does bookkeeping
     loss.backward()                                       # HIP backward
