@@ -32,16 +32,19 @@ using osk::buf_load;
 using osk::make_rsrc;
 using osk::rsrc_t;
 
-constexpr int WD_H = 128, WD_HS = WD_H + 1, WD_NKX = 12, WD_NKH = 8, WD_XCH = 8 * 4 * 14 * 64;
+constexpr int WD_H = 128, WD_HS = WD_H + 1, WD_NKX = 12, WD_NKH = 8, WD_XCH = 8 * 4 * 16 * 64;
+#ifndef WD_AUX
+#define WD_AUX 17      // sc0 | sc1: system scope (development: 16 = sc1, agent scope)
+#endif
 
 
 __device__ __forceinline__ float wd_load_coh(rsrc_t r, uint32_t voff, uint32_t soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 17));      // sc0 sc1: coherent across workgroups / XCDs
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, WD_AUX));      // sc0 sc1: coherent across workgroups / XCDs
 }
 __device__ __forceinline__ void wd_store_coh(rsrc_t r, uint32_t voff, uint32_t soff, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 17);      // write-through
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, WD_AUX);      // write-through
 }
 // The counters of this layer's four groups (lanes 0..3) and of the layer below (lanes 4..7), polled with system-scope loads by every
 // wave; false after max_polls rounds.  Plain coherent loads / stores, not acquire / release atomics: those come with an L2 write-back
@@ -54,7 +57,7 @@ __device__ __forceinline__ bool wd_wait8(rsrc_t rf, uint32_t own_off, uint32_t n
     const uint32_t off = (lane < 4 ? own_off : prev_off) + (uint32_t)(lane & 3) * 4u;
     for (uint32_t spin = 0; spin < max_polls; spin++) {
         uint32_t v = need;
-        if (lane < 8 && need) v = __builtin_amdgcn_raw_buffer_load_b32(rf, off, 0u, 17);
+        if (lane < 8 && need) v = __builtin_amdgcn_raw_buffer_load_b32(rf, off, 0u, WD_AUX);
         if (__builtin_amdgcn_ballot_w64(v < need) == 0) return true;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -71,14 +74,16 @@ __device__ __forceinline__ void wd_lost(int32_t *err, int32_t *err_local)
 template <bool SAVE>
 __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // ht [32][129] | xch [8 waves][4 gates][14 elements][64] | xt [32][XS]
+    // xch [8 waves][4 gates][4 quads][64 lanes][4] (the partial sums) ALIASES the two tiles ht [32][129] | xt [32][XS]: the tiles are dead once
+    // every wave holds its A fragments in registers
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
     // block -> (tile, layer, group): blockIdx % 8 = XCD = tile % 8; inside an XCD the slots run (tile / 8, layer, group)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = 4 * a.n;
     const int tile = (slot / per) * 8 + xcd, l = (slot % per) >> 2, q = slot & 3;
     if (tile >= a.tiles) return;
     const int B = a.B, T = a.T, K = l == 0 ? a.K0 : WD_H, KPx = (K + 1) / 2, XS = 2 * KPx + 1;
-    float *ht = smem, *xch = smem + 32 * WD_HS, *xt = xch + WD_XCH;
+    float *ht = smem, *xt = smem + 32 * WD_HS, *xch = smem;
     const int row0 = tile * 32;
 
     // ---- this wave's weight fragments: chunk q, x k-pairs [xb, xb + nkx), h k-pairs [8 wave, 8 wave + 8) ----
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
         if (l == 0) {
 #pragma unroll
             for (int e = 0; e < WD_NKX; e++)
-                if (k0 + 16 * e < K) xt[li * XS + k0 + 16 * e] = vx[e];
+                if (k0 + 16 * e < 2 * KPx) xt[li * XS + k0 + 16 * e] = k0 + 16 * e < K ? vx[e] : 0.f;      // (the pad column of an odd width: zero, every step -- the tile's LDS is reused)
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e++) xt[srow * XS + sk + 16 * e] = lost ? __builtin_nanf("") : vx[e];
@@ -154,19 +159,25 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
 
     stage(0);
     __syncthreads();
+    OSL_TS_DECL
     for (int t = 0; t < T; t++) {
+        OSL_TS(0)
         f32x16 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[g][e] = 0.f;
         // ---- gate GEMM, this wave's k-pairs: r, z, gi_n <- x_t . W_i^T; r, z, gh_n <- h_{t-1} . W_h^T ----
+        float hp0, hp1;
         {
             float ax[WD_NKX], ah[WD_NKH];
 #pragma unroll
             for (int j = 0; j < WD_NKX; j++) ax[j] = j < nkx ? xt[li * XS + 2 * (xb + j) + lh] : 0.f;
 #pragma unroll
             for (int j = 0; j < WD_NKH; j++) ah[j] = ht[li * WD_HS + 2 * (hb + j) + lh];
+            hp0 = ht[hidx]; hp1 = ht[hidx + WD_HS];            // h_{t-1} of the pair this wave updates
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hp0), "+v"(hp1) :: "memory");
+            __syncthreads();                                    // every wave has its fragments: the tiles' LDS becomes the exchange buffer
 #pragma unroll
             for (int j = 0; j < WD_NKX; j++) {
                 if (j < nkx) {
@@ -182,37 +193,33 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[j], whr[j][2], acc[3], 0, 0, 0);
             }
         }
-        // ---- partial sums: every element goes to the wave that owns it (slot = its index among the 14 a wave gives away) ----
+        OSL_TS(1)                                               // gate GEMM slice
+        // ---- partial sums: all sixteen elements of every gate as 16-byte pieces (no per-element branches: the first form spent more
+        // cycles issuing 56 conditional 4-byte writes than on the MFMAs); the owner of a pair reads its 8 bytes from the other seven ----
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
-            for (int e = 0; e < 16; e++)
-                if ((e >> 1) != wave) xch[((wave * 4 + g) * 14 + ((e >> 1) > wave ? e - 2 : e)) * 64 + lane] = acc[g][e];
+            for (int qd = 0; qd < 4; qd++)
+                *reinterpret_cast<f32x4 *>(xch + (size_t)(((wave * 4 + g) * 4 + qd) * 64 + lane) * 4) =
+                    (f32x4){acc[g][4 * qd], acc[g][4 * qd + 1], acc[g][4 * qd + 2], acc[g][4 * qd + 3]};
+        __syncthreads();
+        OSL_TS(2)                                               // partial sums -> LDS, barrier
         float own[4][2];
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+        for (int g = 0; g < 4; g++) { own[g][0] = 0.f; own[g][1] = 0.f; }
+        {
+            const int oq = wave >> 1, op = 2 * (wave & 1);                           // quad and position of element 2 wave
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                float v = acc[g][i];
-#pragma unroll
-                for (int ww = 1; ww < 8; ww++) v = wave == ww ? acc[g][2 * ww + i] : v;
-                own[g][i] = v;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int ww = 0; ww < 8; ww++) {
-            if (ww != wave) {
-                const int s0 = wave > ww ? 2 * wave - 2 : 2 * wave;                  // slot of element 2 wave in wave ww's fourteen
+            for (int ww = 0; ww < 8; ww++)                                           // (fixed order 0..7, own partial included: deterministic)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    own[g][0] += xch[((ww * 4 + g) * 14 + s0) * 64 + lane];
-                    own[g][1] += xch[((ww * 4 + g) * 14 + s0 + 1) * 64 + lane];
+                    const osk::f2 v = *reinterpret_cast<const osk::f2 *>(xch + (size_t)(((ww * 4 + g) * 4 + oq) * 64 + lane) * 4 + op);
+                    own[g][0] += v[0]; own[g][1] += v[1];
                 }
-            }
         }
         // ---- cell update of the pair (rows orow, orow + 1; unit q * 32 + li) ----
         const CellPair cp = gru_cell_pair((osk::f2){own[0][0], own[0][1]}, (osk::f2){own[1][0], own[1][1]}, (osk::f2){own[2][0], own[2][1]},
-                                          (osk::f2){own[3][0], own[3][1]}, (osk::f2){ht[hidx], ht[hidx + WD_HS]}, nb_r, nb_z, nb_n, b_hn);
+                                          (osk::f2){own[3][0], own[3][1]}, (osk::f2){hp0, hp1}, nb_r, nb_z, nb_n, b_hn);
         {
             const rsrc_t rh = make_rsrc(a.hseq[l] + (size_t)t * B * WD_H, step_bytes);          // rows past the batch are dropped (range check)
             wd_store_coh(rh, out_off, 0u, cp.hn[0]);
@@ -234,15 +241,25 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
                     if (row0 + orow + i < B) a.h_last[l][(size_t)(q * 32 + li) * B + row0 + orow + i] = cp.hn[i];
             }
         }
+        OSL_TS(3)                                               // sum of the partials, cell update, stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's slice stores are acknowledged
         __syncthreads();                                        // ... every wave's; and ht / xch / xt are free again
         if (threadIdx.x == 0 && !(l == a.drop_layer && t >= a.drop_step))
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)t + 1u, rf, own_off + (uint32_t)q * 4u, 0u, 17);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)t + 1u, rf, own_off + (uint32_t)q * 4u, 0u, WD_AUX);
+        OSL_TS(4)                                               // store acknowledgements, barrier, counter
         if (t + 1 < T) {
             stage(t + 1);
+            OSL_TS(5)                                           // wait for the counters + both tiles' loads -> LDS
             __syncthreads();
+            OSL_TS(6)
         }
     }
+#ifdef OS_LAYER_TS
+    if (tile == 0 && q == 0 && threadIdx.x == 0)
+        printf("gru_wide_kernel layer %d K=%d T=%d cycles per step (wave 0): GEMM slice %llu | partials + barrier %llu | sum + cell + stores %llu | acks + barrier + counter %llu | wait + tiles %llu | barrier %llu | sum %llu\n",
+               l, K, T, ts_sum[1] / T, ts_sum[2] / T, ts_sum[3] / T, ts_sum[4] / T, ts_sum[5] / T, ts_sum[6] / T,
+               (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5] + ts_sum[6]) / T);
+#endif
 }
 
 }  // namespace osg
@@ -252,7 +269,8 @@ using namespace osg;
 static size_t wide_lds_bytes(int K0)
 {
     const int KPx = (K0 + 1) / 2, XS = (2 * KPx + 1) > WD_HS ? 2 * KPx + 1 : WD_HS;
-    return ((size_t)32 * WD_HS + WD_XCH + (size_t)32 * XS) * sizeof(float);
+    const size_t tiles = (size_t)32 * (WD_HS + XS);
+    return (tiles > (size_t)WD_XCH ? tiles : (size_t)WD_XCH) * sizeof(float);      // the exchange buffer aliases the tiles
 }
 
 // every workgroup resident at once, a tile's workgroups on one XCD: 4 n slots per tile, cu_count / 8 slots per XCD
