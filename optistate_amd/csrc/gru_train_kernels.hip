@@ -538,6 +538,188 @@ __global__ __launch_bounds__(NW * 64, 1) void bwd_sweep_kernel(const SweepArgs a
     sweep_body<RB, NW, WR, false>(a);
 }
 
+// ---- bwd_sweep_wide_kernel: the stacked sweep on FOUR compute units per (layer, tile) (the backward twin of gru_wide_kernel.hip) ----
+// bwd_sweep_stack_kernel runs a (layer, tile) on one CU: 8 - 10 output chunks x 192 k-pairs = 12.7 us of fp32 MFMA per step there,
+// 18 us per pipeline stage measured at the reference's batch of 64.  Here group q of (layer, tile) is its own workgroup and produces
+// output chunk q of dh_{t-1} (and, above the bottom layer, chunk q of dx_t): its waves split that chunk's 192 k-pair reduction 4 (8)
+// ways and keep their 48 (24) weight fragments in registers for the whole launch.  Every group forms the gate derivatives of the WHOLE
+// tile (cheap VALU work on prefetched activations) and stores its own quarter of them for the dW kernels; per step the four groups
+// exchange their 32-column slices of dh_{t-1} through a [T][B][H] buffer, and hand their slices of dx_t to the layer below, with
+// write-through stores and one counter per group (steps published = T - t), polled with cache-bypassing loads.  Bounded waits, error
+// word, NaN poisoning and the -20 return as in the other progress-counter kernels.  Block index -> (tile, layer, group) keeps a tile's
+// workgroups on one XCD.  Same sums as bwd_sweep_kernel up to the order of the partial reductions.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+struct SweepWideArgs {
+    int n, tiles;
+    uint32_t *flags;             // [n][tiles][4], zeroed before the launch
+    int32_t *err, *err_local;
+    uint32_t max_polls;
+    int drop_y, drop_step;
+    float *dhx[8];               // per launch row: dh exchange buffer [T][B][H] (index t holds the gradient w.r.t. h_t from the later steps)
+    SweepArgs layer[8];          // layer[0] = the top layer
+};
+
+__global__ __launch_bounds__(512, 1) void bwd_sweep_wide_kernel(const SweepWideArgs sa)
+{
+    constexpr int H = 128, HS = H + 1, GS = 4 * H + 1, Q = 3 * H / 2, NKW = 48;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // dh [32][129] | dG [32][513] | partial sums [8 waves][4 quads][64][4]
+    float *dh = sm, *dG = sm + 32 * HS, *xch = dG + 32 * GS;        // (32 * (129 + 513) = 20,544 floats: the exchange area is 16-byte aligned)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = 4 * sa.n;
+    const int tile = (slot / per) * 8 + xcd, y = (slot % per) >> 2, q = slot & 3;
+    if (tile >= sa.tiles) return;
+    const SweepArgs &a = sa.layer[y];
+    const int B = a.B, T = a.T, K = a.K, row0 = tile * 32;
+    // work items of this group: output chunk q of W_hh^T (item 0) and, with need_dx, chunk q of W_ih^T (item 1: K = 128 above the
+    // bottom layer); a chunk's 192 k-pairs over 8 / items waves
+    const int items = a.need_dx ? 2 : 1, slices = 8 / items, nk = Q / slices;
+    const int item = items == 2 ? wave >> 2 : 0, sl = items == 2 ? wave & 3 : wave, qlo = sl * nk;
+    const bool is_h = item == 0;
+    float wreg[NKW];
+    {
+        const float *wp = (is_h ? a.whhT : a.wihT) + (size_t)q * Q * 64 + (size_t)qlo * 64;
+#pragma unroll
+        for (int d = 0; d < NKW; d++) wreg[d] = d < nk ? wp[d * 64 + lane] : 0.f;
+    }
+    const osk::rsrc_t rf = osk::make_rsrc(sa.flags, (uint32_t)sa.n * (uint32_t)sa.tiles * 16u);
+    const uint32_t own_off = (uint32_t)((y * sa.tiles + tile) * 16), up_off = y > 0 ? (uint32_t)(((y - 1) * sa.tiles + tile) * 16) : 0u;
+    bool lost = false;
+    for (int i = threadIdx.x; i < 32 * HS; i += 512) dh[i] = 0.f;
+    __syncthreads();
+
+    // element map of the VALU phase: thread -> column c = tid % 128, rows tid / 128 + 4 e
+    const int c = threadIdx.x & (H - 1), rbase = threadIdx.x >> 7;
+    uint32_t eoff[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int g = row0 + rbase + 4 * e;
+        eoff[e] = (uint32_t)(((size_t)(g < B ? g : B - 1) * H + c) * 4);
+    }
+    const uint32_t step_bytes = (uint32_t)B * H * 4u, all_bytes = (uint32_t)((size_t)T * B * H * 4);
+    float pf_r[8], pf_z[8], pf_n[8], pf_g[8], pf_h[8];
+    auto prefetch = [&](int t) {
+        const uint32_t st = (uint32_t)((size_t)t * B * H * 4), hst = t > 0 ? st - step_bytes : 0u;
+        const osk::rsrc_t rr_ = osk::make_rsrc(a.sv_r, all_bytes), rz_ = osk::make_rsrc(a.sv_z, all_bytes), rn_ = osk::make_rsrc(a.sv_n, all_bytes),
+                          rg_ = osk::make_rsrc(a.sv_g, all_bytes), rh_ = osk::make_rsrc(a.sv_h, all_bytes);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            pf_r[e] = osk::buf_load_nt(rr_, eoff[e], st); pf_z[e] = osk::buf_load_nt(rz_, eoff[e], st); pf_n[e] = osk::buf_load_nt(rn_, eoff[e], st);
+            pf_g[e] = osk::buf_load_nt(rg_, eoff[e], st); pf_h[e] = osk::buf_load_nt(rh_, eoff[e], hst);
+        }
+    };
+    prefetch(T - 1);
+
+    for (int t = T - 1; t >= 0; t--) {
+        // ---- dh_t (the four groups' slices from step t + 1) and dy_t (the layer above, its step t): one wait, all loads together ----
+        const uint32_t need_own = (uint32_t)(T - 1 - t), need_up = y > 0 ? (uint32_t)(T - t) : 0u;
+        if (!lost && (need_own || need_up)) {
+            const uint32_t need = lane < 4 ? need_own : need_up;
+            const uint32_t off = (lane < 4 ? own_off : up_off) + (uint32_t)(lane & 3) * 4u;
+            lost = true;
+            for (uint32_t spin = 0; spin < sa.max_polls; spin++) {
+                uint32_t v = need;
+                if (lane < 8 && need) v = __builtin_amdgcn_raw_buffer_load_b32(rf, off, 0u, 17);
+                if (__builtin_amdgcn_ballot_w64(v < need) == 0) { lost = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lost && lane == 0) {
+                if (sa.err_local) __hip_atomic_fetch_or(sa.err_local, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sa.err) __hip_atomic_fetch_or(sa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        float vd[8], vy[8];
+        {
+            const osk::rsrc_t rd = osk::make_rsrc(sa.dhx[y] + (size_t)t * B * H, step_bytes);
+            const osk::rsrc_t ry = osk::make_rsrc((a.dy ? a.dy : a.sv_r) + (size_t)t * B * H, step_bytes);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                vd[e] = t < T - 1 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, eoff[e], 0u, 17)) : 0.f;
+                vy[e] = y > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, eoff[e], 0u, 17)) : 0.f;
+            }
+        }
+        // ---- gate derivatives of the whole tile (every group), this group's quarter of them to memory for the dW kernels ----
+        {
+            const bool last = t == T - 1;
+            const osk::rsrc_t rg4 = osk::make_rsrc(a.dg4 + (size_t)t * B * 4 * H, (uint32_t)B * 4u * H * 4u);
+            const bool mine = (c >> 5) == q;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int r = rbase + 4 * e, g = row0 + r;
+                const bool ok = g < B;
+                const float rr = pf_r[e], zz = pf_z[e], nn = pf_n[e], gg = pf_g[e], hp = t > 0 ? pf_h[e] : 0.f;
+                float dht = vd[e] + vy[e];
+                if (lost) dht = __builtin_nanf("");
+                if (a.dy_last && last) dht += a.dy_last[(size_t)(ok ? g : B - 1) * H + c];
+                if (!ok) dht = 0.f;
+                const float dn = dht * (1.0f - zz);
+                const float dz = dht * (hp - nn);
+                const float dhc = dht * zz;
+                const float dan = dn * (1.0f - nn * nn);
+                const float danr = dan * rr;
+                const float dar = dan * gg * rr * (1.0f - rr);
+                const float daz = dz * zz * (1.0f - zz);
+                if (ok && mine) {
+                    const uint32_t og = (uint32_t)(((size_t)g * 4 * H + c) * 4);
+                    osk::buf_store_nt(rg4, og, 0u, dar); osk::buf_store_nt(rg4, og, (uint32_t)H * 4u, daz);
+                    osk::buf_store_nt(rg4, og, 2u * H * 4u, dan); osk::buf_store_nt(rg4, og, 3u * H * 4u, danr);
+                }
+                dG[r * GS + c] = dar; dG[r * GS + H + c] = daz; dG[r * GS + 2 * H + c] = dan; dG[r * GS + 3 * H + c] = danr;
+                dh[r * HS + c] = dhc;            // the z * dh part of dh_{t-1}; the matrix part is added at the reduction
+            }
+        }
+        __syncthreads();
+        if (t > 0) prefetch(t - 1);
+        // ---- this wave's slice of its chunk's reduction: W_hh^T reads sections da_r, da_z, da_n r (columns >= 2H shift by H), W_ih^T 0..3H ----
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        {
+            const float *arow = dG + li * GS + lh;
+#pragma unroll
+            for (int d0 = 0; d0 < NKW; d0 += 8) {
+                if (d0 < nk) {
+                    float av[8];
+#pragma unroll
+                    for (int d = 0; d < 8; d++) {
+                        const int kk = qlo + d0 + d;
+                        av[d] = arow[2 * kk + ((is_h && kk >= H) ? H : 0)];
+                    }
+#pragma unroll
+                    for (int d = 0; d < 8; d++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], wreg[d0 + d], acc, 0, 0, 0);
+                }
+            }
+        }
+        // ---- partial sums through LDS: 16-byte pieces; wave `sl` of an item sums elements [sl epw, (sl + 1) epw) over the item's waves ----
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++)
+            *reinterpret_cast<f32x4w *>(xch + (size_t)((wave * 4 + qd) * 64 + lane) * 4) = (f32x4w){acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+        __syncthreads();
+        {
+            const int epw = 16 / slices;                    // 4 (two items) or 2 (one)
+            const osk::rsrc_t rdh = osk::make_rsrc(sa.dhx[y] + (size_t)(t > 0 ? t - 1 : 0) * B * H, t > 0 ? step_bytes : 0u);      // (t = 0: nobody reads dh_{-1})
+            const osk::rsrc_t rdx = osk::make_rsrc(a.dx + (size_t)t * B * K, (uint32_t)B * (uint32_t)K * 4u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < epw) {
+                    const int e = sl * epw + k, row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float v = 0.f;
+                    for (int w2 = item * slices; w2 < (item + 1) * slices; w2++) v += xch[(size_t)((w2 * 4 + (e >> 2)) * 64 + lane) * 4 + (e & 3)];
+                    if (is_h) {
+                        v += dh[row * HS + q * 32 + li];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdh, (uint32_t)(((size_t)(row0 + row) * H + q * 32 + li) * 4), 0u, 17);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdx, (uint32_t)(((size_t)(row0 + row) * K + q * 32 + li) * 4), 0u, 17);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's slice stores (and its gate-derivative stores) are acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0 && !(y == sa.drop_y && T - 1 - t >= sa.drop_step && sa.drop_step >= 0))
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(T - t), rf, own_off + (uint32_t)q * 4u, 0u, 17);
+    }
+}
+
 struct SweepStackArgs {
     int n, tiles, y0;            // y0: first layer index of this launch (0; the debug sequence OS_SWEEP_STACK_DBG=1 launches one layer at a time)
     uint32_t *flags;             // [n][tiles], zeroed before the launch
@@ -1119,6 +1301,8 @@ struct os_train_state {
     float *xs;    size_t xs_floats;      // SoA copy of the input [T][I][B]
     float *dg;    size_t dg_floats;      // gate derivatives [T][B][4H]: da_r | da_z | da_n | da_n * r
     float *dxy;   size_t dxy_floats;     // dx ping-pong [T][B][max(K,H)] x 2 + dh_T [B][H]
+    float *dhx;   size_t dhx_floats;     // bwd_sweep_wide_kernel: dh exchange buffers, L x [T][B][H]
+    bool sweep_wide_attr_set;
     float *wT;    size_t wT_floats;      // transposed-packed weights
     float *lossp; size_t lossp_floats;   // loss_kernel: per-workgroup partial sums + ticket counter
     int B, T;
@@ -1157,7 +1341,7 @@ void os_train_destroy(os_ctx *ctx)
 {
     os_train_state *t = (os_train_state *)ctx->train;
     if (!t) return;
-    float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->wT, t->lossp};
+    float *bufs[] = {t->act, t->seq, t->xs, t->dg, t->dxy, t->dhx, t->wT, t->lossp};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     if (t->side_ready) {
@@ -1320,6 +1504,9 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
                                    (ctx->tune_train_overlap < 0 && !stacked && 2 * ((B + 31) / 32) <= ctx->cu_count && (size_t)T * B >= 2048));
     if (os_ensure_scratch(ctx, &ts->dg, &ts->dg_floats, (stacked ? L : overlap ? 2 : 1) * (size_t)T * B * 4 * H)) return -10;
     if (overlap && train_side_stream(ctx, ts)) return -10;
+    // ... on four CUs per (layer, tile) where gru_wide_kernel's shape conditions hold (bwd_sweep_wide_kernel)
+    const bool wide_bwd = stacked && os_gru_wide_eligible(ctx, B, T, I, H, L);
+    if (wide_bwd && os_ensure_scratch(ctx, &ts->dhx, &ts->dhx_floats, (size_t)L * tbh)) return -10;
     const int ndx = stacked ? L : 2;
     if (os_ensure_scratch(ctx, &ts->dxy, &ts->dxy_floats, ndx * (size_t)T * B * Kmax + (size_t)B * H)) return -10;
     // transposed-packed weights (re-done every call: parameters change every optimiser step)
@@ -1415,7 +1602,33 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
         dim3 grid((B + BM - 1) / BM);
         int nw = (RB == 1 && ((a.need_dx ? (K + 31) / 32 : 0) + H / 32 >= 8 || (!a.need_dx && H / 32 >= 4))) ? 8 : 4;   // enough work items for eight waves
         if (ctx->tune_sweep_nw) nw = ctx->tune_sweep_nw == 8 && RB == 1 ? 8 : 4;
-        if (stacked) {
+        if (stacked && wide_bwd) {
+            if (l == L - 1) {                                  // four CUs per (layer, tile): bwd_sweep_wide_kernel
+                SweepWideArgs wa;
+                wa.n = L; wa.tiles = (B + 31) / 32;
+                const size_t nfl = (size_t)wa.n * wa.tiles * 4;
+                if (ctx->stack_flags_n < nfl) {
+                    if (ctx->stack_flags) OS_HIP(ctx, hipFree(ctx->stack_flags));
+                    ctx->stack_flags = nullptr; ctx->stack_flags_n = 0;
+                    OS_HIP(ctx, hipMalloc((void **)&ctx->stack_flags, nfl * sizeof(uint32_t)));
+                    ctx->stack_flags_n = nfl;
+                }
+                wa.flags = ctx->stack_flags;
+                wa.err = ctx->stack_err_dev; wa.err_local = ctx->stack_err_local; wa.max_polls = ctx->stack_max_polls;
+                wa.drop_y = ctx->stack_dbg_drop_layer >= 0 ? L - 1 - ctx->stack_dbg_drop_layer : -1; wa.drop_step = ctx->stack_dbg_drop_step;
+                OS_HIP(ctx, hipMemsetAsync(wa.flags, 0, nfl * sizeof(uint32_t), s));
+                for (int y = 0; y < L; y++) { wa.layer[y] = sweep_args(L - 1 - y); wa.dhx[y] = ts->dhx + (size_t)y * tbh; }
+                if (!ts->sweep_wide_attr_set) {
+                    OS_HIP(ctx, hipFuncSetAttribute((const void *)bwd_sweep_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    ts->sweep_wide_attr_set = true;
+                }
+                const size_t lds_w = (size_t)(32 * (H + 1) + 32 * (4 * H + 1) + 8 * 4 * 64 * 4) * sizeof(float);
+                const int slot = os_prof_begin(ctx, OS_PHASE_TRAIN_SWEEP, s, "bwd_sweep_wide_kernel");
+                hipLaunchKernelGGL(bwd_sweep_wide_kernel, dim3(8u * (unsigned)((wa.tiles + 7) / 8 * 4 * L)), dim3(512), lds_w, s, wa);
+                os_prof_end(ctx, slot, s);
+                if (const int rcv = os_stack_verify(ctx, s, "bwd_sweep_wide_kernel")) return rcv;
+            }
+        } else if (stacked) {
             if (l == L - 1) {                                  // every layer's sweep in this one launch; the iterations below only reduce
                 SweepStackArgs sa;
                 sa.n = L; sa.tiles = (B + 31) / 32;

@@ -54,7 +54,8 @@ SCRATCH_FREE = {
     "osg::gru_layer_kernel<2, 2>": "H = 128 fallback when the stage kernel steps aside",
     # BASELINE configs[3]: the training step
     "ost::bwd_sweep_kernel<1, 8, 0>": "training backward sweep",
-    "ost::bwd_sweep_stack_kernel": "batch-64 training backward, all layers in one launch (gru/gru_train.py:36)",
+    "ost::bwd_sweep_wide_kernel": "batch-64 training backward (gru/gru_train.py:36): all layers in one launch, four CUs per (layer, tile)",
+    "ost::bwd_sweep_stack_kernel": "training backward of 513 .. 2,048 windows, all layers in one launch (and OS_GRU_WIDE=0)",
     "ost::dw2_kernel<6>": "training weight gradients, the 188-wide first layer",
     "ost::dw2_kernel<4>": "training weight gradients, the 128-wide layers",
     "ost::dw2_kernel<2>": "training weight gradients, 60 / 64-wide layers",
