@@ -102,4 +102,8 @@ bash tools/bf16_layer_ts.sh > $O/bf16_layer_timestamps_raw.txt 2>&1
 bash tools/pmc_any.sh ${TAG}_bf16 "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE" $R/tools/bf16_layer_probe.py 65536 100 > $O/pmc_bf16_layer.txt 2>&1
 [ -x tools/micro/mfma_bf16_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/micro/mfma_bf16_rate tools/micro/mfma_bf16_rate.hip
 tools/micro/mfma_bf16_rate > $O/mfma_bf16_rate.txt 2>&1
+# the small-batch kernels on four CUs per (layer, tile): against one CU per tile, phase timestamps, the batch-64 training step's kernels
+python3 tools/wide_probe.py 200 2>/dev/null | grep "^|" > $O/wide_probe.md
+bash tools/wide_ts.sh 2>&1 | grep "cycles per step" | sort | tail -4 > $O/wide_timestamps_raw.txt
+stats train_B64 --mode train --batch 64 --steps 200 --warmup 20 --cpu-seconds 0
 ls $O
