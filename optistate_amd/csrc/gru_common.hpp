@@ -31,7 +31,8 @@ struct LayerArgs {
 // gru_wide_kernel (gru_wide_kernel.hip): the layer stack of a small batch on four CUs per (layer, tile)
 struct WideArgs {
     int n, tiles, B, T, K0;               // layers in this launch, 32-row tiles, batch, steps, input width of layer 0
-    const float *xs0;                     // layer 0's input, SoA [T][K0][B]
+    const float *xs0;                     // layer 0's input: SoA [T][K0][B], or the caller's batch_first (B, T, K0) tensor when xs0_btf
+    int xs0_btf;
     const float *w[8];                    // packed weight image of each layer (os_gru_load)
     float *hseq[8];                       // h stream of each layer, row-major [T][B][H]: the exchange buffer (training: the saved h stream)
     float *sv_r[8], *sv_z[8], *sv_n[8], *sv_g[8];      // SAVE: the other saved activations, [T][B][H]

@@ -1817,11 +1817,11 @@ static int gru_layers(os_ctx *ctx, int B, int T, const float *in, int in_btf, in
     size_t woff = 0;
     for (int l = 0; l < first_layer; l++) woff += os_layer_packed_floats(l == 0 ? d.input_size : H, H);
     // ---- small H = 128 batch: every layer in ONE launch on four CUs per (layer, tile) (gru_wide_kernel.hip) ----
-    if (!in_btf && first_layer == 0 && L >= 2 && os_gru_wide_eligible(ctx, B, T, d.input_size, H, L)) {
+    if (first_layer == 0 && L >= 2 && os_gru_wide_eligible(ctx, B, T, d.input_size, H, L)) {
         const size_t tbh = (size_t)T * B * H;
         if (os_ensure_scratch(ctx, &ctx->gru_wide_seq, &ctx->gru_wide_seq_floats, (size_t)L * tbh)) return -10;
         WideArgs wa;
-        wa.n = L; wa.tiles = (B + 31) / 32; wa.B = B; wa.T = T; wa.K0 = d.input_size; wa.xs0 = in;
+        wa.n = L; wa.tiles = (B + 31) / 32; wa.B = B; wa.T = T; wa.K0 = d.input_size; wa.xs0 = in; wa.xs0_btf = in_btf;
         for (int l = 0; l < L; l++) {
             wa.w[l] = ctx->gru_packed + woff;
             wa.hseq[l] = ctx->gru_wide_seq + (size_t)l * tbh;
@@ -2031,7 +2031,8 @@ int os_gru_forward(os_ctx *ctx, int32_t B, int32_t T, const float *x, float *out
     const int H = ctx->gru.hidden_size, L = ctx->gru.num_layers;
     if (vec_eligible(ctx, B, T)) return gru_vec_launch(ctx, B, T, x, out, h_last, (hipStream_t)stream);
     // (the stack kernel reads an SoA first layer: packing costs a few microseconds at its sizes)
-    const bool x_direct = stack_group(ctx, B, T, I, H, L) < 2 && os_gru_layer_takes_btf(ctx, B, T, I, H);
+    const bool wide = L >= 2 && os_gru_wide_eligible(ctx, B, T, I, H, L);      // gru_wide_kernel reads the (B, T, I) tensor itself
+    const bool x_direct = wide || (stack_group(ctx, B, T, I, H, L) < 2 && os_gru_layer_takes_btf(ctx, B, T, I, H));
     int rc = 0;
     if (!x_direct) {
         if (os_ensure_scratch(ctx, &ctx->gru_xs, &ctx->gru_xs_floats, (size_t)B * T * I)) return -10;

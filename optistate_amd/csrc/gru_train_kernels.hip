@@ -1386,7 +1386,7 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
     const bool stack = os_gru_stack_eligible(ctx, B, T, I, H, L);
     const bool wide = stack && L >= 2 && os_gru_wide_eligible(ctx, B, T, I, H, L);      // gru_wide_kernel.hip
     // layer 0 reads the caller's (B, T, I) tensor itself where its kernel can (no SoA copy of the input)
-    const bool x_direct = !stack && os_gru_layer_takes_btf(ctx, B, T, I, H);
+    const bool x_direct = wide || (!stack && os_gru_layer_takes_btf(ctx, B, T, I, H));
     if (!x_direct) {
         if (os_ensure_scratch(ctx, &ts->xs, &ts->xs_floats, (size_t)T * I * B)) return -10;
         int rc = os_pack_stream(ctx, B, T, I, x, ts->xs, stream);
@@ -1417,7 +1417,7 @@ static int forward_train_impl(os_ctx *ctx, int32_t B, int32_t T, const float *x,
     if (stack && wide) {
         // four CUs per (layer, tile): the saved h stream [T][B][H] is the exchange buffer; the head's [H][B] comes out as h_last
         osg::WideArgs wa;
-        wa.n = L; wa.tiles = (B + 31) / 32; wa.B = B; wa.T = T; wa.K0 = I; wa.xs0 = ts->xs;
+        wa.n = L; wa.tiles = (B + 31) / 32; wa.B = B; wa.T = T; wa.K0 = I; wa.xs0 = x; wa.xs0_btf = 1;
         for (int l = 0; l < L; l++) {
             wa.w[l] = la[l].w;
             wa.hseq[l] = la[l].sv_h ? la[l].sv_h : ts->seq + (size_t)l * tbh;      // (OS_TRAIN_DBG_NOSAVE: the SoA buffer's memory, row-major)

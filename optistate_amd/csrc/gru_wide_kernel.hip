@@ -115,20 +115,45 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
     const int srow = threadIdx.x >> 4, sk = threadIdx.x & 15;
     const uint32_t rm_off = (uint32_t)(((size_t)(row0 + srow) * WD_H + sk) * 4);
     const uint32_t step_bytes = (uint32_t)B * WD_H * 4u;
+    float vx[WD_NKX];
+    const int k0 = threadIdx.x >> 5, g = row0 + li < B ? row0 + li : B - 1;
+    // Layer 0's x_t depends on nothing inside the launch: its loads are issued a whole step ahead (behind the A-fragment reads of step
+    // t - 1) and wait in registers, so the input -- first touched here, straight from HBM when it is the caller's tensor -- is never on a
+    // step's critical path.
+    auto x0_issue = [&](int t) {
+        if (a.xs0_btf) {
+            // the caller's (B, T, K) tensor itself: thread -> (row tid / 16, inputs tid % 16 + 16 e), 64-byte runs of a row; rows past the
+            // batch fall outside the descriptor (read zero), inputs past K are masked (they would be the next row's)
+            const rsrc_t r = make_rsrc(a.xs0, (uint32_t)B * (uint32_t)T * (uint32_t)K * 4u);
+            if ((K & 3) == 0) {
+                // 16-byte pieces (every width the reference uses: 60, 188): three loads per thread, piece sk + 16 e of the row
+                const uint32_t vo = (uint32_t)((((size_t)(row0 + srow) * T + t) * K + 4 * sk) * 4);
+#pragma unroll
+                for (int e = 0; e < WD_NKX / 4; e++) {
+                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (4 * (sk + 16 * e) < K) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, (uint32_t)(e * 256), 0));
+                    vx[4 * e] = v[0]; vx[4 * e + 1] = v[1]; vx[4 * e + 2] = v[2]; vx[4 * e + 3] = v[3];
+                }
+            } else {
+                const uint32_t vo = (uint32_t)((((size_t)(row0 + srow) * T + t) * K + sk) * 4);
+#pragma unroll
+                for (int e = 0; e < WD_NKX; e++) vx[e] = sk + 16 * e < K ? buf_load(r, vo, (uint32_t)(e * 64)) : 0.f;
+            }
+        } else {
+            // the caller's SoA stream [T][K][B]: thread -> (input k0 + 16 e, row li), 128-byte segments; inputs past K read zero
+            const rsrc_t r = make_rsrc(a.xs0 + (size_t)t * K * B, (uint32_t)K * (uint32_t)B * 4u);
+#pragma unroll
+            for (int e = 0; e < WD_NKX; e++) vx[e] = buf_load(r, (uint32_t)g * 4u + (uint32_t)k0 * (uint32_t)B * 4u, (uint32_t)(e * 16) * (uint32_t)B * 4u);
+        }
+    };
     // x_t (and, for t > 0, h_{t-1}) of this layer: ONE wait on both sets of counters, then every load of both tiles in flight together
     auto stage = [&](int t) {
         if (!lost && (l > 0 || t > 0)) {
             lost = !wd_wait8(rf, own_off, (uint32_t)t, prev_off, l > 0 ? (uint32_t)t + 1u : 0u, a.max_polls);
             if (lost) wd_lost(a.err, a.err_local);
         }
-        float vx[WD_NKX], vh[8];
-        const int k0 = threadIdx.x >> 5, g = row0 + li < B ? row0 + li : B - 1;
-        if (l == 0) {
-            // the caller's SoA stream [T][K][B]: thread -> (input k0 + 16 e, row li), 128-byte segments; inputs past K read zero
-            const rsrc_t r = make_rsrc(a.xs0 + (size_t)t * K * B, (uint32_t)K * (uint32_t)B * 4u);
-#pragma unroll
-            for (int e = 0; e < WD_NKX; e++) vx[e] = buf_load(r, (uint32_t)g * 4u + (uint32_t)k0 * (uint32_t)B * 4u, (uint32_t)(e * 16) * (uint32_t)B * 4u);
-        } else {
+        float vh[8];
+        if (l > 0) {
             const rsrc_t r = make_rsrc(a.hseq[l - 1] + (size_t)t * B * WD_H, step_bytes);      // rows past the batch read zero (range check)
 #pragma unroll
             for (int e = 0; e < 8; e++) vx[e] = wd_load_coh(r, rm_off, (uint32_t)(e * 16 * 4));
@@ -138,7 +163,18 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
 #pragma unroll
             for (int e = 0; e < 8; e++) vh[e] = wd_load_coh(r, rm_off, (uint32_t)(e * 16 * 4));
         }
-        if (l == 0) {
+        if (l == 0 && a.xs0_btf && (K & 3) == 0) {
+#pragma unroll
+            for (int e = 0; e < WD_NKX / 4; e++)
+                if (4 * (sk + 16 * e) < K) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; c4++) xt[srow * XS + 4 * (sk + 16 * e) + c4] = vx[4 * e + c4];
+                }
+        } else if (l == 0 && a.xs0_btf) {
+#pragma unroll
+            for (int e = 0; e < WD_NKX; e++)
+                if (sk + 16 * e < 2 * KPx) xt[srow * XS + sk + 16 * e] = vx[e];      // (masked loads: the pad column of an odd width is zero)
+        } else if (l == 0) {
 #pragma unroll
             for (int e = 0; e < WD_NKX; e++)
                 if (k0 + 16 * e < 2 * KPx) xt[li * XS + k0 + 16 * e] = k0 + 16 * e < K ? vx[e] : 0.f;      // (the pad column of an odd width: zero, every step -- the tile's LDS is reused)
@@ -157,6 +193,7 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
     const int hidx = orow * WD_HS + q * 32 + li;
     const uint32_t out_off = (uint32_t)(((size_t)(row0 + orow) * WD_H + q * 32 + li) * 4);
 
+    if (l == 0) x0_issue(0);
     stage(0);
     __syncthreads();
     OSL_TS_DECL
@@ -178,6 +215,7 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
             hp0 = ht[hidx]; hp1 = ht[hidx + WD_HS];            // h_{t-1} of the pair this wave updates
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hp0), "+v"(hp1) :: "memory");
             __syncthreads();                                    // every wave has its fragments: the tiles' LDS becomes the exchange buffer
+            if (l == 0 && t + 1 < T) x0_issue(t + 1);           // (vx was consumed by stage(t))
 #pragma unroll
             for (int j = 0; j < WD_NKX; j++) {
                 if (j < nkx) {
