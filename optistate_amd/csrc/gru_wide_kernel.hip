@@ -146,46 +146,48 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
             for (int e = 0; e < WD_NKX; e++) vx[e] = buf_load(r, (uint32_t)g * 4u + (uint32_t)k0 * (uint32_t)B * 4u, (uint32_t)(e * 16) * (uint32_t)B * 4u);
         }
     };
-    // x_t (and, for t > 0, h_{t-1}) of this layer: ONE wait on both sets of counters, then every load of both tiles in flight together
-    auto stage = [&](int t) {
-        if (!lost && (l > 0 || t > 0)) {
-            lost = !wd_wait8(rf, own_off, (uint32_t)t, prev_off, l > 0 ? (uint32_t)t + 1u : 0u, a.max_polls);
-            if (lost) wd_lost(a.err, a.err_local);
-        }
-        float vh[8];
+    // x_t of this layer -> xt.  Above layer 0 it is the lower layer's h_t: wait for its four counters (steps published >= t + 1).
+    // (Measured and not kept: polling both layers' counters in one round and requesting both tiles together -- the siblings' counters
+    // become visible ~3 k cycles after a group's own publication, the lower layer's were there a stage ago: 17.0 against 15.4 k cycles per
+    // step; a look at the own counters riding along with this tile's loads, to skip the second poll: 16.0 k.)
+    auto stage_x = [&](int t) {
         if (l > 0) {
+            if (!lost) {
+                lost = !wd_wait8(rf, own_off, 0u, prev_off, (uint32_t)t + 1u, a.max_polls);
+                if (lost) wd_lost(a.err, a.err_local);
+            }
             const rsrc_t r = make_rsrc(a.hseq[l - 1] + (size_t)t * B * WD_H, step_bytes);      // rows past the batch read zero (range check)
 #pragma unroll
             for (int e = 0; e < 8; e++) vx[e] = wd_load_coh(r, rm_off, (uint32_t)(e * 16 * 4));
-        }
-        if (t > 0) {
-            const rsrc_t r = make_rsrc(a.hseq[l] + (size_t)(t - 1) * B * WD_H, step_bytes);
 #pragma unroll
-            for (int e = 0; e < 8; e++) vh[e] = wd_load_coh(r, rm_off, (uint32_t)(e * 16 * 4));
-        }
-        if (l == 0 && a.xs0_btf && (K & 3) == 0) {
+            for (int e = 0; e < 8; e++) xt[srow * XS + sk + 16 * e] = lost ? __builtin_nanf("") : vx[e];
+        } else if (a.xs0_btf && (K & 3) == 0) {
 #pragma unroll
             for (int e = 0; e < WD_NKX / 4; e++)
                 if (4 * (sk + 16 * e) < K) {
 #pragma unroll
                     for (int c4 = 0; c4 < 4; c4++) xt[srow * XS + 4 * (sk + 16 * e) + c4] = vx[4 * e + c4];
                 }
-        } else if (l == 0 && a.xs0_btf) {
+        } else if (a.xs0_btf) {
 #pragma unroll
             for (int e = 0; e < WD_NKX; e++)
                 if (sk + 16 * e < 2 * KPx) xt[srow * XS + sk + 16 * e] = vx[e];      // (masked loads: the pad column of an odd width is zero)
-        } else if (l == 0) {
+        } else {
 #pragma unroll
             for (int e = 0; e < WD_NKX; e++)
                 if (k0 + 16 * e < 2 * KPx) xt[li * XS + k0 + 16 * e] = k0 + 16 * e < K ? vx[e] : 0.f;      // (the pad column of an odd width: zero, every step -- the tile's LDS is reused)
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; e++) xt[srow * XS + sk + 16 * e] = lost ? __builtin_nanf("") : vx[e];
         }
-        if (t > 0) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) ht[srow * WD_HS + sk + 16 * e] = lost ? __builtin_nanf("") : vh[e];
+    };
+    // h_{t-1}, all 128 units: wait for this layer's four counters (>= t), request the tile; it is written to LDS behind the input half's MFMAs
+    float vh[8];
+    auto h_issue = [&](int t) {
+        if (!lost) {
+            lost = !wd_wait8(rf, own_off, (uint32_t)t, prev_off, 0u, a.max_polls);
+            if (lost) wd_lost(a.err, a.err_local);
         }
+        const rsrc_t r = make_rsrc(a.hseq[l] + (size_t)(t - 1) * B * WD_H, step_bytes);
+#pragma unroll
+        for (int e = 0; e < 8; e++) vh[e] = wd_load_coh(r, rm_off, (uint32_t)(e * 16 * 4));
     };
 
     // the two accumulator elements this wave owns: e = 2 wave, 2 wave + 1 -> rows (e & 3) + 8 (e >> 2) + 4 lh of the tile
@@ -193,9 +195,15 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
     const int hidx = orow * WD_HS + q * 32 + li;
     const uint32_t out_off = (uint32_t)(((size_t)(row0 + orow) * WD_H + q * 32 + li) * 4);
 
+    float ax[WD_NKX];
+    auto read_ax = [&]() {
+#pragma unroll
+        for (int j = 0; j < WD_NKX; j++) ax[j] = j < nkx ? xt[li * XS + 2 * (xb + j) + lh] : 0.f;
+    };
     if (l == 0) x0_issue(0);
-    stage(0);
+    stage_x(0);
     __syncthreads();
+    read_ax();
     OSL_TS_DECL
     for (int t = 0; t < T; t++) {
         OSL_TS(0)
@@ -204,26 +212,33 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
         for (int g = 0; g < 4; g++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[g][e] = 0.f;
-        // ---- gate GEMM, this wave's k-pairs: r, z, gi_n <- x_t . W_i^T; r, z, gh_n <- h_{t-1} . W_h^T ----
+        // ---- gate GEMM, this wave's k-pairs.  r, z, gi_n <- x_t . W_i^T (x_t's fragments were read at the end of the previous step;
+        // the tile of h_{t-1} is requested first and lands underneath) ----
+        if (t > 0) h_issue(t);
+#pragma unroll
+        for (int j = 0; j < WD_NKX; j++) {
+            if (j < nkx) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], wxr[j][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], wxr[j][1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], wxr[j][2], acc[2], 0, 0, 0);
+            }
+        }
+        if (t > 0) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) ht[srow * WD_HS + sk + 16 * e] = lost ? __builtin_nanf("") : vh[e];
+        }
+        __syncthreads();
+        OSL_TS(6)                                               // counters of this layer, h tile (under the input half's MFMAs), barrier
+        // ---- r, z, gh_n <- h_{t-1} . W_h^T ----
         float hp0, hp1;
         {
-            float ax[WD_NKX], ah[WD_NKH];
-#pragma unroll
-            for (int j = 0; j < WD_NKX; j++) ax[j] = j < nkx ? xt[li * XS + 2 * (xb + j) + lh] : 0.f;
+            float ah[WD_NKH];
 #pragma unroll
             for (int j = 0; j < WD_NKH; j++) ah[j] = ht[li * WD_HS + 2 * (hb + j) + lh];
             hp0 = ht[hidx]; hp1 = ht[hidx + WD_HS];            // h_{t-1} of the pair this wave updates
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hp0), "+v"(hp1) :: "memory");
             __syncthreads();                                    // every wave has its fragments: the tiles' LDS becomes the exchange buffer
-            if (l == 0 && t + 1 < T) x0_issue(t + 1);           // (vx was consumed by stage(t))
-#pragma unroll
-            for (int j = 0; j < WD_NKX; j++) {
-                if (j < nkx) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], wxr[j][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], wxr[j][1], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], wxr[j][2], acc[2], 0, 0, 0);
-                }
-            }
+            if (l == 0 && t + 1 < T) x0_issue(t + 1);           // (vx was consumed by stage_x(t))
 #pragma unroll
             for (int j = 0; j < WD_NKH; j++) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[j], whr[j][0], acc[0], 0, 0, 0);
@@ -286,15 +301,15 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)t + 1u, rf, own_off + (uint32_t)q * 4u, 0u, WD_AUX);
         OSL_TS(4)                                               // store acknowledgements, barrier, counter
         if (t + 1 < T) {
-            stage(t + 1);
-            OSL_TS(5)                                           // wait for the counters + both tiles' loads -> LDS
+            stage_x(t + 1);
             __syncthreads();
-            OSL_TS(6)
+            read_ax();
+            OSL_TS(5)                                           // the lower layer's counters, x tile -> LDS, barrier, its fragments
         }
     }
 #ifdef OS_LAYER_TS
     if (tile == 0 && q == 0 && threadIdx.x == 0)
-        printf("gru_wide_kernel layer %d K=%d T=%d cycles per step (wave 0): GEMM slice %llu | partials + barrier %llu | sum + cell + stores %llu | acks + barrier + counter %llu | wait + tiles %llu | barrier %llu | sum %llu\n",
+        printf("gru_wide_kernel layer %d K=%d T=%d cycles per step (wave 0): recurrent half %llu | partials + barrier %llu | sum + cell + stores %llu | acks + barrier + counter %llu | x wait + tile + fragments %llu | h wait + tile under the input half %llu | sum %llu\n",
                l, K, T, ts_sum[1] / T, ts_sum[2] / T, ts_sum[3] / T, ts_sum[4] / T, ts_sum[5] / T, ts_sum[6] / T,
                (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5] + ts_sum[6]) / T);
 #endif
