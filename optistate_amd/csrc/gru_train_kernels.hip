@@ -21,6 +21,7 @@
 
 #include "gru_common.hpp"
 #include "kf_device.hpp"   // buffer addressing helpers
+#include "gru_device.hpp"  // OSL_TS (development timestamps)
 
 namespace ost {
 
@@ -609,7 +610,9 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_wide_kernel(const SweepWideA
     };
     prefetch(T - 1);
 
+    OSL_TS_DECL
     for (int t = T - 1; t >= 0; t--) {
+        OSL_TS(0)
         // ---- dh_t (the four groups' slices from step t + 1) and dy_t (the layer above, its step t): one wait, all loads together ----
         const uint32_t need_own = (uint32_t)(T - 1 - t), need_up = y > 0 ? (uint32_t)(T - t) : 0u;
         if (!lost && (need_own || need_up)) {
@@ -637,6 +640,7 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_wide_kernel(const SweepWideA
                 vy[e] = y > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, eoff[e], 0u, 17)) : 0.f;
             }
         }
+        OSL_TS(1)                                               // counters + dh / dy tiles requested
         // ---- gate derivatives of the whole tile (every group), this group's quarter of them to memory for the dW kernels ----
         {
             const bool last = t == T - 1;
@@ -668,56 +672,84 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_wide_kernel(const SweepWideA
             }
         }
         __syncthreads();
+        OSL_TS(2)                                               // tiles landed, gate derivatives, barrier
         if (t > 0) prefetch(t - 1);
-        // ---- this wave's slice of its chunk's reduction: W_hh^T reads sections da_r, da_z, da_n r (columns >= 2H shift by H), W_ih^T 0..3H ----
-        f32x16 acc;
+        // ---- this wave's slice of its chunk's reduction: W_hh^T reads sections da_r, da_z, da_n r (columns >= 2H shift by H), W_ih^T 0..3H;
+        // then the partial sums through LDS as 16-byte pieces: wave `sl` of an item sums elements [sl epw, (sl + 1) epw) over the item's
+        // waves and stores them.  Compile-time in the item count: the A fragments of the next eight k-pairs are requested before the
+        // MFMAs of the current eight, and the reduction's LDS reads are all in flight together (with run-time bounds this phase took
+        // 6 k cycles of a step's 18 k) ----
+        auto mfma_reduce = [&](auto items_c) {
+            constexpr int ITEMS = decltype(items_c)::value, SLICES = 8 / ITEMS, NK = Q / SLICES, EPW = 16 / SLICES;      // 48 / 24 k-pairs, 4 / 2 elements
+            f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.f;
-        {
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
             const float *arow = dG + li * GS + lh;
+            float av[2][8];
+            auto fetch = [&](int d0, float *dst) {
 #pragma unroll
-            for (int d0 = 0; d0 < NKW; d0 += 8) {
-                if (d0 < nk) {
-                    float av[8];
+                for (int d = 0; d < 8; d++) {
+                    const int kk = qlo + d0 + d;
+                    dst[d] = arow[2 * kk + ((is_h && kk >= H) ? H : 0)];
+                }
+            };
+            fetch(0, av[0]);
 #pragma unroll
-                    for (int d = 0; d < 8; d++) {
-                        const int kk = qlo + d0 + d;
-                        av[d] = arow[2 * kk + ((is_h && kk >= H) ? H : 0)];
-                    }
+            for (int b = 0; b < NK / 8; b++) {
+                if (b + 1 < NK / 8) fetch(8 * (b + 1), av[(b + 1) & 1]);
 #pragma unroll
-                    for (int d = 0; d < 8; d++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], wreg[d0 + d], acc, 0, 0, 0);
+                for (int d = 0; d < 8; d++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][d], wreg[8 * b + d], acc, 0, 0, 0);
+            }
+            OSL_TS(3)                                           // MFMA slice
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                *reinterpret_cast<f32x4w *>(xch + (size_t)((wave * 4 + qd) * 64 + lane) * 4) = (f32x4w){acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+            __syncthreads();
+            float own[EPW];
+#pragma unroll
+            for (int k = 0; k < EPW; k++) own[k] = 0.f;
+            if constexpr (EPW == 4) {
+#pragma unroll
+                for (int j = 0; j < SLICES; j++) {
+                    const f32x4w v = *reinterpret_cast<const f32x4w *>(xch + (size_t)(((item * SLICES + j) * 4 + sl) * 64 + lane) * 4);
+                    own[0] += v[0]; own[1] += v[1]; own[2] += v[2]; own[3] += v[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SLICES; j++) {
+                    const osk::f2 v = *reinterpret_cast<const osk::f2 *>(xch + (size_t)((j * 4 + (sl >> 1)) * 64 + lane) * 4 + 2 * (sl & 1));
+                    own[0] += v[0]; own[1] += v[1];
                 }
             }
-        }
-        // ---- partial sums through LDS: 16-byte pieces; wave `sl` of an item sums elements [sl epw, (sl + 1) epw) over the item's waves ----
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++)
-            *reinterpret_cast<f32x4w *>(xch + (size_t)((wave * 4 + qd) * 64 + lane) * 4) = (f32x4w){acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
-        __syncthreads();
-        {
-            const int epw = 16 / slices;                    // 4 (two items) or 2 (one)
             const osk::rsrc_t rdh = osk::make_rsrc(sa.dhx[y] + (size_t)(t > 0 ? t - 1 : 0) * B * H, t > 0 ? step_bytes : 0u);      // (t = 0: nobody reads dh_{-1})
             const osk::rsrc_t rdx = osk::make_rsrc(a.dx + (size_t)t * B * K, (uint32_t)B * (uint32_t)K * 4u);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k < epw) {
-                    const int e = sl * epw + k, row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    float v = 0.f;
-                    for (int w2 = item * slices; w2 < (item + 1) * slices; w2++) v += xch[(size_t)((w2 * 4 + (e >> 2)) * 64 + lane) * 4 + (e & 3)];
-                    if (is_h) {
-                        v += dh[row * HS + q * 32 + li];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdh, (uint32_t)(((size_t)(row0 + row) * H + q * 32 + li) * 4), 0u, 17);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdx, (uint32_t)(((size_t)(row0 + row) * K + q * 32 + li) * 4), 0u, 17);
-                    }
+            for (int k = 0; k < EPW; k++) {
+                // element e = sl EPW + k -> row (e & 3) + 8 (e >> 2) + 4 lh
+                const int row = EPW == 4 ? k + 8 * sl + 4 * lh : (2 * (sl & 1) + k) + 8 * (sl >> 1) + 4 * lh;
+                if (is_h) {
+                    const float v = own[k] + dh[row * HS + q * 32 + li];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdh, (uint32_t)(((size_t)(row0 + row) * H + q * 32 + li) * 4), 0u, 17);
+                } else {
+                    const float v = own[k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rdx, (uint32_t)(((size_t)(row0 + row) * K + q * 32 + li) * 4), 0u, 17);
                 }
             }
-        }
+        };
+        if (items == 2) mfma_reduce(std::integral_constant<int, 2>{});
+        else mfma_reduce(std::integral_constant<int, 1>{});
+        OSL_TS(4)                                               // partial sums, reduction, slice stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's slice stores (and its gate-derivative stores) are acknowledged
         __syncthreads();
         if (threadIdx.x == 0 && !(y == sa.drop_y && T - 1 - t >= sa.drop_step && sa.drop_step >= 0))
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(T - t), rf, own_off + (uint32_t)q * 4u, 0u, 17);
+        OSL_TS(5)                                               // acknowledgements (incl. the next step's prefetch), barrier, counter
     }
+#ifdef OS_LAYER_TS
+    if (tile == 0 && q == 0 && threadIdx.x == 0)
+        printf("bwd_sweep_wide_kernel row %d (0 = top) T=%d cycles per step (wave 0): wait + tile requests %llu | tiles + gate derivatives + barrier %llu | MFMA slice %llu | partials + reduction + stores %llu | acks + barrier + counter %llu | sum %llu\n",
+               y, T, ts_sum[1] / T, ts_sum[2] / T, ts_sum[3] / T, ts_sum[4] / T, ts_sum[5] / T, (ts_sum[1] + ts_sum[2] + ts_sum[3] + ts_sum[4] + ts_sum[5]) / T);
+#endif
 }
 
 struct SweepStackArgs {

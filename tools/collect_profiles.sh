@@ -105,5 +105,6 @@ tools/micro/mfma_bf16_rate > $O/mfma_bf16_rate.txt 2>&1
 # the small-batch kernels on four CUs per (layer, tile): against one CU per tile, phase timestamps, the batch-64 training step's kernels
 python3 tools/wide_probe.py 200 2>/dev/null | grep "^|" > $O/wide_probe.md
 bash tools/wide_ts.sh 2>&1 | grep "cycles per step" | sort | tail -4 > $O/wide_timestamps_raw.txt
+bash tools/wide_bwd_ts.sh 2>&1 | grep "cycles per step" | sort -u | tail -4 > $O/wide_bwd_timestamps_raw.txt
 stats train_B64 --mode train --batch 64 --steps 200 --warmup 20 --cpu-seconds 0
 ls $O
