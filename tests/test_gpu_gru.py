@@ -342,6 +342,11 @@ def test_wide_kernel_four_cus_per_layer_tile(monkeypatch, I, H, L, B, T):
             first = (out1.clone(), hl1.clone())
         assert torch.equal(out1, first[0]) and torch.equal(hl1, first[1]), rep
     assert (out1 - out0).abs().max().item() < 1e-6 and (hl1 - hl0).abs().max().item() < 2e-6
+    # the same kernel fed through its other input layout (os_gru_forward_soa: the [T][I][B] stream instead of the (B, T, I) tensor):
+    # only the staging of layer 0's tile differs, the numbers must not
+    out_soa = e1.gru_forward_soa(x.permute(1, 2, 0).contiguous())
+    torch.cuda.synchronize()
+    assert e1.kernel_name("gru_layer") == "gru_wide_kernel" and torch.equal(out_soa, out1)
     ref, _, _ = orc.gru_forward(x.cpu().numpy(), orc.flatten_state_dict(m.state_dict(), L), I, H, L, C)
     assert np.abs(out1.cpu().numpy() - ref).max() < GRU_TOL
 
