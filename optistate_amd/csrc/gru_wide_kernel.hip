@@ -10,11 +10,12 @@
 //   * per step the four groups exchange their 32-unit slices of h_t through a row-major [T][B][H] buffer (the training forward's saved
 //     h stream itself) with write-through stores and one progress counter per group; a group starts step t + 1 when the four counters of
 //     its layer say h_t is complete, and takes x_{t+1} = h^{l-1}_{t+1} when the four counters of the layer below say so;
-//   * the input half of the gate GEMM of step t + 1 needs only x_{t+1}, which the layer below published a stage earlier: it is computed
-//     BEHIND the publication of h_t, while the sibling groups' slices are still in flight, so the critical path of a step is
-//     wait -> 16 KB h tile -> 24 MFMAs per wave -> exchange of the partial sums -> cell update -> publish;
-//   * the partial sums cross LDS once: every wave keeps the two accumulator elements (rows) it owns and hands the other fourteen to their
-//     owners, so the cell update runs on all eight waves;
+//   * a step is: publish h_t -> wait for the lower layer's counters, x_{t+1} tile -> LDS, its A fragments -> registers -> wait for this
+//     layer's counters, request the h_t tile -> the INPUT half's MFMAs (36 / 24 per wave) while that tile travels -> h_t tile -> LDS ->
+//     the recurrent half's 24 MFMAs -> exchange of the partial sums -> cell update; layer 0's input depends on nothing in the launch and
+//     is requested a whole step ahead (the caller's (B, T, I) tensor is read in place, 16-byte pieces);
+//   * the partial sums cross LDS once, as 16-byte pieces in a buffer that ALIASES the two tiles (dead once every wave holds its A
+//     fragments); every wave sums and updates the two accumulator elements (rows) it owns, so the cell update runs on all eight waves;
 //   * block index -> (tile, layer, group) puts every workgroup of a tile on ONE XCD (blockIdx % 8), so counters and slices stay in
 //     that XCD's L2.
 // Every wait is bounded exactly as in gru_stack_kernel (error word, NaN poisoning, -20 from the call: launch.hpp), and the kernel needs
