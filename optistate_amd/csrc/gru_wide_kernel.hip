@@ -16,8 +16,8 @@
 //     is requested a whole step ahead (the caller's (B, T, I) tensor is read in place, 16-byte pieces);
 //   * the partial sums cross LDS once, as 16-byte pieces in a buffer that ALIASES the two tiles (dead once every wave holds its A
 //     fragments); every wave sums and updates the two accumulator elements (rows) it owns, so the cell update runs on all eight waves;
-//   * block index -> (tile, layer, group) puts every workgroup of a tile on ONE XCD (blockIdx % 8), so counters and slices stay in
-//     that XCD's L2.
+//   * block index -> (tile, layer, group) puts every workgroup of a tile on ONE XCD (blockIdx % 8): a placement choice only, the
+//     exchange goes through cache-bypassing accesses and does not depend on where a workgroup lands.
 // Every wait is bounded exactly as in gru_stack_kernel (error word, NaN poisoning, -20 from the call: launch.hpp), and the kernel needs
 // all its workgroups resident at once: 4 x layers x tiles <= CUs with at most 32 / (4 x layers) tiles per XCD (B <= 512 at four layers).
 // Same arithmetic as the other exact-fp32 layer kernels up to the order of the eight partial sums.
