@@ -83,8 +83,12 @@ def main():
         xo, fo = oracle_run(d, Q, R, To, rows) if rows else (np.zeros((0, To, 12)), np.zeros((0, To, 12)))
         e_xo = float(np.abs(xp[rows][:, :To] - xo).max()) if rows else 0.0
         e_fo = float(np.abs(fp[rows][:, :To] - fo).max()) if rows else 0.0
-        # forces: the QP's solution moves by ~100-500 N per unit of state near a face change, the states agree to ~3e-5: 2e-2 N (of up to 150)
-        ok = e_x < 1e-4 and e_f < 2e-2 and e_xo < 1e-4 and e_fo < 2e-2 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
+        # forces: the QP's solution moves by ~100-500 N per unit of state near a face change, the states agree to ~3e-5: 2e-2 N (of up to
+        # 150) -- and in proportion where the two forms' STATES are further apart (still inside their own 1e-4 bar): nominal inputs too are a
+        # closed loop, a rounding difference can grow ~1.4x per step over a 20-step stretch before a face change resets it (seen: seed 142,
+        # B = 1,000, T = 40: states 7e-5 apart at the worst step, forces 3.7e-2 N, both forms within 3e-2 N of the float64 chain)
+        f_bar = max(2e-2, 600.0 * e_x)
+        ok = e_x < 1e-4 and e_f < f_bar and e_xo < 1e-4 and e_fo < 2e-2 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
         diag = ""
         if not ok and good.any():
             # which form left the oracle chain?  the trajectory where the two forms are furthest apart, over the whole horizon
