@@ -17,7 +17,8 @@
 //   * the partial sums cross LDS once, as 16-byte pieces in a buffer that ALIASES the two tiles (dead once every wave holds its A
 //     fragments); every wave sums and updates the two accumulator elements (rows) it owns, so the cell update runs on all eight waves;
 //   * block index -> (tile, layer, group) puts every workgroup of a tile on ONE XCD (blockIdx % 8): a placement choice only, the
-//     exchange goes through cache-bypassing accesses and does not depend on where a workgroup lands.
+//     exchange goes through cache-bypassing accesses and does not depend on where a workgroup lands (measured with -DWD_SPREAD, a tile's
+//     groups on four different XCDs: 16.0 - 16.3 k cycles per step against 15.5 k).
 // Every wait is bounded exactly as in gru_stack_kernel (error word, NaN poisoning, -20 from the call: launch.hpp), and the kernel needs
 // all its workgroups resident at once: 4 x layers x tiles <= CUs with at most 32 / (4 x layers) tiles per XCD (B <= 512 at four layers).
 // Same arithmetic as the other exact-fp32 layer kernels up to the order of the eight partial sums.
@@ -80,8 +81,12 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
     // block -> (tile, layer, group): blockIdx % 8 = XCD = tile % 8; inside an XCD the slots run (tile / 8, layer, group)
+#ifdef WD_SPREAD      // development (tools/wide_ts.sh -DWD_SPREAD): consecutive blocks = the four groups of a (tile, layer), i.e. four different XCDs
+    const int q = blockIdx.x & 3, l = (int)(blockIdx.x >> 2) % a.n, tile = (int)(blockIdx.x >> 2) / a.n;
+#else
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = 4 * a.n;
     const int tile = (slot / per) * 8 + xcd, l = (slot % per) >> 2, q = slot & 3;
+#endif
     if (tile >= a.tiles) return;
     const int B = a.B, T = a.T, K = l == 0 ? a.K0 : WD_H, KPx = (K + 1) / 2, XS = 2 * KPx + 1;
     float *ht = smem, *xt = smem + 32 * WD_HS, *xch = smem;
