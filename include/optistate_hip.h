@@ -227,6 +227,15 @@ int os_gru_forward_windows(os_ctx *ctx, int32_t n_rows, int32_t window, const fl
  * it, and os_adam_step's kernel skips its update while it is set (the model is never stepped on poisoned gradients).
  * mode 0: a launch per layer, no progress counters. */
 int os_gru_set_stack(os_ctx *ctx, int32_t mode);
+/* The mode in force (the OS_GRU_STACK value os_create read, or the last os_gru_set_stack): 0 | 1 | 2; < 0: invalid context.  A host layer
+ * that switches modes temporarily (the trainer: 2 for its own step) restores THIS value, not a guess. */
+int os_gru_get_stack(const os_ctx *ctx);
+/* Mode 2's explicit verification point: if an asynchronous stacked launch has gone out on this context since the last check, waits for
+ * `stream` and returns -20 when the error word is set (cleared, the device twin too: the stream is drained), 0 otherwise; returns 0 at
+ * once, without waiting, when there was no such launch.  The trainer calls it once per step between the backward and the gradient
+ * all-reduce: a lost step is redone with a launch per layer BEFORE its gradients reach a collective or the optimiser
+ * (gru/gru_train.py:232-249), so no rank ever contributes a poisoned gradient. */
+int os_stack_check(os_ctx *ctx, void *stream);
 
 /* OPT-IN reduced precision for the GRU layer GEMMs at large batches (never the default; env OS_GRU_SPLIT_BF16 = 2 | 3 at os_create).
  * mode 0: exact fp32 (v_mfma_f32_32x32x2_f32).  mode 3 / 2: every fp32 operand of the gate GEMM of an H = 128 inference layer is
@@ -253,6 +262,14 @@ int os_gru_bands(os_ctx *ctx, int32_t B, int32_t n, const float *out, const floa
  * (N, 128) = (B, T, 128)) -> dst [T][F_total][B].  With row0 = 60, F_total = 60 + F this builds the OS_FUSED_LATENT_IN_PLACE input. */
 int os_pack_stream_rows(os_ctx *ctx, int32_t B, int32_t T, int32_t F, const float *src, float *dst, int32_t F_total, int32_t row0,
                         void *stream);
+
+/* The single fused kernel exists for five tile shapes -- trajectories per workgroup (= per CU): 256 | 128 (64 | 32 trajectories per
+ * wavefront, 32x32x2 MFMA), 64 (16 per wavefront, 16x16x4 MFMA), 32 | 16 (a 16-trajectory tile's hidden units split over 2 | 4
+ * wavefronts).  os_fused_run picks the shape that minimises rounds x measured cost for the batch (a shard of 8,192 trajectories of a
+ * 65,536 batch takes 32 per CU and still fills the chip); tile = 0 restores that choice, another value pins the shape (tests, sweeps;
+ * env OS_FUSED_TILE at os_create).  Shapes below 128 exist for one-layer models only; -2 for any other value.  Every shape computes
+ * the same exact-fp32 arithmetic on data_collection/data_conversion_Kalman_to_Training.py:193-199,245-254 + gru/gru_model.py:27-48. */
+int os_fused_set_tile(os_ctx *ctx, int32_t tile);
 
 int os_fused_run(os_ctx *ctx, int32_t B, int32_t T,
                  const float *p, const float *f, const float *dp, const float *imu, const uint32_t *contact,

@@ -38,6 +38,7 @@ EXPORTS = [
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
     "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows", "os_gru_backward_mark",
     "os_gru_forward_windows", "os_gru_bands", "os_gru_set_stack", "os_gru_set_split_bf16",
+    "os_gru_get_stack", "os_fused_set_tile", "os_stack_check",
 ]
 
 
@@ -108,6 +109,12 @@ def load():
     lib.os_gru_bands.restype = C.c_int
     lib.os_gru_set_stack.argtypes = [vp, i32]
     lib.os_gru_set_stack.restype = C.c_int
+    lib.os_gru_get_stack.argtypes = [vp]
+    lib.os_gru_get_stack.restype = C.c_int
+    lib.os_stack_check.argtypes = [vp, vp]
+    lib.os_stack_check.restype = C.c_int
+    lib.os_fused_set_tile.argtypes = [vp, i32]
+    lib.os_fused_set_tile.restype = C.c_int
     lib.os_gru_set_split_bf16.argtypes = [vp, i32]
     lib.os_gru_set_split_bf16.restype = C.c_int
     lib.os_fused_run.argtypes = [vp, i32, i32] + [f32p] * 8 + [i32, f32p] + [f32p] * 4 + [vp, u32, vp]

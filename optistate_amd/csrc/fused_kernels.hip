@@ -166,7 +166,11 @@ __global__ void fused_pack_kernel(const float *__restrict__ w0 /* layer 0, torch
 #define OSF_TS(i)
 #endif
 
-template <bool QDIAG, bool SEQOUT>
+// NRB = 32-trajectory column blocks per wave.  NRB = 2: a wave owns 64 trajectories, lane = trajectory (the layout above).  NRB = 1 (round 6,
+// batches that leave half the chip idle at 256 trajectories per CU): a wave owns 32 trajectories and BOTH lane halves run the filter
+// of trajectory wbase + (lane & 31) redundantly -- the B fragment of a k-pair is then one v_cndmask (lanes 0-31 take feature 2kp, lanes
+// 32-63 feature 2kp + 1) instead of a v_permlane32_swap, the GRU half is the rb = 0 passes alone, only lanes 0-31 store.
+template <bool QDIAG, bool SEQOUT, int NRB>
 __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -182,10 +186,10 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     __syncthreads();
     const float4 *mins4 = reinterpret_cast<const float4 *>(lds + 2 * CHF2);      // minima from LDS: 60 SGPRs would spill
 
-    const int wbase = blockIdx.x * 256 + (threadIdx.x & ~63);      // first trajectory of this wave
-    const int b = wbase + lane;
-    const bool live = b < k.B;
-    const int bb = live ? b : k.B - 1;                 // dead lanes shadow the last trajectory, stores masked
+    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * NRB);      // first trajectory of this wave
+    const int b = wbase + (NRB == 2 ? lane : li);
+    const bool live = b < k.B && (NRB == 2 || lh == 0);      // the lanes that store
+    const int bb = b < k.B ? b : k.B - 1;              // dead lanes shadow the last trajectory, stores masked
     const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
 
     f2 X[6];                       // the filter state as pairs (x[2i], x[2i+1])
@@ -202,9 +206,9 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     }
     // h_t of this wave's 64 trajectories: hreg[rb][c][e] = h[unit 32c + (e&3) + 8(e>>2) + 4 lh][trajectory wbase + 32 rb + li]
     // (AGPR-resident: agpr_put / agpr_get)
-    float hreg[2][2][16];
+    float hreg[NRB][2][16];
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++)
+    for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -251,12 +255,18 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                 const float4 mn = mins4[j0 / 4 + i4];
                 v[4 * i4] -= mn.x; v[4 * i4 + 1] -= mn.y; v[4 * i4 + 2] -= mn.z; v[4 * i4 + 3] -= mn.w;
             }
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
-                         "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\ts_nop 1"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                           "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+            if (NRB == 2) {
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+                             "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\ts_nop 1"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                               "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
 #pragma unroll
-            for (int i = 0; i < 12; i++) FA[j0 + i] = agpr_put(v[i]);
+                for (int i = 0; i < 12; i++) FA[j0 + i] = agpr_put(v[i]);
+            } else {
+                // both lane halves hold the same trajectory: the k-pair's fragment is a select on the lane half
+#pragma unroll
+                for (int i = 0; i < 12; i += 2) FA[j0 + i] = agpr_put(lh ? v[i + 1] : v[i]);
+            }
         };
         feat6(12, acl[0], acl[1], acl[2], acl[3], acl[4], acl[5], OSF_LEG(in.f, 0), OSF_LEG(in.f, 1), OSF_LEG(in.f, 2), OSF_LEG(in.f, 3), OSF_LEG(in.f, 4), OSF_LEG(in.f, 5));
         feat6(24, OSF_LEG(in.f, 6), OSF_LEG(in.f, 7), OSF_LEG(in.f, 8), OSF_LEG(in.f, 9), OSF_LEG(in.f, 10), OSF_LEG(in.f, 11), OSF_LEG(PW, 0), OSF_LEG(PW, 1), OSF_LEG(PW, 2), OSF_LEG(PW, 3), OSF_LEG(PW, 4), OSF_LEG(PW, 5));
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         // update reads them directly (the weight fragments are simply read from LDS again for each of the four passes).  Chunk
         // 0's new h waits in 16 spare AGPRs until chunk 1's MFMAs no longer need the old one.
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++) {
+        for (int rb = 0; rb < NRB; rb++) {
             float park[16];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -315,10 +325,11 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                         // AGPRs: every hreg keeps step t-1's value until the cell update of pass (0, 1).  At t = 0 the descriptor
                         // covers nothing; lanes past the batch use an offset no descriptor covers (no branch in the loop).
                         const int i0 = 2 * (q - 12), srb = i0 >> 5, sc = (i0 >> 4) & 1, se = i0 & 15;      // elements i0, i0 + 1: se even
-                        buf_store_agpr2(rs_prev, srb ? vo_seq1 : vo_seq0, (uint32_t)(32 * sc + (se & 3) + 8 * (se >> 2)) * rowB, hreg[srb][sc][se],
-                                        (uint32_t)(32 * sc + ((se + 1) & 3) + 8 * ((se + 1) >> 2)) * rowB, hreg[srb][sc][se + 1]);
+                        if (srb < NRB)
+                            buf_store_agpr2(rs_prev, srb ? vo_seq1 : vo_seq0, (uint32_t)(32 * sc + (se & 3) + 8 * (se >> 2)) * rowB, hreg[srb < NRB ? srb : 0][sc][se],
+                                            (uint32_t)(32 * sc + ((se + 1) & 3) + 8 * ((se + 1) >> 2)) * rowB, hreg[srb < NRB ? srb : 0][sc][se + 1]);
                     }
-                    if (rb == 1 && c == 1 && q == KPX) {
+                    if (rb == NRB - 1 && c == 1 && q == KPX) {
                         // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
                         const int tn = (t + 1 < k.T) ? t + 1 : t;
                         load_step_p(k, tn, voff, rowB, in);
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         // the last step's h
         const osk::rsrc_t rs = make_rsrc_uniform(a.seq_out + (size_t)(k.T - 1) * H * B, (uint32_t)H * rowB);
 #pragma unroll
-        for (int i = 0; i < 64; i += 2) {
+        for (int i = 0; i < 32 * NRB; i += 2) {
             const int srb = i >> 5, sc = (i >> 4) & 1, se = i & 15;
             buf_store_agpr2(rs, srb ? vo_seq1 : vo_seq0, (uint32_t)(32 * sc + (se & 3) + 8 * (se >> 2)) * rowB, hreg[srb][sc][se],
                             (uint32_t)(32 * sc + ((se + 1) & 3) + 8 * ((se + 1) >> 2)) * rowB, hreg[srb][sc][se + 1]);
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
     }
     if (!SEQOUT) {
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++) {
+        for (int rb = 0; rb < NRB; rb++) {
             const int tr = wbase + 32 * rb + li;
             if (tr < k.B) {
                 rsrc_t rs = make_rsrc(a.h_last, (uint32_t)H * rowB);
@@ -427,6 +438,320 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                         buf_store(rs, vo, (uint32_t)(32 * c + (e & 3) + 8 * (e >> 2)) * rowB, agpr_get(hreg[rb][c][e]));
             }
         }
+    }
+}
+
+// =====================================================================================================================
+// fused_kf_gru_kernel_v3<QDIAG, NSPLIT> (round 6) -- the same path for batches that cannot fill the chip with 32 trajectories per
+// wave: a 16-TRAJECTORY tile on v_mfma_f32_16x16x4_f32 (same flop rate as the 32x32x2 form: 8 passes for a quarter of the work).
+//
+// Lane l = (quarter q = l >> 4, trajectory lt = l & 15).  All four quarters run the filter of trajectory wbase + lt redundantly (the
+// filter's cost per wave does not depend on how many lanes carry distinct trajectories).  gates^T tile = 16 units x 16 trajectories:
+// A = weights (lane: unit row lt, k = q), B = activations (lane: k = q, trajectory lt), D: register v of lane l = unit 4 q + v of the
+// tile -- so, as in v2, the result registers ARE the B operand of a recurrent k-step whose four k values are the units
+// {16 ut + 4 q' + v : q' = 0..3}: h_t stays in 16 AGPRs.  The B fragment of a feature k-step (features 4 ks .. 4 ks + 3) is a select
+// over the quarter (three v_cndmask) minus the quarter's minimum.
+//   NSPLIT = 1: one wave per tile, all four unit tiles (372 MFMAs of 32 cycles per step), 64 trajectories per CU.
+//   NSPLIT = 2 / 4: the tile's hidden units are split over 2 / 4 waves of the workgroup (each on its own SIMD): every wave repeats the
+//     filter, computes 4 / NSPLIT unit tiles of the gates and their cell update, writes its slice of h_t to a parity-double-buffered
+//     LDS block and picks the other slices up behind ONE workgroup barrier placed in the middle of the NEXT step (after the filter
+//     and the feature k-steps: the waves' skew is absorbed there).  32 / 16 trajectories per CU.
+//   A wave keeps its own slice in hreg slots 0 .. UTW-1 and the others' behind it (slot s = unit tile (sw UTW + s) % 4): the image
+//   holds the recurrent fragments per wave position in that rotated k order, so every register index is a compile-time constant.
+// LDS: the image (31 k-steps x 4 unit tiles x 64 lanes x (r, z, n, -) floats + biases + minima = 128,256 B) + the exchange block.
+// =====================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int KS3X = KX / 4, KS3H = H / 4, KS3 = KS3X + KS3H;            // 15 feature + 16 recurrent k-steps
+constexpr int IMG3_W = KS3 * 4 * 256, IMG3_BIAS = IMG3_W, IMG3_MINS = IMG3_BIAS + 256, IMG3 = IMG3_MINS + 64;
+constexpr size_t LDS3_IMG_BYTES = (size_t)IMG3 * sizeof(float);
+template <int NSPLIT> constexpr size_t lds3_bytes() { return LDS3_IMG_BYTES + (NSPLIT > 1 ? (size_t)(4 / NSPLIT) * 2 * 4 * 64 * 16 : 0); }
+
+__global__ void fused_pack3_kernel(const float *__restrict__ w0 /* layer 0, torch layout */, const float *__restrict__ minmax,
+                                   float *__restrict__ img /* [IMG3] */, int nsplit)
+{
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float *Wih = w0, *Whh = Wih + 3 * H * KX, *bih = Whh + 3 * H * H, *bhh = bih + 3 * H;
+    const int utw = 4 / nsplit;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < IMG3_W; i += gridDim.x * blockDim.x) {
+        // [sw][ks][u][lane][4]
+        const int g = i & 3, lane = (i >> 2) & 63, grp = i >> 8;
+        const int u = grp % utw, ks = (grp / utw) % KS3, sw = grp / (utw * KS3);
+        const int lt = lane & 15, q = lane >> 4, ut = sw * utw + u;
+        float v = 0.f;
+        if (g < 3) {
+            const int row = g * H + 16 * ut + lt;
+            const float gs = g < 2 ? -LOG2E : 2.0f * LOG2E;
+            if (ks < KS3X) {
+                const int k = 4 * ks + q;
+                v = Wih[row * KX + k] * (1.0f / (minmax[KX + k] - minmax[k])) * gs;
+            } else {
+                const int kh = ks - KS3X, slot = kh >> 2, vv = kh & 3;
+                const int uin = 16 * ((sw * utw + slot) & 3) + 4 * q + vv;
+                v = Whh[row * H + uin] * gs;
+            }
+        }
+        img[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        // biases [q][ut][g4][v] of unit 16 ut + 4 q + v; minima
+        const int j = threadIdx.x, q = j >> 6, ut = (j >> 4) & 3, g4 = (j >> 2) & 3, vv = j & 3, u = 16 * ut + 4 * q + vv;
+        float v;
+        if (g4 == 0) v = (bih[u] + bhh[u]) * -LOG2E;
+        else if (g4 == 1) v = (bih[H + u] + bhh[H + u]) * -LOG2E;
+        else if (g4 == 2) v = bih[2 * H + u] * (2.0f * LOG2E);
+        else v = bhh[2 * H + u] * (2.0f * LOG2E);
+        img[IMG3_BIAS + j] = v;
+        if (j < 64) img[IMG3_MINS + j] = j < KX ? minmax[j] : 0.f;
+    }
+}
+
+// acc (4 VGPRs) += W-fragment (VGPR, from LDS) x B-fragment (AGPR); see mfma_va for the hazards inline assembly has to respect itself
+__device__ __forceinline__ void mfma16_va(f32x4 &acc, float w, float b_agpr)
+{
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_agpr));
+}
+
+template <bool QDIAG, int NSPLIT>
+__global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs a)
+{
+    constexpr int UTW = 4 / NSPLIT;            // unit tiles per wave
+    constexpr int TPW = 4 / NSPLIT;            // trajectory tiles per workgroup
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lt = lane & 15, q = lane >> 4;
+    const int sw = wave % NSPLIT, tw = wave / NSPLIT;
+    const KfRunArgs &k = a.kf;
+    const size_t B = (size_t)k.B;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.wpacked);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < IMG3 / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *minq = lds + IMG3_MINS + q;                                       // the quarter's minimum of k-step ks: minq[4 ks]
+    const float4 *Wq = reinterpret_cast<const float4 *>(lds) + (size_t)sw * (KS3 * UTW * 64) + lane;      // this wave position's fragments
+    const float4 *bias4 = reinterpret_cast<const float4 *>(lds + IMG3_BIAS) + q * 16 + sw * UTW * 4;
+    float4 *xch = reinterpret_cast<float4 *>(lds + IMG3) + (size_t)tw * (2 * 4 * 64) + lane;   // [tile][parity][unit tile][lane] x 16 B
+
+    const int wbase = (blockIdx.x * TPW + tw) * 16;                                // first trajectory of this wave's tile
+    const int b = wbase + lt;
+    const bool live = b < k.B && q == 0 && sw == 0;                                // the lanes that store
+    const int bb = b < k.B ? b : k.B - 1;
+    const uint32_t voff = (uint32_t)bb * 4u, rowB = (uint32_t)k.B * 4u;
+    const bool q1 = (q & 1) != 0, q2 = (q & 2) != 0;
+
+    f2 X[6];
+    f2 U[NU];
+    int status = 0;
+    float smin = 3.0e38f;
+    {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < 6; i++) X[i] = (f2){buf_load(rx, voff, 2 * i * rowB), buf_load(rx, voff, (2 * i + 1) * rowB)};
+        status = p0_asymmetry_status([&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
+        sym_load(U, [&](int e) { return buf_load(rP, voff, (uint32_t)e * rowB); });
+    }
+    // hreg[s][v] = h[unit 16 ((sw UTW + s) % 4) + 4 q + v][trajectory wbase + lt]  (AGPRs)
+    float hreg[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) hreg[s][v] = agpr_put(0.f);                    // h0 = 0 (gru/gru_model.py:27)
+
+    StepInP in;
+    float acl[6];
+    load_step_p(k, 0, voff, rowB, in);
+    {
+        rsrc_t ra = make_rsrc(k.accel, 6 * rowB);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
+    }
+
+    OSF_TS_DECL
+    for (int t = 0; t < k.T; t++) {
+        OSF_TS(0)
+        float z[NM], FA[KS3X];
+        f2 PW[2][3];
+        float g9[9];
+        status |= kf_step_inputs_sym(X, in, k.k, z, PW, g9);
+        __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(1)
+        // B fragment of feature k-step ks: the quarter's feature 4 ks + q minus its minimum (the 1/(max-min) scale sits in the weights)
+        auto feat4 = [&](int ks, float v0, float v1, float v2, float v3) {
+            const float lo = q1 ? v1 : v0, hi = q1 ? v3 : v2;
+            FA[ks] = agpr_put((q2 ? hi : lo) - minq[4 * ks]);
+        };
+        // feature order [x 0-11 | accel 12-17 | f 18-29 | p_world 30-41 | dp 42-53 | imu 54-59]
+        feat4(3, acl[0], acl[1], acl[2], acl[3]);
+        feat4(4, acl[4], acl[5], OSF_LEG(in.f, 0), OSF_LEG(in.f, 1));
+        feat4(5, OSF_LEG(in.f, 2), OSF_LEG(in.f, 3), OSF_LEG(in.f, 4), OSF_LEG(in.f, 5));
+        feat4(6, OSF_LEG(in.f, 6), OSF_LEG(in.f, 7), OSF_LEG(in.f, 8), OSF_LEG(in.f, 9));
+        feat4(7, OSF_LEG(in.f, 10), OSF_LEG(in.f, 11), OSF_LEG(PW, 0), OSF_LEG(PW, 1));
+        feat4(8, OSF_LEG(PW, 2), OSF_LEG(PW, 3), OSF_LEG(PW, 4), OSF_LEG(PW, 5));
+        feat4(9, OSF_LEG(PW, 6), OSF_LEG(PW, 7), OSF_LEG(PW, 8), OSF_LEG(PW, 9));
+        feat4(10, OSF_LEG(PW, 10), OSF_LEG(PW, 11), OSF_LEG(in.dp, 0), OSF_LEG(in.dp, 1));
+        feat4(11, OSF_LEG(in.dp, 2), OSF_LEG(in.dp, 3), OSF_LEG(in.dp, 4), OSF_LEG(in.dp, 5));
+        feat4(12, OSF_LEG(in.dp, 6), OSF_LEG(in.dp, 7), OSF_LEG(in.dp, 8), OSF_LEG(in.dp, 9));
+        feat4(13, OSF_LEG(in.dp, 10), OSF_LEG(in.dp, 11), in.imu[0], in.imu[1]);
+        feat4(14, in.imu[2], in.imu[3], in.imu[4], in.imu[5]);
+        __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(2)
+        cov_predict_sym_blk<QDIAG>(U, g9, k.k);
+        __builtin_amdgcn_sched_barrier(0);
+        OSF_TS(3)
+        smin = fminf(smin, update_sequential_sym(X, U, z, k.k));
+        feat4(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3));
+        feat4(1, OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7));
+        feat4(2, OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
+        OSF_TS(4)
+
+        // ================= GRU cell: UTW unit tiles x (r, z, gi_n, gh_n) accumulators of 4 registers =================
+        f32x4 acc[UTW][4];
+#pragma unroll
+        for (int u = 0; u < UTW; u++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 bv = bias4[u * 4 + g];
+                acc[u][g] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+            }
+        // groups gi = ks UTW + u: one ds_read_b128 (the three gates' fragments) and three MFMAs; fragments three groups deep, the read
+        // of group gi + 2 goes out behind the SECOND MFMA of group gi (its buffer was last read by group gi - 1: see mfma_va's note on
+        // when the matrix pipe reads its operands)
+        constexpr int NG = KS3 * UTW;
+        float4 wb[3];
+        wb[0] = Wq[0];
+        if (NG > 1) wb[1] = Wq[64];
+#pragma unroll
+        for (int ks = 0; ks < KS3; ks++)
+#pragma unroll
+        for (int u = 0; u < UTW; u++) {
+            const int gi = ks * UTW + u, cur = gi % 3, nx2 = (gi + 2) % 3;
+            if (gi == 2 * UTW) {
+                // x_out of this step (X does not change until the next step's filter phase); shadow lanes: an offset no descriptor covers
+                const uint32_t vst = live ? voff : 0x7ffffff0u;
+                rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+#pragma unroll
+                for (int i = 0; i < NS; i++) buf_store_nt(ro, vst, i * rowB, OSF_X(i));
+            }
+            if (NSPLIT > 1 && gi == KS3X * UTW && t > 0) {
+                // the other waves' slices of h_{t-1}: written at the end of step t - 1 into parity (t - 1) & 1
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const float4 *xr = xch + (size_t)((t - 1) & 1) * (4 * 64);
+#pragma unroll
+                for (int s = UTW; s < 4; s++) {
+                    const float4 hv = xr[((sw * UTW + s) & 3) * 64];
+                    hreg[s][0] = agpr_put(hv.x); hreg[s][1] = agpr_put(hv.y); hreg[s][2] = agpr_put(hv.z); hreg[s][3] = agpr_put(hv.w);
+                }
+            }
+            if (gi == (KS3X + 4) * UTW) {
+                // the next step's 49 input loads go out underneath the remaining MFMAs and the cell update
+                const int tn = (t + 1 < k.T) ? t + 1 : t;
+                load_step_p(k, tn, voff, rowB, in);
+                rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
+#pragma unroll
+                for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
+            }
+            const float bv = ks < KS3X ? FA[ks < KS3X ? ks : 0] : hreg[(ks >= KS3X ? ks - KS3X : 0) >> 2][(ks >= KS3X ? ks - KS3X : 0) & 3];
+            const int gn = ks < KS3X ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
+            mfma16_va(acc[u][0], wb[cur].x, bv);
+            mfma16_va(acc[u][1], wb[cur].y, bv);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 2 < NG) wb[nx2] = Wq[(gi + 2) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16_va(acc[u][gn], wb[cur].z, bv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        OSF_TS(5)
+        {
+            // 8-pass MFMA result -> VALU read (the 16-pass count of mfma_drain covers it)
+#pragma unroll
+            for (int u = 0; u < UTW; u++) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
+        }
+        // cell update on the accumulators (scales folded into the weights: sigmoid = rcp(1 + exp2(a))), stage by stage
+        {
+            const f2 one = {1.0f, 1.0f};
+            f2 R[UTW][2], Z[UTW][2], N[UTW][2], G[UTW][2];
+#pragma unroll
+            for (int u = 0; u < UTW; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) { acc[u][0][v] = __builtin_amdgcn_exp2f(acc[u][0][v]); acc[u][1][v] = __builtin_amdgcn_exp2f(acc[u][1][v]); }
+#pragma unroll
+            for (int u = 0; u < UTW; u++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) {
+                    R[u][p2] = (f2){acc[u][0][2 * p2], acc[u][0][2 * p2 + 1]} + one;
+                    Z[u][p2] = (f2){acc[u][1][2 * p2], acc[u][1][2 * p2 + 1]} + one;
+                }
+#pragma unroll
+            for (int u = 0; u < UTW; u++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) {
+                    R[u][p2] = (f2){__builtin_amdgcn_rcpf(R[u][p2][0]), __builtin_amdgcn_rcpf(R[u][p2][1])};
+                    Z[u][p2] = (f2){__builtin_amdgcn_rcpf(Z[u][p2][0]), __builtin_amdgcn_rcpf(Z[u][p2][1])};
+                }
+#pragma unroll
+            for (int u = 0; u < UTW; u++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) {
+                    const f2 gin = {acc[u][2][2 * p2], acc[u][2][2 * p2 + 1]}, ghn = {acc[u][3][2 * p2], acc[u][3][2 * p2 + 1]};
+                    N[u][p2] = fma2(R[u][p2], ghn, gin);                                  // gi_n + r gh_n (pre-scaled)
+                    N[u][p2] = (f2){__builtin_amdgcn_exp2f(N[u][p2][0]), __builtin_amdgcn_exp2f(N[u][p2][1])} + one;
+                }
+#pragma unroll
+            for (int u = 0; u < UTW; u++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) {
+                    N[u][p2] = (f2){__builtin_amdgcn_rcpf(N[u][p2][0]), __builtin_amdgcn_rcpf(N[u][p2][1])};
+                    N[u][p2] = fma2((f2){-2.0f, -2.0f}, N[u][p2], one);                    // n = tanh(.)
+                    G[u][p2] = (f2){agpr_get(hreg[u][2 * p2]), agpr_get(hreg[u][2 * p2 + 1])};   // h_{t-1} of the wave's own units
+                    G[u][p2] = fma2(Z[u][p2], G[u][p2] - N[u][p2], N[u][p2]);             // (1 - z) n + z h
+                }
+            if (NSPLIT > 1) {
+                float4 *xw = xch + (size_t)(t & 1) * (4 * 64);
+#pragma unroll
+                for (int u = 0; u < UTW; u++) xw[(sw * UTW + u) * 64] = make_float4(G[u][0][0], G[u][0][1], G[u][1][0], G[u][1][1]);
+            }
+#pragma unroll
+            for (int u = 0; u < UTW; u++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) { hreg[u][2 * p2] = agpr_put(G[u][p2][0]); hreg[u][2 * p2 + 1] = agpr_put(G[u][p2][1]); }
+        }
+        OSF_TS(6)
+    }
+#ifdef OS_FUSED_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("fused_v3<NSPLIT=%d> cycles per step: inputs %llu | features %llu | predict %llu | update %llu | mfma %llu | cell %llu\n", NSPLIT,
+               ts_sum[1] / k.T, ts_sum[2] / k.T, ts_sum[3] / k.T, ts_sum[4] / k.T, ts_sum[5] / k.T, ts_sum[6] / k.T);
+#endif
+    status |= singular_status(smin) | finite_status_p(X);
+    if (live) {
+        rsrc_t rx = make_rsrc(k.x, 12 * rowB), rP = make_rsrc(k.P, 144 * rowB);
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf_store(rx, voff, i * rowB, OSF_X(i));
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) buf_store(rP, voff, (i * NS + j) * rowB, OSK_SYM(U, i, j));
+        k.status[b] = status;
+    }
+    if (NSPLIT > 1) {
+        // h_T of the other waves' units (the loop picks a step's slices up in the NEXT step)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float4 *xr = xch + (size_t)((k.T - 1) & 1) * (4 * 64);
+#pragma unroll
+        for (int s = UTW; s < 4; s++) {
+            const float4 hv = xr[((sw * UTW + s) & 3) * 64];
+            hreg[s][0] = agpr_put(hv.x); hreg[s][1] = agpr_put(hv.y); hreg[s][2] = agpr_put(hv.z); hreg[s][3] = agpr_put(hv.w);
+        }
+    }
+    if (sw == 0 && b < k.B) {
+        // h_T [64][B] for the head launch: wave position 0 holds unit tile s in slot s
+        rsrc_t rs = make_rsrc(a.h_last, (uint32_t)H * rowB);
+        const uint32_t vo = (uint32_t)b * 4u + (uint32_t)(4 * q) * rowB;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) buf_store(rs, vo, (uint32_t)(16 * s + v) * rowB, agpr_get(hreg[s][v]));
     }
 }
 
@@ -759,6 +1084,15 @@ int os_gru_head_launch(os_ctx *ctx, int B, const float *top, const float *fcw, f
 
 extern "C" {
 
+int os_fused_set_tile(os_ctx *ctx, int32_t tile)
+{
+    OS_CHECK_CTX(ctx);
+    if (tile != 0 && tile != 256 && tile != 128 && tile != 64 && tile != 32 && tile != 16)
+        return os_fail(ctx, -2, "os_fused_set_tile: 0 (automatic) or 256 | 128 | 64 | 32 | 16 trajectories per workgroup");
+    ctx->tune_fused_tile = tile;
+    return 0;
+}
+
 int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *f, const float *dp, const float *imu,
                  const uint32_t *contact, const float *accel, const float *body_ref, const float *latent,
                  int32_t n_latent, const float *minmax, float *x, float *P, float *x_out, float *out, int32_t *status,
@@ -781,13 +1115,32 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
     a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = nullptr; a.ptrace_out = nullptr; a.kgain_out = nullptr;
     a.status = status; a.accel = accel; a.minmax = minmax; a.feat_out = nullptr; a.feat_I = I;
 
-    // The single kernel puts 256 trajectories on a CU and takes ~27 us per time step whatever the batch; below a third of a
-    // chip of workgroups the two-kernel path (Kalman kernel + layer kernel) is faster (measured, T = 100, ms two-kernel vs
-    // single: B = 8192 1.49 / 2.66, B = 16384 2.45 / 2.69, B = 32768 3.15 / 2.75, B = 65536 4.4 / 2.69): crossover ~80 per CU.
+    // Round 6: the single kernel exists for five tile shapes (trajectories per workgroup of four waves = per CU: the LDS image allows
+    // one workgroup per CU): 256 / 128 (v2: 64 / 32 per wave, 32x32x2 MFMA), 64 (v3: 16 per wave, 16x16x4 MFMA), 32 / 16 (v3 with the
+    // tile's hidden units split over 2 / 4 waves).  A workgroup's time per step does not depend on the batch, so the shape is chosen
+    // to minimise rounds x cost with the measured cycles per step below (profiles/r06_shard_sweep.md); the two-kernel path (Kalman
+    // kernel + layer kernel) remains for shapes the single kernel does not cover and behind OS_FUSED_TWO_KERNEL.
     const bool shapes_ok = (flags & OS_KF_SEQUENTIAL_UPDATE) && (flags & OS_KF_SYMMETRIC_P) && !(flags & OS_KF_DENSE_FD) &&
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
-    const bool single_kernel = shapes_ok && !(flags & OS_FUSED_TWO_KERNEL) &&
-                               ((flags & OS_FUSED_ONE_KERNEL) || B > 80 * ctx->cu_count);
+    int tile = 0;                      // trajectories per workgroup, 0 = two-kernel path
+    if (shapes_ok && !(flags & OS_FUSED_TWO_KERNEL)) {
+        static const struct { int tpw; float cost; } shapes[5] = {{256, 60.7f}, {128, 33.5f}, {64, 19.7f}, {32, 14.0f}, {16, 10.5f}};
+        const int nshape = d.num_layers > 1 ? 2 : 5;          // the v3 shapes have no layer-0 sequence output
+        float best = 0.f;
+        for (int i = 0; i < nshape; i++) {
+            const int nwg = (B + shapes[i].tpw - 1) / shapes[i].tpw, rounds = (nwg + ctx->cu_count - 1) / ctx->cu_count;
+            const float c = rounds * shapes[i].cost;
+            if (!tile || c < best) { tile = shapes[i].tpw; best = c; }
+        }
+        if (ctx->tune_fused_tile > 0) {
+            const int want = ctx->tune_fused_tile;
+            if (want == 256 || want == 128 || (d.num_layers == 1 && (want == 64 || want == 32 || want == 16))) tile = want;
+        }
+        // B <= 80 CUs used to go to the two-kernel path (round 5 and before); the small tiles are faster there now, but a deeper stack
+        // at a small batch still prefers its layer kernels' own input handling unless the caller insists
+        if (d.num_layers > 1 && !(flags & OS_FUSED_ONE_KERNEL) && ctx->tune_fused_tile <= 0 && B <= 80 * ctx->cu_count) tile = 0;
+    }
+    const bool single_kernel = tile != 0;
     if (flags & (OS_FUSED_SPLIT_BF16 | OS_FUSED_SPLIT_BF16_2)) {
         // opt-in reduced-precision gate GEMM (never chosen by default): bf16 split terms on the bf16 MFMA, fp32 accumulate
         if (!shapes_ok || d.num_layers != 1)
@@ -825,7 +1178,7 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
         return os_gru_head_launch(ctx, B, hlast, fcw, out, s);
     }
     if (single_kernel) {
-        // v2: transposed GRU cell, h in registers, scales folded into a per-call LDS image, head as a trailing launch
+        // transposed GRU cell, h in registers, scales folded into a per-call LDS image, head as a trailing launch
         osf::FusedArgs fa;
         fa.kf = a; fa.kf.k = ctx->k;
         fa.fcw = nullptr; fa.fcb = nullptr; fa.C = d.num_classes; fa.use_sigmoid = d.use_sigmoid; fa.out = out;
@@ -833,24 +1186,55 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
         if (os_gru_scratch(ctx, B, T, &seq0, &seq1, &hlast)) return -10;
         fa.seq_out = d.num_layers > 1 ? seq0 : nullptr;
         fa.h_last = d.num_layers > 1 ? nullptr : hlast;
-        if (!ctx->fused2_attr_set) {
-            const void *fns[4] = {(const void *)osf::fused_kf_gru_kernel_v2<true, false>, (const void *)osf::fused_kf_gru_kernel_v2<false, false>,
-                                  (const void *)osf::fused_kf_gru_kernel_v2<true, true>, (const void *)osf::fused_kf_gru_kernel_v2<false, true>};
-            for (const void *fn : fns)
-                OS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS2_BYTES));
-            ctx->fused2_attr_set = true;
+        fa.nrm = nullptr;
+        const bool qd = ctx->q_is_diagonal, so = d.num_layers > 1;
+        dim3 grid((B + tile - 1) / tile), block(256);
+        if (tile >= 128) {
+            if (!ctx->fused2_attr_set) {
+                const void *fns[8] = {(const void *)osf::fused_kf_gru_kernel_v2<true, false, 2>, (const void *)osf::fused_kf_gru_kernel_v2<false, false, 2>,
+                                      (const void *)osf::fused_kf_gru_kernel_v2<true, true, 2>, (const void *)osf::fused_kf_gru_kernel_v2<false, true, 2>,
+                                      (const void *)osf::fused_kf_gru_kernel_v2<true, false, 1>, (const void *)osf::fused_kf_gru_kernel_v2<false, false, 1>,
+                                      (const void *)osf::fused_kf_gru_kernel_v2<true, true, 1>, (const void *)osf::fused_kf_gru_kernel_v2<false, true, 1>};
+                for (const void *fn : fns)
+                    OS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::LDS2_BYTES));
+                ctx->fused2_attr_set = true;
+            }
+            if (!ctx->fused_img) OS_HIP(ctx, hipMalloc((void **)&ctx->fused_img, osf::LDS2_BYTES));
+            hipLaunchKernelGGL(osf::fused_pack_kernel, dim3(32), dim3(256), 0, s, ctx->gru_flat, minmax, ctx->fused_img);
+            fa.wpacked = ctx->fused_img;
+            const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, tile == 256 ? "fused_kf_gru_kernel_v2" : "fused_kf_gru_kernel_v2<32 per wave>");
+#define OSF_LAUNCH2(QD, SO, NRB) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<QD, SO, NRB>), grid, block, osf::LDS2_BYTES, s, fa)
+            if (tile == 256) {
+                if (qd && !so) OSF_LAUNCH2(true, false, 2); else if (qd) OSF_LAUNCH2(true, true, 2);
+                else if (!so) OSF_LAUNCH2(false, false, 2); else OSF_LAUNCH2(false, true, 2);
+            } else {
+                if (qd && !so) OSF_LAUNCH2(true, false, 1); else if (qd) OSF_LAUNCH2(true, true, 1);
+                else if (!so) OSF_LAUNCH2(false, false, 1); else OSF_LAUNCH2(false, true, 1);
+            }
+#undef OSF_LAUNCH2
+            os_prof_end(ctx, slot, s);
+        } else {
+            const int nsplit = 64 / tile;          // 1, 2, 4 waves per 16-trajectory tile
+            if (!ctx->fused3_attr_set) {
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel_v3<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::lds3_bytes<1>()));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel_v3<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::lds3_bytes<1>()));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel_v3<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::lds3_bytes<2>()));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel_v3<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::lds3_bytes<2>()));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel_v3<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::lds3_bytes<4>()));
+                OS_HIP(ctx, hipFuncSetAttribute((const void *)osf::fused_kf_gru_kernel_v3<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osf::lds3_bytes<4>()));
+                ctx->fused3_attr_set = true;
+            }
+            if (!ctx->fused_img3) OS_HIP(ctx, hipMalloc((void **)&ctx->fused_img3, osf::LDS3_IMG_BYTES));
+            hipLaunchKernelGGL(osf::fused_pack3_kernel, dim3(32), dim3(256), 0, s, ctx->gru_flat, minmax, ctx->fused_img3, nsplit);
+            fa.wpacked = ctx->fused_img3;
+            const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, nsplit == 1 ? "fused_kf_gru_kernel_v3<1>" : nsplit == 2 ? "fused_kf_gru_kernel_v3<2>" : "fused_kf_gru_kernel_v3<4>");
+#define OSF_LAUNCH3(QD, NSP) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v3<QD, NSP>), grid, block, osf::lds3_bytes<NSP>(), s, fa)
+            if (nsplit == 1) { if (qd) OSF_LAUNCH3(true, 1); else OSF_LAUNCH3(false, 1); }
+            else if (nsplit == 2) { if (qd) OSF_LAUNCH3(true, 2); else OSF_LAUNCH3(false, 2); }
+            else { if (qd) OSF_LAUNCH3(true, 4); else OSF_LAUNCH3(false, 4); }
+#undef OSF_LAUNCH3
+            os_prof_end(ctx, slot, s);
         }
-        if (!ctx->fused_img) OS_HIP(ctx, hipMalloc((void **)&ctx->fused_img, osf::LDS2_BYTES));
-        hipLaunchKernelGGL(osf::fused_pack_kernel, dim3(32), dim3(256), 0, s, ctx->gru_flat, minmax, ctx->fused_img);
-        fa.wpacked = ctx->fused_img; fa.nrm = nullptr;
-        dim3 grid((B + 255) / 256), block(256);
-        const int slot = os_prof_begin(ctx, OS_PHASE_FUSED, s, "fused_kf_gru_kernel_v2");
-        const bool so = d.num_layers > 1;
-        if (ctx->q_is_diagonal && !so) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<true, false>), grid, block, osf::LDS2_BYTES, s, fa);
-        else if (ctx->q_is_diagonal) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<true, true>), grid, block, osf::LDS2_BYTES, s, fa);
-        else if (!so) hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<false, false>), grid, block, osf::LDS2_BYTES, s, fa);
-        else hipLaunchKernelGGL((osf::fused_kf_gru_kernel_v2<false, true>), grid, block, osf::LDS2_BYTES, s, fa);
-        os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
         if (d.num_layers > 1) return os_gru_layers_impl(ctx, B, T, seq0, 1, out, nullptr, s);
         const float *fcw = ctx->gru_flat + (os_gru_param_count(&d) - ((size_t)d.num_classes * 64 + d.num_classes));

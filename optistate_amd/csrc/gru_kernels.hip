@@ -1694,10 +1694,11 @@ int os_gru_launch_stack(os_ctx *ctx, const LayerArgs *layers, int n, hipStream_t
 // os_stack_pending at the entry of the next os_gru_* call, and adam_kernel keeps the weights unchanged while it is set.
 int os_stack_verify(os_ctx *ctx, hipStream_t s, const char *what)
 {
-    if (ctx->tune_gru_stack == 1) OS_HIP(ctx, hipStreamSynchronize(s));
-    if (ctx->tune_gru_stack == 1 && *(volatile int32_t *)ctx->stack_err_host) {
+    if (ctx->tune_gru_stack != 1) { ctx->stack_dirty = true; return 0; }      // asynchronous: os_stack_check / os_stack_pending look later
+    OS_HIP(ctx, hipStreamSynchronize(s));
+    if (*(volatile int32_t *)ctx->stack_err_host) {
         *(volatile int32_t *)ctx->stack_err_host = 0;
-        (void)hipMemsetAsync(ctx->stack_err_local, 0, sizeof(int32_t), s);
+        (void)hipMemsetAsync(ctx->stack_err_local, 0, sizeof(int32_t), s);      // (the stream is drained: nothing queued reads the twin)
         char msg[256];
         snprintf(msg, sizeof(msg), "%s: a layer's bounded wait for the layer before it expired (progress-counter pipeline); outputs are NaN-poisoned -- "
                  "re-run with a launch per layer (os_gru_set_stack(ctx, 0) / OS_GRU_STACK=0)", what);
@@ -1705,15 +1706,35 @@ int os_stack_verify(os_ctx *ctx, hipStream_t s, const char *what)
     }
     return 0;
 }
+// Entry of later calls (mode 2).  The device twin is what a queued adam_kernel reads: it may only be cleared once everything enqueued
+// behind the lost producer has run, on WHATEVER stream (a caller's non-blocking stream does not order against the null stream), so
+// the report path drains the device first.  An error path: the cost does not matter.
 int os_stack_pending(os_ctx *ctx, const char *what)
 {
     if (*(volatile int32_t *)ctx->stack_err_host) {
+        (void)hipDeviceSynchronize();
         *(volatile int32_t *)ctx->stack_err_host = 0;
-        (void)hipMemset(ctx->stack_err_local, 0, sizeof(int32_t));      // (synchronous: whatever was enqueued behind the lost producer has run)
+        (void)hipMemset(ctx->stack_err_local, 0, sizeof(int32_t));
+        ctx->stack_dirty = false;
         char msg[256];
         snprintf(msg, sizeof(msg), "%s: an EARLIER stacked launch on this context lost a producer (its outputs were NaN-poisoned, optimiser steps behind it "
                  "were skipped): re-run that work with os_gru_set_stack(ctx, 0)", what);
         return os_fail(ctx, -20, msg);
+    }
+    return 0;
+}
+extern "C" int os_stack_check(os_ctx *ctx, void *stream)
+{
+    OS_CHECK_CTX(ctx);
+    if (!ctx->stack_dirty) return 0;                       // no asynchronous stacked launch since the last check: nothing to wait for
+    OS_HIP(ctx, hipSetDevice(ctx->device));
+    OS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    ctx->stack_dirty = false;
+    if (*(volatile int32_t *)ctx->stack_err_host) {
+        *(volatile int32_t *)ctx->stack_err_host = 0;
+        (void)hipMemsetAsync(ctx->stack_err_local, 0, sizeof(int32_t), (hipStream_t)stream);
+        return os_fail(ctx, -20, "os_stack_check: a stacked launch since the last check lost a producer; what it and the launches behind it wrote is "
+                                 "NaN-poisoned -- redo that work with os_gru_set_stack(ctx, 0)");
     }
     return 0;
 }
@@ -1887,6 +1908,7 @@ extern "C" {
 int os_gru_forward_soa(os_ctx *ctx, int32_t B, int32_t T, const float *xs, float *out, float *h_last_all, void *stream)
 {
     OS_CHECK_CTX(ctx);
+    if (int rcp = os_stack_pending(ctx, "os_gru_forward_soa")) return rcp;
     if (!ctx->gru_loaded) return os_fail(ctx, -5, "os_gru_forward: call os_gru_load first");
     if (B <= 0 || T <= 0 || !xs || !out) return os_fail(ctx, -2, "os_gru_forward: bad argument");
     OS_HIP(ctx, hipSetDevice(ctx->device));
@@ -1948,6 +1970,7 @@ int os_gru_set_stack(os_ctx *ctx, int32_t mode)
     ctx->tune_gru_stack = mode;
     return 0;
 }
+int os_gru_get_stack(const os_ctx *ctx) { return (ctx && ctx->magic == OS_MAGIC) ? ctx->tune_gru_stack : -1; }
 
 int os_gru_forward_windows(os_ctx *ctx, int32_t N, int32_t W, const float *rows, float *out, void *stream)
 {

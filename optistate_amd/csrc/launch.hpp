@@ -37,6 +37,7 @@ struct os_ctx {
     int32_t *stack_err_host, *stack_err_dev;
     int32_t *stack_err_local;            // the same bit in DEVICE memory: what adam_kernel polls (422 k threads reading a word of host
                                          // memory over PCIe doubled the batch-64 training step); cleared on the stream when the error is reported
+    bool stack_dirty;                    // mode 2: a stacked launch has gone out since the last os_stack_check / report
     uint32_t stack_max_polls;            // OS_STACK_DBG_POLLS (development / tests): polls before a wait gives up (default 2^22: seconds)
     int stack_dbg_drop_layer, stack_dbg_drop_step;   // OS_STACK_DBG_DROP="layer,step" (tests): that workgroup row stops publishing from that step on
     int tune_dw_dbg;                     // development: Dw3Args.dbg (OS_DW_DBG)
@@ -82,7 +83,10 @@ struct os_ctx {
     bool gi_attr_set;
     float *nrm;                               // fused path: [min | 1/(max-min)] (120 floats)
     float *fused_img;                         // fused v2: per-call LDS image (weights with folded scales, k order of the register-resident h)
-    bool fused2_attr_set, fusedbf_attr_set;
+    bool fused2_attr_set, fusedbf_attr_set, fused3_attr_set;
+    float *fused_img3;                        // fused v3 (16-trajectory tiles): its LDS image
+    int tune_fused_tile;                      // OS_FUSED_TILE (development / sweeps): trajectories per workgroup of the single fused kernel
+                                              // (256 | 128 | 64 | 32 | 16), 0 = chosen from the batch
     float *fused_img_bf;                      // LDS image of the opt-in split-bf16 kernel
     float *feat;     size_t feat_floats;      // fused path v0: normalised feature rows [T][I][B]
     int cu_count;

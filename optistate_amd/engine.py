@@ -54,6 +54,8 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"os_create failed with code {rc} (is this an MI355X / gfx950?)")
         self._h = h
+        self._stack_mode = int(self.lib.os_gru_get_stack(h))      # what os_create read from OS_GRU_STACK (default 1)
+        self.stack_fallbacks = 0
         self._gru_dims = None
         self._gru_flat = None      # keeps the flat weight tensor alive (the library references it for the head)
         self._gru_owner = None     # who loaded the resident GRU weights (a context holds ONE model: see load_gru)
@@ -89,6 +91,11 @@ class Engine:
         self._check(self.lib.os_gru_set_stack(self._h, int(mode)), "os_gru_set_stack")
         self._stack_mode = int(mode)
 
+    def set_fused_tile(self, tile):
+        """Pins the single fused kernel's tile shape (trajectories per workgroup: 256 | 128 | 64 | 32 | 16), 0 = chosen from the batch
+        (os_fused_set_tile in include/optistate_hip.h)."""
+        self._check(self.lib.os_fused_set_tile(self._h, int(tile)), "os_fused_set_tile")
+
     def set_gru_split_bf16(self, terms, any_batch=False):
         """OPT-IN reduced precision for the GRU layer GEMMs (never the default; the reference computes them in fp32,
         gru/gru_model.py:12): 0 = exact fp32; 3 / 2 = every operand of an H = 128 inference layer's gate GEMM split into that many bf16
@@ -97,19 +104,33 @@ class Engine:
         self._check(self.lib.os_gru_set_split_bf16(self._h, int(terms) | (_capi.OS_GRU_SPLIT_ANY_BATCH if any_batch else 0)), "os_gru_set_split_bf16")
 
     def _stack_guarded(self, call):
-        """Runs call(); when a layer-pipelined launch reports a lost producer (StackLost: the library's bounded wait expired -- the
-        producer workgroup never became resident, or another process held its CUs for seconds), runs it again with a launch per
-        layer.  The GRU entry points are idempotent (outputs and the flat gradient are overwritten), so the retry is exact."""
+        """Runs call(); in VERIFIED mode (1) a StackLost belongs to the launch this very call made (the library waited for it: the
+        producer workgroup never became resident, or another process held its CUs for seconds), so the call is run again with a launch
+        per layer -- the GRU entry points are idempotent (outputs and the flat gradient are overwritten), the retry is exact.  In
+        asynchronous mode (2) a StackLost reported at a call's entry refers to an EARLIER launch whose poisoned outputs this call
+        would consume: it is not caught here -- whoever chose mode 2 redoes that work (DataParallelTrainer.step does, through
+        stack_check)."""
         try:
             return call()
         except StackLost:
-            prev = getattr(self, "_stack_mode", None)
+            if self._stack_mode != 1:
+                raise
             self.lib.os_gru_set_stack(self._h, 0)
-            self.stack_fallbacks = getattr(self, "stack_fallbacks", 0) + 1
+            self.stack_fallbacks += 1
             try:
                 return call()
             finally:
-                self.lib.os_gru_set_stack(self._h, 1 if prev is None else prev)
+                self.lib.os_gru_set_stack(self._h, 1)
+
+    def stack_check(self):
+        """Mode 2's verification point (os_stack_check): True when an asynchronous stacked launch since the last check lost a producer
+        (the error word is cleared; what those launches wrote is NaN-poisoned and must be redone with set_stack_mode(0)).  Waits for the
+        stream only if such a launch went out at all."""
+        rc = self.lib.os_stack_check(self._h, self._stream())
+        if rc == _capi.OS_ERR_STACK_LOST:
+            return True
+        self._check(rc, "os_stack_check")
+        return False
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -216,6 +216,7 @@ class DataParallelTrainer:
         self.m = torch.zeros_like(self.bucket.w)
         self.v = torch.zeros_like(self.bucket.w)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.lost_steps = 0                                  # steps redone with a launch per layer after a lost producer (step())
         # force_distributed: run the collectives on a one-rank group too (tests and bench.py --force-dist price the machinery)
         self.force = bool(force_distributed) or split_allreduce == "force"
         self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force)
@@ -253,21 +254,23 @@ class DataParallelTrainer:
     def step(self, x, y):
         e = self.eng
         with e.lock:                                       # the whole step: the context's loaded weights and scratch are this trainer's
-            # Small batches run their layers as progress-counter launches.  The trainer keeps them asynchronous (os_gru_set_stack 2): a
-            # lost producer is reported by the next library call, and until then the fused Adam's kernel skips its update, so the model
-            # is never stepped on poisoned gradients -- no stream synchronise inside the step (verified mode: +6 % at batch 64).
-            prev = getattr(e, "_stack_mode", 1)
+            # Small batches run their layers as progress-counter launches.  The trainer keeps them asynchronous inside the step
+            # (os_gru_set_stack 2: no stream synchronise per launch) and verifies ONCE, between the backward and the all-reduce
+            # (stack_check: waits only if a stacked launch went out at all).  A lost producer means this rank's forward / backward
+            # wrote NaN: the step's forward, loss and backward are redone with a launch per layer BEFORE anything reaches the
+            # collective or the optimiser, so no rank ever contributes a poisoned gradient and the replicas cannot diverge
+            # (the per-call retry of mode 1 is wrong here, and a local-only Adam skip is wrong with world > 1).
+            prev = e._stack_mode                           # the mode in force (os_create's OS_GRU_STACK or the last set_stack_mode)
             if prev == 1:
                 e.set_stack_mode(2)
             try:
                 return self._step(x, y)
             finally:
-                if prev == 1:
-                    e.set_stack_mode(1)
+                if e._stack_mode != prev:
+                    e.set_stack_mode(prev)                 # exactly what was there: a user's OS_GRU_STACK=0 / 2 stays
 
-    def _step(self, x, y):
+    def _fwd_bwd(self, x, y):
         m, e = self.model, self.eng
-        e.load_gru(self.bucket.w, m.input_size, m.hidden_size, m.num_layers, m.num_classes, m.use_sigmoid, owner=self)
         out = e.gru_forward_train(x)
         loss, dout, _ = e.gru_loss(out, y)
         if self.split is not None:
@@ -275,6 +278,22 @@ class DataParallelTrainer:
         e.gru_backward(x, out, dout, grad_flat=self.bucket.g)
         if self.split is not None:
             e.gru_backward_mark(0, None)
+        return loss
+
+    def _step(self, x, y):
+        m, e = self.model, self.eng
+        e.load_gru(self.bucket.w, m.input_size, m.hidden_size, m.num_layers, m.num_classes, m.use_sigmoid, owner=self)
+        loss = self._fwd_bwd(x, y)
+        if e.stack_check():
+            # this step's stacked launches lost a producer: nothing has been applied or sent yet -- redo it with a launch per layer
+            mode = e._stack_mode
+            e.set_stack_mode(0)
+            try:
+                loss = self._fwd_bwd(x, y)
+            finally:
+                e.set_stack_mode(mode)
+            self.lost_steps += 1
+            e.stack_fallbacks += 1
         if self.split is None:
             self.bucket.allreduce_weighted_(x.shape[0], self.group, force=self.force)  # equal shards: the plain mean; ragged: weighted by size
         else:

@@ -50,14 +50,18 @@ def test_slice_and_permutation_independence(setup):
     idx = torch.arange(12288, 12288 + 4096, device="cuda")                          # 16 whole workgroups
     s = _slice(d, idx)
     xs, Ps = s["x0"].clone(), s["P0"].clone()
-    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], s["contact_p"], s["accel"], mm, xs, Ps, two_kernel=False)   # same (single) kernel as the full batch
-    assert torch.equal(r["x_out"], full["x_out"][:, :, idx])
-    assert torch.equal(r["out"], full["out"][idx])
-    assert torch.equal(Ps, P[:, idx])
-    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))[:8192]
-    s = _slice(d, perm)
-    xs, Ps = s["x0"].clone(), s["P0"].clone()
-    r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], s["contact_p"], s["accel"], mm, xs, Ps, two_kernel=False)   # same (single) kernel as the full batch
+    eng.set_fused_tile(256)                                                         # the same kernel (tile shape) as the full batch
+    try:
+        r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], s["contact_p"], s["accel"], mm, xs, Ps, two_kernel=False)
+        assert torch.equal(r["x_out"], full["x_out"][:, :, idx])
+        assert torch.equal(r["out"], full["out"][idx])
+        assert torch.equal(Ps, P[:, idx])
+        perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))[:8192]
+        s = _slice(d, perm)
+        xs, Ps = s["x0"].clone(), s["P0"].clone()
+        r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], s["contact_p"], s["accel"], mm, xs, Ps, two_kernel=False)
+    finally:
+        eng.set_fused_tile(0)
     assert torch.equal(r["x_out"], full["x_out"][:, :, perm])                       # lane/wave placement does not matter
     assert (r["out"] - full["out"][perm]).abs().max().item() < 1e-6                 # rows move between MFMA row blocks
 
@@ -84,6 +88,70 @@ def test_random_sample_matches_oracle(setup):
     rows = np.concatenate([ref["x"], g("accel"), g("f"), ref["p_rot"], g("dp"), g("imu")], axis=2)
     ro, _, _ = orc.gru_forward((rows + 30.0) / 60.0, orc.flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
     assert np.abs(full["out"][idx].cpu().numpy() - ro).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 6: the shards of a FIXED 65,536 batch (GPU g gets trajectories [g B/G, (g+1) B/G)) and the tile shapes that
+# keep the chip full on them (os_fused_set_tile: 256 | 128 | 64 | 32 | 16 trajectories per CU)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_gpus,shard,tile", [(2, 1, 0), (4, 3, 0), (8, 5, 0), (2, 0, 128), (4, 1, 64), (8, 2, 32), (8, 7, 16), (16, 9, 16), (16, 11, 0)])
+def test_shard_of_the_fixed_batch_equals_its_slice_of_the_full_run(setup, n_gpus, shard, tile):
+    """Rank `shard` of `n_gpus` runs its contiguous slice alone, with the shape os_fused_run picks for that size (tile 0) or a pinned
+    one: the filter is the same lane arithmetic in every shape (bit for bit: x_out, the final x and P, status), the gate sums of the
+    smaller tiles run in another k order (fp32 rounding: 1e-6 on the sigmoid outputs).  A random sample of the shard matches the
+    float64 oracle within the parity bars."""
+    from oracle import c_oracle as orc
+    from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
+    eng, d, m, mm, full, x, P = setup
+    n = B // n_gpus
+    idx = torch.arange(shard * n, (shard + 1) * n, device="cuda")
+    s = _slice(d, idx)
+    xs, Ps = s["x0"].clone(), s["P0"].clone()
+    eng.set_fused_tile(tile)
+    try:
+        r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], s["contact_p"], s["accel"], mm, xs, Ps)
+        name = eng.kernel_name("fused")
+    finally:
+        eng.set_fused_tile(0)
+    if tile == 0:                                                   # what the library picks: the shape that fills the chip
+        want = {2: "32 per wave", 4: "v3<1>", 8: "v3<2>", 16: "v3<4>"}[n_gpus]
+        assert want in name, name
+    assert torch.equal(r["x_out"], full["x_out"][:, :, idx]) and torch.equal(xs, x[:, idx]) and torch.equal(Ps, P[:, idx])
+    assert int((r["status"] != 0).sum()) == 0
+    assert (r["out"] - full["out"][idx]).abs().max().item() < 1e-6
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(n_gpus * 100 + shard))[:64].cuda()
+    gi = idx[pick]
+    g = lambda k: d[k][:, :, gi].permute(2, 0, 1).cpu().numpy()
+    contact = d["contact"][:, :, gi].permute(2, 0, 1).cpu().numpy()
+    ref = orc.kf_run_batch(g("p"), g("f"), g("dp"), g("imu"), contact, d["x0"][:, gi].t().cpu().numpy(),
+                           np.tile(Q_DEFAULT, (64, 1, 1)), Q_DEFAULT, R_DEFAULT)
+    assert np.abs(r["x_out"][:, :, pick].permute(2, 0, 1).cpu().numpy() - ref["x"]).max() < 1e-4
+    rows = np.concatenate([ref["x"], g("accel"), g("f"), ref["p_rot"], g("dp"), g("imu")], axis=2)
+    ro, _, _ = orc.gru_forward((rows + 30.0) / 60.0, orc.flatten_state_dict(m.state_dict(), 1), 60, 64, 1, 24)
+    assert np.abs(r["out"][pick].cpu().numpy() - ro).max() < 1e-5
+
+
+@pytest.mark.parametrize("tile", [128, 64, 32, 16])
+def test_tile_shapes_on_a_ragged_batch_and_run_to_run_determinism(setup, tile):
+    """A batch that ends inside a tile (shadow lanes, a partly dead split pair) and is smaller than one round; two runs of the same
+    launch are bit-identical (the kernels' inline-assembly MFMA / ds_read interleave has no compiler hazard cover)."""
+    eng, d, m, mm, full, x, P = setup
+    n = 4096 + 37
+    idx = torch.arange(20000, 20000 + n, device="cuda")
+    s = _slice(d, idx)
+    eng.set_fused_tile(tile)
+    try:
+        outs = []
+        for _ in range(2):
+            xs, Ps = s["x0"].clone(), s["P0"].clone()
+            r = eng.fused_run(s["p"], s["f"], s["dp"], s["imu"], s["contact_p"], s["accel"], mm, xs, Ps)
+            outs.append((r, xs, Ps))
+    finally:
+        eng.set_fused_tile(0)
+    (r, xs, Ps), (r2, xs2, Ps2) = outs
+    assert torch.equal(r["out"], r2["out"]) and torch.equal(r["x_out"], r2["x_out"]) and torch.equal(Ps, Ps2)
+    assert torch.equal(r["x_out"], full["x_out"][:, :, idx]) and torch.equal(Ps, P[:, idx]) and torch.equal(xs, x[:, idx])
+    assert (r["out"] - full["out"][idx]).abs().max().item() < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------------------------
