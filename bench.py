@@ -10,8 +10,13 @@ touches the GPU) and exits with the child's code; launched under torch.distribut
 A "step" is one pass of the hot path (Kalman predict/update + feature pack + GRU + head) over one batch of
 synthetic input: B = 65,536 trajectories x T = 100 timesteps per GPU (BASELINE.json configs[2]).  Inputs are
 resident in HBM before the timed region.  Trajectories are independent, so N GPUs run N disjoint batches with
-no data-path collective (weak scaling); the only cross-rank traffic is the barrier and the max-over-ranks of
+no data-path collective (weak scaling, the default); the only cross-rank traffic is the barrier and the max-over-ranks of
 the elapsed time.  Rank 0 prints ONE JSON line.
+
+--scaling strong (modes fused / kf): --batch is the GLOBAL batch (default 65,536 = BASELINE.json's "at batch 65536"), every rank
+generates the same synthetic batch and runs its contiguous shard [r B/N, (r+1) B/N) of it (optistate_amd.train.shard_range),
+`value` = B x T x K / time, `"scaling": "strong"`.  os_fused_run picks the kernel tile shape for the shard size (256 ... 16
+trajectories per CU), so a shard of 8,192 still fills the chip.
 
 Other lines (same contract): --mode kf (configs[1]: --batch 4096 --seq 1000), --mode train (configs[3]), --mode full
 (configs[4]), --mode mpc (estimate_state_mpc), --mode windows (the reference's own inference mode,
@@ -256,12 +261,12 @@ def emit(line):
 
 def base_line(a, rk, metric, unit, value, el, dtype, config):
     out = {"metric": metric, "value": value, "unit": unit, "n_gpus": rk.world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": getattr(a, "scaling", "weak"), "vs_baseline": None,
            "dtype": dtype, "data": "synthetic", "config": config}
     return out
 
 
-TRAFFIC_SOURCE_OF = {"fused_kf_gru_kernel_v2": "fused_kernels.hip", "fused_kf_gru_bf16_kernel": "fused_kernels.hip",
+TRAFFIC_SOURCE_OF = {"fused_kf_gru_kernel_v2": "fused_kernels.hip", "fused_kf_gru_kernel_v3": "fused_kernels.hip", "fused_kf_gru_bf16_kernel": "fused_kernels.hip",
                      "fused_kf_gru_kernel": "fused_kernels.hip", "kf_run_sym_kernel": "kf_kernels.hip",
                      "kf_run_rows2_kernel": "kf_rows_kernel.hip"}
 
@@ -796,7 +801,20 @@ def bench_hot_path(a, rk):
     fused = a.mode == "fused"
     eng = Engine(rk.device_index)
     dev = eng.device
-    d = synth_torch(B, T, dev, seed=1000 + rk.rank, hostile=a.hostile)
+    strong = a.scaling == "strong"
+    B_global = B * rk.world
+    if strong:
+        # fixed global batch: every rank generates the SAME batch (seed 1000) and keeps its contiguous shard
+        from optistate_amd.train import shard_range
+        B_global = B
+        lo, hi = shard_range(B_global, rk.rank, rk.world)
+        d = synth_torch(B_global, T, dev, seed=1000, hostile=a.hostile)
+        d = {k: (v[..., lo:hi].contiguous() if rk.world > 1 else v) for k, v in d.items()}
+        B = hi - lo
+        if B <= 0:
+            raise SystemExit(f"--scaling strong: --batch {B_global} leaves rank {rk.rank} of {rk.world} without trajectories")
+    else:
+        d = synth_torch(B, T, dev, seed=1000 + rk.rank, hostile=a.hostile)
     contact = eng.contact_soa_to_packed(d["contact"])
     torch.manual_seed(0)
     model = RNN(I, H, L, 24, dev)                       # random-init weights of the named architecture
@@ -846,10 +864,20 @@ def bench_hot_path(a, rk):
     bad = int(eng.failed(r["status"]).sum().item())           # bits 0-3; bit 4 is informational and counted on its own
     edge = int(eng.trunc_edge(r["status"]).sum().item())
     info = rk.report()
+    checksum = None
+    if strong:
+        # the SAME samples whatever N: float64 sums of the final filter states and of the head outputs over the whole global batch
+        # (1-GPU vs N-GPU runs of this line agree to fp32 noise: the filter bit for bit, the gate sums to their tile shape's k order)
+        cs = torch.stack([r["x_out"][-1].double().sum(), (r["out"].double().sum() if fused else torch.zeros((), dtype=torch.float64, device=dev)),
+                          torch.tensor(float(B), dtype=torch.float64, device=dev)])
+        if rk.dist:
+            cs = cs.cpu() if rk.share else cs
+            rk.dist.all_reduce(cs)
+        checksum = {"sum_x_final": float(cs[0]), "sum_out": float(cs[1]), "trajectories": int(cs[2])}
     if rk.rank != 0:
         return
     steps_per_pass = B * T
-    total = steps_per_pass * rk.world * a.steps
+    total = (B_global * T if strong else steps_per_pass * rk.world) * a.steps
     # dominant kernel: the phase with the largest device time per pass; its NAME is the variant the library actually
     # launched (os_profile_kernel_name), so a small batch reports kf_run_rows_kernel, not the fast-path kernel
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
@@ -867,7 +895,7 @@ def bench_hot_path(a, rk):
         on_bf16 = bool(a.split_bf16) and "bf16" in dk["kernel"]
         peak = MFMA_BF16_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF
         insn = ("v_mfma_f32_32x32x16_bf16 x6 (hi/mid/lo split)" if a.split_bf16 == 3 else "v_mfma_f32_32x32x16_bf16 x3 (hi/lo split)") \
-            if on_bf16 else "v_mfma_f32_32x32x2_f32"
+            if on_bf16 else ("v_mfma_f32_16x16x4_f32" if "kernel_v3" in dk["kernel"] else "v_mfma_f32_32x32x2_f32")
         roof = {"kernel": f"{dk['kernel']} ({insn})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None, "traffic_source": "not collected for this mode", "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": fl}
         if on_bf16 and dom == "fused":
@@ -920,11 +948,15 @@ def bench_hot_path(a, rk):
     out = base_line(a, rk, "KF+GRU timesteps/sec" if fused else "KF timesteps/sec", "timesteps/s", total / el, el, dtype,
                     {"workload": f"fused Kalman(12-state/10-meas)+GRU(in={I},hidden={H},layers={L},out=24) inference"
                                  if fused else "Kalman(12-state/10-meas) predict/update only",
-                     "batch_per_gpu": B, "seq_len": T, "global_batch": B * rk.world,
-                     "parallelism": f"trajectory-sharded x{rk.world}, no collective",
+                     "batch_per_gpu": B, "seq_len": T, "global_batch": B_global,
+                     "parallelism": f"trajectory-sharded x{rk.world}, no collective" + (" (contiguous shards of ONE fixed batch)" if strong else ""),
                      "noise": NOISE_NOTE[a.noise], "inputs": INPUT_NOTE["hostile" if a.hostile else "nominal"],
                      "baseline_config": "BASELINE.json configs[2]" if fused else "BASELINE.json configs[1] (true dims 12/10)"})
     out["roofline"] = roof
+    if strong:
+        out["global_checksum"] = checksum
+        out["strong_note"] = ("fixed global batch: rank r runs trajectories shard_range(B, r, N) of the same synthetic batch; roofline / kernels / "
+                              "parity are rank 0's shard; os_fused_run chose the kernel tile shape for the shard size")
     out["kernels"] = kernels
     out["kernel_events"] = "HIP events on the launch stream, recorded over the timed region (the wall time includes them)"
     out["status_nonzero_trajectories"] = bad
@@ -966,14 +998,25 @@ def bench_hot_path(a, rk):
 
 
 def launch_check(a, rk):
-    """Rendezvous self-test of the launcher (CPU contract test): every rank joins, one all-reduce, rank 0 reports."""
+    """Rendezvous self-test of the launcher (CPU contract test): every rank joins, one all-reduce, rank 0 reports.  With
+    --scaling strong every rank also reports the shard of the global batch it would run."""
     import torch
     v = torch.ones(1, device=rk.dev)
     if rk.dist:
         rk.dist.all_reduce(v)
     info = rk.report()
+    extra = {}
+    if a.scaling == "strong":
+        from optistate_amd.train import shard_range
+        mine = list(shard_range(a.batch, rk.rank, rk.world))
+        shards = [None] * rk.world
+        if rk.dist:
+            rk.dist.all_gather_object(shards, mine)
+        else:
+            shards = [mine]
+        extra = {"scaling": "strong", "global_batch": a.batch, "shards": shards}
     if rk.rank == 0:
-        emit(json.dumps({"launch_check": True, "n_gpus": a.gpus, "sum_of_ones": float(v.item()), **info}))
+        emit(json.dumps({"launch_check": True, "n_gpus": a.gpus, "sum_of_ones": float(v.item()), **extra, **info}))
 
 
 def main(argv=None):
@@ -1011,6 +1054,9 @@ def main(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="development: with --gpus N on a box with fewer devices, rank r runs on device r %% device_count over gloo "
                          "(host-staged collectives); runs the world > 1 code paths, not a scaling measurement")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch trajectories PER GPU; strong (modes fused / kf): --batch is the global batch, rank r runs its "
+                         "contiguous shard of the same synthetic batch (SURVEY 8(e))")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous, and report the process group")
     ap.add_argument("--mode", default="fused", choices=["fused", "kf", "train", "full", "mpc", "windows"],
                     help="kf = BASELINE configs[1]-style KF-only run; train = configs[3] data-parallel gru_train step")
@@ -1021,6 +1067,8 @@ def main(argv=None):
         a.steps = 100 if a.mode == "windows" else 10
     if a.warmup is None:
         a.warmup = 20 if a.mode == "windows" else 2
+    if a.scaling == "strong" and a.mode not in ("fused", "kf") and not a.launch_check:
+        raise SystemExit("--scaling strong: modes fused and kf (the trajectory-sharded inference paths)")
 
     # N > 1 and not yet a rank: start the ranks as a child process BEFORE anything here touches the GPU
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

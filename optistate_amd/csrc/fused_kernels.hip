@@ -166,6 +166,30 @@ __global__ void fused_pack_kernel(const float *__restrict__ w0 /* layer 0, torch
 #define OSF_TS(i)
 #endif
 
+// load j (0..48) of a step's 49 input dwords into its place in the paired input block (load_step_p's order: p, f, dp rows as leg
+// pairs, imu, contact, accel): the fused kernels issue them one at a time between their MFMA groups (j is a constant after unrolling)
+struct StepSrc { rsrc_t p, f, dp, imu, contact, accel; };
+__device__ __forceinline__ StepSrc step_src(const KfRunArgs &a, int t, uint32_t rowB)
+{
+    const size_t B = (size_t)a.B;
+    return StepSrc{make_rsrc(a.p + (size_t)t * 12 * B, 12 * rowB), make_rsrc(a.f + (size_t)t * 12 * B, 12 * rowB), make_rsrc(a.dp + (size_t)t * 12 * B, 12 * rowB),
+                   make_rsrc(a.imu + (size_t)t * 6 * B, 6 * rowB), make_rsrc(a.contact + (size_t)t * B, rowB), make_rsrc(a.accel + (size_t)t * 6 * B, 6 * rowB)};
+}
+__device__ __forceinline__ void prefetch_input(const StepSrc &src, uint32_t voff, uint32_t rowB, int j, StepInP &in, float (&acl)[6])
+{
+    if (j < 36) {
+        const int st = j / 12, R = j % 12, q = R / 6, c = (R % 6) % 3, hf = (R % 6) / 3;
+        const float v = buf_load_nt(st == 0 ? src.p : st == 1 ? src.f : src.dp, voff, (uint32_t)R * rowB);
+        if (st == 0) in.p[q][c][hf] = v; else if (st == 1) in.f[q][c][hf] = v; else in.dp[q][c][hf] = v;
+    } else if (j < 42) {
+        in.imu[j - 36] = buf_load_nt(src.imu, voff, (uint32_t)(j - 36) * rowB);
+    } else if (j == 42) {
+        in.contact = buf_load_u32_nt(src.contact, voff, 0);
+    } else {
+        acl[j - 43] = buf_load_nt(src.accel, voff, (uint32_t)(j - 43) * rowB);
+    }
+}
+
 // NRB = 32-trajectory column blocks per wave.  NRB = 2: a wave owns 64 trajectories, lane = trajectory (the layout above).  NRB = 1 (round 6,
 // batches that leave half the chip idle at 256 trajectories per CU): a wave owns 32 trajectories and BOTH lane halves run the filter
 // of trajectory wbase + (lane & 31) redundantly -- the B fragment of a k-pair is then one v_cndmask (lanes 0-31 take feature 2kp, lanes
@@ -284,6 +308,8 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
         feat6(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3), OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7), OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
         OSF_TS(4)                                        // ten measurement updates, x_out stores, 12 state features
 
+        // the next step's input rows (requested under this step's last MFMA pass; the descriptors' scalar arithmetic hides under the first)
+        const StepSrc nsrc = step_src(k, (t + 1 < k.T) ? t + 1 : t, rowB);
         // One 32-trajectory column block and one 32-unit chunk at a time: 64 accumulator registers, in VGPRs, where the cell
         // update reads them directly (the weight fragments are simply read from LDS again for each of the four passes).  Chunk
         // 0's new h waits in 16 spare AGPRs until chunk 1's MFMAs no longer need the old one.
@@ -329,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
                             buf_store_agpr2(rs_prev, srb ? vo_seq1 : vo_seq0, (uint32_t)(32 * sc + (se & 3) + 8 * (se >> 2)) * rowB, hreg[srb < NRB ? srb : 0][sc][se],
                                             (uint32_t)(32 * sc + ((se + 1) & 3) + 8 * ((se + 1) >> 2)) * rowB, hreg[srb < NRB ? srb : 0][sc][se + 1]);
                     }
+#ifdef OSF_V2_PREFETCH_BLOCK
                     if (rb == NRB - 1 && c == 1 && q == KPX) {
                         // the next step's 49 input loads go out underneath the last ~100 MFMAs and the cell update
                         const int tn = (t + 1 < k.T) ? t + 1 : t;
@@ -337,6 +364,13 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v2(const FusedArgs
 #pragma unroll
                         for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
                     }
+#else
+                    if (rb == NRB - 1 && c == 1 && q >= KPX - 18) {
+                        // the next step's 49 input loads, one per k-pair of the last pass's final 49 (round 6: a VMEM instruction costs ~16 issue
+                        // cycles at one wave per SIMD; one at a time the matrix pipe covers them, 49 in a row it ran dry for ~0.8 k cycles)
+                        if (q - (KPX - 18) < 49) prefetch_input(nsrc, voff, rowB, q - (KPX - 18), in, acl);
+                    }
+#endif
                     const float bv = q < KPX ? FA[2 * (q < KPX ? q : 0) + rb]
                                              : hreg[rb][(q - KPX) >> 4 & 1][(q >= KPX ? q - KPX : 0) & 15];
                     const int gn = q < KPX ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
@@ -527,8 +561,12 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < IMG3 / 4; i += 256) dst[i] = src[i];
     }
+    if (NSPLIT > 1)                  // step 0 picks "h_{-1}" = 0 up from parity 1 like any other step (no branch in the loop)
+        for (int i = threadIdx.x; i < TPW * 2 * 4 * 64 * 4; i += 256) lds[IMG3 + i] = 0.f;
     __syncthreads();
-    const float *minq = lds + IMG3_MINS + q;                                       // the quarter's minimum of k-step ks: minq[4 ks]
+    float minA[KS3X];                // the quarter's minimum of feature k-step ks (feature 4 ks + q), AGPR-resident
+#pragma unroll
+    for (int ks = 0; ks < KS3X; ks++) minA[ks] = agpr_put(lds[IMG3_MINS + 4 * ks + q]);
     const float4 *Wq = reinterpret_cast<const float4 *>(lds) + (size_t)sw * (KS3 * UTW * 64) + lane;      // this wave position's fragments
     const float4 *bias4 = reinterpret_cast<const float4 *>(lds + IMG3_BIAS) + q * 16 + sw * UTW * 4;
     float4 *xch = reinterpret_cast<float4 *>(lds + IMG3) + (size_t)tw * (2 * 4 * 64) + lane;   // [tile][parity][unit tile][lane] x 16 B
@@ -570,6 +608,21 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs
     OSF_TS_DECL
     for (int t = 0; t < k.T; t++) {
         OSF_TS(0)
+        if (NSPLIT > 1) {
+            // the other waves' slices of h_{t-1}: written at the end of step t - 1 into parity (t - 1) & 1 (zeros at t = 0).  The matrix
+            // pipe is idle here anyway (the filter phase follows), and the waves arrive together: they all just finished the same step.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const float4 *xr = xch + (size_t)((t + 1) & 1) * (4 * 64);
+            float4 hv[NSPLIT > 1 ? 4 - UTW : 1];
+#pragma unroll
+            for (int s = UTW; s < 4; s++) hv[s - UTW] = xr[((sw * UTW + s) & 3) * 64];
+#pragma unroll
+            for (int s = UTW; s < 4; s++) {
+                hreg[s][0] = agpr_put(hv[s - UTW].x); hreg[s][1] = agpr_put(hv[s - UTW].y);
+                hreg[s][2] = agpr_put(hv[s - UTW].z); hreg[s][3] = agpr_put(hv[s - UTW].w);
+            }
+        }
+        OSF_TS(7)
         float z[NM], FA[KS3X];
         f2 PW[2][3];
         float g9[9];
@@ -579,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs
         // B fragment of feature k-step ks: the quarter's feature 4 ks + q minus its minimum (the 1/(max-min) scale sits in the weights)
         auto feat4 = [&](int ks, float v0, float v1, float v2, float v3) {
             const float lo = q1 ? v1 : v0, hi = q1 ? v3 : v2;
-            FA[ks] = agpr_put((q2 ? hi : lo) - minq[4 * ks]);
+            FA[ks] = agpr_put((q2 ? hi : lo) - agpr_get(minA[ks]));
         };
         // feature order [x 0-11 | accel 12-17 | f 18-29 | p_world 30-41 | dp 42-53 | imu 54-59]
         feat4(3, acl[0], acl[1], acl[2], acl[3]);
@@ -600,12 +653,14 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs
         __builtin_amdgcn_sched_barrier(0);
         OSF_TS(3)
         smin = fminf(smin, update_sequential_sym(X, U, z, k.k));
+        __builtin_amdgcn_sched_barrier(0);
         feat4(0, OSF_X(0), OSF_X(1), OSF_X(2), OSF_X(3));
         feat4(1, OSF_X(4), OSF_X(5), OSF_X(6), OSF_X(7));
         feat4(2, OSF_X(8), OSF_X(9), OSF_X(10), OSF_X(11));
         OSF_TS(4)
 
         // ================= GRU cell: UTW unit tiles x (r, z, gi_n, gh_n) accumulators of 4 registers =================
+        const StepSrc nsrc = step_src(k, (t + 1 < k.T) ? t + 1 : t, rowB);      // the next step's input rows (requested between the MFMA groups)
         f32x4 acc[UTW][4];
 #pragma unroll
         for (int u = 0; u < UTW; u++)
@@ -626,30 +681,19 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs
 #pragma unroll
         for (int u = 0; u < UTW; u++) {
             const int gi = ks * UTW + u, cur = gi % 3, nx2 = (gi + 2) % 3;
-            if (gi == 2 * UTW) {
-                // x_out of this step (X does not change until the next step's filter phase); shadow lanes: an offset no descriptor covers
-                const uint32_t vst = live ? voff : 0x7ffffff0u;
-                rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+            // 12 x_out stores of this step (X does not change until the next step's filter phase; shadow lanes: an offset no descriptor
+            // covers) and the NEXT step's 49 input loads, spread over the groups -- a VMEM instruction costs ~16 issue cycles at one
+            // wave per SIMD, which the matrix pipe covers one at a time but not 49 in a row (round 6: in-kernel timestamps).  Every
+            // input register of this step is dead by now: its features sit in AGPRs.
+            constexpr int VPG = (NS + 49 + NG - 1) / NG;                // VMEM instructions per group
 #pragma unroll
-                for (int i = 0; i < NS; i++) buf_store_nt(ro, vst, i * rowB, OSF_X(i));
-            }
-            if (NSPLIT > 1 && gi == KS3X * UTW && t > 0) {
-                // the other waves' slices of h_{t-1}: written at the end of step t - 1 into parity (t - 1) & 1
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                const float4 *xr = xch + (size_t)((t - 1) & 1) * (4 * 64);
-#pragma unroll
-                for (int s = UTW; s < 4; s++) {
-                    const float4 hv = xr[((sw * UTW + s) & 3) * 64];
-                    hreg[s][0] = agpr_put(hv.x); hreg[s][1] = agpr_put(hv.y); hreg[s][2] = agpr_put(hv.z); hreg[s][3] = agpr_put(hv.w);
+            for (int j = gi * VPG; j < (gi + 1) * VPG && j < NS + 49; j++) {
+                if (j < NS) {
+                    rsrc_t ro = make_rsrc(k.x_out + (size_t)t * 12 * B, 12 * rowB);
+                    buf_store_nt(ro, live ? voff : 0x7ffffff0u, j * rowB, OSF_X(j < NS ? j : 0));
+                } else {
+                    prefetch_input(nsrc, voff, rowB, j - NS, in, acl);
                 }
-            }
-            if (gi == (KS3X + 4) * UTW) {
-                // the next step's 49 input loads go out underneath the remaining MFMAs and the cell update
-                const int tn = (t + 1 < k.T) ? t + 1 : t;
-                load_step_p(k, tn, voff, rowB, in);
-                rsrc_t ra = make_rsrc(k.accel + (size_t)tn * 6 * B, 6 * rowB);
-#pragma unroll
-                for (int i = 0; i < 6; i++) acl[i] = buf_load_nt(ra, voff, i * rowB);
             }
             const float bv = ks < KS3X ? FA[ks < KS3X ? ks : 0] : hreg[(ks >= KS3X ? ks - KS3X : 0) >> 2][(ks >= KS3X ? ks - KS3X : 0) & 3];
             const int gn = ks < KS3X ? 2 : 3;          // input part feeds gi_n, recurrent part gh_n
@@ -720,8 +764,8 @@ __global__ __launch_bounds__(256, 1) void fused_kf_gru_kernel_v3(const FusedArgs
     }
 #ifdef OS_FUSED_TS
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("fused_v3<NSPLIT=%d> cycles per step: inputs %llu | features %llu | predict %llu | update %llu | mfma %llu | cell %llu\n", NSPLIT,
-               ts_sum[1] / k.T, ts_sum[2] / k.T, ts_sum[3] / k.T, ts_sum[4] / k.T, ts_sum[5] / k.T, ts_sum[6] / k.T);
+        printf("fused_v3<NSPLIT=%d> cycles per step: barrier + exchange %llu | inputs %llu | features %llu | predict %llu | update %llu | mfma %llu | cell %llu\n", NSPLIT,
+               ts_sum[7] / k.T, ts_sum[1] / k.T, ts_sum[2] / k.T, ts_sum[3] / k.T, ts_sum[4] / k.T, ts_sum[5] / k.T, ts_sum[6] / k.T);
 #endif
     status |= singular_status(smin) | finite_status_p(X);
     if (live) {
@@ -1124,7 +1168,8 @@ int os_fused_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float 
                            ctx->r_is_diagonal && n_latent == 0 && d.hidden_size == 64 && d.input_size == 60;
     int tile = 0;                      // trajectories per workgroup, 0 = two-kernel path
     if (shapes_ok && !(flags & OS_FUSED_TWO_KERNEL)) {
-        static const struct { int tpw; float cost; } shapes[5] = {{256, 60.7f}, {128, 33.5f}, {64, 19.7f}, {32, 14.0f}, {16, 10.5f}};
+        // cost = measured microseconds per time step of one workgroup (T = 100 sweeps on MI355X, profiles/r06_shard_sweep.md)
+        static const struct { int tpw; float cost; } shapes[5] = {{256, 25.9f}, {128, 14.4f}, {64, 9.0f}, {32, 5.7f}, {16, 4.4f}};
         const int nshape = d.num_layers > 1 ? 2 : 5;          // the v3 shapes have no layer-0 sequence output
         float best = 0.f;
         for (int i = 0; i < nshape; i++) {

@@ -104,6 +104,44 @@ def main():
         res["grad_bucket_bytes"] = int(bucket.g.numel() * 4)
         print(json.dumps(res), flush=True)
     dist.barrier()
+
+    # ---------------- a lost producer on ONE rank (OS_WORKER_DROP_RANK): the trainer's whole-step redo ----------------
+    # The reference's own batch (64 windows per rank) runs its layers as progress-counter launches.  A fresh context on the chosen rank
+    # is created with OS_STACK_DBG_DROP (layer 1 stops publishing at step 3) and a short bounded wait: that rank's forward and backward
+    # lose a producer in EVERY step.  DataParallelTrainer verifies once per step before the all-reduce and redoes the step with a
+    # launch per layer, so no poisoned gradient reaches the collective: replicas stay identical and equal the clean run's weights.
+    drop_rank = int(os.environ.get("OS_WORKER_DROP_RANK", "-1"))
+    if drop_rank >= 0:
+        from optistate_amd import engine as _engine
+        if rank == drop_rank:
+            os.environ["OS_STACK_DBG_DROP"] = "1,3"; os.environ["OS_STACK_DBG_POLLS"] = "3000"
+        _engine._default_engines.__dict__.pop("engines", None)      # a new per-thread default context: os_create reads the knobs
+        solo = [dist.new_group([r]) for r in range(world)]      # (collective: every rank creates every one-rank group)
+        Bs = 64 * world
+        xs_, ys_ = torch.rand(Bs, Tt, dims[0], device=dev, generator=g), torch.rand(Bs, 12, device=dev, generator=g)
+        torch.manual_seed(5)
+        m2 = RNN(*dims, dev).to(dev)
+        tr2 = DataParallelTrainer(m2, lr=1e-4)
+        lo, hi = shard_range(Bs, rank, world)
+        for _ in range(3):
+            loss = tr2.step(xs_[lo:hi], ys_[lo:hi])
+        torch.cuda.synchronize()
+        lost = [None] * world
+        dist.all_gather_object(lost, {"rank": rank, "lost_steps": tr2.lost_steps, "loss_finite": bool(torch.isfinite(loss).all()),
+                                      "stack_mode_after": tr2.eng._stack_mode})
+        w2 = all_gather_cat(tr2.bucket.w.reshape(1, -1), dim=0)
+        if rank == 0:
+            # the clean run: one process, the full batch, no drop (rank 0's context has none), three steps
+            torch.manual_seed(5)
+            m3 = RNN(*dims, dev).to(dev)
+            tr3 = DataParallelTrainer(m3, lr=1e-4, group=solo[0])
+            for _ in range(3):
+                tr3.step(xs_, ys_)
+            torch.cuda.synchronize()
+            res2 = {"lost": lost, "weights_finite": bool(torch.isfinite(w2).all()), "replica_weight_max_abs_diff": float((w2 - w2[0:1]).abs().max()),
+                    "weight_vs_clean_run_max_abs_diff": float((w2[0] - tr3.bucket.w).abs().max())}
+            print("LOST " + json.dumps(res2), flush=True)
+        dist.barrier()
     dist.destroy_process_group()
 
 

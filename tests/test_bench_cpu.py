@@ -59,6 +59,28 @@ def test_gpus_2_starts_its_own_ranks_and_reports_the_process_group():
     assert len({x["pid"] for x in d["rank_devices"]}) == 2            # two separate rank processes
 
 
+def test_scaling_strong_shards_one_fixed_batch_over_the_ranks():
+    """`bench.py --gpus 3 --scaling strong --batch 65536`: --batch is the GLOBAL batch; rank r runs the contiguous shard
+    shard_range(B, r, N) ("GPU g gets trajectories [g B/G, (g+1) B/G)").  The launcher self-test reports the shards
+    every rank computed: they tile the batch exactly, ragged sizes differ by at most one."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_PROTO", "NCCL_ALGO")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check", "--scaling", "strong", "--batch", "65536"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["global_batch"] == 65536 and d["rccl_world_size"] == 3
+    sh = d["shards"]
+    assert sh[0][0] == 0 and sh[-1][1] == 65536 and all(sh[i][1] == sh[i + 1][0] for i in range(2))
+    assert sorted(hi - lo for lo, hi in sh) == [21845, 21845, 21846]
+    # the modes that do not shard trajectories refuse the flag
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "train", "--scaling", "strong"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode != 0 and "strong" in (r.stderr + r.stdout)
+
+
 def test_a_rank_with_the_wrong_world_size_refuses():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -20,9 +20,20 @@ pytestmark = pytest.mark.skipif(not os.path.exists(cr.LIB) or not os.path.exists
 # kernel (demangled, as tools/codeobj_report.py prints it) -> which reference-shaped call reaches it
 SCRATCH_FREE = {
     # BASELINE configs[2]: the headline kernel and its full-Q twin; GRU(60,64,L>1) writes layer 0's sequence (SEQOUT)
-    "osf::fused_kf_gru_kernel_v2<true, false>": "fused KF+GRU headline (diagonal Q)",
-    "osf::fused_kf_gru_kernel_v2<false, false>": "fused KF+GRU, full-matrix Q",
-    "osf::fused_kf_gru_kernel_v2<true, true>": "fused KF+GRU(60,64,L>1): layer 0 with its sequence written",
+    "osf::fused_kf_gru_kernel_v2<true, false, 2>": "fused KF+GRU headline (diagonal Q), 64 trajectories per wavefront",
+    "osf::fused_kf_gru_kernel_v2<false, false, 2>": "fused KF+GRU, full-matrix Q",
+    "osf::fused_kf_gru_kernel_v2<true, true, 2>": "fused KF+GRU(60,64,L>1): layer 0 with its sequence written",
+    # round 6: the tile shapes of the shards of a fixed 65,536 batch (os_fused_set_tile)
+    "osf::fused_kf_gru_kernel_v2<true, false, 1>": "32 trajectories per wavefront (a 32,768 shard)",
+    "osf::fused_kf_gru_kernel_v2<false, false, 1>": "the same with a full-matrix Q",
+    "osf::fused_kf_gru_kernel_v2<true, true, 1>": "the same, layer 0 of GRU(60,64,L>1)",
+    "osf::fused_kf_gru_kernel_v2<false, true, 1>": "the same, full-matrix Q",
+    "osf::fused_kf_gru_kernel_v3<true, 1>": "16-trajectory tiles on the 16x16x4 MFMA (a 16,384 shard)",
+    "osf::fused_kf_gru_kernel_v3<true, 2>": "a tile's hidden units over two wavefronts (an 8,192 shard)",
+    "osf::fused_kf_gru_kernel_v3<true, 4>": "a tile's hidden units over four wavefronts (4,096 trajectories and below)",
+    "osf::fused_kf_gru_kernel_v3<false, 1>": "16-trajectory tiles, full-matrix Q",
+    "osf::fused_kf_gru_kernel_v3<false, 2>": "two wavefronts per tile, full-matrix Q",
+    "osf::fused_kf_gru_kernel_v3<false, 4>": "four wavefronts per tile, full-matrix Q",
     # BASELINE configs[1] and the KF-only large batch
     "osk::kf_run_sym_kernel<0, true, false>": "KF only, B = 65,536",
     "osk::kf_run_sym_kernel<0, true, true>": "KF only with p_rot",
@@ -32,7 +43,7 @@ SCRATCH_FREE = {
     "osg::gru_layer_stage_kernel<4>": "RNN(188,128,4) at the headline batch",
     "osg::gru_layer_stage_kernel<2>": "GRU(60,64,4) layers 1..3 at the headline batch",
     "osg::gru_layer_ahead_kernel": "training / windows forward, H = 128, one tile per CU",
-    "osf::fused_kf_gru_kernel_v2<false, true>": "the same with a full-matrix Q",
+    "osf::fused_kf_gru_kernel_v2<false, true, 2>": "the same with a full-matrix Q",
     "osg::gru_layer_split_kernel<4, false, false>": "H = 128 small batches",
     "osg::gru_layer_split_kernel<4, true, false>": "H = 128 small batches, training forward",
     "osg::gru_layer_split_kernel<2, false, false>": "H = 64 small batches",
@@ -106,7 +117,7 @@ def rows():
 
 def test_metadata_is_readable_and_covers_the_library(rows):
     assert len(rows) > 100
-    hk = rows["osf::fused_kf_gru_kernel_v2<true, false>"]
+    hk = rows["osf::fused_kf_gru_kernel_v2<true, false, 2>"]
     assert hk["vgpr_count"] > 256 and hk["agpr_count"] > 0          # the headline kernel uses both register halves
 
 

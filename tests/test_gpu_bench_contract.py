@@ -48,8 +48,10 @@ def test_default_mode_contract():
     assert "settings.py" in d["config"]["noise"]
     assert cb["reference_python_steps_per_s"] == 3.05e3
     assert d["rccl_world_size"] == 1 and d["rank_devices"][0]["device"] == 0
-    # B = 4096 takes the two-kernel path: the line names the kernels that actually ran
-    assert d["kernels"]["kf"]["kernel"] == "kf_run_rows2_kernel" and d["kernels"]["gru_layer"]["kernel"].startswith("gru_layer")
+    # B = 4096 takes the single fused kernel's smallest tile (16 trajectories per CU, four wavefronts per tile: round 6; the two-kernel
+    # path until round 5): the line names the kernel that actually ran, and its MFMA instruction
+    assert d["kernels"]["fused"]["kernel"] == "fused_kf_gru_kernel_v3<4>" and "kf" not in d["kernels"]
+    assert ro["kernel"].startswith("fused_kf_gru_kernel_v3<4>") and "v_mfma_f32_16x16x4_f32" in ro["kernel"] and ro["bound"] == "mfma"
 
 
 def _has_roofline_and_baseline(d):
@@ -86,6 +88,18 @@ def test_other_modes_print_one_line_with_roofline_and_cpu_baseline():
     assert w["roofline"]["algorithmic_flops_per_pass"] < w["roofline"]["flops_of_the_materialised_form"]
     wm = _run(["--mode", "windows", "--materialise", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])
     assert "materialised" in wm["config"]["form"] and wm["roofline"]["algorithmic_flops_per_pass"] == wm["roofline"]["flops_of_the_materialised_form"]
+
+
+def test_scaling_strong_runs_the_global_batch_and_reports_it():
+    """--scaling strong at N = 1: --batch is the global batch, the line says "strong", carries the global checksum, and `value` counts the
+    global batch once (the N-GPU form shards the same samples: tests/test_bench_cpu.py checks the shards, test_gpu_world_shared.py runs two)."""
+    d = _run(["--scaling", "strong", "--batch", "8192", "--seq", "50", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+              "--parity-samples", "256", "--no-second-noise"])
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 8192 and d["config"]["batch_per_gpu"] == 8192
+    assert abs(d["value"] - 8192 * 50 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    cs = d["global_checksum"]
+    assert cs["trajectories"] == 8192 and cs["sum_out"] > 0 and cs["sum_x_final"] == cs["sum_x_final"]
+    assert d["kernels"]["fused"]["kernel"] == "fused_kf_gru_kernel_v3<2>" and d["parity"]["ok"] is True
 
 
 def test_split_bf16_line_on_the_h128_layer_kernel():

@@ -192,6 +192,47 @@ def test_adam_kernel_skips_its_update_behind_a_lost_producer(monkeypatch):
     assert not torch.equal(w, w0)
 
 
+def test_trainer_redoes_a_lost_step_before_the_optimiser_and_keeps_the_callers_stack_mode(monkeypatch):
+    """DataParallelTrainer runs its stacked launches asynchronously and verifies ONCE per step (os_stack_check) before the
+    all-reduce / Adam.  With layer 1 withheld (OS_STACK_DBG_DROP) every step loses a producer: the step's forward, loss and backward
+    are redone with a launch per layer, the loss is finite, and two steps end on the weights of a clean trainer (gru/gru_train.py:232-249).
+    The context's own mode is restored exactly: a process that opted out of stacked launches (OS_GRU_STACK=0) stays opted out."""
+    import torch
+    from optistate_amd import RNN, engine as _engine
+    from optistate_amd.train import DataParallelTrainer
+    dims = (188, 128, 4, 24)
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x, y = torch.rand(64, 10, 188, device="cuda", generator=g), torch.rand(64, 12, device="cuda", generator=g)
+
+    def run(env):
+        for k in ("OS_STACK_DBG_DROP", "OS_STACK_DBG_POLLS", "OS_GRU_STACK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _engine._default_engines.__dict__.pop("engines", None)          # a fresh per-thread context: os_create reads the knobs
+        torch.manual_seed(4)
+        m = RNN(*dims, torch.device("cuda")).to("cuda")
+        tr = DataParallelTrainer(m, lr=1e-4)
+        mode0 = tr.eng._stack_mode
+        losses = [tr.step(x, y) for _ in range(2)]
+        torch.cuda.synchronize()
+        return tr, mode0, losses
+
+    try:
+        clean, mode_clean, _ = run({})
+        assert mode_clean == 1 and clean.eng._stack_mode == 1 and clean.lost_steps == 0
+        lossy, mode_l, losses = run({"OS_STACK_DBG_DROP": "1,3", "OS_STACK_DBG_POLLS": "3000"})
+        assert lossy.lost_steps == 2 and lossy.eng._stack_mode == 1 and all(torch.isfinite(l).all() for l in losses)
+        assert torch.isfinite(lossy.bucket.w).all()
+        assert (lossy.bucket.w - clean.bucket.w).abs().max().item() <= 2 * 2.0e-4 + 1e-7      # per-layer vs stacked launches: fp32 noise through two Adam steps
+        off, mode_off, _ = run({"OS_GRU_STACK": "0", "OS_STACK_DBG_DROP": "1,3", "OS_STACK_DBG_POLLS": "3000"})
+        assert mode_off == 0 and off.eng._stack_mode == 0 and off.eng.lib.os_gru_get_stack(off.eng._h) == 0 and off.lost_steps == 0
+        asyn, mode_a, _ = run({"OS_GRU_STACK": "2"})
+        assert mode_a == 2 and asyn.eng._stack_mode == 2 and asyn.eng.lib.os_gru_get_stack(asyn.eng._h) == 2
+    finally:
+        _engine._default_engines.__dict__.pop("engines", None)
+
+
 def test_two_threads_two_contexts_equal_the_sequential_results():
     """SURVEY 8(b) threading contract: different contexts from different threads, each on its own stream, concurrently -- the
     Kalman run and the GRU forward of each thread equal what the same calls return one after the other; default_engine() is per

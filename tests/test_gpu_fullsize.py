@@ -97,8 +97,8 @@ def test_random_sample_matches_oracle(setup):
 @pytest.mark.parametrize("n_gpus,shard,tile", [(2, 1, 0), (4, 3, 0), (8, 5, 0), (2, 0, 128), (4, 1, 64), (8, 2, 32), (8, 7, 16), (16, 9, 16), (16, 11, 0)])
 def test_shard_of_the_fixed_batch_equals_its_slice_of_the_full_run(setup, n_gpus, shard, tile):
     """Rank `shard` of `n_gpus` runs its contiguous slice alone, with the shape os_fused_run picks for that size (tile 0) or a pinned
-    one: the filter is the same lane arithmetic in every shape (bit for bit: x_out, the final x and P, status), the gate sums of the
-    smaller tiles run in another k order (fp32 rounding: 1e-6 on the sigmoid outputs).  A random sample of the shard matches the
+    one: the filter is the same lane code in every shape (fp32 noise between instantiations: 1e-6 on x_out / x, 1e-9 on P), the gate
+    sums of the smaller tiles run in another k order (1e-6 on the sigmoid outputs).  A random sample of the shard matches the
     float64 oracle within the parity bars."""
     from oracle import c_oracle as orc
     from optistate_amd.synth import Q_DEFAULT, R_DEFAULT
@@ -116,7 +116,10 @@ def test_shard_of_the_fixed_batch_equals_its_slice_of_the_full_run(setup, n_gpus
     if tile == 0:                                                   # what the library picks: the shape that fills the chip
         want = {2: "32 per wave", 4: "v3<1>", 8: "v3<2>", 16: "v3<4>"}[n_gpus]
         assert want in name, name
-    assert torch.equal(r["x_out"], full["x_out"][:, :, idx]) and torch.equal(xs, x[:, idx]) and torch.equal(Ps, P[:, idx])
+    # same filter arithmetic, but every tile shape is its own instantiation: hipcc contracts / orders a handful of fp32 operations
+    # differently between them (measured 2e-7 on the state, 2e-12 on P), and the gate sums of the 16-wide tiles run in another k order
+    assert (r["x_out"] - full["x_out"][:, :, idx]).abs().max().item() < 1e-6 and (xs - x[:, idx]).abs().max().item() < 1e-6
+    assert (Ps - P[:, idx]).abs().max().item() < 1e-9
     assert int((r["status"] != 0).sum()) == 0
     assert (r["out"] - full["out"][idx]).abs().max().item() < 1e-6
     pick = torch.randperm(n, generator=torch.Generator().manual_seed(n_gpus * 100 + shard))[:64].cuda()
@@ -149,9 +152,20 @@ def test_tile_shapes_on_a_ragged_batch_and_run_to_run_determinism(setup, tile):
     finally:
         eng.set_fused_tile(0)
     (r, xs, Ps), (r2, xs2, Ps2) = outs
-    assert torch.equal(r["out"], r2["out"]) and torch.equal(r["x_out"], r2["x_out"]) and torch.equal(Ps, Ps2)
-    assert torch.equal(r["x_out"], full["x_out"][:, :, idx]) and torch.equal(Ps, P[:, idx]) and torch.equal(xs, x[:, idx])
+    assert torch.equal(r["out"], r2["out"]) and torch.equal(r["x_out"], r2["x_out"]) and torch.equal(Ps, Ps2) and torch.equal(xs, xs2)
+    assert (r["x_out"] - full["x_out"][:, :, idx]).abs().max().item() < 1e-6 and (Ps - P[:, idx]).abs().max().item() < 1e-9
+    assert (xs - x[:, idx]).abs().max().item() < 1e-6 and int((r["status"] != 0).sum()) == 0
     assert (r["out"] - full["out"][idx]).abs().max().item() < 1e-6
+    # within ONE shape a trajectory's result does not depend on its neighbours: a sub-slice run alone reproduces it bit for bit
+    sub = torch.arange(512, 512 + 1024 + 5, device="cuda")
+    s2 = {k: (v[..., sub].contiguous()) for k, v in s.items()}
+    eng.set_fused_tile(tile)
+    try:
+        xs3, Ps3 = s2["x0"].clone(), s2["P0"].clone()
+        r3 = eng.fused_run(s2["p"], s2["f"], s2["dp"], s2["imu"], s2["contact_p"], s2["accel"], mm, xs3, Ps3)
+    finally:
+        eng.set_fused_tile(0)
+    assert torch.equal(r3["x_out"], r["x_out"][:, :, sub]) and torch.equal(Ps3, Ps[:, sub]) and torch.equal(r3["out"], r["out"][sub])
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -29,14 +29,20 @@ def _json_line(stdout):
     return json.loads(lines[0])
 
 
-def _run_worker(world, port, train_batch=None):
+def _run_worker(world, port, train_batch=None, drop_rank=None):
     env = dict(ENV, OS_SHARE_GPU="1")
     if train_batch is not None:
         env["OS_WORKER_TRAIN_BATCH"] = str(train_batch)
+    if drop_rank is not None:
+        env["OS_WORKER_DROP_RANK"] = str(drop_rank)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "multi_gpu_worker.py")],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
+    if drop_rank is not None:
+        lost = [l for l in r.stdout.splitlines() if l.startswith("LOST ")]
+        assert len(lost) == 1, r.stdout
+        return _json_line(r.stdout), json.loads(lost[0][5:])
     return _json_line(r.stdout)
 
 
@@ -66,6 +72,42 @@ def test_three_ranks_ragged_shards_on_one_gpu():
     d = _run_worker(3, 29642, train_batch=4099)
     _check(d, 3)
     assert d["train_shard_sizes"] == [1367, 1366, 1366]
+
+
+def test_a_lost_producer_on_one_rank_never_reaches_the_collective():
+    """ADVICE r5 (medium x2): rank 1's stacked launches lose a producer in every step (OS_STACK_DBG_DROP on that rank's context only).
+    DataParallelTrainer.step verifies once between the backward and the all-reduce (os_stack_check) and redoes the step's forward,
+    loss and backward with a launch per layer BEFORE the gradients are reduced: rank 1 reports three redone steps, rank 0 none, the
+    replicas are identical and finite after three Adam steps and equal the clean single-process run on the full batch (fp32
+    reduction order), and each rank's context is back in its own stack mode."""
+    d, lost = _run_worker(2, 29644, drop_rank=1)
+    _check(d, 2)
+    by = {x["rank"]: x for x in lost["lost"]}
+    assert by[1]["lost_steps"] == 3 and by[0]["lost_steps"] == 0
+    assert by[0]["loss_finite"] and by[1]["loss_finite"] and by[0]["stack_mode_after"] == 1 and by[1]["stack_mode_after"] == 1
+    assert lost["weights_finite"] and lost["replica_weight_max_abs_diff"] == 0.0
+    assert lost["weight_vs_clean_run_max_abs_diff"] <= 3 * 2.0e-4 + 1e-7      # three steps of ~lr each; sign flips of noise-level entries
+
+
+def test_bench_scaling_strong_two_ranks_equal_the_one_rank_checksum():
+    """`bench.py --scaling strong`: the SAME 16,384 trajectories run by one rank and by two ranks (8,192 each, other tile shape) --
+    the global checksums agree to fp32 noise (SURVEY 8(e) determinism check), `value` counts the global batch once."""
+    outs = {}
+    for n in (1, 2):
+        args = ["--gpus", str(n), "--scaling", "strong", "--batch", "16384", "--seq", "20", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                "--parity-samples", "128", "--no-second-noise"] + (["--share-gpu"] if n > 1 else [])
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=ENV)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[n] = _json_line(r.stdout)
+    a, b = outs[1], outs[2]
+    assert a["scaling"] == b["scaling"] == "strong" and a["config"]["global_batch"] == b["config"]["global_batch"] == 16384
+    assert a["config"]["batch_per_gpu"] == 16384 and b["config"]["batch_per_gpu"] == 8192 and b["n_gpus"] == 2
+    assert a["kernels"]["fused"]["kernel"] == "fused_kf_gru_kernel_v3<1>" and b["kernels"]["fused"]["kernel"] == "fused_kf_gru_kernel_v3<2>"
+    ca, cb = a["global_checksum"], b["global_checksum"]
+    assert ca["trajectories"] == cb["trajectories"] == 16384
+    assert abs(ca["sum_x_final"] - cb["sum_x_final"]) < 1e-3 and abs(ca["sum_out"] - cb["sum_out"]) < 1e-2     # sums over 16,384 x 12 / x 24 values
+    assert abs(b["value"] - 16384 * 20 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+    assert b["parity"]["state_linf"] < 1e-4
 
 
 @pytest.mark.parametrize("mode", ["fused", "train"])
