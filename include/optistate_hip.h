@@ -130,11 +130,25 @@ const char *os_build_id(void);
  * attributes.  model: {dt, mass, Ixx, Iyy, Izz, g_z} in float64 or NULL for the context's (float32) configuration.
  * contact: 4 bytes (0/1).  status: bit 0 S not positive definite (the reference's np.linalg.inv raises), bit 1 non-finite x.
  * Unused pointers may be NULL (e.g. K, p_rot). */
-enum { OS_STEP_ODOM = 1, OS_STEP_PREDICT = 2, OS_STEP_UPDATE = 4, OS_STEP_DENSE_FD = 8 };
+enum { OS_STEP_ODOM = 1, OS_STEP_PREDICT = 2, OS_STEP_UPDATE = 4, OS_STEP_DENSE_FD = 8,
+       OS_STEP_MPC = 16 /* the predict's forces come from the convex-MPC QP solved on the device in front of the step (os_kf_step_mpc) */ };
 int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *f, const double *dp,
                const double *imu, const uint8_t *contact, const double *body_ref, const double *Q, const double *R,
                double *x, double *P, double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain,
                int32_t *status, void *stream);
+
+/* Kalman_Filter.estimate_state_mpc (kalman_filter/kalman_filter.py:176-182, the body of the caller loop
+ * data_collection/data_conversion_Kalman_to_Training.py:193-199) in ONE call: the stance controller's QP (:141-152;
+ * misc/force_controller.py:70-225) is solved on the device from the PRIOR state x, body_ref, p and the contact pattern, its horizon-step-0
+ * forces feed next_state, then get_odom + set_measurements + predict_mpc + update as `what` says (OS_STEP_MPC | OS_STEP_PREDICT are
+ * implied; pass OS_STEP_ODOM | OS_STEP_DENSE_FD | OS_STEP_UPDATE for the reference's sequence).  Two launches (the QP instance the
+ * contact word needs, warm-started from the context's previous solve when the contact pattern is unchanged; the float64 step kernel)
+ * and ONE stream synchronise.  f_all (optional): the (12, 5) control matrix the reference keeps in self.f, row-major; qp_iters
+ * (optional): active-set iterations; status bit 2: QP iteration cap.  Everything else as os_kf_step. */
+int os_kf_step_mpc(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *dp, const double *imu,
+                   const uint8_t *contact, const double *body_ref, const double *Q, const double *R, double *x, double *P,
+                   double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain, double *f_all,
+                   int32_t *qp_iters, int32_t *status, void *stream);
 
 /* Replaces the attribute writes KF.Q = Q; KF.R = R (data_collection/data_conversion_Kalman_to_Training.py:139-143).
  * Q host float[144], R host float[100], row-major. */

@@ -23,7 +23,7 @@ OS_STATUS_S_NOT_PD, OS_STATUS_NONFINITE, OS_STATUS_QP_ITER, OS_STATUS_P0_ASYM, O
 OS_STATUS_FAIL_MASK = 15
 OS_GRU_SPLIT_ANY_BATCH = 0x100
 OS_ERR_STACK_LOST = -20     # a layer-pipelined launch (gru_stack_kernel / bwd_sweep_stack_kernel) lost a producer: see os_gru_set_stack
-OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD = 1, 2, 4, 8
+OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD, OS_STEP_MPC = 1, 2, 4, 8, 16
 OS_PROF_PHASES = 12         # include/optistate_hip.h
 PHASE_NAMES = ("kf", "gru_layer", "gru_head", "fused", "mpc", "train_sweep", "train_dw", "train_misc", "vit_gemm",
                "vit_attn", "vit_misc", "pack")
@@ -38,7 +38,7 @@ EXPORTS = [
     "os_kf_run_noise", "os_gru_generation", "os_gru_train_ws_floats", "os_gru_forward_train_ws", "os_gru_backward_ws",
     "os_profile_kernel_name", "os_build_id", "os_kf_step", "os_gru_load_keyed", "os_pack_stream_rows", "os_gru_backward_mark",
     "os_gru_forward_windows", "os_gru_bands", "os_gru_set_stack", "os_gru_set_split_bf16",
-    "os_gru_get_stack", "os_fused_set_tile", "os_stack_check",
+    "os_gru_get_stack", "os_fused_set_tile", "os_stack_check", "os_kf_step_mpc",
 ]
 
 
@@ -150,6 +150,8 @@ def load():
     lib.os_kf_run_noise.restype = C.c_int
     lib.os_kf_step.argtypes = [vp, u32] + [vp] * 19
     lib.os_kf_step.restype = C.c_int
+    lib.os_kf_step_mpc.argtypes = [vp, u32] + [vp] * 20
+    lib.os_kf_step_mpc.restype = C.c_int
     lib.os_gru_generation.argtypes = [vp]
     lib.os_gru_generation.restype = C.c_uint64
     lib.os_gru_train_ws_floats.argtypes = [C.POINTER(OsGruDims), i32, i32]

@@ -66,7 +66,16 @@ __device__ __forceinline__ double rsqrt_nr(double a)
 // One filter step on the LDS-resident block M (one wavefront; the caller has filled M.io and synchronised).  Returns the status bits.
 __device__ __forceinline__ int step_body(StepMem &M, const int lane);
 
-__global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
+// the QP's side of an OS_STEP_MPC step: float32 copies of its inputs, its outputs (pinned, device-mapped like StepIO)
+struct StepMpc {
+    float x[12], ref[12], p[12];
+    uint32_t contact;
+    int32_t iters, status, pad;
+    float u[60];
+};
+
+// mpc_f: null, or the forces of horizon step 0 the QP launch in front of this kernel left in device memory (OS_STEP_MPC)
+__global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g, const float *__restrict__ mpc_f)
 {
     __shared__ StepMem M;
     const int lane = threadIdx.x;
@@ -85,6 +94,10 @@ __global__ __launch_bounds__(64, 1) void kf_step_kernel(StepIO *__restrict__ g)
             if (lane + 64 * i < IO_IN_DOUBLES) dst[lane + 64 * i] = v[i];
     }
     __syncthreads();
+    if (mpc_f) {                     // f = self.f[:, 0] of the QP just solved (kalman_filter.py:150-152,161)
+        if (lane < 12) io.f[lane] = (double)mpc_f[lane];
+        __syncthreads();
+    }
     const int status = step_body(M, lane);
     __syncthreads();
     if (lane == 0) io.status = status;
@@ -423,27 +436,38 @@ int os_kf_run_wave(os_ctx *ctx, const osk::KfRunArgs &a, hipStream_t s)
 
 struct os_step_state {
     oss::StepIO *host, *dev;
+    oss::StepMpc *mhost, *mdev;          // behind the StepIO in the same pinned allocation
+    float *mpc_f;                        // device: the QP's horizon-step-0 forces, read by the step kernel
+    double *warm_u; uint8_t *warm_state; uint32_t *warm_contact;     // device: the context's QP warm start (os_mpc_solve_one)
 };
+
+int os_mpc_solve_one(os_ctx *ctx, const float *x, const float *body_ref, const float *p, const uint32_t *contact, uint32_t contact_word,
+                     float *f_out, float *u_out, int32_t *iters, int32_t *status, double *warm_u, uint8_t *warm_state, uint32_t *warm_contact,
+                     hipStream_t s);      // mpc_kernels.hip
 
 void os_step_destroy(os_ctx *ctx)
 {
     os_step_state *st = (os_step_state *)ctx->step;
     if (!st) return;
     if (st->host) (void)hipHostFree(st->host);
+    if (st->mpc_f) (void)hipFree(st->mpc_f);
+    if (st->warm_u) (void)hipFree(st->warm_u);
     free(st);
     ctx->step = nullptr;
 }
 
-extern "C" int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *f, const double *dp, const double *imu,
-                          const uint8_t *contact, const double *body_ref, const double *Q, const double *R, double *x, double *P,
-                          double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain, int32_t *status,
-                          void *stream)
+static int kf_step_impl(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *f, const double *dp, const double *imu,
+                        const uint8_t *contact, const double *body_ref, const double *Q, const double *R, double *x, double *P,
+                        double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain, int32_t *status,
+                        double *f_all, int32_t *qp_iters, void *stream)
 {
     OS_CHECK_CTX(ctx);
     const bool odom = what & OS_STEP_ODOM, pred = what & OS_STEP_PREDICT, upd = what & OS_STEP_UPDATE, dense = what & OS_STEP_DENSE_FD;
+    const bool mpc = what & OS_STEP_MPC;
     if (!(odom || pred || upd)) return os_fail(ctx, -2, "os_kf_step: nothing to do (what = 0)");
     if (odom && (!p || !dp || !imu || !contact || !z)) return os_fail(ctx, -2, "os_kf_step: OS_STEP_ODOM needs p, dp, imu, contact, z");
-    if (pred && (!p || !f || !x || !P || !Q)) return os_fail(ctx, -2, "os_kf_step: OS_STEP_PREDICT needs p, f, x, P, Q");
+    if (mpc && (!pred || !body_ref || !contact || !p || !x)) return os_fail(ctx, -2, "os_kf_step: OS_STEP_MPC needs OS_STEP_PREDICT and x, p, body_ref, contact");
+    if (pred && (!p || (!f && !mpc) || !x || !P || !Q)) return os_fail(ctx, -2, "os_kf_step: OS_STEP_PREDICT needs p, f, x, P, Q");
     if (pred && dense && !body_ref) return os_fail(ctx, -2, "os_kf_step: OS_STEP_DENSE_FD needs body_ref");
     if (upd && (!x || !P || !z || !R)) return os_fail(ctx, -2, "os_kf_step: OS_STEP_UPDATE needs x, P, z, R");
     OS_HIP(ctx, hipSetDevice(ctx->device));
@@ -451,14 +475,26 @@ extern "C" int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const
     if (!st) {
         st = (os_step_state *)calloc(1, sizeof(os_step_state));
         if (!st) return os_fail(ctx, -13, "os_kf_step: out of memory");
-        if (hipHostMalloc((void **)&st->host, sizeof(oss::StepIO), hipHostMallocMapped) != hipSuccess ||
+        if (hipHostMalloc((void **)&st->host, sizeof(oss::StepIO) + sizeof(oss::StepMpc), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&st->dev, st->host, 0) != hipSuccess) {
             if (st->host) (void)hipHostFree(st->host);
             free(st);
             return os_fail(ctx, -10, "os_kf_step: cannot allocate the pinned staging block");
         }
-        memset(st->host, 0, sizeof(oss::StepIO));
+        memset(st->host, 0, sizeof(oss::StepIO) + sizeof(oss::StepMpc));
+        st->mhost = reinterpret_cast<oss::StepMpc *>(st->host + 1);
+        st->mdev = reinterpret_cast<oss::StepMpc *>(st->dev + 1);
         ctx->step = st;
+    }
+    if (mpc && !st->mpc_f) {
+        // the QP's device-side state: forces of horizon step 0 (12 floats) and the warm start (u [64] doubles, faces [64] bytes, contact word)
+        if (hipMalloc((void **)&st->mpc_f, 16 * sizeof(float)) != hipSuccess || hipMalloc((void **)&st->warm_u, 64 * sizeof(double) + 64 + 16) != hipSuccess)
+            return os_fail(ctx, -10, "os_kf_step: cannot allocate the QP state");
+        st->warm_state = reinterpret_cast<uint8_t *>(st->warm_u + 64);
+        st->warm_contact = reinterpret_cast<uint32_t *>(st->warm_state + 64);
+        OS_HIP(ctx, hipMemset(st->warm_u, 0, 64 * sizeof(double)));
+        OS_HIP(ctx, hipMemset(st->warm_state, 0x05, 64));
+        OS_HIP(ctx, hipMemset(st->warm_contact, 0xff, 16));
     }
     oss::StepIO &io = *st->host;
     auto put = [](double *d, const double *s, int n) { if (s) memcpy(d, s, sizeof(double) * n); };
@@ -475,11 +511,30 @@ extern "C" int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const
         for (int i = 0; i < 3; i++) io.inv_inertia[i] = 1.0 / ctx->inertia64[i];
     }
     hipStream_t s = (hipStream_t)stream;
+    if (mpc) {
+        // kalman_filter.py:141-152: the stance controller's QP from the PRIOR state, the reference pose, the foot positions and the
+        // contact pattern (float32 inputs as os_mpc_solve takes them, float64 inside); its launch goes out in front of the step
+        // kernel on the same stream -- one synchronise for both
+        oss::StepMpc &m = *st->mhost;
+        for (int i = 0; i < 12; i++) { m.x[i] = (float)x[i]; m.ref[i] = (float)body_ref[i]; m.p[i] = (float)p[i]; }
+        m.contact = io.contact; m.status = 0; m.iters = 0;
+        if (int rc = os_mpc_solve_one(ctx, st->mdev->x, st->mdev->ref, st->mdev->p, &st->mdev->contact, io.contact, st->mpc_f, st->mdev->u,
+                                      &st->mdev->iters, &st->mdev->status, st->warm_u, st->warm_state, st->warm_contact, s))
+            return rc;
+    }
     const int slot = os_prof_begin(ctx, OS_PHASE_KF, s, "kf_step_kernel");
-    hipLaunchKernelGGL(oss::kf_step_kernel, dim3(1), dim3(64), 0, s, st->dev);
+    hipLaunchKernelGGL(oss::kf_step_kernel, dim3(1), dim3(64), 0, s, st->dev, mpc ? (const float *)st->mpc_f : (const float *)nullptr);
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     OS_HIP(ctx, hipStreamSynchronize(s));                     // the results are in host memory from here on
+    if (mpc) {
+        // the (12, 5) control matrix the reference keeps in self.f, column h = horizon step h (u is [h][12])
+        if (f_all)
+            for (int h = 0; h < 5; h++)
+                for (int i = 0; i < 12; i++) f_all[i * 5 + h] = (double)st->mhost->u[h * 12 + i];
+        if (qp_iters) *qp_iters = st->mhost->iters;
+        if (st->mhost->status & 4) io.status |= 4;            // QP iteration cap (as os_mpc_solve reports it)
+    }
     auto get = [](double *d, const double *s, int n) { if (d) memcpy(d, s, sizeof(double) * n); };
     if (odom) get(z, io.z, 10);
     if (pred) { get(x, io.x, 12); get(P, io.P, 144); get(p_rot, io.p, 12); get(x_model, io.x_model, 12); }
@@ -487,4 +542,22 @@ extern "C" int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const
     if ((pred && !dense) || upd) { if (ptrace) *ptrace = io.ptrace; }
     if (status) *status = io.status;
     return 0;
+}
+
+extern "C" int os_kf_step(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *f, const double *dp, const double *imu,
+                          const uint8_t *contact, const double *body_ref, const double *Q, const double *R, double *x, double *P,
+                          double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain, int32_t *status,
+                          void *stream)
+{
+    return kf_step_impl(ctx, what, model, p, f, dp, imu, contact, body_ref, Q, R, x, P, z, p_rot, x_model, K, ptrace, kgain, status, nullptr, nullptr,
+                        stream);
+}
+
+extern "C" int os_kf_step_mpc(os_ctx *ctx, uint32_t what, const double *model, const double *p, const double *dp, const double *imu,
+                              const uint8_t *contact, const double *body_ref, const double *Q, const double *R, double *x, double *P,
+                              double *z, double *p_rot, double *x_model, double *K, double *ptrace, double *kgain, double *f_all,
+                              int32_t *qp_iters, int32_t *status, void *stream)
+{
+    return kf_step_impl(ctx, what | OS_STEP_MPC | OS_STEP_PREDICT, model, p, nullptr, dp, imu, contact, body_ref, Q, R, x, P, z, p_rot, x_model, K, ptrace,
+                        kgain, status, f_all, qp_iters, stream);
 }

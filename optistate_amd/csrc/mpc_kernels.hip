@@ -965,6 +965,30 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
     return 0;
 }
 
+}  // extern "C"
+
+// One QP for os_kf_step's OS_STEP_MPC form (kf_step.hip): B = 1, only the solver instance the contact word needs is launched, warm
+// start from the context's previous solve when the contact pattern is unchanged (the pyramids do not move: the old u stays feasible).
+int os_mpc_solve_one(os_ctx *ctx, const float *x, const float *body_ref, const float *p, const uint32_t *contact, uint32_t contact_word,
+                     float *f_out, float *u_out, int32_t *iters, int32_t *status, double *warm_u, uint8_t *warm_state, uint32_t *warm_contact,
+                     hipStream_t s)
+{
+    osm::MpcArgs a;
+    a.B = 1; a.x = x; a.ref = body_ref; a.p = p; a.contact = contact; a.f_out = f_out; a.u_out = u_out; a.iters = iters;
+    a.status = status; a.max_iter = 200;
+    a.warm_u = warm_u; a.warm_state = warm_state; a.warm_contact = warm_contact;
+    osm::fill_args(ctx, a);
+    int nst = 0;
+    for (int l = 0; l < 4; l++) nst += ((contact_word >> (8 * l)) & 0xffu) == 1u;
+    const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
+    osm::launch_instances(a, 1u << nst, s);
+    os_prof_end(ctx, slot, s);
+    if (hipGetLastError() != hipSuccess) return os_fail(ctx, -10, "os_kf_step: QP launch failed");
+    return 0;
+}
+
+extern "C" {
+
 int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
                   const uint32_t *contact, const float *body_ref, float *x, float *P, float *x_out, float *f_out,
                   float *p_rot_out, float *ptrace_out, float *kgain_out, int32_t *mpc_iters, int32_t *status,

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from .engine import default_engine
-from ._capi import OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD
+from ._capi import OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD, OS_STEP_MPC
 from . import synth
 
 
@@ -68,13 +68,15 @@ class Kalman_Filter:
         foreign call (at B = 1 the Python side is as much of the latency as the launch)."""
         dp = C.POINTER(C.c_double)
         b = {k: np.zeros(n) for k, n in (("x", 12), ("P", 144), ("z", 10), ("p", 12), ("f", 12), ("dp", 12), ("imu", 6), ("br", 12),
-                                          ("Q", 144), ("R", 100), ("prot", 12), ("xm", 12), ("K", 120), ("pt", 1), ("kg", 1))}
+                                          ("Q", 144), ("R", 100), ("prot", 12), ("xm", 12), ("K", 120), ("pt", 1), ("kg", 1), ("fall", 60))}
         b["c"] = np.zeros(4, dtype=np.uint8)
         b["st"] = np.zeros(1, dtype=np.int32)
+        b["it"] = np.zeros(1, dtype=np.int32)
         b["model"] = self._MODEL.copy()
         ptr = {k: v.ctypes.data_as(dp) for k, v in b.items() if v.dtype == np.float64}
         ptr["c"] = b["c"].ctypes.data_as(C.POINTER(C.c_uint8))
         ptr["st"] = b["st"].ctypes.data_as(C.POINTER(C.c_int32))
+        ptr["it"] = b["it"].ctypes.data_as(C.POINTER(C.c_int32))
         self._b, self._ptr = b, ptr
 
     def _step(self, what, p=None, f=None, dp=None, imu=None, contact=None, body_ref=None, want_K=False):
@@ -95,13 +97,22 @@ class Kalman_Filter:
             b["c"][:] = np.asarray(contact).reshape(-1)[:4]
         lock = e.__dict__.setdefault("_kf_step_lock", threading.Lock())     # the context's staging block is shared by every instance
         with lock:                                     # os_kf_step returns after its stream synchronise: results are in b[...] here
-            rc = e.lib.os_kf_step(e._h, what, q["model"], q["p"] if p is not None else None, q["f"] if f is not None else None,
-                                  q["dp"] if dp is not None else None, q["imu"] if imu is not None else None,
-                                  q["c"] if contact is not None else None, q["br"] if body_ref is not None else None, q["Q"], q["R"],
-                                  q["x"], q["P"], q["z"], q["prot"], q["xm"], q["K"] if want_K else None, q["pt"], q["kg"], q["st"],
-                                  e._stream())
+            if what & OS_STEP_MPC:                     # the QP in front of the step, one call (os_kf_step_mpc)
+                rc = e.lib.os_kf_step_mpc(e._h, what, q["model"], q["p"], q["dp"] if dp is not None else None, q["imu"] if imu is not None else None,
+                                          q["c"], q["br"], q["Q"], q["R"], q["x"], q["P"], q["z"], q["prot"], q["xm"],
+                                          q["K"] if want_K else None, q["pt"], q["kg"], q["fall"], q["it"], q["st"], e._stream())
+            else:
+                rc = e.lib.os_kf_step(e._h, what, q["model"], q["p"] if p is not None else None, q["f"] if f is not None else None,
+                                      q["dp"] if dp is not None else None, q["imu"] if imu is not None else None,
+                                      q["c"] if contact is not None else None, q["br"] if body_ref is not None else None, q["Q"], q["R"],
+                                      q["x"], q["P"], q["z"], q["prot"], q["xm"], q["K"] if want_K else None, q["pt"], q["kg"], q["st"],
+                                      e._stream())
         if rc:
             e._check(rc, "os_kf_step")
+        if what & OS_STEP_MPC:
+            if b["st"][0] & 4:
+                raise RuntimeError("convex MPC: active-set iteration cap reached")       # qpOASES would report a failed solve
+            self.f = b["fall"].reshape(12, 5).copy()                  # the (12, N) control matrix of kalman_filter.py:150-152
         if what & OS_STEP_ODOM:
             self.z = b["z"].reshape(10, 1).copy()
         if what & OS_STEP_PREDICT:
@@ -184,16 +195,26 @@ class Kalman_Filter:
         return r["u"].cpu().numpy().astype(np.float64).reshape(5, 12).T.copy()
 
     def predict_mpc(self, p, body_ref, cur_contact, f=None):
-        """kalman_filter.py:140-162.  f (12,) or (12,N), column 0 used: forces from a log; None: solve the QP here."""
-        self.f = self.solve_mpc(p, body_ref, cur_contact) if f is None else np.asarray(f, dtype=np.float64).reshape(12, -1)
+        """kalman_filter.py:140-162.  f (12,) or (12,N), column 0 used: forces from a log; None: the QP is solved on the GPU in
+        front of the step, in the same call (os_kf_step_mpc)."""
+        if f is None:
+            self._rotate_in_place(p, self._step(OS_STEP_PREDICT | OS_STEP_DENSE_FD | OS_STEP_MPC, p=p, body_ref=body_ref, contact=cur_contact))
+            return
+        self.f = np.asarray(f, dtype=np.float64).reshape(12, -1)
         self._rotate_in_place(p, self._step(OS_STEP_PREDICT | OS_STEP_DENSE_FD, p=p, f=self.f[:, 0], body_ref=body_ref))
 
     def estimate_state_mpc(self, imu, p, dp, body_ref, contact, f=None):
         """kalman_filter.py:176-182: get_odom + set_measurements + predict_mpc + update as ONE launch (float64 throughout:
         predict_mpc's element-wise exp(dt F) makes P ill-conditioned for float32); x, P, z, x_model, K, P_trace, K_gain and f
         are set as the reference leaves them."""
-        # f = None: the convex MPC of kalman_filter.py:141-152 is solved on the GPU (os_mpc_solve); otherwise forces from a log
-        self.f = self.solve_mpc(p, body_ref, contact) if f is None else np.asarray(f, dtype=np.float64).reshape(12, -1)
+        # f = None: the convex MPC of kalman_filter.py:141-152 is solved on the GPU in front of the step kernel, both launches behind
+        # ONE call and ONE stream synchronise (os_kf_step_mpc; round 6: the separate solve_mpc call through torch tensors was 157 of
+        # the loop's 194 us per step, profiles/r06_dropin_loops.json); otherwise forces from a log
+        if f is None:
+            self._rotate_in_place(p, self._step(OS_STEP_ODOM | OS_STEP_PREDICT | OS_STEP_DENSE_FD | OS_STEP_UPDATE | OS_STEP_MPC, p=p, dp=dp,
+                                                imu=imu, contact=contact, body_ref=body_ref, want_K=True))
+            return self.x
+        self.f = np.asarray(f, dtype=np.float64).reshape(12, -1)
         self._rotate_in_place(p, self._step(OS_STEP_ODOM | OS_STEP_PREDICT | OS_STEP_DENSE_FD | OS_STEP_UPDATE, p=p, f=self.f[:, 0], dp=dp,
                                             imu=imu, contact=contact, body_ref=body_ref, want_K=True))
         return self.x

@@ -78,7 +78,7 @@ def test_split_bf16_ragged_batch_and_default_is_still_fp32():
     assert name == "fused_kf_gru_bf16_kernel<3>" and st == 0 and e_state < 1e-4 and e_out < 1e-5
     torch.manual_seed(5)
     name, e_state, e_out, st = _run(333, 37, seed=8, split=False)
-    assert name == "fused_kf_gru_kernel_v2" and e_out < 1e-5        # the flag is opt-in: the default never takes the bf16 path
+    assert name.startswith("fused_kf_gru_kernel_v") and "bf16" not in name and e_out < 1e-5      # the flag is opt-in: the default never takes the bf16 path (an fp32 tile shape picked for the batch)
 
 
 def test_split_bf16_refuses_other_shapes():

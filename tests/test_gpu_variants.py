@@ -31,11 +31,13 @@ def _feature_rows(d, ref):
                            d["dp"].astype(np.float64), d["imu"].astype(np.float64)], axis=2)
 
 
-@pytest.mark.parametrize("layers,split,two_kernel,B", [(1, False, False, 700), (2, False, False, 700), (1, 3, False, 700), (1, 2, False, 700),
-                                                       (2, False, True, 8256)])
-def test_fused_run_with_a_full_process_noise_matrix(layers, split, two_kernel, B):
-    """fused_kf_gru_kernel_v2<fullQ, *>, fused_kf_gru_bf16_kernel<fullQ, 2|3> and -- two-kernel path at a batch past the rows kernel's
-    range -- kf_run_sym_kernel<features, fullQ>: KF state and GRU head against the oracle chain."""
+@pytest.mark.parametrize("layers,split,two_kernel,B,tile", [(1, False, False, 700, 256), (2, False, False, 700, 256), (1, 3, False, 700, 0), (1, 2, False, 700, 0),
+                                                            (2, False, True, 8256, 0), (1, False, False, 700, 128), (2, False, False, 700, 128),
+                                                            (1, False, False, 700, 64), (1, False, False, 700, 32), (1, False, False, 700, 16)])
+def test_fused_run_with_a_full_process_noise_matrix(layers, split, two_kernel, B, tile):
+    """fused_kf_gru_kernel_v2<fullQ, *, 2 | 1> (tiles 256 / 128), fused_kf_gru_kernel_v3<fullQ, 1 | 2 | 4> (tiles 64 / 32 / 16),
+    fused_kf_gru_bf16_kernel<fullQ, 2|3> and -- two-kernel path at a batch past the rows kernel's range --
+    kf_run_sym_kernel<features, fullQ>: KF state and GRU head against the oracle chain."""
     from optistate_amd import Engine, RNN, flatten_state_dict
     from optistate_amd.synth import synth_numpy, R_FITTED
     from oracle import c_oracle as orc
@@ -50,6 +52,7 @@ def test_fused_run_with_a_full_process_noise_matrix(layers, split, two_kernel, B
     ref_out, _, _ = orc.gru_forward((rows - mn) / (mx - mn), orc.flatten_state_dict(m.state_dict(), layers), 60, 64, layers, 24)
     eng = Engine(0)
     eng.set_noise(Q, R)
+    eng.set_fused_tile(tile)
     eng.load_gru(flatten_state_dict(m.state_dict(), layers), 60, 64, layers, 24)
     s = {k: eng.pack(torch.as_tensor(d[k])) for k in ("p", "f", "dp", "imu", "accel")}
     c = eng.pack_contact(torch.as_tensor(d["contact"]))
@@ -60,8 +63,12 @@ def test_fused_run_with_a_full_process_noise_matrix(layers, split, two_kernel, B
     torch.cuda.synchronize()
     if two_kernel:
         assert eng.kernel_name("kf") == "kf_run_sym_kernel"
+    elif split:
+        assert eng.kernel_name("fused").startswith("fused_kf_gru_bf16_kernel")
     else:
-        assert eng.kernel_name("fused").startswith("fused_kf_gru_bf16_kernel" if split else "fused_kf_gru_kernel_v2")
+        want = {256: "fused_kf_gru_kernel_v2", 128: "fused_kf_gru_kernel_v2<32 per wave>", 64: "fused_kf_gru_kernel_v3<1>",
+                32: "fused_kf_gru_kernel_v3<2>", 16: "fused_kf_gru_kernel_v3<4>"}[tile]
+        assert eng.kernel_name("fused") == want
     assert int(eng.failed(r["status"]).sum()) == 0
     assert np.abs(eng.unpack(r["x_out"]).cpu().numpy() - ref["x"]).max() < STATE_TOL
     assert np.abs(r["out"].cpu().numpy() - ref_out).max() < 1e-5
