@@ -20,8 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liboptistate_hip.so")
-SOURCES = ["capi.hip", "kf_kernels.hip", "kf_rows_kernel.hip", "kf_dense_rows.hip", "kf_step.hip", "gru_kernels.hip", "gru_bf16_kernels.hip", "gru_wide_kernel.hip", "fused_kernels.hip", "gru_train_kernels.hip", "vit_kernels.hip", "mpc_kernels.hip"]
-HEADERS = ["kf_device.hpp", "kf_dense_rows.hpp", "kf_args.hpp", "kf_rows_chain.inc", "gru_common.hpp", "gru_device.hpp", "launch.hpp", os.path.join("..", "..", "include", "optistate_hip.h")]
+SOURCES = ["capi.hip", "kf_kernels.hip", "kf_rows_kernel.hip", "kf_dense_rows.hip", "kf_step.hip", "gru_kernels.hip", "gru_bf16_kernels.hip", "gru_wide_kernel.hip", "fused_kernels.hip", "gru_train_kernels.hip", "vit_kernels.hip", "mpc_kernels.hip", "mpc_quad.hip"]
+HEADERS = ["kf_device.hpp", "kf_dense_rows.hpp", "kf_args.hpp", "kf_rows_chain.inc", "gru_common.hpp", "gru_device.hpp", "launch.hpp", "mpc_common.hpp", os.path.join("..", "..", "include", "optistate_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 # per-file additions (the reason is in the file's header)

@@ -30,34 +30,9 @@
 
 #include "kf_dense_rows.hpp"
 #include "kf_args.hpp"
+#include "mpc_common.hpp"
 
 namespace osm {
-
-constexpr int NVMAX = 60, NLSMAX = 20;
-enum : int { SZ_FREE = 0, SZ_ZERO = 1, SZ_MAX = 2 };
-
-struct MpcParams {
-    double w[12];            // state weights (kalman_filter/kalman_filter.py:64), terminal = stage (:72)
-    double rw, mu, fzmax;    // control weight (:66), friction coefficient and force cap (force_controller.py:147-149)
-    double dt, inv_mass, inv_inertia[3], gz;
-};
-
-struct MpcArgs {
-    int B;
-    const float *x, *ref, *p;      // [12][B]
-    const uint32_t *contact;       // [B] 4 packed bytes
-    float *f_out;                  // [12][B] forces of horizon step 0
-    float *u_out;                  // [60][B] or null
-    int32_t *iters;                // [B] or null
-    int32_t *status;               // [B] bit 2 set when the iteration cap was hit (or-ed in)
-    int max_iter;
-    // warm start across the steps of os_kf_mpc_run (null: always cold): the previous step's solution and faces are reused
-    // when the trajectory's contact word is unchanged (the pyramids do not move, so the old u stays feasible)
-    double *warm_u;                // [B][64]
-    uint8_t *warm_state;           // [B][64]  (sx+1) | (sy+1) << 2 | sz << 4 of the lane's leg-step
-    uint32_t *warm_contact;        // [B]
-    MpcParams prm;
-};
 
 template <int NV_>
 struct WaveMemT {
@@ -72,70 +47,6 @@ struct WaveMemT {
     double ab[25][2];        // (al, be) of alpha_beta() for the horizon-step pairs (i, l) at [5 i + l]: one LDS read instead of ~25
                              // integer / conversion instructions per block of the row formation
 };
-
-// 1/a to full double precision: v_rcp_f64 + two Newton steps (an IEEE division costs ~4x as many instructions)
-__device__ __forceinline__ double rcp64(double a)
-{
-    double r = __builtin_amdgcn_rcp(a);
-    r = fma(fma(-a, r, 1.0), r, r);
-    r = fma(fma(-a, r, 1.0), r, r);
-    return r;
-}
-
-// 1/sqrt(a) to full double precision: v_rsq_f64 + two Newton steps (1.0 / sqrt(a) in IEEE form is ~500 cycles of a
-// ten-column Cholesky's critical path here, this ~100)
-__device__ __forceinline__ double rsqrt64(double a)
-{
-    double r = __builtin_amdgcn_rsq(a);
-    const double h = 0.5 * a;
-    r = r * fma(-h * r, r, 1.5);
-    r = r * fma(-h * r, r, 1.5);
-    return r;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-// sin / cos in double for the attitude angles of a walking robot: below 0.5 rad the Taylor series to theta^15 / theta^16 is
-// exact to 1e-16 (sixteen FMAs instead of the library's range reduction); anything larger takes the library (wave-uniform)
-__device__ __forceinline__ void sincos_small(double t, double *s, double *c)
-{
-    if (__builtin_amdgcn_ballot_w64(!(fabs(t) < 0.5)) != 0ull) { sincos(t, s, c); return; }
-    const double u = t * t;
-    double ps = -1.0 / 1307674368000.0;                                     // -1/15!
-    ps = fma(ps, u, 1.0 / 6227020800.0); ps = fma(ps, u, -1.0 / 39916800.0); ps = fma(ps, u, 1.0 / 362880.0);
-    ps = fma(ps, u, -1.0 / 5040.0); ps = fma(ps, u, 1.0 / 120.0); ps = fma(ps, u, -1.0 / 6.0); ps = fma(ps, u, 1.0);
-    double pc = 1.0 / 20922789888000.0;                                     // 1/16!
-    pc = fma(pc, u, -1.0 / 87178291200.0); pc = fma(pc, u, 1.0 / 479001600.0); pc = fma(pc, u, -1.0 / 3628800.0);
-    pc = fma(pc, u, 1.0 / 40320.0); pc = fma(pc, u, -1.0 / 720.0); pc = fma(pc, u, 1.0 / 24.0); pc = fma(pc, u, -0.5);
-    pc = fma(pc, u, 1.0);
-    *s = ps * t;
-    *c = pc;
-}
-
-__device__ __forceinline__ void rotation64(double tx, double ty, double tz, double *R)
-{
-    double sx, cx, sy, cy, sz, cz;
-    sincos_small(tx, &sx, &cx); sincos_small(ty, &sy, &cy); sincos_small(tz, &sz, &cz);
-    R[0] = cz * cy; R[1] = cz * sy * sx - sz * cx; R[2] = cz * sy * cx + sz * sx;
-    R[3] = sz * cy; R[4] = sz * sy * sx + cz * cx; R[5] = sz * sy * cx - cz * sx;
-    R[6] = -sy;     R[7] = cy * sx;                R[8] = cy * cx;
-}
-
-// al, be of the header comment for horizon steps i, l
-__device__ __forceinline__ void alpha_beta(int i, int l, double dt, double &al, double &be)
-{
-    const int m = i > l ? i : l;
-    int s = 0;
-#pragma unroll
-    for (int k = 1; k <= 5; k++) s += (k > m) ? (k - 1 - i) * (k - 1 - l) : 0;
-    const double dt2 = dt * dt;
-    al = dt2 * (double)(5 - m);
-    be = dt2 * dt2 * (double)s;
-}
 
 struct LaneCtx {
     int lane, v, i, leg, c, ls;
@@ -305,22 +216,6 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     return L.pad ? 0.0 : u;
 }
 
-// The non-zero contact bytes in leg order (the swing legs squeezed out).  A warm start is valid whenever THIS word is unchanged:
-// lane v of an instance is (horizon step, rank among the force-carrying legs, component), so the previous solution and faces
-// map onto the new legs rank by rank, the pyramids are the same for every leg, and the start stays feasible.  (Requiring the
-// identical contact word made every gait phase change a cold start: ~38 active-set iterations against 2-4.)
-__device__ __forceinline__ uint32_t contact_ranks(uint32_t c)
-{
-    uint32_t out = 0;
-    int n = 0;
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-        const uint32_t byte = (c >> (8 * l)) & 0xffu;
-        if (byte) { out |= byte << (8 * n); n++; }
-    }
-    return out;
-}
-
 // Per-lane solver state that survives a call: the lane's variable and the face of its leg-step (warm start of the next step)
 struct QpLane {
     double u;
@@ -462,6 +357,13 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
     while (!done && iters < max_iter) {
         iters++;
         const double us = solve_face<NST, UNR>(L, P, M, sx, sy, sz, cw, cv);
+#ifdef OS_MPC_DBG
+        if (L.lane == 0) {
+            printf("wave it %d sol:", iters);
+            for (int q = 0; q < NV; q++) printf(" %.4e", M.vec[q]);
+            printf("\n");
+        }
+#endif
         if (first) {
             // clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
             first = false;
@@ -544,6 +446,9 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
                 else if (s != 0) u = (double)s * P.mu * fz;
             }
         }
+#ifdef OS_MPC_DBG
+        if (L.lane == 0) printf("wave it %d ratio: amin %.6e lsmin %d cmin %d\n", iters, amin, lsmin, cmin);
+#endif
         if (lsmin >= 0) continue;
 
         // subspace minimiser reached: multiplier signs
@@ -590,6 +495,15 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
             for (int q = 0; q < NLS; q++)
                 if (cdq[q] != 0 && alq[q] > rmax) { rmax = alq[q]; lsr = q; cr = cdq[q]; }
         }
+#ifdef OS_MPC_DBG
+        if (L.lane == 0) {
+            printf("wave it %d mult: rmax %.6e lsr %d cr %d | al:", iters, rmax, lsr, cr);
+            for (int q = 0; q < NLS; q++) printf(" %.3e/%d", M.al[q], M.code[q]);
+            printf(" | grad:");
+            for (int q = 0; q < NV; q++) printf(" %.3e", M.rowbuf[q]);
+            printf("\n");
+        }
+#endif
         if (lsr < 0) { done = true; converged = true; break; }
         if (L.ls == lsr && !L.pad) {
             if (cr == 1) sx = 0;
@@ -915,14 +829,27 @@ static void fill_args(os_ctx *ctx, MpcArgs &a)
     for (int i = 0; i < 3; i++) a.prm.inv_inertia[i] = 1.0 / ctx->inertia64[i];
 }
 
-// nst_mask: bit n set = launch the instance for n legs on the ground (bit 0 rides on the 1-leg instance)
-static void launch_instances(const MpcArgs &a, uint32_t nst_mask, hipStream_t s)
+}  // namespace osm
+void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s);      // mpc_quad.hip
+namespace osm {
+
+// nst_mask: bit n set = launch the instance for n legs on the ground (bit 0 rides on the 1-leg instance).  Batches of at least
+// ctx->tune_mpc_quad problems: those with one / two force-carrying legs (15 / 30 variables) run sixteen lanes each, four to a
+// wavefront, rows fetching problems from a work counter (mpc_quad.hip); three / four legs stay on the wavefront-per-QP instances.
+static int launch_instances(os_ctx *ctx, const MpcArgs &a, uint32_t nst_mask, hipStream_t s)
 {
     const dim3 grid(a.B), block(64);
+    if (ctx->tune_mpc_quad != 0 && a.B >= ctx->tune_mpc_quad && (nst_mask & 7u)) {
+        if (!ctx->mpc_counters && hipMalloc((void **)&ctx->mpc_counters, 64) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: cannot allocate the work counters");
+        if (hipMemsetAsync(ctx->mpc_counters, 0, 8, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
+        os_mpc_launch_quad(a, nst_mask & 7u, ctx->mpc_counters, ctx->cu_count, s);
+        nst_mask &= ~7u;
+    }
     if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a);
     if (nst_mask & 4u) hipLaunchKernelGGL(mpc_solve_kernel<2>, grid, block, 0, s, a);
     if (nst_mask & 8u) hipLaunchKernelGGL(mpc_solve_kernel<3>, grid, block, 0, s, a);
     if (nst_mask & 16u) hipLaunchKernelGGL(mpc_solve_kernel<4>, grid, block, 0, s, a);
+    return 0;
 }
 
 }  // namespace osm
@@ -959,7 +886,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
     osm::fill_args(ctx, a);
     hipStream_t s = (hipStream_t)stream;
     const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
-    osm::launch_instances(a, 31u, s);       // all leg counts: a wavefront whose problem has another count exits at once
+    if (int rcl = osm::launch_instances(ctx, a, 31u, s)) return rcl;       // all leg counts: a wavefront whose problem has another count exits at once
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
     return 0;
@@ -981,7 +908,7 @@ int os_mpc_solve_one(os_ctx *ctx, const float *x, const float *body_ref, const f
     int nst = 0;
     for (int l = 0; l < 4; l++) nst += ((contact_word >> (8 * l)) & 0xffu) == 1u;
     const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
-    osm::launch_instances(a, 1u << nst, s);
+    if (int rcl = osm::launch_instances(ctx, a, 1u << nst, s)) return rcl;
     os_prof_end(ctx, slot, s);
     if (hipGetLastError() != hipSuccess) return os_fail(ctx, -10, "os_kf_step: QP launch failed");
     return 0;
@@ -1062,7 +989,7 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         m.ref = body_ref + o12; m.p = p + o12; m.contact = contact + o1; m.f_out = f_out + o12;
         m.iters = mpc_iters ? mpc_iters + o1 : nullptr;
         const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
-        osm::launch_instances(m, flags_h[t], s);
+        if (int rcl = osm::launch_instances(ctx, m, flags_h[t], s)) { free(flags_h); return rcl; }
         os_prof_end(ctx, slot, s);
         // ... then get_odom + set_measurements + predict_mpc covariance + next_state + update (kalman_filter.py:176-182)
         osk::KfRunArgs a;

@@ -1,0 +1,786 @@
+// mpc_quad.hip -- the convex-MPC force QP (misc/force_controller.py:70-225, solved by casadi + qpOASES at
+// kalman_filter/kalman_filter.py:150) with SIXTEEN LANES PER QP, four QPs per wavefront (round 6).
+//
+// mpc_kernels.hip gives a QP a whole wavefront, one row of the face-restricted system per lane: a trot problem (30 variables) keeps
+// 30 of 64 lanes busy, and the elimination broadcasts the pivot row with two v_readlane per entry -- three instructions per entry,
+// 12 k VALU instructions per QP of which 7 % are useful flops (profiles/r05_pmc_mpc.md).  Here the same exact primal active-set
+// algorithm (same faces, same ratio test, same multiplier rule: read mpc_kernels.hip's header for the mathematics) runs on the
+// 16-lane DPP row: lane l of a row holds variables l and l + 16 (two rows of the system, NV <= 32: one or two stance legs), and
+// every cross-lane term of the elimination is a broadcast FUSED into the FMA (v_fmac_f64_dpp ... row_newbcast: the one fp64 VOP2
+// arithmetic instruction with a 64-bit DPP operand, kf_dense_rows.hpp).  One instruction updates an entry of the rows of FOUR
+// problems: ~0.83 k elimination instructions per wavefront-solve = ~0.2 k per QP against 1.4 k.
+// Three and four stance legs (45 / 60 variables: four rows per lane = 488 registers) stay on mpc_kernels.hip's instances.
+// The four QPs of a wavefront iterate together: the solve is unconditional (a finished problem's rows ride along), the ratio test and
+// the multiplier check run under the lanes' own predicates; a wavefront leaves when all four have converged.
+// The hazard rule inline assembly must respect itself (hipcc does not look inside): a VALU write needs two wait states before a DPP
+// operand reads the register (tools/isa_dpp_hazard_scan.py scans this file too).
+#include "mpc_common.hpp"
+
+#include <stdlib.h>
+#include <type_traits>
+
+#include "kf_dense_rows.hpp"
+
+namespace osq {
+
+// Development build only (-DOSQ_TS): shader-clock stamps between the phases of an active-set iteration, summed by lane 0 of workgroup 0
+#ifdef OSQ_TS
+__shared__ unsigned long long osq_ts_sum[12];            // (LDS: a stamp costs one LDS round trip of lane 0, ~100 cycles)
+__shared__ unsigned long long osq_ts_prev;
+#define OSQ_STAMP(i)                                                                       \
+    {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                         \
+            const unsigned long long now = __builtin_readcyclecounter();                   \
+            if ((i) > 0) osq_ts_sum[i] += now - osq_ts_prev;                               \
+            osq_ts_prev = now;                                                             \
+        }                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+#else
+#define OSQ_STAMP(i)
+#endif
+
+using namespace osm;
+using osk::rows64::bc64;
+
+// per-QP LDS block
+template <int NV>
+struct QuadMem {
+    double gen0[NV][6];      // generators (a, b) of the variables
+    double gent[NV][6];      // generators of the face coordinates
+    double vec[32];          // per-variable exchange (solution / u / u0)
+    double rowbuf[32];
+    double S[32];            // the 5 x 6 per-step sums of form_dot
+    double cwv[5][6];        // (cw | cv) of the linear term per horizon step
+    double Cth[9];           // R1 diag(w_theta) R1^T
+    double al[10];
+    int code[10];
+    double prob[36];         // x | ref | p (float64) while the problem is set up
+};
+struct QuadShared {
+    double ab[25][2];        // (al, be) of alpha_beta() at [5 i + l]: depends on dt only, one copy per wavefront
+};
+
+// acc += (src of lane S of this lane's 16-lane row) * m; the same register may be accumulator and source (rank-1 form)
+template <int S, bool NOP>
+__device__ __forceinline__ void fmac_self(double &acc, double m)
+{
+    if (NOP) asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(S));
+    else asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(S));
+}
+template <int S, bool NOP>
+__device__ __forceinline__ void fmac_other(double &acc, double src, double m)
+{
+    if (NOP) asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(S));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(S));
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// does any lane of this lane's 16-lane row satisfy p?
+__device__ __forceinline__ bool any16(bool p, int lane)
+{
+    const unsigned long long m = __ballot(p);
+    return ((m >> (lane & 48)) & 0xffffull) != 0ull;
+}
+
+template <int NST>
+struct Quad {
+    static constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST, VPL = NV > 16 ? 2 : 1;
+    typedef QuadMem<NV> Mem;
+
+    struct Var {              // one of the lane's variables
+        int v, i, c, ls;      // variable, horizon step, component, leg-step
+        bool pad;
+    };
+    struct Lane {
+        int lane, l;
+        Var var[VPL];
+    };
+
+    // z-vectors of a face generator g at horizon step i against the columns of step l: val(w) = zA . a_w + zB . b_w
+    static __device__ __forceinline__ void zvec(const Mem &M, const MpcParams &P, const QuadShared &Sh, const double *g, int i, int l, double *zA,
+                                                double *zB)
+    {
+        const double al = Sh.ab[5 * i + l][0], be = Sh.ab[5 * i + l][1];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            zA[r] = al * P.w[6 + r] * g[r] + be * (M.Cth[3 * r] * g[0] + M.Cth[3 * r + 1] * g[1] + M.Cth[3 * r + 2] * g[2]);
+            zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+        }
+    }
+
+    // sum_w form(g_h, G[w]) vec[w] for the lane's variables (mpc_kernels.hip form_dot: the sum over a step's columns factors into
+    // per-step six-vector sums, formed by thirty lanes -- here fifteen lanes, two sums each)
+    static __device__ __forceinline__ void form_dot(const Lane &L, const MpcParams &P, const QuadShared &Sh, const double (*gg)[6], const double (*G)[6],
+                                                    const double *vec, Mem &M, double *out)
+    {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e = L.l + 16 * q;
+            if (e < 30) {
+                const int l = e / 6, r = e % 6;
+                double sum = 0.0;
+#pragma unroll
+                for (int j = 0; j < NPS; j++) sum = fma(G[NPS * l + j][r], vec[NPS * l + j], sum);
+                M.S[e] = sum;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            double acc = 0.0;
+#pragma clang loop unroll(disable)
+            for (int l = 0; l < 5; l++) {
+                double zA[3], zB[3];
+                zvec(M, P, Sh, gg[h], L.var[h].i, l, zA, zB);
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    acc = fma(zA[r], M.S[6 * l + r], acc);
+                    acc = fma(zB[r], M.S[6 * l + 3 + r], acc);
+                }
+            }
+            out[h] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // Minimiser of the QP restricted to the faces (sx, sy, sz per variable = of its leg-step); returns the lane's components.
+    // the face of a variable's leg-step, packed: (sx + 1) | (sy + 1) << 2 | sz << 4 (the warm-start format); by value: arrays handed
+    // around by pointer stay in scratch memory
+    struct Faces { int f[VPL]; };
+    static __device__ __forceinline__ int fsx(int f) { return (f & 3) - 1; }
+    static __device__ __forceinline__ int fsy(int f) { return ((f >> 2) & 3) - 1; }
+    static __device__ __forceinline__ int fsz(int f) { return (f >> 4) & 3; }
+    static __device__ __forceinline__ int fpack(int sx, int sy, int sz) { return (sx + 1) | ((sy + 1) << 2) | (sz << 4); }
+    struct Sol { double u[VPL]; };
+
+    static __device__ __forceinline__ Sol solve_face(const Lane &L, const MpcParams &P, const QuadShared &Sh, Mem &M, const Faces F)
+    {
+        OSQ_STAMP(0)
+        int sx[VPL], sy[VPL], sz[VPL];
+#pragma unroll
+        for (int h = 0; h < VPL; h++) { sx[h] = fsx(F.f[h]); sy[h] = fsy(F.f[h]); sz[h] = fsz(F.f[h]); }
+        Sol out;
+        double *us = out.u;
+        bool live[VPL];
+        double g[VPL][6], tt[VPL], u0[VPL];
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const Var &V = L.var[h];
+            const int b0 = 3 * V.ls;
+            tt[h] = 1.0;
+            if (V.c == 2) {
+                live[h] = sz[h] == SZ_FREE;
+                const double fx = sx[h] * P.mu, fy = sy[h] * P.mu;
+#pragma unroll
+                for (int r = 0; r < 6; r++) g[h][r] = M.gen0[b0 + 2][r] + fx * M.gen0[b0][r] + fy * M.gen0[b0 + 1][r];
+                tt[h] = 1.0 + P.mu * P.mu * (double)(sx[h] * sx[h] + sy[h] * sy[h]);
+            } else {
+                live[h] = sz[h] != SZ_ZERO && (V.c == 0 ? sx[h] : sy[h]) == 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) g[h][r] = M.gen0[V.v][r];
+            }
+            live[h] = live[h] && !V.pad;
+            if (!live[h]) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) g[h][r] = 0.0;
+            }
+            // the fixed part of the face (fz = fz_max faces)
+            u0[h] = (sz[h] == SZ_MAX && !V.pad) ? (V.c == 2 ? P.fzmax : (double)(V.c == 0 ? sx[h] : sy[h]) * P.mu * P.fzmax) : 0.0;
+        }
+        bool anyu = false;
+#pragma unroll
+        for (int h = 0; h < VPL; h++) anyu = anyu || u0[h] != 0.0;
+        const bool any_u0 = __ballot(anyu) != 0ull;                    // (wave-uniform: the sums below are zero for a QP without such a face)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            if (!L.var[h].pad) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) M.gent[L.var[h].v][r] = g[h][r];
+                M.vec[L.var[h].v] = u0[h];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        OSQ_STAMP(1)                                 // face generators -> LDS
+        // ---- rows of the reduced system: A[h][w], w < NV, and the right-hand side in A[h][NV] ----
+        double A[VPL][NV + 1];
+        double dot[VPL] = {};
+        if (any_u0) form_dot(L, P, Sh, g, M.gen0, M.vec, M, dot);
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const double *cwv = M.cwv[L.var[h].i];
+            const double rhs = -(g[h][0] * cwv[0] + g[h][1] * cwv[1] + g[h][2] * cwv[2] + g[h][3] * cwv[3] + g[h][4] * cwv[4] + g[h][5] * cwv[5]) - dot[h];
+            A[h][NV] = live[h] ? rhs : 0.0;
+        }
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+            double zA[VPL][3], zB[VPL][3];
+#pragma unroll
+            for (int h = 0; h < VPL; h++) zvec(M, P, Sh, g[h], L.var[h].i, l, zA[h], zB[h]);
+#pragma unroll
+            for (int j = 0; j < NPS; j++) {
+                const int w = NPS * l + j;
+                // a dead slot's generator is zero, so its row and column are zero here; the diagonal (r + ..., or 1 for a dead slot) is
+                // added where the elimination reads the pivot
+                double gw[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) gw[r] = M.gent[w][r];
+#pragma unroll
+                for (int h = 0; h < VPL; h++)
+                    A[h][w] = zA[h][0] * gw[0] + zA[h][1] * gw[1] + zA[h][2] * gw[2] + zB[h][0] * gw[3] + zB[h][1] * gw[4] + zB[h][2] * gw[5];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        OSQ_STAMP(2)                                 // right-hand side + rows
+        // ---- forward elimination: pivot k lives in lane k & 15 of the row, half k >> 4; its row is broadcast inside the FMA.  Compile-time
+        // recursion (static_for), not `#pragma unroll` + a switch over the lane select: the DPP control is an immediate, and the
+        // unroller gives up on 30 x 31 / 2 bodies of sixteen cases each (the arrays then live in scratch) ----
+        double dsel[VPL], dinv[VPL];
+#pragma unroll
+        for (int h = 0; h < VPL; h++) { dsel[h] = live[h] ? P.rw * tt[h] : 1.0; dinv[h] = 1.0; }
+        // (the NEXT pivot's inverse -- broadcast, v_rcp_f64, two Newton steps: a ~150-cycle dependent chain -- is started as soon as this
+        // pivot's first entry has finalised that diagonal, and runs underneath the rest of this pivot's entries)
+        double inv_next = rcp64(bc64<0>(A[0][0] + dsel[0]));
+        static_for<0, NV>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, hk = k >> 4, kk = k & 15;
+            const double inv = inv_next;
+            if (L.l == kk) dinv[hk] = inv;
+            double nf[VPL];
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const int row = L.l + 16 * h;
+                nf[h] = (h >= hk && row > k && row < NV) ? -A[h][k] * inv : 0.0;
+            }
+            // entry j of every row below the pivot: the upper half first (it reads the pivot row's register, which the lower half's
+            // own update then rewrites: a DPP operand must not have been written by the two preceding instructions)
+            static_for<k + 1, NV + 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr bool first = j == k + 1;
+                if constexpr (VPL == 2 && hk == 0) {
+                    fmac_other<kk, first>(A[VPL - 1][j], A[0][j], nf[VPL - 1]);
+                    fmac_self<kk, false>(A[0][j], nf[0]);
+                } else {
+                    fmac_self<kk, first>(A[hk][j], nf[hk]);
+                }
+                if constexpr (first && k + 1 < NV) {
+                    constexpr int k1 = k + 1, hk1 = k1 >> 4, kk1 = k1 & 15;
+                    inv_next = rcp64(bc64<kk1>(A[hk1][k1] + dsel[hk1]));
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        OSQ_STAMP(3)                                 // elimination
+        // ---- back substitution ----
+        double r[VPL], sol[VPL];
+#pragma unroll
+        for (int h = 0; h < VPL; h++) { r[h] = A[h][NV]; sol[h] = 0.0; }
+        static_for<0, NV>([&](auto ic) {
+            constexpr int k = NV - 1 - decltype(ic)::value, hk = k >> 4, kk = k & 15;
+            const double wk = bc64<kk>(r[hk] * dinv[hk]);
+            if (L.l == kk) sol[hk] = wk;
+#pragma unroll
+            for (int h = 0; h <= hk; h++)
+                if (L.l + 16 * h < k) r[h] = fma(-A[h][k], wk, r[h]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        OSQ_STAMP(4)                                 // back substitution
+        // ---- face coordinates -> forces ----
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < VPL; h++)
+            if (!L.var[h].pad) M.vec[L.var[h].v] = sol[h];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const Var &V = L.var[h];
+            const double fz = sz[h] == SZ_MAX ? P.fzmax : (sz[h] == SZ_ZERO ? 0.0 : M.vec[3 * V.ls + 2]);
+            double u;
+            if (V.c == 2) u = fz;
+            else {
+                const int s = V.c == 0 ? sx[h] : sy[h];
+                u = s != 0 ? (double)s * P.mu * fz : (sz[h] == SZ_ZERO ? 0.0 : sol[h]);
+            }
+            us[h] = V.pad ? 0.0 : u;
+        }
+        return out;
+    }
+
+    // Per-row solver state: a 16-lane row owns ONE problem at a time and fetches the next from the batch's work counter when it has
+    // converged -- the four rows of a wavefront do not wait for each other's iteration counts (measured on the bench's data: mean
+    // 4.1 iterations per QP, mean of the maximum over four consecutive QPs 7.7; tools/mpc_iter_stats.py).
+    struct Row {
+        bool has, exhausted, first, done, converged;
+        int b, iters, nb_next;      // nb_next: the work-counter value reserved for the row's NEXT problem (requested a problem ahead)
+        uint32_t cbits;
+        bool stance[VPL];
+        Faces F;
+        double u[VPL];
+    };
+
+    // problem b -> the row's LDS block and state (row-uniform control flow: every lane of the row is here)
+    static __device__ __forceinline__ void setup_row(const Lane &L, const MpcArgs &a, const MpcParams &P, Mem &M, Row &R, int b, uint32_t cbits)
+    {
+        const size_t B = (size_t)a.B;
+        __builtin_amdgcn_wave_barrier();
+        if (L.l < 12) {
+            M.prob[L.l] = (double)a.x[(size_t)L.l * B + b];
+            M.prob[12 + L.l] = (double)a.ref[(size_t)L.l * B + b];
+            M.prob[24 + L.l] = (double)a.p[(size_t)L.l * B + b];
+        }
+        __builtin_amdgcn_wave_barrier();
+        int legs[4] = {0, 0, 0, 0};
+        {
+            int n = 0;
+#pragma unroll
+            for (int lg = 0; lg < 4; lg++) {
+                if (((cbits >> (8 * lg)) & 0xffu) != 0u) {
+                    if (n == 0) legs[0] = lg; else if (n == 1) legs[1] = lg; else if (n == 2) legs[2] = lg; else legs[3] = lg;
+                    n++;
+                }
+            }
+        }
+        int leg[VPL];
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const int rank = (L.var[h].v % NPS) / 3;
+            leg[h] = rank == 0 ? legs[0] : rank == 1 ? legs[1] : rank == 2 ? legs[2] : legs[3];
+            R.stance[h] = ((cbits >> (8 * leg[h])) & 0xffu) == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
+        }
+        const double *x = M.prob, *ref = M.prob + 12, *p = M.prob + 24;
+        double R0[9], R1[9];
+        rotation64(x[0], x[1], x[2], R0);
+        rotation64(ref[0], ref[1], ref[2], R1);
+        if (L.l < 9) {
+            const int r = L.l / 3, s = L.l % 3;
+            double v = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                for (int ss = 0; ss < 3; ss++)
+                    if (rr == r && ss == s) v = R1[3 * rr] * P.w[0] * R1[3 * ss] + R1[3 * rr + 1] * P.w[1] * R1[3 * ss + 1] + R1[3 * rr + 2] * P.w[2] * R1[3 * ss + 2];
+            M.Cth[L.l] = v;
+        }
+        // generators of the lane's variables: a = I_hat^-1 (R p_leg x e_c), b = e_c / m, with R of the variable's horizon step
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const Var &V = L.var[h];
+            double Rm[9];
+#pragma unroll
+            for (int r = 0; r < 9; r++) Rm[r] = V.i == 0 ? R0[r] : R1[r];
+            const double px = p[3 * leg[h]], py = p[3 * leg[h] + 1], pz = p[3 * leg[h] + 2];
+            const double wx = Rm[0] * px + Rm[1] * py + Rm[2] * pz, wy = Rm[3] * px + Rm[4] * py + Rm[5] * pz, wz = Rm[6] * px + Rm[7] * py + Rm[8] * pz;
+            double cr[3];                                  // pw x e_c
+            if (V.c == 0) { cr[0] = 0.0; cr[1] = wz; cr[2] = -wy; }
+            else if (V.c == 1) { cr[0] = -wz; cr[1] = 0.0; cr[2] = wx; }
+            else { cr[0] = wy; cr[1] = -wx; cr[2] = 0.0; }
+            double tb[3];                                  // I_hat^-1 = R diag(1/I) R^T
+#pragma unroll
+            for (int q = 0; q < 3; q++) tb[q] = (Rm[q] * cr[0] + Rm[3 + q] * cr[1] + Rm[6 + q] * cr[2]) * P.inv_inertia[q];
+            if (!V.pad) {
+#pragma unroll
+                for (int r = 0; r < 3; r++) M.gen0[V.v][r] = Rm[3 * r] * tb[0] + Rm[3 * r + 1] * tb[1] + Rm[3 * r + 2] * tb[2];
+#pragma unroll
+                for (int r = 0; r < 3; r++) M.gen0[V.v][3 + r] = (r == V.c) ? P.inv_mass : 0.0;
+            }
+        }
+        // linear term per horizon step (mpc_kernels.hip: closed forms in the step index): lanes 0..4 of the row compute step l's (cw | cv)
+        if (L.l < 5) {
+            const double dt = P.dt, dt2 = dt * dt;
+            const double di = (double)L.l, Mm = 4.0 - di, n = Mm + 1.0;
+            const double s1 = 0.5 * Mm * n, s2m = Mm * n * (2.0 * Mm + 1.0) * (1.0 / 6.0), s3m = s1 * s1;
+            const double S1 = s1, S2 = s2m + di * s1, T1 = s1 + n * (di + 1.0), T2 = s2m + (di + 1.0) * s1;
+            const double T3 = s3m + (2.0 * di + 1.0) * s2m + di * (di + 1.0) * s1;
+            double e0[3], dd[3], wt[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double r0w = R0[r] * x[6] + R0[3 + r] * x[7] + R0[6 + r] * x[8];
+                const double r1w = R1[r] * x[6] + R1[3 + r] * x[7] + R1[6 + r] * x[8];
+                e0[r] = x[r] + dt * r0w - ref[r];
+                dd[r] = dt * r1w;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) wt[r] = P.w[r] * (S1 * e0[r] + S2 * dd[r]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double ew = x[6 + r] - ref[6 + r];
+                M.cwv[L.l][r] = n * dt * P.w[6 + r] * ew + dt2 * (R1[3 * r] * wt[0] + R1[3 * r + 1] * wt[1] + R1[3 * r + 2] * wt[2]);
+                double sev = n * (x[9 + r] - ref[9 + r]);
+                double ser = S1 * (x[3 + r] - ref[3 + r]) + dt * x[9 + r] * T2;
+                if (r == 2) { sev += dt * P.gz * T1; ser += 0.5 * dt2 * P.gz * T3; }
+                M.cwv[L.l][3 + r] = dt * P.w[9 + r] * sev + dt2 * P.w[3 + r] * ser;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // cold start: stance (and unconstrained) legs free, swing legs zero; warm: the previous solve's point and faces when the
+        // force-carrying legs' contact bytes are unchanged (the pyramids do not move: the old u stays feasible)
+        const bool warm = a.warm_u && a.warm_contact[b] != 0xffffffffu && contact_ranks(a.warm_contact[b]) == contact_ranks(cbits);
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const int v = L.l + 16 * h;
+            R.F.f[h] = fpack(0, 0, SZ_FREE); R.u[h] = 0.0;
+            if (warm && v < NV) { R.u[h] = a.warm_u[(size_t)b * 64 + v]; R.F.f[h] = a.warm_state[(size_t)b * 64 + v] & 0x3f; }
+        }
+        R.first = !warm; R.done = false; R.converged = false; R.iters = 0; R.b = b; R.cbits = cbits; R.has = true;
+    }
+
+    // the converged (or capped) problem's outputs in the reference's variable order (12 per horizon step, leg-major; swing legs zero)
+    static __device__ __forceinline__ void finish_row(const Lane &L, const MpcArgs &a, Mem &M, Row &R)
+    {
+        const size_t B = (size_t)a.B;
+        const int b = R.b;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < VPL; h++)
+            if (!L.var[h].pad) M.vec[L.var[h].v] = R.u[h];
+        __builtin_amdgcn_wave_barrier();
+        int legs[4] = {0, 0, 0, 0};
+        {
+            int n = 0;
+#pragma unroll
+            for (int lg = 0; lg < 4; lg++)
+                if (((R.cbits >> (8 * lg)) & 0xffu) != 0u) { if (n == 0) legs[0] = lg; else if (n == 1) legs[1] = lg; else if (n == 2) legs[2] = lg; else legs[3] = lg; n++; }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int o = L.l + 16 * m;
+            if (o < 60) {
+                const int oi = o / 12, oleg = (o % 12) / 3, oc = o % 3;
+                int rank = -1;
+#pragma unroll
+                for (int r = 0; r < NST; r++)
+                    if ((r == 0 ? legs[0] : (r == 1 ? legs[1] : (r == 2 ? legs[2] : legs[3]))) == oleg) rank = r;
+                const float val = rank < 0 ? 0.f : (float)M.vec[oi * NPS + 3 * (rank < 0 ? 0 : rank) + oc];
+                if (o < 12) a.f_out[(size_t)o * B + b] = val;
+                if (a.u_out) a.u_out[(size_t)o * B + b] = val;
+            }
+        }
+        if (a.warm_u) {
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const int v = L.l + 16 * h;
+                a.warm_u[(size_t)b * 64 + v] = L.var[h].pad ? 0.0 : R.u[h];
+                a.warm_state[(size_t)b * 64 + v] = (uint8_t)R.F.f[h];
+            }
+            if (L.l == 0) a.warm_contact[b] = R.cbits;
+        }
+        if (L.l == 0) {
+            if (a.iters) a.iters[b] = R.iters;
+            if (!R.converged) a.status[b] |= 4;
+        }
+        __builtin_amdgcn_wave_barrier();
+        R.has = false;
+    }
+
+    // one active-set iteration of the row's problem behind the (unconditional) solve
+    static __device__ __forceinline__ void iterate_row(const Lane &L, const MpcParams &P, const QuadShared &Sh, Mem &M, Row &R, const Sol &S)
+    {
+        Faces &F = R.F;
+        double (&u)[VPL] = R.u;
+        bool &first = R.first, &done = R.done, &converged = R.converged;
+        int &iters = R.iters;
+        const bool (&stance)[VPL] = R.stance;
+        constexpr double EPS = 1e-11, TOL = 1e-12;
+        iters++;
+        do {
+            if (first) {
+                // clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
+                first = false;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int h = 0; h < VPL; h++) { u[h] = S.u[h]; if (!L.var[h].pad) M.vec[L.var[h].v] = u[h]; }
+                __builtin_amdgcn_wave_barrier();
+                bool clamped = false;
+#pragma unroll
+                for (int h = 0; h < VPL; h++) {
+                    const Var &V = L.var[h];
+                    double fx = M.vec[3 * V.ls], fy = M.vec[3 * V.ls + 1], fz = M.vec[3 * V.ls + 2];
+                    int sx = 0, sy = 0, sz = SZ_FREE;
+                    bool cl = false;
+                    if (fz <= 0.0) { sz = SZ_ZERO; fx = fy = fz = 0.0; cl = true; }
+                    else {
+                        if (fz >= P.fzmax) { sz = SZ_MAX; fz = P.fzmax; cl = true; }
+                        const double lim = P.mu * fz;
+                        if (fx >= lim) { sx = 1; fx = lim; cl = true; } else if (fx <= -lim) { sx = -1; fx = -lim; cl = true; }
+                        if (fy >= lim) { sy = 1; fy = lim; cl = true; } else if (fy <= -lim) { sy = -1; fy = -lim; cl = true; }
+                    }
+                    const bool act = stance[h] && !V.pad;
+                    F.f[h] = act ? fpack(sx, sy, sz) : F.f[h];
+                    u[h] = act ? (V.c == 0 ? fx : (V.c == 1 ? fy : fz)) : u[h];
+                    clamped = clamped || (act && cl);
+                }
+                if (!any16(clamped, L.lane)) { done = true; converged = true; }
+                break;
+            }
+            double d[VPL];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                d[h] = S.u[h] - u[h];
+                if (!L.var[h].pad) { M.vec[L.var[h].v] = u[h]; M.rowbuf[L.var[h].v] = d[h]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ratio test of a leg-step (computed by its fz variable)
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const Var &V = L.var[h];
+                if (V.c == 2 && !V.pad) {
+                    const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+                    double best = 2.0; int code = 0;
+                    if (stance[h] && sz != SZ_ZERO) {
+                        const double fx = M.vec[3 * V.ls], fy = M.vec[3 * V.ls + 1], fz = M.vec[3 * V.ls + 2];
+                        const double dx = M.rowbuf[3 * V.ls], dy = M.rowbuf[3 * V.ls + 1], dz = M.rowbuf[3 * V.ls + 2];
+                        auto cand = [&](double num, double den, int cd) {
+                            if (den > EPS) {
+                                const double al = fmax(0.0, num * rcp64(den));
+                                if (al < best) { best = al; code = cd; }
+                            }
+                        };
+                        if (sz == SZ_FREE) { cand(fz, -dz, 1); cand(P.fzmax - fz, dz, 2); }
+                        if (sx == 0) { cand(P.mu * fz - fx, dx - P.mu * dz, 3); cand(P.mu * fz + fx, -dx - P.mu * dz, 4); }
+                        if (sy == 0) { cand(P.mu * fz - fy, dy - P.mu * dz, 5); cand(P.mu * fz + fy, -dy - P.mu * dz, 6); }
+                    }
+                    M.al[V.ls] = best; M.code[V.ls] = code;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double amin = 1.0; int lsmin = -1, cmin = 0;
+            {
+                double alq[NLS]; int cdq[NLS];
+#pragma unroll
+                for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
+#pragma unroll
+                for (int q = 0; q < NLS; q++)
+                    if (alq[q] < amin) { amin = alq[q]; lsmin = q; cmin = cdq[q]; }
+            }
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                u[h] += amin * d[h];
+                int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+                if (cmin == 1) { sx = 0; sy = 0; sz = SZ_ZERO; }
+                else if (cmin == 2) sz = SZ_MAX;
+                else if (cmin == 3) sx = 1;
+                else if (cmin == 4) sx = -1;
+                else if (cmin == 5) sy = 1;
+                else if (cmin == 6) sy = -1;
+                const bool hit = lsmin >= 0 && L.var[h].ls == lsmin && !L.var[h].pad;
+                F.f[h] = hit ? fpack(sx, sy, sz) : F.f[h];
+            }
+            // snap onto the face equalities
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < VPL; h++)
+                if (!L.var[h].pad) M.vec[L.var[h].v] = u[h];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const Var &V = L.var[h];
+                const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+                double fz = M.vec[3 * V.ls + 2];
+                if (sz == SZ_ZERO) fz = 0.0;
+                if (sz == SZ_MAX) fz = P.fzmax;
+                double un = u[h];
+                if (V.c == 2) un = fz;
+                else {
+                    const int sgn = V.c == 0 ? sx : sy;
+                    if (sz == SZ_ZERO) un = 0.0;
+                    else if (sgn != 0) un = (double)sgn * P.mu * fz;
+                }
+                u[h] = (!V.pad && stance[h]) ? un : u[h];
+            }
+#ifdef OS_MPC_DBG
+            if (L.lane == 0) printf("quad it %d ratio: amin %.6e lsmin %d cmin %d\n", iters, amin, lsmin, cmin);
+#endif
+            if (lsmin >= 0) break;
+
+            // subspace minimiser reached: multiplier signs
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < VPL; h++)
+                if (!L.var[h].pad) M.vec[L.var[h].v] = u[h];
+            __builtin_amdgcn_wave_barrier();
+            double g0[VPL][6], fd[VPL];
+#pragma unroll
+            for (int h = 0; h < VPL; h++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) g0[h][r] = M.gen0[L.var[h].v][r];
+            form_dot(L, P, Sh, g0, M.gen0, M.vec, M, fd);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const double *cwv = M.cwv[L.var[h].i];
+                const double q0 = g0[h][0] * cwv[0] + g0[h][1] * cwv[1] + g0[h][2] * cwv[2] + g0[h][3] * cwv[3] + g0[h][4] * cwv[4] + g0[h][5] * cwv[5];
+                const double grad = 2.0 * (fd[h] + P.rw * u[h] + q0);
+                if (!L.var[h].pad) M.rowbuf[L.var[h].v] = grad;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const Var &V = L.var[h];
+                if (V.c == 2 && !V.pad) {
+                    const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+                    double best = TOL; int code = 0;
+                    if (stance[h]) {
+                        const double gx = M.rowbuf[3 * V.ls], gy = M.rowbuf[3 * V.ls + 1], gz = M.rowbuf[3 * V.ls + 2];
+                        if (sz == SZ_ZERO) {
+                            // apex: optimal iff the gradient lies in the dual cone; otherwise release along the steepest edge ray
+                            const double vx = P.mu * fabs(gx), vy = P.mu * fabs(gy);
+                            const double val = gz - vx - vy;
+                            if (-val > best) { best = -val; code = 16 + (gx > 0.0 ? 0 : 1) + (gy > 0.0 ? 0 : 2); }
+                        } else {
+                            if (sx == 1 && gx > best) { best = gx; code = 1; }
+                            if (sx == -1 && -gx > best) { best = -gx; code = 1; }
+                            if (sy == 1 && gy > best) { best = gy; code = 2; }
+                            if (sy == -1 && -gy > best) { best = -gy; code = 2; }
+                            if (sz == SZ_MAX) {
+                                const double lamU = -gz - sx * P.mu * gx - sy * P.mu * gy;
+                                if (-lamU > best) { best = -lamU; code = 3; }
+                            }
+                        }
+                    }
+                    M.al[V.ls] = best; M.code[V.ls] = code;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double rmax = TOL; int lsr = -1, cr = 0;
+            {
+                double alq[NLS]; int cdq[NLS];
+#pragma unroll
+                for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
+#pragma unroll
+                for (int q = 0; q < NLS; q++)
+                    if (cdq[q] != 0 && alq[q] > rmax) { rmax = alq[q]; lsr = q; cr = cdq[q]; }
+            }
+#ifdef OS_MPC_DBG
+            if (L.lane == 0) printf("quad it %d mult: rmax %.6e lsr %d cr %d\n", iters, rmax, lsr, cr);
+#endif
+            if (lsr < 0) { done = true; converged = true; break; }
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+                if (cr == 1) sx = 0;
+                else if (cr == 2) sy = 0;
+                else if (cr == 3) sz = SZ_FREE;
+                else { sx = (cr & 1) ? 1 : -1; sy = (cr & 2) ? 1 : -1; sz = SZ_FREE; }
+                const bool hit = L.var[h].ls == lsr && !L.var[h].pad;
+                F.f[h] = hit ? fpack(sx, sy, sz) : F.f[h];
+            }
+        } while (false);
+    }
+};
+
+// One workgroup = one wavefront = four independent 16-lane rows.  A row takes a problem index from the launch's work counter, sets the
+// problem up, iterates until its KKT conditions hold, writes its outputs and takes the next index; problems with another number of
+// force-carrying legs are skipped (their instance handles them).  The grid is sized to fill the chip, not to the batch.
+#ifndef OSQ_OCC
+#define OSQ_OCC 2            // wavefronts per SIMD the register budget is sized for
+#endif
+template <int NST>
+__global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcArgs a, int *__restrict__ counter)
+{
+    typedef Quad<NST> Q;
+    __shared__ typename Q::Mem Mq[4];
+    __shared__ QuadShared Sh;
+    typename Q::Lane L;
+    L.lane = threadIdx.x;
+    L.l = L.lane & 15;
+#pragma unroll
+    for (int h = 0; h < Q::VPL; h++) {
+        typename Q::Var &V = L.var[h];
+        const int v = L.l + 16 * h;
+        V.pad = v >= Q::NV;
+        V.v = V.pad ? Q::NV - 1 : v;
+        V.i = V.v / Q::NPS; V.c = V.v % 3; V.ls = V.v / 3;
+    }
+    if (L.lane < 25) {
+        double al, be;
+        alpha_beta(L.lane / 5, L.lane % 5, a.prm.dt, al, be);
+        Sh.ab[L.lane][0] = al; Sh.ab[L.lane][1] = be;
+    }
+    __builtin_amdgcn_wave_barrier();
+#ifdef OSQ_TS
+    if (threadIdx.x < 12) osq_ts_sum[threadIdx.x] = 0;
+#endif
+    typename Q::Mem &M = Mq[L.lane >> 4];
+    const size_t B = (size_t)a.B;
+    typename Q::Row R;
+    R.has = false; R.exhausted = false; R.first = false; R.done = true; R.converged = true; R.b = 0; R.iters = 0; R.cbits = 0;
+    {
+        int nx = 0;
+        if (L.l == 0) nx = atomicAdd(counter, 1);
+        R.nb_next = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);
+    }
+#pragma unroll
+    for (int h = 0; h < Q::VPL; h++) { R.F.f[h] = Q::fpack(0, 0, SZ_ZERO); R.u[h] = 0.0; R.stance[h] = false; }
+    // a row that has never had a problem rides along in the solve with an all-dead system (identity rows): its LDS block holds zeros
+    for (int i = L.l; i < (int)(sizeof(typename Q::Mem) / 8); i += 16) reinterpret_cast<double *>(&M)[i] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (;;) {
+        if (!R.has && !R.exhausted) {
+            // (row-uniform) next problem of this leg count; its index was reserved when the previous problem started (the work counter's
+            // round trip travels under a whole problem's iterations)
+            for (;;) {
+                const int nb = R.nb_next;
+                if (nb >= a.B) { R.exhausted = true; break; }
+                int nx = 0;
+                if (L.l == 0) nx = atomicAdd(counter, 1);
+                R.nb_next = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);      // row_newbcast:0
+                const uint32_t cb = a.contact[nb];
+                const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
+                if (NST == 1 && nst == 0) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
+                    if (L.l < 12) a.f_out[(size_t)L.l * B + nb] = 0.f;
+                    if (a.u_out)
+                        for (int o = L.l; o < 60; o += 16) a.u_out[(size_t)o * B + nb] = 0.f;
+                    if (L.l == 0 && a.iters) a.iters[nb] = 0;
+                    if (L.l == 0 && a.warm_contact) a.warm_contact[nb] = cb;
+                }
+                if (nst != NST) continue;
+                Q::setup_row(L, a, a.prm, M, R, nb, cb);
+                break;
+            }
+        }
+        if (__ballot(R.has) == 0ull) break;
+        OSQ_STAMP(7)                                 // fetch + set-up of new problems
+        const typename Q::Sol S = Q::solve_face(L, a.prm, Sh, M, R.F);
+        OSQ_STAMP(5)                                 // face coordinates -> forces
+        if (R.has) {
+            Q::iterate_row(L, a.prm, Sh, M, R, S);
+            if (R.done || R.iters >= a.max_iter) Q::finish_row(L, a, M, R);
+        }
+        OSQ_STAMP(6)                                 // ratio test / multipliers / outputs
+#ifdef OSQ_TS
+        if (blockIdx.x == 0 && threadIdx.x == 0) osq_ts_sum[0] += 1;
+#endif
+    }
+#ifdef OSQ_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && NST == 2) {
+        const unsigned long long n = osq_ts_sum[0] ? osq_ts_sum[0] : 1;
+        printf("quad<2> cycles per wave-iteration (%llu iterations): faces %llu | rows %llu | elimination %llu | back-substitution %llu | forces %llu | ratio/multipliers/outputs %llu | fetch+setup %llu\n",
+               n, osq_ts_sum[1] / n, osq_ts_sum[2] / n, osq_ts_sum[3] / n, osq_ts_sum[4] / n, osq_ts_sum[5] / n, osq_ts_sum[6] / n, osq_ts_sum[7] / n);
+    }
+#endif
+}
+
+}  // namespace osq
+
+// the instances for one / two force-carrying legs over the whole batch (mpc_kernels.hip launch_instances); counters: two zeroed ints
+void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s)
+{
+    // two wavefronts per SIMD fill the chip; fewer rows than problems never hurts (a row takes the next index), more would idle
+    const int rows = (a.B + 3) / 4, full = cu_count * 4 * OSQ_OCC;
+    const dim3 grid(rows < full ? rows : full), block(64);
+    if (nst_mask & 3u) hipLaunchKernelGGL(osq::mpc_solve_quad_kernel<1>, grid, block, 0, s, a, counters);
+    if (nst_mask & 4u) hipLaunchKernelGGL(osq::mpc_solve_quad_kernel<2>, grid, block, 0, s, a, counters + 1);
+}

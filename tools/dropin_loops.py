@@ -134,6 +134,7 @@ class _CpuRNN(nn.Module):                                                 # gru/
         return torch.sigmoid(self.fc(self.gru(x)[0][:, -1, :]))
 
 
+torch.set_num_threads(min(8, os.cpu_count() or 1))     # the build container's eight cores (18.9 ms there); all 128 of the GPU box oversubscribe a batch of 64: 760 ms
 torch.manual_seed(1)
 ms_cpu, _ = reference_loop(_CpuRNN(), torch.device("cpu"), min(a.train_steps, 60))
 res["train_loop_torch_cpu"] = {"ms_per_step": ms_cpu, "threads": torch.get_num_threads(),
