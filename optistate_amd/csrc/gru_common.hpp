@@ -91,4 +91,13 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t *t)
     t[SPL - 1] = pack_bf16(ra, rb);
 }
 
+// Launch-wide latch of the progress-counter kernels (round 6): once ANY workgroup of the context has given a wait up, the others stop
+// waiting too -- a workgroup that starts late reads the word before its first wait, a waiting one looks at it every 1,024 polls.  Without
+// this a starved launch paid the bounded wait once per ROUND of late workgroups (measured: 5.7 s for 14 rounds of 0.67 s on two free
+// CUs per XCD, tests/test_gpu_contention.py); with it the whole launch costs one wait.
+__device__ __forceinline__ bool stack_lost_already(const int32_t *err_local)
+{
+    return err_local && __hip_atomic_load(err_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
 }  // namespace osg

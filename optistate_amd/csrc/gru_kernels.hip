@@ -506,10 +506,11 @@ __device__ __forceinline__ void stack_lost(int32_t *err, int32_t *err_local)
         if (err) __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-__device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need, uint32_t max_polls = 1u << 22)
+__device__ __forceinline__ bool stack_wait(const uint32_t *flag, uint32_t need, uint32_t max_polls = 1u << 22, const int32_t *err_local = nullptr)
 {
     for (uint32_t spin = 0; spin < max_polls; spin++) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if ((spin & 1023u) == 1023u && stack_lost_already(err_local)) return false;      // somebody else gave up: so do we
         __builtin_amdgcn_s_sleep(4);
     }
     return false;
@@ -568,10 +569,10 @@ __device__ __forceinline__ void split_layer_body(const LayerArgs &a, const Stack
     const uint32_t xsoff = (uint32_t)growc * 4u + (uint32_t)xk0 * rowB;
     float xr[XE];
     const bool consume = STACK && sy.prev != nullptr;               // x comes from a producer inside this launch
-    bool lost = false;                                               // latched: after one expired wait this workgroup stops waiting
+    bool lost = STACK && stack_lost_already(sy.err_local);          // latched: after one expired wait (anywhere in the launch) this workgroup stops waiting
     auto xfetch = [&](int t) {
         if (consume && !lost) {
-            lost = !stack_wait(sy.prev, (uint32_t)t + 1u, sy.max_polls);   // every lane polls (one request per wave): step t is published
+            lost = !stack_wait(sy.prev, (uint32_t)t + 1u, sy.max_polls, sy.err_local);   // every lane polls (one request per wave): step t is published
             if (lost) stack_lost(sy.err, sy.err_local);
         }
         const rsrc_t rx = make_rsrc(a.xs + (size_t)t * a.K * B, (uint32_t)a.K * rowB);

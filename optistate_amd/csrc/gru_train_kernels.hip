@@ -264,7 +264,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a)
         const int r = ic >> lgH, c = ic & (H - 1), g = row0 + r;
         pf_off[e] = (uint32_t)(((size_t)(g < a.B ? g : a.B - 1) * H + c) * 4);
     }
-    bool lost = false;                                         // STACK: latched after one expired wait (no further waits in this launch)
+    bool lost = STACK && osg::stack_lost_already(a.err_local);      // STACK: latched after one expired wait anywhere in the launch (no further waits)
     auto prefetch = [&](int t) {
         const uint32_t step = (uint32_t)((size_t)t * B * H * 4), bytes = (uint32_t)((size_t)a.T * B * H * 4);
         const osk::rsrc_t rr_ = osk::make_rsrc(a.sv_r, bytes), rz_ = osk::make_rsrc(a.sv_z, bytes), rn_ = osk::make_rsrc(a.sv_n, bytes),
@@ -284,6 +284,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a)
                     lost = true;
                     for (uint32_t spin = 0; spin < a.max_polls; spin++) {
                         if (__hip_atomic_load(a.flag_prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)(a.T - t)) { lost = false; break; }
+                        if ((spin & 1023u) == 1023u && osg::stack_lost_already(a.err_local)) break;      // somebody else gave up: so do we
                         __builtin_amdgcn_s_sleep(4);
                     }
                     // reported in the context's error word: the call (or the next one) fails with -20, adam_kernel skips its update
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_wide_kernel(const SweepWideA
     }
     const osk::rsrc_t rf = osk::make_rsrc(sa.flags, (uint32_t)sa.n * (uint32_t)sa.tiles * 16u);
     const uint32_t own_off = (uint32_t)((y * sa.tiles + tile) * 16), up_off = y > 0 ? (uint32_t)(((y - 1) * sa.tiles + tile) * 16) : 0u;
-    bool lost = false;
+    bool lost = osg::stack_lost_already(sa.err_local);
     for (int i = threadIdx.x; i < 32 * HS; i += 512) dh[i] = 0.f;
     __syncthreads();
 
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(512, 1) void bwd_sweep_wide_kernel(const SweepWideA
                 uint32_t v = need;
                 if (lane < 8 && need) v = __builtin_amdgcn_raw_buffer_load_b32(rf, off, 0u, 17);
                 if (__builtin_amdgcn_ballot_w64(v < need) == 0) { lost = false; break; }
+                if ((spin & 1023u) == 1023u && osg::stack_lost_already(sa.err_local)) break;      // somebody else gave up: so do we
                 __builtin_amdgcn_s_sleep(1);
             }
             if (lost && lane == 0) {

@@ -52,7 +52,7 @@ __device__ __forceinline__ void wd_store_coh(rsrc_t r, uint32_t voff, uint32_t s
 // wave; false after max_polls rounds.  Plain coherent loads / stores, not acquire / release atomics: those come with an L2 write-back
 // before every release and an L2 invalidate behind every polling acquire, and everything that crosses workgroups here is moved with
 // cache-bypassing accesses anyway (the publisher waits for its data stores' acknowledgements before it writes its counter).
-__device__ __forceinline__ bool wd_wait8(rsrc_t rf, uint32_t own_off, uint32_t need_own, uint32_t prev_off, uint32_t need_prev, uint32_t max_polls)
+__device__ __forceinline__ bool wd_wait8(rsrc_t rf, uint32_t own_off, uint32_t need_own, uint32_t prev_off, uint32_t need_prev, uint32_t max_polls, const int32_t *err_local)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t need = lane < 4 ? need_own : need_prev;
@@ -61,6 +61,7 @@ __device__ __forceinline__ bool wd_wait8(rsrc_t rf, uint32_t own_off, uint32_t n
         uint32_t v = need;
         if (lane < 8 && need) v = __builtin_amdgcn_raw_buffer_load_b32(rf, off, 0u, WD_AUX);
         if (__builtin_amdgcn_ballot_w64(v < need) == 0) return true;
+        if ((spin & 1023u) == 1023u && stack_lost_already(err_local)) return false;      // somebody else gave up: so do we
         __builtin_amdgcn_s_sleep(1);
     }
     return false;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
 
     const rsrc_t rf = make_rsrc(a.flags, (uint32_t)a.n * (uint32_t)a.tiles * 16u);
     const uint32_t own_off = (uint32_t)((l * a.tiles + tile) * 16), prev_off = l > 0 ? (uint32_t)(((l - 1) * a.tiles + tile) * 16) : 0u;
-    bool lost = false;                                                // latched: after one expired wait this workgroup stops waiting
+    bool lost = stack_lost_already(a.err_local);                      // latched: after one expired wait (anywhere in the launch) this workgroup stops waiting
 
     for (int i = threadIdx.x; i < 32 * WD_HS; i += 512) ht[i] = 0.f;   // h0 = 0 (gru/gru_model.py:27)
     for (int i = threadIdx.x; i < 32 * XS; i += 512) xt[i] = 0.f;      // (the pad column of an odd input width stays zero)
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
     auto stage_x = [&](int t) {
         if (l > 0) {
             if (!lost) {
-                lost = !wd_wait8(rf, own_off, 0u, prev_off, (uint32_t)t + 1u, a.max_polls);
+                lost = !wd_wait8(rf, own_off, 0u, prev_off, (uint32_t)t + 1u, a.max_polls, a.err_local);
                 if (lost) wd_lost(a.err, a.err_local);
             }
             const rsrc_t r = make_rsrc(a.hseq[l - 1] + (size_t)t * B * WD_H, step_bytes);      // rows past the batch read zero (range check)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void gru_wide_kernel(const WideArgs a)
     float vh[8];
     auto h_issue = [&](int t) {
         if (!lost) {
-            lost = !wd_wait8(rf, own_off, (uint32_t)t, prev_off, 0u, a.max_polls);
+            lost = !wd_wait8(rf, own_off, (uint32_t)t, prev_off, 0u, a.max_polls, a.err_local);
             if (lost) wd_lost(a.err, a.err_local);
         }
         const rsrc_t r = make_rsrc(a.hseq[l] + (size_t)(t - 1) * B * WD_H, step_bytes);

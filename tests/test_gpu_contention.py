@@ -106,3 +106,54 @@ def test_stacked_training_sweeps_beside_a_process_that_fills_the_gpu():
         assert n > 20
     finally:
         hog.wait(timeout=60)
+
+
+def test_one_long_kernel_on_30_of_32_cus_per_xcd_starves_a_tile_and_the_call_falls_back(tmp_path):
+    """The pattern that CAN starve a producer (docs/stack_protocol.md: co-residency is a LIVENESS assumption): another process holds 240 of the
+    256 CUs with ONE kernel that runs for seconds (tools/micro/cu_hog.hip: 150 KB of LDS per workgroup, so nothing of ours fits beside it) --
+    two CUs stay free on every XCD, 16 in all, and gru_wide_kernel's 32 workgroups cannot all be resident.  The resident ones wait for
+    partners that are not scheduled; their bounded wait expires (2^22 polls = 0.67 s), they poison their tiles and set the error word.
+    Measured (tools/hog_diag.py): the launch itself drains only when the other process's kernel leaves -- the dispatcher does not place the
+    remaining workgroups before that -- so the call returns -20 at the hog's end, whatever the poll bound; the engine then re-runs it
+    with a launch per layer (0.8 ms) and the result is the per-layer one bit for bit.  (gru_stack_kernel, one CU per (layer, tile): its 8
+    workgroups fit into the 16 free CUs and the call takes its usual 0.5 ms beside the same hog.)"""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "cu_hog")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tools", "micro", "cu_hog.hip"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from optistate_amd import RNN
+    torch.manual_seed(9)
+    m = RNN(188, 128, 4, 24, torch.device("cuda")).to("cuda").eval()
+    x = torch.rand(64, 10, 188, device="cuda")
+    with torch.no_grad():
+        m(x)
+        eng = m._engine
+        if eng.kernel_name("gru_layer") != "gru_wide_kernel":
+            pytest.skip("the four-CUs-per-tile kernel is switched off in this environment")
+        eng.set_stack_mode(0)
+        ref = m(x).clone()                                  # a launch per layer, idle GPU
+        eng.set_stack_mode(1)
+    torch.cuda.synchronize()
+    fb0 = eng.stack_fallbacks
+    HOG_S = 3.0
+    hog = subprocess.Popen([exe, "240", str(int(HOG_S * 1000))], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = hog.stdout.readline()
+        assert "hog running" in line, line
+        time.sleep(0.3)                                     # the hog's workgroups are resident
+        t0 = time.time()
+        with torch.no_grad():
+            out = m(x)
+        torch.cuda.synchronize()
+        el = time.time() - t0
+    finally:
+        hog.wait(timeout=60)
+    assert torch.equal(out, ref)                            # the per-layer result, nothing poisoned left behind
+    assert eng.stack_fallbacks == fb0 + 1                   # -20 -> one fallback
+    assert 0.5 < el < HOG_S + 1.0, el                       # at least the bounded wait; at most the hog's lifetime + the per-layer launches
+    print(f"starved launch: -20 and the fallback to a launch per layer after {el:.2f} s (hog: {HOG_S} s on 240 of 256 CUs)")
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x)) and eng.kernel_name("gru_layer") == "gru_wide_kernel"      # the stacked mode is back on

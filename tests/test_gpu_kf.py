@@ -57,7 +57,10 @@ def test_g3_trajectory_matches_reference(eng, s, v):
         # K_gain = np.trace(K) (kalman_filter.py:174) from every family: the batch form sums the K it built, the sequential /
         # symmetric / 16-lane forms evaluate trace(P+ H^T R^-1) on their posterior (they never form K)
         kg = r["K_gain"].cpu().numpy()[:, b]
-        assert np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max() < 1e-3 * max(1.0, np.abs(g[f"s{s}_b{b}_K_gain"]).max()), (np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max())
+        # bar: ABSOLUTE 1e-4, the state bar (K_gain is a sum of ten gains, ~2 here; measured 5e-8 ... 5e-7 for every family under the
+        # default noise and 1e-7 (float64 families) / 3.3e-5 (float32 posterior / R = 1e-4) under the fitted set: tools/kgain_error.py;
+        # until round 5 this was a relative 1e-3)
+        assert np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max() < 1e-4, (np.abs(kg - g[f"s{s}_b{b}_K_gain"]).max(), np.abs(g[f"s{s}_b{b}_K_gain"]).max())
         Pf = r["P_final"].cpu().numpy()[:, b].reshape(12, 12)
         ref = g[f"s{s}_b{b}_P_final"]
         assert np.abs(Pf - ref).max() < 1e-3 * np.abs(ref).max()
