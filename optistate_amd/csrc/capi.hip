@@ -60,6 +60,7 @@ int os_create(const os_kf_config *cfg, os_ctx **out)
         e = getenv("OS_FUSED_TILE"); c->tune_fused_tile = e ? atoi(e) : 0;
         e = getenv("OS_MPC_PERSISTENT"); c->tune_mpc_persistent = e ? atoi(e) : 1;
         e = getenv("OS_MPC_QUAD"); c->tune_mpc_quad = e ? atoi(e) : 64;
+        e = getenv("OS_MPC_CAP"); c->tune_mpc_cap = e ? atoi(e) : 0;
         e = getenv("OS_VIT_MLP_FUSED"); c->tune_vit_mlp_fused = e ? atoi(e) : 3;
         // rows per weight-gradient slice; unset (0) = about 32 slices, between one 32-row tile and 512 rows (gru_train_kernels.hip)
         e = getenv("OS_DW_RPS"); c->tune_dw_rps = e && atoi(e) > 0 ? atoi(e) : 0;
@@ -120,10 +121,9 @@ void os_destroy(os_ctx *ctx)
         if (sl.bf) (void)hipFree(sl.bf);
     }
     if (ctx->stack_flags) (void)hipFree(ctx->stack_flags);
-    if (ctx->mpc_counters) (void)hipFree(ctx->mpc_counters);
     if (ctx->stack_err_host) (void)hipHostFree(ctx->stack_err_host);
     if (ctx->stack_err_local) (void)hipFree(ctx->stack_err_local);
-    float *bufs[] = {ctx->gru_seq, ctx->gru_wide_seq, ctx->gru_xs, ctx->gru_hl, ctx->gru_gi, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf, ctx->fused_img3};
+    float *bufs[] = {ctx->gru_seq, ctx->gru_wide_seq, ctx->gru_xs, ctx->gru_hl, ctx->gru_gi, ctx->feat, ctx->nrm, ctx->kf_qr, ctx->mpc_scratch, ctx->fused_img, ctx->fused_img_bf, ctx->fused_img3, ctx->mpc_hand};
     for (float *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < 2 * 512; i++)

@@ -44,7 +44,8 @@ struct os_ctx {
     int tune_gru_stage;                  // 1: large-batch H = 128 inference layers use gru_layer_stage_kernel (x tile by LDS-DMA), 0: gru_layer_kernel<2,2>
     int tune_gru_ahead;                  // 1: H = 128 small-batch layers use gru_layer_ahead_kernel (input half one step ahead), 0: split kernel
     int tune_mpc_persistent;             // os_kf_mpc_run: 1 = one persistent kernel up to 24 trajectories per CU (default), 2 = always, 0 = the per-step launch sequence
-    int *mpc_counters;                   // device: the work counters of mpc_quad.hip's instances (zeroed before every launch)
+    float *mpc_hand; size_t mpc_hand_floats;   // device: hand-over record, todo lists and counters of the two-pass QP (mpc_kernels.hip launch_instances)
+    int tune_mpc_cap;                    // OS_MPC_CAP: iterations after which a 16-lane row hands its problem to a wavefront of its own (default 0: never -- measured at B = 65,536: cap 8 moves 0.35 of 1.38 ms into the second launch, the sum does not change)
     int tune_mpc_quad;                   // OS_MPC_QUAD: batches of at least this many QPs with one / two stance legs run four to a wavefront
                                          // (mpc_quad.hip: 16 lanes per QP); 0 = never; default 64
     int tune_vit_mlp_fused;              // ViT block tail: 3 = projection + LayerNorm + MLP + the next block's LayerNorm / qkv in one kernel (default),

@@ -31,6 +31,14 @@ struct MpcArgs {
     double *warm_u;                // [B][64]
     uint8_t *warm_state;           // [B][64]  (sx+1) | (sy+1) << 2 | sz << 4 of the lane's leg-step
     uint32_t *warm_contact;        // [B]
+    // round 6, the two-pass form (mpc_quad.hip -> mpc_kernels.hip): a 16-lane row gives a problem up after `cap` active-set iterations,
+    // leaves its state (point + faces = the warm-start record) in the warm arrays and appends the index to todo[]; the
+    // wavefront-per-QP instance then continues exactly there.  The iteration count is long-tailed (mean 4, maximum 30-40 at every
+    // step): a straggler costs 30-50 k cycles per iteration on a row and 15 k on a wavefront of its own.
+    int cap;                       // 0: no cap
+    int cold_in;                   // 1: ignore the warm arrays' CONTENT on entry (they are the hand-over buffer of a cold solve)
+    int32_t *todo;                 // [2][B]: indices handed over, per leg count 1 / 2
+    int32_t *todo_count;           // [2]
     MpcParams prm;
 };
 

@@ -580,12 +580,18 @@ template <int NST>
 // B = 65,536: 1.758 -> 1.683 ms per launch against 3), 3 at three (160), 2 at four (185)
 #define OS_MPC_SOLVE_OCC (NST <= 2 ? 4 : NST == 3 ? 3 : 2)
 #endif
-__global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const MpcArgs a)
+__global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const MpcArgs a, int handover)
 {
     typedef WaveMemT<15 * NST> WaveMem;
     __shared__ WaveMem M;
-    const int b = blockIdx.x;
     const size_t B = (size_t)a.B;
+    // handover = 1 (second pass behind mpc_quad.hip's rows): this wavefront continues problem todo[blockIdx.x] from the state the row
+    // left in the warm arrays; the iteration counts add up
+    int b = blockIdx.x;
+    if (handover) {
+        if (NST > 2 || b >= a.todo_count[NST <= 2 ? NST - 1 : 0]) return;
+        b = a.todo[(size_t)(NST <= 2 ? NST - 1 : 0) * B + b];
+    }
     const uint32_t cbits = a.contact[b];
     int legs[4] = {0, 0, 0, 0}, nst = 0;
 #pragma unroll
@@ -613,12 +619,12 @@ __global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const M
         p[j] = (double)a.p[(size_t)j * B + b];
     }
     QpLane io = {0.0, 0};
-    const bool warm = a.warm_u && a.warm_contact[b] != 0xffffffffu && contact_ranks(a.warm_contact[b]) == contact_ranks(cbits);
+    const bool warm = handover || (a.warm_u && !a.cold_in && a.warm_contact[b] != 0xffffffffu && contact_ranks(a.warm_contact[b]) == contact_ranks(cbits));
     if (warm) { io.u = a.warm_u[(size_t)b * 64 + lane]; io.face = a.warm_state[(size_t)b * 64 + lane]; }
     float val;
     int iters;
     bool converged;
-    mpc_solve_wave<NST>(a.prm, cbits, legs, x, ref, p, a.max_iter, warm, M, io, val, iters, converged);
+    mpc_solve_wave<NST>(a.prm, cbits, legs, x, ref, p, handover ? a.max_iter - a.cap : a.max_iter, warm, M, io, val, iters, converged);
     if (lane < 12) a.f_out[(size_t)lane * B + b] = val;
     if (a.u_out && lane < 60) a.u_out[(size_t)lane * B + b] = val;
     if (a.warm_u) {
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const M
         if (lane == 0) a.warm_contact[b] = cbits;
     }
     if (lane == 0) {
-        if (a.iters) a.iters[b] = iters;
+        if (a.iters) a.iters[b] = handover ? a.iters[b] + iters : iters;
         if (!converged) a.status[b] |= 4;
     }
 }
@@ -836,19 +842,41 @@ namespace osm {
 // nst_mask: bit n set = launch the instance for n legs on the ground (bit 0 rides on the 1-leg instance).  Batches of at least
 // ctx->tune_mpc_quad problems: those with one / two force-carrying legs (15 / 30 variables) run sixteen lanes each, four to a
 // wavefront, rows fetching problems from a work counter (mpc_quad.hip); three / four legs stay on the wavefront-per-QP instances.
-static int launch_instances(os_ctx *ctx, const MpcArgs &a, uint32_t nst_mask, hipStream_t s)
+static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask, hipStream_t s)
 {
+    MpcArgs a = a_in;
+    a.cap = 0; a.cold_in = 0; a.todo = nullptr; a.todo_count = nullptr;
     const dim3 grid(a.B), block(64);
     if (ctx->tune_mpc_quad != 0 && a.B >= ctx->tune_mpc_quad && (nst_mask & 7u)) {
-        if (!ctx->mpc_counters && hipMalloc((void **)&ctx->mpc_counters, 64) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: cannot allocate the work counters");
-        if (hipMemsetAsync(ctx->mpc_counters, 0, 8, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
-        os_mpc_launch_quad(a, nst_mask & 7u, ctx->mpc_counters, ctx->cu_count, s);
+        // pass 1: sixteen lanes per QP, rows fetch problems from a work counter and give one up after `cap` iterations;
+        // pass 2: the problems handed over continue on a wavefront of their own.  The hand-over record is the warm-start record: a cold
+        // solve borrows the context's scratch for it.
+        const size_t Bz = (size_t)a.B;
+        const size_t need = Bz * 128 + Bz * 16 + Bz + 2 * Bz + 16;      // u [B][64] doubles | faces [B][64] bytes | contact [B] | todo [2][B] | counters
+        if (os_ensure_scratch(ctx, &ctx->mpc_hand, &ctx->mpc_hand_floats, need)) return -10;
+        int32_t *counters = (int32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16 + Bz + 2 * Bz);
+        a.todo = (int32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16 + Bz);
+        a.todo_count = counters + 2;
+        a.cap = ctx->tune_mpc_cap;
+        if (!a.warm_u) {
+            a.warm_u = (double *)ctx->mpc_hand; a.warm_state = (uint8_t *)(ctx->mpc_hand + Bz * 128);
+            a.warm_contact = (uint32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16);
+            a.cold_in = 1;
+        }
+        if (hipMemsetAsync(counters, 0, 16, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
+        os_mpc_launch_quad(a, nst_mask & 7u, counters, ctx->cu_count, s);
+        if (a.cap > 0) {
+            if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a, 1);
+            if (nst_mask & 4u) hipLaunchKernelGGL(mpc_solve_kernel<2>, grid, block, 0, s, a, 1);
+        }
         nst_mask &= ~7u;
+        a.cap = 0; a.todo = nullptr;
+        if (a.cold_in) { a.warm_u = nullptr; a.warm_state = nullptr; a.warm_contact = nullptr; a.cold_in = 0; }
     }
-    if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a);
-    if (nst_mask & 4u) hipLaunchKernelGGL(mpc_solve_kernel<2>, grid, block, 0, s, a);
-    if (nst_mask & 8u) hipLaunchKernelGGL(mpc_solve_kernel<3>, grid, block, 0, s, a);
-    if (nst_mask & 16u) hipLaunchKernelGGL(mpc_solve_kernel<4>, grid, block, 0, s, a);
+    if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a, 0);
+    if (nst_mask & 4u) hipLaunchKernelGGL(mpc_solve_kernel<2>, grid, block, 0, s, a, 0);
+    if (nst_mask & 8u) hipLaunchKernelGGL(mpc_solve_kernel<3>, grid, block, 0, s, a, 0);
+    if (nst_mask & 16u) hipLaunchKernelGGL(mpc_solve_kernel<4>, grid, block, 0, s, a, 0);
     return 0;
 }
 

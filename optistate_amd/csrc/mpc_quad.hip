@@ -426,7 +426,7 @@ struct Quad {
         __builtin_amdgcn_wave_barrier();
         // cold start: stance (and unconstrained) legs free, swing legs zero; warm: the previous solve's point and faces when the
         // force-carrying legs' contact bytes are unchanged (the pyramids do not move: the old u stays feasible)
-        const bool warm = a.warm_u && a.warm_contact[b] != 0xffffffffu && contact_ranks(a.warm_contact[b]) == contact_ranks(cbits);
+        const bool warm = a.warm_u && !a.cold_in && a.warm_contact[b] != 0xffffffffu && contact_ranks(a.warm_contact[b]) == contact_ranks(cbits);
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
             const int v = L.l + 16 * h;
@@ -437,6 +437,28 @@ struct Quad {
     }
 
     // the converged (or capped) problem's outputs in the reference's variable order (12 per horizon step, leg-major; swing legs zero)
+    // the problem goes on in the second pass: its state into the warm arrays (the hand-over record), its index onto the todo list
+    static __device__ __forceinline__ void hand_over_row(const Lane &L, const MpcArgs &a, Row &R)
+    {
+        const size_t B = (size_t)a.B;
+        const int b = R.b;
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const int v = L.l + 16 * h;
+            a.warm_u[(size_t)b * 64 + v] = L.var[h].pad ? 0.0 : R.u[h];
+            a.warm_state[(size_t)b * 64 + v] = (uint8_t)R.F.f[h];
+        }
+        if (VPL == 1) { a.warm_u[(size_t)b * 64 + 16 + L.l] = 0.0; a.warm_state[(size_t)b * 64 + 16 + L.l] = 0x05; }
+        // (lanes 32..63 of the wavefront-per-QP layout are pad lanes at one / two legs: their record is never read as a variable)
+        if (L.l == 0) {
+            a.warm_contact[b] = R.cbits;
+            if (a.iters) a.iters[b] = R.iters;
+            const int at = atomicAdd(&a.todo_count[NST - 1], 1);
+            a.todo[(size_t)(NST - 1) * B + at] = b;
+        }
+        R.has = false;
+    }
+
     static __device__ __forceinline__ void finish_row(const Lane &L, const MpcArgs &a, Mem &M, Row &R)
     {
         const size_t B = (size_t)a.B;
@@ -758,6 +780,7 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
         if (R.has) {
             Q::iterate_row(L, a.prm, Sh, M, R, S);
             if (R.done || R.iters >= a.max_iter) Q::finish_row(L, a, M, R);
+            else if (a.cap > 0 && R.iters >= a.cap) Q::hand_over_row(L, a, R);
         }
         OSQ_STAMP(6)                                 // ratio test / multipliers / outputs
 #ifdef OSQ_TS

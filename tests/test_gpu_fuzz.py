@@ -19,3 +19,26 @@ def test_fixed_seed_slice_of_the_shape_sweeps(script, n, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(n), str(seed)], capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.splitlines()[-6:])
     assert r.returncode == 0 and (f"{n} cases, 0 above the bars" in r.stdout or f"{n} problems, 0 above the bars" in r.stdout), tail + r.stderr[-1500:]
+
+
+def test_fresh_seeds_from_the_build_id_keep_hunting():
+    """the sweeps found two real bugs in round 5 with seeds nobody had fixed beforehand.  Every build of the library
+    gets two seeds of its own (from os_build_id(): a changed kernel is fuzzed with inputs the previous build never saw) on each of the
+    eight sweeps, smaller slices than the fixed one, four processes at a time; a failure prints script, seed and the offending case."""
+    from concurrent.futures import ThreadPoolExecutor
+    from optistate_amd import _capi
+    bid = _capi.load().os_build_id().decode()
+    base = int(bid.split("-")[0][:8], 16) % (2 ** 30)
+    jobs = [(script, n, base + 1000 * k) for script, n in (("fuzz_shapes.py", 8), ("fuzz_kf.py", 8), ("fuzz_fused.py", 5), ("fuzz_mpc.py", 40), ("fuzz_pieces.py", 16),
+                                                           ("fuzz_mpc_run.py", 3), ("fuzz_vit.py", 2), ("fuzz_trainer.py", 3)) for k in (1, 2)]
+
+    def run(job):
+        script, n, seed = job
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(n), str(seed)], capture_output=True, text=True, timeout=900)
+        ok = r.returncode == 0 and (f"{n} cases, 0 above the bars" in r.stdout or f"{n} problems, 0 above the bars" in r.stdout)
+        return ok, f"{script} n={n} seed={seed} (build {bid})\n" + "\n".join(l for l in r.stdout.splitlines() if "ABOVE" in l or "above the bars" in l)[-3000:] + r.stderr[-800:]
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(run, jobs))
+    bad = [msg for ok, msg in res if not ok]
+    assert not bad, "\n\n".join(bad)

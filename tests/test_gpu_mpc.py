@@ -57,6 +57,25 @@ def test_mpc_matches_certified_oracle(eng, monkeypatch):
     assert worst < 2e-4, worst
 
 
+def test_two_pass_form_hands_long_problems_over_exactly(monkeypatch):
+    """OS_MPC_CAP = 3: the sixteen-lanes-per-QP rows (mpc_quad.hip) give every problem up after three active-set iterations and the
+    wavefront-per-QP instance continues from the hand-over record (point + faces): the same controls, the same total iteration count
+    as the one-pass solve and as the wavefront-per-QP solver alone (OS_MPC_QUAD=0)."""
+    from optistate_amd import Engine
+    X, R, P, Cn = _problems(512, seed=21)
+    res = {}
+    for name, env in (("wave", {"OS_MPC_QUAD": "0"}), ("quad", {"OS_MPC_QUAD": "1", "OS_MPC_CAP": "0"}), ("two-pass", {"OS_MPC_QUAD": "1", "OS_MPC_CAP": "3"})):
+        for k in ("OS_MPC_QUAD", "OS_MPC_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = _solve_gpu(Engine(0), X, R, P, Cn)
+        res[name] = (r["u"].cpu().numpy(), r["iters"].cpu().numpy(), r["status"].cpu().numpy())
+    for name in ("quad", "two-pass"):
+        assert np.abs(res[name][0] - res["wave"][0]).max() < 1e-5 and np.array_equal(res[name][1], res["wave"][1]) and not res[name][2].any(), name
+    assert (res["wave"][1] > 3).sum() > 50          # the second pass had work to do
+
+
 def test_mpc_constraints_hold_and_swing_zero(eng):
     X, R, P, Cn = _problems(512, seed=5, scale_cycle=(1.0, 3.0, 6.0))
     r = _solve_gpu(eng, X, R, P, Cn)

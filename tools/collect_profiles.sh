@@ -107,4 +107,14 @@ python3 tools/wide_probe.py 200 2>/dev/null | grep "^|" > $O/wide_probe.md
 bash tools/wide_ts.sh 2>&1 | grep "cycles per step" | sort | tail -4 > $O/wide_timestamps_raw.txt
 bash tools/wide_bwd_ts.sh 2>&1 | grep "cycles per step" | sort -u | tail -4 > $O/wide_bwd_timestamps_raw.txt
 stats train_B64 --mode train --batch 64 --steps 200 --warmup 20 --cpu-seconds 0
+# round 6: the shards of a fixed 65,536 batch (tile shapes of the single fused kernel), the strong-scaling form of the bench line at the
+# shard sizes (one rank each: what a rank of an N-GPU job runs), the reference's caller loops on the drop-in classes, the QP's counters
+python3 tools/shard_sweep.py --iters 10 --out $O/shard_sweep.md > $O/shard_sweep.log 2>&1
+for b in 32768 16384 8192; do python3 bench.py --scaling strong --batch $b --steps 20 --warmup 3 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_strong_shard_B$b.json 2>> $O/bench.err; done
+python3 bench.py --gpus 2 --share-gpu --scaling strong --steps 5 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_share_gpu2_strong.json 2>> $O/bench.err
+python3 tools/dropin_loops.py --out $O/dropin_loops.json > $O/dropin_loops.log 2>&1
+OS_MPC_QUAD=0 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_wave_per_qp.json 2>> $O/bench.err
+bash tools/pmc_any.sh ${TAG}_mpcq2 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAVE_CYCLES" $R/tools/mpc_run_bench.py 65536 10 > $O/pmc_mpc_lds.txt 2>&1
+python3 tools/mpc_iter_stats.py > $O/mpc_iter_stats.txt 2>> $O/bench.err
+python3 tools/stack_wait_time.py > $O/stack_wait_time.txt 2>&1
 ls $O

@@ -81,12 +81,14 @@ def main():
         rows = [b for b in np.unique(np.r_[0, B // 2, B - 1]) if good[b]][:2]
         To = min(T, 8)
         xo, fo = oracle_run(d, Q, R, To, rows) if rows else (np.zeros((0, To, 12)), np.zeros((0, To, 12)))
-        e_xo = float(np.abs(xp[rows][:, :To] - xo).max()) if rows else 0.0
-        e_fo = float(np.abs(fp[rows][:, :To] - fo).max()) if rows else 0.0
+        # EACH form against the float64 oracle chain, separately, with the FLAT bars (state 1e-4, forces 2e-2 N): ADVICE r5
+        e_xo = float(max(np.abs(xp[rows][:, :To] - xo).max(), np.abs(xs[rows][:, :To] - xo).max())) if rows else 0.0
+        e_fo = float(max(np.abs(fp[rows][:, :To] - fo).max(), np.abs(fs[rows][:, :To] - fo).max())) if rows else 0.0
         # forces: the QP's solution moves by ~100-500 N per unit of state near a face change, the states agree to ~3e-5: 2e-2 N (of up to
         # 150) -- and in proportion where the two forms' STATES are further apart (still inside their own 1e-4 bar): nominal inputs too are a
         # closed loop, a rounding difference can grow ~1.4x per step over a 20-step stretch before a face change resets it (seen: seed 142,
         # B = 1,000, T = 40: states 7e-5 apart at the worst step, forces 3.7e-2 N, both forms within 3e-2 N of the float64 chain)
+        # (only THIS bar, form against form, scales with their state distance; restated after seed 142 of the round-5 sweep, recorded above)
         f_bar = max(2e-2, 600.0 * e_x)
         ok = e_x < 1e-4 and e_f < f_bar and e_xo < 1e-4 and e_fo < 2e-2 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
         diag = ""

@@ -2,7 +2,7 @@
 # Copies the summaries of a tools/collect_profiles.sh run (gpurun_out/<tag>/: bench lines, kernel-stat tables, counter and timestamp
 # summaries -- not the raw rocprofv3 directories) into profiles/ as <tag>_<name>.   usage: tools/publish_profiles.sh <tag>
 TAG=${1:-r04}; R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/$TAG
-for f in $O/*.json $O/*_kernel_stats.md $O/*.txt $O/*_raw.md; do
+for f in $O/*.json $O/*_kernel_stats.md $O/*.txt $O/*_raw.md $O/shard_sweep.md; do
   [ -f "$f" ] || continue
   # an empty file or a Python traceback is a collection step that failed: say so, keep what profiles/ holds
   if [ ! -s "$f" ] || grep -q "^Traceback (most recent call last)" "$f"; then echo "NOT PUBLISHED (empty or a traceback): $f" >&2; continue; fi
