@@ -561,6 +561,9 @@ def bench_train(a, rk):
     model = RNN(I, H, L, C, dev).to(dev)
     tr = DataParallelTrainer(model, lr=1e-4, split_allreduce=not a.no_split_allreduce, force_distributed=a.force_dist,
                              proto=a.rccl_proto if rk.dist else None, algo=a.rccl_algo if rk.dist else None)
+    if a.split_bf16:
+        # opt-in (second line, never the default): the weight-gradient products on the bf16 matrix instruction with split operands
+        tr.eng.set_gru_split_bf16(a.split_bf16, train=True)
     g = torch.Generator(device=dev); g.manual_seed(100 + rk.rank)
     x = torch.rand(B, T, I, device=dev, generator=g); y = torch.rand(B, C // 2, device=dev, generator=g)
     el, loss, _ = timed_region(rk, a.warmup, a.steps, lambda: tr.step(x, y))
@@ -593,7 +596,7 @@ def bench_train(a, rk):
         fl_launch = phase_flops[dom] / dk["launches_per_step"]
         ach = fl_launch / (dk["ms_per_launch"] * 1e-3) / 1e12
         out = base_line(a, rk, "GRU training windows/sec (gru_train.py step, data parallel)", "windows/s", B * rk.world * a.steps / el,
-                        el, "f32", {"workload": "gru_train.py step RNN(188,128,4,24), Adam lr 1e-4, windows of 10", "batch_per_gpu": B,
+                        el, f"f32; weight-gradient GEMMs on bf16x{a.split_bf16}-split operands, f32 accumulate (opt-in)" if a.split_bf16 else "f32", {"workload": "gru_train.py step RNN(188,128,4,24), Adam lr 1e-4, windows of 10", "batch_per_gpu": B,
                                     "seq_len": T, "global_batch": B * rk.world,
                                     "parallelism": f"dp{rk.world}, one flat fp32 bucket all-reduce", "baseline_config": "BASELINE.json configs[3]"})
         tot = fl_fwd + fl_sweep + fl_dw

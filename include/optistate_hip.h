@@ -260,6 +260,10 @@ int os_stack_check(os_ctx *ctx, void *stream);
  * OS_GRU_SPLIT_ANY_BATCH: any batch that is a multiple of 4 -- tests); every other shape and the training path stay on the fp32
  * kernels.  The reference computes this GEMM in fp32 (torch.nn.GRU, gru/gru_model.py:12); returns -4 for another mode. */
 #define OS_GRU_SPLIT_ANY_BATCH 0x100
+/* round 6: | OS_GRU_SPLIT_TRAIN extends the opt-in to the TRAINING step's weight-gradient products (gru/gru_train.py:247 loss.backward():
+ * dW_ih += dG^T X, dW_hh += dG^T H_prev on dw3_bf16_kernel, fp32 accumulation and fp32 atomics unchanged); the training forward and the
+ * backward sweep stay on the fp32 matrix instruction.  With 3 terms the gradients equal the fp32 path's to fp32 rounding. */
+#define OS_GRU_SPLIT_TRAIN 0x200
 int os_gru_set_split_bf16(os_ctx *ctx, int32_t mode);
 
 /* The post-processing of the reference's evaluation loop (gru/gru_test.py:184-189,208-213) in one launch: out [B][2 n] = [prediction |

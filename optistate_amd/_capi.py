@@ -22,6 +22,7 @@ OS_KF_WAVE_PER_TRAJECTORY = 4096
 OS_STATUS_S_NOT_PD, OS_STATUS_NONFINITE, OS_STATUS_QP_ITER, OS_STATUS_P0_ASYM, OS_STATUS_TRUNC_EDGE = 1, 2, 4, 8, 16
 OS_STATUS_FAIL_MASK = 15
 OS_GRU_SPLIT_ANY_BATCH = 0x100
+OS_GRU_SPLIT_TRAIN = 0x200
 OS_ERR_STACK_LOST = -20     # a layer-pipelined launch (gru_stack_kernel / bwd_sweep_stack_kernel) lost a producer: see os_gru_set_stack
 OS_STEP_ODOM, OS_STEP_PREDICT, OS_STEP_UPDATE, OS_STEP_DENSE_FD, OS_STEP_MPC = 1, 2, 4, 8, 16
 OS_PROF_PHASES = 12         # include/optistate_hip.h

@@ -375,7 +375,8 @@ extern "C" int os_gru_set_split_bf16(os_ctx *ctx, int32_t mode)
 {
     OS_CHECK_CTX(ctx);
     const int spl = mode & 3;
-    if ((mode & ~(3 | OS_GRU_SPLIT_ANY_BATCH)) || spl == 1) return os_fail(ctx, -4, "os_gru_set_split_bf16: mode is 0 (exact fp32), 2 or 3 bf16 terms, optionally | OS_GRU_SPLIT_ANY_BATCH");
+    if ((mode & ~(3 | OS_GRU_SPLIT_ANY_BATCH | OS_GRU_SPLIT_TRAIN)) || spl == 1)
+        return os_fail(ctx, -4, "os_gru_set_split_bf16: mode is 0 (exact fp32), 2 or 3 bf16 terms, optionally | OS_GRU_SPLIT_ANY_BATCH | OS_GRU_SPLIT_TRAIN");
     ctx->gru_split_bf16 = mode;
     return 0;
 }

@@ -1253,6 +1253,208 @@ __global__ __launch_bounds__(256, 2) void dw3_kernel(const Dw3Args a)
     }
 }
 
+// ---- dw3_bf16_kernel<NCX, NCH, SPL> (round 6, OPT-IN: os_gru_set_split_bf16 | OS_GRU_SPLIT_TRAIN; never the default) --------------------
+// The same two products (dW_ih += dG_i^T X, dW_hh += dG_h^T H_prev) with every fp32 operand split into SPL bf16 terms and the products
+// on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 atomics unchanged): SPL = 3 issues hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid per
+// operand pair (everything down to 2^-16 of a product; what is dropped is below fp32 rounding), SPL = 2 hi.hi, hi.lo, lo.hi.  The fp32
+// matrix instruction runs at 1/16 of the bf16 rate, so six bf16 products cost 6/16 of one fp32 product's matrix-pipe time.
+// A 32-row tile = two 16-row k-blocks.  The X / h_{t-1} tile is split ONCE per workgroup (a thread takes eight consecutive rows of a
+// column: the eight k values of one lane's B fragment) and its bf16 terms are written to LDS in fragment order, one ds_read_b128 per
+// (chunk, term) and wave afterwards; the gate-derivative column of a wave (A operand) is split in registers.  The tile of step t + 1
+// travels in registers underneath the MFMAs of step t.  Same slices, same XCD-aware order, same epilogue as dw3_kernel.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// workgroup barrier that orders LDS traffic only (__syncthreads() also waits for the loads in flight: the next tile's)
+__device__ __forceinline__ void lds_barrier_dw()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#ifndef OST_DWBF_OCC
+#define OST_DWBF_OCC 1
+#endif
+template <int NCX, int NCH, int SPL>
+__global__ __launch_bounds__(256, OST_DWBF_OCC) void dw3_bf16_kernel(const Dw3Args a)
+{
+    constexpr int TR = 32, NCT = NCX + NCH, PX = NCX * 32, PH = NCH * 32;
+    constexpr int UX = NCX / 2, UH = NCH / 2;                     // (column, 8-row group) units per thread and tile: PX * 4 / 256
+    static_assert(NCX % 2 == 0 && NCH % 2 == 0, "whole units per thread");
+    // bf16 terms of the tile in B-fragment order: [k-block 2][chunk NCT][term SPL][lane 64] x 16 bytes
+    __shared__ __attribute__((aligned(16))) i32x4_t Bt[2 * NCT * SPL * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, kk = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = slot % a.ngroups, by = (slot / a.ngroups) * 8 + xcd;
+    const int j0 = (bx * 4 + wave) * 32;
+    const bool jok = j0 < a.H3;
+    const bool ngate = 3 * j0 >= 2 * a.H3;
+    const size_t r0 = (size_t)by * a.rows_per_slice;
+    size_t r1 = r0 + a.rows_per_slice;
+    if (r1 > a.rows) r1 = a.rows;
+    if (r0 >= r1) return;
+    const int ntiles = (int)((r1 - r0 + TR - 1) / TR);
+    const uint32_t nrows = (uint32_t)(r1 - r0);
+    const osk::rsrc_t rg = osk::make_rsrc(a.dG + r0 * a.ldg, jok ? nrows * (uint32_t)a.ldg * 4u : 0u);
+    // A operand: rows 16 kb + 8 kk + q of the tile, column j0 + li
+    const uint32_t gli = (uint32_t)(8 * kk * a.ldg + j0 + li) * 4u, glh = gli + (ngate ? (uint32_t)a.H * 4u : 0u), grow = (uint32_t)a.ldg * 4u;
+    const uint32_t xstride = a.x_btf ? (uint32_t)a.T * (uint32_t)a.Kx : (uint32_t)a.Kx;
+    const osk::rsrc_t rxs = osk::make_rsrc(a.X, (uint32_t)((size_t)a.T * a.B * a.Kx * 4));
+    const osk::rsrc_t rhs = osk::make_rsrc(a.Hp, (uint32_t)((size_t)a.T * a.B * a.H * 4));
+    // this thread's units: u = threadIdx.x + 256 i -> column u % P, row group u / P (k-block rg >> 1, lane half rg & 1)
+    uint32_t uxo[UX], uho[UH];
+    int uxl[UX], uhl[UH];                                          // LDS slot (in 16-byte units) of term 0
+#pragma unroll
+    for (int i = 0; i < UX; i++) {
+        const int u = threadIdx.x + 256 * i, col = u % PX, rgp = u / PX;
+        uxo[i] = col < a.Kx ? ((uint32_t)(8 * rgp) * xstride + (uint32_t)col) * 4u : 0x80000000u;
+        uxl[i] = (((rgp >> 1) * NCT + col / 32) * SPL) * 64 + (rgp & 1) * 32 + (col & 31);
+    }
+#pragma unroll
+    for (int i = 0; i < UH; i++) {
+        const int u = threadIdx.x + 256 * i, col = u % PH, rgp = u / PH;
+        uho[i] = ((uint32_t)(8 * rgp) * (uint32_t)a.H + (uint32_t)col) * 4u;
+        uhl[i] = (((rgp >> 1) * NCT + NCX + col / 32) * SPL) * 64 + (rgp & 1) * 32 + (col & 31);
+    }
+    auto hzero = [&](int tile) { return r0 + (size_t)tile * TR < (size_t)a.B; };
+    float vx[UX][8], vh[UH][8];
+    auto tile_load = [&](int tile) {
+        const uint32_t xr0 = (uint32_t)r0 + (uint32_t)tile * TR;
+        const uint32_t sox = __builtin_amdgcn_readfirstlane(
+            (a.x_btf ? (xr0 % (uint32_t)a.B) * (uint32_t)a.T + xr0 / (uint32_t)a.B : xr0) * (uint32_t)a.Kx * 4u);
+#pragma unroll
+        for (int i = 0; i < UX; i++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) vx[i][q] = osk::buf_load(rxs, uxo[i] + (uint32_t)q * xstride * 4u, sox);
+        if (!hzero(tile)) {
+            const uint32_t soh = __builtin_amdgcn_readfirstlane((xr0 - (uint32_t)a.B) * (uint32_t)a.H * 4u);
+#pragma unroll
+            for (int i = 0; i < UH; i++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) vh[i][q] = osk::buf_load(rhs, uho[i] + (uint32_t)q * (uint32_t)a.H * 4u, soh);
+        }
+    };
+    auto split8 = [&](const float (&v)[8], i32x4_t (&t)[SPL]) {   // eight k values -> SPL fragments of eight bf16 (array references: pointers put the arrays in scratch)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            uint32_t w[SPL];
+            osg::split_pair<SPL>(v[2 * jj], v[2 * jj + 1], w);
+#pragma unroll
+            for (int sp = 0; sp < SPL; sp++) t[sp][jj] = (int)w[sp];
+        }
+    };
+    auto tile_store = [&](bool hz) {
+#pragma unroll
+        for (int i = 0; i < UX; i++) {
+            i32x4_t t[SPL];
+            split8(vx[i], t);
+#pragma unroll
+            for (int sp = 0; sp < SPL; sp++) Bt[uxl[i] + sp * 64] = t[sp];
+        }
+        if (!hz) {
+#pragma unroll
+            for (int i = 0; i < UH; i++) {
+                i32x4_t t[SPL];
+                split8(vh[i], t);
+#pragma unroll
+                for (int sp = 0; sp < SPL; sp++) Bt[uhl[i] + sp * 64] = t[sp];
+            }
+        }
+    };
+    f32x16 accx[NCX], acch[NCH];
+#pragma unroll
+    for (int c = 0; c < NCX; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) accx[c][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acch[c][e] = 0.f;
+    // the wave's gate-derivative column of tile t + 1 is requested together with the X / h tile, a tile ahead (two register sets)
+    float gi0[2][8], gh0[2][8], gi1[2][8], gh1[2][8];         // (separately named sets: a leading buffer dimension put all four in scratch)
+    auto dg_load = [&](int tile, float (&gi_)[2][8], float (&gh_)[2][8]) {
+        const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)tile * (uint32_t)TR * grow);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                gi_[kb][q] = osk::buf_load_nt(rg, gli, so + (uint32_t)(16 * kb + q) * grow);
+                gh_[kb][q] = ngate ? osk::buf_load_nt(rg, glh, so + (uint32_t)(16 * kb + q) * grow) : 0.f;
+            }
+    };
+    // (weight term, activation term), largest first
+    constexpr int NP = SPL == 3 ? 6 : 3;
+    constexpr int PW3[6] = {0, 0, 1, 0, 2, 1}, PB3[6] = {0, 1, 0, 2, 0, 1}, PW2[3] = {0, 0, 1}, PB2[3] = {0, 1, 0};
+    float bsi = 0.f, bsh = 0.f;
+    auto tile_mfma = [&](bool hz, const float (&gi_)[2][8], const float (&gh_)[2][8]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            i32x4_t Ai[SPL], Ah[SPL];
+            split8(gi_[kb], Ai);
+            split8(gh_[kb], Ah);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { bsi += gi_[kb][q]; bsh += ngate ? gh_[kb][q] : gi_[kb][q]; }
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                if (c >= NCX && hz) break;
+                i32x4_t Bf[SPL];
+#pragma unroll
+                for (int sp = 0; sp < SPL; sp++) Bf[sp] = Bt[((kb * NCT + c) * SPL + sp) * 64 + lane];
+#pragma unroll
+                for (int pi = 0; pi < NP; pi++) {
+                    const int wt = SPL == 3 ? PW3[pi] : PW2[pi], bt = SPL == 3 ? PB3[pi] : PB2[pi];
+                    const i32x4_t aw = (c >= NCX && ngate) ? Ah[wt] : Ai[wt];
+                    if (c < NCX) accx[c < NCX ? c : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, Bf[bt]), accx[c < NCX ? c : 0], 0, 0, 0);
+                    else acch[c >= NCX ? c - NCX : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, Bf[bt]), acch[c >= NCX ? c - NCX : 0], 0, 0, 0);
+                }
+            }
+        }
+    };
+    tile_load(0);
+    dg_load(0, gi0, gh0);
+    for (int tile = 0; tile < ntiles; tile += 2) {
+        // (two tiles per trip: the register sets of the gate-derivative column alternate with compile-time indices)
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            const int tl = tile + par;
+            if (tl >= ntiles) break;
+            const bool hz = hzero(tl);
+            tile_store(hz);                                         // (waits for the tile's loads)
+            lds_barrier_dw();                                       // the tile's terms are in LDS
+            if (tl + 1 < ntiles) {                                  // travel underneath this tile's MFMAs
+                tile_load(tl + 1);
+                if (par == 0) dg_load(tl + 1, gi1, gh1); else dg_load(tl + 1, gi0, gh0);
+            }
+            if (par == 0) tile_mfma(hz, gi0, gh0); else tile_mfma(hz, gi1, gh1);
+            lds_barrier_dw();                                       // every wave has read its fragments: the buffer may be rewritten
+        }
+    }
+    if (jok && !(a.dbg & 1)) {
+        const osk::rsrc_t rwx = osk::make_rsrc(a.dWih, (uint32_t)a.H3 * (uint32_t)a.Kx * 4u);
+        const osk::rsrc_t rwh = osk::make_rsrc(a.dWhh, (uint32_t)a.H3 * (uint32_t)a.H * 4u);
+#pragma unroll
+        for (int c = 0; c < NCX; c++) {
+            const int k = c * 32 + li;
+            if (k < a.Kx) {
+                const uint32_t vo = (uint32_t)((4 * kk) * a.Kx + k) * 4u;
+#pragma unroll
+                for (int e = 0; e < 16; e++) buf_atomic_add(accx[c][e], rwx, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.Kx) * 4u);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const uint32_t vo = (uint32_t)((4 * kk) * a.H + c * 32 + li) * 4u;
+#pragma unroll
+            for (int e = 0; e < 16; e++) buf_atomic_add(acch[c][e], rwh, vo, (uint32_t)((j0 + (e & 3) + 8 * (e >> 2)) * a.H) * 4u);
+        }
+        bsi += __shfl_xor(bsi, 32, 64);              // the two row halves of the same gate unit
+        bsh += __shfl_xor(bsh, 32, 64);
+        if (kk == 0) {
+            global_fadd(a.dbih, (uint32_t)a.H3 * 4u, (uint32_t)(j0 + li), bsi);
+            global_fadd(a.dbhh, (uint32_t)a.H3 * 4u, (uint32_t)(j0 + li), bsh);
+        }
+    }
+}
+
 // column sums of columns [n0, N) of a [R][N] row-major matrix into dst (bias gradients): 64 columns x 4 row-lanes per
 // workgroup, 256 rows per workgroup (64 loads per thread, eight in flight), one atomic per column per workgroup
 // copy_src / copy_n: block (0, 0) also copies copy_n floats copy_src -> dst (the r and z thirds of b_hh's gradient equal b_ih's)
@@ -1741,8 +1943,14 @@ static int backward_impl(os_ctx *ctx, const os_gru_dims &d, const float *w_flat,
             d.dbg = ctx->tune_dw_dbg;
             const unsigned nslices = (unsigned)((rows + rps - 1) / rps);
             const dim3 grid(8u * ((nslices + 7) / 8) * (unsigned)d.ngroups);       // see the XCD-aware order in the kernel
-            const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, "dw3_kernel");
-            if (wide) hipLaunchKernelGGL((dw3_kernel<6, 4, 16>), grid, dim3(256), 0, sw, d);
+            const int spl = (ctx->gru_split_bf16 & OS_GRU_SPLIT_TRAIN) ? (ctx->gru_split_bf16 & 3) : 0;      // opt-in: bf16 terms per fp32 operand
+            const int dslot = os_prof_begin(ctx, OS_PHASE_TRAIN_DW, sw, spl == 3 ? "dw3_bf16_kernel<3>" : spl == 2 ? "dw3_bf16_kernel<2>" : "dw3_kernel");
+            if (spl && rps % 32 == 0 && B % 32 == 0) {
+#define OST_DWBF(NCX_, NCH_) { if (spl == 3) hipLaunchKernelGGL((dw3_bf16_kernel<NCX_, NCH_, 3>), grid, dim3(256), 0, sw, d); else hipLaunchKernelGGL((dw3_bf16_kernel<NCX_, NCH_, 2>), grid, dim3(256), 0, sw, d); }
+                if (wide) OST_DWBF(6, 4) else if (nchh == 4 && ncx == 4) OST_DWBF(4, 4) else if (nchh == 4) OST_DWBF(2, 4) else OST_DWBF(2, 2)
+#undef OST_DWBF
+            }
+            else if (wide) hipLaunchKernelGGL((dw3_kernel<6, 4, 16>), grid, dim3(256), 0, sw, d);
             else if (nchh == 4 && ncx == 4) hipLaunchKernelGGL((dw3_kernel<4, 4>), grid, dim3(256), 0, sw, d);
             else if (nchh == 4) hipLaunchKernelGGL((dw3_kernel<2, 4>), grid, dim3(256), 0, sw, d);
             else hipLaunchKernelGGL((dw3_kernel<2, 2>), grid, dim3(256), 0, sw, d);

@@ -96,12 +96,14 @@ class Engine:
         (os_fused_set_tile in include/optistate_hip.h)."""
         self._check(self.lib.os_fused_set_tile(self._h, int(tile)), "os_fused_set_tile")
 
-    def set_gru_split_bf16(self, terms, any_batch=False):
+    def set_gru_split_bf16(self, terms, any_batch=False, train=False):
         """OPT-IN reduced precision for the GRU layer GEMMs (never the default; the reference computes them in fp32,
         gru/gru_model.py:12): 0 = exact fp32; 3 / 2 = every operand of an H = 128 inference layer's gate GEMM split into that many bf16
         terms, products on the bf16 matrix instruction with fp32 accumulation (os_gru_set_split_bf16 in include/optistate_hip.h:
         batches of at least 128 x CUs trajectories; any_batch: every batch that is a multiple of 4)."""
-        self._check(self.lib.os_gru_set_split_bf16(self._h, int(terms) | (_capi.OS_GRU_SPLIT_ANY_BATCH if any_batch else 0)), "os_gru_set_split_bf16")
+        # train=True: also the training step's weight-gradient products (OS_GRU_SPLIT_TRAIN, round 6)
+        self._check(self.lib.os_gru_set_split_bf16(self._h, int(terms) | (_capi.OS_GRU_SPLIT_ANY_BATCH if any_batch else 0) |
+                                                   (_capi.OS_GRU_SPLIT_TRAIN if train else 0)), "os_gru_set_split_bf16")
 
     def _stack_guarded(self, call):
         """Runs call(); in VERIFIED mode (1) a StackLost belongs to the launch this very call made (the library waited for it: the

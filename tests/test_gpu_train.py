@@ -64,6 +64,35 @@ def test_backward_matches_torch_autograd(dims, B, T):
     assert (xg.grad.cpu().double() - ref_dx).abs().max().item() < 2e-4 * scale
 
 
+@pytest.mark.parametrize("terms,bar", [(3, 2e-4), (2, 2e-3)])
+@pytest.mark.parametrize("dims,B,T", [((60, 128, 2, 24), 256, 6), ((60, 64, 2, 24), 96, 5), ((188, 128, 2, 24), 64, 3), ((188, 128, 4, 24), 2048, 10)])
+def test_opt_in_split_bf16_weight_gradients_match_float64_autograd(dims, B, T, terms, bar):
+    """OS_GRU_SPLIT_TRAIN (opt-in, never the default): the weight-gradient products on dw3_bf16_kernel -- every fp32 operand split into
+    three (two) bf16 terms, fp32 accumulation.  Three terms keep the fp32 path's bar against float64 autograd (2e-4 of the largest entry);
+    two terms (16 mantissa bits per operand) are held to 2e-3.  The default path is untouched (the engine is switched back)."""
+    from optistate_amd import RNN
+    I, H, L, C = dims
+    torch.manual_seed(2)
+    m = RNN(I, H, L, C, torch.device("cuda")).to("cuda")
+    x = torch.rand(B, T, I); y = torch.rand(B, C // 2)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref_out, ref_tgt, ref_loss, ref_g, ref_dx = torch_reference_grads(sd, dims, x, y)
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg)
+    eng = m._engine
+    eng.set_gru_split_bf16(terms, train=True)
+    try:
+        tgt = torch.cat([y.cuda(), (out[:, :C // 2].detach() - y.cuda()).abs()], dim=1)
+        torch.nn.functional.mse_loss(out, tgt).backward()
+        assert eng.kernel_name("train_dw") == f"dw3_bf16_kernel<{terms}>", eng.kernel_name("train_dw")
+    finally:
+        eng.set_gru_split_bf16(0)
+    for k, p in m.named_parameters():
+        g, r = p.grad.cpu().double(), ref_g[k]
+        scale = max(r.abs().max().item(), 1e-8)
+        assert (g - r).abs().max().item() < bar * scale + 1e-9, (k, (g - r).abs().max().item(), scale)
+
+
 def test_g6_adam_step_matches_reference_loop():
     """One optimisation step with the reference's loop (gru_train.py:232-249) and torch.optim.Adam on the drop-in RNN."""
     from optistate_amd import RNN
