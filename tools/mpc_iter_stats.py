@@ -20,3 +20,12 @@ for t in range(T):
 print("all", it.mean().item(), it.reshape(T, -1, 4).max(2).values.mean().item())
 h = torch.bincount(it[1:].flatten().long(), minlength=12)[:16]
 print("histogram of warm steps (iterations 0..15):", (h / h.sum()).cpu().numpy().round(3))
+# how well does a trajectory's count at step t predict its count at step t + 1?  (the lock-step cost of four rows sharing a wavefront
+# disappears if the four have similar counts: sorting a step's problems by the previous step's count)
+a, b = it[1:-1].flatten(), it[2:].flatten()
+print("correlation of consecutive steps' counts:", float(torch.corrcoef(torch.stack([a, b]))[0, 1]))
+for t in (3, 10):
+    order = torch.argsort(it[t - 1])
+    srt = it[t][order]
+    print(f"step {t}: mean {it[t].mean().item():.2f}, mean(max of 4) unsorted {it[t].reshape(-1, 4).max(1).values.mean().item():.2f}, "
+          f"sorted by step {t - 1}'s count {srt.reshape(-1, 4).max(1).values.mean().item():.2f}")
