@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "optistate_amd", "csrc")
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-@pytest.mark.parametrize("src, extra", [("kf_dense_rows.hip", []), ("kf_rows_kernel.hip", ["-fno-slp-vectorize"]), ("mpc_kernels.hip", []),
+@pytest.mark.parametrize("src, extra", [("kf_dense_rows.hip", []), ("kf_rows_kernel.hip", ["-fno-slp-vectorize"]), ("mpc_kernels.hip", []), ("mpc_quad.hip", []),
                                         ("fused_kernels.hip", [])])
 def test_inline_asm_operands_are_past_their_hazard_windows(tmp_path, src, extra):
     out = tmp_path / (src + ".s")
