@@ -39,6 +39,8 @@ struct MpcArgs {
     int cold_in;                   // 1: ignore the warm arrays' CONTENT on entry (they are the hand-over buffer of a cold solve)
     int32_t *todo;                 // [2][B]: indices handed over, per leg count 1 / 2
     int32_t *todo_count;           // [2]
+    // round 6: the per-problem records of mpc_quad.hip (QuadRec: generators, linear term; written by mpc_prep_kernel, read by the rows)
+    double *rec;                   // [B] x 1,792 bytes
     MpcParams prm;
 };
 

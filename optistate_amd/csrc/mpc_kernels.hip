@@ -845,18 +845,21 @@ namespace osm {
 static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask, hipStream_t s)
 {
     MpcArgs a = a_in;
-    a.cap = 0; a.cold_in = 0; a.todo = nullptr; a.todo_count = nullptr;
+    a.cap = 0; a.cold_in = 0; a.todo = nullptr; a.todo_count = nullptr; a.rec = nullptr;
     const dim3 grid(a.B), block(64);
     if (ctx->tune_mpc_quad != 0 && a.B >= ctx->tune_mpc_quad && (nst_mask & 7u)) {
         // pass 1: sixteen lanes per QP, rows fetch problems from a work counter and give one up after `cap` iterations;
         // pass 2: the problems handed over continue on a wavefront of their own.  The hand-over record is the warm-start record: a cold
         // solve borrows the context's scratch for it.
         const size_t Bz = (size_t)a.B;
-        const size_t need = Bz * 128 + Bz * 16 + Bz + 2 * Bz + 16;      // u [B][64] doubles | faces [B][64] bytes | contact [B] | todo [2][B] | counters
+        // u [B][64] doubles | faces [B][64] bytes | contact [B] | todo [2][B] | counters | records [B] x 1,792 bytes (16-byte aligned)
+        const size_t rec_at = (Bz * 128 + Bz * 16 + Bz + 2 * Bz + 16 + 3) & ~(size_t)3;
+        const size_t need = rec_at + Bz * 448;
         if (os_ensure_scratch(ctx, &ctx->mpc_hand, &ctx->mpc_hand_floats, need)) return -10;
         int32_t *counters = (int32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16 + Bz + 2 * Bz);
         a.todo = (int32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16 + Bz);
         a.todo_count = counters + 2;
+        a.rec = (double *)(ctx->mpc_hand + rec_at);
         a.cap = ctx->tune_mpc_cap;
         if (!a.warm_u) {
             a.warm_u = (double *)ctx->mpc_hand; a.warm_state = (uint8_t *)(ctx->mpc_hand + Bz * 128);

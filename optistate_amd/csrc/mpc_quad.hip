@@ -25,7 +25,7 @@ namespace osq {
 
 // Development build only (-DOSQ_TS): shader-clock stamps between the phases of an active-set iteration, summed by lane 0 of workgroup 0
 #ifdef OSQ_TS
-__shared__ unsigned long long osq_ts_sum[12];            // (LDS: a stamp costs one LDS round trip of lane 0, ~100 cycles)
+__shared__ unsigned long long osq_ts_sum[16];            // (LDS: a stamp costs one LDS round trip of lane 0, ~100 cycles)
 __shared__ unsigned long long osq_ts_prev;
 #define OSQ_STAMP(i)                                                                       \
     {                                                                                      \
@@ -44,19 +44,35 @@ __shared__ unsigned long long osq_ts_prev;
 using namespace osm;
 using osk::rows64::bc64;
 
+// The per-problem RECORD (round 6): everything of a problem that does not change over its active-set iterations -- generators of the
+// variables, the linear term per horizon step, R1 diag(w_theta) R1^T -- is computed ONCE by mpc_prep_kernel (all four rows of a
+// wavefront in lock step, many wavefronts per SIMD) and written to global memory in exactly the layout of the head of a row's LDS
+// block; a row of mpc_solve_quad_kernel copies it in with REC_CHUNKS 16-byte loads per lane.  Inside the persistent rows the same
+// set-up (~2.2 k instructions, five dependent global round trips) ran once per ROW, not once per wavefront: the rows do not start
+// their problems together.
+constexpr int REC_BYTES = 1792;                          // 7 x (16 lanes x 16 bytes); the global stride of a record
+template <int NV>
+struct QuadRec {
+    double gen0[NV][6];      // generators (a, b) of the variables
+    double cwv[5][6];        // (cw | cv) of the linear term per horizon step
+    double Cth[9];           // R1 diag(w_theta) R1^T
+};
+template <int NV>
+constexpr int rec_chunks() { return ((int)sizeof(QuadRec<NV>) + 255) / 256; }
+
 // per-QP LDS block
 template <int NV>
 struct QuadMem {
-    double gen0[NV][6];      // generators (a, b) of the variables
+    union {
+        QuadRec<NV> rec;
+        double rec_image[rec_chunks<NV>() * 32];
+    };
     double gent[NV][6];      // generators of the face coordinates
     double vec[32];          // per-variable exchange (solution / u / u0)
     double rowbuf[32];
     double S[32];            // the 5 x 6 per-step sums of form_dot
-    double cwv[5][6];        // (cw | cv) of the linear term per horizon step
-    double Cth[9];           // R1 diag(w_theta) R1^T
     double al[10];
     int code[10];
-    double prob[36];         // x | ref | p (float64) while the problem is set up
 };
 struct QuadShared {
     double ab[25][2];        // (al, be) of alpha_beta() at [5 i + l]: depends on dt only, one copy per wavefront
@@ -95,7 +111,7 @@ __device__ __forceinline__ bool any16(bool p, int lane)
 
 template <int NST>
 struct Quad {
-    static constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST, VPL = NV > 16 ? 2 : 1;
+    static constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST, VPL = NV > 16 ? 2 : 1, RCH = rec_chunks<15 * NST>();
     typedef QuadMem<NV> Mem;
 
     struct Var {              // one of the lane's variables
@@ -106,21 +122,50 @@ struct Quad {
         int lane, l;
         Var var[VPL];
     };
-
-    // z-vectors of a face generator g at horizon step i against the columns of step l: val(w) = zA . a_w + zB . b_w
-    static __device__ __forceinline__ void zvec(const Mem &M, const MpcParams &P, const QuadShared &Sh, const double *g, int i, int l, double *zA,
-                                                double *zB)
+    static __device__ __forceinline__ Lane this_lane()
     {
-        const double al = Sh.ab[5 * i + l][0], be = Sh.ab[5 * i + l][1];
+        Lane L;
+        L.lane = threadIdx.x & 63;
+        L.l = L.lane & 15;
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            Var &V = L.var[h];
+            const int v = L.l + 16 * h;
+            V.pad = v >= NV;
+            V.v = V.pad ? NV - 1 : v;
+            V.i = V.v / NPS; V.c = V.v % 3; V.ls = V.v / 3;
+        }
+        return L;
+    }
+
+    // z-vectors of a face generator g at horizon step i against the columns of step l: val(w) = zA . a_w + zB . b_w.
+    // Cg = (R1 diag(w_theta) R1^T) g[0..2] and the lane's five (al, be) pairs do not depend on l: formed once per generator
+    struct ZCtx { double Cg[3], ab[5][2]; };
+    static __device__ __forceinline__ ZCtx zctx(const Mem &M, const QuadShared &Sh, const double *g, int i)
+    {
+        ZCtx Z;
+        double C[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) C[r] = M.rec.Cth[r];
+#pragma unroll
+        for (int l = 0; l < 5; l++) { Z.ab[l][0] = Sh.ab[5 * i + l][0]; Z.ab[l][1] = Sh.ab[5 * i + l][1]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) Z.Cg[r] = C[3 * r] * g[0] + C[3 * r + 1] * g[1] + C[3 * r + 2] * g[2];
+        return Z;
+    }
+    static __device__ __forceinline__ void zvec(const MpcParams &P, const ZCtx &Z, const double *g, int l, double *zA, double *zB)
+    {
+        const double al = Z.ab[l][0], be = Z.ab[l][1];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            zA[r] = al * P.w[6 + r] * g[r] + be * (M.Cth[3 * r] * g[0] + M.Cth[3 * r + 1] * g[1] + M.Cth[3 * r + 2] * g[2]);
+            zA[r] = al * P.w[6 + r] * g[r] + be * Z.Cg[r];
             zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
         }
     }
 
     // sum_w form(g_h, G[w]) vec[w] for the lane's variables (mpc_kernels.hip form_dot: the sum over a step's columns factors into
-    // per-step six-vector sums, formed by thirty lanes -- here fifteen lanes, two sums each)
+    // per-step six-vector sums, formed by thirty lanes -- here fifteen lanes, two sums each).  One LDS round trip for the sums, one for
+    // reading all thirty back (a rolled loop over the steps was five dependent round trips).
     static __device__ __forceinline__ void form_dot(const Lane &L, const MpcParams &P, const QuadShared &Sh, const double (*gg)[6], const double (*G)[6],
                                                     const double *vec, Mem &M, double *out)
     {
@@ -128,26 +173,31 @@ struct Quad {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int e = L.l + 16 * q;
-            if (e < 30) {
-                const int l = e / 6, r = e % 6;
-                double sum = 0.0;
+            const int ec = e < 30 ? e : 29, l = ec / 6, r = ec % 6;
+            double gv[NPS], vv[NPS];
 #pragma unroll
-                for (int j = 0; j < NPS; j++) sum = fma(G[NPS * l + j][r], vec[NPS * l + j], sum);
-                M.S[e] = sum;
-            }
+            for (int j = 0; j < NPS; j++) { gv[j] = G[NPS * l + j][r]; vv[j] = vec[NPS * l + j]; }
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < NPS; j++) sum = fma(gv[j], vv[j], sum);
+            if (e < 30) M.S[e] = sum;
         }
         __builtin_amdgcn_wave_barrier();
+        double Sv[30];
+#pragma unroll
+        for (int e = 0; e < 30; e++) Sv[e] = M.S[e];
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
+            const ZCtx Z = zctx(M, Sh, gg[h], L.var[h].i);
             double acc = 0.0;
-#pragma clang loop unroll(disable)
+#pragma unroll
             for (int l = 0; l < 5; l++) {
                 double zA[3], zB[3];
-                zvec(M, P, Sh, gg[h], L.var[h].i, l, zA, zB);
+                zvec(P, Z, gg[h], l, zA, zB);
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
-                    acc = fma(zA[r], M.S[6 * l + r], acc);
-                    acc = fma(zB[r], M.S[6 * l + 3 + r], acc);
+                    acc = fma(zA[r], Sv[6 * l + r], acc);
+                    acc = fma(zB[r], Sv[6 * l + 3 + r], acc);
                 }
             }
             out[h] = acc;
@@ -155,7 +205,8 @@ struct Quad {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // Minimiser of the QP restricted to the faces (sx, sy, sz per variable = of its leg-step); returns the lane's components.
+    // Minimiser of the QP restricted to the faces (sx, sy, sz per variable = of its leg-step); returns the lane's components IN FACE
+    // COORDINATES (iterate_row maps them to forces in the same LDS exchange that hands a leg-step's point to its three lanes).
     // the face of a variable's leg-step, packed: (sx + 1) | (sy + 1) << 2 | sz << 4 (the warm-start format); by value: arrays handed
     // around by pointer stay in scratch memory
     struct Faces { int f[VPL]; };
@@ -172,32 +223,32 @@ struct Quad {
 #pragma unroll
         for (int h = 0; h < VPL; h++) { sx[h] = fsx(F.f[h]); sy[h] = fsy(F.f[h]); sz[h] = fsz(F.f[h]); }
         Sol out;
-        double *us = out.u;
         bool live[VPL];
         double g[VPL][6], tt[VPL], u0[VPL];
+        // the three generators of the lane's leg-steps in ONE batch of reads, selects instead of branches (a branch per variable kind was
+        // a dependent LDS round trip each)
+        double g3[VPL][3][6];
+#pragma unroll
+        for (int h = 0; h < VPL; h++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) g3[h][q][r] = M.rec.gen0[3 * L.var[h].ls + q][r];
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
             const Var &V = L.var[h];
-            const int b0 = 3 * V.ls;
-            tt[h] = 1.0;
-            if (V.c == 2) {
-                live[h] = sz[h] == SZ_FREE;
-                const double fx = sx[h] * P.mu, fy = sy[h] * P.mu;
+            const double fx = sx[h] * P.mu, fy = sy[h] * P.mu;
+            const bool isz = V.c == 2;
+            live[h] = (isz ? sz[h] == SZ_FREE : (sz[h] != SZ_ZERO && (V.c == 0 ? sx[h] : sy[h]) == 0)) && !V.pad;
+            tt[h] = isz ? 1.0 + P.mu * P.mu * (double)(sx[h] * sx[h] + sy[h] * sy[h]) : 1.0;
 #pragma unroll
-                for (int r = 0; r < 6; r++) g[h][r] = M.gen0[b0 + 2][r] + fx * M.gen0[b0][r] + fy * M.gen0[b0 + 1][r];
-                tt[h] = 1.0 + P.mu * P.mu * (double)(sx[h] * sx[h] + sy[h] * sy[h]);
-            } else {
-                live[h] = sz[h] != SZ_ZERO && (V.c == 0 ? sx[h] : sy[h]) == 0;
-#pragma unroll
-                for (int r = 0; r < 6; r++) g[h][r] = M.gen0[V.v][r];
-            }
-            live[h] = live[h] && !V.pad;
-            if (!live[h]) {
-#pragma unroll
-                for (int r = 0; r < 6; r++) g[h][r] = 0.0;
+            for (int r = 0; r < 6; r++) {
+                const double gz = g3[h][2][r] + fx * g3[h][0][r] + fy * g3[h][1][r];
+                const double gxy = V.c == 0 ? g3[h][0][r] : g3[h][1][r];
+                g[h][r] = live[h] ? (isz ? gz : gxy) : 0.0;
             }
             // the fixed part of the face (fz = fz_max faces)
-            u0[h] = (sz[h] == SZ_MAX && !V.pad) ? (V.c == 2 ? P.fzmax : (double)(V.c == 0 ? sx[h] : sy[h]) * P.mu * P.fzmax) : 0.0;
+            u0[h] = (sz[h] == SZ_MAX && !V.pad) ? (isz ? P.fzmax : (double)(V.c == 0 ? sx[h] : sy[h]) * P.mu * P.fzmax) : 0.0;
         }
         bool anyu = false;
 #pragma unroll
@@ -218,10 +269,12 @@ struct Quad {
         // ---- rows of the reduced system: A[h][w], w < NV, and the right-hand side in A[h][NV] ----
         double A[VPL][NV + 1];
         double dot[VPL] = {};
-        if (any_u0) form_dot(L, P, Sh, g, M.gen0, M.vec, M, dot);
+        if (any_u0) form_dot(L, P, Sh, g, M.rec.gen0, M.vec, M, dot);
+        ZCtx Z[VPL];
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
-            const double *cwv = M.cwv[L.var[h].i];
+            Z[h] = zctx(M, Sh, g[h], L.var[h].i);
+            const double *cwv = M.rec.cwv[L.var[h].i];
             const double rhs = -(g[h][0] * cwv[0] + g[h][1] * cwv[1] + g[h][2] * cwv[2] + g[h][3] * cwv[3] + g[h][4] * cwv[4] + g[h][5] * cwv[5]) - dot[h];
             A[h][NV] = live[h] ? rhs : 0.0;
         }
@@ -229,7 +282,7 @@ struct Quad {
         for (int l = 0; l < 5; l++) {
             double zA[VPL][3], zB[VPL][3];
 #pragma unroll
-            for (int h = 0; h < VPL; h++) zvec(M, P, Sh, g[h], L.var[h].i, l, zA[h], zB[h]);
+            for (int h = 0; h < VPL; h++) zvec(P, Z[h], g[h], l, zA[h], zB[h]);
 #pragma unroll
             for (int j = 0; j < NPS; j++) {
                 const int w = NPS * l + j;
@@ -297,24 +350,8 @@ struct Quad {
             __builtin_amdgcn_sched_barrier(0);
         });
         OSQ_STAMP(4)                                 // back substitution
-        // ---- face coordinates -> forces ----
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int h = 0; h < VPL; h++)
-            if (!L.var[h].pad) M.vec[L.var[h].v] = sol[h];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < VPL; h++) {
-            const Var &V = L.var[h];
-            const double fz = sz[h] == SZ_MAX ? P.fzmax : (sz[h] == SZ_ZERO ? 0.0 : M.vec[3 * V.ls + 2]);
-            double u;
-            if (V.c == 2) u = fz;
-            else {
-                const int s = V.c == 0 ? sx[h] : sy[h];
-                u = s != 0 ? (double)s * P.mu * fz : (sz[h] == SZ_ZERO ? 0.0 : sol[h]);
-            }
-            us[h] = V.pad ? 0.0 : u;
-        }
+        for (int h = 0; h < VPL; h++) out.u[h] = sol[h];
         return out;
     }
 
@@ -330,15 +367,16 @@ struct Quad {
         double u[VPL];
     };
 
-    // problem b -> the row's LDS block and state (row-uniform control flow: every lane of the row is here)
-    static __device__ __forceinline__ void setup_row(const Lane &L, const MpcArgs &a, const MpcParams &P, Mem &M, Row &R, int b, uint32_t cbits)
+    // The record of problem b (mpc_prep_kernel; every row of the wavefront is here): into the row's LDS block, then out to a.rec.
+    template <typename MemT>
+    static __device__ __forceinline__ void prep_row(const Lane &L, const MpcArgs &a, const MpcParams &P, MemT &M, double *prob /* LDS [36] */, int b, uint32_t cbits)
     {
         const size_t B = (size_t)a.B;
         __builtin_amdgcn_wave_barrier();
         if (L.l < 12) {
-            M.prob[L.l] = (double)a.x[(size_t)L.l * B + b];
-            M.prob[12 + L.l] = (double)a.ref[(size_t)L.l * B + b];
-            M.prob[24 + L.l] = (double)a.p[(size_t)L.l * B + b];
+            prob[L.l] = (double)a.x[(size_t)L.l * B + b];
+            prob[12 + L.l] = (double)a.ref[(size_t)L.l * B + b];
+            prob[24 + L.l] = (double)a.p[(size_t)L.l * B + b];
         }
         __builtin_amdgcn_wave_barrier();
         int legs[4] = {0, 0, 0, 0};
@@ -357,9 +395,8 @@ struct Quad {
         for (int h = 0; h < VPL; h++) {
             const int rank = (L.var[h].v % NPS) / 3;
             leg[h] = rank == 0 ? legs[0] : rank == 1 ? legs[1] : rank == 2 ? legs[2] : legs[3];
-            R.stance[h] = ((cbits >> (8 * leg[h])) & 0xffu) == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
         }
-        const double *x = M.prob, *ref = M.prob + 12, *p = M.prob + 24;
+        const double *x = prob, *ref = prob + 12, *p = prob + 24;
         double R0[9], R1[9];
         rotation64(x[0], x[1], x[2], R0);
         rotation64(ref[0], ref[1], ref[2], R1);
@@ -371,7 +408,7 @@ struct Quad {
 #pragma unroll
                 for (int ss = 0; ss < 3; ss++)
                     if (rr == r && ss == s) v = R1[3 * rr] * P.w[0] * R1[3 * ss] + R1[3 * rr + 1] * P.w[1] * R1[3 * ss + 1] + R1[3 * rr + 2] * P.w[2] * R1[3 * ss + 2];
-            M.Cth[L.l] = v;
+            M.rec.Cth[L.l] = v;
         }
         // generators of the lane's variables: a = I_hat^-1 (R p_leg x e_c), b = e_c / m, with R of the variable's horizon step
 #pragma unroll
@@ -391,9 +428,9 @@ struct Quad {
             for (int q = 0; q < 3; q++) tb[q] = (Rm[q] * cr[0] + Rm[3 + q] * cr[1] + Rm[6 + q] * cr[2]) * P.inv_inertia[q];
             if (!V.pad) {
 #pragma unroll
-                for (int r = 0; r < 3; r++) M.gen0[V.v][r] = Rm[3 * r] * tb[0] + Rm[3 * r + 1] * tb[1] + Rm[3 * r + 2] * tb[2];
+                for (int r = 0; r < 3; r++) M.rec.gen0[V.v][r] = Rm[3 * r] * tb[0] + Rm[3 * r + 1] * tb[1] + Rm[3 * r + 2] * tb[2];
 #pragma unroll
-                for (int r = 0; r < 3; r++) M.gen0[V.v][3 + r] = (r == V.c) ? P.inv_mass : 0.0;
+                for (int r = 0; r < 3; r++) M.rec.gen0[V.v][3 + r] = (r == V.c) ? P.inv_mass : 0.0;
             }
         }
         // linear term per horizon step (mpc_kernels.hip: closed forms in the step index): lanes 0..4 of the row compute step l's (cw | cv)
@@ -416,22 +453,73 @@ struct Quad {
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 const double ew = x[6 + r] - ref[6 + r];
-                M.cwv[L.l][r] = n * dt * P.w[6 + r] * ew + dt2 * (R1[3 * r] * wt[0] + R1[3 * r + 1] * wt[1] + R1[3 * r + 2] * wt[2]);
+                M.rec.cwv[L.l][r] = n * dt * P.w[6 + r] * ew + dt2 * (R1[3 * r] * wt[0] + R1[3 * r + 1] * wt[1] + R1[3 * r + 2] * wt[2]);
                 double sev = n * (x[9 + r] - ref[9 + r]);
                 double ser = S1 * (x[3 + r] - ref[3 + r]) + dt * x[9 + r] * T2;
                 if (r == 2) { sev += dt * P.gz * T1; ser += 0.5 * dt2 * P.gz * T3; }
-                M.cwv[L.l][3 + r] = dt * P.w[9 + r] * sev + dt2 * P.w[3 + r] * ser;
+                M.rec.cwv[L.l][3 + r] = dt * P.w[9 + r] * sev + dt2 * P.w[3 + r] * ser;
             }
         }
         __builtin_amdgcn_wave_barrier();
+        // the record image out: chunk c = 16 lanes x 16 bytes
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        d2_t *dst = reinterpret_cast<d2_t *>(reinterpret_cast<char *>(a.rec) + (size_t)b * REC_BYTES);
+        const d2_t *src = reinterpret_cast<const d2_t *>(M.rec_image);
+#pragma unroll
+        for (int c = 0; c < RCH; c++) dst[c * 16 + L.l] = src[c * 16 + L.l];
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // problem b -> the row's LDS block and state (row-uniform control flow: every lane of the row is here): the record in, the stance
+    // flags from the contact word, the warm-start record where it applies
+    static __device__ __forceinline__ void load_row(const Lane &L, const MpcArgs &a, Mem &M, Row &R, int b, uint32_t cbits)
+    {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t *src = reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(a.rec) + (size_t)b * REC_BYTES);
+        d2_t rc[RCH];
+#pragma unroll
+        for (int c = 0; c < RCH; c++) rc[c] = src[c * 16 + L.l];
         // cold start: stance (and unconstrained) legs free, swing legs zero; warm: the previous solve's point and faces when the
         // force-carrying legs' contact bytes are unchanged (the pyramids do not move: the old u stays feasible)
-        const bool warm = a.warm_u && !a.cold_in && a.warm_contact[b] != 0xffffffffu && contact_ranks(a.warm_contact[b]) == contact_ranks(cbits);
+        uint32_t wc = 0xffffffffu;
+        double wu[VPL]; int wf[VPL];
+        const bool try_warm = a.warm_u && !a.cold_in;
+        if (try_warm) {
+            wc = a.warm_contact[b];
+#pragma unroll
+            for (int h = 0; h < VPL; h++) {
+                const int v = L.l + 16 * h;
+                wu[h] = a.warm_u[(size_t)b * 64 + v]; wf[h] = a.warm_state[(size_t)b * 64 + v] & 0x3f;
+            }
+        }
+        int legs[4] = {0, 0, 0, 0};
+        {
+            int n = 0;
+#pragma unroll
+            for (int lg = 0; lg < 4; lg++) {
+                if (((cbits >> (8 * lg)) & 0xffu) != 0u) {
+                    if (n == 0) legs[0] = lg; else if (n == 1) legs[1] = lg; else if (n == 2) legs[2] = lg; else legs[3] = lg;
+                    n++;
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const int rank = (L.var[h].v % NPS) / 3;
+            const int leg = rank == 0 ? legs[0] : rank == 1 ? legs[1] : rank == 2 ? legs[2] : legs[3];
+            R.stance[h] = ((cbits >> (8 * leg)) & 0xffu) == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
+        }
+        __builtin_amdgcn_wave_barrier();
+        d2_t *dst = reinterpret_cast<d2_t *>(M.rec_image);
+#pragma unroll
+        for (int c = 0; c < RCH; c++) dst[c * 16 + L.l] = rc[c];
+        __builtin_amdgcn_wave_barrier();
+        const bool warm = try_warm && wc != 0xffffffffu && contact_ranks(wc) == contact_ranks(cbits);
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
             const int v = L.l + 16 * h;
-            R.F.f[h] = fpack(0, 0, SZ_FREE); R.u[h] = 0.0;
-            if (warm && v < NV) { R.u[h] = a.warm_u[(size_t)b * 64 + v]; R.F.f[h] = a.warm_state[(size_t)b * 64 + v] & 0x3f; }
+            const bool w = warm && v < NV;
+            R.F.f[h] = w ? wf[h] : fpack(0, 0, SZ_FREE); R.u[h] = w ? wu[h] : 0.0;
         }
         R.first = !warm; R.done = false; R.converged = false; R.iters = 0; R.b = b; R.cbits = cbits; R.has = true;
     }
@@ -463,6 +551,9 @@ struct Quad {
     {
         const size_t B = (size_t)a.B;
         const int b = R.b;
+#ifdef OSQ_X_NOSTORE
+        if (R.iters < 1000) { R.has = false; return; }
+#endif
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < VPL; h++)
@@ -506,202 +597,220 @@ struct Quad {
         R.has = false;
     }
 
-    // one active-set iteration of the row's problem behind the (unconditional) solve
+    // One active-set iteration of the row's problem behind the (unconditional) solve.  S: the face-restricted minimiser in face
+    // coordinates.  Every quantity of a leg-step (point, candidate point, step, ratio test, snap, multiplier test) is computed by ALL
+    // THREE of its lanes from one exchange through LDS, without branches: the round-5 form (only the fz lane decides, every stage
+    // hands its result on through LDS, six candidate ratios behind six branches) was ~100 dependent LDS waits = 12 k of an
+    // iteration's 40 k cycles on a wavefront alone (in-kernel stamps, round 6).  Exchanges now: 1 (point + solution) + 1 (the row's
+    // minimum ratio) per iteration, + 4 when the subspace minimiser is reached (gradient: 2, multipliers: 2).
+    static __device__ __forceinline__ double pick3(const double (&a)[3], int c) { return c == 0 ? a[0] : (c == 1 ? a[1] : a[2]); }
+
     static __device__ __forceinline__ void iterate_row(const Lane &L, const MpcParams &P, const QuadShared &Sh, Mem &M, Row &R, const Sol &S)
     {
         Faces &F = R.F;
         double (&u)[VPL] = R.u;
-        bool &first = R.first, &done = R.done, &converged = R.converged;
-        int &iters = R.iters;
         const bool (&stance)[VPL] = R.stance;
         constexpr double EPS = 1e-11, TOL = 1e-12;
-        iters++;
-        do {
-            if (first) {
-                // clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
-                first = false;
-                __builtin_amdgcn_wave_barrier();
+        R.iters++;
+        // ---- the leg-step's solution (face coordinates) and current point to each of its lanes ----
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int h = 0; h < VPL; h++) { u[h] = S.u[h]; if (!L.var[h].pad) M.vec[L.var[h].v] = u[h]; }
-                __builtin_amdgcn_wave_barrier();
-                bool clamped = false;
+        for (int h = 0; h < VPL; h++)
+            if (!L.var[h].pad) { M.vec[L.var[h].v] = S.u[h]; M.rowbuf[L.var[h].v] = u[h]; }
+        __builtin_amdgcn_wave_barrier();
+        double s3[VPL][3], u3[VPL][3], c3[VPL][3];
 #pragma unroll
-                for (int h = 0; h < VPL; h++) {
-                    const Var &V = L.var[h];
-                    double fx = M.vec[3 * V.ls], fy = M.vec[3 * V.ls + 1], fz = M.vec[3 * V.ls + 2];
-                    int sx = 0, sy = 0, sz = SZ_FREE;
-                    bool cl = false;
-                    if (fz <= 0.0) { sz = SZ_ZERO; fx = fy = fz = 0.0; cl = true; }
-                    else {
-                        if (fz >= P.fzmax) { sz = SZ_MAX; fz = P.fzmax; cl = true; }
-                        const double lim = P.mu * fz;
-                        if (fx >= lim) { sx = 1; fx = lim; cl = true; } else if (fx <= -lim) { sx = -1; fx = -lim; cl = true; }
-                        if (fy >= lim) { sy = 1; fy = lim; cl = true; } else if (fy <= -lim) { sy = -1; fy = -lim; cl = true; }
-                    }
-                    const bool act = stance[h] && !V.pad;
-                    F.f[h] = act ? fpack(sx, sy, sz) : F.f[h];
-                    u[h] = act ? (V.c == 0 ? fx : (V.c == 1 ? fy : fz)) : u[h];
-                    clamped = clamped || (act && cl);
-                }
-                if (!any16(clamped, L.lane)) { done = true; converged = true; }
-                break;
-            }
-            double d[VPL];
-            __builtin_amdgcn_wave_barrier();
+        for (int h = 0; h < VPL; h++)
 #pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                d[h] = S.u[h] - u[h];
-                if (!L.var[h].pad) { M.vec[L.var[h].v] = u[h]; M.rowbuf[L.var[h].v] = d[h]; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ratio test of a leg-step (computed by its fz variable)
+            for (int q = 0; q < 3; q++) { s3[h][q] = M.vec[3 * L.var[h].ls + q]; u3[h][q] = M.rowbuf[3 * L.var[h].ls + q]; }
+        // face coordinates -> forces: the candidate point of the face
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+            const double fz = sz == SZ_MAX ? P.fzmax : (sz == SZ_ZERO ? 0.0 : s3[h][2]);
+            c3[h][0] = sx != 0 ? (double)sx * P.mu * fz : (sz == SZ_ZERO ? 0.0 : s3[h][0]);
+            c3[h][1] = sy != 0 ? (double)sy * P.mu * fz : (sz == SZ_ZERO ? 0.0 : s3[h][1]);
+            c3[h][2] = fz;
+        }
+        if (R.first) {
+            // (row-uniform) clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
+            R.first = false;
+            bool clamped = false;
 #pragma unroll
             for (int h = 0; h < VPL; h++) {
                 const Var &V = L.var[h];
-                if (V.c == 2 && !V.pad) {
-                    const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
-                    double best = 2.0; int code = 0;
-                    if (stance[h] && sz != SZ_ZERO) {
-                        const double fx = M.vec[3 * V.ls], fy = M.vec[3 * V.ls + 1], fz = M.vec[3 * V.ls + 2];
-                        const double dx = M.rowbuf[3 * V.ls], dy = M.rowbuf[3 * V.ls + 1], dz = M.rowbuf[3 * V.ls + 2];
-                        auto cand = [&](double num, double den, int cd) {
-                            if (den > EPS) {
-                                const double al = fmax(0.0, num * rcp64(den));
-                                if (al < best) { best = al; code = cd; }
-                            }
-                        };
-                        if (sz == SZ_FREE) { cand(fz, -dz, 1); cand(P.fzmax - fz, dz, 2); }
-                        if (sx == 0) { cand(P.mu * fz - fx, dx - P.mu * dz, 3); cand(P.mu * fz + fx, -dx - P.mu * dz, 4); }
-                        if (sy == 0) { cand(P.mu * fz - fy, dy - P.mu * dz, 5); cand(P.mu * fz + fy, -dy - P.mu * dz, 6); }
-                    }
-                    M.al[V.ls] = best; M.code[V.ls] = code;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            double amin = 1.0; int lsmin = -1, cmin = 0;
-            {
-                double alq[NLS]; int cdq[NLS];
-#pragma unroll
-                for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
-#pragma unroll
-                for (int q = 0; q < NLS; q++)
-                    if (alq[q] < amin) { amin = alq[q]; lsmin = q; cmin = cdq[q]; }
-            }
-#pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                u[h] += amin * d[h];
-                int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
-                if (cmin == 1) { sx = 0; sy = 0; sz = SZ_ZERO; }
-                else if (cmin == 2) sz = SZ_MAX;
-                else if (cmin == 3) sx = 1;
-                else if (cmin == 4) sx = -1;
-                else if (cmin == 5) sy = 1;
-                else if (cmin == 6) sy = -1;
-                const bool hit = lsmin >= 0 && L.var[h].ls == lsmin && !L.var[h].pad;
-                F.f[h] = hit ? fpack(sx, sy, sz) : F.f[h];
-            }
-            // snap onto the face equalities
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < VPL; h++)
-                if (!L.var[h].pad) M.vec[L.var[h].v] = u[h];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                const Var &V = L.var[h];
-                const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
-                double fz = M.vec[3 * V.ls + 2];
-                if (sz == SZ_ZERO) fz = 0.0;
-                if (sz == SZ_MAX) fz = P.fzmax;
-                double un = u[h];
-                if (V.c == 2) un = fz;
+                double fx = c3[h][0], fy = c3[h][1], fz = c3[h][2];
+                int sx = 0, sy = 0, sz = SZ_FREE;
+                bool cl = false;
+                if (fz <= 0.0) { sz = SZ_ZERO; fx = fy = fz = 0.0; cl = true; }
                 else {
-                    const int sgn = V.c == 0 ? sx : sy;
-                    if (sz == SZ_ZERO) un = 0.0;
-                    else if (sgn != 0) un = (double)sgn * P.mu * fz;
+                    if (fz >= P.fzmax) { sz = SZ_MAX; fz = P.fzmax; cl = true; }
+                    const double lim = P.mu * fz;
+                    if (fx >= lim) { sx = 1; fx = lim; cl = true; } else if (fx <= -lim) { sx = -1; fx = -lim; cl = true; }
+                    if (fy >= lim) { sy = 1; fy = lim; cl = true; } else if (fy <= -lim) { sy = -1; fy = -lim; cl = true; }
                 }
-                u[h] = (!V.pad && stance[h]) ? un : u[h];
+                const bool act = stance[h] && !V.pad;
+                F.f[h] = act ? fpack(sx, sy, sz) : F.f[h];
+                const double own = V.pad ? 0.0 : pick3(c3[h], V.c);
+                u[h] = act ? (V.c == 0 ? fx : (V.c == 1 ? fy : fz)) : own;
+                clamped = clamped || (act && cl);
             }
-#ifdef OS_MPC_DBG
-            if (L.lane == 0) printf("quad it %d ratio: amin %.6e lsmin %d cmin %d\n", iters, amin, lsmin, cmin);
-#endif
-            if (lsmin >= 0) break;
-
-            // subspace minimiser reached: multiplier signs
-            __builtin_amdgcn_wave_barrier();
+            if (!any16(clamped, L.lane)) { R.done = true; R.converged = true; }
+            return;
+        }
+        // ---- ratio test of the lane's leg-steps (all six candidates, no branches) ----
+        double d3[VPL][3];
 #pragma unroll
-            for (int h = 0; h < VPL; h++)
-                if (!L.var[h].pad) M.vec[L.var[h].v] = u[h];
-            __builtin_amdgcn_wave_barrier();
-            double g0[VPL][6], fd[VPL];
+        for (int h = 0; h < VPL; h++) {
+            const Var &V = L.var[h];
+            const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
 #pragma unroll
-            for (int h = 0; h < VPL; h++)
+            for (int q = 0; q < 3; q++) d3[h][q] = c3[h][q] - u3[h][q];
+            const double fx = u3[h][0], fy = u3[h][1], fz = u3[h][2], dx = d3[h][0], dy = d3[h][1], dz = d3[h][2];
+            const bool on = stance[h] && sz != SZ_ZERO;
+            const double num[6] = {fz, P.fzmax - fz, P.mu * fz - fx, P.mu * fz + fx, P.mu * fz - fy, P.mu * fz + fy};
+            const double den[6] = {-dz, dz, dx - P.mu * dz, -dx - P.mu * dz, dy - P.mu * dz, -dy - P.mu * dz};
+            const bool ok[6] = {on && sz == SZ_FREE, on && sz == SZ_FREE, on && sx == 0, on && sx == 0, on && sy == 0, on && sy == 0};
+            double best = 2.0; int code = 0;
 #pragma unroll
-                for (int r = 0; r < 6; r++) g0[h][r] = M.gen0[L.var[h].v][r];
-            form_dot(L, P, Sh, g0, M.gen0, M.vec, M, fd);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                const double *cwv = M.cwv[L.var[h].i];
-                const double q0 = g0[h][0] * cwv[0] + g0[h][1] * cwv[1] + g0[h][2] * cwv[2] + g0[h][3] * cwv[3] + g0[h][4] * cwv[4] + g0[h][5] * cwv[5];
-                const double grad = 2.0 * (fd[h] + P.rw * u[h] + q0);
-                if (!L.var[h].pad) M.rowbuf[L.var[h].v] = grad;
+            for (int q = 0; q < 6; q++) {
+                const bool v = ok[q] && den[q] > EPS;
+                const double al = fmax(0.0, num[q] * rcp64(v ? den[q] : 1.0));
+                const bool take = v && al < best;
+                best = take ? al : best; code = take ? q + 1 : code;
             }
-            __builtin_amdgcn_wave_barrier();
+            if (V.c == 2 && !V.pad) { M.al[V.ls] = best; M.code[V.ls] = code; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        double amin = 1.0; int lsmin = -1, cmin = 0;
+        {
+            double alq[NLS]; int cdq[NLS];
 #pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                const Var &V = L.var[h];
-                if (V.c == 2 && !V.pad) {
-                    const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
-                    double best = TOL; int code = 0;
-                    if (stance[h]) {
-                        const double gx = M.rowbuf[3 * V.ls], gy = M.rowbuf[3 * V.ls + 1], gz = M.rowbuf[3 * V.ls + 2];
-                        if (sz == SZ_ZERO) {
-                            // apex: optimal iff the gradient lies in the dual cone; otherwise release along the steepest edge ray
-                            const double vx = P.mu * fabs(gx), vy = P.mu * fabs(gy);
-                            const double val = gz - vx - vy;
-                            if (-val > best) { best = -val; code = 16 + (gx > 0.0 ? 0 : 1) + (gy > 0.0 ? 0 : 2); }
-                        } else {
-                            if (sx == 1 && gx > best) { best = gx; code = 1; }
-                            if (sx == -1 && -gx > best) { best = -gx; code = 1; }
-                            if (sy == 1 && gy > best) { best = gy; code = 2; }
-                            if (sy == -1 && -gy > best) { best = -gy; code = 2; }
-                            if (sz == SZ_MAX) {
-                                const double lamU = -gz - sx * P.mu * gx - sy * P.mu * gy;
-                                if (-lamU > best) { best = -lamU; code = 3; }
-                            }
-                        }
-                    }
-                    M.al[V.ls] = best; M.code[V.ls] = code;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            double rmax = TOL; int lsr = -1, cr = 0;
+            for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
+#pragma unroll
+            for (int q = 0; q < NLS; q++)
+                if (alq[q] < amin) { amin = alq[q]; lsmin = q; cmin = cdq[q]; }
+        }
+        // the step, the blocking face and the snap onto the face equalities: all three components on every lane of the leg-step
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const Var &V = L.var[h];
+#pragma unroll
+            for (int q = 0; q < 3; q++) u3[h][q] += amin * d3[h][q];
+            int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
             {
-                double alq[NLS]; int cdq[NLS];
-#pragma unroll
-                for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
-#pragma unroll
-                for (int q = 0; q < NLS; q++)
-                    if (cdq[q] != 0 && alq[q] > rmax) { rmax = alq[q]; lsr = q; cr = cdq[q]; }
+                int nx = sx, ny = sy, nz = sz;
+                if (cmin == 1) { nx = 0; ny = 0; nz = SZ_ZERO; }
+                else if (cmin == 2) nz = SZ_MAX;
+                else if (cmin == 3) nx = 1;
+                else if (cmin == 4) nx = -1;
+                else if (cmin == 5) ny = 1;
+                else if (cmin == 6) ny = -1;
+                const bool hit = lsmin >= 0 && V.ls == lsmin && !V.pad;
+                sx = hit ? nx : sx; sy = hit ? ny : sy; sz = hit ? nz : sz;
+                F.f[h] = fpack(sx, sy, sz);
             }
+            const double fz = sz == SZ_ZERO ? 0.0 : (sz == SZ_MAX ? P.fzmax : u3[h][2]);
+            const double own = pick3(u3[h], V.c);
+            const int sgn = V.c == 0 ? sx : sy;
+            const double un = V.c == 2 ? fz : (sz == SZ_ZERO ? 0.0 : (sgn != 0 ? (double)sgn * P.mu * fz : own));
+            u[h] = V.pad ? u[h] : (stance[h] ? un : own);
+        }
 #ifdef OS_MPC_DBG
-            if (L.lane == 0) printf("quad it %d mult: rmax %.6e lsr %d cr %d\n", iters, rmax, lsr, cr);
+        if (L.lane == 0) printf("quad it %d ratio: amin %.6e lsmin %d cmin %d\n", R.iters, amin, lsmin, cmin);
 #endif
-            if (lsr < 0) { done = true; converged = true; break; }
+        if (lsmin >= 0) return;
+
+        // ---- subspace minimiser reached (row-uniform): multiplier signs ----
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
-                if (cr == 1) sx = 0;
-                else if (cr == 2) sy = 0;
-                else if (cr == 3) sz = SZ_FREE;
-                else { sx = (cr & 1) ? 1 : -1; sy = (cr & 2) ? 1 : -1; sz = SZ_FREE; }
-                const bool hit = L.var[h].ls == lsr && !L.var[h].pad;
-                F.f[h] = hit ? fpack(sx, sy, sz) : F.f[h];
-            }
-        } while (false);
+        for (int h = 0; h < VPL; h++)
+            if (!L.var[h].pad) M.vec[L.var[h].v] = u[h];
+        __builtin_amdgcn_wave_barrier();
+        double g0[VPL][6], fd[VPL];
+#pragma unroll
+        for (int h = 0; h < VPL; h++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) g0[h][r] = M.rec.gen0[L.var[h].v][r];
+        form_dot(L, P, Sh, g0, M.rec.gen0, M.vec, M, fd);
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const double *cwv = M.rec.cwv[L.var[h].i];
+            const double q0 = g0[h][0] * cwv[0] + g0[h][1] * cwv[1] + g0[h][2] * cwv[2] + g0[h][3] * cwv[3] + g0[h][4] * cwv[4] + g0[h][5] * cwv[5];
+            const double grad = 2.0 * (fd[h] + P.rw * u[h] + q0);
+            if (!L.var[h].pad) M.rowbuf[L.var[h].v] = grad;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const Var &V = L.var[h];
+            const int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+            const double gx = M.rowbuf[3 * V.ls], gy = M.rowbuf[3 * V.ls + 1], gz = M.rowbuf[3 * V.ls + 2];
+            double best = TOL; int code = 0;
+            // apex: optimal iff the gradient lies in the dual cone; otherwise release along the steepest edge ray
+            const double val = gz - P.mu * fabs(gx) - P.mu * fabs(gy);
+            const bool apex = sz == SZ_ZERO;
+            if (apex && -val > best) { best = -val; code = 16 + (gx > 0.0 ? 0 : 1) + (gy > 0.0 ? 0 : 2); }
+            if (!apex && sx == 1 && gx > best) { best = gx; code = 1; }
+            if (!apex && sx == -1 && -gx > best) { best = -gx; code = 1; }
+            if (!apex && sy == 1 && gy > best) { best = gy; code = 2; }
+            if (!apex && sy == -1 && -gy > best) { best = -gy; code = 2; }
+            const double lamU = -gz - sx * P.mu * gx - sy * P.mu * gy;
+            if (!apex && sz == SZ_MAX && -lamU > best) { best = -lamU; code = 3; }
+            if (!stance[h]) { best = TOL; code = 0; }
+            if (V.c == 2 && !V.pad) { M.al[V.ls] = best; M.code[V.ls] = code; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        double rmax = TOL; int lsr = -1, cr = 0;
+        {
+            double alq[NLS]; int cdq[NLS];
+#pragma unroll
+            for (int q = 0; q < NLS; q++) { alq[q] = M.al[q]; cdq[q] = M.code[q]; }
+#pragma unroll
+            for (int q = 0; q < NLS; q++)
+                if (cdq[q] != 0 && alq[q] > rmax) { rmax = alq[q]; lsr = q; cr = cdq[q]; }
+        }
+#ifdef OS_MPC_DBG
+        if (L.lane == 0) printf("quad it %d mult: rmax %.6e lsr %d cr %d\n", R.iters, rmax, lsr, cr);
+#endif
+        if (lsr < 0) { R.done = true; R.converged = true; return; }
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            int sx = fsx(F.f[h]), sy = fsy(F.f[h]), sz = fsz(F.f[h]);
+            if (cr == 1) sx = 0;
+            else if (cr == 2) sy = 0;
+            else if (cr == 3) sz = SZ_FREE;
+            else { sx = (cr & 1) ? 1 : -1; sy = (cr & 2) ? 1 : -1; sz = SZ_FREE; }
+            const bool hit = L.var[h].ls == lsr && !L.var[h].pad;
+            F.f[h] = hit ? fpack(sx, sy, sz) : F.f[h];
+        }
     }
 };
+
+// The records of a batch (see QuadRec): one 16-lane row per problem, the four rows of a wavefront in lock step.
+template <int NV>
+struct PrepMem {
+    union {
+        QuadRec<NV> rec;
+        double rec_image[rec_chunks<NV>() * 32];
+    };
+    double prob[36];         // x | ref | p (float64)
+};
+template <int NST>
+__global__ __launch_bounds__(64) void mpc_prep_kernel(const MpcArgs a)
+{
+    typedef Quad<NST> Q;
+    __shared__ PrepMem<Q::NV> Mp[4];
+    const typename Q::Lane L = Q::this_lane();
+    PrepMem<Q::NV> &M = Mp[L.lane >> 4];
+    const int b = blockIdx.x * 4 + (L.lane >> 4);
+    if (b >= a.B) return;
+    const uint32_t cb = a.contact[b];
+    const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
+    if (nst != NST) return;
+    for (int i = L.l; i < Q::RCH * 32; i += 16) M.rec_image[i] = 0.0;
+    Q::prep_row(L, a, a.prm, M, M.prob, b, cb);
+}
 
 // One workgroup = one wavefront = four independent 16-lane rows.  A row takes a problem index from the launch's work counter, sets the
 // problem up, iterates until its KKT conditions hold, writes its outputs and takes the next index; problems with another number of
@@ -715,17 +824,7 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
     typedef Quad<NST> Q;
     __shared__ typename Q::Mem Mq[4];
     __shared__ QuadShared Sh;
-    typename Q::Lane L;
-    L.lane = threadIdx.x;
-    L.l = L.lane & 15;
-#pragma unroll
-    for (int h = 0; h < Q::VPL; h++) {
-        typename Q::Var &V = L.var[h];
-        const int v = L.l + 16 * h;
-        V.pad = v >= Q::NV;
-        V.v = V.pad ? Q::NV - 1 : v;
-        V.i = V.v / Q::NPS; V.c = V.v % 3; V.ls = V.v / 3;
-    }
+    const typename Q::Lane L = Q::this_lane();
     if (L.lane < 25) {
         double al, be;
         alpha_beta(L.lane / 5, L.lane % 5, a.prm.dt, al, be);
@@ -733,17 +832,22 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
     }
     __builtin_amdgcn_wave_barrier();
 #ifdef OSQ_TS
-    if (threadIdx.x < 12) osq_ts_sum[threadIdx.x] = 0;
+    if (threadIdx.x < 16) osq_ts_sum[threadIdx.x] = 0;
 #endif
     typename Q::Mem &M = Mq[L.lane >> 4];
     const size_t B = (size_t)a.B;
     typename Q::Row R;
     R.has = false; R.exhausted = false; R.first = false; R.done = true; R.converged = true; R.b = 0; R.iters = 0; R.cbits = 0;
+#ifdef OSQ_X_STATIC
+    int x_next = blockIdx.x * 4 + (L.lane >> 4);
+    R.nb_next = x_next; x_next += gridDim.x * 4;
+#else
     {
         int nx = 0;
         if (L.l == 0) nx = atomicAdd(counter, 1);
         R.nb_next = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);
     }
+#endif
 #pragma unroll
     for (int h = 0; h < Q::VPL; h++) { R.F.f[h] = Q::fpack(0, 0, SZ_ZERO); R.u[h] = 0.0; R.stance[h] = false; }
     // a row that has never had a problem rides along in the solve with an all-dead system (identity rows): its LDS block holds zeros
@@ -756,9 +860,13 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
             for (;;) {
                 const int nb = R.nb_next;
                 if (nb >= a.B) { R.exhausted = true; break; }
+#ifdef OSQ_X_STATIC
+                R.nb_next = x_next; x_next += gridDim.x * 4;
+#else
                 int nx = 0;
                 if (L.l == 0) nx = atomicAdd(counter, 1);
                 R.nb_next = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);      // row_newbcast:0
+#endif
                 const uint32_t cb = a.contact[nb];
                 const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
                 if (NST == 1 && nst == 0) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
@@ -769,20 +877,29 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
                     if (L.l == 0 && a.warm_contact) a.warm_contact[nb] = cb;
                 }
                 if (nst != NST) continue;
-                Q::setup_row(L, a, a.prm, M, R, nb, cb);
+                OSQ_STAMP(10)                        // work counter + contact word
+                Q::load_row(L, a, M, R, nb, cb);
                 break;
             }
         }
         if (__ballot(R.has) == 0ull) break;
         OSQ_STAMP(7)                                 // fetch + set-up of new problems
+        OSQ_STAMP(8)                                 // (nothing: the cost of a stamp)
         const typename Q::Sol S = Q::solve_face(L, a.prm, Sh, M, R.F);
         OSQ_STAMP(5)                                 // face coordinates -> forces
         if (R.has) {
             Q::iterate_row(L, a.prm, Sh, M, R, S);
+            OSQ_STAMP(9)                             // ratio test / multipliers
+#ifdef OSQ_X_FIXED
+            R.done = R.iters >= OSQ_X_FIXED; R.converged = true;
+#endif
+#ifdef OSQ_X_PRIO
+            if (__ballot(R.has && R.iters == OSQ_X_PRIO) != 0ull) __builtin_amdgcn_s_setprio(3);
+#endif
             if (R.done || R.iters >= a.max_iter) Q::finish_row(L, a, M, R);
             else if (a.cap > 0 && R.iters >= a.cap) Q::hand_over_row(L, a, R);
         }
-        OSQ_STAMP(6)                                 // ratio test / multipliers / outputs
+        OSQ_STAMP(6)                                 // outputs of finished problems
 #ifdef OSQ_TS
         if (blockIdx.x == 0 && threadIdx.x == 0) osq_ts_sum[0] += 1;
 #endif
@@ -790,8 +907,10 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
 #ifdef OSQ_TS
     if (blockIdx.x == 0 && threadIdx.x == 0 && NST == 2) {
         const unsigned long long n = osq_ts_sum[0] ? osq_ts_sum[0] : 1;
-        printf("quad<2> cycles per wave-iteration (%llu iterations): faces %llu | rows %llu | elimination %llu | back-substitution %llu | forces %llu | ratio/multipliers/outputs %llu | fetch+setup %llu\n",
-               n, osq_ts_sum[1] / n, osq_ts_sum[2] / n, osq_ts_sum[3] / n, osq_ts_sum[4] / n, osq_ts_sum[5] / n, osq_ts_sum[6] / n, osq_ts_sum[7] / n);
+        printf("quad<2> cycles per wave-iteration (%llu iterations): faces %llu | rows %llu | elimination %llu | back-substitution %llu | ratio/multipliers %llu | outputs %llu | "
+               "counter+contact %llu | record + warm start %llu | one stamp %llu\n",
+               n, osq_ts_sum[1] / n, osq_ts_sum[2] / n, osq_ts_sum[3] / n, osq_ts_sum[4] / n, osq_ts_sum[5] / n + osq_ts_sum[9] / n, osq_ts_sum[6] / n, osq_ts_sum[10] / n,
+               osq_ts_sum[7] / n, osq_ts_sum[8] / n);
     }
 #endif
 }
@@ -804,6 +923,8 @@ void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters,
     // two wavefronts per SIMD fill the chip; fewer rows than problems never hurts (a row takes the next index), more would idle
     const int rows = (a.B + 3) / 4, full = cu_count * 4 * OSQ_OCC;
     const dim3 grid(rows < full ? rows : full), block(64);
+    if (nst_mask & 3u) hipLaunchKernelGGL(osq::mpc_prep_kernel<1>, dim3(rows), block, 0, s, a);
+    if (nst_mask & 4u) hipLaunchKernelGGL(osq::mpc_prep_kernel<2>, dim3(rows), block, 0, s, a);
     if (nst_mask & 3u) hipLaunchKernelGGL(osq::mpc_solve_quad_kernel<1>, grid, block, 0, s, a, counters);
     if (nst_mask & 4u) hipLaunchKernelGGL(osq::mpc_solve_quad_kernel<2>, grid, block, 0, s, a, counters + 1);
 }

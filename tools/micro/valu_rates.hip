@@ -29,6 +29,11 @@ __global__ __launch_bounds__(512, 1) void k(float *out, int iters, unsigned long
                 if (KIND == 10) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d[v].x) : "s"(1.0001f), "v"(c.x));
                 if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(d[v]) : "v"(m), "v"(c));
                 if (KIND == 12) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(d[v].x) : "v"(m.x));
+                if (KIND == 14) asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[v]) : "v"(m));
+                if (KIND == 15) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(d[v]) : "v"(m), "v"(c));
+                if (KIND == 16) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[v]));
+                if (KIND == 17) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[v]) : "v"(d[(v + 2) & 7]));
+                if (KIND == 18) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[v]) : "v"(d[(v + 4) & 7]), "v"(m));
                 if (KIND == 13) asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %0, a0" : "+v"(d[v].x));
             }
         }
@@ -69,6 +74,11 @@ int main()
     run<5>(d, "v_mov_b32_dpp row_share", 1);
     run<6>(d, "v_permlane32_swap_b32", 1);
     run<7>(d, "v_fma_f64", 1);
+    run<15>(d, "v_fmac_f64", 1);
+    run<14>(d, "v_fmac_f64_dpp (self)", 1);
+    run<18>(d, "v_fmac_f64_dpp (other)", 1);
+    run<17>(d, "v_mov_b64_dpp", 1);
+    run<16>(d, "v_rcp_f64", 1);
     run<12>(d, "v_cndmask_b32", 1);
     run<13>(d, "accvgpr write+read", 2);
     return 0;

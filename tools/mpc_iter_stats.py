@@ -29,3 +29,26 @@ for t in (3, 10):
     srt = it[t][order]
     print(f"step {t}: mean {it[t].mean().item():.2f}, mean(max of 4) unsorted {it[t].reshape(-1, 4).max(1).values.mean().item():.2f}, "
           f"sorted by step {t - 1}'s count {srt.reshape(-1, 4).max(1).values.mean().item():.2f}")
+# cold starts (a trajectory whose force-carrying legs changed since the previous step: the warm record is not reused) against warm ones
+cw = c.reshape(T, -1).cpu().numpy().astype("uint32")
+import numpy as np
+def ranks(w):
+    out = np.zeros_like(w); n = np.zeros(w.shape, dtype=np.uint32)
+    for l in range(4):
+        byte = (w >> np.uint32(8 * l)) & np.uint32(0xff)
+        nz = byte != 0
+        out = np.where(nz, out | (byte << (np.uint32(8) * n)), out); n = n + nz.astype(np.uint32)
+    return out
+rk = ranks(cw)
+cold = np.ones((T, cw.shape[1]), dtype=bool); cold[1:] = rk[1:] != rk[:-1]
+itn = it.cpu().numpy()
+for t in (1, 5, 10, 15):
+    cc = cold[t]
+    print(f"step {t}: cold {cc.mean():.4f} of the batch; iterations cold mean {itn[t][cc].mean() if cc.any() else 0:.1f} max {itn[t][cc].max() if cc.any() else 0:.0f} | warm mean {itn[t][~cc].mean():.2f} max {itn[t][~cc].max():.0f}; "
+          f"of the problems above 12 iterations {((itn[t] > 12) & cc).sum()} cold, {((itn[t] > 12) & ~cc).sum()} warm")
+chg = np.zeros_like(cold); chg[1:] = cw[1:] != cw[:-1]
+for t in (5, 10, 15):
+    cc = chg[t]
+    print(f"step {t}: contact word changed for {cc.mean():.4f}; iterations changed mean {itn[t][cc].mean() if cc.any() else 0:.1f} | unchanged mean {itn[t][~cc].mean():.2f} max {itn[t][~cc].max():.0f}; "
+          f"above 12 iterations: {((itn[t] > 12) & cc).sum()} changed, {((itn[t] > 12) & ~cc).sum()} unchanged; previous step's count of those above 12: mean {itn[t-1][itn[t] > 12].mean():.1f}; "
+          f"P(>12 | prev > 12) = {((itn[t] > 12) & (itn[t-1] > 12)).sum() / max(1, (itn[t-1] > 12).sum()):.3f}, P(>12 | prev <= 3) = {((itn[t] > 12) & (itn[t-1] <= 3)).sum() / max(1, (itn[t-1] <= 3).sum()):.4f}")
