@@ -6,6 +6,8 @@
 
 #include <math.h>
 
+#include "kf_args.hpp"
+
 namespace osm {
 
 constexpr int NVMAX = 60, NLSMAX = 20;
@@ -18,7 +20,9 @@ struct MpcParams {
 };
 
 struct MpcArgs {
-    int B;
+    int B;                         // row stride of every [rows][B] stream
+    int n;                         // problems of this launch: indices 0 .. n - 1 behind the pointers (n = B, or a shard of the batch whose
+                                   // pointers are offset to its first trajectory: os_kf_mpc_run's two concurrent halves)
     const float *x, *ref, *p;      // [12][B]
     const uint32_t *contact;       // [B] 4 packed bytes
     float *f_out;                  // [12][B] forces of horizon step 0
@@ -42,6 +46,17 @@ struct MpcArgs {
     // round 6: the per-problem records of mpc_quad.hip (QuadRec: generators, linear term; written by mpc_prep_kernel, read by the rows)
     double *rec;                   // [B] x 1,792 bytes
     MpcParams prm;
+};
+
+// Round 6, the filter step inside the QP launch (mpc_quad.hip): a row that finishes a QP marks its trajectory done; wavefronts whose
+// rows have run out of QPs take blocks of four consecutive trajectories (a ticket counter), wait for their marks and run the step of
+// kf_dense_rows_kernel<BATCH> on them -- the work of the filter kernel (0.10 ms per step at B = 65,536) moves under the stragglers of
+// the QP launch (its last ~0.3 ms keep a few percent of the chip busy), and the step has one dependent launch fewer.
+struct PostArgs {
+    osk::KfRunArgs kf;             // this step's streams and state (T = 1); kf.status = the run's status words (or-ed into)
+    const float *qr;               // Q 144 | R 100 (the context's device copy)
+    uint32_t *done;                // [B]: the launch sequence number once the trajectory's forces are written
+    uint32_t seq;                  // this launch's sequence number (marks of earlier launches never match)
 };
 
 // 1/a to full double precision: v_rcp_f64 + two Newton steps (an IEEE division costs ~4x as many instructions)

@@ -28,6 +28,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "kf_dense_rows.hpp"
 #include "kf_args.hpp"
 #include "mpc_common.hpp"
@@ -836,38 +839,63 @@ static void fill_args(os_ctx *ctx, MpcArgs &a)
 }
 
 }  // namespace osm
-void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s);      // mpc_quad.hip
+void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s, const osm::PostArgs *post);      // mpc_quad.hip
 namespace osm {
+
+// layout of the context's QP scratch (floats): u [B][64] doubles | faces [B][64] bytes | contact [B] | todo [2][B] | counters (32 ints per
+// shard) | records [B] x 1,792 bytes (16-byte aligned) | done marks [B]
+constexpr int MAX_SHARDS = 4;
+struct HandLayout {
+    size_t faces, contact, todo, counters, rec, done, need;
+    explicit HandLayout(size_t Bz)
+    {
+        faces = Bz * 128; contact = faces + Bz * 16; todo = contact + Bz; counters = todo + 2 * Bz;
+        rec = (counters + 32 * MAX_SHARDS + 3) & ~(size_t)3; done = rec + Bz * 448; need = done + Bz;
+    }
+};
+static std::atomic<uint32_t> g_post_seq{0};
+// a contiguous part of the batch solved by one launch sequence: the caller's pointers are offset to trajectory b0, n trajectories behind
+// them, the row stride stays the batch's B (os_kf_mpc_run: two halves on two streams, one in the drain of its QP launch -- a few
+// stragglers, most of the chip idle -- while the other is in the bulk of its own)
+struct Shard { int index, b0, n; };
 
 // nst_mask: bit n set = launch the instance for n legs on the ground (bit 0 rides on the 1-leg instance).  Batches of at least
 // ctx->tune_mpc_quad problems: those with one / two force-carrying legs (15 / 30 variables) run sixteen lanes each, four to a
 // wavefront, rows fetching problems from a work counter (mpc_quad.hip); three / four legs stay on the wavefront-per-QP instances.
-static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask, hipStream_t s)
+// post (os_kf_mpc_run, one / two legs only): the filter step of every trajectory inside the same launch; post->done / seq are set here.
+static bool quad_path(const os_ctx *ctx, int n, uint32_t nst_mask) { return ctx->tune_mpc_quad != 0 && n >= ctx->tune_mpc_quad && (nst_mask & 7u); }
+static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask, hipStream_t s, PostArgs *post = nullptr, const Shard *shard = nullptr)
 {
     MpcArgs a = a_in;
+    const Shard sh = shard ? *shard : Shard{0, 0, a.B};
+    a.n = sh.n;
     a.cap = 0; a.cold_in = 0; a.todo = nullptr; a.todo_count = nullptr; a.rec = nullptr;
-    const dim3 grid(a.B), block(64);
-    if (ctx->tune_mpc_quad != 0 && a.B >= ctx->tune_mpc_quad && (nst_mask & 7u)) {
+    const dim3 grid(a.n), block(64);
+    if (quad_path(ctx, a.n, nst_mask)) {
         // pass 1: sixteen lanes per QP, rows fetch problems from a work counter and give one up after `cap` iterations;
         // pass 2: the problems handed over continue on a wavefront of their own.  The hand-over record is the warm-start record: a cold
         // solve borrows the context's scratch for it.
-        const size_t Bz = (size_t)a.B;
-        // u [B][64] doubles | faces [B][64] bytes | contact [B] | todo [2][B] | counters | records [B] x 1,792 bytes (16-byte aligned)
-        const size_t rec_at = (Bz * 128 + Bz * 16 + Bz + 2 * Bz + 16 + 3) & ~(size_t)3;
-        const size_t need = rec_at + Bz * 448;
-        if (os_ensure_scratch(ctx, &ctx->mpc_hand, &ctx->mpc_hand_floats, need)) return -10;
-        int32_t *counters = (int32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16 + Bz + 2 * Bz);
-        a.todo = (int32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16 + Bz);
-        a.todo_count = counters + 2;
-        a.rec = (double *)(ctx->mpc_hand + rec_at);
-        a.cap = ctx->tune_mpc_cap;
+        const size_t Bz = (size_t)a.B, b0 = (size_t)sh.b0;
+        const HandLayout hl(Bz);
+        if (os_ensure_scratch(ctx, &ctx->mpc_hand, &ctx->mpc_hand_floats, hl.need)) return -10;
+        int32_t *counters = (int32_t *)(ctx->mpc_hand + hl.counters) + 32 * sh.index;
+        a.todo = (int32_t *)(ctx->mpc_hand + hl.todo);
+        a.todo_count = counters + 16;
+        a.rec = (double *)(ctx->mpc_hand + hl.rec) + b0 * 224;
+        a.cap = (post || shard) ? 0 : ctx->tune_mpc_cap;
         if (!a.warm_u) {
-            a.warm_u = (double *)ctx->mpc_hand; a.warm_state = (uint8_t *)(ctx->mpc_hand + Bz * 128);
-            a.warm_contact = (uint32_t *)(ctx->mpc_hand + Bz * 128 + Bz * 16);
+            a.warm_u = (double *)ctx->mpc_hand + b0 * 64; a.warm_state = (uint8_t *)(ctx->mpc_hand + hl.faces) + b0 * 64;
+            a.warm_contact = (uint32_t *)(ctx->mpc_hand + hl.contact) + b0;
             a.cold_in = 1;
         }
-        if (hipMemsetAsync(counters, 0, 16, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
-        os_mpc_launch_quad(a, nst_mask & 7u, counters, ctx->cu_count, s);
+        if (post) {
+            post->done = (uint32_t *)(ctx->mpc_hand + hl.done) + b0;
+            uint32_t q = ++g_post_seq;
+            if (q == 0) q = ++g_post_seq;
+            post->seq = q;
+        }
+        if (hipMemsetAsync(counters, 0, 128, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
+        os_mpc_launch_quad(a, nst_mask & 7u, counters, ctx->cu_count, s, post);
         if (a.cap > 0) {
             if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a, 1);
             if (nst_mask & 4u) hipLaunchKernelGGL(mpc_solve_kernel<2>, grid, block, 0, s, a, 1);
@@ -881,6 +909,18 @@ static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask,
     if (nst_mask & 8u) hipLaunchKernelGGL(mpc_solve_kernel<3>, grid, block, 0, s, a, 0);
     if (nst_mask & 16u) hipLaunchKernelGGL(mpc_solve_kernel<4>, grid, block, 0, s, a, 0);
     return 0;
+}
+
+// the extra streams of the sharded os_kf_mpc_run, one set per device for the life of the process (contexts of a device share them: their
+// work is ordered by the fork / join events of each call)
+static hipStream_t g_shard_stream[16][MAX_SHARDS];
+static std::mutex g_shard_mutex;
+static hipStream_t shard_stream(int device, int i)
+{
+    std::lock_guard<std::mutex> lk(g_shard_mutex);
+    if (device < 0 || device >= 16) return nullptr;
+    if (!g_shard_stream[device][i] && hipStreamCreateWithFlags(&g_shard_stream[device][i], hipStreamNonBlocking) != hipSuccess) g_shard_stream[device][i] = nullptr;
+    return g_shard_stream[device][i];
 }
 
 }  // namespace osm
@@ -1002,6 +1042,17 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         const int gx = (B + 255) / 256 < 64 ? (B + 255) / 256 : 64;
         hipLaunchKernelGGL(osm::nst_presence_kernel, dim3(gx, T), dim3(256), 0, s, B, T, contact, flags_d);
     }
+    // The filter step inside the QP launch (mpc_quad.hip drain phase) where the step is the plain one: batch update, no P_trace /
+    // K_gain outputs, every trajectory with at most two force-carrying legs.  OS_MPC_FUSE_KF=0: the separate launch everywhere.
+    const char *fuse_env = getenv("OS_MPC_FUSE_KF");
+    const bool can_fuse = !(fuse_env && fuse_env[0] == '0') && (flags & ~(uint32_t)OS_MPC_COLD_START) == 0 && !ptrace_out && !kgain_out &&
+                          ctx->kf_qr && (size_t)B * 144 * 4 < 0xffffffffull && ctx->tune_mpc_cap == 0;
+    if (can_fuse && osm::quad_path(ctx, B, 7u)) {
+        // (the done marks once per call: whatever an earlier call with another batch size left at these addresses never matches)
+        const osm::HandLayout hl((size_t)B);
+        if (os_ensure_scratch(ctx, &ctx->mpc_hand, &ctx->mpc_hand_floats, hl.need)) return -10;
+        OS_HIP(ctx, hipMemsetAsync(ctx->mpc_hand + hl.done, 0, (size_t)B * 4, s));
+    }
     // one host read-back per call: only the solver instances a step needs are launched
     uint32_t *flags_h = (uint32_t *)malloc((size_t)T * sizeof(uint32_t));
     if (!flags_h) return os_fail(ctx, -13, "os_kf_mpc_run: out of host memory");
@@ -1009,29 +1060,79 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { free(flags_h); return os_fail(ctx, -10, hipGetErrorString(e)); }
 
+    // Shards: when EVERY step of the call runs the fused form, the batch is cut into contiguous parts on streams of their own (the
+    // caller's stream forks into them and joins them).  A part's QP launch ends with a few stragglers on an almost idle chip; the
+    // other part's launches fill it (measured at B = 65,536: 1.15 -> 1.05 ms per step with two parts; three and four gain nothing).
+    // OS_MPC_SHARDS=1 keeps one part.
+    int S = 1;
+    {
+        const char *sh_env = getenv("OS_MPC_SHARDS");
+        int want = sh_env ? atoi(sh_env) : 2;
+        if (want > osm::MAX_SHARDS) want = osm::MAX_SHARDS;
+        bool all_fused = can_fuse && want > 1 && B / want >= 16384;
+        for (int t = 0; t < T && all_fused; t++) all_fused = (flags_h[t] & ~7u) == 0 && osm::quad_path(ctx, B / want - 16, flags_h[t]);
+        if (all_fused) S = want;
+    }
+    hipStream_t st[osm::MAX_SHARDS] = {s, nullptr, nullptr, nullptr};
+    osm::Shard shard[osm::MAX_SHARDS];
+    hipEvent_t ev_fork = nullptr, ev_join[osm::MAX_SHARDS] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0, b0 = 0; i < S; i++) {
+        const int b1 = i + 1 == S ? B : (int)(((int64_t)B * (i + 1) / S) / 16 * 16);
+        shard[i] = osm::Shard{i, b0, b1 - b0};
+        b0 = b1;
+        if (i > 0 && !(st[i] = osm::shard_stream(ctx->device, i))) S = 1;
+    }
+    if (S == 1) shard[0] = osm::Shard{0, 0, B};
+    if (S > 1) {
+        bool ok = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev_fork, s) == hipSuccess;
+        for (int i = 1; i < S && ok; i++)
+            ok = hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) == hipSuccess && hipStreamWaitEvent(st[i], ev_fork, 0) == hipSuccess;
+        if (!ok) { free(flags_h); return os_fail(ctx, -10, "os_kf_mpc_run: could not fork the shard streams"); }
+    }
+
     osm::MpcArgs m;
-    m.B = B; m.x = x; m.u_out = nullptr; m.status = status; m.max_iter = 200;
-    m.warm_u = (flags & OS_MPC_COLD_START) ? nullptr : warm_u; m.warm_state = warm_state; m.warm_contact = warm_contact;
+    m.B = B; m.n = B; m.u_out = nullptr; m.max_iter = 200;
     osm::fill_args(ctx, m);
+    const bool keep_warm = !(flags & OS_MPC_COLD_START);
     int rc = 0;
     for (int t = 0; t < T && rc == 0; t++) {
         const size_t o12 = (size_t)t * 12 * B, o6 = (size_t)t * 6 * B, o1 = (size_t)t * B;
-        // forces from the state BEFORE this step's predict (kalman_filter.py:141-152) ...
-        m.ref = body_ref + o12; m.p = p + o12; m.contact = contact + o1; m.f_out = f_out + o12;
-        m.iters = mpc_iters ? mpc_iters + o1 : nullptr;
-        const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
-        if (int rcl = osm::launch_instances(ctx, m, flags_h[t], s)) { free(flags_h); return rcl; }
-        os_prof_end(ctx, slot, s);
-        // ... then get_odom + set_measurements + predict_mpc covariance + next_state + update (kalman_filter.py:176-182)
-        osk::KfRunArgs a;
-        a.B = B; a.T = 1; a.p = p + o12; a.f = f_out + o12; a.dp = dp + o12; a.imu = imu + o6; a.contact = contact + o1;
-        a.body_ref = body_ref + o12; a.x = x; a.P = P; a.x_out = x_out + o12;
-        a.p_rot_out = p_rot_out ? p_rot_out + o12 : nullptr;
-        a.ptrace_out = ptrace_out ? ptrace_out + o1 : nullptr; a.kgain_out = kgain_out ? kgain_out + o1 : nullptr;
-        a.status = st_step; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
-        rc = os_kf_run_impl(ctx, a, (flags | OS_KF_DENSE_FD) & ~(uint32_t)OS_KF_SYMMETRIC_P, s);
-        hipLaunchKernelGGL(osm::or_status_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, status, st_step);
+        const bool fuse = can_fuse && osm::quad_path(ctx, shard[0].n, flags_h[t]) && (flags_h[t] & ~7u) == 0;
+        for (int i = 0; i < S && rc == 0; i++) {
+            const size_t b0 = (size_t)shard[i].b0;
+            // forces from the state BEFORE this step's predict (kalman_filter.py:141-152) ...
+            m.x = x + b0; m.status = status + b0;
+            m.ref = body_ref + o12 + b0; m.p = p + o12 + b0; m.contact = contact + o1 + b0; m.f_out = f_out + o12 + b0;
+            m.iters = mpc_iters ? mpc_iters + o1 + b0 : nullptr;
+            m.warm_u = keep_warm ? warm_u + b0 * 64 : nullptr; m.warm_state = warm_state + b0 * 64; m.warm_contact = warm_contact + b0;
+            // ... then get_odom + set_measurements + predict_mpc covariance + next_state + update (kalman_filter.py:176-182)
+            osk::KfRunArgs a;
+            a.B = B; a.T = 1; a.p = p + o12 + b0; a.f = f_out + o12 + b0; a.dp = dp + o12 + b0; a.imu = imu + o6 + b0; a.contact = contact + o1 + b0;
+            a.body_ref = body_ref + o12 + b0; a.x = x + b0; a.P = P + b0; a.x_out = x_out + o12 + b0;
+            a.p_rot_out = p_rot_out ? p_rot_out + o12 + b0 : nullptr;
+            a.ptrace_out = ptrace_out ? ptrace_out + o1 : nullptr; a.kgain_out = kgain_out ? kgain_out + o1 : nullptr;
+            a.status = st_step; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
+            const int slot = os_prof_begin(ctx, 4, st[i], "mpc_solve_kernel<NST>");
+            if (fuse) {
+                osm::PostArgs post;
+                post.kf = a; post.kf.k = ctx->k; post.kf.status = status + b0;
+                post.qr = (const float *)ctx->kf_qr; post.done = nullptr; post.seq = 0;
+                if (int rcl = osm::launch_instances(ctx, m, flags_h[t], st[i], &post, &shard[i])) { free(flags_h); return rcl; }
+                os_prof_end(ctx, slot, st[i]);
+                continue;
+            }
+            // (the separate launches: one part only -- S > 1 needs every step fused)
+            if (int rcl = osm::launch_instances(ctx, m, flags_h[t], s)) { free(flags_h); return rcl; }
+            os_prof_end(ctx, slot, s);
+            rc = os_kf_run_impl(ctx, a, (flags | OS_KF_DENSE_FD) & ~(uint32_t)OS_KF_SYMMETRIC_P, s);
+            hipLaunchKernelGGL(osm::or_status_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, status, st_step);
+        }
     }
+    for (int i = 1; i < S; i++) {
+        if (hipEventRecord(ev_join[i], st[i]) != hipSuccess || hipStreamWaitEvent(s, ev_join[i], 0) != hipSuccess) rc = rc ? rc : -10;
+        hipEventDestroy(ev_join[i]);
+    }
+    if (ev_fork) hipEventDestroy(ev_fork);
     free(flags_h);
     if (rc) return rc;
     OS_HIP(ctx, hipGetLastError());

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "kf_dense_rows.hpp"
+#include "kf_args.hpp"
 
 namespace osq {
 
@@ -109,6 +110,19 @@ __device__ __forceinline__ bool any16(bool p, int lane)
     return ((m >> (lane & 48)) & 0xffffull) != 0ull;
 }
 
+// The forces cross from the row that solved the QP to the row that runs the filter step -- another CU, usually another XCD -- inside
+// one launch.  The L2 of an XCD is not coherent with the others': an agent-scope release / acquire pair is a write-back of the whole
+// L2 and an invalidate of it (measured: every finished QP paid one, every poll the other -- the launch took 2.6 ms instead of 1.1).
+// Here only the twelve force values and the mark travel, with agent-scope (sc1) stores and loads that go through to memory
+// themselves; `s_waitcnt vmcnt(0)` orders the mark behind them.
+__device__ __forceinline__ void store_agent(float *p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float *p)
+{
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 template <int NST>
 struct Quad {
     static constexpr int NV = 15 * NST, NPS = 3 * NST, NLS = 5 * NST, VPL = NV > 16 ? 2 : 1, RCH = rec_chunks<15 * NST>();
@@ -304,17 +318,22 @@ struct Quad {
         double dsel[VPL], dinv[VPL];
 #pragma unroll
         for (int h = 0; h < VPL; h++) { dsel[h] = live[h] ? P.rw * tt[h] : 1.0; dinv[h] = 1.0; }
+        // (an opaque copy of the lane index: the ~90 lane predicates of the pivots below -- `row > k`, `l == k & 15` -- are otherwise
+        // hoisted out of the solver loop as lane masks in SGPR pairs, spilled to VGPR lanes and fetched back with two v_readlane each;
+        // recomputed, a predicate is one v_cmp against an inline constant)
+        int ll = L.l;
+        asm volatile("" : "+v"(ll));
         // (the NEXT pivot's inverse -- broadcast, v_rcp_f64, two Newton steps: a ~150-cycle dependent chain -- is started as soon as this
         // pivot's first entry has finalised that diagonal, and runs underneath the rest of this pivot's entries)
         double inv_next = rcp64(bc64<0>(A[0][0] + dsel[0]));
         static_for<0, NV>([&](auto kc) {
             constexpr int k = decltype(kc)::value, hk = k >> 4, kk = k & 15;
             const double inv = inv_next;
-            if (L.l == kk) dinv[hk] = inv;
+            if (ll == kk) dinv[hk] = inv;
             double nf[VPL];
 #pragma unroll
             for (int h = 0; h < VPL; h++) {
-                const int row = L.l + 16 * h;
+                const int row = ll + 16 * h;
                 nf[h] = (h >= hk && row > k && row < NV) ? -A[h][k] * inv : 0.0;
             }
             // entry j of every row below the pivot: the upper half first (it reads the pivot row's register, which the lower half's
@@ -343,10 +362,10 @@ struct Quad {
         static_for<0, NV>([&](auto ic) {
             constexpr int k = NV - 1 - decltype(ic)::value, hk = k >> 4, kk = k & 15;
             const double wk = bc64<kk>(r[hk] * dinv[hk]);
-            if (L.l == kk) sol[hk] = wk;
+            if (ll == kk) sol[hk] = wk;
 #pragma unroll
             for (int h = 0; h <= hk; h++)
-                if (L.l + 16 * h < k) r[h] = fma(-A[h][k], wk, r[h]);
+                if (ll + 16 * h < k) r[h] = fma(-A[h][k], wk, r[h]);
             __builtin_amdgcn_sched_barrier(0);
         });
         OSQ_STAMP(4)                                 // back substitution
@@ -547,6 +566,7 @@ struct Quad {
         R.has = false;
     }
 
+    template <bool SCOPED = false>
     static __device__ __forceinline__ void finish_row(const Lane &L, const MpcArgs &a, Mem &M, Row &R)
     {
         const size_t B = (size_t)a.B;
@@ -576,7 +596,7 @@ struct Quad {
                 for (int r = 0; r < NST; r++)
                     if ((r == 0 ? legs[0] : (r == 1 ? legs[1] : (r == 2 ? legs[2] : legs[3]))) == oleg) rank = r;
                 const float val = rank < 0 ? 0.f : (float)M.vec[oi * NPS + 3 * (rank < 0 ? 0 : rank) + oc];
-                if (o < 12) a.f_out[(size_t)o * B + b] = val;
+                if (o < 12) { if (SCOPED) store_agent(&a.f_out[(size_t)o * B + b], val); else a.f_out[(size_t)o * B + b] = val; }
                 if (a.u_out) a.u_out[(size_t)o * B + b] = val;
             }
         }
@@ -591,7 +611,7 @@ struct Quad {
         }
         if (L.l == 0) {
             if (a.iters) a.iters[b] = R.iters;
-            if (!R.converged) a.status[b] |= 4;
+            if (!R.converged) atomicOr(&a.status[b], 4);
         }
         __builtin_amdgcn_wave_barrier();
         R.has = false;
@@ -804,7 +824,7 @@ __global__ __launch_bounds__(64) void mpc_prep_kernel(const MpcArgs a)
     const typename Q::Lane L = Q::this_lane();
     PrepMem<Q::NV> &M = Mp[L.lane >> 4];
     const int b = blockIdx.x * 4 + (L.lane >> 4);
-    if (b >= a.B) return;
+    if (b >= a.n) return;
     const uint32_t cb = a.contact[b];
     const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
     if (nst != NST) return;
@@ -818,10 +838,88 @@ __global__ __launch_bounds__(64) void mpc_prep_kernel(const MpcArgs a)
 #ifndef OSQ_OCC
 #define OSQ_OCC 2            // wavefronts per SIMD the register budget is sized for
 #endif
-template <int NST>
-__global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcArgs a, int *__restrict__ counter)
+// counters of an instance (zeroed by the host before the launch)
+enum : int { CNT_WORK = 0, CNT_TICKET = 1, CNT_INTS = 8 };
+// what a launch does beyond the QPs: nothing | marks finished trajectories (an instance that is followed by another one) | marks them
+// and runs the filter step of EVERY trajectory of the batch in its drain phase (the last instance of the step)
+enum : int { POST_NONE = 0, POST_MARK = 1, POST_STEP = 2 };
+
+// the trajectory of a finished QP is marked done (row-uniform), behind the row's force stores
+__device__ __forceinline__ void mark_done(int l, const PostArgs &post, int b)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (l == 0) __hip_atomic_store(&post.done[b], post.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One predict_mpc + update step of trajectory b on this 16-lane row: kf_dense_rows_kernel<BATCH, dense> at T = 1 (kf_dense_rows.hip),
+// the same building blocks in the same order -- the results are bit-identical to the separate launch.  qs / rs: Q and R in float64 (LDS).
+__device__ __forceinline__ void kf_step_row(const osk::KfRunArgs &a, const double *qs, const double *rs, int b, bool live, int r)
+{
+    using namespace osk;
+    namespace rw = osk::rows64;
+    const int rr = r < 12 ? r : 11, am = rw::row_measurement(r);
+    const size_t B = (size_t)a.B;
+    const uint32_t voff = (uint32_t)b * 4u, rowB = (uint32_t)a.B * 4u;
+    const KfConst &k = a.k;
+    const double *qrow = qs + rr * NS, *rrow_b = rs + (am >= 0 ? am : NM) * NM;
+    double P[NS];
+    float xr;
+    {
+        rsrc_t rx = make_rsrc(a.x, 12 * rowB), rP = make_rsrc(a.P, 144 * rowB);
+        xr = buf_load(rx, voff + (uint32_t)rr * rowB, 0);
+#pragma unroll
+        for (int j = 0; j < NS; j++) P[j] = (double)buf_load(rP, voff + (uint32_t)(rr * NS + j) * rowB, 0);
+    }
+    double one = 1.0;
+    asm volatile("" : "+v"(one));                      // a register operand for the DPP sums
+    const double ed = expm1((double)k.dt);
+    StepIn in;
+    float bref[3];
+    load_step(a, 0, voff, rowB, in);
+#pragma unroll
+    for (int i = 0; i < 12; i++) in.f[i] = load_agent(a.f + (size_t)i * B + b);      // (written in this launch, by another CU)
+    {
+        rsrc_t rb = make_rsrc(a.body_ref, 12 * rowB);
+#pragma unroll
+        for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
+    }
+    float x[NS], z[NM], pw[12];
+    rw::gather_state(xr, x);
+    int status = rw::front_row<true>(x, xr, P, in, bref, k, ed, qrow, one, r, z, pw);
+    float xn = x[0];
+#pragma unroll
+    for (int i = 1; i < NS; i++) xn = (rr == i) ? x[i] : xn;
+    if (a.p_rot_out && live && r < 12) {
+        float pv = pw[0];
+#pragma unroll
+        for (int i = 1; i < 12; i++) pv = (r == i) ? pw[i] : pv;
+        a.p_rot_out[(size_t)r * B + b] = pv;
+    }
+    double xd = (double)xn;
+    {
+        double K[NM], rrow[NM];
+#pragma unroll
+        for (int q = 0; q < NM; q++) rrow[q] = rrow_b[q];
+        status |= rw::update_batch_row(xd, P, z, rrow, K, am);
+    }
+    xr = (float)xd;
+    if (!(xr * 0.f == 0.f)) status |= 2;
+    status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
+    status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
+    if (live && r < 12) {
+        a.x_out[(size_t)r * B + b] = xr;
+        a.x[(size_t)r * B + b] = xr;
+#pragma unroll
+        for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = (float)P[j];
+        if (r == 0 && status) atomicOr(&a.status[b], status);
+    }
+}
+
+template <int NST, int POST>
+__global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcArgs a, int *__restrict__ cnt, const PostArgs post)
 {
     typedef Quad<NST> Q;
+    int *const counter = cnt + CNT_WORK;
     __shared__ typename Q::Mem Mq[4];
     __shared__ QuadShared Sh;
     const typename Q::Lane L = Q::this_lane();
@@ -859,7 +957,7 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
             // round trip travels under a whole problem's iterations)
             for (;;) {
                 const int nb = R.nb_next;
-                if (nb >= a.B) { R.exhausted = true; break; }
+                if (nb >= a.n) { R.exhausted = true; break; }
 #ifdef OSQ_X_STATIC
                 R.nb_next = x_next; x_next += gridDim.x * 4;
 #else
@@ -870,11 +968,12 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
                 const uint32_t cb = a.contact[nb];
                 const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
                 if (NST == 1 && nst == 0) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
-                    if (L.l < 12) a.f_out[(size_t)L.l * B + nb] = 0.f;
+                    if (L.l < 12) { if (POST != POST_NONE) store_agent(&a.f_out[(size_t)L.l * B + nb], 0.f); else a.f_out[(size_t)L.l * B + nb] = 0.f; }
                     if (a.u_out)
                         for (int o = L.l; o < 60; o += 16) a.u_out[(size_t)o * B + nb] = 0.f;
                     if (L.l == 0 && a.iters) a.iters[nb] = 0;
                     if (L.l == 0 && a.warm_contact) a.warm_contact[nb] = cb;
+                    if constexpr (POST != POST_NONE) mark_done(L.l, post, nb);
                 }
                 if (nst != NST) continue;
                 OSQ_STAMP(10)                        // work counter + contact word
@@ -893,16 +992,55 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
 #ifdef OSQ_X_FIXED
             R.done = R.iters >= OSQ_X_FIXED; R.converged = true;
 #endif
+#ifdef OSQ_X_TRUNC
+            if (R.iters >= OSQ_X_TRUNC) { R.done = true; R.converged = true; }
+#endif
 #ifdef OSQ_X_PRIO
             if (__ballot(R.has && R.iters == OSQ_X_PRIO) != 0ull) __builtin_amdgcn_s_setprio(3);
 #endif
-            if (R.done || R.iters >= a.max_iter) Q::finish_row(L, a, M, R);
+            if (R.done || R.iters >= a.max_iter) {
+                Q::template finish_row<POST != POST_NONE>(L, a, M, R);
+                if constexpr (POST != POST_NONE) mark_done(L.l, post, R.b);
+            }
             else if (a.cap > 0 && R.iters >= a.cap) Q::hand_over_row(L, a, R);
         }
         OSQ_STAMP(6)                                 // outputs of finished problems
 #ifdef OSQ_TS
         if (blockIdx.x == 0 && threadIdx.x == 0) osq_ts_sum[0] += 1;
 #endif
+    }
+    if constexpr (POST == POST_STEP) {
+        // ---- drain phase: this wavefront has solved everything it will; it now takes blocks of four CONSECUTIVE trajectories (the
+        // [rows][B] streams want neighbours together: in completion order a step touched ~380 cache lines per trajectory and the
+        // launch took 2.8 ms) from a ticket counter, each row waits for its trajectory's mark and the four filter steps run in
+        // lock step.  The wait is for a row that is running (this launch's, or an earlier instance's that has completed): no
+        // co-residency assumption; the poll limit only guards against a lost device (status bit 6 of the trajectory).
+        double *qs = reinterpret_cast<double *>(&Mq[0]), *rs = qs + osk::NS * osk::NS;      // (the rows' LDS blocks are idle now)
+        __builtin_amdgcn_wave_barrier();
+        for (int i = L.lane; i < osk::NS * osk::NS; i += 64) qs[i] = (double)post.qr[i];
+        for (int i = L.lane; i < (osk::NM + 2) * osk::NM; i += 64) rs[i] = i < osk::NM * osk::NM ? (double)post.qr[144 + i] : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for (;;) {
+            // a ticket = sixteen consecutive trajectories, four at a time: the four sub-steps touch the same cache lines of every stream
+            // (four trajectories per ticket fetched each line on four different XCDs)
+            int t = 0;
+            if (L.lane == 0) t = atomicAdd(&cnt[CNT_TICKET], 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (16 * t >= a.n) break;
+            for (int j = 0; j < 4; j++) {
+                const int tb = 16 * t + 4 * j + (L.lane >> 4);
+                if (16 * t + 4 * j >= a.n) break;
+                const bool have = tb < a.n;
+                if (have) {
+                    unsigned polls = 0;
+                    while (__hip_atomic_load(&post.done[tb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != post.seq) {
+                        if (++polls > (1u << 24)) { if (L.l == 0) atomicOr(&post.kf.status[tb], 64); break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                kf_step_row(post.kf, qs, rs, have ? tb : a.n - 1, have, L.l);
+            }
+        }
     }
 #ifdef OSQ_TS
     if (blockIdx.x == 0 && threadIdx.x == 0 && NST == 2) {
@@ -917,14 +1055,25 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
 
 }  // namespace osq
 
-// the instances for one / two force-carrying legs over the whole batch (mpc_kernels.hip launch_instances); counters: two zeroed ints
-void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s)
+// the instances for one / two force-carrying legs over the whole batch (mpc_kernels.hip launch_instances); counters: CNT_INTS zeroed
+// ints per instance; post: the filter step of the finished trajectories inside the same launch (null: QP only)
+void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s, const osm::PostArgs *post)
 {
     // two wavefronts per SIMD fill the chip; fewer rows than problems never hurts (a row takes the next index), more would idle
-    const int rows = (a.B + 3) / 4, full = cu_count * 4 * OSQ_OCC;
+    const int rows = (a.n + 3) / 4, full = cu_count * 4 * OSQ_OCC;
     const dim3 grid(rows < full ? rows : full), block(64);
     if (nst_mask & 3u) hipLaunchKernelGGL(osq::mpc_prep_kernel<1>, dim3(rows), block, 0, s, a);
     if (nst_mask & 4u) hipLaunchKernelGGL(osq::mpc_prep_kernel<2>, dim3(rows), block, 0, s, a);
-    if (nst_mask & 3u) hipLaunchKernelGGL(osq::mpc_solve_quad_kernel<1>, grid, block, 0, s, a, counters);
-    if (nst_mask & 4u) hipLaunchKernelGGL(osq::mpc_solve_quad_kernel<2>, grid, block, 0, s, a, counters + 1);
+    if (post) {
+        // the last instance of the step runs the filter step of every trajectory; one in front of it only marks its own
+        if ((nst_mask & 3u) && (nst_mask & 4u)) {
+            hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<1, osq::POST_MARK>), grid, block, 0, s, a, counters, *post);
+            hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<2, osq::POST_STEP>), grid, block, 0, s, a, counters + osq::CNT_INTS, *post);
+        } else if (nst_mask & 3u) hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<1, osq::POST_STEP>), grid, block, 0, s, a, counters, *post);
+        else if (nst_mask & 4u) hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<2, osq::POST_STEP>), grid, block, 0, s, a, counters + osq::CNT_INTS, *post);
+    } else {
+        static const osm::PostArgs none = {};
+        if (nst_mask & 3u) hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<1, osq::POST_NONE>), grid, block, 0, s, a, counters, none);
+        if (nst_mask & 4u) hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<2, osq::POST_NONE>), grid, block, 0, s, a, counters + osq::CNT_INTS, none);
+    }
 }
