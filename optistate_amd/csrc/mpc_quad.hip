@@ -136,10 +136,20 @@ struct Quad {
         int lane, l;
         Var var[VPL];
     };
-    static __device__ __forceinline__ Lane this_lane()
+    static __device__ __forceinline__ Lane this_lane() { return lane_of(threadIdx.x & 63); }
+    // (the lane's constants again from an opaque copy of the lane index: at two wavefronts per SIMD hipcc keeps ~25 of these loop
+    // invariants -- LDS addresses of the leg-step's entries, component selectors -- in scratch and reloads them in every iteration
+    // behind an s_waitcnt vmcnt(0); recomputed they are a dozen integer instructions)
+    static __device__ __forceinline__ Lane again(const Lane &L0)
+    {
+        int lane = L0.lane;
+        asm volatile("" : "+v"(lane));
+        return lane_of(lane);
+    }
+    static __device__ __forceinline__ Lane lane_of(int lane)
     {
         Lane L;
-        L.lane = threadIdx.x & 63;
+        L.lane = lane;
         L.l = L.lane & 15;
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
@@ -230,8 +240,9 @@ struct Quad {
     static __device__ __forceinline__ int fpack(int sx, int sy, int sz) { return (sx + 1) | ((sy + 1) << 2) | (sz << 4); }
     struct Sol { double u[VPL]; };
 
-    static __device__ __forceinline__ Sol solve_face(const Lane &L, const MpcParams &P, const QuadShared &Sh, Mem &M, const Faces F)
+    static __device__ __forceinline__ Sol solve_face(const Lane &L0, const MpcParams &P, const QuadShared &Sh, Mem &M, const Faces F)
     {
+        const Lane L = again(L0);
         OSQ_STAMP(0)
         int sx[VPL], sy[VPL], sz[VPL];
 #pragma unroll
@@ -491,8 +502,9 @@ struct Quad {
 
     // problem b -> the row's LDS block and state (row-uniform control flow: every lane of the row is here): the record in, the stance
     // flags from the contact word, the warm-start record where it applies
-    static __device__ __forceinline__ void load_row(const Lane &L, const MpcArgs &a, Mem &M, Row &R, int b, uint32_t cbits)
+    static __device__ __forceinline__ void load_row(const Lane &L0, const MpcArgs &a, Mem &M, Row &R, int b, uint32_t cbits)
     {
+        const Lane L = again(L0);
         typedef double d2_t __attribute__((ext_vector_type(2)));
         const d2_t *src = reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(a.rec) + (size_t)b * REC_BYTES);
         d2_t rc[RCH];
@@ -567,8 +579,9 @@ struct Quad {
     }
 
     template <bool SCOPED = false>
-    static __device__ __forceinline__ void finish_row(const Lane &L, const MpcArgs &a, Mem &M, Row &R)
+    static __device__ __forceinline__ void finish_row(const Lane &L0, const MpcArgs &a, Mem &M, Row &R)
     {
+        const Lane L = again(L0);
         const size_t B = (size_t)a.B;
         const int b = R.b;
 #ifdef OSQ_X_NOSTORE
@@ -625,8 +638,9 @@ struct Quad {
     // minimum ratio) per iteration, + 4 when the subspace minimiser is reached (gradient: 2, multipliers: 2).
     static __device__ __forceinline__ double pick3(const double (&a)[3], int c) { return c == 0 ? a[0] : (c == 1 ? a[1] : a[2]); }
 
-    static __device__ __forceinline__ void iterate_row(const Lane &L, const MpcParams &P, const QuadShared &Sh, Mem &M, Row &R, const Sol &S)
+    static __device__ __forceinline__ void iterate_row(const Lane &L0, const MpcParams &P, const QuadShared &Sh, Mem &M, Row &R, const Sol &S)
     {
+        const Lane L = again(L0);
         Faces &F = R.F;
         double (&u)[VPL] = R.u;
         const bool (&stance)[VPL] = R.stance;
