@@ -341,12 +341,12 @@ struct Quad {
             constexpr int k = decltype(kc)::value, hk = k >> 4, kk = k & 15;
             const double inv = inv_next;
             if (ll == kk) dinv[hk] = inv;
+            // rows below the pivot (the rows of the other half are all below or all above; a pad row is zero, its factor too)
             double nf[VPL];
 #pragma unroll
-            for (int h = 0; h < VPL; h++) {
-                const int row = ll + 16 * h;
-                nf[h] = (h >= hk && row > k && row < NV) ? -A[h][k] * inv : 0.0;
-            }
+            for (int h = 0; h < VPL; h++) nf[h] = 0.0;
+            nf[hk] = ll > kk ? -A[hk][k] * inv : 0.0;
+            if constexpr (VPL == 2 && hk == 0) nf[1] = -A[1][k] * inv;
             // entry j of every row below the pivot: the upper half first (it reads the pivot row's register, which the lower half's
             // own update then rewrites: a DPP operand must not have been written by the two preceding instructions)
             static_for<k + 1, NV + 1>([&](auto jc) {
@@ -367,21 +367,22 @@ struct Quad {
         });
         OSQ_STAMP(3)                                 // elimination
         // ---- back substitution ----
-        double r[VPL], sol[VPL];
+        double r[VPL];
 #pragma unroll
-        for (int h = 0; h < VPL; h++) { r[h] = A[h][NV]; sol[h] = 0.0; }
+        for (int h = 0; h < VPL; h++) r[h] = A[h][NV];
         static_for<0, NV>([&](auto ic) {
             constexpr int k = NV - 1 - decltype(ic)::value, hk = k >> 4, kk = k & 15;
             const double wk = bc64<kk>(r[hk] * dinv[hk]);
-            if (ll == kk) sol[hk] = wk;
 #pragma unroll
             for (int h = 0; h <= hk; h++)
                 if (ll + 16 * h < k) r[h] = fma(-A[h][k], wk, r[h]);
             __builtin_amdgcn_sched_barrier(0);
         });
         OSQ_STAMP(4)                                 // back substitution
+        // (a row's right-hand side is final once its own step has passed -- later steps touch the rows above -- so every lane forms its
+        // own component at the end: the product the step broadcast, without a select per step)
 #pragma unroll
-        for (int h = 0; h < VPL; h++) out.u[h] = sol[h];
+        for (int h = 0; h < VPL; h++) out.u[h] = r[h] * dinv[h];
         return out;
     }
 
@@ -592,22 +593,21 @@ struct Quad {
         for (int h = 0; h < VPL; h++)
             if (!L.var[h].pad) M.vec[L.var[h].v] = R.u[h];
         __builtin_amdgcn_wave_barrier();
-        int legs[4] = {0, 0, 0, 0};
-        {
-            int n = 0;
+        // rank of each leg among the force-carrying ones (-1: swing), from the contact word: a few scalar-free selects
+        int rank_of[4], nr = 0;
 #pragma unroll
-            for (int lg = 0; lg < 4; lg++)
-                if (((R.cbits >> (8 * lg)) & 0xffu) != 0u) { if (n == 0) legs[0] = lg; else if (n == 1) legs[1] = lg; else if (n == 2) legs[2] = lg; else legs[3] = lg; n++; }
+        for (int lg = 0; lg < 4; lg++) {
+            const bool on = ((R.cbits >> (8 * lg)) & 0xffu) != 0u;
+            rank_of[lg] = on ? nr : -1;
+            nr += on ? 1 : 0;
         }
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
+        // horizon step 0 (the forces the filter step wants) always, the other four steps when the caller asked for the whole control
+        const int mmax = a.u_out ? 4 : 1;
+        for (int m = 0; m < mmax; m++) {
             const int o = L.l + 16 * m;
             if (o < 60) {
                 const int oi = o / 12, oleg = (o % 12) / 3, oc = o % 3;
-                int rank = -1;
-#pragma unroll
-                for (int r = 0; r < NST; r++)
-                    if ((r == 0 ? legs[0] : (r == 1 ? legs[1] : (r == 2 ? legs[2] : legs[3]))) == oleg) rank = r;
+                const int rank = oleg == 0 ? rank_of[0] : (oleg == 1 ? rank_of[1] : (oleg == 2 ? rank_of[2] : rank_of[3]));
                 const float val = rank < 0 ? 0.f : (float)M.vec[oi * NPS + 3 * (rank < 0 ? 0 : rank) + oc];
                 if (o < 12) { if (SCOPED) store_agent(&a.f_out[(size_t)o * B + b], val); else a.f_out[(size_t)o * B + b] = val; }
                 if (a.u_out) a.u_out[(size_t)o * B + b] = val;
