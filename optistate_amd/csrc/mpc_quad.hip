@@ -303,24 +303,31 @@ struct Quad {
             const double rhs = -(g[h][0] * cwv[0] + g[h][1] * cwv[1] + g[h][2] * cwv[2] + g[h][3] * cwv[3] + g[h][4] * cwv[4] + g[h][5] * cwv[5]) - dot[h];
             A[h][NV] = live[h] ? rhs : 0.0;
         }
+        // a dead slot's generator is zero, so its row and column are zero here; the diagonal (r + ..., or 1 for a dead slot) is added
+        // where the elimination reads the pivot.  Column w + 1's generator is requested before column w's products are formed (hipcc
+        // left to itself waits for each column's three reads right behind them: ~110 exposed LDS round trips per solve)
+        {
+            double zA[VPL][3], zB[VPL][3], gn[6];
 #pragma unroll
-        for (int l = 0; l < 5; l++) {
-            double zA[VPL][3], zB[VPL][3];
+            for (int r = 0; r < 6; r++) gn[r] = M.gent[0][r];
+            static_for<0, NV>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                if constexpr (w % NPS == 0) {
 #pragma unroll
-            for (int h = 0; h < VPL; h++) zvec(P, Z[h], g[h], l, zA[h], zB[h]);
-#pragma unroll
-            for (int j = 0; j < NPS; j++) {
-                const int w = NPS * l + j;
-                // a dead slot's generator is zero, so its row and column are zero here; the diagonal (r + ..., or 1 for a dead slot) is
-                // added where the elimination reads the pivot
+                    for (int h = 0; h < VPL; h++) zvec(P, Z[h], g[h], w / NPS, zA[h], zB[h]);
+                }
                 double gw[6];
 #pragma unroll
-                for (int r = 0; r < 6; r++) gw[r] = M.gent[w][r];
+                for (int r = 0; r < 6; r++) gw[r] = gn[r];
+                if constexpr (w + 1 < NV) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++) gn[r] = M.gent[w + 1][r];
+                }
 #pragma unroll
                 for (int h = 0; h < VPL; h++)
                     A[h][w] = zA[h][0] * gw[0] + zA[h][1] * gw[1] + zA[h][2] * gw[2] + zB[h][0] * gw[3] + zB[h][1] * gw[4] + zB[h][2] * gw[5];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                if constexpr (w % NPS == NPS - 1) __builtin_amdgcn_sched_barrier(0);
+            });
         }
         OSQ_STAMP(2)                                 // right-hand side + rows
         // ---- forward elimination: pivot k lives in lane k & 15 of the row, half k >> 4; its row is broadcast inside the FMA.  Compile-time
