@@ -398,7 +398,7 @@ struct Quad {
     // 4.1 iterations per QP, mean of the maximum over four consecutive QPs 7.7; tools/mpc_iter_stats.py).
     struct Row {
         bool has, exhausted, first, done, converged;
-        int b, iters, nb_next;      // nb_next: the work-counter value reserved for the row's NEXT problem (requested a problem ahead)
+        int b, iters, nx_raw;       // nx_raw (lane 0 of the row): the work-counter value reserved for the row's NEXT problem, requested a problem ahead
         uint32_t cbits;
         bool stance[VPL];
         Faces F;
@@ -509,28 +509,42 @@ struct Quad {
     }
 
     // problem b -> the row's LDS block and state (row-uniform control flow: every lane of the row is here): the record in, the stance
-    // flags from the contact word, the warm-start record where it applies
-    static __device__ __forceinline__ void load_row(const Lane &L0, const MpcArgs &a, Mem &M, Row &R, int b, uint32_t cbits)
+    // flags from the contact word, the warm-start record where it applies.  In two halves: every global read of the problem is
+    // requested at once (request_row), load_row picks the data up, and only then does the caller reserve the row's NEXT index at the
+    // work counter (its round trip travels under the problem's iterations): one exposed round trip per problem instead of three
+    // (counter, contact word, record).
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    struct Pre {
+        d2_t rc[RCH];
+        uint32_t cb, wc;
+        double wu[VPL];
+        int wf[VPL];
+    };
+    static __device__ __forceinline__ Pre request_row(const Lane &L0, const MpcArgs &a, int b)
     {
         const Lane L = again(L0);
-        typedef double d2_t __attribute__((ext_vector_type(2)));
+        Pre pre;
+        pre.cb = a.contact[b];
         const d2_t *src = reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(a.rec) + (size_t)b * REC_BYTES);
-        d2_t rc[RCH];
 #pragma unroll
-        for (int c = 0; c < RCH; c++) rc[c] = src[c * 16 + L.l];
-        // cold start: stance (and unconstrained) legs free, swing legs zero; warm: the previous solve's point and faces when the
-        // force-carrying legs' contact bytes are unchanged (the pyramids do not move: the old u stays feasible)
-        uint32_t wc = 0xffffffffu;
-        double wu[VPL]; int wf[VPL];
-        const bool try_warm = a.warm_u && !a.cold_in;
-        if (try_warm) {
-            wc = a.warm_contact[b];
+        for (int c = 0; c < RCH; c++) pre.rc[c] = src[c * 16 + L.l];
+        pre.wc = 0xffffffffu;
+#pragma unroll
+        for (int h = 0; h < VPL; h++) { pre.wu[h] = 0.0; pre.wf[h] = 0; }
+        if (a.warm_u && !a.cold_in) {
+            pre.wc = a.warm_contact[b];
 #pragma unroll
             for (int h = 0; h < VPL; h++) {
                 const int v = L.l + 16 * h;
-                wu[h] = a.warm_u[(size_t)b * 64 + v]; wf[h] = a.warm_state[(size_t)b * 64 + v] & 0x3f;
+                pre.wu[h] = a.warm_u[(size_t)b * 64 + v]; pre.wf[h] = a.warm_state[(size_t)b * 64 + v] & 0x3f;
             }
         }
+        return pre;
+    }
+    static __device__ __forceinline__ void load_row(const Lane &L0, const MpcArgs &a, Mem &M, Row &R, int b, const Pre &pre)
+    {
+        const Lane L = again(L0);
+        const uint32_t cbits = pre.cb;
         int legs[4] = {0, 0, 0, 0};
         {
             int n = 0;
@@ -551,14 +565,16 @@ struct Quad {
         __builtin_amdgcn_wave_barrier();
         d2_t *dst = reinterpret_cast<d2_t *>(M.rec_image);
 #pragma unroll
-        for (int c = 0; c < RCH; c++) dst[c * 16 + L.l] = rc[c];
+        for (int c = 0; c < RCH; c++) dst[c * 16 + L.l] = pre.rc[c];
         __builtin_amdgcn_wave_barrier();
-        const bool warm = try_warm && wc != 0xffffffffu && contact_ranks(wc) == contact_ranks(cbits);
+        // cold start: stance (and unconstrained) legs free, swing legs zero; warm: the previous solve's point and faces when the
+        // force-carrying legs' contact bytes are unchanged (the pyramids do not move: the old u stays feasible)
+        const bool warm = a.warm_u && !a.cold_in && pre.wc != 0xffffffffu && contact_ranks(pre.wc) == contact_ranks(cbits);
 #pragma unroll
         for (int h = 0; h < VPL; h++) {
             const int v = L.l + 16 * h;
             const bool w = warm && v < NV;
-            R.F.f[h] = w ? wf[h] : fpack(0, 0, SZ_FREE); R.u[h] = w ? wu[h] : 0.0;
+            R.F.f[h] = w ? pre.wf[h] : fpack(0, 0, SZ_FREE); R.u[h] = w ? pre.wu[h] : 0.0;
         }
         R.first = !warm; R.done = false; R.converged = false; R.iters = 0; R.b = b; R.cbits = cbits; R.has = true;
     }
@@ -957,16 +973,8 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
     const size_t B = (size_t)a.B;
     typename Q::Row R;
     R.has = false; R.exhausted = false; R.first = false; R.done = true; R.converged = true; R.b = 0; R.iters = 0; R.cbits = 0;
-#ifdef OSQ_X_STATIC
-    int x_next = blockIdx.x * 4 + (L.lane >> 4);
-    R.nb_next = x_next; x_next += gridDim.x * 4;
-#else
-    {
-        int nx = 0;
-        if (L.l == 0) nx = atomicAdd(counter, 1);
-        R.nb_next = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);
-    }
-#endif
+    R.nx_raw = 0;
+    if (L.l == 0) R.nx_raw = atomicAdd(counter, 1);
 #pragma unroll
     for (int h = 0; h < Q::VPL; h++) { R.F.f[h] = Q::fpack(0, 0, SZ_ZERO); R.u[h] = 0.0; R.stance[h] = false; }
     // a row that has never had a problem rides along in the solve with an all-dead system (identity rows): its LDS block holds zeros
@@ -977,16 +985,10 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
             // (row-uniform) next problem of this leg count; its index was reserved when the previous problem started (the work counter's
             // round trip travels under a whole problem's iterations)
             for (;;) {
-                const int nb = R.nb_next;
+                const int nb = __builtin_amdgcn_update_dpp(0, R.nx_raw, 0x150, 0xf, 0xf, true);      // row_newbcast:0
                 if (nb >= a.n) { R.exhausted = true; break; }
-#ifdef OSQ_X_STATIC
-                R.nb_next = x_next; x_next += gridDim.x * 4;
-#else
-                int nx = 0;
-                if (L.l == 0) nx = atomicAdd(counter, 1);
-                R.nb_next = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);      // row_newbcast:0
-#endif
-                const uint32_t cb = a.contact[nb];
+                const typename Q::Pre pre = Q::request_row(L, a, nb);
+                const uint32_t cb = pre.cb;
                 const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
                 if (NST == 1 && nst == 0) {          // no leg on the ground: all forces zero (force_controller.py:114-123)
                     if (L.l < 12) { if (POST != POST_NONE) store_agent(&a.f_out[(size_t)L.l * B + nb], 0.f); else a.f_out[(size_t)L.l * B + nb] = 0.f; }
@@ -996,9 +998,14 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
                     if (L.l == 0 && a.warm_contact) a.warm_contact[nb] = cb;
                     if constexpr (POST != POST_NONE) mark_done(L.l, post, nb);
                 }
-                if (nst != NST) continue;
+                // (the row's next index: requested BEHIND everything that waits for this problem's reads -- the vector memory counter
+                // is in order, and across the branches hipcc's wait placement falls back to "all of them")
+                const bool mine = nst == NST;
+                if (mine) Q::load_row(L, a, M, R, nb, pre);
+                R.nx_raw = 0;
+                if (L.l == 0) R.nx_raw = atomicAdd(counter, 1);
+                if (!mine) continue;
                 OSQ_STAMP(10)                        // work counter + contact word
-                Q::load_row(L, a, M, R, nb, cb);
                 break;
             }
         }
