@@ -714,18 +714,31 @@ def bench_mpc(a, rk):
         qp_flops = float((fl_iter * last["iters"].double()).sum())
         mk = kernels.get("mpc", {})
         mpc_ms = mk.get("ms_per_launch", 0.0) * mk.get("launches_per_step", 0.0)
+        # (two parts of the batch on two streams: their launches overlap and the sum of their durations exceeds the pass -- the pass's
+        # own time is the denominator then, filter steps included)
+        overlapped = mpc_ms > el / a.steps * 1e3
+        if overlapped:
+            mpc_ms = el / a.steps * 1e3
         ach = qp_flops / (mpc_ms * 1e-3) / 1e12 if mpc_ms else 0.0
-        persistent = mk.get("kernel", "").startswith("kf_mpc_persistent")
+        kname = mk.get("kernel", "")
+        persistent = kname.startswith("kf_mpc_persistent")
+        quad = "quad" in kname
         out["roofline"] = {"kernel": mk.get("kernel", "mpc_solve_kernel") + " (float64 vector pipe: v_fma_f64)", "bound": "mfma", "pipe": "fp64 VECTOR pipe (compute-bound class of the contract's two; nothing here runs on a matrix core)", "achieved": ach,
                            "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TF, "traffic": None,
                            "traffic_source": "not collected for this mode", "algorithmic_flops_per_pass": qp_flops,
                            "flops_per_iteration": "2 n^3 / 3 + 14 n^2 + 260 n, n = 15 x stance legs (30 at trot: 32 kflop)",
                            "device_ms_of_the_phase": mpc_ms,
                            "note": ("one persistent kernel: the phase time includes the float64 filter step of every time step" if persistent else
-                                    "mpc_solve_kernel launches only (the filter steps are the kf phase)"),
-                           "limiter": "latency: one QP per wavefront, a dependent chain of n pivots per elimination whose pivot rows cross lanes by "
-                                      "v_readlane (profiles/r05_pmc_mpc.md: SQ_INSTS_VALU against SQ_WAIT_INST_ANY); 64 lanes execute, n - k do useful "
-                                      "work at pivot k",
+                                    "the whole pass (QP launches of two parts of the batch overlap; the filter step runs inside them)" if overlapped else
+                                    "QP launches, the filter step of every trajectory inside them" if "filter step inside" in kname else
+                                    "QP launches only (the filter steps are the kf phase)"),
+                           "limiter": ("sixteen lanes per QP, four QPs per wavefront, two wavefronts per SIMD at 256 registers: the vector pipe is busy ~50 % of "
+                                       "a launch (profiles/r06_pmc_mpc.md: SQ_ACTIVE_INST_VALU against the launch time), the rest is LDS round trips "
+                                       "between the phases of an active-set iteration and the long tail of the iteration count (mean 4.5, maximum ~45: "
+                                       "the last quarter of a launch runs a few stragglers)" if quad else
+                                       "latency: one QP per wavefront, a dependent chain of n pivots per elimination whose pivot rows cross lanes by "
+                                       "v_readlane (profiles/r05_pmc_mpc.md: SQ_INSTS_VALU against SQ_WAIT_INST_ANY); 64 lanes execute, n - k do useful "
+                                       "work at pivot k"),
                            "hbm_algorithmic_GBps": 268 * B * T / (el / a.steps) / 1e9}
         out.update(qp_iterations_mean=float(it.mean()), qp_iterations_max=int(it.max()),
                    status_nonzero_trajectories=int(eng.failed(last["status"]).sum()),

@@ -956,7 +956,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
     a.warm_u = nullptr; a.warm_state = nullptr; a.warm_contact = nullptr;
     osm::fill_args(ctx, a);
     hipStream_t s = (hipStream_t)stream;
-    const int slot = os_prof_begin(ctx, 4, s, "mpc_solve_kernel<NST>");
+    const int slot = os_prof_begin(ctx, 4, s, osm::quad_path(ctx, B, 7u) ? "mpc_prep_kernel + mpc_solve_quad_kernel<NST>" : "mpc_solve_kernel<NST>");
     if (int rcl = osm::launch_instances(ctx, a, 31u, s)) return rcl;       // all leg counts: a wavefront whose problem has another count exits at once
     os_prof_end(ctx, slot, s);
     OS_HIP(ctx, hipGetLastError());
@@ -1112,7 +1112,9 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
             a.p_rot_out = p_rot_out ? p_rot_out + o12 + b0 : nullptr;
             a.ptrace_out = ptrace_out ? ptrace_out + o1 : nullptr; a.kgain_out = kgain_out ? kgain_out + o1 : nullptr;
             a.status = st_step; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
-            const int slot = os_prof_begin(ctx, 4, st[i], "mpc_solve_kernel<NST>");
+            const int slot = os_prof_begin(ctx, 4, st[i], fuse ? (S > 1 ? "mpc_prep_kernel + mpc_solve_quad_kernel<NST, filter step inside> (a part of the batch, two in flight)"
+                                                                          : "mpc_prep_kernel + mpc_solve_quad_kernel<NST, filter step inside>")
+                                                               : osm::quad_path(ctx, B, flags_h[t]) ? "mpc_prep_kernel + mpc_solve_quad_kernel<NST>" : "mpc_solve_kernel<NST>");
             if (fuse) {
                 osm::PostArgs post;
                 post.kf = a; post.kf.k = ctx->k; post.kf.status = status + b0;

@@ -382,3 +382,44 @@ def test_dropin_estimate_state_mpc_matches_reference_trajectory_g12():
         assert np.abs(kf.f[:, 0] - g["t_f"][0, t]).max() < 5e-3, t
         assert np.abs(p.ravel() - g["t_p_rot"][0, t]).max() < 1e-5          # p is rotated in place, as next_state does
         assert abs(kf.P_trace / g["t_P_trace"][0, t] - 1) < 1e-3
+
+
+@pytest.mark.parametrize("B,T,shards,mix", [(4096, 8, "1", True), (4096, 6, "1", False), (32768, 5, "2", False), (49168, 4, "3", True)])
+def test_filter_step_inside_the_qp_launch_equals_the_separate_launches(monkeypatch, B, T, shards, mix):
+    """Round 6: at large batch the filter step of a trajectory runs inside the QP launch that solved its forces (mpc_quad.hip drain
+    phase; the forces cross CUs through agent-scope stores and a per-trajectory mark), and a batch of two 16,384s or more runs as
+    two (OS_MPC_SHARDS) concurrent parts.  Same building blocks in the same order as kf_dense_rows_kernel: x_out, f, P, status and the
+    iteration counts are IDENTICAL to the separate launches (OS_MPC_FUSE_KF=0).  mix: trajectories with zero and one leg on the
+    ground (the one-leg instance marks, the two-leg instance steps all of them) and, in one step, with three (that step falls back
+    to the separate launches, which also keeps the batch in one part)."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("OS_MPC_PERSISTENT", "0")
+    monkeypatch.setenv("OS_MPC_SHARDS", shards)
+    d = synth_torch(B, T, dev, seed=77)
+    c4 = d["contact"].clone()                               # [T][4][B] uint8
+    if mix:
+        c4[:, :, 5::7] = 0; c4[:, 1, 5::7] = 1             # one leg
+        c4[2:, :, 3::11] = 0                                # none from step 2 on
+        if shards == "1":
+            c4[3, :, 8::13] = 1; c4[3, 0, 8::13] = 0        # three legs in step 3
+    ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("OS_MPC_FUSE_KF", fuse)
+        e = Engine(0); e.set_noise(Q_DEFAULT, R_DEFAULT)
+        contact = e.contact_soa_to_packed(c4)
+        x, P = d["x0"].clone(), d["P0"].clone()
+        r = e.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True, want_p_rot=True)
+        e.profile(True)
+        e.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, d["x0"].clone(), d["P0"].clone())
+        out[fuse] = (r, x, P, e.profile_read())
+    r0, x0, P0, p0 = out["0"]; r1, x1, P1, p1 = out["1"]
+    for k in ("x_out", "f", "iters", "status", "p_rot"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert torch.equal(x0, x1) and torch.equal(P0, P1)
+    assert int(r1["status"].abs().max()) == 0 and int(r1["iters"].max()) > 3
+    # the separate form launches the filter kernel every step, the fused form only in the step with a three-leg trajectory
+    assert p0["kf"][1] == T and p1.get("kf", (0.0, 0))[1] == (1 if (mix and shards == "1") else 0)
+    assert p1["mpc"][1] == T * (int(shards) if not (mix and shards == "1") else 1)
