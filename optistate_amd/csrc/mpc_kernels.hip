@@ -857,7 +857,7 @@ static std::atomic<uint32_t> g_post_seq{0};
 // a contiguous part of the batch solved by one launch sequence: the caller's pointers are offset to trajectory b0, n trajectories behind
 // them, the row stride stays the batch's B (os_kf_mpc_run: two halves on two streams, one in the drain of its QP launch -- a few
 // stragglers, most of the chip idle -- while the other is in the bulk of its own)
-struct Shard { int index, b0, n; };
+struct Shard { int index, b0, n; int32_t *counters; };      // counters: 32 zeroed ints of this launch (null: the scratch's, zeroed here)
 
 // nst_mask: bit n set = launch the instance for n legs on the ground (bit 0 rides on the 1-leg instance).  Batches of at least
 // ctx->tune_mpc_quad problems: those with one / two force-carrying legs (15 / 30 variables) run sixteen lanes each, four to a
@@ -867,7 +867,7 @@ static bool quad_path(const os_ctx *ctx, int n, uint32_t nst_mask) { return ctx-
 static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask, hipStream_t s, PostArgs *post = nullptr, const Shard *shard = nullptr)
 {
     MpcArgs a = a_in;
-    const Shard sh = shard ? *shard : Shard{0, 0, a.B};
+    const Shard sh = shard ? *shard : Shard{0, 0, a.B, nullptr};
     a.n = sh.n;
     a.cap = 0; a.cold_in = 0; a.todo = nullptr; a.todo_count = nullptr; a.rec = nullptr;
     const dim3 grid(a.n), block(64);
@@ -878,7 +878,7 @@ static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask,
         const size_t Bz = (size_t)a.B, b0 = (size_t)sh.b0;
         const HandLayout hl(Bz);
         if (os_ensure_scratch(ctx, &ctx->mpc_hand, &ctx->mpc_hand_floats, hl.need)) return -10;
-        int32_t *counters = (int32_t *)(ctx->mpc_hand + hl.counters) + 32 * sh.index;
+        int32_t *counters = sh.counters ? sh.counters : (int32_t *)(ctx->mpc_hand + hl.counters) + 32 * sh.index;
         a.todo = (int32_t *)(ctx->mpc_hand + hl.todo);
         a.todo_count = counters + 16;
         a.rec = (double *)(ctx->mpc_hand + hl.rec) + b0 * 224;
@@ -894,7 +894,7 @@ static int launch_instances(os_ctx *ctx, const MpcArgs &a_in, uint32_t nst_mask,
             if (q == 0) q = ++g_post_seq;
             post->seq = q;
         }
-        if (hipMemsetAsync(counters, 0, 128, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
+        if (!sh.counters && hipMemsetAsync(counters, 0, 128, s) != hipSuccess) return os_fail(ctx, -10, "os_mpc_solve: hipMemsetAsync failed");
         os_mpc_launch_quad(a, nst_mask & 7u, counters, ctx->cu_count, s, post);
         if (a.cap > 0) {
             if (nst_mask & 3u) hipLaunchKernelGGL(mpc_solve_kernel<1>, grid, block, 0, s, a, 1);
@@ -1025,7 +1025,9 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
     }
     // scratch: warm-start store (u [B][64] doubles, faces [B][64] bytes, contact [B]) + per-step Kalman status [B] +
     // leg-count presence flags [T]
-    const size_t need = (size_t)B * 128 + (size_t)B * 16 + (size_t)B + (size_t)B + (size_t)T;
+    // + the work / ticket counters of every (step, part) launch, zeroed once per call (a fill launch per step otherwise)
+    const size_t cnt_at = (size_t)B * 146 + (size_t)T, cnt_floats = (size_t)T * osm::MAX_SHARDS * 32;
+    const size_t need = cnt_at + cnt_floats;
     if (os_ensure_scratch(ctx, &ctx->mpc_scratch, &ctx->mpc_scratch_floats, need)) return -10;
     double *warm_u = (double *)ctx->mpc_scratch;                       // hipMalloc alignment covers the doubles
     uint8_t *warm_state = (uint8_t *)(ctx->mpc_scratch + (size_t)B * 128);
@@ -1037,7 +1039,8 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
     OS_HIP(ctx, hipMemsetAsync(warm_state, 0x05, (size_t)B * 64, s));
     OS_HIP(ctx, hipMemsetAsync(warm_contact, 0xff, (size_t)B * sizeof(uint32_t), s));
     OS_HIP(ctx, hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
-    OS_HIP(ctx, hipMemsetAsync(flags_d, 0, (size_t)T * sizeof(uint32_t), s));
+    OS_HIP(ctx, hipMemsetAsync(flags_d, 0, ((size_t)T + cnt_floats) * sizeof(uint32_t), s));      // (the counters lie behind the flags)
+    int32_t *step_counters = (int32_t *)(ctx->mpc_scratch + cnt_at);
     {
         const int gx = (B + 255) / 256 < 64 ? (B + 255) / 256 : 64;
         hipLaunchKernelGGL(osm::nst_presence_kernel, dim3(gx, T), dim3(256), 0, s, B, T, contact, flags_d);
@@ -1078,11 +1081,11 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
     hipEvent_t ev_fork = nullptr, ev_join[osm::MAX_SHARDS] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0, b0 = 0; i < S; i++) {
         const int b1 = i + 1 == S ? B : (int)(((int64_t)B * (i + 1) / S) / 16 * 16);
-        shard[i] = osm::Shard{i, b0, b1 - b0};
+        shard[i] = osm::Shard{i, b0, b1 - b0, nullptr};
         b0 = b1;
         if (i > 0 && !(st[i] = osm::shard_stream(ctx->device, i))) S = 1;
     }
-    if (S == 1) shard[0] = osm::Shard{0, 0, B};
+    if (S == 1) shard[0] = osm::Shard{0, 0, B, nullptr};
     if (S > 1) {
         bool ok = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev_fork, s) == hipSuccess;
         for (int i = 1; i < S && ok; i++)
@@ -1119,6 +1122,7 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
                 osm::PostArgs post;
                 post.kf = a; post.kf.k = ctx->k; post.kf.status = status + b0;
                 post.qr = (const float *)ctx->kf_qr; post.done = nullptr; post.seq = 0;
+                shard[i].counters = step_counters + ((size_t)t * osm::MAX_SHARDS + i) * 32;
                 if (int rcl = osm::launch_instances(ctx, m, flags_h[t], st[i], &post, &shard[i])) { free(flags_h); return rcl; }
                 os_prof_end(ctx, slot, st[i]);
                 continue;
