@@ -6,11 +6,24 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 #include "kf_args.hpp"
 
 namespace osm {
 
 constexpr int NVMAX = 60, NLSMAX = 20;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- where a loop body needs its index as an immediate (a DPP lane
+// select) or the unroller must not be allowed to give up
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 enum : int { SZ_FREE = 0, SZ_ZERO = 1, SZ_MAX = 2 };
 
 struct MpcParams {

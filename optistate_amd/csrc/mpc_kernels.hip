@@ -37,6 +37,25 @@
 
 namespace osm {
 
+// Development build only (-DOSM_TS): shader-clock stamps between the phases of an active-set iteration of the wavefront-per-QP solver and
+// around the persistent kernel's two halves, summed by lane 0 of workgroup 0 (printed at the end of kf_mpc_persistent_kernel)
+#ifdef OSM_TS
+__shared__ unsigned long long osm_ts_sum[16];
+__shared__ unsigned long long osm_ts_prev;
+#define OSM_STAMP(i)                                                                       \
+    {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                         \
+            const unsigned long long now = __builtin_readcyclecounter();                   \
+            if ((i) > 0) osm_ts_sum[i] += now - osm_ts_prev;                               \
+            osm_ts_prev = now;                                                             \
+        }                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+#else
+#define OSM_STAMP(i)
+#endif
+
 template <int NV_>
 struct WaveMemT {
     static constexpr int LW = NV_ <= 32 ? 32 : 64;   // lanes that own a row
@@ -88,12 +107,53 @@ __device__ __forceinline__ void form_row_block(const LaneCtx &L, const MpcParams
     }
 }
 
+// The whole row at once, straight into registers (UNR = 0; round 6): column w + 1's generator is requested before column w's products are
+// formed, the (al, be) pairs of the lane's step and C_theta g once per row.  In-kernel stamps at the reference's shape (B = 8, 3.1
+// iterations per step): the staged form above cost 7.6 k cycles per iteration -- more than the elimination (4.4 k).  Same expressions,
+// same order: the same bits.  Needs ~70 registers beside the row: the one-wave-per-SIMD persistent kernel's solver call uses it.
+template <int NST, typename WaveMem>
+__device__ __forceinline__ void form_rows_direct(const LaneCtx &L, const MpcParams &P, const double *g, WaveMem &M, double *A)
+{
+    constexpr int NV = 15 * NST, NPS = 3 * NST;
+    int li = L.i;
+    asm volatile("" : "+v"(li));
+    double ab[5][2];
+#pragma unroll
+    for (int l = 0; l < 5; l++) { ab[l][0] = M.ab[5 * li + l][0]; ab[l][1] = M.ab[5 * li + l][1]; }
+    double Cg[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) Cg[r] = L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2];
+    double zA[3], zB[3], gn[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) gn[r] = M.gent[0][r];
+    static_for<0, NV>([&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        if constexpr (w % NPS == 0) {
+            const double al = ab[w / NPS][0], be = ab[w / NPS][1];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                zA[r] = al * P.w[6 + r] * g[r] + be * Cg[r];
+                zB[r] = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+            }
+        }
+        double gw[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) gw[r] = gn[r];
+        if constexpr (w + 1 < NV) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) gn[r] = M.gent[w + 1][r];
+        }
+        A[w] = zA[0] * gw[0] + zA[1] * gw[1] + zA[2] * gw[2] + zB[0] * gw[3] + zB[1] * gw[4] + zB[2] * gw[5];
+        if constexpr (w % NPS == NPS - 1) __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // sum_w form(g, G[w]) * vec[w].  form() depends on the column w only through its generator and, via (al, be), its horizon
 // step, so the sum over the NPS columns of a step factors: sum_w (zA . a_w + zB . b_w) vec[w] = zA . A_l + zB . B_l with the
 // per-step sums (A_l | B_l) = sum_{w in step l} G[w] vec[w].  Thirty lanes form the 5 x 6 sums (NPS loads in flight each),
 // then every lane needs five steps x six products instead of 15 NST columns x seven behind a rolled, LDS-latency-bound
 // loop (~10 k -> ~2 k cycles per multiplier check; the rounding differs from the column-by-column sum at the 1e-16 level).
-template <int NPS, typename WaveMem>
+template <int NPS, bool FLAT = false, typename WaveMem>
 __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P, const double *g, const double (*G)[6], const double *vec,
                                            WaveMem &M)
 {
@@ -101,9 +161,12 @@ __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P,
     __builtin_amdgcn_wave_barrier();
     if (L.lane < 30) {
         const int l = L.lane / 6, r = L.lane % 6;
+        double gv[NPS], vv[NPS];
+#pragma unroll
+        for (int j = 0; j < NPS; j++) { gv[j] = G[NPS * l + j][r]; vv[j] = vec[NPS * l + j]; }
         double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < NPS; j++) sum = fma(G[NPS * l + j][r], vec[NPS * l + j], sum);
+        for (int j = 0; j < NPS; j++) sum = fma(gv[j], vv[j], sum);
         S[L.lane] = sum;
     }
     __builtin_amdgcn_wave_barrier();
@@ -111,15 +174,36 @@ __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P,
     int li = L.i;
     asm volatile("" : "+v"(li));
     double acc = 0.0;
-#pragma clang loop unroll(disable)              // unrolled, the thirty sums are all read up front: spills in the 168-register instances
-    for (int l = 0; l < 5; l++) {
-        const double al = M.ab[5 * li + l][0], be = M.ab[5 * li + l][1];
+    if constexpr (FLAT) {
+        // (all thirty sums and the five (al, be) pairs in one batch of reads: the rolled loop below is five dependent round trips)
+        double Sv[30], ab[5][2], Cg[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const double zA = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
-            const double zB = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
-            acc = fma(zA, S[6 * l + r], acc);
-            acc = fma(zB, S[6 * l + 3 + r], acc);
+        for (int e = 0; e < 30; e++) Sv[e] = S[e];
+#pragma unroll
+        for (int l = 0; l < 5; l++) { ab[l][0] = M.ab[5 * li + l][0]; ab[l][1] = M.ab[5 * li + l][1]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) Cg[r] = L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2];
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double zA = ab[l][0] * P.w[6 + r] * g[r] + ab[l][1] * Cg[r];
+                const double zB = (ab[l][0] * P.w[9 + r] + ab[l][1] * P.w[3 + r]) * g[3 + r];
+                acc = fma(zA, Sv[6 * l + r], acc);
+                acc = fma(zB, Sv[6 * l + 3 + r], acc);
+            }
+        }
+    } else {
+#pragma clang loop unroll(disable)              // unrolled, the thirty sums are all read up front: spills in the 168-register instances
+        for (int l = 0; l < 5; l++) {
+            const double al = M.ab[5 * li + l][0], be = M.ab[5 * li + l][1];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double zA = al * P.w[6 + r] * g[r] + be * (L.Cth[3 * r] * g[0] + L.Cth[3 * r + 1] * g[1] + L.Cth[3 * r + 2] * g[2]);
+                const double zB = (al * P.w[9 + r] + be * P.w[3 + r]) * g[3 + r];
+                acc = fma(zA, S[6 * l + r], acc);
+                acc = fma(zB, S[6 * l + 3 + r], acc);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -127,12 +211,13 @@ __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P,
 }
 
 // Minimiser of the QP restricted to the face (sx, sy, sz of this lane's leg-step); returns this lane's component.
-template <int NST, int UNR, typename WaveMem>
+template <int NST, int UNR, bool RAW = false, typename WaveMem>
 __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &P, WaveMem &M, int sx, int sy, int sz,
                                              const double *cw, const double *cv /* this lane's step */)
 {
     constexpr int NV = 15 * NST, NPS = 3 * NST;
     const int b0 = 3 * L.ls;
+    OSM_STAMP(0)
     // ---- face generators ----
     bool live;
     double g[6], tt = 1.0;
@@ -163,19 +248,24 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     }
     __builtin_amdgcn_wave_barrier();
 
+    OSM_STAMP(1)                                     // faces
     // ---- row of the reduced system ----
     double rhs = -(g[0] * cw[0] + g[1] * cw[1] + g[2] * cw[2] + g[3] * cv[0] + g[4] * cv[1] + g[5] * cv[2]);
     if (any_u0) rhs -= form_dot<NPS>(L, P, g, M.gen0, M.vec, M);
     double A[NV + 1];
+    if constexpr (UNR == 0) form_rows_direct<NST>(L, P, g, M, A);
+    else {
 #pragma unroll
-    for (int l = 0; l < 5; l++) {
-        form_row_block<NPS, UNR>(L, P, g, l, M);
+        for (int l = 0; l < 5; l++) {
+            form_row_block<NPS, UNR>(L, P, g, l, M);
 #pragma unroll
-        for (int j = 0; j < NPS; j++) A[NPS * l + j] = M.rows[j][L.lane & (WaveMem::LW - 1)];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NPS; j++) A[NPS * l + j] = M.rows[j][L.lane & (WaveMem::LW - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     A[NV] = live ? rhs : 0.0;
     const unsigned long long live_mask = __ballot(live);
+    OSM_STAMP(2)                                     // rows
 
     // ---- forward elimination, one row per lane; the pivot row is broadcast straight from lane k's registers (k is a
     // compile-time lane index here: two v_readlane_b32 per entry into an SGPR pair that the FMA reads) -- no LDS round
@@ -195,6 +285,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    OSM_STAMP(3)                                     // elimination
     // ---- back substitution ----
     double r = A[NV], sol = 0.0;
 #pragma unroll
@@ -205,6 +296,8 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
         if (L.lane < k) r = fma(-A[k], wk, r);
         __builtin_amdgcn_sched_barrier(0);
     }
+    OSM_STAMP(4)                                     // back substitution
+    if constexpr (RAW) return L.pad ? 0.0 : sol;     // (face coordinates: the caller maps them to forces in its own exchange)
     // ---- face coordinates -> forces ----
     __builtin_amdgcn_wave_barrier();
     if (!L.pad) M.vec[L.v] = sol;
@@ -216,6 +309,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
         const int s = L.c == 0 ? sx : sy;
         u = s != 0 ? (double)s * P.mu * fz : (sz == SZ_ZERO ? 0.0 : sol);
     }
+    OSM_STAMP(5)                                     // forces
     return L.pad ? 0.0 : u;
 }
 
@@ -357,63 +451,72 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         first = false;
     }
     constexpr double EPS = 1e-11, TOL = 1e-12;
+    OSM_STAMP(7)                                     // set-up
+    // One active-set iteration = solve + ONE exchange of the leg-step's solution and point to its three lanes + the row's minimum ratio
+    // (+ four exchanges when the subspace minimiser is reached); every leg-step quantity is computed by all three of its lanes without
+    // branches -- mpc_quad.hip's iterate_row on one lane per variable (round 6: the round-5 form handed every stage's result on
+    // through LDS, with six candidate ratios behind six branches: 4.4 k cycles of an iteration at the reference's shape).
     while (!done && iters < max_iter) {
         iters++;
-        const double us = solve_face<NST, UNR>(L, P, M, sx, sy, sz, cw, cv);
+        const double sol = solve_face<NST, UNR, true>(L, P, M, sx, sy, sz, cw, cv);
 #ifdef OS_MPC_DBG
-        if (L.lane == 0) {
-            printf("wave it %d sol:", iters);
-            for (int q = 0; q < NV; q++) printf(" %.4e", M.vec[q]);
-            printf("\n");
-        }
+        if (L.lane == 0) printf("wave it %d\n", iters);
 #endif
+        __builtin_amdgcn_wave_barrier();
+        if (!L.pad) { M.vec[L.v] = sol; M.rowbuf[L.v] = u; }
+        __builtin_amdgcn_wave_barrier();
+        double s3[3], u3[3], c3[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { s3[q] = M.vec[3 * L.ls + q]; u3[q] = M.rowbuf[3 * L.ls + q]; }
+        {
+            // face coordinates -> forces: the candidate point of the face
+            const double fz = sz == SZ_MAX ? P.fzmax : (sz == SZ_ZERO ? 0.0 : s3[2]);
+            c3[0] = sx != 0 ? (double)sx * P.mu * fz : (sz == SZ_ZERO ? 0.0 : s3[0]);
+            c3[1] = sy != 0 ? (double)sy * P.mu * fz : (sz == SZ_ZERO ? 0.0 : s3[1]);
+            c3[2] = fz;
+        }
         if (first) {
             // clamp the stance-free minimiser into the pyramids; the faces come from the clamps.  Nothing clamped: optimal.
             first = false;
-            u = us;
-            __builtin_amdgcn_wave_barrier();
-            if (!L.pad) M.vec[L.v] = u;
-            __builtin_amdgcn_wave_barrier();
-            bool clamped = false;
-            if (stance && !L.pad) {
-                double fx = M.vec[3 * L.ls], fy = M.vec[3 * L.ls + 1], fz = M.vec[3 * L.ls + 2];
-                if (fz <= 0.0) { sx = 0; sy = 0; sz = SZ_ZERO; fx = fy = fz = 0.0; clamped = true; }
-                else {
-                    if (fz >= P.fzmax) { sz = SZ_MAX; fz = P.fzmax; clamped = true; }
-                    const double lim = P.mu * fz;
-                    if (fx >= lim) { sx = 1; fx = lim; clamped = true; } else if (fx <= -lim) { sx = -1; fx = -lim; clamped = true; }
-                    if (fy >= lim) { sy = 1; fy = lim; clamped = true; } else if (fy <= -lim) { sy = -1; fy = -lim; clamped = true; }
-                }
-                u = L.c == 0 ? fx : (L.c == 1 ? fy : fz);
+            double fx = c3[0], fy = c3[1], fz = c3[2];
+            int nx = 0, ny = 0, nz = SZ_FREE;
+            bool cl = false;
+            if (fz <= 0.0) { nz = SZ_ZERO; fx = fy = fz = 0.0; cl = true; }
+            else {
+                if (fz >= P.fzmax) { nz = SZ_MAX; fz = P.fzmax; cl = true; }
+                const double lim = P.mu * fz;
+                if (fx >= lim) { nx = 1; fx = lim; cl = true; } else if (fx <= -lim) { nx = -1; fx = -lim; cl = true; }
+                if (fy >= lim) { ny = 1; fy = lim; cl = true; } else if (fy <= -lim) { ny = -1; fy = -lim; cl = true; }
             }
-            if (__ballot(clamped) == 0ull) { done = true; converged = true; }
+            const bool act = stance && !L.pad;
+            sx = act ? nx : sx; sy = act ? ny : sy; sz = act ? nz : sz;
+            const double own = L.pad ? 0.0 : (L.c == 0 ? c3[0] : (L.c == 1 ? c3[1] : c3[2]));
+            u = act ? (L.c == 0 ? fx : (L.c == 1 ? fy : fz)) : own;
+            if (__ballot(act && cl) == 0ull) { done = true; converged = true; }
+            OSM_STAMP(6)
             continue;
         }
-        const double d = us - u;
-        __builtin_amdgcn_wave_barrier();
-        if (!L.pad) { M.vec[L.v] = u; M.rowbuf[L.v] = d; }
-        __builtin_amdgcn_wave_barrier();
-        // ratio test of this lane's leg-step (computed by its fz lane)
-        if (L.c == 2 && !L.pad) {
+        // ---- ratio test of the lane's leg-step (all six candidates, no branches) ----
+        double d3[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) d3[q] = c3[q] - u3[q];
+        {
+            const double fx = u3[0], fy = u3[1], fz = u3[2], dx = d3[0], dy = d3[1], dz = d3[2];
+            const bool on = stance && sz != SZ_ZERO;
+            const double num[6] = {fz, P.fzmax - fz, P.mu * fz - fx, P.mu * fz + fx, P.mu * fz - fy, P.mu * fz + fy};
+            const double den[6] = {-dz, dz, dx - P.mu * dz, -dx - P.mu * dz, dy - P.mu * dz, -dy - P.mu * dz};
+            const bool ok[6] = {on && sz == SZ_FREE, on && sz == SZ_FREE, on && sx == 0, on && sx == 0, on && sy == 0, on && sy == 0};
             double best = 2.0; int code = 0;
-            if (stance && sz != SZ_ZERO) {
-                const double fx = M.vec[3 * L.ls], fy = M.vec[3 * L.ls + 1], fz = M.vec[3 * L.ls + 2];
-                const double dx = M.rowbuf[3 * L.ls], dy = M.rowbuf[3 * L.ls + 1], dz = M.rowbuf[3 * L.ls + 2];
-                auto cand = [&](double num, double den, int cd) {
-                    if (den > EPS) {
-                        const double al = fmax(0.0, num * rcp64(den));
-                        if (al < best) { best = al; code = cd; }
-                    }
-                };
-                if (sz == SZ_FREE) { cand(fz, -dz, 1); cand(P.fzmax - fz, dz, 2); }
-                if (sx == 0) { cand(P.mu * fz - fx, dx - P.mu * dz, 3); cand(P.mu * fz + fx, -dx - P.mu * dz, 4); }
-                if (sy == 0) { cand(P.mu * fz - fy, dy - P.mu * dz, 5); cand(P.mu * fz + fy, -dy - P.mu * dz, 6); }
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const bool v = ok[q] && den[q] > EPS;
+                const double al = fmax(0.0, num[q] * rcp64(v ? den[q] : 1.0));
+                const bool take = v && al < best;
+                best = take ? al : best; code = take ? q + 1 : code;
             }
-            M.al[L.ls] = best; M.code[L.ls] = code;
+            if (L.c == 2 && !L.pad) { M.al[L.ls] = best; M.code[L.ls] = code; }
         }
         __builtin_amdgcn_wave_barrier();
-        // all NLS (step length, code) pairs are requested from LDS at once, then scanned (a rolled read - compare loop was NLS
-        // dependent LDS round trips)
         double amin = 1.0; int lsmin = -1, cmin = 0;
         {
             double alq[NLS]; int cdq[NLS];
@@ -423,38 +526,31 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
             for (int q = 0; q < NLS; q++)
                 if (alq[q] < amin) { amin = alq[q]; lsmin = q; cmin = cdq[q]; }
         }
-        u += amin * d;
-        if (lsmin >= 0) {
-            if (L.ls == lsmin && !L.pad) {
-                if (cmin == 1) { sx = 0; sy = 0; sz = SZ_ZERO; }
-                else if (cmin == 2) sz = SZ_MAX;
-                else if (cmin == 3) sx = 1;
-                else if (cmin == 4) sx = -1;
-                else if (cmin == 5) sy = 1;
-                else if (cmin == 6) sy = -1;
-            }
-        }
-        // snap onto the face equalities
-        __builtin_amdgcn_wave_barrier();
-        if (!L.pad) M.vec[L.v] = u;
-        __builtin_amdgcn_wave_barrier();
-        if (!L.pad && stance) {
-            double fz = M.vec[3 * L.ls + 2];
-            if (sz == SZ_ZERO) fz = 0.0;
-            if (sz == SZ_MAX) fz = P.fzmax;
-            if (L.c == 2) u = fz;
-            else {
-                const int s = L.c == 0 ? sx : sy;
-                if (sz == SZ_ZERO) u = 0.0;
-                else if (s != 0) u = (double)s * P.mu * fz;
-            }
+        // the step, the blocking face and the snap onto the face equalities: all three components on every lane of the leg-step
+        {
+#pragma unroll
+            for (int q = 0; q < 3; q++) u3[q] += amin * d3[q];
+            int nx = sx, ny = sy, nz = sz;
+            if (cmin == 1) { nx = 0; ny = 0; nz = SZ_ZERO; }
+            else if (cmin == 2) nz = SZ_MAX;
+            else if (cmin == 3) nx = 1;
+            else if (cmin == 4) nx = -1;
+            else if (cmin == 5) ny = 1;
+            else if (cmin == 6) ny = -1;
+            const bool hit = lsmin >= 0 && L.ls == lsmin && !L.pad;
+            sx = hit ? nx : sx; sy = hit ? ny : sy; sz = hit ? nz : sz;
+            const double fz = sz == SZ_ZERO ? 0.0 : (sz == SZ_MAX ? P.fzmax : u3[2]);
+            const double own = L.c == 0 ? u3[0] : (L.c == 1 ? u3[1] : u3[2]);
+            const int sgn = L.c == 0 ? sx : sy;
+            const double un = L.c == 2 ? fz : (sz == SZ_ZERO ? 0.0 : (sgn != 0 ? (double)sgn * P.mu * fz : own));
+            u = L.pad ? u : (stance ? un : own);
         }
 #ifdef OS_MPC_DBG
         if (L.lane == 0) printf("wave it %d ratio: amin %.6e lsmin %d cmin %d\n", iters, amin, lsmin, cmin);
 #endif
-        if (lsmin >= 0) continue;
+        if (lsmin >= 0) { OSM_STAMP(6) continue; }
 
-        // subspace minimiser reached: multiplier signs
+        // ---- subspace minimiser reached: multiplier signs ----
         __builtin_amdgcn_wave_barrier();
         if (!L.pad) M.vec[L.v] = u;
         __builtin_amdgcn_wave_barrier();
@@ -462,31 +558,25 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
 #pragma unroll
         for (int r = 0; r < 6; r++) g0[r] = M.gen0[L.v][r];
         const double q0 = g0[0] * cw[0] + g0[1] * cw[1] + g0[2] * cw[2] + g0[3] * cv[0] + g0[4] * cv[1] + g0[5] * cv[2];
-        const double grad = 2.0 * (form_dot<NPS>(L, P, g0, M.gen0, M.vec, M) + P.rw * u + q0);
+        const double grad = 2.0 * (form_dot<NPS, UNR == 0>(L, P, g0, M.gen0, M.vec, M) + P.rw * u + q0);
         __builtin_amdgcn_wave_barrier();
         if (!L.pad) M.rowbuf[L.v] = grad;
         __builtin_amdgcn_wave_barrier();
-        if (L.c == 2 && !L.pad) {
+        {
+            const double gx = M.rowbuf[3 * L.ls], gy = M.rowbuf[3 * L.ls + 1], gz = M.rowbuf[3 * L.ls + 2];
             double best = TOL; int code = 0;
-            if (stance) {
-                const double gx = M.rowbuf[3 * L.ls], gy = M.rowbuf[3 * L.ls + 1], gz = M.rowbuf[3 * L.ls + 2];
-                if (sz == SZ_ZERO) {
-                    // apex: optimal iff the gradient lies in the dual cone; otherwise release along the steepest edge ray
-                    const double vx = P.mu * fabs(gx), vy = P.mu * fabs(gy);
-                    const double val = gz - vx - vy;
-                    if (-val > best) { best = -val; code = 16 + (gx > 0.0 ? 0 : 1) + (gy > 0.0 ? 0 : 2); }
-                } else {
-                    if (sx == 1 && gx > best) { best = gx; code = 1; }
-                    if (sx == -1 && -gx > best) { best = -gx; code = 1; }
-                    if (sy == 1 && gy > best) { best = gy; code = 2; }
-                    if (sy == -1 && -gy > best) { best = -gy; code = 2; }
-                    if (sz == SZ_MAX) {
-                        const double lamU = -gz - sx * P.mu * gx - sy * P.mu * gy;
-                        if (-lamU > best) { best = -lamU; code = 3; }
-                    }
-                }
-            }
-            M.al[L.ls] = best; M.code[L.ls] = code;
+            // apex: optimal iff the gradient lies in the dual cone; otherwise release along the steepest edge ray
+            const double val = gz - P.mu * fabs(gx) - P.mu * fabs(gy);
+            const bool apex = sz == SZ_ZERO;
+            if (apex && -val > best) { best = -val; code = 16 + (gx > 0.0 ? 0 : 1) + (gy > 0.0 ? 0 : 2); }
+            if (!apex && sx == 1 && gx > best) { best = gx; code = 1; }
+            if (!apex && sx == -1 && -gx > best) { best = -gx; code = 1; }
+            if (!apex && sy == 1 && gy > best) { best = gy; code = 2; }
+            if (!apex && sy == -1 && -gy > best) { best = -gy; code = 2; }
+            const double lamU = -gz - sx * P.mu * gx - sy * P.mu * gy;
+            if (!apex && sz == SZ_MAX && -lamU > best) { best = -lamU; code = 3; }
+            if (!stance) { best = TOL; code = 0; }
+            if (L.c == 2 && !L.pad) { M.al[L.ls] = best; M.code[L.ls] = code; }
         }
         __builtin_amdgcn_wave_barrier();
         double rmax = TOL; int lsr = -1, cr = 0;
@@ -499,23 +589,17 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
                 if (cdq[q] != 0 && alq[q] > rmax) { rmax = alq[q]; lsr = q; cr = cdq[q]; }
         }
 #ifdef OS_MPC_DBG
-        if (L.lane == 0) {
-            printf("wave it %d mult: rmax %.6e lsr %d cr %d | al:", iters, rmax, lsr, cr);
-            for (int q = 0; q < NLS; q++) printf(" %.3e/%d", M.al[q], M.code[q]);
-            printf(" | grad:");
-            for (int q = 0; q < NV; q++) printf(" %.3e", M.rowbuf[q]);
-            printf("\n");
-        }
+        if (L.lane == 0) printf("wave it %d mult: rmax %.6e lsr %d cr %d\n", iters, rmax, lsr, cr);
 #endif
-        if (lsr < 0) { done = true; converged = true; break; }
+        if (lsr < 0) { done = true; converged = true; OSM_STAMP(6) break; }
         if (L.ls == lsr && !L.pad) {
             if (cr == 1) sx = 0;
             else if (cr == 2) sy = 0;
             else if (cr == 3) sz = SZ_FREE;
             else { sx = (cr & 1) ? 1 : -1; sy = (cr & 2) ? 1 : -1; sz = SZ_FREE; }
         }
+        OSM_STAMP(6)                                 // ratio test / multipliers
     }
-
 
     // ---- outputs in the reference's variable order (12 per horizon step, leg-major); swing legs are zero ----
     __builtin_amdgcn_wave_barrier();
@@ -569,7 +653,7 @@ static __device__ __attribute__((noinline)) QpRet mpc_solve_wave_call(QpCallLds 
     QpLane io = {u_in, face_in};
     QpRet r;
     bool conv;
-    mpc_solve_wave<NST>(P, cbits, legs, x, ref, p, max_iter, warm, M, io, r.val, r.iters, conv);
+    mpc_solve_wave<NST, 0>(P, cbits, legs, x, ref, p, max_iter, warm, M, io, r.val, r.iters, conv);
     r.u = io.u; r.face = io.face; r.conv = conv ? 1 : 0;
     return r;
 }
@@ -722,7 +806,11 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
         for (int i = 0; i < 12; i++) bref_n[i] = buf_load_nt(rb, voff, i * rowB);
     };
     fetch(0);
+#ifdef OSM_TS
+    if (threadIdx.x < 16) osm_ts_sum[threadIdx.x] = 0;
+#endif
     for (int t = 0; t < a.kf.T; t++) {
+        OSM_STAMP(9)                                 // filter + stores of the previous step
         StepIn in = in_n;
         float bref[12];
 #pragma unroll
@@ -771,7 +859,11 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
             }
             if (!conv) status |= 4;
         }
+        OSM_STAMP(8)                                 // outputs of the QP (behind its last iteration)
         prev_c = cbits;
+#ifdef OSM_TS
+        if (blockIdx.x == 0 && threadIdx.x == 0) { osm_ts_sum[10] += iters; osm_ts_sum[11] += 1; }
+#endif
         if (lane < 12) a.f_out[((size_t)t * 12 + lane) * B + b] = fval;
         if (a.iters && lane == 0) a.iters[(size_t)t * B + b] = iters;
 #pragma unroll
@@ -801,6 +893,14 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
         }
         if (a.kf.kgain_out && lane == 0) a.kf.kgain_out[(size_t)t * B + b] = kg;
     }
+#ifdef OSM_TS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long n = osm_ts_sum[11] ? osm_ts_sum[11] : 1;
+        printf("persistent kernel, cycles per step (%llu steps, %.2f iterations per step): faces %llu | rows %llu | elimination %llu | back-substitution %llu | forces %llu | "
+               "ratio/multipliers %llu | QP set-up %llu | QP outputs %llu | filter step %llu\n", n, (double)osm_ts_sum[10] / (double)n, osm_ts_sum[1] / n, osm_ts_sum[2] / n,
+               osm_ts_sum[3] / n, osm_ts_sum[4] / n, osm_ts_sum[5] / n, osm_ts_sum[6] / n, osm_ts_sum[7] / n, osm_ts_sum[8] / n, osm_ts_sum[9] / n);
+    }
+#endif
     // the status word is OR-reduced over the wavefront (bit 1 is per state component)
     for (int m = 1; m < 64; m <<= 1) status |= __shfl_xor(status, m, 64);
     if (lane < 12) {

@@ -43,6 +43,7 @@ __shared__ unsigned long long osq_ts_prev;
 #endif
 
 using namespace osm;
+using osm::static_for;
 using osk::rows64::bc64;
 
 // The per-problem RECORD (round 6): everything of a problem that does not change over its active-set iterations -- generators of the
@@ -91,16 +92,6 @@ __device__ __forceinline__ void fmac_other(double &acc, double src, double m)
 {
     if (NOP) asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(S));
     else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(S));
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 // does any lane of this lane's 16-lane row satisfy p?
