@@ -92,7 +92,7 @@ python3 bench.py --mode windows --materialise > $O/bench_windows_materialised.js
 python3 tools/windows_probe.py > $O/windows_probe.txt 2>> $O/bench.err
 python3 tools/baseline_probe.py > $O/dense_kf_and_mpc_probe.json 2>> $O/bench.err
 python3 bench.py --mode mpc --seq 100 --steps 2 --warmup 1 --cpu-seconds 0 > $O/bench_mpc_T100.json 2>> $O/bench.err
-bash tools/pmc_any.sh ${TAG}_mpc "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" $R/tools/mpc_run_bench.py 65536 10 > $O/pmc_mpc.txt 2>&1
+OS_MPC_SHARDS=1 bash tools/pmc_any.sh ${TAG}_mpc "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" $R/tools/mpc_run_bench.py 65536 10 > $O/pmc_mpc.txt 2>&1      # (one part: counters per launch of the whole batch)
 python3 bench.py --gpus 2 --share-gpu --steps 5 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_share_gpu2_fused.json 2>> $O/bench.err
 python3 bench.py --gpus 2 --share-gpu --mode train --steps 10 --warmup 2 --cpu-seconds 0 > $O/bench_share_gpu2_train.json 2>> $O/bench.err
 for e in "" "OS_TRAIN_DBG_NOSAVE=1" "OS_DW_DBG=1"; do env $e python3 bench.py --mode train --steps 20 --cpu-seconds 0 > $O/bench_train_ablation_${e%%=*}.json 2>> $O/bench.err; done
@@ -114,7 +114,21 @@ for b in 32768 16384 8192; do python3 bench.py --scaling strong --batch $b --ste
 python3 bench.py --gpus 2 --share-gpu --scaling strong --steps 5 --warmup 1 --cpu-seconds 0 --parity-samples 2048 --no-second-noise > $O/bench_share_gpu2_strong.json 2>> $O/bench.err
 python3 tools/dropin_loops.py --out $O/dropin_loops.json > $O/dropin_loops.log 2>&1
 OS_MPC_QUAD=0 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_wave_per_qp.json 2>> $O/bench.err
-bash tools/pmc_any.sh ${TAG}_mpcq2 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAVE_CYCLES" $R/tools/mpc_run_bench.py 65536 10 > $O/pmc_mpc_lds.txt 2>&1
+OS_MPC_SHARDS=1 bash tools/pmc_any.sh ${TAG}_mpcq2 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAVE_CYCLES" $R/tools/mpc_run_bench.py 65536 10 > $O/pmc_mpc_lds.txt 2>&1
 python3 tools/mpc_iter_stats.py > $O/mpc_iter_stats.txt 2>> $O/bench.err
 python3 tools/stack_wait_time.py > $O/stack_wait_time.txt 2>&1
+# round 6, second half: the QP with per-problem records, the filter step inside the QP launch, two concurrent parts of the batch -- the
+# line in one part and with the separate filter launch, kernel tables of both, the identity check, in-kernel stamps (one wavefront
+# alone, and the wavefront-per-QP solver inside the persistent kernel at the reference's shape), the B = 4,096 line
+OS_MPC_SHARDS=1 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_one_part.json 2>> $O/bench.err
+OS_MPC_SHARDS=1 OS_MPC_FUSE_KF=0 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_separate_filter.json 2>> $O/bench.err
+python3 bench.py --mode mpc --batch 4096 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B4096.json 2>> $O/bench.err
+OS_MPC_SHARDS=1 bash tools/kstats_any.sh ${TAG}_mpc1 tools/mpc_run_bench.py 65536 40 > /dev/null 2>&1; cp gpurun_out/${TAG}_mpc1_kernel_stats.md $O/mpc_one_part_kernel_stats.md
+OS_MPC_SHARDS=1 OS_MPC_FUSE_KF=0 bash tools/kstats_any.sh ${TAG}_mpc0 tools/mpc_run_bench.py 65536 40 > /dev/null 2>&1; cp gpurun_out/${TAG}_mpc0_kernel_stats.md $O/mpc_separate_filter_kernel_stats.md
+bash tools/kstats_any.sh ${TAG}_mpc2 tools/mpc_run_bench.py 65536 40 > /dev/null 2>&1; cp gpurun_out/${TAG}_mpc2_kernel_stats.md $O/mpc_two_parts_kernel_stats.md
+python3 tools/mpc_fuse_check.py 65536 40 2 2>/dev/null | grep "^B=" > $O/mpc_fuse_check.txt
+L=$(bash tools/ts_lib.sh qts1 liboptistate_qts.so mpc_quad -DOSQ_TS -DOSQ_X_FIXED=40 -DOSQ_OCC=1 | tail -1)
+OPTISTATE_HIP_LIB=$L python3 tools/quad_one_wave.py 64 2>&1 | grep "cycles per" | tail -1 > $O/quad_timestamps_raw.txt
+L=$(bash tools/ts_lib.sh mts liboptistate_mts.so mpc_kernels -DOSM_TS | tail -1)
+OPTISTATE_HIP_LIB=$L python3 bench.py --mode mpc --batch 8 --seq 4000 --steps 1 --warmup 1 --cpu-seconds 0 2>&1 | grep "persistent kernel, cycles" | tail -1 > $O/mpc_persistent_timestamps_raw.txt
 ls $O
