@@ -362,9 +362,15 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * MI355X) this is ONE persistent kernel, a wavefront per trajectory for all T steps (QP with its warm start in registers,
  * then the filter step with the float64 covariance in LDS spread over the 64 lanes): no per-step launches, nothing read
  * back, no stream synchronisation; P is carried in float64 between steps, as in the reference, and rounded to float32
- * only when it is written back at the end of the call.  Larger batches take the launch sequence (QP instances + a T = 1
- * filter launch per step, one trajectory per lane; the leg-count histogram is read back once at entry), which has the
- * higher throughput there.  OS_MPC_PERSISTENT=0 / 2 in the environment forces the sequence / the persistent kernel.
+ * only when it is written back at the end of the call.  Larger batches take the launch sequence (per step a QP launch per
+ * leg count + the T = 1 filter step; the leg-count histogram is read back once at entry), which has the higher throughput
+ * there.  OS_MPC_PERSISTENT=0 / 2 in the environment forces the sequence / the persistent kernel.
+ * Round 6, the sequence at batches of 64 and more whose trajectories carry force on at most two legs in a step: the QPs run
+ * sixteen lanes each (mpc_quad.hip), and -- for the plain call: no flag but OS_MPC_COLD_START, no P_trace / K_gain output --
+ * the filter step of a trajectory runs INSIDE the QP launch that solved its forces (same arithmetic: x, P, x_out, status are
+ * bit-identical to the separate launch; OS_MPC_FUSE_KF=0 switches back).  When every step of the call qualifies and B >= 32,768
+ * the batch runs as two contiguous halves on two internal streams, forked from and joined into `stream` by events (the halves
+ * share nothing; OS_MPC_SHARDS=1 keeps one part): the call stays asynchronous and ordered with respect to `stream`.
  * OS_KF_SEQUENTIAL_UPDATE in `flags` selects the scalar-update form in the launch sequence only; the persistent kernel always
  * uses the batch form of kalman_filter.py:166-172 (LU of S) -- the same posterior for the diagonal R the flag requires. */
 int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,
