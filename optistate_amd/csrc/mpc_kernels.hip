@@ -663,9 +663,10 @@ static __device__ __attribute__((noinline)) QpRet mpc_solve_wave_call(QpCallLds 
 // Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
 template <int NST>
 #ifndef OS_MPC_SOLVE_OCC
-// waves per SIMD the register budget is sized for: 4 at one / two stance legs (108 / 127 registers, no spills; measured at trot,
-// B = 65,536: 1.758 -> 1.683 ms per launch against 3), 3 at three (160), 2 at four (185)
-#define OS_MPC_SOLVE_OCC (NST <= 2 ? 4 : NST == 3 ? 3 : 2)
+// waves per SIMD the register budget is sized for: 4 at one stance leg (109 registers), 3 at two and three (the single-exchange
+// iteration of round 6 keeps a leg-step's three components per lane: 130 registers at trot -- two spilled at a budget of 128; since
+// round 6 this instance serves batches below 64 and OS_MPC_QUAD=0 only), 2 at four (185)
+#define OS_MPC_SOLVE_OCC (NST <= 1 ? 4 : NST <= 3 ? 3 : 2)
 #endif
 __global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const MpcArgs a, int handover)
 {
