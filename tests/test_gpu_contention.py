@@ -157,3 +157,50 @@ def test_one_long_kernel_on_30_of_32_cus_per_xcd_starves_a_tile_and_the_call_fal
     print(f"starved launch: -20 and the fallback to a launch per layer after {el:.2f} s (hog: {HOG_S} s on 240 of 256 CUs)")
     with torch.no_grad():
         assert torch.equal(m(x), m(x)) and eng.kernel_name("gru_layer") == "gru_wide_kernel"      # the stacked mode is back on
+
+
+def test_the_drain_phase_of_the_qp_launch_needs_no_co_residency(tmp_path, monkeypatch):
+    """Round 6: the filter step inside the QP launch (mpc_quad.hip) is one workgroup waiting for another inside a launch too -- but a
+    drained wavefront only ever waits for a row that is RUNNING (docs/stack_protocol.md, last section).  Beside the same hog that
+    starves the four-CUs-per-tile GRU kernel (240 of 256 CUs held by one kernel for seconds: of the QP launch's 2,048 wavefronts a
+    few dozen are resident at a time) os_kf_mpc_run in its fused, two-part form completes with every status word clean and the
+    numbers of the idle-GPU run, bit for bit."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "cu_hog")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tools", "micro", "cu_hog.hip"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    monkeypatch.setenv("OS_MPC_PERSISTENT", "0")
+    B, T = 32768, 4
+    dev = torch.device("cuda:0")
+    d = synth_torch(B, T, dev, seed=31)
+    eng = Engine(0); eng.set_noise(Q_DEFAULT, R_DEFAULT)
+    contact = eng.contact_soa_to_packed(d["contact"])
+    ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
+
+    def run():
+        x, P = d["x0"].clone(), d["P0"].clone()
+        r = eng.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True)
+        torch.cuda.synchronize()
+        return r, x, P
+    r0, x0, P0 = run()
+    assert "filter step inside" in eng.kernel_name("mpc") and "two in flight" in eng.kernel_name("mpc")
+    HOG_S = 3.0
+    hog = subprocess.Popen([exe, "240", str(int(HOG_S * 1000))], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = hog.stdout.readline()
+        assert "hog running" in line, line
+        time.sleep(0.3)
+        t0 = time.time()
+        r1, x1, P1 = run()
+        el = time.time() - t0
+    finally:
+        hog.wait(timeout=60)
+    for k in ("x_out", "f", "iters", "status"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert torch.equal(x0, x1) and torch.equal(P0, P1) and int(r1["status"].abs().max()) == 0
+    print(f"os_kf_mpc_run (fused, two parts, {B} x {T}) beside a hog on 240 of 256 CUs: {el:.2f} s, identical to the idle-GPU run")

@@ -1,6 +1,8 @@
 """GPU: os_kf_mpc_run (estimate_state_mpc over B x T, kalman_filter.py:176-182) -- the persistent kernel against the per-step launch
 sequence on random batch sizes (around the forms' crossovers), horizons, nominal and hostile inputs (every contact pattern), both
-update forms; a few short trajectories of each case also against the two oracles (QP: mpc_oracle, filter step: the C oracle).
+update forms; a few short trajectories of each case also against the two oracles (QP: mpc_oracle, filter step: the C oracle).  Round 6:
+at 64 trajectories and more the launch sequence is also run in its plain form (no P_trace output) with the filter step inside the QP
+launch and, at 32,768 and more, in two concurrent parts -- against OS_MPC_FUSE_KF=0: every output has to be IDENTICAL.
     python tools/fuzz_mpc_run.py [n_cases] [seed]"""
 import os
 import sys
@@ -44,10 +46,12 @@ def main():
         engs[mode] = Engine(0)
     bad = 0
     for case in range(n):
-        B = int(rng.choice([1, 2, 7, 8, 63, 65, 256, 1000, 2047, 2049, 6144]))
+        B = int(rng.choice([1, 2, 7, 8, 63, 65, 256, 1000, 2047, 2049, 6144, 32768 + 16 * int(rng.integers(0, 40)) + int(rng.integers(0, 16))]))
         T = int(rng.choice([1, 2, 7, 20, 40]))
         if B > 1000:
             T = min(T, 7)
+        if B > 10000:
+            T = min(T, 3)
         hostile = bool(rng.integers(0, 2))
         if hostile:
             # the QP closes a loop around the filter: on hostile stretches (fast yaw, one or two stance legs) the closed loop is unstable
@@ -74,6 +78,21 @@ def main():
             torch.cuda.synchronize()
             out[mode] = (eng.unpack(r["x_out"]).cpu().numpy(), eng.unpack(r["f"]).cpu().numpy(), eng.failed(r["status"]).cpu().numpy().astype(bool),
                          eng.kernel_name("mpc"))
+        # the plain launch sequence, filter step inside the QP launch (and two parts at >= 32,768) against the separate launches: identical
+        same = True
+        if B >= 64:
+            eng = engs["0"]
+            res = {}
+            for fuse in ("0", "1"):
+                os.environ["OS_MPC_FUSE_KF"] = fuse
+                x = torch.as_tensor(d["x0"].T.copy()).cuda()
+                P = torch.as_tensor(np.tile(np.asarray(Q, dtype=np.float32).reshape(144, 1), (1, B))).cuda()
+                r = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x, P, sequential=sequential, want_iters=True, want_p_rot=True)
+                torch.cuda.synchronize()
+                res[fuse] = (r, x, P)
+            os.environ.pop("OS_MPC_FUSE_KF")
+            same = all(torch.equal(res["0"][0][k], res["1"][0][k]) for k in ("x_out", "f", "iters", "status", "p_rot")) and \
+                torch.equal(res["0"][1], res["1"][1]) and torch.equal(res["0"][2], res["1"][2])
         xp, fp, sp, kp = out["2"]; xs, fs, ss, ks = out["0"]
         good = ~sp & ~ss
         e_x = float(np.abs(xp[good] - xs[good]).max()) if good.any() else 0.0
@@ -90,7 +109,7 @@ def main():
         # B = 1,000, T = 40: states 7e-5 apart at the worst step, forces 3.7e-2 N, both forms within 3e-2 N of the float64 chain)
         # (only THIS bar, form against form, scales with their state distance; restated after seed 142 of the round-5 sweep, recorded above)
         f_bar = max(2e-2, 600.0 * e_x)
-        ok = e_x < 1e-4 and e_f < f_bar and e_xo < 1e-4 and e_fo < 2e-2 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B
+        ok = e_x < 1e-4 and e_f < f_bar and e_xo < 1e-4 and e_fo < 2e-2 and int((sp != ss).sum()) == 0 and int(sp.sum()) <= 0.01 * B and same
         diag = ""
         if not ok and good.any():
             # which form left the oracle chain?  the trajectory where the two forms are furthest apart, over the whole horizon
@@ -104,6 +123,7 @@ def main():
             diag += "\n     stance legs per step: " + " ".join(str(int(d["contact"][bw, t].sum())) for t in range(T))
         print(f"case {case}: B={B} T={T} hostile={hostile} {'seq' if sequential else 'batch'} noise={noise} [{kp} | {ks}] persistent vs sequence: x {e_x:.1e} f {e_f:.1e} N | "
               f"vs oracles ({len(rows)} trajectories x {To}): x {e_xo:.1e} f {e_fo:.1e} N | flagged {int(sp.sum())}/{int(ss.sum())}"
+              + ("" if B < 64 else " | filter step inside the QP launch: identical" if same else " | filter step inside the QP launch: DIFFERENT")
               + ("" if ok else "   <-- ABOVE THE BAR") + diag, flush=True)
         bad += 0 if ok else 1
     print(f"{n} cases, {bad} above the bars")
