@@ -272,12 +272,17 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     // trip and no barrier per pivot ----
     const double dsel = live ? P.rw * tt : 1.0;            // this lane's diagonal term (see form_row_block)
     double dinv = 1.0;
+    // (an opaque copy of the lane index, as in mpc_quad.hip: the lane predicates of the pivots -- `lane > k`, `lane == k` -- are otherwise
+    // hoisted out of the active-set loop as ~2 NV lane masks in SGPR pairs, spilled to VGPR lanes at the solver's entry and fetched
+    // back with two v_readlane each; recomputed, a predicate is one v_cmp against an inline constant)
+    int ll = L.lane;
+    asm volatile("" : "+v"(ll));
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         if (!((live_mask >> k) & 1ull)) continue;          // wave-uniform
         const double inv = rcp64(readlane_f64(A[k] + dsel, k));
-        if (L.lane == k) dinv = inv;
-        const double f = (L.lane > k && L.lane < NV) ? A[k] * inv : 0.0;
+        if (ll == k) dinv = inv;
+        const double f = (ll > k && ll < NV) ? A[k] * inv : 0.0;
 #pragma unroll
         for (int j = k + 1; j <= NV; j++) {
             A[j] = fma(-f, readlane_f64(A[j], k), A[j]);
@@ -292,8 +297,8 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     for (int k = NV - 1; k >= 0; k--) {
         if (!((live_mask >> k) & 1ull)) continue;
         const double wk = readlane_f64(r * dinv, k);
-        if (L.lane == k) sol = wk;
-        if (L.lane < k) r = fma(-A[k], wk, r);
+        if (ll == k) sol = wk;
+        if (ll < k) r = fma(-A[k], wk, r);
         __builtin_amdgcn_sched_barrier(0);
     }
     OSM_STAMP(4)                                     // back substitution
@@ -345,6 +350,7 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         L.leg = lg;
     }
 
+    OSM_STAMP(12)                                    // call + argument block
     // ---- problem data (wave-uniform) ----
     const uint32_t cleg = (cbits >> (8 * L.leg)) & 0xffu;
     const bool stance = cleg == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
@@ -358,6 +364,7 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         for (int s = 0; s < 3; s++)
             L.Cth[3 * r + s] = readlane_f64(R1[3 * r] * P.w[0] * R1[3 * s] + R1[3 * r + 1] * P.w[1] * R1[3 * s + 1] + R1[3 * r + 2] * P.w[2] * R1[3 * s + 2], 0);
 
+    OSM_STAMP(13)                                    // rotations, C_theta
     // generators of this lane's variable: a = I_hat^-1 (R p_leg x e_c), b = e_c / m, with R of the lane's horizon step
     {
         const double *R = L.i == 0 ? R0 : R1;
@@ -394,6 +401,7 @@ __device__ __forceinline__ void mpc_solve_wave(const MpcParams &P, uint32_t cbit
         }
     }
 
+    OSM_STAMP(14)                                    // generators
     // linear term: q_v = a_v . cw_i + b_v . cv_i from the zero-input trajectory (see header / docs/DESIGN_history_r01-r04.md section 4.5).  The errors of the
     // zero-input trajectory at horizon step k are polynomials in k (attitude and velocity linear, position quadratic through
     // gravity), so the sums over the steps k > i that variable v still influences are closed forms in the lane's step i:
@@ -898,8 +906,8 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_persistent_kernel(const MpcRun
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned long long n = osm_ts_sum[11] ? osm_ts_sum[11] : 1;
         printf("persistent kernel, cycles per step (%llu steps, %.2f iterations per step): faces %llu | rows %llu | elimination %llu | back-substitution %llu | forces %llu | "
-               "ratio/multipliers %llu | QP set-up %llu | QP outputs %llu | filter step %llu\n", n, (double)osm_ts_sum[10] / (double)n, osm_ts_sum[1] / n, osm_ts_sum[2] / n,
-               osm_ts_sum[3] / n, osm_ts_sum[4] / n, osm_ts_sum[5] / n, osm_ts_sum[6] / n, osm_ts_sum[7] / n, osm_ts_sum[8] / n, osm_ts_sum[9] / n);
+               "ratio/multipliers %llu | QP set-up: call + arguments %llu, rotations %llu, generators %llu, linear term + tables %llu | QP outputs %llu | filter step %llu\n", n, (double)osm_ts_sum[10] / (double)n, osm_ts_sum[1] / n, osm_ts_sum[2] / n,
+               osm_ts_sum[3] / n, osm_ts_sum[4] / n, osm_ts_sum[5] / n, osm_ts_sum[6] / n, osm_ts_sum[12] / n, osm_ts_sum[13] / n, osm_ts_sum[14] / n, osm_ts_sum[7] / n, osm_ts_sum[8] / n, osm_ts_sum[9] / n);
     }
 #endif
     // the status word is OR-reduced over the wavefront (bit 1 is per state component)
