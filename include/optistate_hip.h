@@ -371,6 +371,8 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * bit-identical to the separate launch; OS_MPC_FUSE_KF=0 switches back).  When every step of the call qualifies and B >= 32,768
  * the batch runs as two contiguous halves on two internal streams, forked from and joined into `stream` by events (the halves
  * share nothing; OS_MPC_SHARDS=1 keeps one part): the call stays asynchronous and ordered with respect to `stream`.
+ * (status bit 6 = 64: a filter step inside a QP launch gave up waiting for its trajectory's forces after 2^24 polls -- a lost
+ * device; never seen, tested beside a process that holds 240 of the 256 compute units.)
  * OS_KF_SEQUENTIAL_UPDATE in `flags` selects the scalar-update form in the launch sequence only; the persistent kernel always
  * uses the batch form of kalman_filter.py:166-172 (LU of S) -- the same posterior for the diagonal R the flag requires. */
 int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float *dp, const float *imu,

@@ -1232,13 +1232,14 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
                 post.kf = a; post.kf.k = ctx->k; post.kf.status = status + b0;
                 post.qr = (const float *)ctx->kf_qr; post.done = nullptr; post.seq = 0;
                 shard[i].counters = step_counters + ((size_t)t * osm::MAX_SHARDS + i) * 32;
-                if (int rcl = osm::launch_instances(ctx, m, flags_h[t], st[i], &post, &shard[i])) { free(flags_h); return rcl; }
+                rc = osm::launch_instances(ctx, m, flags_h[t], st[i], &post, &shard[i]);          // (a failure still joins the parts below)
                 os_prof_end(ctx, slot, st[i]);
                 continue;
             }
             // (the separate launches: one part only -- S > 1 needs every step fused)
-            if (int rcl = osm::launch_instances(ctx, m, flags_h[t], s)) { free(flags_h); return rcl; }
+            rc = osm::launch_instances(ctx, m, flags_h[t], s);
             os_prof_end(ctx, slot, s);
+            if (rc) break;
             rc = os_kf_run_impl(ctx, a, (flags | OS_KF_DENSE_FD) & ~(uint32_t)OS_KF_SYMMETRIC_P, s);
             hipLaunchKernelGGL(osm::or_status_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, status, st_step);
         }
