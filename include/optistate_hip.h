@@ -358,7 +358,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * (solved from the state before the predict), then get_odom + set_measurements + predict_mpc (dense F_d covariance,
  * next_state with f[:, 0]) + update.  Streams as os_kf_run; f_out [T][12][B] receives the forces (KF2.f[:, 0], the
  * feature columns 18..29 of :248-250), mpc_iters [T][B] (optional) the active-set iteration counts; status [B] is
- * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  Up to 24 trajectories per compute unit (B <= 6144 on an
+ * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  Up to 40 trajectories per compute unit (B <= 10240 on an
  * MI355X) this is ONE persistent kernel, a wavefront per trajectory for all T steps (QP with its warm start in registers,
  * then the filter step with the float64 covariance in LDS spread over the 64 lanes): no per-step launches, nothing read
  * back, no stream synchronisation; P is carried in float64 between steps, as in the reference, and rounded to float32

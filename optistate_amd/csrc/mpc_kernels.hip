@@ -1107,10 +1107,10 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    // persistent kernel up to 24 trajectories per CU (it spends a whole wavefront on one trajectory's filter step and
-    // saturates at ~1.2e7 steps/s; measured on 256 CUs, persistent / launch sequence: B = 4096 1.16e7 / 0.83e7, 8192
-    // 1.23e7 / 1.31e7, 16,384 1.26e7 / 1.95e7, 32,768 1.29e7 / 2.53e7)
-    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 24 * ctx->cu_count)) {
+    // persistent kernel up to 40 trajectories per CU (it spends a whole wavefront on one trajectory and saturates at ~2.2e7 steps/s;
+    // measured on 256 CUs at the end of round 6, persistent / launch sequence: B = 4,096 1.94e7 / 1.11e7, 8,192 2.10e7 / 1.87e7,
+    // 10,240 2.11e7 / 2.11e7, 12,288 2.19e7 / 2.26e7, 16,384 2.19e7 / 2.75e7, 24,576 2.26e7 / 3.65e7)
+    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 40 * ctx->cu_count)) {
         // one launch, one wavefront per trajectory for all T steps; nothing is read back, nothing synchronises
         osm::MpcRunArgs m;
         osk::KfRunArgs &a = m.kf;

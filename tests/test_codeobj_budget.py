@@ -73,7 +73,7 @@ SCRATCH_FREE = {
     "ost::dw_kernel<false, 4>": "weight gradients of an epoch's last, partial batch (B % 32 != 0 with the batch_first input): two passes for 188 columns",
     "ost::dw_kernel<false, 2>": "the same, 60 / 64-wide layers",
     # estimate_state_mpc -- the reference's real loop
-    # NOT HELD: "osm::kf_mpc_persistent_kernel<1>" (estimate_state_mpc at the reference's shape): 172 B = the callee-saved VGPRs of the QP
+    # NOT HELD: "osm::kf_mpc_persistent_kernel<1>" (estimate_state_mpc at the reference's shape): 344 B = the callee-saved VGPRs of the QP
     # call's ABI, written at call entry and read back at its exit, nothing inside a loop body; the two ways around the call that were
     # built and measured (all four solver instances inlined in a QP wave: 460 registers, 44 us per step against 33; one QP wave per
     # leg count: 5 waves, 256-register cap, spills) are slower -- DESIGN.md section 4.5
