@@ -358,7 +358,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * (solved from the state before the predict), then get_odom + set_measurements + predict_mpc (dense F_d covariance,
  * next_state with f[:, 0]) + update.  Streams as os_kf_run; f_out [T][12][B] receives the forces (KF2.f[:, 0], the
  * feature columns 18..29 of :248-250), mpc_iters [T][B] (optional) the active-set iteration counts; status [B] is
- * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  Up to 40 trajectories per compute unit (B <= 10240 on an
+ * written (bits 0/1 as os_kf_run, bit 2 = QP iteration cap).  Up to 32 trajectories per compute unit (B <= 8192 on an
  * MI355X) this is ONE persistent kernel, a wavefront per trajectory for all T steps (QP with its warm start in registers,
  * then the filter step with the float64 covariance in LDS spread over the 64 lanes): no per-step launches, nothing read
  * back, no stream synchronisation; P is carried in float64 between steps, as in the reference, and rounded to float32
@@ -368,7 +368,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * Round 6, the sequence at batches of 64 and more whose trajectories carry force on at most two legs in a step: the QPs run
  * sixteen lanes each (mpc_quad.hip), and -- for the plain call: no flag but OS_MPC_COLD_START, no P_trace / K_gain output --
  * the filter step of a trajectory runs INSIDE the QP launch that solved its forces (same arithmetic: x, P, x_out, status are
- * bit-identical to the separate launch; OS_MPC_FUSE_KF=0 switches back).  When every step of the call qualifies and B >= 32,768
+ * bit-identical to the separate launch; OS_MPC_FUSE_KF=0 switches back).  When every step of the call qualifies and B > 8,192
  * the batch runs as two contiguous halves on two internal streams, forked from and joined into `stream` by events (the halves
  * share nothing; OS_MPC_SHARDS=1 keeps one part): the call stays asynchronous and ordered with respect to `stream`.
  * (status bit 6 = 64: a filter step inside a QP launch gave up waiting for its trajectory's forces after 2^24 polls -- a lost

@@ -1107,10 +1107,10 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    // persistent kernel up to 40 trajectories per CU (it spends a whole wavefront on one trajectory and saturates at ~2.2e7 steps/s;
-    // measured on 256 CUs at the end of round 6, persistent / launch sequence: B = 4,096 1.94e7 / 1.11e7, 8,192 2.10e7 / 1.87e7,
-    // 10,240 2.11e7 / 2.11e7, 12,288 2.19e7 / 2.26e7, 16,384 2.19e7 / 2.75e7, 24,576 2.26e7 / 3.65e7)
-    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 40 * ctx->cu_count)) {
+    // persistent kernel up to 32 trajectories per CU (it spends a whole wavefront on one trajectory and saturates at ~2.2e7 steps/s;
+    // measured on 256 CUs at the end of round 6, persistent / launch sequence in two parts: B = 4,096 1.97e7 / 1.18e7, 6,144 2.07e7 /
+    // 1.67e7, 8,192 2.13e7 / 2.13e7, 10,240 2.16e7 / 2.47e7, 16,384 2.19e7 / 3.32e7, 24,576 2.26e7 / 4.30e7)
+    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 32 * ctx->cu_count)) {
         // one launch, one wavefront per trajectory for all T steps; nothing is read back, nothing synchronises
         osm::MpcRunArgs m;
         osk::KfRunArgs &a = m.kf;
@@ -1174,14 +1174,14 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
 
     // Shards: when EVERY step of the call runs the fused form, the batch is cut into contiguous parts on streams of their own (the
     // caller's stream forks into them and joins them).  A part's QP launch ends with a few stragglers on an almost idle chip; the
-    // other part's launches fill it (measured at B = 65,536: 1.15 -> 1.05 ms per step with two parts; three and four gain nothing).
-    // OS_MPC_SHARDS=1 keeps one part.
+    // other part's launches fill it (measured at B = 65,536: 1.15 -> 1.05 ms per step with two parts; three and four gain nothing; at
+    // 12,288 / 16,384 / 24,576: +22 / +17 / +15 %).  OS_MPC_SHARDS=1 keeps one part.
     int S = 1;
     {
         const char *sh_env = getenv("OS_MPC_SHARDS");
         int want = sh_env ? atoi(sh_env) : 2;
         if (want > osm::MAX_SHARDS) want = osm::MAX_SHARDS;
-        bool all_fused = can_fuse && want > 1 && B / want >= 16384;
+        bool all_fused = can_fuse && want > 1 && B / want >= 4096;
         for (int t = 0; t < T && all_fused; t++) all_fused = (flags_h[t] & ~7u) == 0 && osm::quad_path(ctx, B / want - 16, flags_h[t]);
         if (all_fused) S = want;
     }

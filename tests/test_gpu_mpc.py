@@ -284,7 +284,7 @@ def test_mpc_nonfinite_input_terminates_and_flags(eng):
 
 
 def test_persistent_kernel_agrees_with_the_launch_sequence(monkeypatch):
-    """os_kf_mpc_run has two forms (one persistent kernel up to 40 trajectories per CU, the per-step launch sequence above):
+    """os_kf_mpc_run has two forms (one persistent kernel up to 32 trajectories per CU, the per-step launch sequence above):
     same forces and states on a trot with phase changes, to the state bar -- the persistent kernel carries P in float64
     between steps, the sequence rounds it to float32 at every step."""
     from optistate_amd import Engine
