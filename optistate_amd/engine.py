@@ -516,7 +516,10 @@ class Engine:
     def kf_mpc_run(self, p, dp, imu, contact, body_ref, x, P, sequential=False, want_p_rot=False, want_trace=False,
                    want_gain=False, want_iters=False, cold_start=False):
         """estimate_state_mpc for B trajectories x T steps (kalman_filter.py:176-182): QP forces + dense-F_d filter step.
-        Streams [T][.][B] as kf_run; x [12][B], P [144][B] in/out.  Returns dict(x_out, f [T][12][B], status, ...)."""
+        Streams [T][.][B] as kf_run; x [12][B], P [144][B] in/out.  Returns dict(x_out, f [T][12][B], status, ...).
+        Up to 32 trajectories per CU one persistent kernel; above, a launch sequence per step whose plain form (no sequential update, no
+        P_trace / K_gain output) runs the filter step inside the QP launch and the batch as two concurrent halves (include/optistate_hip.h;
+        OS_MPC_FUSE_KF=0 / OS_MPC_SHARDS=1 switch those off): same results either way, the call stays asynchronous on the current stream."""
         T, _, B = p.shape
         mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
         x_out, f_out = mk(T, 12, B), mk(T, 12, B)

@@ -384,7 +384,7 @@ def test_dropin_estimate_state_mpc_matches_reference_trajectory_g12():
         assert abs(kf.P_trace / g["t_P_trace"][0, t] - 1) < 1e-3
 
 
-@pytest.mark.parametrize("B,T,shards,mix", [(4096, 8, "1", True), (4096, 6, "1", False), (32768, 5, "2", False), (32816, 4, "2", True)])
+@pytest.mark.parametrize("B,T,shards,mix", [(4096, 8, "1", True), (4096, 6, "1", False), (9000, 5, "2", False), (32816, 4, "2", True), (65536, 3, "2", False)])
 def test_filter_step_inside_the_qp_launch_equals_the_separate_launches(monkeypatch, B, T, shards, mix):
     """Round 6: at large batch the filter step of a trajectory runs inside the QP launch that solved its forces (mpc_quad.hip drain
     phase; the forces cross CUs through agent-scope stores and a per-trajectory mark), and a batch of two 16,384s or more runs as
