@@ -10,10 +10,21 @@
 // arithmetic instruction with a 64-bit DPP operand, kf_dense_rows.hpp).  One instruction updates an entry of the rows of FOUR
 // problems: ~0.83 k elimination instructions per wavefront-solve = ~0.2 k per QP against 1.4 k.
 // Three and four stance legs (45 / 60 variables: four rows per lane = 488 registers) stay on mpc_kernels.hip's instances.
-// The four QPs of a wavefront iterate together: the solve is unconditional (a finished problem's rows ride along), the ratio test and
-// the multiplier check run under the lanes' own predicates; a wavefront leaves when all four have converged.
+//
+// How a launch runs (profiles/r06_pmc_mpc.md for the measurements behind each piece):
+//   * mpc_prep_kernel writes a per-problem RECORD (generators, linear term: everything constant over the iterations) -- four rows in lock
+//     step, many wavefronts per SIMD;
+//   * mpc_solve_quad_kernel: a persistent grid, each 16-lane ROW takes a problem index from a work counter, copies its record into LDS,
+//     iterates until its KKT conditions hold, writes its outputs and takes the next index.  The solve of an iteration is unconditional
+//     for the wavefront (a row without a problem rides along on an all-dead system); set-up, ratio test, multiplier check and outputs
+//     run under the rows' own predicates.  One LDS exchange hands a leg-step's solution and point to its three lanes, which compute
+//     every leg-step quantity redundantly and without branches;
+//   * os_kf_mpc_run's form (POST_STEP): a row that finishes a QP marks its trajectory; wavefronts whose rows have run out of QPs take
+//     tickets of sixteen consecutive trajectories and run the filter step of kf_dense_rows_kernel<BATCH> on them (drain phase).
 // The hazard rule inline assembly must respect itself (hipcc does not look inside): a VALU write needs two wait states before a DPP
 // operand reads the register (tools/isa_dpp_hazard_scan.py scans this file too).
+// Development switches (tools/quad_variants.sh): -DOSQ_TS in-kernel stamps; -DOSQ_X_FIXED=n every problem exactly n iterations,
+// -DOSQ_X_TRUNC=n at most n (what the tail costs), -DOSQ_OCC=1 one wavefront per SIMD.
 #include "mpc_common.hpp"
 
 #include <stdlib.h>
@@ -599,9 +610,6 @@ struct Quad {
         const Lane L = again(L0);
         const size_t B = (size_t)a.B;
         const int b = R.b;
-#ifdef OSQ_X_NOSTORE
-        if (R.iters < 1000) { R.has = false; return; }
-#endif
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < VPL; h++)
@@ -973,8 +981,8 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
     __builtin_amdgcn_wave_barrier();
     for (;;) {
         if (!R.has && !R.exhausted) {
-            // (row-uniform) next problem of this leg count; its index was reserved when the previous problem started (the work counter's
-            // round trip travels under a whole problem's iterations)
+            // (row-uniform) next problem of this leg count; its index was requested when the previous problem's data had arrived (the work
+            // counter's round trip travels under a whole problem's iterations)
             for (;;) {
                 const int nb = __builtin_amdgcn_update_dpp(0, R.nx_raw, 0x150, 0xf, 0xf, true);      // row_newbcast:0
                 if (nb >= a.n) { R.exhausted = true; break; }
@@ -996,15 +1004,15 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
                 R.nx_raw = 0;
                 if (L.l == 0) R.nx_raw = atomicAdd(counter, 1);
                 if (!mine) continue;
-                OSQ_STAMP(10)                        // work counter + contact word
+                OSQ_STAMP(10)                        // (the row has its next problem)
                 break;
             }
         }
         if (__ballot(R.has) == 0ull) break;
-        OSQ_STAMP(7)                                 // fetch + set-up of new problems
+        OSQ_STAMP(7)                                 // next problems: record + warm start
         OSQ_STAMP(8)                                 // (nothing: the cost of a stamp)
         const typename Q::Sol S = Q::solve_face(L, a.prm, Sh, M, R.F);
-        OSQ_STAMP(5)                                 // face coordinates -> forces
+        OSQ_STAMP(5)                                 // (solve_face returns)
         if (R.has) {
             Q::iterate_row(L, a.prm, Sh, M, R, S);
             OSQ_STAMP(9)                             // ratio test / multipliers
@@ -1013,9 +1021,6 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
 #endif
 #ifdef OSQ_X_TRUNC
             if (R.iters >= OSQ_X_TRUNC) { R.done = true; R.converged = true; }
-#endif
-#ifdef OSQ_X_PRIO
-            if (__ballot(R.has && R.iters == OSQ_X_PRIO) != 0ull) __builtin_amdgcn_s_setprio(3);
 #endif
             if (R.done || R.iters >= a.max_iter) {
                 Q::template finish_row<POST != POST_NONE>(L, a, M, R);
