@@ -26,6 +26,7 @@
 #include "launch.hpp"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -949,6 +950,8 @@ static void fill_args(os_ctx *ctx, MpcArgs &a)
 
 }  // namespace osm
 void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters, int cu_count, hipStream_t s, const osm::PostArgs *post);      // mpc_quad.hip
+namespace osq { struct RowsArgs { osk::KfRunArgs kf; osm::MpcParams prm; float *f_out; int32_t *iters; int max_iter, cold; const float *qr; }; }      // mpc_quad.hip (same layout)
+void os_mpc_launch_rows(const osq::RowsArgs &a, int nst, int *counter, int cu_count, hipStream_t s);
 namespace osm {
 
 // layout of the context's QP scratch (floats): u [B][64] doubles | faces [B][64] bytes | contact [B] | todo [2][B] | counters (32 ints per
@@ -1107,10 +1110,24 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         return os_fail(ctx, -2, "os_kf_mpc_run: null required pointer");
     OS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    // persistent kernel up to 32 trajectories per CU (it spends a whole wavefront on one trajectory and saturates at ~2.2e7 steps/s;
-    // measured on 256 CUs at the end of round 6, persistent / launch sequence in two parts: B = 4,096 1.97e7 / 1.18e7, 6,144 2.07e7 /
-    // 1.67e7, 8,192 2.13e7 / 2.13e7, 10,240 2.16e7 / 2.47e7, 16,384 2.19e7 / 3.32e7, 24,576 2.26e7 / 4.30e7)
-    if (ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 32 * ctx->cu_count)) {
+    // Three forms (OS_MPC_PERSISTENT=1, the default, picks; 0 / 2 force the launch sequence / the wavefront-per-trajectory kernel):
+    //  * kf_mpc_persistent_kernel, a wavefront per trajectory for all T steps: up to 32 trajectories per CU unless the rows form takes the
+    //    batch (it spends a whole wavefront on one trajectory and saturates at ~2.2e7 steps/s);
+    //  * kf_mpc_rows_kernel (mpc_quad.hip), a 16-lane row per trajectory for all T steps: batches of 10 .. 80 trajectories per CU whose every
+    //    step carries force on NST legs or none, the plain call (no flag but OS_MPC_COLD_START, no P_trace / K_gain output); OS_MPC_ROWS=0
+    //    switches it off, OS_MPC_ROWS=<lo>:<hi> moves the range;
+    //  * the per-step launch sequence (two concurrent parts, the filter step inside the QP launch) for everything else.
+    // Measured on 256 CUs at the end of round 6, steps/s at T = 100, wavefront kernel / rows kernel / sequence: B = 2,048 1.76e7 / 1.67e7 /
+    // 0.59e7, 3,072 1.73e7 / 2.51e7 / 0.85e7, 4,096 1.84e7 / 3.41e7 / 1.10e7, 8,192 2.06e7 / 3.76e7 / 2.14e7, 16,384 2.20e7 / 4.15e7 /
+    // 3.20e7, 24,576 2.24e7 / 4.18e7 / 4.15e7, 32,768 2.24e7 / 4.33e7 / 5.10e7.
+    int rows_lo = 10 * ctx->cu_count, rows_hi = 80 * ctx->cu_count;
+    if (const char *re = getenv("OS_MPC_ROWS")) {
+        if (sscanf(re, "%d:%d", &rows_lo, &rows_hi) != 2) { rows_lo = 0; rows_hi = -1; }       // ("0": off)
+    }
+    const bool rows_plain = (flags & ~(uint32_t)OS_MPC_COLD_START) == 0 && !ptrace_out && !kgain_out && ctx->kf_qr && ctx->tune_mpc_quad != 0 &&
+                            (size_t)B * 144 * 4 < 0xffffffffull;
+    const bool rows_wanted = rows_plain && B >= rows_lo && B <= rows_hi && ctx->tune_mpc_persistent == 1;
+    auto launch_persistent = [&]() -> int {
         // one launch, one wavefront per trajectory for all T steps; nothing is read back, nothing synchronises
         osm::MpcRunArgs m;
         osk::KfRunArgs &a = m.kf;
@@ -1131,7 +1148,9 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
         os_prof_end(ctx, slot, s);
         OS_HIP(ctx, hipGetLastError());
         return 0;
-    }
+    };
+    const bool small = ctx->tune_mpc_persistent == 2 || (ctx->tune_mpc_persistent == 1 && B <= 32 * ctx->cu_count);
+    if (small && !rows_wanted) return launch_persistent();
     // scratch: warm-start store (u [B][64] doubles, faces [B][64] bytes, contact [B]) + per-step Kalman status [B] +
     // leg-count presence flags [T]
     // + the work / ticket counters of every (step, part) launch, zeroed once per call (a fill launch per step otherwise)
@@ -1172,6 +1191,35 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { free(flags_h); return os_fail(ctx, -10, hipGetErrorString(e)); }
 
+    if (rows_wanted) {
+        // every step: force on exactly NST legs or on none, the same NST throughout
+        uint32_t all = 0;
+        for (int t = 0; t < T; t++) all |= flags_h[t];
+        const uint32_t nz = all & ~1u;
+        if (nz == 2u || nz == 4u) {
+            free(flags_h);
+            osq::RowsArgs r;
+            osk::KfRunArgs &a = r.kf;
+            a.B = B; a.T = T; a.p = p; a.f = f_out; a.dp = dp; a.imu = imu; a.contact = contact; a.body_ref = body_ref;
+            a.x = x; a.P = P; a.x_out = x_out; a.p_rot_out = p_rot_out; a.ptrace_out = nullptr; a.kgain_out = nullptr;
+            a.status = status; a.accel = nullptr; a.minmax = nullptr; a.feat_out = nullptr; a.feat_I = 0;
+            a.k = ctx->k;
+            r.f_out = f_out; r.iters = mpc_iters; r.max_iter = 200; r.cold = (flags & OS_MPC_COLD_START) ? 1 : 0;
+            r.qr = (const float *)ctx->kf_qr;
+            {
+                osm::MpcArgs tmp;
+                osm::fill_args(ctx, tmp);
+                r.prm = tmp.prm;
+            }
+            // (status was zeroed above; the counter: the first of the per-step counters, zeroed with them)
+            const int slot = os_prof_begin(ctx, 4, s, "kf_mpc_rows_kernel<NST> (a 16-lane row per trajectory for all T steps)");
+            os_mpc_launch_rows(r, nz == 4u ? 2 : 1, step_counters, ctx->cu_count, s);
+            os_prof_end(ctx, slot, s);
+            OS_HIP(ctx, hipGetLastError());
+            return 0;
+        }
+        if (small) { free(flags_h); return launch_persistent(); }      // (mixed leg counts: the wavefront-per-trajectory kernel takes them all)
+    }
     // Shards: when EVERY step of the call runs the fused form, the batch is cut into contiguous parts on streams of their own (the
     // caller's stream forks into them and joins them).  A part's QP launch ends with a few stragglers on an almost idle chip; the
     // other part's launches fill it (measured at B = 65,536: 1.15 -> 1.05 ms per step with two parts; three and four gain nothing; at

@@ -418,6 +418,13 @@ struct Quad {
             prob[12 + L.l] = (double)a.ref[(size_t)L.l * B + b];
             prob[24 + L.l] = (double)a.p[(size_t)L.l * B + b];
         }
+        prep_compute(L, a.rec, P, M, prob, b, cbits);
+    }
+    // prob (LDS): x | ref | p of the problem in float64, written by the row's lanes before the call.  rec_base null: the record stays in
+    // the row's LDS block (kf_mpc_rows_kernel builds it where the solver reads it)
+    template <typename MemT>
+    static __device__ __forceinline__ void prep_compute(const Lane &L, double *rec_base, const MpcParams &P, MemT &M, const double *prob, int b, uint32_t cbits)
+    {
         __builtin_amdgcn_wave_barrier();
         int legs[4] = {0, 0, 0, 0};
         {
@@ -502,12 +509,35 @@ struct Quad {
         }
         __builtin_amdgcn_wave_barrier();
         // the record image out: chunk c = 16 lanes x 16 bytes
-        typedef double d2_t __attribute__((ext_vector_type(2)));
-        d2_t *dst = reinterpret_cast<d2_t *>(reinterpret_cast<char *>(a.rec) + (size_t)b * REC_BYTES);
-        const d2_t *src = reinterpret_cast<const d2_t *>(M.rec_image);
+        if (rec_base) {
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            d2_t *dst = reinterpret_cast<d2_t *>(reinterpret_cast<char *>(rec_base) + (size_t)b * REC_BYTES);
+            const d2_t *src = reinterpret_cast<const d2_t *>(M.rec_image);
 #pragma unroll
-        for (int c = 0; c < RCH; c++) dst[c * 16 + L.l] = src[c * 16 + L.l];
+            for (int c = 0; c < RCH; c++) dst[c * 16 + L.l] = src[c * 16 + L.l];
+        }
         __builtin_amdgcn_wave_barrier();
+    }
+    // the stance flags of the lane's variables from the contact word (load_row; kf_mpc_rows_kernel)
+    static __device__ __forceinline__ void set_stance(const Lane &L, uint32_t cbits, Row &R)
+    {
+        int legs[4] = {0, 0, 0, 0};
+        {
+            int n = 0;
+#pragma unroll
+            for (int lg = 0; lg < 4; lg++) {
+                if (((cbits >> (8 * lg)) & 0xffu) != 0u) {
+                    if (n == 0) legs[0] = lg; else if (n == 1) legs[1] = lg; else if (n == 2) legs[2] = lg; else legs[3] = lg;
+                    n++;
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < VPL; h++) {
+            const int rank = (L.var[h].v % NPS) / 3;
+            const int leg = rank == 0 ? legs[0] : rank == 1 ? legs[1] : rank == 2 ? legs[2] : legs[3];
+            R.stance[h] = ((cbits >> (8 * leg)) & 0xffu) == 1u;      // any other non-zero value: unconstrained (force_controller.py:114-131)
+        }
     }
 
     // problem b -> the row's LDS block and state (row-uniform control flow: every lane of the row is here): the record in, the stance
@@ -889,7 +919,7 @@ __device__ __forceinline__ void mark_done(int l, const PostArgs &post, int b)
 
 // One predict_mpc + update step of trajectory b on this 16-lane row: kf_dense_rows_kernel<BATCH, dense> at T = 1 (kf_dense_rows.hip),
 // the same building blocks in the same order -- the results are bit-identical to the separate launch.  qs / rs: Q and R in float64 (LDS).
-__device__ __forceinline__ void kf_step_row(const osk::KfRunArgs &a, const double *qs, const double *rs, int b, bool live, int r)
+__device__ __forceinline__ float kf_step_row(const osk::KfRunArgs &a, const double *qs, const double *rs, int b, bool live, int r, int t, double ed /* expm1(dt) */)
 {
     using namespace osk;
     namespace rw = osk::rows64;
@@ -908,14 +938,13 @@ __device__ __forceinline__ void kf_step_row(const osk::KfRunArgs &a, const doubl
     }
     double one = 1.0;
     asm volatile("" : "+v"(one));                      // a register operand for the DPP sums
-    const double ed = expm1((double)k.dt);
     StepIn in;
     float bref[3];
-    load_step(a, 0, voff, rowB, in);
+    load_step(a, t, voff, rowB, in);
 #pragma unroll
-    for (int i = 0; i < 12; i++) in.f[i] = load_agent(a.f + (size_t)i * B + b);      // (written in this launch, by another CU)
+    for (int i = 0; i < 12; i++) in.f[i] = load_agent(a.f + ((size_t)t * 12 + i) * B + b);      // (written in this launch, by another CU)
     {
-        rsrc_t rb = make_rsrc(a.body_ref, 12 * rowB);
+        rsrc_t rb = make_rsrc(a.body_ref + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
         for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
     }
@@ -929,7 +958,7 @@ __device__ __forceinline__ void kf_step_row(const osk::KfRunArgs &a, const doubl
         float pv = pw[0];
 #pragma unroll
         for (int i = 1; i < 12; i++) pv = (r == i) ? pw[i] : pv;
-        a.p_rot_out[(size_t)r * B + b] = pv;
+        a.p_rot_out[((size_t)t * 12 + r) * B + b] = pv;
     }
     double xd = (double)xn;
     {
@@ -943,12 +972,13 @@ __device__ __forceinline__ void kf_step_row(const osk::KfRunArgs &a, const doubl
     status |= __shfl_xor(status, 1, 64); status |= __shfl_xor(status, 2, 64);
     status |= __shfl_xor(status, 4, 64); status |= __shfl_xor(status, 8, 64);
     if (live && r < 12) {
-        a.x_out[(size_t)r * B + b] = xr;
+        a.x_out[((size_t)t * 12 + r) * B + b] = xr;
         a.x[(size_t)r * B + b] = xr;
 #pragma unroll
         for (int j = 0; j < NS; j++) a.P[(size_t)(r * NS + j) * B + b] = (float)P[j];
         if (r == 0 && status) atomicOr(&a.status[b], status);
     }
+    return xr;                                         // lane r < 12: component r of the new state (what a.x now holds)
 }
 
 template <int NST, int POST>
@@ -1040,6 +1070,7 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
         // lock step.  The wait is for a row that is running (this launch's, or an earlier instance's that has completed): no
         // co-residency assumption; the poll limit only guards against a lost device (status bit 6 of the trajectory).
         double *qs = reinterpret_cast<double *>(&Mq[0]), *rs = qs + osk::NS * osk::NS;      // (the rows' LDS blocks are idle now)
+        const double ed = expm1((double)post.kf.k.dt);
         __builtin_amdgcn_wave_barrier();
         for (int i = L.lane; i < osk::NS * osk::NS; i += 64) qs[i] = (double)post.qr[i];
         for (int i = L.lane; i < (osk::NM + 2) * osk::NM; i += 64) rs[i] = i < osk::NM * osk::NM ? (double)post.qr[144 + i] : 0.0;
@@ -1062,7 +1093,7 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
                         __builtin_amdgcn_s_sleep(8);
                     }
                 }
-                kf_step_row(post.kf, qs, rs, have ? tb : a.n - 1, have, L.l);
+                kf_step_row(post.kf, qs, rs, have ? tb : a.n - 1, have, L.l, 0, ed);
             }
         }
     }
@@ -1075,6 +1106,121 @@ __global__ __launch_bounds__(64, OSQ_OCC) void mpc_solve_quad_kernel(const MpcAr
                osq_ts_sum[7] / n, osq_ts_sum[8] / n);
     }
 #endif
+}
+
+// =====================================================================================================================
+// estimate_state_mpc with a 16-lane ROW per trajectory for ALL T steps (round 6; batches between the wavefront-per-trajectory persistent
+// kernel and the launch sequence).  The launch sequence pays, per step, for the few problems with 30-45 active-set iterations: at
+// B = 65,536 two concurrent parts hide that drain, at 8-24 k trajectories a launch IS the drain (a part of 8,192 problems has one
+// problem per row).  Here nothing is synchronised between steps: a row takes a trajectory from a work counter and runs QP -> filter
+// step -> next QP for all its steps -- the record of the next QP is built in the row's LDS block from the state the filter step has
+// just produced (prep_compute, no global round trip), the warm start stays in the row's registers, x and P travel through global
+// memory as in the launch sequence (P rounded to float32 at every step: the sequence's numbers up to the last bits of the record --
+// the same source inlined into another kernel contracts differently).  The four rows of a wavefront are at different steps of
+// different trajectories; the solve of an iteration is shared, set-up / outputs / filter step run under the rows' predicates.
+// Every trajectory at every step must carry force on NST legs or on none (the host checks the leg-count histogram).
+// =====================================================================================================================
+struct RowsArgs {
+    osk::KfRunArgs kf;             // all T steps' streams, x / P in place, x_out, p_rot_out, status
+    MpcParams prm;
+    float *f_out;                  // [T][12][B] (kf.f points at the same array)
+    int32_t *iters;                // [T][B] or null
+    int max_iter, cold;
+    const float *qr;               // Q 144 | R 100
+};
+
+// OCC: wavefronts per SIMD the register budget is sized for -- 1 (no spills: the filter step alone wants ~250 registers beside the row's
+// QP state) while a wavefront per SIMD covers the batch (B <= 16 x CUs: measured at B = 4,096 3.4e7 against 2.3e7 steps/s), else 2
+template <int NST, int OCC>
+__global__ __launch_bounds__(64, OCC) void kf_mpc_rows_kernel(const RowsArgs a, int *__restrict__ counter)
+{
+    typedef Quad<NST> Q;
+    __shared__ typename Q::Mem Mq[4];
+    __shared__ QuadShared Sh;
+    __shared__ double qrs[osk::NS * osk::NS + (osk::NM + 2) * osk::NM];
+    const typename Q::Lane L = Q::this_lane();
+    if (L.lane < 25) {
+        double al, be;
+        alpha_beta(L.lane / 5, L.lane % 5, a.prm.dt, al, be);
+        Sh.ab[L.lane][0] = al; Sh.ab[L.lane][1] = be;
+    }
+    double *qs = qrs, *rs = qrs + osk::NS * osk::NS;
+    for (int i = L.lane; i < osk::NS * osk::NS; i += 64) qs[i] = (double)a.qr[i];
+    for (int i = L.lane; i < (osk::NM + 2) * osk::NM; i += 64) rs[i] = i < osk::NM * osk::NM ? (double)a.qr[144 + i] : 0.0;
+    typename Q::Mem &M = Mq[L.lane >> 4];
+    for (int i = L.l; i < (int)(sizeof(typename Q::Mem) / 8); i += 16) reinterpret_cast<double *>(&M)[i] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int T = a.kf.T, nB = a.kf.B;
+    const size_t B = (size_t)a.kf.B;
+    const double ed = expm1((double)a.kf.k.dt);
+    typename Q::Row R;
+    R.has = false; R.exhausted = false; R.first = false; R.done = true; R.converged = true; R.b = 0; R.iters = 0; R.cbits = 0; R.nx_raw = 0;
+#pragma unroll
+    for (int h = 0; h < Q::VPL; h++) { R.F.f[h] = Q::fpack(0, 0, SZ_ZERO); R.u[h] = 0.0; R.stance[h] = false; }
+    int b = -1, t = 0;                      // the row's trajectory and its current step
+    uint32_t prev_c = 0xffffffffu;          // contact word of the previous step's solve (warm start valid while the leg ranks are unchanged)
+    float xr = 0.f;                         // lane l < 12: component l of the trajectory's state
+    bool airborne = false;                  // this step has no leg on the ground: no QP, the filter step only
+    MpcArgs ma;                             // the per-step view finish_row writes through (only the fields it reads)
+    ma.B = a.kf.B; ma.u_out = nullptr; ma.warm_u = nullptr; ma.warm_state = nullptr; ma.warm_contact = nullptr; ma.status = a.kf.status;
+    for (;;) {
+        if (!R.has && !R.exhausted) {
+            for (;;) {                      // (row-uniform)
+                if (b < 0 || t >= T) {
+                    int nx = 0;
+                    if (L.l == 0) nx = atomicAdd(counter, 1);
+                    nx = __builtin_amdgcn_update_dpp(0, nx, 0x150, 0xf, 0xf, true);
+                    if (nx >= nB) { R.exhausted = true; break; }
+                    b = nx; t = 0; prev_c = 0xffffffffu;
+                    xr = a.kf.x[(size_t)(L.l < 12 ? L.l : 11) * B + b];
+                }
+                const uint32_t cb = a.kf.contact[(size_t)t * B + b];
+                const int nst = ((cb & 0xffu) != 0) + (((cb >> 8) & 0xffu) != 0) + (((cb >> 16) & 0xffu) != 0) + (((cb >> 24) & 0xffu) != 0);
+                if (nst == 0) {             // no leg on the ground: all forces zero (force_controller.py:114-123); the row rides through one
+                                            // solve and takes the filter step below (one copy of it in the kernel)
+                    if (L.l < 12) a.f_out[((size_t)t * 12 + L.l) * B + b] = 0.f;
+                    if (L.l == 0 && a.iters) a.iters[(size_t)t * B + b] = 0;
+                    prev_c = cb;
+                    airborne = true; R.has = true;
+                    break;
+                }
+                // the record of this step's QP from the state the row holds, straight into the row's LDS block
+                double *prob = &M.gent[0][0];
+                __builtin_amdgcn_wave_barrier();
+                if (L.l < 12) {
+                    prob[L.l] = (double)xr;
+                    prob[12 + L.l] = (double)a.kf.body_ref[((size_t)t * 12 + L.l) * B + b];
+                    prob[24 + L.l] = (double)a.kf.p[((size_t)t * 12 + L.l) * B + b];
+                }
+                Q::prep_compute(L, nullptr, a.prm, M, prob, b, cb);
+                Q::set_stance(L, cb, R);
+                const bool warm = !a.cold && prev_c != 0xffffffffu && contact_ranks(prev_c) == contact_ranks(cb);
+#pragma unroll
+                for (int h = 0; h < Q::VPL; h++) {
+                    const bool keep = warm && L.l + 16 * h < Q::NV;
+                    R.F.f[h] = keep ? R.F.f[h] : Q::fpack(0, 0, SZ_FREE); R.u[h] = keep ? R.u[h] : 0.0;
+                }
+                R.first = !warm; R.done = false; R.converged = false; R.iters = 0; R.b = b; R.cbits = cb; R.has = true;
+                break;
+            }
+        }
+        if (__ballot(R.has) == 0ull) break;
+        const typename Q::Sol S = Q::solve_face(L, a.prm, Sh, M, R.F);
+        if (R.has) {
+            if (!airborne) Q::iterate_row(L, a.prm, Sh, M, R, S);
+            if (airborne || R.done || R.iters >= a.max_iter) {
+                if (!airborne) {
+                    ma.f_out = a.f_out + (size_t)t * 12 * B;
+                    ma.iters = a.iters ? a.iters + (size_t)t * B : nullptr;
+                    Q::template finish_row<false>(L, ma, M, R);         // forces of horizon step 0, iteration count, status bit 2
+                    prev_c = R.cbits;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the filter step reads this row's forces back)
+                xr = kf_step_row(a.kf, qs, rs, b, true, L.l, t, ed);
+                t++; R.has = false; airborne = false;
+            }
+        }
+    }
 }
 
 }  // namespace osq
@@ -1099,5 +1245,20 @@ void os_mpc_launch_quad(const osm::MpcArgs &a, uint32_t nst_mask, int *counters,
         static const osm::PostArgs none = {};
         if (nst_mask & 3u) hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<1, osq::POST_NONE>), grid, block, 0, s, a, counters, none);
         if (nst_mask & 4u) hipLaunchKernelGGL((osq::mpc_solve_quad_kernel<2, osq::POST_NONE>), grid, block, 0, s, a, counters + osq::CNT_INTS, none);
+    }
+}
+
+// kf_mpc_rows_kernel over the whole batch (mpc_kernels.hip os_kf_mpc_run); counter: one zeroed int
+void os_mpc_launch_rows(const osq::RowsArgs &a, int nst, int *counter, int cu_count, hipStream_t s)
+{
+    const int rows = (a.kf.B + 3) / 4, simds = cu_count * 4;
+    const dim3 block(64);
+    if (rows <= simds) {
+        if (nst == 1) hipLaunchKernelGGL((osq::kf_mpc_rows_kernel<1, 1>), dim3(rows), block, 0, s, a, counter);
+        else hipLaunchKernelGGL((osq::kf_mpc_rows_kernel<2, 1>), dim3(rows), block, 0, s, a, counter);
+    } else {
+        const dim3 grid(rows < 2 * simds ? rows : 2 * simds);
+        if (nst == 1) hipLaunchKernelGGL((osq::kf_mpc_rows_kernel<1, 2>), grid, block, 0, s, a, counter);
+        else hipLaunchKernelGGL((osq::kf_mpc_rows_kernel<2, 2>), grid, block, 0, s, a, counter);
     }
 }

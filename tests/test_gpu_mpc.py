@@ -427,3 +427,62 @@ def test_filter_step_inside_the_qp_launch_equals_the_separate_launches(monkeypat
     # the separate form launches the filter kernel every step, the fused form only in the step with a three-leg trajectory
     assert p0["kf"][1] == T and p1.get("kf", (0.0, 0))[1] == (1 if (mix and shards == "1") else 0)
     assert p1["mpc"][1] == T * (int(shards) if not (mix and shards == "1") else 1)
+
+
+@pytest.mark.parametrize("B,T", [(4096, 12), (6000, 8), (16384, 5)])
+def test_a_row_per_trajectory_for_all_steps_agrees_with_the_launch_sequence(monkeypatch, B, T):
+    """Round 6: batches of 10 .. 80 trajectories per CU run kf_mpc_rows_kernel -- a 16-lane row owns a trajectory for all T steps (QP ->
+    filter step -> next QP, the next QP's record built in LDS from the state the filter step has just produced, the warm start in the
+    row's registers) -- one wavefront per SIMD up to 4,096 trajectories, two above.  Against the per-step launch sequence
+    (OS_MPC_PERSISTENT=0): the same iteration counts, states to 2e-6, forces to 1e-3 N (the sequence's numbers up to the last bits of
+    the record: the same source inlined into another kernel contracts differently), P identical (it does not depend on the forces).
+    Some trajectories are airborne in some steps (no QP: zero forces, the filter step only)."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    dev = torch.device("cuda:0")
+    d = synth_torch(B, T, dev, seed=91)
+    c4 = d["contact"].clone()
+    c4[2:4, :, 7::9] = 0                                     # airborne in steps 2 and 3
+    ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OS_MPC_PERSISTENT", mode)
+        e = Engine(0); e.set_noise(Q_DEFAULT, R_DEFAULT)
+        contact = e.contact_soa_to_packed(c4)
+        x, P = d["x0"].clone(), d["P0"].clone()
+        r = e.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True, want_p_rot=True)
+        torch.cuda.synchronize()
+        out[mode] = (r, x, P, e.kernel_name("mpc"))
+    rs, xs, Ps, ks = out["0"]; rr, xr, Pr, kr = out["1"]
+    assert kr.startswith("kf_mpc_rows_kernel") and "quad" in ks, (kr, ks)
+    assert torch.equal(rr["iters"], rs["iters"]) and int(rr["iters"].max()) > 3 and int(rr["iters"][2, 7::9].max()) == 0
+    assert int(rr["status"].abs().max()) == 0 and torch.equal(rr["status"], rs["status"])
+    assert float((rr["x_out"] - rs["x_out"]).abs().max()) < 2e-6 and float((xr - xs).abs().max()) < 2e-6
+    assert float((rr["f"] - rs["f"]).abs().max()) < 1e-3 and float((rr["p_rot"] - rs["p_rot"]).abs().max()) < 1e-5
+    assert torch.equal(Pr, Ps)
+    assert float(rr["f"][2, :, 7::9].abs().max()) == 0.0
+
+
+def test_rows_form_leaves_mixed_leg_counts_to_the_other_forms(monkeypatch):
+    """A batch in the rows form's range with one- AND two-leg trajectories is not its case (one variable layout per launch): the
+    wavefront-per-trajectory kernel takes it (B <= 32 per CU), same numbers as the launch sequence to the form-against-form bars."""
+    from optistate_amd import Engine
+    from optistate_amd.synth import synth_torch, Q_DEFAULT, R_DEFAULT
+    dev = torch.device("cuda:0")
+    B, T = 4096, 6
+    d = synth_torch(B, T, dev, seed=92)
+    c4 = d["contact"].clone()
+    c4[:, :, 5::7] = 0; c4[:, 1, 5::7] = 1                  # one leg
+    ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OS_MPC_PERSISTENT", mode)
+        e = Engine(0); e.set_noise(Q_DEFAULT, R_DEFAULT)
+        contact = e.contact_soa_to_packed(c4)
+        x, P = d["x0"].clone(), d["P0"].clone()
+        r = e.kf_mpc_run(d["p"], d["dp"], d["imu"], contact, ref, x, P, want_iters=True)
+        torch.cuda.synchronize()
+        out[mode] = (r, x, e.kernel_name("mpc"))
+    assert out["1"][2] == "kf_mpc_persistent_kernel", out["1"][2]
+    assert float((out["1"][0]["x_out"] - out["0"][0]["x_out"]).abs().max()) < 1e-4 and float((out["1"][0]["f"] - out["0"][0]["f"]).abs().max()) < 5e-3
+    assert int(out["1"][0]["status"].abs().max()) == 0
