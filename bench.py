@@ -721,14 +721,15 @@ def bench_mpc(a, rk):
             mpc_ms = el / a.steps * 1e3
         ach = qp_flops / (mpc_ms * 1e-3) / 1e12 if mpc_ms else 0.0
         kname = mk.get("kernel", "")
-        persistent = kname.startswith("kf_mpc_persistent")
-        quad = "quad" in kname
+        persistent = kname.startswith("kf_mpc_persistent") or kname.startswith("kf_mpc_rows")
+        quad = "quad" in kname or kname.startswith("kf_mpc_rows")
         out["roofline"] = {"kernel": mk.get("kernel", "mpc_solve_kernel") + " (float64 vector pipe: v_fma_f64)", "bound": "mfma", "pipe": "fp64 VECTOR pipe (compute-bound class of the contract's two; nothing here runs on a matrix core)", "achieved": ach,
                            "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TF, "traffic": None,
                            "traffic_source": "not collected for this mode", "algorithmic_flops_per_pass": qp_flops,
                            "flops_per_iteration": "2 n^3 / 3 + 14 n^2 + 260 n, n = 15 x stance legs (30 at trot: 32 kflop)",
                            "device_ms_of_the_phase": mpc_ms,
-                           "note": ("one persistent kernel: the phase time includes the float64 filter step of every time step" if persistent else
+                           "note": ("one kernel, a 16-lane row per trajectory for all T steps: the phase time includes the float64 filter step of every time step" if kname.startswith("kf_mpc_rows") else
+                                    "one persistent kernel: the phase time includes the float64 filter step of every time step" if persistent else
                                     "the whole pass (QP launches of two parts of the batch overlap; the filter step runs inside them)" if overlapped else
                                     "QP launches, the filter step of every trajectory inside them" if "filter step inside" in kname else
                                     "QP launches only (the filter steps are the kf phase)"),

@@ -371,6 +371,10 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * bit-identical to the separate launch; OS_MPC_FUSE_KF=0 switches back).  When every step of the call qualifies and B > 8,192
  * the batch runs as two contiguous halves on two internal streams, forked from and joined into `stream` by events (the halves
  * share nothing; OS_MPC_SHARDS=1 keeps one part): the call stays asynchronous and ordered with respect to `stream`.
+ * Batches of 10 .. 80 trajectories per compute unit (2,560 .. 20,480) whose every step carries force on the same number (one or two) of
+ * legs or on none take a third form in the plain call: kf_mpc_rows_kernel, a 16-lane row per trajectory for ALL T steps (QP -> filter
+ * step -> next QP with nothing synchronised between steps; x and P travel through memory as in the launch sequence, so its numbers
+ * are the sequence's to ~1e-7); OS_MPC_ROWS=0 switches it off, OS_MPC_ROWS=<lo>:<hi> moves the range.
  * (status bit 6 = 64: a filter step inside a QP launch gave up waiting for its trajectory's forces after 2^24 polls -- a lost
  * device; never seen, tested beside a process that holds 240 of the 256 compute units.)
  * OS_KF_SEQUENTIAL_UPDATE in `flags` selects the scalar-update form in the launch sequence only; the persistent kernel always

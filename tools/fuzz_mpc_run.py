@@ -41,12 +41,12 @@ def main():
     mo.MASS = float(np.float32(8.8))
     mo.INERTIA = np.asarray(np.float32([0.05530364, 0.06011944, 0.10530434]), np.float64)
     engs = {}
-    for mode in ("2", "0"):
+    for mode in ("2", "0", "1"):             # forced wavefront-per-trajectory kernel / forced launch sequence / the library's own pick
         os.environ["OS_MPC_PERSISTENT"] = mode
         engs[mode] = Engine(0)
     bad = 0
     for case in range(n):
-        B = int(rng.choice([1, 2, 7, 8, 63, 65, 256, 1000, 2047, 2049, 6144, 8192 + int(rng.integers(0, 3000)), 32768 + 16 * int(rng.integers(0, 40)) + int(rng.integers(0, 16))]))
+        B = int(rng.choice([1, 2, 7, 8, 63, 65, 256, 1000, 2047, 2049, 2560 + int(rng.integers(0, 3000)), 6144, 8192 + int(rng.integers(0, 3000)), 32768 + 16 * int(rng.integers(0, 40)) + int(rng.integers(0, 16))]))
         T = int(rng.choice([1, 2, 7, 20, 40]))
         if B > 1000:
             T = min(T, 7)
@@ -69,6 +69,8 @@ def main():
         d["body_ref"] = ref
         out = {}
         for mode, eng in engs.items():
+            if mode == "1":
+                continue
             eng.set_noise(Q, R)
             s = {k: eng.pack(torch.as_tensor(np.asarray(d[k], dtype=np.float32))) for k in ("p", "dp", "imu", "body_ref")}
             c = eng.pack_contact(torch.as_tensor(np.asarray(d["contact"])))
@@ -93,6 +95,21 @@ def main():
             os.environ.pop("OS_MPC_FUSE_KF")
             same = all(torch.equal(res["0"][0][k], res["1"][0][k]) for k in ("x_out", "f", "iters", "status", "p_rot")) and \
                 torch.equal(res["0"][1], res["1"][1]) and torch.equal(res["0"][2], res["1"][2])
+        # the library's own pick in its plain form: in the rows form's range (a 16-lane row per trajectory for all steps, where every step
+        # qualifies) against the launch sequence: same iteration counts, the form-against-form bars
+        rows_note = ""
+        if B >= 64:
+            eng = engs["1"]; eng.set_noise(Q, R)
+            x = torch.as_tensor(d["x0"].T.copy()).cuda()
+            P = torch.as_tensor(np.tile(np.asarray(Q, dtype=np.float32).reshape(144, 1), (1, B))).cuda()
+            r = eng.kf_mpc_run(s["p"], s["dp"], s["imu"], c, s["body_ref"], x, P, sequential=sequential, want_iters=True, want_p_rot=True)
+            torch.cuda.synchronize()
+            if eng.kernel_name("mpc").startswith("kf_mpc_rows"):
+                r0 = res["0"][0]
+                e_rx = float((r["x_out"] - r0["x_out"]).abs().max()); e_rf = float((r["f"] - r0["f"]).abs().max())
+                it_same = bool(torch.equal(r["iters"], r0["iters"])) and bool(torch.equal(r["status"], r0["status"]))
+                same = same and e_rx < 1e-4 and e_rf < max(2e-2, 600.0 * e_rx) and it_same
+                rows_note = f" | rows form vs sequence: x {e_rx:.1e} f {e_rf:.1e} N, iterations {'equal' if it_same else 'DIFFERENT'}"
         xp, fp, sp, kp = out["2"]; xs, fs, ss, ks = out["0"]
         good = ~sp & ~ss
         e_x = float(np.abs(xp[good] - xs[good]).max()) if good.any() else 0.0
@@ -140,7 +157,7 @@ def main():
             diag += "\n     stance legs per step: " + " ".join(str(int(d["contact"][bw, t].sum())) for t in range(T))
         print(f"case {case}: B={B} T={T} hostile={hostile} {'seq' if sequential else 'batch'} noise={noise} [{kp} | {ks}] persistent vs sequence: x {e_x:.1e} f {e_f:.1e} N | "
               f"vs oracles ({len(rows)} trajectories x {To}): x {e_xo:.1e} f {e_fo:.1e} N | flagged {int(sp.sum())}/{int(ss.sum())}"
-              + ("" if B < 64 else " | filter step inside the QP launch: identical" if same else " | filter step inside the QP launch: DIFFERENT") + self_note
+              + ("" if B < 64 else " | filter step inside the QP launch: identical" if same else " | filter step inside the QP launch or rows form: DIFFERENT") + rows_note + self_note
               + ("" if ok else "   <-- ABOVE THE BAR") + diag, flush=True)
         bad += 0 if ok else 1
     print(f"{n} cases, {bad} above the bars")
