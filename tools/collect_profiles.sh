@@ -123,6 +123,10 @@ python3 tools/stack_wait_time.py > $O/stack_wait_time.txt 2>&1
 OS_MPC_SHARDS=1 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_one_part.json 2>> $O/bench.err
 OS_MPC_SHARDS=1 OS_MPC_FUSE_KF=0 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_separate_filter.json 2>> $O/bench.err
 python3 bench.py --mode mpc --batch 4096 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B4096.json 2>> $O/bench.err
+# (the row-per-trajectory kernel's range: the line at 8,192 and 16,384, and the three forms side by side)
+python3 bench.py --mode mpc --batch 8192 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B8192.json 2>> $O/bench.err
+python3 bench.py --mode mpc --batch 16384 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B16384.json 2>> $O/bench.err
+for b in 4096 8192 16384; do python3 tools/mpc_rows_check.py $b 100 2>/dev/null | grep -v amdgpu.ids; done > $O/mpc_rows_check.txt
 OS_MPC_SHARDS=1 bash tools/kstats_any.sh ${TAG}_mpc1 tools/mpc_run_bench.py 65536 40 > /dev/null 2>&1; cp gpurun_out/${TAG}_mpc1_kernel_stats.md $O/mpc_one_part_kernel_stats.md
 OS_MPC_SHARDS=1 OS_MPC_FUSE_KF=0 bash tools/kstats_any.sh ${TAG}_mpc0 tools/mpc_run_bench.py 65536 40 > /dev/null 2>&1; cp gpurun_out/${TAG}_mpc0_kernel_stats.md $O/mpc_separate_filter_kernel_stats.md
 bash tools/kstats_any.sh ${TAG}_mpc2 tools/mpc_run_bench.py 65536 40 > /dev/null 2>&1; cp gpurun_out/${TAG}_mpc2_kernel_stats.md $O/mpc_two_parts_kernel_stats.md
