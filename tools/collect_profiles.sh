@@ -123,6 +123,7 @@ python3 tools/stack_wait_time.py > $O/stack_wait_time.txt 2>&1
 OS_MPC_SHARDS=1 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_one_part.json 2>> $O/bench.err
 OS_MPC_SHARDS=1 OS_MPC_FUSE_KF=0 python3 bench.py --mode mpc --steps 3 --cpu-seconds 0 > $O/bench_mpc_separate_filter.json 2>> $O/bench.err
 python3 bench.py --mode mpc --batch 4096 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B4096.json 2>> $O/bench.err
+OS_MPC_ROWS=0 python3 bench.py --mode mpc --batch 4096 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B4096_wave_per_trajectory.json 2>> $O/bench.err
 # (the row-per-trajectory kernel's range: the line at 8,192 and 16,384, and the three forms side by side)
 python3 bench.py --mode mpc --batch 8192 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B8192.json 2>> $O/bench.err
 python3 bench.py --mode mpc --batch 16384 --steps 3 --cpu-seconds 0 > $O/bench_mpc_B16384.json 2>> $O/bench.err
