@@ -423,8 +423,9 @@ struct Quad {
     // prob (LDS): x | ref | p of the problem in float64, written by the row's lanes before the call.  rec_base null: the record stays in
     // the row's LDS block (kf_mpc_rows_kernel builds it where the solver reads it)
     template <typename MemT>
-    static __device__ __forceinline__ void prep_compute(const Lane &L, double *rec_base, const MpcParams &P, MemT &M, const double *prob, int b, uint32_t cbits)
+    static __device__ __forceinline__ void prep_compute(const Lane &L0, double *rec_base, const MpcParams &P, MemT &M, const double *prob, int b, uint32_t cbits)
     {
+        const Lane L = again(L0);
         __builtin_amdgcn_wave_barrier();
         int legs[4] = {0, 0, 0, 0};
         {
@@ -519,8 +520,9 @@ struct Quad {
         __builtin_amdgcn_wave_barrier();
     }
     // the stance flags of the lane's variables from the contact word (load_row; kf_mpc_rows_kernel)
-    static __device__ __forceinline__ void set_stance(const Lane &L, uint32_t cbits, Row &R)
+    static __device__ __forceinline__ void set_stance(const Lane &L0, uint32_t cbits, Row &R)
     {
+        const Lane L = again(L0);
         int legs[4] = {0, 0, 0, 0};
         {
             int n = 0;
@@ -919,6 +921,10 @@ __device__ __forceinline__ void mark_done(int l, const PostArgs &post, int b)
 
 // One predict_mpc + update step of trajectory b on this 16-lane row: kf_dense_rows_kernel<BATCH, dense> at T = 1 (kf_dense_rows.hip),
 // the same building blocks in the same order -- the results are bit-identical to the separate launch.  qs / rs: Q and R in float64 (LDS).
+// TV: the step index t differs between the rows of the wavefront (kf_mpc_rows_kernel).  A buffer descriptor has to be wave-uniform: with the
+// step in its base address every stream access would be a waterfall loop over the rows' distinct steps (it was: 150 spilled
+// registers at two wavefronts per SIMD); the descriptors then span the whole [T][rows][B] stream and the step travels in the lane's offset.
+template <bool TV = false>
 __device__ __forceinline__ float kf_step_row(const osk::KfRunArgs &a, const double *qs, const double *rs, int b, bool live, int r, int t, double ed /* expm1(dt) */)
 {
     using namespace osk;
@@ -940,14 +946,26 @@ __device__ __forceinline__ float kf_step_row(const osk::KfRunArgs &a, const doub
     asm volatile("" : "+v"(one));                      // a register operand for the DPP sums
     StepIn in;
     float bref[3];
-    load_step(a, t, voff, rowB, in);
+    if constexpr (TV) {
+        const uint32_t span = (uint32_t)a.T * rowB;                    // (the host holds T x 12 x B x 4 below 2^32)
+        rsrc_t rp = make_rsrc(a.p, 12 * span), rd = make_rsrc(a.dp, 12 * span), ri = make_rsrc(a.imu, 6 * span), rc = make_rsrc(a.contact, span);
+        const uint32_t v12 = voff + (uint32_t)t * 12u * rowB, v6 = voff + (uint32_t)t * 6u * rowB, v1 = voff + (uint32_t)t * rowB;
 #pragma unroll
-    for (int i = 0; i < 12; i++) in.f[i] = load_agent(a.f + ((size_t)t * 12 + i) * B + b);      // (written in this launch, by another CU)
-    {
+        for (int i = 0; i < 12; i++) { in.p[i] = buf_load_nt(rp, v12, i * rowB); in.dp[i] = buf_load_nt(rd, v12, i * rowB); }
+#pragma unroll
+        for (int i = 0; i < 6; i++) in.imu[i] = buf_load_nt(ri, v6, i * rowB);
+        in.contact = buf_load_u32_nt(rc, v1, 0);
+        rsrc_t rb = make_rsrc(a.body_ref, 12 * span);
+#pragma unroll
+        for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, v12, i * rowB);
+    } else {
+        load_step(a, t, voff, rowB, in);
         rsrc_t rb = make_rsrc(a.body_ref + (size_t)t * 12 * B, 12 * rowB);
 #pragma unroll
         for (int i = 0; i < 3; i++) bref[i] = buf_load(rb, voff, i * rowB);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) in.f[i] = load_agent(a.f + ((size_t)t * 12 + i) * B + b);      // (written in this launch, by another CU)
     float x[NS], z[NM], pw[12];
     rw::gather_state(xr, x);
     int status = rw::front_row<true>(x, xr, P, in, bref, k, ed, qrow, one, r, z, pw);
@@ -1216,8 +1234,9 @@ __global__ __launch_bounds__(64, OCC) void kf_mpc_rows_kernel(const RowsArgs a, 
                     prev_c = R.cbits;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the filter step reads this row's forces back)
-                xr = kf_step_row(a.kf, qs, rs, b, true, L.l, t, ed);
-                t++; R.has = false; airborne = false;
+                xr = kf_step_row<true>(a.kf, qs, rs, b, true, L.l, t, ed);
+                t++;
+                R.has = false; airborne = false;
             }
         }
     }
