@@ -371,7 +371,7 @@ int os_mpc_solve(os_ctx *ctx, int32_t B, const float *x, const float *body_ref, 
  * bit-identical to the separate launch; OS_MPC_FUSE_KF=0 switches back).  When every step of the call qualifies and B > 8,192
  * the batch runs as two contiguous halves on two internal streams, forked from and joined into `stream` by events (the halves
  * share nothing; OS_MPC_SHARDS=1 keeps one part): the call stays asynchronous and ordered with respect to `stream`.
- * Batches of 8 .. 120 trajectories per compute unit (2,048 .. 30,720) whose every step carries force on the same number (one or two) of
+ * Batches of 8 .. 200 trajectories per compute unit (2,048 .. 51,200) whose every step carries force on the same number (one or two) of
  * legs or on none take a third form in the plain call: kf_mpc_rows_kernel, a 16-lane row per trajectory for ALL T steps (QP -> filter
  * step -> next QP with nothing synchronised between steps; x and P travel through memory as in the launch sequence, so its numbers
  * are the sequence's to ~1e-7); OS_MPC_ROWS=0 switches it off, OS_MPC_ROWS=<lo>:<hi> moves the range.

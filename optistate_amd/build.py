@@ -25,7 +25,10 @@ HEADERS = ["kf_device.hpp", "kf_dense_rows.hpp", "kf_args.hpp", "kf_rows_chain.i
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 # per-file additions (the reason is in the file's header)
-EXTRA_FLAGS = {"kf_rows_kernel.hip": ["-fno-slp-vectorize"]}
+# mpc_quad.hip: machine LICM hoists the materialisation of 64-bit literals (polynomial coefficients of expm1 / sincos, weights) out of the
+# persistent kernels' outer loops and then SPILLS them -- a scratch reload where two v_mov would do (kf_mpc_rows_kernel at two wavefronts
+# per SIMD: 416 -> 176 B of scratch, B = 8,192 4.4e7 -> 5.1e7 steps/s; the drain phase of mpc_solve_quad_kernel: 28 -> 0 B)
+EXTRA_FLAGS = {"kf_rows_kernel.hip": ["-fno-slp-vectorize"], "mpc_quad.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _all_flags():

@@ -1113,14 +1113,15 @@ int os_kf_mpc_run(os_ctx *ctx, int32_t B, int32_t T, const float *p, const float
     // Three forms (OS_MPC_PERSISTENT=1, the default, picks; 0 / 2 force the launch sequence / the wavefront-per-trajectory kernel):
     //  * kf_mpc_persistent_kernel, a wavefront per trajectory for all T steps: up to 32 trajectories per CU unless the rows form takes the
     //    batch (it spends a whole wavefront on one trajectory and saturates at ~2.2e7 steps/s);
-    //  * kf_mpc_rows_kernel (mpc_quad.hip), a 16-lane row per trajectory for all T steps: batches of 8 .. 120 trajectories per CU whose every
+    //  * kf_mpc_rows_kernel (mpc_quad.hip), a 16-lane row per trajectory for all T steps: batches of 8 .. 200 trajectories per CU whose every
     //    step carries force on NST legs or none, the plain call (no flag but OS_MPC_COLD_START, no P_trace / K_gain output); OS_MPC_ROWS=0
     //    switches it off, OS_MPC_ROWS=<lo>:<hi> moves the range;
     //  * the per-step launch sequence (two concurrent parts, the filter step inside the QP launch) for everything else.
     // Measured on 256 CUs at the end of round 6, steps/s at T = 100, wavefront kernel / rows kernel / sequence: B = 2,048 1.76e7 / 1.82e7 /
-    // 0.59e7, 2,560 1.70e7 / 2.39e7 / -, 4,096 1.84e7 / 3.68e7 / 1.10e7, 8,192 2.06e7 / 4.24e7 / 2.14e7, 16,384 2.20e7 / 4.70e7 / 3.20e7,
-    // 24,576 2.23e7 / 4.88e7 / 4.14e7, 28,672 2.24e7 / 5.05e7 / 4.66e7, 32,768 2.24e7 / 5.06e7 / 5.07e7, 40,960 2.26e7 / 5.18e7 / 5.82e7.
-    int rows_lo = 8 * ctx->cu_count, rows_hi = 120 * ctx->cu_count;
+    // 0.59e7, 2,560 1.70e7 / 2.39e7 / -, 4,096 1.84e7 / 3.80e7 / 1.10e7, 8,192 2.06e7 / 5.13e7 / 2.14e7, 16,384 2.20e7 / 5.74e7 / 3.20e7,
+    // 32,768 2.24e7 / 6.37e7 / 5.13e7, 40,960 - / 6.53e7 / 5.91e7, 57,344 - / 6.74e7 / 6.70e7, 65,536 2.27e7 / 6.72e7 / 6.98e7, 98,304 - /
+    // 6.87e7 / 7.73e7, 131,072 - / 6.99e7 / 8.16e7.
+    int rows_lo = 8 * ctx->cu_count, rows_hi = 200 * ctx->cu_count;
     if (const char *re = getenv("OS_MPC_ROWS")) {
         if (sscanf(re, "%d:%d", &rows_lo, &rows_hi) != 2) { rows_lo = 0; rows_hi = -1; }       // ("0": off)
     }

@@ -429,9 +429,9 @@ def test_filter_step_inside_the_qp_launch_equals_the_separate_launches(monkeypat
     assert p1["mpc"][1] == T * (int(shards) if not (mix and shards == "1") else 1)
 
 
-@pytest.mark.parametrize("B,T", [(4096, 12), (6000, 8), (16384, 5)])
+@pytest.mark.parametrize("B,T", [(4096, 12), (6000, 8), (16384, 5), (40000, 4)])
 def test_a_row_per_trajectory_for_all_steps_agrees_with_the_launch_sequence(monkeypatch, B, T):
-    """Round 6: batches of 8 .. 120 trajectories per CU run kf_mpc_rows_kernel -- a 16-lane row owns a trajectory for all T steps (QP ->
+    """Round 6: batches of 8 .. 200 trajectories per CU run kf_mpc_rows_kernel -- a 16-lane row owns a trajectory for all T steps (QP ->
     filter step -> next QP, the next QP's record built in LDS from the state the filter step has just produced, the warm start in the
     row's registers) -- one wavefront per SIMD up to 4,096 trajectories, two above.  Against the per-step launch sequence
     (OS_MPC_PERSISTENT=0): the same iteration counts, states to 2e-6, forces to 1e-3 N (the sequence's numbers up to the last bits of

@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/build_ab/$1; LIB=$2; SRC=",$3,"; shift 3
 mkdir -p $D
 cd $R/optistate_amd/csrc
 for f in $(ls *.hip | sed 's/\.hip$//'); do
-  X=; [ $f = kf_rows_kernel ] && X="-fno-slp-vectorize"
+  X=; [ $f = kf_rows_kernel ] && X="-fno-slp-vectorize"; [ $f = mpc_quad ] && X="-mllvm -disable-machine-licm"       # (optistate_amd/build.py EXTRA_FLAGS)
   case $SRC in *,$f,*) X="$X $*"; rm -f $D/$f.o;; esac
-  [ -f $D/$f.o ] || { [ -z "$X" -o "$X" = "-fno-slp-vectorize" ] && [ -f build/$f.o ] && cp build/$f.o $D/$f.o; }
+  [ -f $D/$f.o ] || { [ -z "$X" -o "$X" = "-fno-slp-vectorize" -o "$X" = "-mllvm -disable-machine-licm" ] && [ -f build/$f.o ] && cp build/$f.o $D/$f.o; }
   [ -f $D/$f.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $X -DOS_BUILD_ID='"ts-build"' -c $f.hip -o $D/$f.o &
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/$LIB $D/*.o -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib && echo $D/$LIB
