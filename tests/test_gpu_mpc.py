@@ -442,6 +442,12 @@ def test_a_row_per_trajectory_for_all_steps_agrees_with_the_launch_sequence(monk
     dev = torch.device("cuda:0")
     d = synth_torch(B, T, dev, seed=91)
     c4 = d["contact"].clone()
+    # a trot: every trajectory on one diagonal pair of legs, a third of them switching to the other pair every other step (same leg
+    # COUNT and ranks: the warm start carries over by rank -- in the rows kernel it never leaves the row's registers)
+    c4[:] = 0; c4[:, 0] = 1; c4[:, 3] = 1
+    sw = torch.arange(B, device=dev) % 3 == 1
+    for t in range(1, T, 2):
+        c4[t, 0, sw] = 0; c4[t, 3, sw] = 0; c4[t, 1, sw] = 1; c4[t, 2, sw] = 1
     c4[2:4, :, 7::9] = 0                                     # airborne in steps 2 and 3
     ref = torch.zeros((T, 12, B), device=dev); ref[:, 5] = 0.28; ref[:, 9] = 0.1
     out = {}
