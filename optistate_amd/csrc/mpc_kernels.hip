@@ -17,8 +17,11 @@
 //     (sx, sy) in {-1, 0, +1} (fx = +-mu fz active) and sz in {free, fz = 0 (apex, f = 0), fz = fz_max}.  Restricting
 //     the QP to a face only replaces each generator by a linear combination of its leg's three generators, so the
 //     reduced Hessian has the same closed form: no KKT system, no projections of a stored matrix.
-//   * the face-restricted system (dead slots = identity rows) is solved by Gaussian elimination with one row per lane:
-//     the pivot row is broadcast through LDS, dead pivots are skipped wave-uniformly.
+//   * the face-restricted system (dead slots = identity rows) is solved by Gaussian elimination with one row per lane.  The system
+//     is symmetric: entry j of pivot row k is element k of row j, ONE register across the lanes, which a 16-lane DPP row reads
+//     inside the FMA (round 6; rounds 1-5 broadcast the pivot row through LDS, then by two v_readlane per entry).  Dead pivots are
+//     skipped wave-uniformly when most are dead; with most alive the elimination is straight-line code with the next pivot's
+//     inverse computed under the current pivot's entries (solve_face).
 // Algorithm: cold start (stance legs free, swing legs zero) -> subspace minimiser -> clamp into the pyramids -> primal
 // active-set iteration (ratio test adds the blocking constraint, multiplier signs release one constraint; at the apex the
 // dual-cone test g_z >= mu(|g_x|+|g_y|) decides and the steepest edge ray is released) until the KKT conditions hold.
@@ -211,6 +214,56 @@ __device__ __forceinline__ double form_dot(const LaneCtx &L, const MpcParams &P,
     return acc;
 }
 
+#ifndef OS_MPC_DPP_ELIM
+#define OS_MPC_DPP_ELIM(NST) true
+#endif
+#ifndef OS_MPC_PIVOT_AHEAD
+#define OS_MPC_PIVOT_AHEAD(NST) ((NST) <= 2 ? 4 : 1000)      // straight-line elimination from this many sixths of the variables live (never for 3-4 legs)
+#endif
+// acc += (src of lane S of this lane's 16-lane DPP row) * m.  Inline assembly answers for its own hazard: a VALU write needs two wait
+// states before a DPP operand reads the register (NOP on the first use after src was written; tools/isa_dpp_hazard_scan.py).
+template <int S, bool NOP>
+__device__ __forceinline__ void fmac_bcast(double &acc, double src, double m)
+{
+    if (NOP) asm volatile("s_nop 1\nv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(S));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+&v"(acc) : "v"(src), "v"(m), "n"(S));
+}
+typedef unsigned osm_u2 __attribute__((ext_vector_type(2)));
+// (a, b) -> a's even DPP rows in both rows of each pair, b's odd rows likewise
+__device__ __forceinline__ void swap16(double &a, double &b)
+{
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const osm_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const osm_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a = __builtin_bit_cast(double, (unsigned long long)lo.x | ((unsigned long long)hi.x << 32));
+    b = __builtin_bit_cast(double, (unsigned long long)lo.y | ((unsigned long long)hi.y << 32));
+}
+__device__ __forceinline__ void swap32(double &a, double &b)
+{
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const osm_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const osm_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a = __builtin_bit_cast(double, (unsigned long long)lo.x | ((unsigned long long)hi.x << 32));
+    b = __builtin_bit_cast(double, (unsigned long long)lo.y | ((unsigned long long)hi.y << 32));
+}
+// bc[r] (r >= KR: the rows a pivot of DPP row KR still touches) = the sixteen values of c held by DPP row r, in every DPP row
+template <int NROWS, int KR>
+__device__ __forceinline__ void dpp_row_copies(double c, double (&bc)[4])
+{
+    bc[0] = bc[1] = bc[2] = bc[3] = c;
+    if constexpr (NROWS == 2) {
+        if constexpr (KR == 0) swap16(bc[0], bc[1]);           // (a pivot of the last row: every row it touches is its own)
+    } else if constexpr (NROWS > 2) {
+        if constexpr (KR < NROWS - 1) {
+            double lo = c, hi = c;
+            swap32(lo, hi);                                    // lo = rows (0, 1, 0, 1), hi = rows (2, 3, 2, 3)
+            bc[0] = bc[1] = lo; bc[2] = bc[3] = hi;
+            if constexpr (KR <= 1) swap16(bc[0], bc[1]);
+            swap16(bc[2], bc[3]);
+        }
+    }
+}
+
 // Minimiser of the QP restricted to the face (sx, sy, sz of this lane's leg-step); returns this lane's component.
 template <int NST, int UNR, bool RAW = false, typename WaveMem>
 __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &P, WaveMem &M, int sx, int sy, int sz,
@@ -268,9 +321,7 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     const unsigned long long live_mask = __ballot(live);
     OSM_STAMP(2)                                     // rows
 
-    // ---- forward elimination, one row per lane; the pivot row is broadcast straight from lane k's registers (k is a
-    // compile-time lane index here: two v_readlane_b32 per entry into an SGPR pair that the FMA reads) -- no LDS round
-    // trip and no barrier per pivot ----
+    // ---- forward elimination, one row per lane ----
     const double dsel = live ? P.rw * tt : 1.0;            // this lane's diagonal term (see form_row_block)
     double dinv = 1.0;
     // (an opaque copy of the lane index, as in mpc_quad.hip: the lane predicates of the pivots -- `lane > k`, `lane == k` -- are otherwise
@@ -278,30 +329,96 @@ __device__ __forceinline__ double solve_face(const LaneCtx &L, const MpcParams &
     // back with two v_readlane each; recomputed, a predicate is one v_cmp against an inline constant)
     int ll = L.lane;
     asm volatile("" : "+v"(ll));
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-        if (!((live_mask >> k) & 1ull)) continue;          // wave-uniform
-        const double inv = rcp64(readlane_f64(A[k] + dsel, k));
-        if (ll == k) dinv = inv;
-        const double f = (ll > k && ll < NV) ? A[k] * inv : 0.0;
-#pragma unroll
-        for (int j = k + 1; j <= NV; j++) {
-            A[j] = fma(-f, readlane_f64(A[j], k), A[j]);
-            if (((j - k) & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (OS_MPC_DPP_ELIM(NST)) {
+        // The system is symmetric and stays so under the elimination: entry j of pivot row k is ALSO element k of row j, i.e. register
+        // A[k] of lane j -- ONE register across the lanes instead of one register per entry in lane k.  A 16-lane DPP row reads it inside
+        // the FMA (v_fmac_f64_dpp row_newbcast: one instruction per entry where the broadcast out of lane k's registers took two
+        // v_readlane_b32, a two-cycle s_nop and the FMA); rows of the system that sit in another DPP row get that row's sixteen values
+        // of A[k] from one v_permlane16_swap (+ one v_permlane32_swap from 33 variables on) per pivot.  Only the right-hand side
+        // (register NV, no transpose partner) still crosses by v_readlane.
+        // The pivots' inverses are a chain of their own (~10 dependent instructions each: as long as a pivot's entries from the
+        // second stance leg on).  With most variables on the face the elimination runs WITHOUT the dead-pivot skips, as straight-line
+        // code: a dead variable's pivot is the 1.0 of its dsel over an all-zero row and column -- a no-op, bit for bit -- and pivot k
+        // computes what its update will leave on lane k + 1's diagonal (the same FMA on the same operands) so that the next inverse
+        // is on its way while the entries run.  With few variables on the face the skips are worth more than the overlap.
+        if (__builtin_popcountll(live_mask) * 6 >= NV * OS_MPC_PIVOT_AHEAD(NST)) {
+            double inv = rcp64(readlane_f64(A[0] + dsel, 0));
+            static_for<0, NV>([&](auto kc) {
+                constexpr int k = decltype(kc)::value, KR = k >> 4, E = NV - k - 1;
+                if (ll == k) dinv = inv;
+                const double nfa = -(A[k] * inv);
+                const double nf = ll > k ? nfa : 0.0;            // (lanes from NV on hold all-zero rows: their nfa is a zero already)
+                double dn = 1.0, rr = 0.0, ee = 0.0;             // next pivot (uniform), its inverse in the making
+                if constexpr (k + 1 < NV) dn = readlane_f64(fma(A[k], nfa, A[k + 1]) + dsel, k + 1);
+                double bc[4];
+                dpp_row_copies<(NV + 15) / 16, KR>(A[k], bc);
+                // rcp64()'s five instructions, one after every second entry (the entries are volatile assembly: hipcc schedules
+                // nothing between them by itself)
+                auto chain = [&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    if constexpr (k + 1 < NV) {
+                        if constexpr (st == 0) asm volatile("s_nop 1\nv_rcp_f64 %0, %1" : "=v"(rr) : "s"(dn));
+                        if constexpr (st == 1 || st == 3) asm volatile("s_nop 0\nv_fma_f64 %0, -%1, %2, 1.0" : "=&v"(ee) : "s"(dn), "v"(rr));
+                        if constexpr (st == 2 || st == 4) asm volatile("v_fma_f64 %0, %1, %0, %0" : "+v"(rr) : "v"(ee));
+                    }
+                };
+                static_for<k + 1, NV>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, i = j - k;
+                    fmac_bcast<j & 15, j == k + 1 || ((j & 15) == 0)>(A[j], bc[j >> 4], nf);
+                    if constexpr (i % 2 == 0 && i / 2 <= 5) chain(std::integral_constant<int, i / 2 - 1>{});
+                });
+                static_for<(E / 2 < 5 ? E / 2 : 5), 5>(chain);
+                A[NV] = fma(nf, readlane_f64(A[NV], k), A[NV]);
+                // (column k below the pivot is spent: with two DPP rows its register keeps bc[0], whose first row -- the finished
+                // rows' entries the back substitution reads -- is A[k]'s own: one copy less per pivot)
+                if constexpr ((NV + 15) / 16 == 2 && KR == 0) A[k] = bc[0];
+                inv = rr;
+            });
+        } else {
+            static_for<0, NV>([&](auto kc) {
+                constexpr int k = decltype(kc)::value, KR = k >> 4;
+                if (!((live_mask >> k) & 1ull)) return;            // wave-uniform
+                const double inv = rcp64(readlane_f64(A[k] + dsel, k));
+                if (ll == k) dinv = inv;
+                const double nf = ll > k ? -(A[k] * inv) : 0.0;
+                double bc[4];
+                dpp_row_copies<(NV + 15) / 16, KR>(A[k], bc);      // bc[r] = DPP row r's sixteen values of A[k] in every row that needs them
+                static_for<k + 1, NV>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    fmac_bcast<j & 15, j == k + 1 || ((j & 15) == 0)>(A[j], bc[j >> 4], nf);
+                });
+                A[NV] = fma(nf, readlane_f64(A[NV], k), A[NV]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
-        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // the pivot row broadcast straight from lane k's registers (k is a compile-time lane index here: two v_readlane_b32 per entry
+        // into an SGPR pair that the FMA reads) -- no LDS round trip and no barrier per pivot
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            if (!((live_mask >> k) & 1ull)) continue;          // wave-uniform
+            const double inv = rcp64(readlane_f64(A[k] + dsel, k));
+            if (ll == k) dinv = inv;
+            const double f = (ll > k && ll < NV) ? A[k] * inv : 0.0;
+#pragma unroll
+            for (int j = k + 1; j <= NV; j++) {
+                A[j] = fma(-f, readlane_f64(A[j], k), A[j]);
+                if (((j - k) & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     OSM_STAMP(3)                                     // elimination
     // ---- back substitution ----
-    double r = A[NV], sol = 0.0;
+    double r = A[NV];
 #pragma unroll
     for (int k = NV - 1; k >= 0; k--) {
         if (!((live_mask >> k) & 1ull)) continue;
         const double wk = readlane_f64(r * dinv, k);
-        if (ll == k) sol = wk;
         if (ll < k) r = fma(-A[k], wk, r);
         __builtin_amdgcn_sched_barrier(0);
     }
+    const double sol = live ? r * dinv : 0.0;              // (lane k's r is final when pivot k is reached and no later pivot touches it)
     OSM_STAMP(4)                                     // back substitution
     if constexpr (RAW) return L.pad ? 0.0 : sol;     // (face coordinates: the caller maps them to forces in its own exchange)
     // ---- face coordinates -> forces ----
@@ -672,10 +789,10 @@ static __device__ __attribute__((noinline)) QpRet mpc_solve_wave_call(QpCallLds 
 // Every instance is launched over the whole batch; a wavefront whose problem has a different leg count exits at once.
 template <int NST>
 #ifndef OS_MPC_SOLVE_OCC
-// waves per SIMD the register budget is sized for: 4 at one stance leg (109 registers), 3 at two and three (the single-exchange
-// iteration of round 6 keeps a leg-step's three components per lane: 130 registers at trot -- two spilled at a budget of 128; since
-// round 6 this instance serves batches below 64 and OS_MPC_QUAD=0 only), 2 at four (185)
-#define OS_MPC_SOLVE_OCC (NST <= 1 ? 4 : NST <= 3 ? 3 : 2)
+// waves per SIMD the register budget is sized for: 4 at one stance leg (109 registers), 2 at two (the straight-line elimination beside
+// the skipping one: eight registers spilled at a budget of 168; since round 6 this instance serves batches below 64 and OS_MPC_QUAD=0
+// only), 3 at three (152), 2 at four (185)
+#define OS_MPC_SOLVE_OCC (NST <= 1 ? 4 : NST == 3 ? 3 : 2)
 #endif
 __global__ __launch_bounds__(64, OS_MPC_SOLVE_OCC) void mpc_solve_kernel(const MpcArgs a, int handover)
 {

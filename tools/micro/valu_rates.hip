@@ -35,6 +35,24 @@ __global__ __launch_bounds__(512, 1) void k(float *out, int iters, unsigned long
                 if (KIND == 17) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[v]) : "v"(d[(v + 2) & 7]));
                 if (KIND == 18) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[v]) : "v"(d[(v + 4) & 7]), "v"(m));
                 if (KIND == 13) asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %0, a0" : "+v"(d[v].x));
+                if (KIND == 19) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(d[v].x) : "v"(m.x) : "s20", "s21");
+                if (KIND == 20) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(d[v].x) : "v"(m.x), "v"(c.x));
+                if (KIND == 21) asm volatile("v_and_b32 %0, %0, %1" : "+v"(d[v].x) : "v"(m.x));
+                if (KIND == 22) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(d[v].x), "v"(m.x) : "vcc");
+                if (KIND == 23) asm volatile("v_cmp_gt_f32 vcc, %0, %1\nv_cndmask_b32 %0, %0, %1, vcc" : "+v"(d[v].x) : "v"(m.x) : "vcc");
+                if (KIND == 30) asm volatile("v_cmp_gt_f32 vcc, %0, %2\nv_cndmask_b32 %0, %0, %2, vcc\nv_cndmask_b32 %1, %1, %2, vcc" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "vcc");
+                if (KIND == 31) asm volatile("v_cmp_gt_f32 vcc, %0, %2\nv_cndmask_b32 %0, %0, %2, vcc\nv_cndmask_b32 %1, %1, %2, vcc\nv_cndmask_b32 %0, %0, %2, vcc\nv_cndmask_b32 %1, %1, %2, vcc" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "vcc");
+                if (KIND == 32) asm volatile("v_cmp_gt_f32 s[20:21], %0, %2\nv_cndmask_b32_e64 %0, %0, %2, s[20:21]\nv_cndmask_b32_e64 %1, %1, %2, s[20:21]" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "s20", "s21");
+                if (KIND == 33) asm volatile("v_cmp_gt_f32 vcc, %0, %2\nv_mul_f32 %1, %1, %2\nv_mul_f32 %1, %1, %2\nv_cndmask_b32 %0, %0, %2, vcc\nv_cndmask_b32 %1, %1, %2, vcc" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "vcc");
+                if (KIND == 34) asm volatile("v_cmp_gt_f32 vcc, %0, %2\ns_nop 1\nv_cndmask_b32 %0, %0, %2, vcc\nv_cndmask_b32 %1, %1, %2, vcc" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "vcc");
+                if (KIND == 35) asm volatile("v_cmp_gt_f32 s[20:21], %0, %2\ns_nop 1\nv_cndmask_b32_e64 %0, %0, %2, s[20:21]\nv_cndmask_b32_e64 %1, %1, %2, s[20:21]" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "s20", "s21");
+                if (KIND == 36) asm volatile("v_cmp_gt_f32 vcc, %0, %2\ns_nop 1\nv_cndmask_b32 %0, %0, %2, vcc\nv_mul_f32 %1, %1, %2\nv_cndmask_b32 %1, %1, %2, vcc" : "+v"(d[v].x), "+v"(d[v].y) : "v"(m.x) : "vcc");
+                if (KIND == 24) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(d[v].x) : "s20");
+                if (KIND == 25) asm volatile("v_writelane_b32 %0, s20, 3" : "+v"(d[v].x) : : "s20");
+                if (KIND == 26) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[v]) : "v"(m));
+                if (KIND == 27) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d[v].x) : "v"(m.x), "v"(c.x));
+                if (KIND == 28) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[v]) : "v"(m));
+                if (KIND == 29) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[v]) : "v"(m));
             }
         }
     }
@@ -81,5 +99,23 @@ int main()
     run<16>(d, "v_rcp_f64", 1);
     run<12>(d, "v_cndmask_b32", 1);
     run<13>(d, "accvgpr write+read", 2);
+    run<19>(d, "v_cndmask_b32_e64 (sgpr mask)", 1);
+    run<27>(d, "v_cndmask_b32 (no self dep)", 1);
+    run<20>(d, "v_bfi_b32", 1);
+    run<21>(d, "v_and_b32", 1);
+    run<22>(d, "v_cmp_gt_f32 vcc", 1);
+    run<23>(d, "v_cmp + v_cndmask", 2);
+    run<30>(d, "v_cmp + 2 v_cndmask", 3);
+    run<31>(d, "v_cmp + 4 v_cndmask", 5);
+    run<32>(d, "v_cmp sgpr + 2 v_cndmask_e64", 3);
+    run<33>(d, "v_cmp + 2 v_mul + 2 v_cndmask", 5);
+    run<34>(d, "v_cmp + nop + 2 v_cndmask", 3);
+    run<35>(d, "v_cmp sgpr + nop + 2 cndmask_e64", 3);
+    run<36>(d, "v_cmp + nop + cnd + mul + cnd", 4);
+    run<24>(d, "v_readlane_b32", 1);
+    run<25>(d, "v_writelane_b32", 1);
+    run<26>(d, "v_max_f64", 1);
+    run<28>(d, "v_mul_f64", 1);
+    run<29>(d, "v_add_f64", 1);
     return 0;
 }

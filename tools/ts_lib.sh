@@ -9,7 +9,8 @@ cd $R/optistate_amd/csrc
 for f in $(ls *.hip | sed 's/\.hip$//'); do
   X=; [ $f = kf_rows_kernel ] && X="-fno-slp-vectorize"; [ $f = mpc_quad ] && X="-mllvm -disable-machine-licm"       # (optistate_amd/build.py EXTRA_FLAGS)
   case $SRC in *,$f,*) X="$X $*"; rm -f $D/$f.o;; esac
-  [ -f $D/$f.o ] || { [ -z "$X" -o "$X" = "-fno-slp-vectorize" -o "$X" = "-mllvm -disable-machine-licm" ] && [ -f build/$f.o ] && cp build/$f.o $D/$f.o; }
+  # (an unflagged source: always the shipped object -- a copy left in build_ab/ by an earlier build of the library would link a stale kernel)
+  [ -z "$X" -o "$X" = "-fno-slp-vectorize" -o "$X" = "-mllvm -disable-machine-licm" ] && [ -f build/$f.o ] && cp build/$f.o $D/$f.o
   [ -f $D/$f.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-pass-failed $X -DOS_BUILD_ID='"ts-build"' -c $f.hip -o $D/$f.o &
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/$LIB $D/*.o -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib && echo $D/$LIB
